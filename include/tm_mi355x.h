@@ -1,0 +1,209 @@
+/*
+ * tm_mi355x.h -- C ABI of libtm_mi355x.so: the MI355X-native (gfx950, hand-written HIP) replacement for the
+ * TurboMind quantized decode hot path of InternLM/lmdeploy.
+ *
+ * Every entry point is `extern "C"`, takes plain pointers / sizes (device pointers unless noted "host"),
+ * never throws and never aborts on the request path: it returns a tm_status code, and tm_last_error()
+ * describes the last failure on the calling thread.  Streams are hipStream_t passed as void*.
+ *
+ * What each group replaces in the reference (paths relative to the lmdeploy checkout, v0.16.0):
+ *   engine  : pybind11 module `_turbomind` -- TurboMind.create / create_context / create_root / process_weight /
+ *             create_engine / ModelRequest.forward  (src/turbomind/python/bind.cpp:743-793,938-999;
+ *             src/turbomind/turbomind.cc:159-361), weight slots = Module/Param protocol
+ *             (lmdeploy/turbomind/builders/_base.py:72-99).
+ *   linear  : `_tm.LinearWeight` + `_tm.LlamaLinear.forward_dense` + `tm.QuantizeGroupwise`
+ *             (src/turbomind/python/linear_bind.cpp:111-137,265-294), the operator-level surface the
+ *             reference's tests/turbomind/linear fixtures drive.
+ *   kernels : invokeRMSNorm / invokeResidualBiasRMSNorm (kernels/norm/rms_norm.cu), invokeProcessKV_v2_ /
+ *             invokeFlattenKV_v2_ (kernels/attention/kv_cache_utils_v2.h:36-112), dispatchDecoding /
+ *             dispatchAttention (kernels/attention/decoding.cu, attention.cu), embedding + greedy sampling.
+ */
+#ifndef TM_MI355X_H
+#define TM_MI355X_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Request status codes == src/turbomind/engine/request.h:120-131 */
+enum tm_status {
+    TM_OK        = 0,
+    TM_INVALID   = 1,
+    TM_CONFLICT  = 2,
+    TM_FAIL      = 5,
+    TM_TOO_LONG  = 6,
+    TM_FINISH    = 7,
+    TM_CANCEL    = 8,
+    TM_NO_QUEUE  = 10,
+    TM_OOM       = 11
+};
+
+typedef void* tm_stream_t; /* hipStream_t; NULL = default stream */
+
+int         tm_version(void);
+const char* tm_last_error(void);
+/* number of visible gfx950 devices (0 without a GPU); never fails */
+int         tm_device_count(void);
+
+/* ----------------------------------------------------------------------------------------------
+ * Paged KV cache view (kernels/attention/block.h:126-219, block_iterator.h:9-100)
+ * --------------------------------------------------------------------------------------------*/
+typedef struct tm_kv_cache {
+    const uint64_t* block_ptrs;    /* device: base address of every cache block (char**)           */
+    const int*      cu_block_nums; /* device [batch+1]: first block of each sequence in block_ptrs */
+    int64_t         layer_offset;  /* bytes: layer * tm_kv_layer_size()                            */
+    int             kv_heads;      /* local kv heads                                               */
+    int             head_dim;      /* 128                                                          */
+    int             block_len;     /* 64 tokens (lmdeploy/messages.py:323)                         */
+    int             bits;          /* quant_policy: 16 (none) | 8 | 4 (lmdeploy/messages.py:20-27) */
+} tm_kv_cache;
+
+/* bytes of one layer inside a block: kv_heads*2*block_len*(head_dim*bits/8) + kv_heads*2*block_len*4*[bits<16] */
+int64_t tm_kv_layer_size(int kv_heads, int head_dim, int block_len, int bits);
+
+/* ----------------------------------------------------------------------------------------------
+ * Operator level
+ * --------------------------------------------------------------------------------------------*/
+/* y = rmsnorm(x) * w          x,y fp16 [M,H], w fp16 [H]                     (rms_norm.cu:21-138) */
+int tm_rmsnorm(void* y, const void* x, const void* w, float eps, int M, int H, tm_stream_t st);
+/* r <- r + hidden (+ bias), y <- rmsnorm(r) * w ; residual stream accumulates in fp16 (rms_norm.cu:286-362).
+ * If `partial` != NULL, hidden is given as `splits` fp32 split-K slabs [splits][M][H] (hidden must be NULL). */
+int tm_residual_rmsnorm(void* y, void* resid, const void* hidden, const float* partial, int splits,
+                        const void* bias, const void* w, float eps, int M, int H, tm_stream_t st);
+
+/* (cos,sin) fp16 table [max_pos][rope_dim/2][2] on the HOST (rotary_embedding.h:11-52, attention_weight.cc:37-93).
+ * rope_type: 0 default, 1 linear, 2 llama3.  The caller uploads it. */
+int tm_rope_table(void* host_out, int max_pos, int rope_dim, float base, int rope_type, float factor,
+                  float low_freq_factor, float high_freq_factor, int original_max_position);
+
+/* RoPE(q,k) + quantise-and-store K/V of the new tokens into the paged cache (ProcessKV_v2 / decode prologue).
+ * qkv fp16 [total_tokens][(q_heads + 2 kv_heads)*128]; q is rotated in place.
+ * cu_q_len [batch+1], k_len [batch] = context length of each sequence AFTER adding its new tokens (device).
+ * cos_sin may be NULL (no rotation). */
+int tm_kv_rope_store(void* qkv, int q_heads, const int* cu_q_len, const int* k_len, int batch, int total_tokens,
+                     const void* cos_sin, int max_pos, const tm_kv_cache* cache, tm_stream_t st);
+/* FlattenKV_v2: dequantise the whole context into linear fp16 scratch.  k_out [kv_heads][k_stride][128];
+ * v_out the same, or transposed [kv_heads][128][k_stride] when transpose_v != 0.  Sequence b starts at
+ * cu_k_off[b] (device; must be 64-aligned when transposing). */
+int tm_flatten_kv(void* k_out, void* v_out, int transpose_v, const int* cu_k_off, const int* k_len, int batch,
+                  int max_k_len, int k_stride, const tm_kv_cache* cache, tm_stream_t st);
+
+/* Paged flash-decode, one query token per sequence (dispatchDecoding).  q fp16 [batch][q_stride] already
+ * rotated (head h at h*128), out fp16 [batch][q_heads*128].  splits >= 1; workspace of
+ * tm_decode_attention_workspace() bytes needed when splits > 1.  softmax_scale <= 0 -> 1/sqrt(128). */
+size_t tm_decode_attention_workspace(int batch, int q_heads, int splits);
+int    tm_decode_attention(void* out, const void* q, int q_stride, const int* k_len, int batch, int q_heads,
+                           float softmax_scale, int splits, void* workspace, const tm_kv_cache* cache,
+                           tm_stream_t st);
+/* Causal prefill attention over flattened KV (dispatchAttention).  vt is the transposed V of tm_flatten_kv. */
+int tm_prefill_attention(void* out, const void* q, int q_stride, const void* k, const void* vt, int k_stride,
+                         const int* cu_q_len, const int* cu_k_off, const int* k_len, int batch, int max_q_len,
+                         int q_heads, int kv_heads, float softmax_scale, tm_stream_t st);
+
+int tm_embedding(void* out, const void* table, const int* ids, int tokens, int hidden, int vocab, tm_stream_t st);
+/* greedy top-1 on fp32-cast logits (generation/sampling.cc:92-183); out_val (fp16 [batch]) may be NULL */
+int tm_argmax(int* out_ids, void* out_val, const void* logits, int batch, int vocab, int ld, tm_stream_t st);
+/* unfused activation on [M][2*inter] laid out [gate | up]            (kernels/activation.cu:27-130) */
+int tm_silu_mul(void* out, const void* gate_up, int M, int inter, tm_stream_t st);
+
+/* ---- Linear (mirrors _tm.LinearWeight / LlamaLinear.forward_dense / QuantizeGroupwise) -------- */
+typedef struct tm_linear tm_linear;
+enum { TM_WEIGHT_U4 = 0, TM_WEIGHT_F16 = 1 };
+int tm_linear_create(tm_linear** out, int in_features, int out_features, int weight_type, int group_size);
+/* Boundary ("TM") layout, device pointers: qweight int32 [K][N/8] (nibble j of word c = column 8c+j,
+ * lmdeploy/turbomind/weight_format.py:63-74), scales / zeros fp16 [K/g][N].  For TM_WEIGHT_F16: weight fp16
+ * [K][N], scales = zeros = NULL.  Performs LinearWeight::prepare (repack to MFMA-fragment order, fuse (s,-z*s)). */
+int tm_linear_prepare(tm_linear* w, const void* weight, const void* scales, const void* zeros, tm_stream_t st);
+/* y fp16 [M][N] (or [M][N/2] when gated_silu: columns interleaved (gate_j, up_j), epilogue.h:159-176).
+ * nt / splits: 0 = heuristic.  workspace >= tm_linear_workspace() bytes when split-K may be used. */
+size_t tm_linear_workspace(const tm_linear* w, int M);
+int    tm_linear_forward(const tm_linear* w, const void* x, int ldx, void* y, int ldy, int M, int gated_silu,
+                         int nt, int splits, void* workspace, tm_stream_t st);
+int    tm_linear_destroy(tm_linear* w);
+/* IntegralQuantizer<half,4> (kernels/quantization.cu:384-440): w fp16 [K][N] -> qweight int32 [K][N/8],
+ * scales/zeros fp16 [K/g][N], dequant fp16 [K][N] (may be NULL).  Groups run along K. */
+int tm_quantize_groupwise(void* qweight, void* scales, void* zeros, void* dequant, const void* w, int K, int N,
+                          int group_size, tm_stream_t st);
+
+/* ----------------------------------------------------------------------------------------------
+ * Engine level (static batcher around LanguageModel::Forward)
+ * --------------------------------------------------------------------------------------------*/
+typedef struct tm_model_config {
+    int   hidden, layers, q_heads, kv_heads, head_dim, inter, vocab;
+    float rms_eps;
+    float rope_base;
+    int   rope_type; /* 0 default, 1 linear, 2 llama3 */
+    float rope_factor, rope_low_freq_factor, rope_high_freq_factor;
+    int   rope_original_max_position;
+    int   group_size;   /* 128 */
+    int   weight_type;  /* TM_WEIGHT_U4 (AWQ) or TM_WEIGHT_F16 for the decoder linears; lm_head is always fp16 */
+} tm_model_config;
+
+typedef struct tm_engine_config {
+    tm_model_config model;
+    int   tp;                 /* tensor-parallel world size (one process per GPU)            */
+    int   rank;               /* this process' rank                                          */
+    int   device;             /* HIP device ordinal                                          */
+    int   max_batch_size;     /* TurbomindEngineConfig.max_batch_size                        */
+    int   session_len;        /* max context per sequence                                    */
+    int   quant_policy;       /* 0 | 4 | 8  (lmdeploy/messages.py:20-27)                     */
+    int   cache_block_seq_len;/* 64                                                          */
+    float cache_max_entry_count; /* fraction of free HBM for KV blocks if cache_blocks == 0 */
+    int   cache_blocks;       /* explicit number of KV blocks (0 = derive)                   */
+    int   max_prefill_token_num; /* tokens per prefill iteration (messages.py:334: 8192)    */
+    int   decode_splits;      /* 0 = heuristic                                               */
+    int   use_graph;          /* capture the decode step in a hipGraph                       */
+} tm_engine_config;
+
+typedef struct tm_engine tm_engine;
+
+int tm_engine_create(tm_engine** out, const tm_engine_config* cfg);
+int tm_engine_destroy(tm_engine* e);
+/* RCCL bootstrap for tp > 1: rank 0 calls tm_comm_unique_id (128 bytes, host), broadcasts it out of band
+ * (torch.distributed / TCPStore), then every rank calls tm_engine_comm_init. */
+int tm_comm_unique_id(void* host_out128);
+int tm_engine_comm_init(tm_engine* e, const void* host_id128);
+
+/* Weight hand-off: named Param slots, already TP-sharded / QKV-fused / w1w3-interleaved by the loader
+ * (lmdeploy/turbomind/builders/_base.py:72-113).  Names: "layers.{i}.attention.w_qkv.{qweight,scales,zeros}",
+ * "layers.{i}.attention.wo.*", "layers.{i}.feed_forward.w1w3.*", "layers.{i}.feed_forward.w2.*"
+ * (".weight" instead for fp16 linears), "layers.{i}.attention_norm.weight", "layers.{i}.ffn_norm.weight",
+ * "tok_embeddings.weight", "norm.weight", "output.weight".
+ * tm_engine_weight_bytes: expected byte size of a slot (0 + TM_INVALID for unknown names).
+ * tm_engine_weight_copy : host -> device staging copy; byte size must match exactly. */
+int64_t tm_engine_weight_bytes(tm_engine* e, const char* name);
+int     tm_engine_weight_copy(tm_engine* e, const char* name, const void* host_src, int64_t bytes);
+/* Device-side synthetic init (random weights with the real shapes): N(0,1)*0.1/sqrt(K) fp16
+ * master -> group-128 asymmetric u4; norms 1+0.02N; embeddings 0.02N.  For benchmarks without checkpoints. */
+int     tm_engine_init_synthetic(tm_engine* e, uint64_t seed);
+/* ModelRoot::prepare(): repack every linear, free staging */
+int     tm_engine_process_weights(tm_engine* e);
+/* allocate KV pool + activation buffers, build RoPE table (TurboMind::CreateEngine) */
+int     tm_engine_start(tm_engine* e);
+
+/* Static batch.  Admit `batch` sequences (host token ids, concatenated; host lens), run chunked prefill and
+ * produce the first token of every sequence.  Each sequence reserves ceil((len + max_new_tokens)/64) blocks. */
+int tm_engine_prefill(tm_engine* e, const int* host_ids, const int* host_lens, int batch, int max_new_tokens);
+/* run `steps` decode iterations for the admitted batch (every sequence generates one token per step,
+ * ignore_eos semantics).  Asynchronous on the engine stream; tm_engine_sync() waits. */
+int tm_engine_decode(tm_engine* e, int steps);
+int tm_engine_sync(tm_engine* e);
+/* copy generated tokens so far to host: out [batch][max_new_tokens] int32 (row-major), n_generated (host) */
+int tm_engine_fetch(tm_engine* e, int* host_out, int* n_generated);
+/* last step's logits of the local vocab shard, fp16 [batch][vocab/tp] -> host (debug / parity tests) */
+int tm_engine_fetch_logits(tm_engine* e, void* host_out);
+/* release the batch (blocks return to the pool) */
+int tm_engine_release(tm_engine* e);
+/* the engine's stream (hipStream_t) so callers can bracket it with their own events */
+tm_stream_t tm_engine_stream(tm_engine* e);
+/* introspection for benchmarks: bytes of quantised weights + scales + lm_head, KV bytes per token, #blocks */
+int tm_engine_stats(tm_engine* e, int64_t* weight_bytes, int64_t* kv_bytes_per_token, int64_t* num_blocks,
+                    int* decode_splits);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TM_MI355X_H */

@@ -1,0 +1,144 @@
+"""ctypes binding of libtm_mi355x.so (the C-ABI declared in include/tm_mi355x.h).
+
+This is the only place where Python touches the native library.  There is NO fallback: if the
+shared object is missing or a call fails, an exception is raised (the product path never routes
+through a CPU implementation).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from ctypes import POINTER, c_char_p, c_float, c_int, c_int64, c_size_t, c_uint64, c_void_p
+
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'lib', 'libtm_mi355x.so')
+
+
+class TmError(RuntimeError):
+
+    def __init__(self, status: int, message: str):
+        super().__init__(f'tm_mi355x status {status}: {message}')
+        self.status = status
+
+
+class KvCache(C.Structure):
+    """struct tm_kv_cache"""
+    _fields_ = [('block_ptrs', c_void_p), ('cu_block_nums', c_void_p), ('layer_offset', c_int64),
+                ('kv_heads', c_int), ('head_dim', c_int), ('block_len', c_int), ('bits', c_int)]
+
+
+class ModelConfig(C.Structure):
+    """struct tm_model_config"""
+    _fields_ = [('hidden', c_int), ('layers', c_int), ('q_heads', c_int), ('kv_heads', c_int), ('head_dim', c_int),
+                ('inter', c_int), ('vocab', c_int), ('rms_eps', c_float), ('rope_base', c_float),
+                ('rope_type', c_int), ('rope_factor', c_float), ('rope_low_freq_factor', c_float),
+                ('rope_high_freq_factor', c_float), ('rope_original_max_position', c_int), ('group_size', c_int),
+                ('weight_type', c_int)]
+
+
+class EngineConfig(C.Structure):
+    """struct tm_engine_config"""
+    _fields_ = [('model', ModelConfig), ('tp', c_int), ('rank', c_int), ('device', c_int),
+                ('max_batch_size', c_int), ('session_len', c_int), ('quant_policy', c_int),
+                ('cache_block_seq_len', c_int), ('cache_max_entry_count', c_float), ('cache_blocks', c_int),
+                ('max_prefill_token_num', c_int), ('decode_splits', c_int), ('use_graph', c_int)]
+
+
+# name -> (restype, argtypes); every int-returning function is a tm_status
+_SIGNATURES = {
+    'tm_version': (c_int, []),
+    'tm_last_error': (c_char_p, []),
+    'tm_device_count': (c_int, []),
+    'tm_kv_layer_size': (c_int64, [c_int, c_int, c_int, c_int]),
+    'tm_rmsnorm': (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_int, c_int, c_void_p]),
+    'tm_residual_rmsnorm': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_float,
+                                    c_int, c_int, c_void_p]),
+    'tm_rope_table': (c_int, [c_void_p, c_int, c_int, c_float, c_int, c_float, c_float, c_float, c_int]),
+    'tm_kv_rope_store': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int,
+                                 POINTER(KvCache), c_void_p]),
+    'tm_flatten_kv': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, POINTER(KvCache),
+                              c_void_p]),
+    'tm_decode_attention_workspace': (c_size_t, [c_int, c_int, c_int]),
+    'tm_decode_attention': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_float, c_int, c_void_p,
+                                    POINTER(KvCache), c_void_p]),
+    'tm_prefill_attention': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
+                                     c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p]),
+    'tm_embedding': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    'tm_argmax': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    'tm_silu_mul': (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    'tm_linear_create': (c_int, [POINTER(c_void_p), c_int, c_int, c_int, c_int]),
+    'tm_linear_prepare': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'tm_linear_workspace': (c_size_t, [c_void_p, c_int]),
+    'tm_linear_forward': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p,
+                                  c_void_p]),
+    'tm_linear_destroy': (c_int, [c_void_p]),
+    'tm_quantize_groupwise': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
+                                      c_void_p]),
+    'tm_engine_create': (c_int, [POINTER(c_void_p), POINTER(EngineConfig)]),
+    'tm_engine_destroy': (c_int, [c_void_p]),
+    'tm_comm_unique_id': (c_int, [c_void_p]),
+    'tm_engine_comm_init': (c_int, [c_void_p, c_void_p]),
+    'tm_engine_weight_bytes': (c_int64, [c_void_p, c_char_p]),
+    'tm_engine_weight_copy': (c_int, [c_void_p, c_char_p, c_void_p, c_int64]),
+    'tm_engine_init_synthetic': (c_int, [c_void_p, c_uint64]),
+    'tm_engine_process_weights': (c_int, [c_void_p]),
+    'tm_engine_start': (c_int, [c_void_p]),
+    'tm_engine_prefill': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int]),
+    'tm_engine_decode': (c_int, [c_void_p, c_int]),
+    'tm_engine_sync': (c_int, [c_void_p]),
+    'tm_engine_fetch': (c_int, [c_void_p, c_void_p, POINTER(c_int)]),
+    'tm_engine_fetch_logits': (c_int, [c_void_p, c_void_p]),
+    'tm_engine_release': (c_int, [c_void_p]),
+    'tm_engine_stream': (c_void_p, [c_void_p]),
+    'tm_engine_stats': (c_int, [c_void_p, POINTER(c_int64), POINTER(c_int64), POINTER(c_int64), POINTER(c_int)]),
+}
+
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+_lib = None
+
+
+def lib_path() -> str:
+    return _LIB_PATH
+
+
+def load():
+    """Load the native library (raises if it has not been built: no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIB_PATH):
+        raise ImportError(f'{_LIB_PATH} not found: build it with `python -c "import __graft_entry__ as g; g.build()"` '
+                          f'or `make -C lmdeploy_amd/csrc`. There is no CPU fallback.')
+    lib = C.CDLL(_LIB_PATH, mode=C.RTLD_GLOBAL)
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the .so does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def last_error() -> str:
+    msg = load().tm_last_error()
+    return msg.decode() if msg else ''
+
+
+def check(status: int):
+    if status != 0:
+        raise TmError(status, last_error())
+
+
+def ptr(t) -> int:
+    """Device (or host) address of a torch tensor / numpy array, None -> NULL."""
+    if t is None:
+        return None
+    if hasattr(t, 'data_ptr'):
+        return t.data_ptr()
+    return t.ctypes.data
+
+
+def stream_ptr(stream=None):
+    if stream is None:
+        import torch
+        return torch.cuda.current_stream().cuda_stream
+    return stream

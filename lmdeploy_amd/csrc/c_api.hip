@@ -1,0 +1,274 @@
+// C-ABI shims for the operator-level entry points declared in include/tm_mi355x.h.
+#include "../../include/tm_mi355x.h"
+#include "tm_common.h"
+#include "tm_kernels.h"
+#include <cmath>
+#include <vector>
+
+namespace tmk {
+
+static thread_local std::string g_last_error;
+
+void set_last_error(const std::string& msg)
+{
+    g_last_error = msg;
+}
+const char* get_last_error()
+{
+    return g_last_error.c_str();
+}
+
+static KvCacheView to_view(const tm_kv_cache* c)
+{
+    KvCacheView v{};
+    v.block_ptrs    = c->block_ptrs;
+    v.cu_block_nums = c->cu_block_nums;
+    v.layer_offset  = c->layer_offset;
+    v.layout        = KvLayout{c->kv_heads, c->head_dim, c->block_len, c->bits};
+    return v;
+}
+
+// Host-side (cos, sin) table.  Deterministic recipe shared with the oracle: freq and the angle are fp32
+// products, exp2 / sin / cos are evaluated in double on those fp32 values and rounded fp32 -> fp16.
+int build_rope_table(half_t* out, int max_pos, int dim, float base, int type, float factor, float low, float high,
+                     int orig_max_pos)
+{
+    TM_REQUIRE(dim > 0 && dim % 2 == 0, "rope dim");
+    TM_REQUIRE(type >= 0 && type <= 2, "rope_type in {0 default, 1 linear, 2 llama3}");
+    const float        scale_factor = (float)(-std::log2((double)base) / dim);
+    std::vector<float> inv(dim / 2);
+    for (int i = 0; i < dim; i += 2) {
+        const float prod = (float)i * scale_factor;
+        const float freq = (float)std::exp2((double)prod);
+        float       f    = freq;
+        if (type == 1) {
+            f = (float)(1.0 / factor) * freq;
+        }
+        else if (type == 2) {
+            const double inv_diff   = 1.0 / ((double)high - (double)low);
+            const float  alpha      = (float)((double)orig_max_pos / (2.0 * M_PI) * inv_diff);
+            const float  beta       = (float)((double)low * inv_diff);
+            const float  inv_factor = (float)(1.0 / factor);
+            float        smooth     = alpha * freq - beta;
+            smooth                  = smooth < 0.f ? 0.f : (smooth > 1.f ? 1.f : smooth);
+            f                       = (1.f - smooth) * freq * inv_factor + smooth * freq;
+        }
+        inv[i / 2] = f;
+    }
+    for (int t = 0; t < max_pos; ++t) {
+        for (int i = 0; i < dim / 2; ++i) {
+            const float ang                        = (float)t * inv[i];
+            out[((size_t)t * (dim / 2) + i) * 2]   = (half_t)(float)std::cos((double)ang);
+            out[((size_t)t * (dim / 2) + i) * 2 + 1] = (half_t)(float)std::sin((double)ang);
+        }
+    }
+    return 0;
+}
+
+}  // namespace tmk
+
+using namespace tmk;
+
+struct tm_linear {
+    LinearWeight w;
+};
+
+extern "C" {
+
+int tm_version(void)
+{
+    return 100;  // 0.1.0
+}
+
+const char* tm_last_error(void)
+{
+    return get_last_error();
+}
+
+int tm_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return n;
+}
+
+int64_t tm_kv_layer_size(int kv_heads, int head_dim, int block_len, int bits)
+{
+    return KvLayout{kv_heads, head_dim, block_len, bits}.layer_size();
+}
+
+int tm_rmsnorm(void* y, const void* x, const void* w, float eps, int M, int H, tm_stream_t st)
+{
+    TM_REQUIRE(y && x && w, "null pointer");
+    return launch_rmsnorm((half_t*)y, (const half_t*)x, (const half_t*)w, eps, M, H, (hipStream_t)st);
+}
+
+int tm_residual_rmsnorm(void* y, void* resid, const void* hidden, const float* partial, int splits, const void* bias,
+                        const void* w, float eps, int M, int H, tm_stream_t st)
+{
+    TM_REQUIRE(y && resid && w, "null pointer");
+    return launch_residual_rmsnorm((half_t*)y, (half_t*)resid, (const half_t*)hidden, partial, splits,
+                                   (const half_t*)bias, (const half_t*)w, eps, M, H, (hipStream_t)st);
+}
+
+int tm_rope_table(void* host_out, int max_pos, int rope_dim, float base, int rope_type, float factor,
+                  float low_freq_factor, float high_freq_factor, int original_max_position)
+{
+    TM_REQUIRE(host_out, "null pointer");
+    return build_rope_table((half_t*)host_out, max_pos, rope_dim, base, rope_type, factor, low_freq_factor,
+                            high_freq_factor, original_max_position);
+}
+
+int tm_kv_rope_store(void* qkv, int q_heads, const int* cu_q_len, const int* k_len, int batch, int total_tokens,
+                     const void* cos_sin, int max_pos, const tm_kv_cache* cache, tm_stream_t st)
+{
+    TM_REQUIRE(qkv && cu_q_len && k_len && cache, "null pointer");
+    return launch_kv_rope_store((half_t*)qkv, q_heads, cu_q_len, k_len, batch, total_tokens, (const half2_t*)cos_sin,
+                                max_pos, to_view(cache), (hipStream_t)st);
+}
+
+int tm_flatten_kv(void* k_out, void* v_out, int transpose_v, const int* cu_k_off, const int* k_len, int batch,
+                  int max_k_len, int k_stride, const tm_kv_cache* cache, tm_stream_t st)
+{
+    TM_REQUIRE(k_out && v_out && cu_k_off && k_len && cache, "null pointer");
+    return launch_flatten_kv((half_t*)k_out, (half_t*)v_out, transpose_v, cu_k_off, k_len, batch, max_k_len, k_stride,
+                             to_view(cache), (hipStream_t)st);
+}
+
+size_t tm_decode_attention_workspace(int batch, int q_heads, int splits)
+{
+    return decode_attention_workspace_bytes(batch, q_heads, 128, splits);
+}
+
+int tm_decode_attention(void* out, const void* q, int q_stride, const int* k_len, int batch, int q_heads,
+                        float softmax_scale, int splits, void* workspace, const tm_kv_cache* cache, tm_stream_t st)
+{
+    TM_REQUIRE(out && q && k_len && cache, "null pointer");
+    DecodeAttnParams p{};
+    p.q          = (const half_t*)q;
+    p.q_stride   = q_stride;
+    p.out        = (half_t*)out;
+    p.k_len      = k_len;
+    p.batch      = batch;
+    p.q_heads    = q_heads;
+    const float s = softmax_scale > 0.f ? softmax_scale : 1.0f / std::sqrt(128.0f);
+    p.scale_log2 = s * 1.4426950408889634f;
+    p.splits     = splits < 1 ? 1 : splits;
+    p.partial_o  = (float*)workspace;
+    p.partial_ml = workspace ? (float*)workspace + (size_t)batch * q_heads * p.splits * 128 : nullptr;
+    p.cache      = to_view(cache);
+    return launch_decode_attention(p, (hipStream_t)st);
+}
+
+int tm_prefill_attention(void* out, const void* q, int q_stride, const void* k, const void* vt, int k_stride,
+                         const int* cu_q_len, const int* cu_k_off, const int* k_len, int batch, int max_q_len,
+                         int q_heads, int kv_heads, float softmax_scale, tm_stream_t st)
+{
+    TM_REQUIRE(out && q && k && vt && cu_q_len && cu_k_off && k_len, "null pointer");
+    PrefillAttnParams p{};
+    p.q          = (const half_t*)q;
+    p.q_stride   = q_stride;
+    p.out        = (half_t*)out;
+    p.k          = (const half_t*)k;
+    p.vt         = (const half_t*)vt;
+    p.k_stride   = k_stride;
+    p.cu_q_len   = cu_q_len;
+    p.cu_k_off   = cu_k_off;
+    p.k_len      = k_len;
+    p.batch      = batch;
+    p.max_q_len  = max_q_len;
+    p.q_heads    = q_heads;
+    p.kv_heads   = kv_heads;
+    const float s = softmax_scale > 0.f ? softmax_scale : 1.0f / std::sqrt(128.0f);
+    p.scale_log2 = s * 1.4426950408889634f;
+    return launch_prefill_attention(p, (hipStream_t)st);
+}
+
+int tm_embedding(void* out, const void* table, const int* ids, int tokens, int hidden, int vocab, tm_stream_t st)
+{
+    TM_REQUIRE(out && table && ids, "null pointer");
+    return launch_embedding((half_t*)out, (const half_t*)table, ids, tokens, hidden, vocab, (hipStream_t)st);
+}
+
+int tm_argmax(int* out_ids, void* out_val, const void* logits, int batch, int vocab, int ld, tm_stream_t st)
+{
+    TM_REQUIRE(out_ids && logits, "null pointer");
+    return launch_argmax(out_ids, (half_t*)out_val, (const half_t*)logits, batch, vocab, ld, 0, (hipStream_t)st);
+}
+
+int tm_silu_mul(void* out, const void* gate_up, int M, int inter, tm_stream_t st)
+{
+    TM_REQUIRE(out && gate_up, "null pointer");
+    return launch_silu_mul((half_t*)out, (const half_t*)gate_up, M, inter, (hipStream_t)st);
+}
+
+int tm_linear_create(tm_linear** out, int in_features, int out_features, int weight_type, int group_size)
+{
+    TM_REQUIRE(out, "null pointer");
+    TM_REQUIRE(weight_type == TM_WEIGHT_U4 || weight_type == TM_WEIGHT_F16, "weight_type");
+    TM_REQUIRE(in_features > 0 && out_features > 0, "shape");
+    auto* l     = new tm_linear();
+    l->w.K      = in_features;
+    l->w.N      = out_features;
+    l->w.group  = group_size;
+    l->w.type   = weight_type;
+    *out        = l;
+    return 0;
+}
+
+int tm_linear_prepare(tm_linear* w, const void* weight, const void* scales, const void* zeros, tm_stream_t st)
+{
+    TM_REQUIRE(w && weight, "null pointer");
+    if (w->w.type == TM_WEIGHT_U4) {
+        TM_REQUIRE(scales && zeros, "u4 weights need scales and zeros");
+        return linear_weight_prepare_u4(w->w, (const int32_t*)weight, (const half_t*)scales, (const half_t*)zeros,
+                                        (hipStream_t)st);
+    }
+    return linear_weight_prepare_f16(w->w, (const half_t*)weight, (hipStream_t)st);
+}
+
+size_t tm_linear_workspace(const tm_linear* w, int M)
+{
+    return w ? gemm_workspace_bytes(M, w->w.N, 16) : 0;
+}
+
+int tm_linear_forward(const tm_linear* w, const void* x, int ldx, void* y, int ldy, int M, int gated_silu, int nt,
+                      int splits, void* workspace, tm_stream_t st)
+{
+    TM_REQUIRE(w && x && y, "null pointer");
+    GemmConfig cfg = gemm_pick_config(w->w, M);
+    if (nt > 0) {
+        cfg.nt = nt;
+    }
+    if (splits > 0) {
+        cfg.splits = splits;
+    }
+    TM_REQUIRE(cfg.splits <= 16, "splits <= 16");
+    if (!workspace) {
+        cfg.splits = 1;
+    }
+    return launch_linear(w->w, (const half_t*)x, ldx, (half_t*)y, ldy, M, gated_silu != 0, cfg, (float*)workspace, false,
+                         nullptr, (hipStream_t)st);
+}
+
+int tm_linear_destroy(tm_linear* w)
+{
+    if (w) {
+        linear_weight_free(w->w);
+        delete w;
+    }
+    return 0;
+}
+
+int tm_quantize_groupwise(void* qweight, void* scales, void* zeros, void* dequant, const void* w, int K, int N,
+                          int group_size, tm_stream_t st)
+{
+    TM_REQUIRE(qweight && scales && zeros && w, "null pointer");
+    return launch_quantize_groupwise_u4((int32_t*)qweight, (half_t*)scales, (half_t*)zeros, (half_t*)dequant,
+                                        (const half_t*)w, K, N, group_size, (hipStream_t)st);
+}
+
+}  // extern "C"

@@ -1,0 +1,1012 @@
+// Static-batch decode engine around the HIP kernels: the MI355X-native counterpart of
+//   TurboMind::CreateEngine / ModelExecutor::Run / LanguageModel::Forward / UnifiedDecoder::Forward
+//   (src/turbomind/turbomind.cc:281-361, engine/model_executor.cc:68-101, models/language_model.cc:493-542,
+//    models/llama/unified_decoder.cc:163-380, unified_attention_layer.cc:365-441, LlamaFfnLayer.cc:28-91).
+//
+// One process per GPU.  All per-step state (context lengths, current token ids, generated tokens, step
+// counter) lives in device memory so a whole decode step is a fixed kernel sequence that is captured ONCE in
+// a hipGraph and replayed (the reference keeps ids on the device too: language_model.cc:540).  Tensor
+// parallelism: column-parallel w_qkv / w1w3, row-parallel wo / w2 followed by an RCCL all-reduce of the
+// fp16 [M,H] partial sums (comm/nccl/nccl.cu:356-398), lm_head sharded over the vocabulary with a
+// (value, index) all-gather instead of gathering logits.
+#include "../../include/tm_mi355x.h"
+#include "tm_common.h"
+#include "tm_kernels.h"
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <map>
+#include <rccl/rccl.h>
+#include <string>
+#include <vector>
+
+namespace tmk {
+
+int build_rope_table(half_t* out, int max_pos, int dim, float base, int type, float factor, float low, float high,
+                     int orig_max_pos);
+
+#define TM_NCCL_CHECK(expr)                                                                        \
+    do {                                                                                           \
+        ncclResult_t _r = (expr);                                                                  \
+        if (_r != ncclSuccess) {                                                                   \
+            ::tmk::set_last_error(std::string(#expr) + ": " + ncclGetErrorString(_r));             \
+            return 5;                                                                              \
+        }                                                                                          \
+    } while (0)
+
+#define TM_TRY(expr)                                                                               \
+    do {                                                                                           \
+        int _rc = (expr);                                                                          \
+        if (_rc) {                                                                                 \
+            return _rc;                                                                            \
+        }                                                                                          \
+    } while (0)
+
+// ---------------------------------------------------------------------------------------------
+// device-side helpers for the engine
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t splitmix64(uint64_t x)
+{
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+
+// out[i] = h(mean + std * N(0,1)), counter-based (Box-Muller on splitmix64), 2 values per thread
+__global__ void fill_normal_kernel(half_t* out, size_t n, float mean, float stddev, uint64_t seed)
+{
+    const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 2;
+    if (i >= n) {
+        return;
+    }
+    const uint64_t r  = splitmix64(seed ^ (i * 0x9E3779B97F4A7C15ull + 0x1234567ull));
+    const float    u1 = ((float)(uint32_t)(r >> 40) + 1.0f) * (1.0f / 16777217.0f);  // (0,1)
+    const float    u2 = (float)(uint32_t)((r >> 8) & 0xffffffu) * (1.0f / 16777216.0f);
+    const float    rr = sqrtf(-2.0f * __logf(u1));
+    float          s, c;
+    __sincosf(6.283185307179586f * u2, &s, &c);
+    out[i] = (half_t)(mean + stddev * rr * c);
+    if (i + 1 < n) {
+        out[i + 1] = (half_t)(mean + stddev * rr * s);
+    }
+}
+
+__global__ void advance_kernel(int* k_len, int batch)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < batch) {
+        k_len[b] += 1;
+    }
+}
+
+// ids -> generated[b][step]; step++ (single thread does the counter after everybody read it)
+__global__ void record_kernel(const int* ids, int* generated, int* step_counter, int batch, int max_new)
+{
+    const int b    = blockIdx.x * blockDim.x + threadIdx.x;
+    const int step = *step_counter;
+    if (b < batch && step < max_new) {
+        generated[(size_t)b * max_new + step] = ids[b];
+    }
+    __syncthreads();
+    if (b == 0) {
+        *step_counter = step + 1;
+    }
+}
+
+// pick the global arg-max out of tp (value, index) candidates per sequence
+__global__ void pick_kernel(int* out_ids, const float* cand /*[tp][B][2]*/, int tp, int batch)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= batch) {
+        return;
+    }
+    float best = -INFINITY;
+    int   bi   = 0;
+    for (int r = 0; r < tp; ++r) {
+        const float v = cand[((size_t)r * batch + b) * 2];
+        const int   i = __float_as_int(cand[((size_t)r * batch + b) * 2 + 1]);
+        if (v > best || (v == best && i < bi)) {
+            best = v;
+            bi   = i;
+        }
+    }
+    out_ids[b] = bi;
+}
+
+__global__ void pack_candidates_kernel(float* cand, const int* ids, const half_t* vals, int batch)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < batch) {
+        cand[b * 2]     = (float)vals[b];
+        cand[b * 2 + 1] = __int_as_float(ids[b]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+struct Slot {
+    void*   dev   = nullptr;  // staging (boundary layout) -- freed by process_weights for linears
+    int64_t bytes = 0;
+    bool    filled = false;
+};
+
+struct LinearSlots {
+    LinearWeight w;
+    std::string  prefix;
+};
+
+struct Layer {
+    LinearSlots qkv, wo, w13, w2;
+    half_t*     attn_norm = nullptr;
+    half_t*     ffn_norm  = nullptr;
+};
+
+}  // namespace tmk
+
+using namespace tmk;
+
+struct tm_engine {
+    tm_engine_config cfg{};
+    // local (per-rank) dims
+    int q_heads = 0, kv_heads = 0, inter = 0, vocab_local = 0, hidden = 0, D = 128;
+    int qkv_n = 0;
+
+    hipStream_t  stream = nullptr;
+    ncclComm_t   comm   = nullptr;
+    std::map<std::string, Slot> slots;
+    std::vector<Layer>          layers;
+    half_t*      tok_embeddings = nullptr;
+    half_t*      final_norm     = nullptr;
+    LinearSlots  output;
+    bool         weights_ready = false;
+    bool         started       = false;
+
+    // KV cache
+    KvLayout  layout{};
+    char*     pool        = nullptr;
+    int64_t   block_bytes = 0;
+    int64_t   num_blocks  = 0;
+    std::vector<int> free_blocks;
+    int       max_blocks_per_seq = 0;
+    uint64_t* d_block_ptrs    = nullptr;  // [max_batch][max_blocks_per_seq]
+    int*      d_cu_block_nums = nullptr;  // [max_batch+1]
+
+    // activations
+    int     max_tokens = 0;
+    half_t *d_resid = nullptr, *d_x = nullptr, *d_qkv = nullptr, *d_attn = nullptr, *d_act = nullptr, *d_tmp = nullptr;
+    half_t* d_logits = nullptr;
+    half_t* d_last   = nullptr;
+    float*  d_gemm_ws = nullptr;
+    size_t  gemm_ws_bytes = 0;
+    float*  d_attn_ws = nullptr;
+    half_t *d_kflat = nullptr, *d_vflat = nullptr;
+    int     kflat_stride = 0;
+    half2_t* d_rope = nullptr;
+    int      rope_max_pos = 0;
+
+    // batch state (device)
+    int *d_next_ids = nullptr;
+    int *d_ids = nullptr, *d_k_len = nullptr, *d_cu_q = nullptr, *d_cu_koff = nullptr, *d_rows = nullptr;
+    int *d_generated = nullptr, *d_step = nullptr;
+    int *d_prefill_ids = nullptr;
+    half_t* d_argmax_val = nullptr;
+    float*  d_cand = nullptr;
+    float*  d_cand_all = nullptr;
+
+    // batch state (host)
+    int              batch = 0, max_new = 0;
+    std::vector<int> h_len;
+    std::vector<std::vector<int>> h_blocks;
+    int              steps_done = 0;
+
+    int            decode_splits = 1;
+    hipGraphExec_t graph = nullptr;
+    int            graph_batch = 0;
+};
+
+namespace tmk {
+
+static int64_t slot_bytes_linear(const tm_engine* e, int K, int N, const char* part)
+{
+    if (!strcmp(part, "qweight")) return (int64_t)K * N / 2;
+    if (!strcmp(part, "scales") || !strcmp(part, "zeros")) return (int64_t)(K / e->cfg.model.group_size) * N * 2;
+    if (!strcmp(part, "weight")) return (int64_t)K * N * 2;
+    return 0;
+}
+
+static void add_linear(tm_engine* e, LinearSlots& l, const std::string& prefix, int K, int N, int type)
+{
+    l.prefix  = prefix;
+    l.w.K     = K;
+    l.w.N     = N;
+    l.w.group = e->cfg.model.group_size;
+    l.w.type  = type;
+    if (type == TM_WEIGHT_U4) {
+        for (const char* part : {"qweight", "scales", "zeros"}) {
+            e->slots[prefix + "." + part].bytes = slot_bytes_linear(e, K, N, part);
+        }
+    }
+    else {
+        e->slots[prefix + ".weight"].bytes = slot_bytes_linear(e, K, N, "weight");
+    }
+}
+
+static int ensure_slot(tm_engine* e, const std::string& name, Slot** out)
+{
+    auto it = e->slots.find(name);
+    TM_REQUIRE(it != e->slots.end(), "unknown weight slot: " + name);
+    Slot& s = it->second;
+    if (!s.dev) {
+        TM_HIP_CHECK(hipMalloc(&s.dev, s.bytes));
+    }
+    *out = &s;
+    return 0;
+}
+
+static int fill_normal(tm_engine* e, void* dst, size_t n, float mean, float stddev, uint64_t seed)
+{
+    const size_t thr = (n + 1) / 2;
+    fill_normal_kernel<<<(thr + 255) / 256, 256, 0, e->stream>>>((half_t*)dst, n, mean, stddev, seed);
+    TM_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+static int prepare_linear(tm_engine* e, LinearSlots& l)
+{
+    if (l.w.type == TM_WEIGHT_U4) {
+        Slot &q = e->slots[l.prefix + ".qweight"], &s = e->slots[l.prefix + ".scales"], &z = e->slots[l.prefix + ".zeros"];
+        TM_REQUIRE(q.filled && s.filled && z.filled, "weight not loaded: " + l.prefix);
+        TM_TRY(linear_weight_prepare_u4(l.w, (const int32_t*)q.dev, (const half_t*)s.dev, (const half_t*)z.dev, e->stream));
+        TM_HIP_CHECK(hipStreamSynchronize(e->stream));
+        for (Slot* p : {&q, &s, &z}) {
+            TM_HIP_CHECK(hipFree(p->dev));
+            p->dev = nullptr;
+        }
+    }
+    else {
+        Slot& w = e->slots[l.prefix + ".weight"];
+        TM_REQUIRE(w.filled, "weight not loaded: " + l.prefix);
+        TM_TRY(linear_weight_prepare_f16(l.w, (const half_t*)w.dev, e->stream));
+        TM_HIP_CHECK(hipStreamSynchronize(e->stream));
+        TM_HIP_CHECK(hipFree(w.dev));
+        w.dev = nullptr;
+    }
+    return 0;
+}
+
+static KvCacheView cache_view(const tm_engine* e, int layer)
+{
+    KvCacheView v{};
+    v.block_ptrs    = e->d_block_ptrs;
+    v.cu_block_nums = e->d_cu_block_nums;
+    v.layer_offset  = (int64_t)layer * e->layout.layer_size();
+    v.layout        = e->layout;
+    return v;
+}
+
+static int allreduce_hidden(tm_engine* e, half_t* buf, int M)
+{
+    if (e->cfg.tp > 1) {
+        TM_NCCL_CHECK(ncclAllReduce(buf, buf, (size_t)M * e->hidden, ncclHalf, ncclSum, e->comm, e->stream));
+    }
+    return 0;
+}
+
+// row-parallel linear followed by (all-reduce +) residual + RMSNorm
+static int linear_residual_norm(tm_engine* e, LinearSlots& l, const half_t* x, int ldx, int M, const half_t* norm_w)
+{
+    GemmConfig cfg = gemm_pick_config(l.w, M);
+    const bool can_defer = e->cfg.tp == 1 && cfg.splits > 1
+                           && gemm_workspace_bytes(M, l.w.N, cfg.splits) <= e->gemm_ws_bytes;
+    if (gemm_workspace_bytes(M, l.w.N, cfg.splits) > e->gemm_ws_bytes) {
+        cfg.splits = 1;
+    }
+    int slabs = 1;
+    TM_TRY(launch_linear(l.w, x, ldx, e->d_tmp, e->hidden, M, false, cfg, e->d_gemm_ws, can_defer, &slabs, e->stream));
+    if (can_defer && slabs > 1) {
+        return launch_residual_rmsnorm(e->d_x, e->d_resid, nullptr, e->d_gemm_ws, slabs, nullptr, norm_w,
+                                       e->cfg.model.rms_eps, M, e->hidden, e->stream);
+    }
+    TM_REQUIRE(!can_defer || slabs == 1, "internal: deferred reduce without slabs");
+    TM_TRY(allreduce_hidden(e, e->d_tmp, M));
+    return launch_residual_rmsnorm(e->d_x, e->d_resid, e->d_tmp, nullptr, 0, nullptr, norm_w, e->cfg.model.rms_eps, M,
+                                   e->hidden, e->stream);
+}
+
+static int linear_plain(tm_engine* e, LinearSlots& l, const half_t* x, int ldx, half_t* y, int ldy, int M, bool gated)
+{
+    GemmConfig cfg = gemm_pick_config(l.w, M);
+    if (gemm_workspace_bytes(M, l.w.N, cfg.splits) > e->gemm_ws_bytes) {
+        cfg.splits = 1;
+    }
+    return launch_linear(l.w, x, ldx, y, ldy, M, gated, cfg, e->d_gemm_ws, false, nullptr, e->stream);
+}
+
+// One forward over M tokens.  decode: one token per sequence (cu_q = 0..B); prefill: nseq sequences.
+static int forward(tm_engine* e, const int* d_ids, int M, int nseq, bool decode, int max_q_len, int max_k_len,
+                   int kflat_stride, int slot0)
+{
+    const tm_model_config& m = e->cfg.model;
+    hipStream_t            st = e->stream;
+    TM_TRY(launch_embedding(e->d_resid, e->tok_embeddings, d_ids, M, e->hidden, m.vocab, st));
+    TM_TRY(launch_rmsnorm(e->d_x, e->d_resid, e->layers[0].attn_norm, m.rms_eps, M, e->hidden, st));
+    const float scale_log2 = (1.0f / std::sqrt((float)e->D)) * 1.4426950408889634f;
+    for (int li = 0; li < m.layers; ++li) {
+        Layer& L = e->layers[li];
+        TM_TRY(linear_plain(e, L.qkv, e->d_x, e->hidden, e->d_qkv, e->qkv_n, M, false));
+        KvCacheView cv = cache_view(e, li);
+        TM_TRY(launch_kv_rope_store(e->d_qkv, e->q_heads, e->d_cu_q, e->d_k_len, nseq, M, e->d_rope, e->rope_max_pos, cv, st));
+        if (decode) {
+            DecodeAttnParams p{};
+            p.q          = e->d_qkv;
+            p.q_stride   = e->qkv_n;
+            p.out        = e->d_attn;
+            p.k_len      = e->d_k_len;
+            p.batch      = nseq;
+            p.q_heads    = e->q_heads;
+            p.scale_log2 = scale_log2;
+            p.splits     = e->decode_splits;
+            p.partial_o  = e->d_attn_ws;
+            p.partial_ml = e->d_attn_ws + (size_t)nseq * e->q_heads * e->decode_splits * e->D;
+            p.cache      = cv;
+            TM_TRY(launch_decode_attention(p, st));
+        }
+        else {
+            TM_TRY(launch_flatten_kv(e->d_kflat, e->d_vflat, 1, e->d_cu_koff, e->d_k_len, nseq, max_k_len, kflat_stride, cv, st));
+            PrefillAttnParams p{};
+            p.q          = e->d_qkv;
+            p.q_stride   = e->qkv_n;
+            p.out        = e->d_attn;
+            p.k          = e->d_kflat;
+            p.vt         = e->d_vflat;
+            p.k_stride   = kflat_stride;
+            p.cu_q_len   = e->d_cu_q;
+            p.cu_k_off   = e->d_cu_koff;
+            p.k_len      = e->d_k_len;
+            p.batch      = nseq;
+            p.max_q_len  = max_q_len;
+            p.q_heads    = e->q_heads;
+            p.kv_heads   = e->kv_heads;
+            p.scale_log2 = scale_log2;
+            TM_TRY(launch_prefill_attention(p, st));
+        }
+        TM_TRY(linear_residual_norm(e, L.wo, e->d_attn, e->q_heads * e->D, M, L.ffn_norm));
+        TM_TRY(linear_plain(e, L.w13, e->d_x, e->hidden, e->d_act, e->inter, M, true));
+        const half_t* next_norm = li + 1 < m.layers ? e->layers[li + 1].attn_norm : e->final_norm;
+        TM_TRY(linear_residual_norm(e, L.w2, e->d_act, e->inter, M, next_norm));
+    }
+    // last-token hidden states -> logits -> greedy
+    const half_t* hx = e->d_x;
+    if (!decode) {
+        TM_TRY(launch_gather_rows(e->d_last, e->d_x, e->d_rows, nseq, e->hidden, st));
+        hx = e->d_last;
+    }
+    // logits / next ids land in the batch slots [slot0, slot0 + nseq)
+    half_t* logits = e->d_logits + (size_t)slot0 * e->vocab_local;
+    int*    ids    = e->d_next_ids + slot0;
+    TM_TRY(linear_plain(e, e->output, hx, e->hidden, logits, e->vocab_local, nseq, false));
+    if (e->cfg.tp == 1) {
+        TM_TRY(launch_argmax(ids, nullptr, logits, nseq, e->vocab_local, e->vocab_local, 0, st));
+    }
+    else {
+        TM_TRY(launch_argmax(ids, e->d_argmax_val, logits, nseq, e->vocab_local, e->vocab_local,
+                             e->cfg.rank * e->vocab_local, st));
+        pack_candidates_kernel<<<(nseq + 63) / 64, 64, 0, st>>>(e->d_cand, ids, e->d_argmax_val, nseq);
+        TM_HIP_CHECK(hipGetLastError());
+        TM_NCCL_CHECK(ncclAllGather(e->d_cand, e->d_cand_all, (size_t)nseq * 2, ncclFloat, e->comm, st));
+        pick_kernel<<<(nseq + 63) / 64, 64, 0, st>>>(ids, e->d_cand_all, e->cfg.tp, nseq);
+        TM_HIP_CHECK(hipGetLastError());
+    }
+    return 0;
+}
+
+// next ids become the current ids and are appended to generated[b][step]
+static int commit_tokens(tm_engine* e)
+{
+    TM_HIP_CHECK(hipMemcpyAsync(e->d_ids, e->d_next_ids, (size_t)e->batch * 4, hipMemcpyDeviceToDevice, e->stream));
+    record_kernel<<<1, std::max(64, ((e->batch + 63) / 64) * 64), 0, e->stream>>>(e->d_ids, e->d_generated, e->d_step,
+                                                                                  e->batch, e->max_new);
+    TM_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+static int decode_step(tm_engine* e)
+{
+    advance_kernel<<<(e->batch + 63) / 64, 64, 0, e->stream>>>(e->d_k_len, e->batch);
+    TM_HIP_CHECK(hipGetLastError());
+    TM_TRY(forward(e, e->d_ids, e->batch, e->batch, true, 1, 0, 0, 0));
+    return commit_tokens(e);
+}
+
+template<class T>
+static int dmalloc(T** p, size_t n)
+{
+    TM_HIP_CHECK(hipMalloc((void**)p, n * sizeof(T)));
+    return 0;
+}
+
+}  // namespace tmk
+
+extern "C" {
+
+int tm_engine_create(tm_engine** out, const tm_engine_config* c)
+{
+    TM_REQUIRE(out && c, "null pointer");
+    const tm_model_config& m = c->model;
+    TM_REQUIRE(m.head_dim == 128, "head_dim must be 128");
+    TM_REQUIRE(m.group_size == 128, "AWQ group size must be 128");
+    TM_REQUIRE(c->tp >= 1 && c->rank >= 0 && c->rank < c->tp, "0 <= rank < tp");
+    TM_REQUIRE(m.q_heads % c->tp == 0 && m.inter % c->tp == 0 && m.vocab % c->tp == 0, "heads/inter/vocab % tp");
+    TM_REQUIRE(m.kv_heads % c->tp == 0 || c->tp % m.kv_heads == 0, "kv_heads vs tp");
+    TM_REQUIRE(c->quant_policy == 0 || c->quant_policy == 4 || c->quant_policy == 8,
+               "quant_policy in {0,4,8} (lmdeploy/messages.py:351-358)");
+    TM_REQUIRE(c->cache_block_seq_len == 64, "cache_block_seq_len must be 64");
+    TM_REQUIRE(m.weight_type == TM_WEIGHT_U4 || m.weight_type == TM_WEIGHT_F16, "weight_type");
+    TM_REQUIRE(c->max_batch_size >= 1 && c->max_batch_size <= 1024 && c->session_len >= 1,
+               "1 <= max_batch_size <= 1024, session_len >= 1");
+    TM_HIP_CHECK(hipSetDevice(c->device));
+
+    auto* e        = new tm_engine();
+    e->cfg         = *c;
+    e->hidden      = m.hidden;
+    e->q_heads     = m.q_heads / c->tp;
+    e->kv_heads    = std::max(1, m.kv_heads / c->tp);
+    e->inter       = m.inter / c->tp;
+    e->vocab_local = m.vocab / c->tp;
+    e->qkv_n       = (e->q_heads + 2 * e->kv_heads) * e->D;
+    TM_REQUIRE((e->inter * 1) % 128 == 0 && (e->q_heads * e->D) % 128 == 0 && m.hidden % 128 == 0,
+               "K dims must be multiples of 128 after TP sharding");
+    TM_HIP_CHECK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+
+    e->layers.resize(m.layers);
+    for (int i = 0; i < m.layers; ++i) {
+        const std::string p = "layers." + std::to_string(i);
+        Layer&            L = e->layers[i];
+        add_linear(e, L.qkv, p + ".attention.w_qkv", m.hidden, e->qkv_n, m.weight_type);
+        add_linear(e, L.wo, p + ".attention.wo", e->q_heads * e->D, m.hidden, m.weight_type);
+        add_linear(e, L.w13, p + ".feed_forward.w1w3", m.hidden, 2 * e->inter, m.weight_type);
+        add_linear(e, L.w2, p + ".feed_forward.w2", e->inter, m.hidden, m.weight_type);
+        e->slots[p + ".attention_norm.weight"].bytes = (int64_t)m.hidden * 2;
+        e->slots[p + ".ffn_norm.weight"].bytes       = (int64_t)m.hidden * 2;
+    }
+    e->slots["tok_embeddings.weight"].bytes = (int64_t)m.vocab * m.hidden * 2;  // replicated
+    e->slots["norm.weight"].bytes           = (int64_t)m.hidden * 2;
+    add_linear(e, e->output, "output", m.hidden, e->vocab_local, TM_WEIGHT_F16);
+    *out = e;
+    return 0;
+}
+
+int tm_comm_unique_id(void* host_out128)
+{
+    TM_REQUIRE(host_out128, "null pointer");
+    static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId size");
+    ncclUniqueId id;
+    TM_NCCL_CHECK(ncclGetUniqueId(&id));
+    memcpy(host_out128, &id, sizeof(id));
+    return 0;
+}
+
+int tm_engine_comm_init(tm_engine* e, const void* host_id128)
+{
+    TM_REQUIRE(e && host_id128, "null pointer");
+    if (e->cfg.tp == 1) {
+        return 0;
+    }
+    ncclUniqueId id;
+    memcpy(&id, host_id128, sizeof(id));
+    TM_HIP_CHECK(hipSetDevice(e->cfg.device));
+    TM_NCCL_CHECK(ncclCommInitRank(&e->comm, e->cfg.tp, id, e->cfg.rank));
+    return 0;
+}
+
+int64_t tm_engine_weight_bytes(tm_engine* e, const char* name)
+{
+    if (!e || !name) {
+        return 0;
+    }
+    auto it = e->slots.find(name);
+    if (it == e->slots.end()) {
+        set_last_error(std::string("unknown weight slot: ") + name);
+        return 0;
+    }
+    return it->second.bytes;
+}
+
+int tm_engine_weight_copy(tm_engine* e, const char* name, const void* host_src, int64_t bytes)
+{
+    TM_REQUIRE(e && name && host_src, "null pointer");
+    TM_REQUIRE(!e->weights_ready, "weights already processed");
+    Slot* s = nullptr;
+    TM_TRY(ensure_slot(e, name, &s));
+    TM_REQUIRE(bytes == s->bytes, std::string("byte size mismatch for ") + name + ": got " + std::to_string(bytes)
+                                      + " expected " + std::to_string(s->bytes));
+    TM_HIP_CHECK(hipMemcpy(s->dev, host_src, bytes, hipMemcpyHostToDevice));
+    s->filled = true;
+    return 0;
+}
+
+int tm_engine_init_synthetic(tm_engine* e, uint64_t seed)
+{
+    TM_REQUIRE(e, "null pointer");
+    TM_REQUIRE(!e->weights_ready, "weights already processed");
+    const tm_model_config& m = e->cfg.model;
+    uint64_t               sd = seed * 1000003ull + 17;
+    half_t*                master = nullptr;  // fp16 master of the largest linear, reused
+    size_t                 master_elems = 0;
+    auto                   linear = [&](LinearSlots& l) -> int {
+        const size_t n = (size_t)l.w.K * l.w.N;
+        if (l.w.type == TM_WEIGHT_F16) {
+            Slot* w = nullptr;
+            TM_TRY(ensure_slot(e, l.prefix + ".weight", &w));
+            TM_TRY(fill_normal(e, w->dev, n, 0.f, 0.1f / std::sqrt((float)l.w.K), ++sd));
+            w->filled = true;
+            return 0;
+        }
+        if (n > master_elems) {
+            if (master) {
+                TM_HIP_CHECK(hipStreamSynchronize(e->stream));
+                TM_HIP_CHECK(hipFree(master));
+            }
+            TM_HIP_CHECK(hipMalloc((void**)&master, n * 2));
+            master_elems = n;
+        }
+        TM_TRY(fill_normal(e, master, n, 0.f, 0.1f / std::sqrt((float)l.w.K), ++sd));
+        Slot *q = nullptr, *s = nullptr, *z = nullptr;
+        TM_TRY(ensure_slot(e, l.prefix + ".qweight", &q));
+        TM_TRY(ensure_slot(e, l.prefix + ".scales", &s));
+        TM_TRY(ensure_slot(e, l.prefix + ".zeros", &z));
+        TM_TRY(launch_quantize_groupwise_u4((int32_t*)q->dev, (half_t*)s->dev, (half_t*)z->dev, nullptr, master, l.w.K,
+                                            l.w.N, l.w.group, e->stream));
+        q->filled = s->filled = z->filled = true;
+        // repack right away so that staging never holds more than one linear
+        TM_TRY(prepare_linear(e, l));
+        return 0;
+    };
+    auto vec = [&](const std::string& name, size_t n, float mean, float stddev) -> int {
+        Slot* s = nullptr;
+        TM_TRY(ensure_slot(e, name, &s));
+        TM_TRY(fill_normal(e, s->dev, n, mean, stddev, ++sd));
+        s->filled = true;
+        return 0;
+    };
+    for (int i = 0; i < m.layers; ++i) {
+        const std::string p = "layers." + std::to_string(i);
+        Layer&            L = e->layers[i];
+        TM_TRY(linear(L.qkv));
+        TM_TRY(linear(L.wo));
+        TM_TRY(linear(L.w13));
+        TM_TRY(linear(L.w2));
+        TM_TRY(vec(p + ".attention_norm.weight", m.hidden, 1.f, 0.02f));
+        TM_TRY(vec(p + ".ffn_norm.weight", m.hidden, 1.f, 0.02f));
+    }
+    TM_TRY(vec("tok_embeddings.weight", (size_t)m.vocab * m.hidden, 0.f, 0.02f));
+    TM_TRY(vec("norm.weight", m.hidden, 1.f, 0.02f));
+    TM_TRY(linear(e->output));
+    TM_HIP_CHECK(hipStreamSynchronize(e->stream));
+    if (master) {
+        TM_HIP_CHECK(hipFree(master));
+    }
+    return 0;
+}
+
+int tm_engine_process_weights(tm_engine* e)
+{
+    TM_REQUIRE(e, "null pointer");
+    if (e->weights_ready) {
+        return 0;
+    }
+    TM_HIP_CHECK(hipSetDevice(e->cfg.device));
+    const tm_model_config& m = e->cfg.model;
+    auto norm = [&](const std::string& name, half_t** dst) -> int {
+        Slot& s = e->slots[name];
+        TM_REQUIRE(s.filled, "weight not loaded: " + name);
+        *dst = (half_t*)s.dev;  // used in place
+        return 0;
+    };
+    for (int i = 0; i < m.layers; ++i) {
+        const std::string p = "layers." + std::to_string(i);
+        Layer&            L = e->layers[i];
+        for (LinearSlots* l : {&L.qkv, &L.wo, &L.w13, &L.w2}) {
+            if (!l->w.packed) {
+                TM_TRY(prepare_linear(e, *l));
+            }
+        }
+        TM_TRY(norm(p + ".attention_norm.weight", &L.attn_norm));
+        TM_TRY(norm(p + ".ffn_norm.weight", &L.ffn_norm));
+    }
+    TM_TRY(norm("tok_embeddings.weight", &e->tok_embeddings));
+    TM_TRY(norm("norm.weight", &e->final_norm));
+    if (!e->output.w.packed) {
+        TM_TRY(prepare_linear(e, e->output));
+    }
+    e->weights_ready = true;
+    return 0;
+}
+
+int tm_engine_start(tm_engine* e)
+{
+    TM_REQUIRE(e, "null pointer");
+    TM_REQUIRE(e->weights_ready, "process_weights first");
+    if (e->started) {
+        return 0;
+    }
+    TM_HIP_CHECK(hipSetDevice(e->cfg.device));
+    const tm_engine_config& c = e->cfg;
+    const tm_model_config&  m = c.model;
+    const int bits = c.quant_policy == 0 ? 16 : c.quant_policy;
+    e->layout      = KvLayout{e->kv_heads, e->D, c.cache_block_seq_len, bits};
+    e->block_bytes = (int64_t)m.layers * e->layout.layer_size();
+    e->max_blocks_per_seq = (c.session_len + 63) / 64;
+
+    const int B   = c.max_batch_size;
+    e->max_tokens = std::max(B, std::max(64, c.max_prefill_token_num));
+    const size_t T = e->max_tokens;
+    TM_TRY(dmalloc(&e->d_resid, T * e->hidden));
+    TM_TRY(dmalloc(&e->d_x, T * e->hidden));
+    TM_TRY(dmalloc(&e->d_tmp, T * e->hidden));
+    TM_TRY(dmalloc(&e->d_qkv, T * e->qkv_n));
+    TM_TRY(dmalloc(&e->d_attn, T * e->q_heads * e->D));
+    TM_TRY(dmalloc(&e->d_act, T * e->inter));
+    TM_TRY(dmalloc(&e->d_logits, (size_t)B * e->vocab_local));
+    TM_TRY(dmalloc(&e->d_last, (size_t)B * e->hidden));
+    // split-K workspace: decode-sized problems only (M <= 64 rows x widest N x 16 slabs)
+    e->gemm_ws_bytes = (size_t)16 * 64 * std::max(std::max(e->qkv_n, 2 * e->inter), e->hidden) * sizeof(float);
+    TM_HIP_CHECK(hipMalloc((void**)&e->d_gemm_ws, e->gemm_ws_bytes));
+    // prefill scratch: every sequence padded to a multiple of 64 keys
+    e->kflat_stride = ((e->max_tokens + c.session_len + 63) / 64) * 64 + 64 * (std::min(B, e->max_tokens) + 1);
+    TM_TRY(dmalloc(&e->d_kflat, (size_t)e->kv_heads * e->kflat_stride * e->D));
+    TM_TRY(dmalloc(&e->d_vflat, (size_t)e->kv_heads * e->kflat_stride * e->D));
+
+    // RoPE table
+    e->rope_max_pos = c.session_len + 1;
+    {
+        std::vector<half_t> tab((size_t)e->rope_max_pos * e->D);
+        TM_TRY(build_rope_table(tab.data(), e->rope_max_pos, e->D, m.rope_base, m.rope_type, m.rope_factor,
+                                m.rope_low_freq_factor, m.rope_high_freq_factor, m.rope_original_max_position));
+        TM_TRY(dmalloc(&e->d_rope, tab.size() / 2));
+        TM_HIP_CHECK(hipMemcpy(e->d_rope, tab.data(), tab.size() * 2, hipMemcpyHostToDevice));
+    }
+
+    TM_TRY(dmalloc(&e->d_ids, (size_t)B));
+    TM_TRY(dmalloc(&e->d_next_ids, (size_t)B));
+    TM_TRY(dmalloc(&e->d_k_len, (size_t)B));
+    TM_TRY(dmalloc(&e->d_cu_q, (size_t)B + 1));
+    TM_TRY(dmalloc(&e->d_cu_koff, (size_t)B + 1));
+    TM_TRY(dmalloc(&e->d_rows, (size_t)B));
+    TM_TRY(dmalloc(&e->d_generated, (size_t)B * c.session_len));
+    TM_TRY(dmalloc(&e->d_step, (size_t)1));
+    TM_TRY(dmalloc(&e->d_prefill_ids, T));
+    TM_TRY(dmalloc(&e->d_argmax_val, (size_t)B));
+    TM_TRY(dmalloc(&e->d_cand, (size_t)B * 2));
+    TM_TRY(dmalloc(&e->d_cand_all, (size_t)B * 2 * c.tp));
+    TM_TRY(dmalloc(&e->d_block_ptrs, (size_t)B * e->max_blocks_per_seq));
+    TM_TRY(dmalloc(&e->d_cu_block_nums, (size_t)B + 1));
+    {
+        std::vector<int> cu(B + 1);
+        for (int b = 0; b <= B; ++b) {
+            cu[b] = b * e->max_blocks_per_seq;
+        }
+        TM_HIP_CHECK(hipMemcpy(e->d_cu_block_nums, cu.data(), cu.size() * 4, hipMemcpyHostToDevice));
+    }
+    const int max_splits = 16;
+    TM_HIP_CHECK(hipMalloc((void**)&e->d_attn_ws, decode_attention_workspace_bytes(B, e->q_heads, e->D, max_splits)));
+
+    // KV pool
+    int64_t blocks = c.cache_blocks;
+    if (blocks <= 0) {
+        size_t free_b = 0, total_b = 0;
+        TM_HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
+        const float frac = c.cache_max_entry_count > 0.f ? c.cache_max_entry_count : 0.8f;
+        blocks           = (int64_t)((double)free_b * frac / (double)e->block_bytes);
+        const int64_t need = (int64_t)B * e->max_blocks_per_seq;
+        blocks           = std::min(blocks, need);
+    }
+    TM_REQUIRE(blocks >= 1, "no memory for KV blocks");
+    if (hipMalloc((void**)&e->pool, (size_t)blocks * e->block_bytes) != hipSuccess) {
+        (void)hipGetLastError();
+        set_last_error("KV pool allocation failed");
+        return TM_OOM;
+    }
+    TM_HIP_CHECK(hipMemsetAsync(e->pool, 0, (size_t)blocks * e->block_bytes, e->stream));
+    e->num_blocks = blocks;
+    e->free_blocks.resize(blocks);
+    for (int64_t i = 0; i < blocks; ++i) {
+        e->free_blocks[i] = (int)(blocks - 1 - i);
+    }
+    TM_HIP_CHECK(hipStreamSynchronize(e->stream));
+    e->started = true;
+    return 0;
+}
+
+int tm_engine_release(tm_engine* e)
+{
+    TM_REQUIRE(e, "null pointer");
+    if (e->stream) {
+        TM_HIP_CHECK(hipStreamSynchronize(e->stream));
+    }
+    for (auto& blks : e->h_blocks) {
+        for (int b : blks) {
+            e->free_blocks.push_back(b);
+        }
+    }
+    e->h_blocks.clear();
+    e->h_len.clear();
+    e->batch      = 0;
+    e->steps_done = 0;
+    return 0;
+}
+
+int tm_engine_prefill(tm_engine* e, const int* host_ids, const int* host_lens, int batch, int max_new_tokens)
+{
+    TM_REQUIRE(e && host_ids && host_lens, "null pointer");
+    TM_REQUIRE(e->started, "engine not started");
+    TM_REQUIRE(e->batch == 0, "a batch is already admitted (release it first)");
+    TM_REQUIRE(batch >= 1 && batch <= e->cfg.max_batch_size, "1 <= batch <= max_batch_size");
+    TM_REQUIRE(max_new_tokens >= 1, "max_new_tokens >= 1");
+    TM_HIP_CHECK(hipSetDevice(e->cfg.device));
+    const tm_engine_config& c = e->cfg;
+
+    // ---- admit: reserve blocks for prompt + generation ------------------------------------------
+    int64_t need = 0;
+    for (int b = 0; b < batch; ++b) {
+        TM_REQUIRE(host_lens[b] >= 1, "empty prompt");
+        if (host_lens[b] + max_new_tokens > c.session_len) {
+            set_last_error("prompt + max_new_tokens exceeds session_len");
+            return TM_TOO_LONG;
+        }
+        need += (host_lens[b] + max_new_tokens + 63) / 64;
+    }
+    if (need > (int64_t)e->free_blocks.size()) {
+        set_last_error("out of KV cache blocks");
+        return TM_OOM;
+    }
+    std::vector<uint64_t> ptrs((size_t)batch * e->max_blocks_per_seq, 0);
+    e->h_blocks.assign(batch, {});
+    for (int b = 0; b < batch; ++b) {
+        const int nb = (host_lens[b] + max_new_tokens + 63) / 64;
+        for (int i = 0; i < nb; ++i) {
+            const int blk = e->free_blocks.back();
+            e->free_blocks.pop_back();
+            e->h_blocks[b].push_back(blk);
+            ptrs[(size_t)b * e->max_blocks_per_seq + i] = (uint64_t)(e->pool + (int64_t)blk * e->block_bytes);
+        }
+    }
+    TM_HIP_CHECK(hipMemcpyAsync(e->d_block_ptrs, ptrs.data(), ptrs.size() * 8, hipMemcpyHostToDevice, e->stream));
+    TM_HIP_CHECK(hipMemsetAsync(e->d_step, 0, 4, e->stream));
+    TM_HIP_CHECK(hipStreamSynchronize(e->stream));
+    e->batch   = batch;
+    e->max_new = max_new_tokens;
+    e->h_len.assign(host_lens, host_lens + batch);
+    e->steps_done = 0;
+
+    // ---- chunked prefill: whole sequences, <= max_prefill_token_num tokens per iteration ------------
+    // (a sequence longer than the budget is split into history + new tokens)
+    std::vector<int> offs(batch + 1, 0);
+    for (int b = 0; b < batch; ++b) {
+        offs[b + 1] = offs[b] + host_lens[b];
+    }
+    const int budget = e->max_tokens;
+    // Because the batch tables (block_ptrs, cu_block_nums) are indexed by the batch slot, every prefill
+    // iteration covers a contiguous range of slots [b0, b1]; the block table is offset accordingly and the
+    // logits / first tokens of the iteration land in d_logits / d_next_ids at slot b0 + i.
+    int b0 = 0;
+    int done_in_b0 = 0;  // tokens of sequence b0 already prefilled (chunked long prompt)
+    while (b0 < batch) {
+        std::vector<int> cu_q{0}, klen, koff{0}, rows, ids;
+        int b1 = b0, tokens = 0, max_q = 0, max_k = 0;
+        bool partial_last = false;
+        while (b1 < batch) {
+            const int start  = (b1 == b0) ? done_in_b0 : 0;
+            const int remain = host_lens[b1] - start;
+            const int take   = std::min(remain, budget - tokens);
+            if (take <= 0) {
+                break;
+            }
+            ids.insert(ids.end(), host_ids + offs[b1] + start, host_ids + offs[b1] + start + take);
+            tokens += take;
+            cu_q.push_back(tokens);
+            klen.push_back(start + take);
+            koff.push_back(koff.back() + ((start + take + 63) / 64) * 64);
+            rows.push_back(tokens - 1);
+            max_q = std::max(max_q, take);
+            max_k = std::max(max_k, start + take);
+            if (take < remain) {  // budget exhausted inside this sequence: it continues in the next iteration
+                done_in_b0   = start + take;
+                partial_last = true;
+                break;
+            }
+            ++b1;
+        }
+        const int nseq = (int)klen.size();
+        TM_REQUIRE(nseq >= 1, "internal: empty prefill iteration");
+        TM_REQUIRE(koff.back() <= e->kflat_stride, "internal: flatten scratch too small");
+        TM_HIP_CHECK(hipMemcpyAsync(e->d_prefill_ids, ids.data(), ids.size() * 4, hipMemcpyHostToDevice, e->stream));
+        TM_HIP_CHECK(hipMemcpyAsync(e->d_cu_q, cu_q.data(), cu_q.size() * 4, hipMemcpyHostToDevice, e->stream));
+        TM_HIP_CHECK(hipMemcpyAsync(e->d_k_len, klen.data(), klen.size() * 4, hipMemcpyHostToDevice, e->stream));
+        TM_HIP_CHECK(hipMemcpyAsync(e->d_cu_koff, koff.data(), koff.size() * 4, hipMemcpyHostToDevice, e->stream));
+        TM_HIP_CHECK(hipMemcpyAsync(e->d_rows, rows.data(), rows.size() * 4, hipMemcpyHostToDevice, e->stream));
+        // shift the block tables so that slot 0 of this iteration is sequence b0
+        uint64_t* saved_ptrs = e->d_block_ptrs;
+        e->d_block_ptrs += (size_t)b0 * e->max_blocks_per_seq;
+        const int rc    = forward(e, e->d_prefill_ids, tokens, nseq, false, max_q, max_k, e->kflat_stride, b0);
+        e->d_block_ptrs = saved_ptrs;
+        if (rc) {
+            return rc;
+        }
+        // the host vectors above are pageable: make sure the async copies are done before they die
+        TM_HIP_CHECK(hipStreamSynchronize(e->stream));
+        b0 = b1;  // a partially prefilled sequence (b1) is revisited with done_in_b0 tokens of history
+        if (!partial_last) {
+            done_in_b0 = 0;
+        }
+    }
+
+    // ---- steady-state decode layout: one token per sequence ------------------------------------------
+    std::vector<int> cu_q(batch + 1);
+    for (int b = 0; b <= batch; ++b) {
+        cu_q[b] = b;
+    }
+    TM_HIP_CHECK(hipMemcpyAsync(e->d_cu_q, cu_q.data(), cu_q.size() * 4, hipMemcpyHostToDevice, e->stream));
+    TM_HIP_CHECK(hipMemcpyAsync(e->d_k_len, host_lens, batch * 4, hipMemcpyHostToDevice, e->stream));
+    // generated[b][0] = first token; step counter = 1
+    TM_HIP_CHECK(hipMemsetAsync(e->d_step, 0, 4, e->stream));
+    TM_TRY(commit_tokens(e));
+    TM_HIP_CHECK(hipStreamSynchronize(e->stream));
+    e->steps_done = 1;
+
+    // decode split heuristic: fill >= 2 workgroups per CU (GetSplitCount, kernels/attention/utils.cc:11-46)
+    int splits = c.decode_splits;
+    if (splits <= 0) {
+        int group = e->q_heads / e->kv_heads, hpw = 1;
+        for (int cand = 4; cand >= 1; --cand) {
+            if (group % cand == 0) {
+                hpw = cand;
+                break;
+            }
+        }
+        const int wgs = e->kv_heads * (group / hpw) * batch;
+        splits        = 1;
+        while (wgs * splits < 512 && splits < 16) {
+            splits *= 2;
+        }
+    }
+    e->decode_splits = std::min(std::max(splits, 1), 16);
+    if (e->graph && (e->graph_batch != batch)) {
+        (void)hipGraphExecDestroy(e->graph);
+        e->graph = nullptr;
+    }
+    return 0;
+}
+
+int tm_engine_decode(tm_engine* e, int steps)
+{
+    TM_REQUIRE(e && e->batch > 0, "no admitted batch");
+    TM_HIP_CHECK(hipSetDevice(e->cfg.device));
+    if (e->steps_done + steps > e->max_new) {
+        set_last_error("decode past max_new_tokens");
+        return TM_TOO_LONG;
+    }
+    const bool use_graph = e->cfg.use_graph && e->cfg.tp == 1;
+    if (use_graph && !e->graph) {
+        // run one eager step first (lazy module loading etc. must not happen inside a capture)
+        if (steps == 0) {
+            return 0;
+        }
+        TM_TRY(decode_step(e));
+        TM_HIP_CHECK(hipStreamSynchronize(e->stream));
+        e->steps_done += 1;
+        steps -= 1;
+        hipGraph_t g = nullptr;
+        TM_HIP_CHECK(hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal));
+        int rc = decode_step(e);
+        hipError_t ce = hipStreamEndCapture(e->stream, &g);
+        if (rc) {
+            return rc;
+        }
+        TM_HIP_CHECK(ce);
+        TM_HIP_CHECK(hipGraphInstantiate(&e->graph, g, nullptr, nullptr, 0));
+        TM_HIP_CHECK(hipGraphDestroy(g));
+        e->graph_batch = e->batch;
+    }
+    for (int i = 0; i < steps; ++i) {
+        if (use_graph) {
+            TM_HIP_CHECK(hipGraphLaunch(e->graph, e->stream));
+        }
+        else {
+            TM_TRY(decode_step(e));
+        }
+    }
+    e->steps_done += steps;
+    return 0;
+}
+
+int tm_engine_sync(tm_engine* e)
+{
+    TM_REQUIRE(e, "null pointer");
+    TM_HIP_CHECK(hipStreamSynchronize(e->stream));
+    return 0;
+}
+
+int tm_engine_fetch(tm_engine* e, int* host_out, int* n_generated)
+{
+    TM_REQUIRE(e && host_out && n_generated, "null pointer");
+    TM_HIP_CHECK(hipStreamSynchronize(e->stream));
+    TM_HIP_CHECK(hipMemcpy(host_out, e->d_generated, (size_t)e->batch * e->max_new * 4, hipMemcpyDeviceToHost));
+    *n_generated = e->steps_done;
+    return 0;
+}
+
+int tm_engine_fetch_logits(tm_engine* e, void* host_out)
+{
+    TM_REQUIRE(e && host_out, "null pointer");
+    TM_HIP_CHECK(hipStreamSynchronize(e->stream));
+    TM_HIP_CHECK(hipMemcpy(host_out, e->d_logits, (size_t)e->batch * e->vocab_local * 2, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+tm_stream_t tm_engine_stream(tm_engine* e)
+{
+    return e ? (tm_stream_t)e->stream : nullptr;
+}
+
+int tm_engine_stats(tm_engine* e, int64_t* weight_bytes, int64_t* kv_bytes_per_token, int64_t* num_blocks,
+                    int* decode_splits)
+{
+    TM_REQUIRE(e, "null pointer");
+    int64_t wb = 0;
+    for (auto& L : e->layers) {
+        for (const LinearSlots* l : {&L.qkv, &L.wo, &L.w13, &L.w2}) {
+            wb += (int64_t)l->w.packed_bytes + (int64_t)l->w.sz_bytes;
+        }
+    }
+    wb += (int64_t)e->output.w.packed_bytes;
+    if (weight_bytes) *weight_bytes = wb;
+    if (kv_bytes_per_token) *kv_bytes_per_token = e->started ? e->block_bytes / 64 : 0;
+    if (num_blocks) *num_blocks = e->num_blocks;
+    if (decode_splits) *decode_splits = e->decode_splits;
+    return 0;
+}
+
+int tm_engine_destroy(tm_engine* e)
+{
+    if (!e) {
+        return 0;
+    }
+    (void)hipSetDevice(e->cfg.device);
+    if (e->stream) {
+        (void)hipStreamSynchronize(e->stream);
+    }
+    if (e->graph) {
+        (void)hipGraphExecDestroy(e->graph);
+    }
+    for (auto& L : e->layers) {
+        for (LinearSlots* l : {&L.qkv, &L.wo, &L.w13, &L.w2}) {
+            linear_weight_free(l->w);
+        }
+    }
+    linear_weight_free(e->output.w);
+    for (auto& kv : e->slots) {
+        if (kv.second.dev) {
+            (void)hipFree(kv.second.dev);
+        }
+    }
+    void* bufs[] = {e->pool, e->d_block_ptrs, e->d_cu_block_nums, e->d_resid, e->d_x, e->d_qkv, e->d_attn, e->d_act,
+                    e->d_tmp, e->d_logits, e->d_last, e->d_gemm_ws, e->d_attn_ws, e->d_kflat, e->d_vflat, e->d_rope,
+                    e->d_ids, e->d_k_len, e->d_cu_q, e->d_cu_koff, e->d_rows, e->d_generated, e->d_step,
+                    e->d_prefill_ids, e->d_argmax_val, e->d_cand, e->d_cand_all, e->d_next_ids};
+    for (void* p : bufs) {
+        if (p) {
+            (void)hipFree(p);
+        }
+    }
+    if (e->comm) {
+        (void)ncclCommDestroy(e->comm);
+    }
+    if (e->stream) {
+        (void)hipStreamDestroy(e->stream);
+    }
+    delete e;
+    return 0;
+}
+
+}  // extern "C"

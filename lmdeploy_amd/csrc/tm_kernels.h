@@ -1,0 +1,121 @@
+// Internal launcher declarations (host side of every HIP kernel in this library).
+#pragma once
+#include "tm_common.h"
+
+namespace tmk {
+
+// ---- paged KV cache geometry (reference: kernels/attention/block.h:126-219) ----------------
+struct KvLayout {
+    int kv_heads;
+    int head_dim;   // 128
+    int block_len;  // 64
+    int bits;       // 16 | 8 | 4
+    __host__ __device__ int token_data_size() const { return bits * head_dim / 8; }
+    __host__ __device__ int token_param_size() const { return bits < 16 ? 4 : 0; }
+    __host__ __device__ int head_data_size() const { return block_len * token_data_size(); }
+    __host__ __device__ int head_param_size() const { return block_len * token_param_size(); }
+    __host__ __device__ int layer_size() const
+    {
+        return kv_heads * 2 * head_data_size() + kv_heads * 2 * head_param_size();
+    }
+    __host__ __device__ int k_data(int head, int ti) const { return head * 2 * head_data_size() + ti * token_data_size(); }
+    __host__ __device__ int v_data(int head, int ti) const { return k_data(head, ti) + head_data_size(); }
+    __host__ __device__ int k_param(int head, int ti) const
+    {
+        return kv_heads * 2 * head_data_size() + head * 2 * head_param_size() + ti * token_param_size();
+    }
+    __host__ __device__ int v_param(int head, int ti) const { return k_param(head, ti) + head_param_size(); }
+};
+
+struct KvCacheView {
+    const uint64_t* block_ptrs;     // device array of block base addresses (char**)
+    const int*      cu_block_nums;  // [B+1] prefix offsets into block_ptrs
+    int64_t         layer_offset;   // bytes: layer * layout.layer_size()
+    KvLayout        layout;
+};
+
+// ---- norm.hip ---------------------------------------------------------------------------
+int launch_rmsnorm(half_t* y, const half_t* x, const half_t* w, float eps, int M, int H, hipStream_t st);
+int launch_residual_rmsnorm(half_t* y, half_t* resid, const half_t* hidden, const float* partial, int splits,
+                            const half_t* bias, const half_t* w, float eps, int M, int H, hipStream_t st);
+
+// ---- kv_cache.hip -----------------------------------------------------------------------
+// RoPE(q,k) in fp16 from a (cos,sin) table, quantise K/V of the new tokens and scatter them into the
+// paged cache.  q is rotated in place inside the qkv buffer.
+int launch_kv_rope_store(half_t* qkv, int q_heads, const int* cu_q_len, const int* k_len, int batch, int total_tokens,
+                         const half2_t* cos_sin, int max_pos, KvCacheView cache, hipStream_t st);
+// Gather + dequantise (two-rounding "flatten" form) the whole context of every sequence into linear
+// scratch: K [kv_heads][k_stride][D]; V either [kv_heads][k_stride][D] or transposed [kv_heads][D][k_stride].
+int launch_flatten_kv(half_t* k_out, half_t* v_out, int transpose_v, const int* cu_k_off, const int* k_len, int batch,
+                      int max_k_len, int k_stride, KvCacheView cache, hipStream_t st);
+
+// ---- attention_decode.hip ---------------------------------------------------------------
+struct DecodeAttnParams {
+    const half_t* q;         // [B][q_stride] roped queries (head h at h*D)
+    int           q_stride;  // elements between consecutive tokens
+    half_t*       out;       // [B][q_heads*D]
+    const int*    k_len;     // [B] context length including the new token
+    int           batch;
+    int           q_heads;
+    float         scale_log2;  // softmax_scale * log2(e)
+    int           splits;
+    float*        partial_o;   // [B][q_heads][splits][D]
+    float*        partial_ml;  // [B][q_heads][splits][2]
+    KvCacheView   cache;
+};
+int launch_decode_attention(const DecodeAttnParams& p, hipStream_t st);
+size_t decode_attention_workspace_bytes(int batch, int q_heads, int head_dim, int splits);
+
+// ---- attention_prefill.hip --------------------------------------------------------------
+struct PrefillAttnParams {
+    const half_t* q;         // [T][q_stride] roped
+    int           q_stride;
+    half_t*       out;       // [T][q_heads*D]
+    const half_t* k;         // [kv_heads][k_stride][D]
+    const half_t* vt;        // [kv_heads][D][k_stride]
+    int           k_stride;
+    const int*    cu_q_len;  // [B+1]
+    const int*    cu_k_off;  // [B+1] start of every sequence in k / vt (multiple of 64)
+    const int*    k_len;     // [B]
+    int           batch;
+    int           max_q_len;
+    int           q_heads;
+    int           kv_heads;
+    float         scale_log2;
+};
+int launch_prefill_attention(const PrefillAttnParams& p, hipStream_t st);
+
+// ---- gemm_w4a16.hip ---------------------------------------------------------------------
+struct LinearWeight {
+    int       K = 0, N = 0, group = 128;
+    int       type = 0;          // 0 = u4 (AWQ), 1 = f16 dense
+    void*     packed = nullptr;  // fragment-ordered weights
+    uint32_t* sz     = nullptr;  // fragment-ordered (s, -z*s) half2 pairs (u4 only)
+    size_t    packed_bytes = 0, sz_bytes = 0;
+};
+struct GemmConfig {
+    int nt;      // n-tiles (16 cols) per wave: 1,2,4
+    int splits;  // split-K
+};
+// Load-time repack (reference: LinearWeight::prepare, models/linear_weight.cc:101-324)
+int    linear_weight_prepare_u4(LinearWeight& w, const int32_t* qweight /*[K][N/8]*/, const half_t* scales,
+                                const half_t* zeros, hipStream_t st);
+int    linear_weight_prepare_f16(LinearWeight& w, const half_t* weight /*[K][N]*/, hipStream_t st);
+void   linear_weight_free(LinearWeight& w);
+size_t gemm_workspace_bytes(int M, int N, int splits);
+GemmConfig gemm_pick_config(const LinearWeight& w, int M);
+// y[M][N (or N/2 if gated)] = x[M][K] . W ; if cfg.splits > 1 fp32 slabs land in `workspace` and, unless
+// `defer_reduce`, a reduce kernel writes y.
+int launch_linear(const LinearWeight& w, const half_t* x, int ldx, half_t* y, int ldy, int M, bool gated_silu,
+                  GemmConfig cfg, float* workspace, bool defer_reduce, int* slabs, hipStream_t st);
+
+// ---- misc.hip ---------------------------------------------------------------------------
+int launch_embedding(half_t* out, const half_t* table, const int* ids, int T, int H, int vocab, hipStream_t st);
+int launch_argmax(int* out_ids, half_t* out_val, const half_t* logits, int B, int V, int ld, int id_offset,
+                  hipStream_t st);
+int launch_gather_rows(half_t* out, const half_t* in, const int* rows, int n, int H, hipStream_t st);
+int launch_silu_mul(half_t* out, const half_t* gate_up, int M, int inter, hipStream_t st);
+int launch_quantize_groupwise_u4(int32_t* qweight, half_t* scales, half_t* zeros, half_t* dequant, const half_t* w,
+                                 int K, int N, int group, hipStream_t st);
+
+}  // namespace tmk

@@ -1,0 +1,124 @@
+"""Python adapter over the native engine (C-ABI `tm_engine_*`).
+
+Host-side mirror of `lmdeploy/turbomind/turbomind.py:108-850` (class TurboMind / TurboMindInstance) for the
+hot path: config -> native EngineConfig, weight slot hand-off, static-batch prefill / decode, token fetch.
+Everything numeric happens in libtm_mi355x.so; a failing native call raises `_ffi.TmError` carrying the
+reference's request status code.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Sequence
+
+import numpy as np
+
+from .. import _ffi
+
+_ROPE_TYPES = {'default': 0, 'linear': 1, 'llama3': 2}
+
+
+def make_model_config(cfg, weight_type: int = 0) -> _ffi.ModelConfig:
+    """cfg: any object with hidden, layers, q_heads, kv_heads, head_dim, inter, vocab, rms_eps, rope(.dim,.base,.type,
+    .factor,.low_freq_factor,.high_freq_factor,.original_max_position_embeddings), group."""
+    r = cfg.rope
+    return _ffi.ModelConfig(cfg.hidden, cfg.layers, cfg.q_heads, cfg.kv_heads, cfg.head_dim, cfg.inter, cfg.vocab,
+                            cfg.rms_eps, r.base, _ROPE_TYPES[r.type], r.factor, r.low_freq_factor, r.high_freq_factor,
+                            r.original_max_position_embeddings, cfg.group, weight_type)
+
+
+class Engine:
+
+    def __init__(self, model_cfg: _ffi.ModelConfig, *, tp: int = 1, rank: int = 0, device: int = 0,
+                 max_batch_size: int = 64, session_len: int = 2048, quant_policy: int = 8,
+                 cache_max_entry_count: float = 0.8, cache_blocks: int = 0, max_prefill_token_num: int = 8192,
+                 decode_splits: int = 0, use_graph: int = 1):
+        self._lib = _ffi.load()
+        self.cfg = _ffi.EngineConfig(model_cfg, tp, rank, device, max_batch_size, session_len, quant_policy, 64,
+                                     cache_max_entry_count, cache_blocks, max_prefill_token_num, decode_splits,
+                                     use_graph)
+        self._h = C.c_void_p()
+        _ffi.check(self._lib.tm_engine_create(C.byref(self._h), C.byref(self.cfg)))
+        self.batch = 0
+        self.max_new = 0
+
+    @classmethod
+    def from_model_config(cls, cfg, weight_type: int = 0, **kw) -> 'Engine':
+        return cls(make_model_config(cfg, weight_type), **kw)
+
+    # ---- weights ---------------------------------------------------------------------------------
+    def load_weights(self, slots: dict):
+        """slots: {name: numpy array} as produced by loader.export_weights (already sharded for this rank)."""
+        for name, arr in slots.items():
+            arr = np.ascontiguousarray(arr)
+            expect = self._lib.tm_engine_weight_bytes(self._h, name.encode())
+            if expect != arr.nbytes:      # same assertion as builders/_base.py:72-99 (dst.byte_size == shard.nbytes)
+                raise ValueError(f'{name}: {arr.nbytes} bytes given, slot holds {expect}')
+            _ffi.check(self._lib.tm_engine_weight_copy(self._h, name.encode(), arr.ctypes.data, arr.nbytes))
+        _ffi.check(self._lib.tm_engine_process_weights(self._h))
+
+    def init_synthetic(self, seed: int = 0):
+        _ffi.check(self._lib.tm_engine_init_synthetic(self._h, seed))
+        _ffi.check(self._lib.tm_engine_process_weights(self._h))
+
+    def comm_init(self, unique_id: bytes):
+        buf = C.create_string_buffer(unique_id, 128)
+        _ffi.check(self._lib.tm_engine_comm_init(self._h, buf))
+
+    @staticmethod
+    def comm_unique_id() -> bytes:
+        buf = C.create_string_buffer(128)
+        _ffi.check(_ffi.load().tm_comm_unique_id(buf))
+        return buf.raw
+
+    def start(self):
+        _ffi.check(self._lib.tm_engine_start(self._h))
+
+    # ---- static batch ----------------------------------------------------------------------------
+    def prefill(self, prompts: Sequence[Sequence[int]], max_new_tokens: int):
+        lens = np.asarray([len(p) for p in prompts], np.int32)
+        ids = np.concatenate([np.asarray(p, np.int32) for p in prompts]).astype(np.int32)
+        _ffi.check(self._lib.tm_engine_prefill(self._h, ids.ctypes.data, lens.ctypes.data, len(prompts),
+                                               max_new_tokens))
+        self.batch, self.max_new = len(prompts), max_new_tokens
+
+    def decode(self, steps: int = 1):
+        _ffi.check(self._lib.tm_engine_decode(self._h, steps))
+
+    def sync(self):
+        _ffi.check(self._lib.tm_engine_sync(self._h))
+
+    def fetch(self) -> np.ndarray:
+        out = np.zeros((self.batch, self.max_new), np.int32)
+        n = C.c_int(0)
+        _ffi.check(self._lib.tm_engine_fetch(self._h, out.ctypes.data, C.byref(n)))
+        return out[:, :n.value]
+
+    def fetch_logits(self) -> np.ndarray:
+        v_local = self.cfg.model.vocab // self.cfg.tp
+        out = np.zeros((self.batch, v_local), np.float16)
+        _ffi.check(self._lib.tm_engine_fetch_logits(self._h, out.ctypes.data))
+        return out
+
+    def release(self):
+        _ffi.check(self._lib.tm_engine_release(self._h))
+        self.batch = 0
+
+    @property
+    def stream(self) -> int:
+        return self._lib.tm_engine_stream(self._h)
+
+    def stats(self) -> dict:
+        wb, kv, nb, sp = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int()
+        _ffi.check(self._lib.tm_engine_stats(self._h, C.byref(wb), C.byref(kv), C.byref(nb), C.byref(sp)))
+        return dict(weight_bytes=wb.value, kv_bytes_per_token=kv.value, num_blocks=nb.value, decode_splits=sp.value)
+
+    def close(self):
+        if self._h:
+            self._lib.tm_engine_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

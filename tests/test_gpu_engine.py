@@ -1,0 +1,72 @@
+"""End-to-end parity: the C++ engine (prefill + hipGraph decode) against the oracle's whole-model restatement on a
+small synthetic Llama-shaped model, same weights, same prompts.
+
+Tolerance (SURVEY 8c "end-to-end tokens"): fp16 logits max_abs <= 0.25 * logit scale is the reference-style gate;
+we require max |logit diff| <= 3e-2 (logits are O(1)) at every compared step and greedy-token agreement wherever the
+oracle's top-2 margin exceeds that tolerance (no exact ties by construction)."""
+import numpy as np
+import pytest
+
+from lmdeploy_amd import _ffi
+from lmdeploy_amd.turbomind.engine import Engine
+from lmdeploy_amd.turbomind.loader import export_weights
+from oracle import tm_oracle as o
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize('kv_bits,use_graph', [(8, 1), (4, 0), (16, 1)])
+def test_engine_matches_oracle(cuda, kv_bits, use_graph):
+    cfg = o.ModelConfig(hidden=256, layers=2, q_heads=4, kv_heads=2, head_dim=128, inter=512, vocab=1024,
+                        kv_bits=kv_bits, rope=o.RopeParam(128, 500000.0, 'llama3', 8.0, 1.0, 4.0, 8192))
+    w = o.make_synthetic_weights(cfg, seed=3)
+    rng = np.random.default_rng(0)
+    prompts = [rng.integers(0, cfg.vocab, n).astype(np.int32) for n in (70, 5, 64)]
+    steps = 6
+
+    eng = Engine.from_model_config(cfg, max_batch_size=4, session_len=256, quant_policy=0 if kv_bits == 16 else kv_bits,
+                                    max_prefill_token_num=96, use_graph=use_graph)
+    eng.load_weights(export_weights(cfg, w))
+    eng.start()
+    eng.prefill(prompts, max_new_tokens=steps + 1)
+    logits = [eng.fetch_logits()]
+    for _ in range(steps):
+        eng.decode(1)
+        logits.append(eng.fetch_logits())
+    toks = eng.fetch()          # [B, steps+1]
+    eng.close()
+
+    om = o.OracleModel(cfg, w, batch=len(prompts), max_ctx=256)
+    ids, lg = om.forward(prompts)
+    ref_logits, ref_toks = [lg], [ids]
+    cur = toks[:, 0]            # teacher-force the ENGINE's tokens so that one flipped near-tie cannot cascade
+    for s in range(steps):
+        ids, lg = om.forward([[int(t)] for t in cur])
+        ref_logits.append(lg)
+        ref_toks.append(ids)
+        cur = toks[:, s + 1]
+    for s in range(steps + 1):
+        d = np.abs(logits[s].astype(np.float32) - ref_logits[s].astype(np.float32))
+        assert d.max() <= 3e-2, f'step {s}: max logit diff {d.max()}'
+        top2 = np.sort(ref_logits[s].astype(np.float32), -1)[:, -2:]
+        safe = (top2[:, 1] - top2[:, 0]) > 6e-2
+        assert np.array_equal(toks[safe, s], ref_toks[s][safe]), f'step {s}: greedy tokens differ'
+
+
+def test_engine_errors_are_status_codes(cuda):
+    cfg = o.ModelConfig(hidden=256, layers=1, q_heads=2, kv_heads=1, head_dim=128, inter=256, vocab=512)
+    eng = Engine.from_model_config(cfg, max_batch_size=2, session_len=128, quant_policy=8)
+    with pytest.raises(_ffi.TmError) as ei:
+        eng.start()                      # weights not processed
+    assert ei.value.status == 1
+    eng.init_synthetic(0)
+    eng.start()
+    with pytest.raises(_ffi.TmError) as ei:
+        eng.prefill([np.arange(100, dtype=np.int32)], max_new_tokens=100)   # 200 > session_len
+    assert ei.value.status == 6          # TM_TOO_LONG == Request::kTooLong
+    eng.prefill([np.arange(10, dtype=np.int32)], max_new_tokens=4)
+    eng.decode(3)
+    assert eng.fetch().shape == (1, 4)
+    with pytest.raises(_ffi.TmError):
+        eng.decode(1)                    # past max_new_tokens
+    eng.close()
