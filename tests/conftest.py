@@ -26,3 +26,11 @@ def cuda():
         pytest.fail('GPU test selected but no GPU is visible')
     torch.cuda.set_device(0)
     return torch.device('cuda:0')
+
+
+@pytest.fixture(autouse=True)
+def _release_device_buffers(request):
+    yield
+    if request.node.get_closest_marker('gpu') is not None:
+        from tests import gpu_helpers
+        gpu_helpers.release_all()

@@ -11,9 +11,21 @@ from lmdeploy_amd import _ffi
 from oracle import tm_oracle as o
 
 
+_KEEP = []   # tensors whose raw pointers were handed to the C-ABI must outlive the (asynchronous) call
+
+
 def dev(a: np.ndarray) -> torch.Tensor:
-    """numpy -> device tensor with the same bytes (fp16 stays fp16, ints stay ints)."""
-    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    """numpy -> device tensor with the same bytes (fp16 stays fp16, ints stay ints).  The tensor is kept alive
+    until release_all() (called after every test): `dev(x).data_ptr()` would otherwise free the buffer before the
+    kernel that reads it has even been launched."""
+    t = torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    _KEEP.append(t)
+    return t
+
+
+def release_all():
+    torch.cuda.synchronize()
+    _KEEP.clear()
 
 
 def host(t: torch.Tensor) -> np.ndarray:
