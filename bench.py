@@ -1,0 +1,180 @@
+#!/usr/bin/env python
+"""Headline benchmark: decode tokens/s (+ p50 TTFT) of Llama-3-8B W4A16 (AWQ g128) + int8 KV, batch 64,
+1k-token synthetic prompts, on N MI355X GPUs of one node (TP=N, one process per GPU, RCCL).
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+         bench.py --gpus N --steps K --warmup W
+
+A "step" = one decode iteration of the whole batch (64 tokens).  Rank 0 prints ONE JSON line.
+`value` = batch * K / t, where t brackets exactly K steps (graph replays) with barrier + device sync on both
+sides, max over ranks.  Inputs (weights, KV cache of the prefilled prompts) are resident in HBM.
+`roofline` is for the dominant kernel (paged decode attention: 58 % of the step's algorithmic bytes at
+ctx 1536): algorithmic KV bytes per launch / mean launch duration, the duration measured with HIP events on the
+engine's stream in eager steps run right after the timed region (same process, same batch state).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+LLAMA3_8B = dict(hidden=4096, layers=32, q_heads=32, kv_heads=8, head_dim=128, inter=14336, vocab=128256,
+                 rms_eps=1e-5)
+HBM_PEAK_GBPS = 8000.0     # MI355X HBM3E spec (/opt/skills/guides/MI355X_MICROARCH.md); 6290 measured copy
+
+
+class _Rope:
+    dim, base, type, factor = 128, 500000.0, 'llama3', 8.0
+    low_freq_factor, high_freq_factor, original_max_position_embeddings = 1.0, 4.0, 8192
+
+
+class _Cfg:
+    group = 128
+    rope = _Rope()
+
+    def __init__(self, d):
+        self.__dict__.update(d)
+
+
+def algorithmic_bytes(m, batch, ctx, kv_bits, tp):
+    """bytes(step) = W_q + W_sz + W_head + B*ctx*kv_bytes_per_token (per rank: / tp)."""
+    H, D = m['hidden'], m['head_dim']
+    P = m['layers'] * (H * (m['q_heads'] + 2 * m['kv_heads']) * D + m['q_heads'] * D * H + 3 * H * m['inter'])
+    w = 0.5 * P + 4.0 * P / 128 + 2.0 * H * m['vocab']
+    kv_tok = m['layers'] * 2 * m['kv_heads'] * (D * kv_bits / 8 + (4 if kv_bits < 16 else 0))
+    return (w + batch * ctx * kv_tok) / tp, kv_tok / tp
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=512)
+    ap.add_argument('--warmup', type=int, default=16)
+    ap.add_argument('--batch', type=int, default=64)
+    ap.add_argument('--prompt-len', type=int, default=1024)
+    ap.add_argument('--quant-policy', type=int, default=8)
+    ap.add_argument('--profile-steps', type=int, default=8)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--layers', type=int, default=0, help='debug only: override the layer count (result is then INVALID)')
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from lmdeploy_amd.turbomind.engine import Engine
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('gloo', rank=rank, world_size=world)   # control plane only; data plane = RCCL in C++
+
+    model = dict(LLAMA3_8B)
+    if args.layers:
+        model['layers'] = args.layers
+    K, W, B, S = args.steps, args.warmup, args.batch, args.prompt_len
+    P = args.profile_steps
+    max_new = 1 + W + K + P + 2
+    eng = Engine.from_model_config(_Cfg(model), tp=world, rank=rank, device=local_rank, max_batch_size=B,
+                                   session_len=S + max_new + 1, quant_policy=args.quant_policy,
+                                   max_prefill_token_num=8192, use_graph=1)
+    if world > 1:
+        uid = [Engine.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        eng.comm_init(uid[0])
+    eng.init_synthetic(seed=0)          # same seed on every rank: shards are generated per rank-local shape
+    eng.start()
+
+    gen = torch.Generator().manual_seed(0)
+    prompts = torch.randint(0, model['vocab'], (B, S), generator=gen, dtype=torch.int32).numpy()
+
+    def barrier():
+        eng.sync()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    barrier()
+    t0 = time.perf_counter()
+    eng.prefill(list(prompts), max_new_tokens=max_new)
+    eng.sync()
+    prefill_s = time.perf_counter() - t0
+    ttft = eng.prefill_times_ms()
+
+    eng.decode(W)                       # untimed warm-up (includes the graph capture)
+    barrier()
+    t0 = time.perf_counter()
+    eng.decode(K)                       # exactly K steps
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    ctx_first = S + 1 + W               # context length (incl. the new token) of the first timed step
+    ctx_mean = ctx_first + (K - 1) / 2.0
+    kv_bits = 16 if args.quant_policy == 0 else args.quant_policy
+    step_bytes, kv_tok = algorithmic_bytes(model, B, ctx_mean, kv_bits, world)
+
+    # ---- per-kernel durations: HIP events on the engine stream, eager steps right after the timed region ----
+    prof = eng.profile_decode(P) if P > 0 else {}
+    ctx_prof = S + 1 + W + K + (P - 1) / 2.0
+    toks = eng.fetch()
+    stats = eng.stats()
+
+    if rank == 0:
+        ms_step = dt / K * 1e3
+        value = B * K / dt
+        out = {
+            'metric': 'decode tokens/sec, Llama-3-8B W4A16 int8-KV batch 64 (1k-in/1k-out synthetic)',
+            'value': round(value, 1), 'unit': 'tokens/s', 'n_gpus': world, 'steps': K, 'warmup': W,
+            'ms_per_step': round(ms_step, 4), 'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None,
+            'dtype': 'f16', 'data': 'synthetic',
+            'config': {'workload': f'Llama-3-8B shapes, W4A16 AWQ g128 random weights, quant_policy={args.quant_policy} '
+                                   f'KV, batch {B}, {S}-token random prompts, greedy decode, TP={world}',
+                       'batch': B, 'prompt_len': S, 'ctx_first_timed_step': ctx_first, 'ctx_mean': ctx_mean,
+                       'parallelism': f'tp{world}', 'decode_splits': stats['decode_splits'], 'hipgraph': True},
+            'ttft_p50_ms': round(float(np.median(ttft)), 2), 'prefill_total_s': round(prefill_s, 3),
+            'prefill_tokens_per_s': round(B * S / prefill_s, 1),
+            'step_roofline': {'bound': 'hbm', 'algorithmic_bytes_per_step': int(step_bytes),
+                              'achieved': round(step_bytes / (dt / K) / 1e9, 1), 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
+                              'frac': round(step_bytes / (dt / K) / 1e9 / HBM_PEAK_GBPS, 4)},
+        }
+        if prof:
+            attn_ms, attn_n = prof['attention']
+            per_launch_bytes = B * ctx_prof * kv_tok / model['layers']      # one layer's KV of the whole batch
+            per_launch_s = attn_ms / 1e3 / max(model['layers'], 1)          # attention (+ split-K merge) of one layer
+            ach = per_launch_bytes / per_launch_s / 1e9
+            out['roofline'] = {'bound': 'hbm', 'kernel': 'decode_attention_kernel<8,4> (+decode_reduce_kernel)',
+                               'achieved': round(ach, 1), 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
+                               'frac': round(ach / HBM_PEAK_GBPS, 4), 'traffic': None,
+                               'bytes_per_launch': int(per_launch_bytes), 'us_per_launch': round(per_launch_s * 1e6, 2),
+                               'ctx': ctx_prof, 'timing': f'HIP events, {P} eager steps after the timed region'}
+            out['kernel_ms_per_step'] = {k: round(v[0], 4) for k, v in prof.items()}
+            gemm_ms = sum(prof[k][0] for k in ('gemm_qkv', 'gemm_o', 'gemm_gate_up', 'gemm_down'))
+            wbytes = (stats['weight_bytes'] - 2 * model['hidden'] * model['vocab'] / world)
+            out['gemm_roofline'] = {'bound': 'hbm', 'achieved': round(wbytes / (gemm_ms / 1e3) / 1e9, 1),
+                                    'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
+                                    'frac': round(wbytes / (gemm_ms / 1e3) / 1e9 / HBM_PEAK_GBPS, 4),
+                                    'bytes_per_step': int(wbytes)}
+        if not args.no_cpu_baseline and world == 1:
+            from oracle import cpu_baseline
+            out['cpu_baseline'] = cpu_baseline.run(model, B, S, sample_layers=1)
+        out['sample_tokens'] = toks[0, :4].tolist()
+        print(json.dumps(out), flush=True)
+    eng.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -191,6 +191,16 @@ int tm_engine_prefill(tm_engine* e, const int* host_ids, const int* host_lens, i
  * ignore_eos semantics).  Asynchronous on the engine stream; tm_engine_sync() waits. */
 int tm_engine_decode(tm_engine* e, int steps);
 int tm_engine_sync(tm_engine* e);
+/* per-sequence time-to-first-token of the last tm_engine_prefill, milliseconds since the call started (host [batch]) */
+int tm_engine_prefill_times(tm_engine* e, float* host_ms);
+/* Run `steps` EAGER decode steps with HIP events around every kernel category on the engine stream and return the
+ * mean milliseconds per step per category (host float[TM_PROF_NUM]) and launches per step (host int[TM_PROF_NUM],
+ * may be NULL).  Categories: */
+enum {
+    TM_PROF_EMBED = 0, TM_PROF_GEMM_QKV, TM_PROF_KV_STORE, TM_PROF_ATTN, TM_PROF_GEMM_O, TM_PROF_RES_NORM,
+    TM_PROF_GEMM_GATE_UP, TM_PROF_GEMM_DOWN, TM_PROF_LM_HEAD, TM_PROF_SAMPLE, TM_PROF_ALLREDUCE, TM_PROF_NUM
+};
+int tm_engine_profile_decode(tm_engine* e, int steps, float* host_ms_per_step, int* host_launches_per_step);
 /* copy generated tokens so far to host: out [batch][max_new_tokens] int32 (row-major), n_generated (host) */
 int tm_engine_fetch(tm_engine* e, int* host_out, int* n_generated);
 /* last step's logits of the local vocab shard, fp16 [batch][vocab/tp] -> host (debug / parity tests) */

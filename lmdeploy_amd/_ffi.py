@@ -85,6 +85,8 @@ _SIGNATURES = {
     'tm_engine_prefill': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int]),
     'tm_engine_decode': (c_int, [c_void_p, c_int]),
     'tm_engine_sync': (c_int, [c_void_p]),
+    'tm_engine_prefill_times': (c_int, [c_void_p, c_void_p]),
+    'tm_engine_profile_decode': (c_int, [c_void_p, c_int, c_void_p, c_void_p]),
     'tm_engine_fetch': (c_int, [c_void_p, c_void_p, POINTER(c_int)]),
     'tm_engine_fetch_logits': (c_int, [c_void_p, c_void_p]),
     'tm_engine_release': (c_int, [c_void_p]),

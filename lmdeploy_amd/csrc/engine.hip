@@ -17,7 +17,9 @@
 #include <cstring>
 #include <map>
 #include <rccl/rccl.h>
+#include <chrono>
 #include <string>
+#include <tuple>
 #include <vector>
 
 namespace tmk {
@@ -201,6 +203,12 @@ struct tm_engine {
 
     int            decode_splits = 1;
     hipGraphExec_t graph = nullptr;
+    // per-kernel-category HIP event profiling (tm_engine_profile_decode)
+    bool                                            prof_on = false;
+    std::vector<hipEvent_t>                         prof_pool;
+    size_t                                          prof_used = 0;
+    std::vector<std::tuple<int, size_t, size_t>>    prof_spans;  // (category, start event, stop event)
+    std::vector<float>                              h_ttft_ms;
     int            graph_batch = 0;
 };
 
@@ -292,8 +300,35 @@ static int allreduce_hidden(tm_engine* e, half_t* buf, int M)
     return 0;
 }
 
+enum ProfCat { P_EMBED = 0, P_GEMM_QKV, P_KV_STORE, P_ATTN, P_GEMM_O, P_RES_NORM, P_GEMM_GATE_UP, P_GEMM_DOWN, P_LM_HEAD,
+               P_SAMPLE, P_ALLREDUCE, P_NUM };
+
+static size_t prof_event(tm_engine* e)
+{
+    if (e->prof_used == e->prof_pool.size()) {
+        hipEvent_t ev;
+        (void)hipEventCreate(&ev);
+        e->prof_pool.push_back(ev);
+    }
+    (void)hipEventRecord(e->prof_pool[e->prof_used], e->stream);
+    return e->prof_used++;
+}
+
+#define TM_PROF(cat, stmt)                                                                         \
+    do {                                                                                           \
+        size_t _a = 0;                                                                             \
+        if (e->prof_on) {                                                                          \
+            _a = prof_event(e);                                                                    \
+        }                                                                                          \
+        stmt;                                                                                      \
+        if (e->prof_on) {                                                                          \
+            e->prof_spans.emplace_back((int)(cat), _a, prof_event(e));                             \
+        }                                                                                          \
+    } while (0)
+
 // row-parallel linear followed by (all-reduce +) residual + RMSNorm
-static int linear_residual_norm(tm_engine* e, LinearSlots& l, const half_t* x, int ldx, int M, const half_t* norm_w)
+static int linear_residual_norm(tm_engine* e, LinearSlots& l, const half_t* x, int ldx, int M, const half_t* norm_w,
+                                int gemm_cat)
 {
     GemmConfig cfg = gemm_pick_config(l.w, M);
     const bool can_defer = e->cfg.tp == 1 && cfg.splits > 1
@@ -302,15 +337,18 @@ static int linear_residual_norm(tm_engine* e, LinearSlots& l, const half_t* x, i
         cfg.splits = 1;
     }
     int slabs = 1;
-    TM_TRY(launch_linear(l.w, x, ldx, e->d_tmp, e->hidden, M, false, cfg, e->d_gemm_ws, can_defer, &slabs, e->stream));
+    TM_PROF(gemm_cat, TM_TRY(launch_linear(l.w, x, ldx, e->d_tmp, e->hidden, M, false, cfg, e->d_gemm_ws, can_defer, &slabs,
+                                           e->stream)));
     if (can_defer && slabs > 1) {
-        return launch_residual_rmsnorm(e->d_x, e->d_resid, nullptr, e->d_gemm_ws, slabs, nullptr, norm_w,
-                                       e->cfg.model.rms_eps, M, e->hidden, e->stream);
+        TM_PROF(P_RES_NORM, TM_TRY(launch_residual_rmsnorm(e->d_x, e->d_resid, nullptr, e->d_gemm_ws, slabs, nullptr, norm_w,
+                                                           e->cfg.model.rms_eps, M, e->hidden, e->stream)));
+        return 0;
     }
     TM_REQUIRE(!can_defer || slabs == 1, "internal: deferred reduce without slabs");
-    TM_TRY(allreduce_hidden(e, e->d_tmp, M));
-    return launch_residual_rmsnorm(e->d_x, e->d_resid, e->d_tmp, nullptr, 0, nullptr, norm_w, e->cfg.model.rms_eps, M,
-                                   e->hidden, e->stream);
+    TM_PROF(P_ALLREDUCE, TM_TRY(allreduce_hidden(e, e->d_tmp, M)));
+    TM_PROF(P_RES_NORM, TM_TRY(launch_residual_rmsnorm(e->d_x, e->d_resid, e->d_tmp, nullptr, 0, nullptr, norm_w,
+                                                       e->cfg.model.rms_eps, M, e->hidden, e->stream)));
+    return 0;
 }
 
 static int linear_plain(tm_engine* e, LinearSlots& l, const half_t* x, int ldx, half_t* y, int ldy, int M, bool gated)
@@ -328,14 +366,15 @@ static int forward(tm_engine* e, const int* d_ids, int M, int nseq, bool decode,
 {
     const tm_model_config& m = e->cfg.model;
     hipStream_t            st = e->stream;
-    TM_TRY(launch_embedding(e->d_resid, e->tok_embeddings, d_ids, M, e->hidden, m.vocab, st));
-    TM_TRY(launch_rmsnorm(e->d_x, e->d_resid, e->layers[0].attn_norm, m.rms_eps, M, e->hidden, st));
+    TM_PROF(P_EMBED, TM_TRY(launch_embedding(e->d_resid, e->tok_embeddings, d_ids, M, e->hidden, m.vocab, st)));
+    TM_PROF(P_RES_NORM, TM_TRY(launch_rmsnorm(e->d_x, e->d_resid, e->layers[0].attn_norm, m.rms_eps, M, e->hidden, st)));
     const float scale_log2 = (1.0f / std::sqrt((float)e->D)) * 1.4426950408889634f;
     for (int li = 0; li < m.layers; ++li) {
         Layer& L = e->layers[li];
-        TM_TRY(linear_plain(e, L.qkv, e->d_x, e->hidden, e->d_qkv, e->qkv_n, M, false));
+        TM_PROF(P_GEMM_QKV, TM_TRY(linear_plain(e, L.qkv, e->d_x, e->hidden, e->d_qkv, e->qkv_n, M, false)));
         KvCacheView cv = cache_view(e, li);
-        TM_TRY(launch_kv_rope_store(e->d_qkv, e->q_heads, e->d_cu_q, e->d_k_len, nseq, M, e->d_rope, e->rope_max_pos, cv, st));
+        TM_PROF(P_KV_STORE, TM_TRY(launch_kv_rope_store(e->d_qkv, e->q_heads, e->d_cu_q, e->d_k_len, nseq, M, e->d_rope,
+                                                       e->rope_max_pos, cv, st)));
         if (decode) {
             DecodeAttnParams p{};
             p.q          = e->d_qkv;
@@ -349,10 +388,11 @@ static int forward(tm_engine* e, const int* d_ids, int M, int nseq, bool decode,
             p.partial_o  = e->d_attn_ws;
             p.partial_ml = e->d_attn_ws + (size_t)nseq * e->q_heads * e->decode_splits * e->D;
             p.cache      = cv;
-            TM_TRY(launch_decode_attention(p, st));
+            TM_PROF(P_ATTN, TM_TRY(launch_decode_attention(p, st)));
         }
         else {
-            TM_TRY(launch_flatten_kv(e->d_kflat, e->d_vflat, 1, e->d_cu_koff, e->d_k_len, nseq, max_k_len, kflat_stride, cv, st));
+            TM_PROF(P_KV_STORE, TM_TRY(launch_flatten_kv(e->d_kflat, e->d_vflat, 1, e->d_cu_koff, e->d_k_len, nseq, max_k_len,
+                                                        kflat_stride, cv, st)));
             PrefillAttnParams p{};
             p.q          = e->d_qkv;
             p.q_stride   = e->qkv_n;
@@ -368,12 +408,12 @@ static int forward(tm_engine* e, const int* d_ids, int M, int nseq, bool decode,
             p.q_heads    = e->q_heads;
             p.kv_heads   = e->kv_heads;
             p.scale_log2 = scale_log2;
-            TM_TRY(launch_prefill_attention(p, st));
+            TM_PROF(P_ATTN, TM_TRY(launch_prefill_attention(p, st)));
         }
-        TM_TRY(linear_residual_norm(e, L.wo, e->d_attn, e->q_heads * e->D, M, L.ffn_norm));
-        TM_TRY(linear_plain(e, L.w13, e->d_x, e->hidden, e->d_act, e->inter, M, true));
+        TM_TRY(linear_residual_norm(e, L.wo, e->d_attn, e->q_heads * e->D, M, L.ffn_norm, P_GEMM_O));
+        TM_PROF(P_GEMM_GATE_UP, TM_TRY(linear_plain(e, L.w13, e->d_x, e->hidden, e->d_act, e->inter, M, true)));
         const half_t* next_norm = li + 1 < m.layers ? e->layers[li + 1].attn_norm : e->final_norm;
-        TM_TRY(linear_residual_norm(e, L.w2, e->d_act, e->inter, M, next_norm));
+        TM_TRY(linear_residual_norm(e, L.w2, e->d_act, e->inter, M, next_norm, P_GEMM_DOWN));
     }
     // last-token hidden states -> logits -> greedy
     const half_t* hx = e->d_x;
@@ -384,9 +424,9 @@ static int forward(tm_engine* e, const int* d_ids, int M, int nseq, bool decode,
     // logits / next ids land in the batch slots [slot0, slot0 + nseq)
     half_t* logits = e->d_logits + (size_t)slot0 * e->vocab_local;
     int*    ids    = e->d_next_ids + slot0;
-    TM_TRY(linear_plain(e, e->output, hx, e->hidden, logits, e->vocab_local, nseq, false));
+    TM_PROF(P_LM_HEAD, TM_TRY(linear_plain(e, e->output, hx, e->hidden, logits, e->vocab_local, nseq, false)));
     if (e->cfg.tp == 1) {
-        TM_TRY(launch_argmax(ids, nullptr, logits, nseq, e->vocab_local, e->vocab_local, 0, st));
+        TM_PROF(P_SAMPLE, TM_TRY(launch_argmax(ids, nullptr, logits, nseq, e->vocab_local, e->vocab_local, 0, st)));
     }
     else {
         TM_TRY(launch_argmax(ids, e->d_argmax_val, logits, nseq, e->vocab_local, e->vocab_local,
@@ -786,6 +826,8 @@ int tm_engine_prefill(tm_engine* e, const int* host_ids, const int* host_lens, i
         offs[b + 1] = offs[b] + host_lens[b];
     }
     const int budget = e->max_tokens;
+    const auto t_start = std::chrono::steady_clock::now();
+    e->h_ttft_ms.assign(batch, 0.f);
     // Because the batch tables (block_ptrs, cu_block_nums) are indexed by the batch slot, every prefill
     // iteration covers a contiguous range of slots [b0, b1]; the block table is offset accordingly and the
     // logits / first tokens of the iteration land in d_logits / d_next_ids at slot b0 + i.
@@ -835,6 +877,12 @@ int tm_engine_prefill(tm_engine* e, const int* host_ids, const int* host_lens, i
         }
         // the host vectors above are pageable: make sure the async copies are done before they die
         TM_HIP_CHECK(hipStreamSynchronize(e->stream));
+        {
+            const float ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_start).count();
+            for (int b = b0; b < b1; ++b) {
+                e->h_ttft_ms[b] = ms;  // first token of sequence b exists once its last chunk has been processed
+            }
+        }
         b0 = b1;  // a partially prefilled sequence (b1) is revisited with done_in_b0 tokens of history
         if (!partial_last) {
             done_in_b0 = 0;
@@ -917,6 +965,51 @@ int tm_engine_decode(tm_engine* e, int steps)
         }
     }
     e->steps_done += steps;
+    return 0;
+}
+
+int tm_engine_prefill_times(tm_engine* e, float* host_ms)
+{
+    TM_REQUIRE(e && host_ms, "null pointer");
+    TM_REQUIRE((int)e->h_ttft_ms.size() == e->batch, "no admitted batch");
+    memcpy(host_ms, e->h_ttft_ms.data(), sizeof(float) * e->batch);
+    return 0;
+}
+
+int tm_engine_profile_decode(tm_engine* e, int steps, float* host_ms_per_step, int* host_launches_per_step)
+{
+    TM_REQUIRE(e && host_ms_per_step && e->batch > 0 && steps >= 1, "arguments");
+    TM_HIP_CHECK(hipSetDevice(e->cfg.device));
+    if (e->steps_done + steps > e->max_new) {
+        set_last_error("decode past max_new_tokens");
+        return TM_TOO_LONG;
+    }
+    std::vector<double> acc(P_NUM, 0.0);
+    std::vector<int>    cnt(P_NUM, 0);
+    for (int i = 0; i < steps; ++i) {
+        e->prof_on   = true;
+        e->prof_used = 0;
+        e->prof_spans.clear();
+        int rc     = decode_step(e);
+        e->prof_on = false;
+        if (rc) {
+            return rc;
+        }
+        TM_HIP_CHECK(hipStreamSynchronize(e->stream));
+        for (auto& sp : e->prof_spans) {
+            float ms = 0.f;
+            TM_HIP_CHECK(hipEventElapsedTime(&ms, e->prof_pool[std::get<1>(sp)], e->prof_pool[std::get<2>(sp)]));
+            acc[std::get<0>(sp)] += ms;
+            cnt[std::get<0>(sp)] += 1;
+        }
+        e->steps_done += 1;
+    }
+    for (int c = 0; c < P_NUM; ++c) {
+        host_ms_per_step[c] = (float)(acc[c] / steps);
+        if (host_launches_per_step) {
+            host_launches_per_step[c] = cnt[c] / steps;
+        }
+    }
     return 0;
 }
 

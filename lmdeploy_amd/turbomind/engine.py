@@ -84,6 +84,21 @@ class Engine:
     def decode(self, steps: int = 1):
         _ffi.check(self._lib.tm_engine_decode(self._h, steps))
 
+    PROF_CATEGORIES = ('embed', 'gemm_qkv', 'kv_store', 'attention', 'gemm_o', 'residual_norm', 'gemm_gate_up',
+                       'gemm_down', 'lm_head', 'sample', 'allreduce')
+
+    def profile_decode(self, steps: int = 1) -> dict:
+        """Eager decode steps with HIP events around every kernel category -> {category: (ms per step, launches)}."""
+        ms = (C.c_float * len(self.PROF_CATEGORIES))()
+        n = (C.c_int * len(self.PROF_CATEGORIES))()
+        _ffi.check(self._lib.tm_engine_profile_decode(self._h, steps, ms, n))
+        return {k: (ms[i], n[i]) for i, k in enumerate(self.PROF_CATEGORIES)}
+
+    def prefill_times_ms(self) -> np.ndarray:
+        out = np.zeros(self.batch, np.float32)
+        _ffi.check(self._lib.tm_engine_prefill_times(self._h, out.ctypes.data))
+        return out
+
     def sync(self):
         _ffi.check(self._lib.tm_engine_sync(self._h))
 

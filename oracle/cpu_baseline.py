@@ -1,0 +1,109 @@
+"""CPU baseline for bench.py's `cpu_baseline` leg (TEST / MEASUREMENT INFRASTRUCTURE, never the product path).
+
+kind = "port": the reference has no CPU backend (`PytorchEngineConfig.device_type` in {cuda, ascend, maca, camb},
+lmdeploy/messages.py:531) and `/root/reference` does not exist on the GPU box, so this is a torch-CPU port of the
+reference PyTorchEngine's pure-torch "default" op backend, restated from:
+  * W4A16:   lmdeploy/pytorch/backends/default/awq_modules.py:37-46,58-81  ((q - z) * s in fp16, then matmul)
+  * RMSNorm: lmdeploy/pytorch/backends/default/norm.py:14-28
+  * SiLU*up: lmdeploy/pytorch/backends/default/activation.py:15-18
+  * RoPE:    lmdeploy/pytorch/backends/default/apply_rotary_emb.py (rotate-half form)
+  * attention: torch.nn.functional.scaled_dot_product_attention over a contiguous (dequantised int8) KV cache --
+    the default backend has no attention op.
+It times a BOUNDED sample of the bench workload (same model shapes, same batch, same context): `sample_layers`
+decoder layers + lm_head for one decode step, and extrapolates to the full layer count.
+"""
+from __future__ import annotations
+
+import os
+import time
+
+import torch
+
+
+def _awq_linear(x, q, s, z, group):
+    # awq_modules.dequantize_gemm: (iweight - izeros) * scales, fp16 -> matmul.  CPU fp16 matmul is slow / partly
+    # unsupported, so the contraction runs in fp32 (stated in the bench output).
+    K, N = q.shape
+    w = ((q.view(K // group, group, N).to(torch.float16) - z[:, None, :]) * s[:, None, :]).view(K, N)
+    return (x.float() @ w.float()).to(torch.float16)
+
+
+def _rmsnorm(x, w, eps, residual=None):
+    if residual is not None:
+        x = x + residual
+        residual = x
+    xf = x.float()
+    var = xf.square().mean(-1, keepdim=True)
+    y = (w.float() * (xf * torch.rsqrt(var + eps))).to(x.dtype)
+    return y, residual
+
+
+def _rope(x, cos, sin):
+    d = x.shape[-1] // 2
+    x1, x2 = x[..., :d], x[..., d:]
+    return torch.cat([x1 * cos - x2 * sin, x2 * cos + x1 * sin], -1)
+
+
+def run(model: dict, batch: int, ctx: int, sample_layers: int = 1, seed: int = 0, threads: int | None = None) -> dict:
+    threads = threads or os.cpu_count() or 1
+    torch.set_num_threads(threads)
+    g = torch.Generator().manual_seed(seed)
+    H, D = model['hidden'], model['head_dim']
+    Hq, Hkv, I, V, G = model['q_heads'], model['kv_heads'], model['inter'], model['vocab'], 128
+
+    def lin(K, N):
+        q = torch.randint(0, 16, (K, N), generator=g, dtype=torch.uint8)
+        s = (torch.rand((K // G, N), generator=g) * 2e-3 + 1e-3).to(torch.float16)
+        z = torch.randint(0, 16, (K // G, N), generator=g).to(torch.float16)
+        return q, s, z
+
+    layers = []
+    for _ in range(sample_layers):
+        layers.append(dict(qkv=lin(H, (Hq + 2 * Hkv) * D), wo=lin(Hq * D, H), w13=lin(H, 2 * I), w2=lin(I, H),
+                           n1=torch.ones(H, dtype=torch.float16), n2=torch.ones(H, dtype=torch.float16),
+                           # int8 KV cache + per-token (scale, zero), contiguous [B, Hkv, ctx, D]
+                           kq=torch.randint(0, 256, (batch, Hkv, ctx, D), generator=g, dtype=torch.uint8),
+                           vq=torch.randint(0, 256, (batch, Hkv, ctx, D), generator=g, dtype=torch.uint8),
+                           kp=torch.rand((batch, Hkv, ctx, 2), generator=g).to(torch.float16),
+                           vp=torch.rand((batch, Hkv, ctx, 2), generator=g).to(torch.float16)))
+    w_out = (torch.randn((H, V), generator=g) * 0.01).to(torch.float16)
+    x = torch.randn((batch, H), generator=g).to(torch.float16)
+    resid = x.clone()
+    cos = torch.ones((batch, 1, D // 2), dtype=torch.float16)
+    sin = torch.zeros((batch, 1, D // 2), dtype=torch.float16)
+
+    def layer_fwd(L, x, resid):
+        qkv = _awq_linear(x, *L['qkv'], G)
+        q = _rope(qkv[:, :Hq * D].view(batch, Hq, D), cos, sin)
+        k = qkv[:, Hq * D:(Hq + Hkv) * D].view(batch, Hkv, 1, D)
+        v = qkv[:, (Hq + Hkv) * D:].view(batch, Hkv, 1, D)
+        kc = L['kq'].to(torch.float16) * L['kp'][..., :1] + L['kp'][..., 1:]
+        vc = L['vq'].to(torch.float16) * L['vp'][..., :1] + L['vp'][..., 1:]
+        kc = torch.cat([kc[:, :, 1:], k], 2).float()
+        vc = torch.cat([vc[:, :, 1:], v], 2).float()
+        rep = Hq // Hkv
+        o = torch.nn.functional.scaled_dot_product_attention(
+            q.view(batch, Hq, 1, D).float(), kc.repeat_interleave(rep, 1), vc.repeat_interleave(rep, 1))
+        a = o.view(batch, Hq * D).to(torch.float16)
+        h = _awq_linear(a, *L['wo'], G)
+        x, resid = _rmsnorm(h, L['n2'], 1e-5, resid)
+        gu = _awq_linear(x, *L['w13'], G)
+        act = torch.nn.functional.silu(gu[:, 0::2].float()).to(torch.float16) * gu[:, 1::2]
+        d = _awq_linear(act, *L['w2'], G)
+        x, resid = _rmsnorm(d, L['n1'], 1e-5, resid)
+        return x, resid
+
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        for L in layers:
+            x, resid = layer_fwd(L, x, resid)
+        t_layers = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        logits = (x.float() @ w_out.float())
+        logits.argmax(-1)
+        t_head = time.perf_counter() - t0
+    step_s = t_layers / sample_layers * model['layers'] + t_head
+    return dict(value=batch / step_s, unit='tokens/s', cores=threads, kind='port',
+                sample=(f'{sample_layers} of {model["layers"]} decoder layers + lm_head, one decode step, batch {batch}, '
+                        f'ctx {ctx}, int8 KV; fp32 contraction on CPU; extrapolated to {model["layers"]} layers '
+                        f'({t_layers:.2f}s layers + {t_head:.2f}s head measured)'))
