@@ -68,8 +68,8 @@ _SIGNATURES = {
     'tm_linear_create': (c_int, [POINTER(c_void_p), c_int, c_int, c_int, c_int]),
     'tm_linear_prepare': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     'tm_linear_workspace': (c_size_t, [c_void_p, c_int]),
-    'tm_linear_forward': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p,
-                                  c_void_p]),
+    'tm_linear_forward': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
+                                  c_void_p, c_void_p]),
     'tm_linear_destroy': (c_int, [c_void_p]),
     'tm_quantize_groupwise': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                                       c_void_p]),

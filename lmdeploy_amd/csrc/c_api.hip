@@ -236,7 +236,7 @@ size_t tm_linear_workspace(const tm_linear* w, int M)
 }
 
 int tm_linear_forward(const tm_linear* w, const void* x, int ldx, void* y, int ldy, int M, int gated_silu, int nt,
-                      int splits, void* workspace, tm_stream_t st)
+                      int splits, int waves, void* workspace, tm_stream_t st)
 {
     TM_REQUIRE(w && x && y, "null pointer");
     GemmConfig cfg = gemm_pick_config(w->w, M);
@@ -245,6 +245,10 @@ int tm_linear_forward(const tm_linear* w, const void* x, int ldx, void* y, int l
     }
     if (splits > 0) {
         cfg.splits = splits;
+    }
+    if (waves > 0) {
+        TM_REQUIRE(waves == 4 || waves == 8, "waves in {4, 8}");
+        cfg.waves = waves;
     }
     TM_REQUIRE(cfg.splits <= 16, "splits <= 16");
     if (!workspace) {

@@ -34,18 +34,20 @@ namespace tmk {
 // ------------------------------------------------------------------------------------------------
 __global__ void repack_u4_kernel(uint32_t* __restrict__ out, const int32_t* __restrict__ qw, int K, int N)
 {
-    // one thread per output dword: idx = ((nt*KB + kb)*64 + lane)*4 + j
+    // one thread per output dword: idx = ((kb*NTILES + nt)*64 + lane)*4 + j   (k-block major: all column tiles of
+    // one k-block are contiguous, so the whole grid walks HBM as ONE sequential stream -- panel-major layouts
+    // (one 32 KiB stream per wave) thrash DRAM pages across ~2000 concurrent streams)
     const size_t idx   = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t total = (size_t)K * N / 8;
     if (idx >= total) {
         return;
     }
-    const int    KB   = K / 128;
+    const int    NTILES = N / 16;
     const int    j    = idx & 3;
     const int    lane = (idx >> 2) & 63;
     const size_t tile = idx >> 8;
-    const int    kb   = tile % KB;
-    const int    nt   = tile / KB;
+    const int    nt   = tile % NTILES;
+    const int    kb   = tile / NTILES;
     const int    n    = nt * 16 + (lane & 15);
     const int    k0   = kb * 128 + j * 32 + (lane >> 4) * 8;
     uint32_t     w    = 0;
@@ -65,7 +67,7 @@ __global__ void repack_sz_kernel(uint32_t* __restrict__ out,
                                  int KB,
                                  int N)
 {
-    // idx = (nt*KB + kb)*16 + i
+    // idx = (kb*NTILES + nt)*16 + i
     const size_t idx   = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t total = (size_t)KB * N;
     if (idx >= total) {
@@ -73,8 +75,8 @@ __global__ void repack_sz_kernel(uint32_t* __restrict__ out,
     }
     const int    i    = idx & 15;
     const size_t tile = idx >> 4;
-    const int    kb   = tile % KB;
-    const int    nt   = tile / KB;
+    const int    nt   = tile % (N / 16);
+    const int    kb   = tile / (N / 16);
     const int    n    = nt * 16 + i;
     const half_t s    = scales[(size_t)kb * N + n];
     const half_t z    = zeros[(size_t)kb * N + n];
@@ -85,17 +87,17 @@ __global__ void repack_sz_kernel(uint32_t* __restrict__ out,
 
 __global__ void repack_f16_kernel(half_t* __restrict__ out, const half_t* __restrict__ w, int K, int N)
 {
-    // one thread per 8 halves: idx = (nt*KQ + kq)*64 + lane
+    // one thread per 8 halves: idx = ((kb*NTILES + nt)*4 + v)*64 + lane, k-quarter kq = 4*kb + v
     const size_t idx   = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t total = (size_t)K * N / 8;
     if (idx >= total) {
         return;
     }
-    const int    KQ   = K / 32;
     const int    lane = idx & 63;
-    const size_t tile = idx >> 6;
-    const int    kq   = tile % KQ;
-    const int    nt   = tile / KQ;
+    const int    v    = (idx >> 6) & 3;
+    const size_t tile = idx >> 8;
+    const int    nt   = tile % (N / 16);
+    const int    kq   = (int)(tile / (N / 16)) * 4 + v;
     const int    n    = nt * 16 + (lane & 15);
     const int    k0   = kq * 32 + (lane >> 4) * 8;
     half8_t      o;
@@ -154,6 +156,7 @@ int linear_weight_prepare_f16(LinearWeight& w, const half_t* weight, hipStream_t
     return 0;
 }
 
+
 // ------------------------------------------------------------------------------------------------
 // main kernel
 // ------------------------------------------------------------------------------------------------
@@ -166,19 +169,24 @@ struct GemmParams {
     int             ldy;
     float*          partial;  // [splits][M][N]
     int             M, N, K;
-    int             KB;                // K / 128
-    int             chunks_per_split;  // in units of KBC k-blocks
-    int             total_chunks;
-    int             epilogue;  // 0: fp16 store  1: gated silu fp16 store  2: fp32 partial slabs
+    int             KB;            // K / 128
+    int             kb_per_split;  // k-blocks (128 k) per grid.y slice
+    int             epilogue;      // 0: fp16 store  1: gated silu fp16 store  2: fp32 partial slabs
 };
 
-__device__ __forceinline__ half8_t dequant8(uint32_t w, half2_t s2, half2_t z2)
+// m1024 / m64 hold 0x64006400 / 0x54005400 in VGPRs (made opaque by the caller): with the magic in a register
+// hipcc selects ONE v_and_or_b32 per pair instead of v_and + v_or (VOP3 takes a single literal on gfx9).
+__device__ __forceinline__ half8_t dequant8(uint32_t w, half2_t s2, half2_t z2, uint32_t m1024, uint32_t m64)
 {
+    // nibble p (p<4) = k_2p, nibble 4+p = k_2p+1.  Bits 0-3 / 16-19 under 0x6400 read 1024+q, bits 4-7 / 20-23 under
+    // 0x5400 read 64+q (quantization.h:503-524); both subtractions are exact in fp16.
     const half2_t k1024 = {(half_t)1024.0f, (half_t)1024.0f};
-    half2_t       p0 = bit_cast<half2_t>((w & 0x000f000fu) | 0x64006400u) - k1024;
-    half2_t       p1 = bit_cast<half2_t>(((w >> 4) & 0x000f000fu) | 0x64006400u) - k1024;
-    half2_t       p2 = bit_cast<half2_t>(((w >> 8) & 0x000f000fu) | 0x64006400u) - k1024;
-    half2_t       p3 = bit_cast<half2_t>(((w >> 12) & 0x000f000fu) | 0x64006400u) - k1024;
+    const half2_t k64   = {(half_t)64.0f, (half_t)64.0f};
+    const uint32_t hi   = w >> 8;
+    half2_t       p0 = bit_cast<half2_t>((w & 0x000f000fu) | m1024) - k1024;
+    half2_t       p1 = bit_cast<half2_t>((w & 0x00f000f0u) | m64) - k64;
+    half2_t       p2 = bit_cast<half2_t>((hi & 0x000f000fu) | m1024) - k1024;
+    half2_t       p3 = bit_cast<half2_t>((hi & 0x00f000f0u) | m64) - k64;
     p0               = h2_fma(p0, s2, z2);
     p1               = h2_fma(p1, s2, z2);
     p2               = h2_fma(p2, s2, z2);
@@ -186,17 +194,26 @@ __device__ __forceinline__ half8_t dequant8(uint32_t w, half2_t s2, half2_t z2)
     return half8_t{p0[0], p0[1], p1[0], p1[1], p2[0], p2[1], p3[0], p3[1]};
 }
 
-template<int WT, int MT, int NT, int KBC>
-__global__ __launch_bounds__(256) void gemm_kernel(GemmParams p)
+// One workgroup = WAVES waves x NT column tiles (16 wide) x MT row tiles (16 tall) over a slice of K.
+// K advances one k-block (128 = one quantisation group = one 16-B lane load per tile) per iteration:
+//   * weights: per-wave register ring, PF k-blocks deep (PF KiB per tile in flight per wave) -- the HBM stream
+//     is never waited on for less than PF iterations;
+//   * activations: [MB][128] fp16 per k-block through a double-buffered, XOR-swizzled LDS tile shared by all
+//     waves (global -> registers two iterations ahead -> LDS one iteration ahead), ONE barrier per iteration.
+template<int WT, int MT, int NT, int WAVES, int PF>
+__global__ __launch_bounds__(WAVES * 64) void gemm_kernel(GemmParams p)
 {
-    constexpr int MB   = 16 * MT;      // rows per workgroup
-    constexpr int KCH  = 128 * KBC;    // k per chunk
-    constexpr int ROWB = KCH * 2;      // LDS row bytes (multiple of 256)
-    constexpr int CPR  = KCH / 8;      // 16-B chunks per row
-    constexpr int XR   = (MB * CPR + 255) / 256;  // x staging vectors per thread
-    constexpr int WV   = WT == 0 ? 1 : 4;         // u32x4 per (tile, k-block) per lane
+    static_assert(PF % 2 == 0, "ring depth must be even (x register sets alternate)");
+    constexpr int MB      = 16 * MT;
+    constexpr int THREADS = WAVES * 64;
+    constexpr int ROWB    = 256;            // one k-block of one row
+    constexpr int BUFB    = MB * ROWB;      // one LDS stage
+    constexpr int NCHUNK  = MB * 16;        // 16-B chunks per stage
+    constexpr int XR      = (NCHUNK + THREADS - 1) / THREADS;
+    constexpr int WV      = WT == 0 ? 1 : 4;  // u32x4 per (tile, k-block) per lane
+    constexpr bool XFULL  = NCHUNK % THREADS == 0;  // every thread stages exactly XR chunks
 
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // 2 * BUFB
 
     const int tid  = threadIdx.x;
     const int lane = tid & 63;
@@ -205,20 +222,26 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p)
     const int g    = lane >> 4;
 
     const int ntiles = p.N / 16;
-    const int nt0    = (blockIdx.x * 4 + wave) * NT;
+    const int nt0    = (blockIdx.x * WAVES + wave) * NT;
     const int m0     = blockIdx.z * MB;
-    const int c_beg  = blockIdx.y * p.chunks_per_split;
-    const int c_end  = min(c_beg + p.chunks_per_split, p.total_chunks);
+    const int kb0    = blockIdx.y * p.kb_per_split;
+    const int nkb    = min(p.kb_per_split, p.KB - kb0);
 
-    // per-tile streams (tiles past the edge are clamped: loads stay in bounds, stores are skipped)
-    const u32x4*    wp[NT];
-    const uint32_t* sp[NT];
+    // Buffer descriptors (SRD) + per-lane 32-bit byte offsets + SCALAR k-block offsets: the address math of every
+    // load in the loop is SALU-only (raw pointers cost ~10 VALU per load in 64-bit adds -- the loop is VALU-bound).
+    // Tiles past the edge are clamped: loads stay in bounds, stores are skipped.
+    const auto rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.wq, 0, (int)((size_t)p.KB * ntiles * 1024 * WV), 0x00020000);
+    const auto rs_s = __builtin_amdgcn_make_buffer_rsrc((void*)p.sz, 0, WT == 0 ? p.KB * ntiles * 64 : 0, 0x00020000);
+    const auto rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)(((size_t)(p.M - 1) * p.ldx + p.K) * 2), 0x00020000);
+    int woff[NT], soff[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         const int nt = min(nt0 + t, ntiles - 1);
-        wp[t]        = p.wq + ((size_t)nt * p.KB) * 64 * WV + lane;
-        sp[t]        = WT == 0 ? p.sz + ((size_t)nt * p.KB) * 16 + i16 : nullptr;
+        woff[t]      = (nt * 64 * WV + lane) * 16;
+        soff[t]      = (nt * 16 + i16) * 4;
     }
+    const int wstride = ntiles * 1024 * WV;  // bytes per k-block of packed weights
+    const int sstride = ntiles * 64;         // bytes per k-block of (s, -z*s) pairs
 
     floatx4 acc[NT][MT];
 #pragma unroll
@@ -229,107 +252,118 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p)
         }
     }
 
-    u32x4    wcur[NT][KBC][WV], wnxt[NT][KBC][WV];
-    uint32_t scur[NT][KBC], snxt[NT][KBC];
-    u32x4    xr[XR];
+    u32x4    ring[PF][NT][WV];
+    uint32_t sring[PF][NT];
+    u32x4    xs[PF][XR];
 
-    auto load_w = [&](int c, u32x4 (&wb)[NT][KBC][WV], uint32_t (&sb)[NT][KBC]) {
+    // x chunk q of a k-block: row q/16, 16-B chunk q%16.  Loads are UNCONDITIONAL (clamped row / chunk): a
+    // per-lane "load or zero" select makes hipcc branch around every load and drain vmcnt(0) each time.
+    // Rows past M only feed output rows that are never stored.
+    int xoff[XR];
+    int xlds[XR];
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-#pragma unroll
-            for (int kk = 0; kk < KBC; ++kk) {
-                const int kb = c * KBC + kk;
-#pragma unroll
-                for (int v = 0; v < WV; ++v) {
-                    wb[t][kk][v] = __builtin_nontemporal_load(wp[t] + ((size_t)kb * WV + v) * 64);
-                }
-                if constexpr (WT == 0) {
-                    sb[t][kk] = sp[t][(size_t)kb * 16];
-                }
-            }
-        }
-    };
-    auto load_x = [&](int c) {
-#pragma unroll
-        for (int r = 0; r < XR; ++r) {
-            const int q  = tid + 256 * r;
-            const int m  = q / CPR;
-            const int ci = q % CPR;
-            u32x4     v  = {0u, 0u, 0u, 0u};
-            if (m < MB && m0 + m < p.M) {
-                v = *(const u32x4*)(p.x + (size_t)(m0 + m) * p.ldx + (size_t)c * KCH + ci * 8);
-            }
-            xr[r] = v;
-        }
-    };
-    auto store_x = [&]() {
-#pragma unroll
-        for (int r = 0; r < XR; ++r) {
-            const int q  = tid + 256 * r;
-            const int m  = q / CPR;
-            const int ci = q % CPR;
-            if (m < MB) {
-                *(u32x4*)(smem + m * ROWB + ((ci ^ (m & 15)) << 4)) = xr[r];
-            }
-        }
-    };
+    for (int r = 0; r < XR; ++r) {
+        const int q  = tid + THREADS * r;
+        const int qc = min(q, NCHUNK - 1);
+        const int m  = qc >> 4;
+        const int ci = qc & 15;
+        xoff[r]      = (min(m0 + m, p.M - 1) * p.ldx + ci * 8) * 2;
+        xlds[r]      = q < NCHUNK ? m * ROWB + ((ci ^ (m & 15)) << 4) : -1;
+    }
+    uint32_t m1024 = 0x64006400u, m64 = 0x54005400u;
+    asm volatile("" : "+v"(m1024), "+v"(m64));  // keep the magic numbers in VGPRs (see dequant8)
+    const int last = nkb - 1;  // k-block indices are clamped to `last`: the tail re-loads harmlessly
 
-    if (c_beg < c_end) {
-        load_x(c_beg);
-        load_w(c_beg, wcur, scur);
+#define TM_LOAD_W(slot, i)                                                                                   \
+    {                                                                                                        \
+        const int kb_ = kb0 + min((i), last);                                                                \
+        _Pragma("unroll") for (int t = 0; t < NT; ++t)                                                       \
+        {                                                                                                    \
+            _Pragma("unroll") for (int v = 0; v < WV; ++v)                                                   \
+            {                                                                                                \
+                ring[slot][t][v] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, woff[t] + v * 1024,           \
+                                                                         kb_ * wstride, /*nt*/ 2);           \
+            }                                                                                                \
+            if constexpr (WT == 0) {                                                                         \
+                sring[slot][t] = __builtin_amdgcn_raw_buffer_load_b32(rs_s, soff[t], kb_ * sstride, 0);      \
+            }                                                                                                \
+        }                                                                                                    \
+    }
+#define TM_LOAD_X(set, i)                                                                                    \
+    {                                                                                                        \
+        const int kb_ = kb0 + min((i), last);                                                                \
+        _Pragma("unroll") for (int r = 0; r < XR; ++r)                                                       \
+        {                                                                                                    \
+            xs[set][r] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, xoff[r], kb_ * 256, 0);                 \
+        }                                                                                                    \
+    }
+#define TM_STORE_X(set, buf)                                                                                 \
+    _Pragma("unroll") for (int r = 0; r < XR; ++r)                                                           \
+    {                                                                                                        \
+        if (XFULL || xlds[r] >= 0) {                                                                         \
+            *(u32x4*)(smem + (buf)*BUFB + xlds[r]) = xs[set][r];                                             \
+        }                                                                                                    \
     }
 
-    for (int c = c_beg; c < c_end; ++c) {
-        __syncthreads();  // every wave is done reading the previous chunk
-        store_x();
-        __syncthreads();
-        if (c + 1 < c_end) {
-            load_x(c + 1);
-            load_w(c + 1, wnxt, snxt);
+    if (nkb > 0) {
+        // ---- prologue --------------------------------------------------------------------------
+        // Issue order matters: VMEM loads return IN ORDER, so a wait for x(i) also waits for every older
+        // load.  x(i) is therefore always issued right before w(i), PF iterations ahead of its use: no
+        // wait in the loop ever covers a load younger than PF-1 iterations.
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+            TM_LOAD_X(u, u);
+            TM_LOAD_W(u, u);
+            // pin the issue order: if the scheduler moves slot 0's loads to the end of the prologue, the waitcnt
+            // pass needs vmcnt(0) on the loop-entry edge and -- merging edges conservatively -- drains the whole
+            // ring at the top of EVERY trip (measured: 61 % of wave time in s_waitcnt)
+            __builtin_amdgcn_sched_barrier(0);
         }
+        TM_STORE_X(0, 0);
+        __syncthreads();
 
+        // ---- main loop: branch-free body, statically unrolled over the ring --------------------------
+        // Iterations past nkb (ring padding) contract zeroed weights, so they add exactly 0.
+        for (int base = 0; base < nkb; base += PF) {
 #pragma unroll
-        for (int kk = 0; kk < KBC; ++kk) {
+            for (int u = 0; u < PF; ++u) {
+                const int  i    = base + u;
+                const bool live = i < nkb;  // wave-uniform
+                const char* xb = smem + (u & 1) * BUFB;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                half8_t xf[MT];
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt) {
-                    const int ci = kk * 16 + j * 4 + g;
-                    xf[mt]       = *(const half8_t*)(smem + (mt * 16 + i16) * ROWB + ((ci ^ i16) << 4));
-                }
-#pragma unroll
-                for (int t = 0; t < NT; ++t) {
-                    half8_t wf;
-                    if constexpr (WT == 0) {
-                        const half2_t pr = bit_cast<half2_t>(scur[t][kk]);
-                        wf               = dequant8(wcur[t][kk][0][j], half2_t{pr[0], pr[0]}, half2_t{pr[1], pr[1]});
-                    }
-                    else {
-                        wf = bit_cast<half8_t>(wcur[t][kk][j]);
-                    }
+                for (int j = 0; j < 4; ++j) {
+                    half8_t xf[MT];
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt) {
-                        acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf, xf[mt], acc[t][mt], 0, 0, 0);
+                        xf[mt] = *(const half8_t*)(xb + (mt * 16 + i16) * ROWB + (((j * 4 + g) ^ i16) << 4));
+                    }
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) {
+                        half8_t wf;
+                        if constexpr (WT == 0) {
+                            const half2_t pr = bit_cast<half2_t>(live ? sring[u][t] : 0u);  // (s, -z*s) = 0 -> w = 0
+                            wf               = dequant8(ring[u][t][0][j], half2_t{pr[0], pr[0]}, half2_t{pr[1], pr[1]}, m1024, m64);
+                        }
+                        else {
+                            const u32x4 wv = ring[u][t][j];
+                            wf = bit_cast<half8_t>(live ? wv : u32x4{0u, 0u, 0u, 0u});
+                        }
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt) {
+                            acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf, xf[mt], acc[t][mt], 0, 0, 0);
+                        }
                     }
                 }
-            }
-        }
-
-        if (c + 1 < c_end) {
-#pragma unroll
-            for (int t = 0; t < NT; ++t) {
-#pragma unroll
-                for (int kk = 0; kk < KBC; ++kk) {
-#pragma unroll
-                    for (int v = 0; v < WV; ++v) {
-                        wcur[t][kk][v] = wnxt[t][kk][v];
-                    }
-                    scur[t][kk] = snxt[t][kk];
-                }
+                TM_STORE_X((u + 1) % PF, (u + 1) & 1);  // x(i+1), issued PF-1 iterations ago, -> the other LDS stage
+                TM_LOAD_X(u, i + PF);                   // refill slot u: x first, then w (see prologue)
+                TM_LOAD_W(u, i + PF);
+                __syncthreads();
             }
         }
     }
+#undef TM_LOAD_W
+#undef TM_LOAD_X
+#undef TM_STORE_X
 
     // ---- epilogue: lane holds y[m = m0+16mt+i16][n = 16(nt0+t) + 4g + r], r = 0..3 ------------------
 #pragma unroll
@@ -407,59 +441,70 @@ static int env_int(const char* name, int dflt)
 
 GemmConfig gemm_pick_config(const LinearWeight& w, int M)
 {
-    // Heuristic: keep >= ~256 workgroups in flight (one per CU) with as little split-K as possible.
-    // TM_GEMM_NT / TM_GEMM_SPLITS override (the tuner in tools/ uses them).
+    // Heuristic (measured on MI355X with tools/tune_gemm.py): the decode GEMMs are latency /
+    // occupancy bound, so aim at ~256..512 workgroups with the widest column tile that still gets there.
+    // TM_GEMM_NT / TM_GEMM_SPLITS / TM_GEMM_WAVES override.
     GemmConfig cfg{};
     const int  ntiles = w.N / 16;
     const int  KB     = w.K / 128;
     const int  mblk   = (M + 63) / 64;
     if (w.type == 1) {
-        cfg.nt = 2;
+        cfg.nt     = 2;
+        cfg.waves  = 4;
+        cfg.splits = 1;
+    }
+    else if (mblk > 1) {  // prefill: plenty of row blocks, maximise weight reuse per workgroup
+        cfg.nt     = 4;
+        cfg.waves  = 4;
+        cfg.splits = 1;
     }
     else {
-        cfg.nt = ntiles >= 4 * 4 * 256 / mblk ? 4 : (ntiles >= 2 * 4 * 256 / mblk ? 2 : (M > 64 ? 4 : 2));
+        // measured (tools/tune_gemm.py, Llama-3-8B decode shapes, M=64): 8 waves x 1 tile per wave wins everywhere;
+        // split-K only until ~256 workgroups exist and never below 8 k-blocks per slice (slab traffic + reduce).
+        cfg.waves = 8;
+        cfg.nt    = 1;
+        const int col_wgs = (ntiles + cfg.waves * cfg.nt - 1) / (cfg.waves * cfg.nt);
+        int       splits  = 1;
+        while (col_wgs * splits * 2 <= 256 && KB / (splits * 2) >= 8 && splits < 16) {
+            splits *= 2;
+        }
+        cfg.splits = splits;
     }
-    const int col_wgs = (ntiles + 4 * cfg.nt - 1) / (4 * cfg.nt);
-    int       splits  = 1;
-    const int kbc     = (w.type == 0 && KB % 2 == 0) ? 2 : 1;
-    const int chunks  = KB / kbc;
-    while (col_wgs * mblk * splits < 256 && splits * 2 <= chunks / 2 && splits < 16) {
-        splits *= 2;
-    }
-    cfg.splits = splits;
     cfg.nt     = env_int("TM_GEMM_NT", cfg.nt);
     cfg.splits = env_int("TM_GEMM_SPLITS", cfg.splits);
-    if (cfg.splits > chunks) {
-        cfg.splits = chunks;
+    cfg.waves  = env_int("TM_GEMM_WAVES", cfg.waves);
+    if (cfg.splits > KB) {
+        cfg.splits = KB;
     }
     return cfg;
 }
 
-template<int WT, int MT, int NT, int KBC>
+template<int WT, int MT, int NT, int WAVES, int PF>
 static int launch_one(const GemmParams& p, dim3 grid, hipStream_t st)
 {
-    constexpr int lds = 16 * MT * 128 * KBC * 2;
-    gemm_kernel<WT, MT, NT, KBC><<<grid, 256, lds, st>>>(p);
+    constexpr int lds = 2 * 16 * MT * 256;
+    gemm_kernel<WT, MT, NT, WAVES, PF><<<grid, WAVES * 64, lds, st>>>(p);
     TM_HIP_CHECK(hipGetLastError());
     return 0;
 }
 
 template<int WT, int MT>
-static int launch_mt(const GemmParams& p, dim3 grid, int nt, int kbc, hipStream_t st)
+static int launch_mt(const GemmParams& p, dim3 grid, int nt, int waves, hipStream_t st)
 {
+    // ring depth: 8 k-blocks when the K slice is long enough to use it, else 4 (padding iterations are wasted work)
+    const bool deep = p.kb_per_split >= 16;
     if constexpr (WT == 1) {
-        if (nt == 1) return launch_one<1, MT, 1, 1>(p, grid, st);
-        return launch_one<1, MT, 2, 1>(p, grid, st);
+        if (nt == 1) return launch_one<1, MT, 1, 4, 4>(p, grid, st);
+        return launch_one<1, MT, 2, 4, 2>(p, grid, st);
     }
     else {
-        if (kbc == 2) {
-            if (nt == 1) return launch_one<0, MT, 1, 2>(p, grid, st);
-            if (nt == 2) return launch_one<0, MT, 2, 2>(p, grid, st);
-            return launch_one<0, MT, 4, 2>(p, grid, st);
+        if (waves == 8) {
+            if (nt == 1) return deep ? launch_one<0, MT, 1, 8, 8>(p, grid, st) : launch_one<0, MT, 1, 8, 4>(p, grid, st);
+            return deep ? launch_one<0, MT, 2, 8, 8>(p, grid, st) : launch_one<0, MT, 2, 8, 4>(p, grid, st);
         }
-        if (nt == 1) return launch_one<0, MT, 1, 1>(p, grid, st);
-        if (nt == 2) return launch_one<0, MT, 2, 1>(p, grid, st);
-        return launch_one<0, MT, 4, 1>(p, grid, st);
+        if (nt == 1) return deep ? launch_one<0, MT, 1, 4, 8>(p, grid, st) : launch_one<0, MT, 1, 4, 4>(p, grid, st);
+        if (nt == 2) return deep ? launch_one<0, MT, 2, 4, 8>(p, grid, st) : launch_one<0, MT, 2, 4, 4>(p, grid, st);
+        return launch_one<0, MT, 4, 4, 4>(p, grid, st);
     }
 }
 
@@ -485,51 +530,53 @@ int launch_linear(const LinearWeight& w,
     if (M == 0) {
         return 0;
     }
-    int nt = cfg.nt;
-    if (w.type == 1 && nt > 2) {
+    int nt    = cfg.nt;
+    int waves = cfg.waves == 8 ? 8 : 4;
+    if (w.type == 1) {
+        waves = 4;
+        nt    = nt > 2 ? 2 : nt;
+    }
+    if (waves == 8 && nt > 2) {
         nt = 2;
     }
     TM_REQUIRE(nt == 1 || nt == 2 || nt == 4, "nt in {1,2,4}");
-    const int KB  = w.K / 128;
-    const int kbc = (w.type == 0 && KB % 2 == 0) ? 2 : 1;
-    const int mt  = M <= 16 ? 1 : (M <= 32 ? 2 : 4);
+    const int KB     = w.K / 128;
+    const int mt     = M <= 16 ? 1 : (M <= 32 ? 2 : 4);
     int       splits = cfg.splits < 1 ? 1 : cfg.splits;
-    const int chunks = KB / kbc;
-    if (splits > chunks) {
-        splits = chunks;
+    if (splits > KB) {
+        splits = KB;
     }
     TM_REQUIRE(splits == 1 || workspace != nullptr, "split-K needs a workspace");
     TM_REQUIRE(!defer_reduce || splits > 1, "defer_reduce only with split-K");
 
     GemmParams p{};
-    p.x                = x;
-    p.ldx              = ldx;
-    p.wq               = (const u32x4*)w.packed;
-    p.sz               = w.sz;
-    p.y                = y;
-    p.ldy              = ldy;
-    p.partial          = workspace;
-    p.M                = M;
-    p.N                = w.N;
-    p.K                = w.K;
-    p.KB               = KB;
-    p.total_chunks     = chunks;
-    p.chunks_per_split = (chunks + splits - 1) / splits;
-    splits             = (chunks + p.chunks_per_split - 1) / p.chunks_per_split;  // no empty splits
-    p.epilogue         = splits > 1 ? 2 : (gated_silu ? 1 : 0);
+    p.x            = x;
+    p.ldx          = ldx;
+    p.wq           = (const u32x4*)w.packed;
+    p.sz           = w.sz;
+    p.y            = y;
+    p.ldy          = ldy;
+    p.partial      = workspace;
+    p.M            = M;
+    p.N            = w.N;
+    p.K            = w.K;
+    p.KB           = KB;
+    p.kb_per_split = (KB + splits - 1) / splits;
+    splits         = (KB + p.kb_per_split - 1) / p.kb_per_split;  // no empty splits
+    p.epilogue     = splits > 1 ? 2 : (gated_silu ? 1 : 0);
 
     const int ntiles = w.N / 16;
-    dim3      grid((ntiles + 4 * nt - 1) / (4 * nt), splits, (M + 16 * mt - 1) / (16 * mt));
+    dim3      grid((ntiles + waves * nt - 1) / (waves * nt), splits, (M + 16 * mt - 1) / (16 * mt));
     int       rc = 0;
     if (w.type == 0) {
-        rc = mt == 1 ? launch_mt<0, 1>(p, grid, nt, kbc, st) :
-             mt == 2 ? launch_mt<0, 2>(p, grid, nt, kbc, st) :
-                       launch_mt<0, 4>(p, grid, nt, kbc, st);
+        rc = mt == 1 ? launch_mt<0, 1>(p, grid, nt, waves, st) :
+             mt == 2 ? launch_mt<0, 2>(p, grid, nt, waves, st) :
+                       launch_mt<0, 4>(p, grid, nt, waves, st);
     }
     else {
-        rc = mt == 1 ? launch_mt<1, 1>(p, grid, nt, kbc, st) :
-             mt == 2 ? launch_mt<1, 2>(p, grid, nt, kbc, st) :
-                       launch_mt<1, 4>(p, grid, nt, kbc, st);
+        rc = mt == 1 ? launch_mt<1, 1>(p, grid, nt, waves, st) :
+             mt == 2 ? launch_mt<1, 2>(p, grid, nt, waves, st) :
+                       launch_mt<1, 4>(p, grid, nt, waves, st);
     }
     if (rc) {
         return rc;

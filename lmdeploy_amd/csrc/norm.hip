@@ -60,11 +60,30 @@ __global__ __launch_bounds__(kNormThreads) void rmsnorm_kernel(half_t* __restric
                 r            = r + hcur;  // fp16 add, one rounding per element
             }
             if constexpr (MODE == 2) {
-                float acc[8] = {};
-                for (int s = 0; s < splits; ++s) {
-                    const float* p  = partial + ((size_t)s * M + row) * H + (size_t)vi * 8;
-                    floatx4      a0 = *(const floatx4*)p;
-                    floatx4      a1 = *(const floatx4*)(p + 4);
+                float        acc[8] = {};
+                const float* p0     = partial + (size_t)row * H + (size_t)vi * 8;
+                const size_t slab   = (size_t)M * H;
+                int          s      = 0;
+                // slabs are summed in order (deterministic); loads of 4 slabs are issued together
+                for (; s + 4 <= splits; s += 4) {
+                    floatx4 a[4][2];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        a[u][0] = *(const floatx4*)(p0 + (s + u) * slab);
+                        a[u][1] = *(const floatx4*)(p0 + (s + u) * slab + 4);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            acc[e] += a[u][0][e];
+                            acc[4 + e] += a[u][1][e];
+                        }
+                    }
+                }
+                for (; s < splits; ++s) {
+                    const floatx4 a0 = *(const floatx4*)(p0 + s * slab);
+                    const floatx4 a1 = *(const floatx4*)(p0 + s * slab + 4);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         acc[e] += a0[e];

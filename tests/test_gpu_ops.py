@@ -337,12 +337,12 @@ def test_w4a16_linear(tm, cuda, K, N, M):
     ref = x.astype(np.float32) @ _QCACHE[(K, N)][3]
     ws = torch.zeros(max(1, tm.tm_linear_workspace(h, M)), dtype=torch.uint8, device='cuda')
     x_d = dev(x)
-    for nt, splits in ((0, 0), (1, 1), (2, 2), (4, 4), (4, 1)):
+    for nt, splits, waves in ((0, 0, 0), (1, 1, 4), (2, 2, 4), (4, 4, 4), (1, 2, 8), (2, 1, 8), (2, 16, 8)):
         y = torch.zeros((M, N), dtype=torch.float16, device='cuda')
-        _ffi.check(tm.tm_linear_forward(h, x_d.data_ptr(), K, y.data_ptr(), N, M, 0, nt, splits, ws.data_ptr(), st()))
+        _ffi.check(tm.tm_linear_forward(h, x_d.data_ptr(), K, y.data_ptr(), N, M, 0, nt, splits, waves, ws.data_ptr(), st()))
         err = np.abs(host(y).astype(np.float32) - ref)
         tol = 2e-3 + 2.0**-10 * np.abs(ref)
-        assert np.all(err <= tol), f'nt={nt} splits={splits}: max err {err.max()} (ref max {np.abs(ref).max()})'
+        assert np.all(err <= tol), f'nt={nt} splits={splits} waves={waves}: max err {err.max()} (ref max {np.abs(ref).max()})'
     _ffi.check(tm.tm_linear_destroy(h))
 
 
@@ -353,9 +353,9 @@ def test_w4a16_gated_silu(tm, cuda, K, N, M):
     x = (rng.standard_normal((M, K)) * 3).astype(f16)
     ref = o.w4a16_linear_gated_silu(x, q, s, z).astype(np.float32)
     ws = torch.zeros(max(1, tm.tm_linear_workspace(h, M)), dtype=torch.uint8, device='cuda')
-    for nt, splits in ((0, 0), (2, 1), (4, 2)):
+    for nt, splits, waves in ((0, 0, 0), (2, 1, 4), (4, 2, 4), (2, 2, 8)):
         y = torch.zeros((M, N // 2), dtype=torch.float16, device='cuda')
-        _ffi.check(tm.tm_linear_forward(h, dev(x).data_ptr(), K, y.data_ptr(), N // 2, M, 1, nt, splits, ws.data_ptr(), st()))
+        _ffi.check(tm.tm_linear_forward(h, dev(x).data_ptr(), K, y.data_ptr(), N // 2, M, 1, nt, splits, waves, ws.data_ptr(), st()))
         err = np.abs(host(y).astype(np.float32) - ref)
         assert np.all(err <= 2e-3 + 2.0**-9 * np.abs(ref)), f'max err {err.max()}'
     _ffi.check(tm.tm_linear_destroy(h))
@@ -371,7 +371,7 @@ def test_w4a16_identity_asymmetric(tm, cuda):
     rows = rng.permutation(K)[:64]
     x[np.arange(64), rows] = 1
     y = torch.zeros((64, N), dtype=torch.float16, device='cuda')
-    _ffi.check(tm.tm_linear_forward(h, dev(x).data_ptr(), K, y.data_ptr(), N, 64, 0, 0, 1, None, st()))
+    _ffi.check(tm.tm_linear_forward(h, dev(x).data_ptr(), K, y.data_ptr(), N, 64, 0, 0, 1, 0, None, st()))
     assert np.array_equal(host(y).view(np.uint16), w[rows].view(np.uint16)), 'dequantised weights must be bit exact'
     _ffi.check(tm.tm_linear_destroy(h))
 
@@ -385,7 +385,7 @@ def test_f16_linear(tm, cuda, K, N, M):
     _ffi.check(tm.tm_linear_create(_ffi.C.byref(h), K, N, 1, 128))
     _ffi.check(tm.tm_linear_prepare(h, dev(w).data_ptr(), None, None, st()))
     y = torch.zeros((M, N), dtype=torch.float16, device='cuda')
-    _ffi.check(tm.tm_linear_forward(h, dev(x).data_ptr(), K, y.data_ptr(), N, M, 0, 0, 1, None, st()))
+    _ffi.check(tm.tm_linear_forward(h, dev(x).data_ptr(), K, y.data_ptr(), N, M, 0, 0, 1, 0, None, st()))
     ref = o.gemm_f16_f32acc(x, w)
     err = np.abs(host(y).astype(np.float32) - ref)
     assert np.all(err <= 1e-3 + 2.0**-10 * np.abs(ref)), f'max err {err.max()}'   # fixture.py gate for f16: 1e-2

@@ -47,9 +47,9 @@ def main():
         ws = torch.empty(max(1, tm.tm_linear_workspace(h, M)), dtype=torch.uint8, device='cuda')
         wbytes = K * N / 2 + K * N / 32
         best = None
-        for nt in (1, 2, 4):
-            for splits in (1, 2, 4, 8, 16):
-                if splits > K // 256:
+        for waves, nt, splits in [(w_, n_, s_) for w_ in (4, 8) for n_ in (1, 2, 4) for s_ in (1, 2, 4, 8, 16)]:
+            if True:
+                if splits > K // 256 or (waves == 8 and nt == 4):
                     continue
                 ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
                       for _ in range(args.iters)]
@@ -57,17 +57,17 @@ def main():
                     flush.fill_(1)
                     a.record()
                     _ffi.check(tm.tm_linear_forward(h, x.data_ptr(), K, y.data_ptr(), N // (2 if gated else 1), M, gated,
-                                                    nt, splits, ws.data_ptr(), st))
+                                                    nt, splits, waves, ws.data_ptr(), st))
                     b.record()
                 torch.cuda.synchronize()
                 ts = sorted(a.elapsed_time(b) for a, b in ev)
                 med = ts[len(ts) // 2]
                 gbs = wbytes / (med * 1e-3) / 1e9
-                print(f'{name:8s} K={K:6d} N={N:6d} M={M} nt={nt} splits={splits:2d}  {med*1e3:8.1f} us  {gbs:7.0f} GB/s',
+                print(f'{name:8s} K={K:6d} N={N:6d} M={M} waves={waves} nt={nt} splits={splits:2d}  {med*1e3:8.1f} us  {gbs:7.0f} GB/s',
                       flush=True)
                 if best is None or med < best[0]:
-                    best = (med, nt, splits, gbs)
-        results[name] = dict(K=K, N=N, us=best[0] * 1e3, nt=best[1], splits=best[2], gbs=best[3])
+                    best = (med, nt, splits, gbs, waves)
+        results[name] = dict(K=K, N=N, us=best[0] * 1e3, nt=best[1], splits=best[2], gbs=best[3], waves=best[4])
         _ffi.check(tm.tm_linear_destroy(h))
     print('BEST ' + json.dumps(results))
 
