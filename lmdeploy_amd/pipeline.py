@@ -1,0 +1,151 @@
+"""`lmdeploy.pipeline()` surface over the MI355X engine.
+
+Reference: lmdeploy/api.py:15-82 (pipeline), lmdeploy/pipeline.py:33-183,317-327 (Pipeline.infer / __call__ /
+stream_infer / close).  The reference routes through AsyncEngine + a continuous-batching scheduler; here the
+caller of the hot path is a static batcher (SURVEY 8f item 1 is the "next" row): prompts are processed in batches of
+at most `max_batch_size`, every batch = chunked prefill + greedy decode.
+"""
+from __future__ import annotations
+
+import os
+from typing import Sequence
+
+import numpy as np
+
+from . import _ffi
+from .messages import STATUS_TO_RESPONSE, GenerationConfig, Response, ResponseType, TurbomindEngineConfig
+from .turbomind import checkpoint
+from .turbomind.engine import Engine
+from .turbomind.loader import export_weights
+
+# synthetic model shapes (no checkpoints on disk in CI): "synthetic:<name>"
+SYNTHETIC = {
+    'llama3_8b': dict(hidden=4096, layers=32, q_heads=32, kv_heads=8, head_dim=128, inter=14336, vocab=128256,
+                      rope=checkpoint.RopeConfig(128, 500000.0, 'llama3', 8.0, 1.0, 4.0, 8192)),
+    'internlm2_1_8b': dict(hidden=2048, layers=24, q_heads=16, kv_heads=8, head_dim=128, inter=8192, vocab=92544,
+                           rope=checkpoint.RopeConfig(128, 1000000.0)),
+    'internlm2_20b': dict(hidden=6144, layers=48, q_heads=48, kv_heads=8, head_dim=128, inter=16384, vocab=92544,
+                          rope=checkpoint.RopeConfig(128, 1000000.0)),
+    'llama3_70b': dict(hidden=8192, layers=80, q_heads=64, kv_heads=8, head_dim=128, inter=28672, vocab=128256,
+                       rope=checkpoint.RopeConfig(128, 500000.0, 'llama3', 8.0, 1.0, 4.0, 8192)),
+    'tiny': dict(hidden=256, layers=2, q_heads=4, kv_heads=2, head_dim=128, inter=512, vocab=1024,
+                 rope=checkpoint.RopeConfig(128, 10000.0)),
+}
+
+
+class Pipeline:
+
+    def __init__(self, model_path: str, backend_config: TurbomindEngineConfig | None = None, rank: int = 0,
+                 comm_unique_id: bytes | None = None, **kwargs):
+        if kwargs.get('speculative_config') is not None or kwargs.get('chat_template_config') is not None:
+            raise NotImplementedError('speculative decoding / chat templates are outside the MI355X hot path')
+        cfg = backend_config or TurbomindEngineConfig()
+        if not isinstance(cfg, TurbomindEngineConfig):
+            raise NotImplementedError('only TurbomindEngineConfig is supported (the PyTorch engine is out of scope)')
+        self.backend_config = cfg
+        self.tokenizer = None
+        synthetic = model_path.startswith('synthetic:')
+        if synthetic:
+            self.model_cfg = checkpoint.ModelConfig(**SYNTHETIC[model_path.split(':', 1)[1]],
+                                                    quantized=cfg.model_format != 'hf')
+        else:
+            self.model_cfg = checkpoint.read_config(model_path)
+            if cfg.model_format == 'awq' and not self.model_cfg.quantized:
+                raise ValueError('model_format="awq" but the checkpoint has no AWQ quantization_config')
+        session_len = cfg.session_len or self.model_cfg.max_position_embeddings
+        devices = cfg.devices or list(range(cfg.tp))
+        self.engine = Engine.from_model_config(
+            self.model_cfg, weight_type=0 if self.model_cfg.quantized else 1, tp=cfg.tp, rank=rank,
+            device=devices[rank % len(devices)], max_batch_size=cfg.max_batch_size or 64, session_len=session_len,
+            quant_policy=int(cfg.quant_policy), cache_max_entry_count=cfg.cache_max_entry_count,
+            max_prefill_token_num=cfg.max_prefill_token_num or 8192)
+        if cfg.tp > 1:
+            if comm_unique_id is None:
+                raise ValueError('tp > 1: one process per GPU, pass the broadcast RCCL unique id as comm_unique_id')
+            self.engine.comm_init(comm_unique_id)
+        if synthetic:
+            self.engine.init_synthetic(seed=0)
+        else:
+            w = checkpoint.load_hf_weights(model_path, self.model_cfg)
+            self.engine.load_weights(export_weights(self.model_cfg, w, cfg.tp, rank))
+            if os.path.exists(os.path.join(model_path, 'tokenizer.json')) or \
+                    os.path.exists(os.path.join(model_path, 'tokenizer.model')):
+                from transformers import AutoTokenizer
+                self.tokenizer = AutoTokenizer.from_pretrained(model_path)
+        self.engine.start()
+        self.max_batch_size = cfg.max_batch_size or 64
+
+    # ---- reference-compatible entry points -----------------------------------------------------------
+    def __call__(self, prompts, gen_config: GenerationConfig | None = None, **kwargs):
+        return self.infer(prompts, gen_config, **kwargs)
+
+    def infer(self, prompts, gen_config: GenerationConfig | None = None, **kwargs) -> list[Response] | Response:
+        single = isinstance(prompts, str) or (len(prompts) > 0 and isinstance(prompts[0], (int, np.integer)))
+        batch = [prompts] if single else list(prompts)
+        out = []
+        for res in self._generate(batch, gen_config or GenerationConfig()):
+            out.append(res)
+        return out[0] if single else out
+
+    def stream_infer(self, prompts, gen_config: GenerationConfig | None = None, **kwargs):
+        """Static batching: a response is yielded when its batch has finished."""
+        yield from self._generate(list(prompts), gen_config or GenerationConfig())
+
+    def close(self):
+        self.engine.close()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    # ---- static batcher ----------------------------------------------------------------------------------
+    def _encode(self, p) -> np.ndarray:
+        if isinstance(p, str):
+            if self.tokenizer is None:
+                raise ValueError('string prompts need a tokenizer in the model directory; pass token ids instead')
+            return np.asarray(self.tokenizer.encode(p), np.int32)
+        return np.asarray(p, np.int32)
+
+    def _stop_ids(self, g: GenerationConfig) -> set:
+        ids = set(g.stop_token_ids or [])
+        if not g.ignore_eos and self.model_cfg.eos_token_id is not None:
+            e = self.model_cfg.eos_token_id
+            ids |= set(e if isinstance(e, (list, tuple)) else [e])
+        return ids
+
+    def _generate(self, prompts: Sequence, g: GenerationConfig):
+        ids = [self._encode(p) for p in prompts]
+        stop = self._stop_ids(g)
+        for b0 in range(0, len(ids), self.max_batch_size):
+            chunk = ids[b0:b0 + self.max_batch_size]
+            try:
+                self.engine.prefill(chunk, max_new_tokens=g.max_new_tokens)
+                done = 1
+                while done < g.max_new_tokens:
+                    n = min(32, g.max_new_tokens - done)
+                    self.engine.decode(n)
+                    done += n
+                    if stop:
+                        toks = self.engine.fetch()
+                        if all(any(int(t) in stop for t in row) for row in toks):
+                            break
+                toks = self.engine.fetch()
+            except _ffi.TmError as e:
+                self.engine.release()
+                rt = STATUS_TO_RESPONSE.get(e.status, ResponseType.INTERNAL_ENGINE_ERROR)
+                for i in range(len(chunk)):
+                    yield Response('', 0, len(chunk[i]), 'error', [], index=b0 + i, error_code=rt.name,
+                                   error_message=str(e))
+                continue
+            self.engine.release()
+            for i, row in enumerate(toks):
+                out, reason = [], 'length'
+                for tkn in row.tolist():
+                    if tkn in stop:
+                        reason = 'stop'
+                        break
+                    out.append(tkn)
+                text = self.tokenizer.decode(out, skip_special_tokens=g.skip_special_tokens) if self.tokenizer else ''
+                yield Response(text, len(out), len(chunk[i]), reason, out, index=b0 + i)

@@ -1,0 +1,173 @@
+"""HF checkpoint -> logical TM-layout weights (the on-disk side of the boundary).
+
+Host-side mirror of the reference loader for Llama / InternLM2 with AWQ (W4A16 g128) or fp16 weights:
+  * source models                    lmdeploy/turbomind/models/llama.py:45-101, internlm2.py:34-87
+  * AWQ normalize (unpack order)     lmdeploy/turbomind/weight_format.py:200-234
+  * RoPE q/k channel permutation     lmdeploy/turbomind/models/utils.py:306-373 (weight, scales and zeros alike)
+  * QKV fusion / w1w3 interleave     lmdeploy/turbomind/builders/attention.py:65-108, ffn.py:31-65,138-170
+  * config -> engine model config    lmdeploy/turbomind/converter.py:154-259
+HF linears are [out, in]; TM layout is [in, out] (= AWQ's native [K, N/8] packing for quantised tensors).
+"""
+from __future__ import annotations
+
+import json
+import os
+from dataclasses import dataclass, field
+from glob import glob
+
+import numpy as np
+
+from .loader import interleave_gate_up, permute_qk_for_interleaved_rope, unpack_awq_gemm
+
+
+@dataclass
+class RopeConfig:
+    dim: int = 128
+    base: float = 10000.0
+    type: str = 'default'
+    factor: float = 1.0
+    low_freq_factor: float = 1.0
+    high_freq_factor: float = 4.0
+    original_max_position_embeddings: int = 8192
+
+
+@dataclass
+class ModelConfig:
+    hidden: int
+    layers: int
+    q_heads: int
+    kv_heads: int
+    head_dim: int
+    inter: int
+    vocab: int
+    rms_eps: float = 1e-5
+    rope: RopeConfig = field(default_factory=RopeConfig)
+    group: int = 128
+    arch: str = 'llama'
+    quantized: bool = True
+    eos_token_id: int | list | None = None
+    max_position_embeddings: int = 8192
+
+
+def read_config(model_path: str) -> ModelConfig:
+    with open(os.path.join(model_path, 'config.json')) as f:
+        c = json.load(f)
+    arch = (c.get('architectures') or ['LlamaForCausalLM'])[0]
+    kind = 'internlm2' if 'InternLM2' in arch else 'llama'
+    if kind == 'llama' and 'Llama' not in arch and 'Mistral' not in arch:
+        raise NotImplementedError(f'architecture {arch}: the MI355X hot path covers Llama / InternLM2 decoders')
+    H = c['hidden_size']
+    heads = c['num_attention_heads']
+    D = c.get('head_dim') or H // heads
+    q = c.get('quantization_config')
+    if q is not None:
+        if q.get('quant_method') != 'awq' or q.get('bits', 4) != 4 or q.get('group_size', 128) != 128:
+            raise NotImplementedError(f'quantization_config {q}: only AWQ 4-bit group 128 '
+                                      f'(lmdeploy/turbomind/converter.py:86-92)')
+    rope = RopeConfig(dim=D, base=float(c.get('rope_theta', 10000.0)))
+    rs = c.get('rope_scaling')
+    if rs:
+        t = rs.get('rope_type', rs.get('type'))
+        if t == 'llama3':
+            rope = RopeConfig(D, rope.base, 'llama3', float(rs['factor']), float(rs.get('low_freq_factor', 1.0)),
+                              float(rs.get('high_freq_factor', 4.0)), int(rs.get('original_max_position_embeddings', 8192)))
+        elif t == 'linear':
+            rope = RopeConfig(D, rope.base, 'linear', float(rs['factor']))
+        elif t not in (None, 'default'):
+            raise NotImplementedError(f'rope_scaling type {t}')
+    return ModelConfig(hidden=H, layers=c['num_hidden_layers'], q_heads=heads,
+                       kv_heads=c.get('num_key_value_heads', heads), head_dim=D, inter=c['intermediate_size'],
+                       vocab=c['vocab_size'], rms_eps=float(c.get('rms_norm_eps', 1e-5)), rope=rope, arch=kind,
+                       quantized=q is not None, eos_token_id=c.get('eos_token_id'),
+                       max_position_embeddings=int(c.get('max_position_embeddings', 8192)))
+
+
+class _Tensors:
+    """Lazy name -> numpy lookup over every *.safetensors shard of a checkpoint."""
+
+    def __init__(self, model_path: str):
+        from safetensors import safe_open
+        self._files = []
+        self._index = {}
+        for fn in sorted(glob(os.path.join(model_path, '*.safetensors'))):
+            f = safe_open(fn, framework='np')
+            self._files.append(f)
+            for k in f.keys():
+                self._index[k] = f
+        if not self._index:
+            raise FileNotFoundError(f'no *.safetensors under {model_path}')
+
+    def __contains__(self, k):
+        return k in self._index
+
+    def get(self, k) -> np.ndarray:
+        return self._index[k].get_tensor(k)
+
+
+def _linear(t: _Tensors, prefix: str, quantized: bool) -> dict:
+    """-> {'q','s','z'} (uint8 [K,N], fp16 [K/g,N] x2) or {'w'} fp16 [K,N]."""
+    if quantized and (prefix + '.qweight') in t:
+        return dict(q=unpack_awq_gemm(t.get(prefix + '.qweight')),
+                    s=t.get(prefix + '.scales').astype(np.float16),
+                    z=unpack_awq_gemm(t.get(prefix + '.qzeros')).astype(np.float16))
+    return dict(w=np.ascontiguousarray(t.get(prefix + '.weight').astype(np.float16).T))
+
+
+def _cat(parts: list) -> dict:
+    return {k: np.concatenate([p[k] for p in parts], axis=-1) for k in parts[0]}
+
+
+def _map(lin: dict, fn) -> dict:
+    return {k: fn(v) for k, v in lin.items()}
+
+
+def load_hf_weights(model_path: str, cfg: ModelConfig) -> dict:
+    t = _Tensors(model_path)
+    D, Hq, Hkv = cfg.head_dim, cfg.q_heads, cfg.kv_heads
+    layers = []
+    for i in range(cfg.layers):
+        if cfg.arch == 'llama':
+            p = f'model.layers.{i}'
+            q = _linear(t, p + '.self_attn.q_proj', cfg.quantized)
+            k = _linear(t, p + '.self_attn.k_proj', cfg.quantized)
+            v = _linear(t, p + '.self_attn.v_proj', cfg.quantized)
+            wo = _linear(t, p + '.self_attn.o_proj', cfg.quantized)
+            w1 = _linear(t, p + '.mlp.gate_proj', cfg.quantized)
+            w3 = _linear(t, p + '.mlp.up_proj', cfg.quantized)
+            w2 = _linear(t, p + '.mlp.down_proj', cfg.quantized)
+            n1 = t.get(p + '.input_layernorm.weight')
+            n2 = t.get(p + '.post_attention_layernorm.weight')
+        else:   # internlm2: fused wqkv, per kv group [q_0..q_{g-1}, k, v] (models/internlm2.py:34-87)
+            p = f'model.layers.{i}'
+            wqkv = _linear(t, p + '.attention.wqkv', cfg.quantized)
+            g = Hq // Hkv
+
+            def split(x):
+                lead = x.shape[:-1]
+                x = x.reshape(*lead, Hkv, g + 2, D)
+                return (x[..., :g, :].reshape(*lead, Hq * D), x[..., g, :].reshape(*lead, Hkv * D),
+                        x[..., g + 1, :].reshape(*lead, Hkv * D))
+            parts = {k_: split(v_) for k_, v_ in wqkv.items()}
+            q = {k_: parts[k_][0] for k_ in parts}
+            k = {k_: parts[k_][1] for k_ in parts}
+            v = {k_: parts[k_][2] for k_ in parts}
+            wo = _linear(t, p + '.attention.wo', cfg.quantized)
+            w1 = _linear(t, p + '.feed_forward.w1', cfg.quantized)
+            w3 = _linear(t, p + '.feed_forward.w3', cfg.quantized)
+            w2 = _linear(t, p + '.feed_forward.w2', cfg.quantized)
+            n1 = t.get(p + '.attention_norm.weight')
+            n2 = t.get(p + '.ffn_norm.weight')
+        q = _map(q, lambda a: permute_qk_for_interleaved_rope(a, Hq, D))
+        k = _map(k, lambda a: permute_qk_for_interleaved_rope(a, Hkv, D))
+        layers.append(dict(attn_norm=n1.astype(np.float16), ffn_norm=n2.astype(np.float16), w_qkv=_cat([q, k, v]), wo=wo,
+                           w1w3={kk: interleave_gate_up(w1[kk], w3[kk]) for kk in w1}, w2=w2))
+    if cfg.arch == 'llama':
+        emb = t.get('model.embed_tokens.weight')
+        norm = t.get('model.norm.weight')
+        head = t.get('lm_head.weight') if 'lm_head.weight' in t else emb
+    else:
+        emb = t.get('model.tok_embeddings.weight')
+        norm = t.get('model.norm.weight')
+        head = t.get('output.weight')
+    return dict(tok_embeddings=emb.astype(np.float16), layers=layers, norm=norm.astype(np.float16),
+                output=np.ascontiguousarray(head.astype(np.float16).T))

@@ -70,3 +70,20 @@ def test_engine_errors_are_status_codes(cuda):
     with pytest.raises(_ffi.TmError):
         eng.decode(1)                    # past max_new_tokens
     eng.close()
+
+
+def test_pipeline_surface_on_gpu(cuda):
+    """lmdeploy.pipeline()-style call path end to end on synthetic weights (no checkpoints on disk)."""
+    import lmdeploy_amd
+    pipe = lmdeploy_amd.pipeline('synthetic:tiny', backend_config=lmdeploy_amd.TurbomindEngineConfig(
+        quant_policy=8, session_len=256, max_batch_size=2))
+    prompts = [list(range(5, 40)), list(range(100, 103)), list(range(7, 90))]      # 3 prompts, batches of 2
+    res = pipe(prompts, lmdeploy_amd.GenerationConfig(max_new_tokens=5, ignore_eos=True))
+    assert [r.index for r in res] == [0, 1, 2]
+    assert all(r.generate_token_len == 5 and r.finish_reason == 'length' for r in res)
+    assert [r.input_token_len for r in res] == [35, 3, 83]
+    again = pipe(prompts[0], lmdeploy_amd.GenerationConfig(max_new_tokens=5, ignore_eos=True))
+    assert again.token_ids == res[0].token_ids            # batch composition must not change a sequence's tokens
+    too_long = pipe([list(range(300))], lmdeploy_amd.GenerationConfig(max_new_tokens=5))
+    assert too_long[0].finish_reason == 'error' and too_long[0].error_code == 'INPUT_LENGTH_ERROR'
+    pipe.close()

@@ -1,0 +1,200 @@
+"""CPU tests of the host side: the C-ABI library loads and exports every symbol include/tm_mi355x.h declares (no
+compute calls without a GPU), the loader's layout / sharding logic, the HF AWQ checkpoint reader on a fabricated
+checkpoint, and the lmdeploy-compatible API surface."""
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+
+from lmdeploy_amd import GenerationConfig, QuantPolicy, TurbomindEngineConfig, _ffi
+from lmdeploy_amd.turbomind import checkpoint, loader
+from oracle import tm_oracle as o
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+f16 = np.float16
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, 'include', 'tm_mi355x.h')).read()
+    declared = set(re.findall(r'\b(tm_[a-z0-9_]+)\s*\(', hdr))
+    declared -= {'tm_status'}
+    lib = _ffi.load()
+    for name in sorted(declared):
+        assert hasattr(lib, name), f'{name} declared in include/tm_mi355x.h but not exported'
+    assert declared == set(_ffi.EXPORTED_SYMBOLS), declared ^ set(_ffi.EXPORTED_SYMBOLS)
+    assert lib.tm_version() >= 100
+    assert lib.tm_device_count() >= 0
+    assert lib.tm_kv_layer_size(8, 128, 64, 8) == 135168
+    assert lib.tm_kv_layer_size(8, 128, 64, 4) == 69632
+    assert lib.tm_kv_layer_size(1, 128, 64, 4) == 8704             # 70B / TP8 per rank
+
+
+def test_errors_are_status_codes_not_exceptions():
+    lib = _ffi.load()
+    rc = lib.tm_rmsnorm(None, None, None, 1e-5, 1, 8, None)
+    assert rc == 1 and 'null' in _ffi.last_error()
+    h = _ffi.C.c_void_p()
+    assert lib.tm_linear_create(_ffi.C.byref(h), 128, 16, 7, 128) == 1      # bad weight type
+    cfg = _ffi.EngineConfig()
+    e = _ffi.C.c_void_p()
+    assert lib.tm_engine_create(_ffi.C.byref(e), _ffi.C.byref(cfg)) == 1   # head_dim must be 128 ...
+
+
+def test_rope_table_on_host_matches_oracle():
+    lib = _ffi.load()
+    p = o.RopeParam(128, 500000.0, 'llama3', 8.0, 1.0, 4.0, 8192)
+    tab = np.zeros((2049, 64, 2), f16)
+    assert lib.tm_rope_table(tab.ctypes.data, 2049, 128, p.base, 2, p.factor, p.low_freq_factor, p.high_freq_factor,
+                             p.original_max_position_embeddings) == 0
+    c, s = o.rope_cos_sin(p, np.arange(2049))
+    assert np.array_equal(tab[..., 0].view(np.uint16), c.view(np.uint16))
+    assert np.array_equal(tab[..., 1].view(np.uint16), s.view(np.uint16))
+
+
+def test_loader_layout_helpers_match_oracle():
+    rng = np.random.default_rng(0)
+    q = rng.integers(0, 16, (64, 32), dtype=np.uint8)
+    assert np.array_equal(loader.pack_u4_row(q), o.pack_u4_row(q))
+    assert np.array_equal(loader.unpack_awq_gemm(o.pack_awq_gemm(q)), q)
+    w = rng.standard_normal((4, 2 * 128)).astype(f16)
+    assert np.array_equal(loader.permute_qk_for_interleaved_rope(w, 2, 128), o.permute_qk_for_interleaved_rope(w, 2, 128))
+    a, b = rng.standard_normal((3, 5)), rng.standard_normal((3, 5))
+    assert np.array_equal(loader.interleave_gate_up(a, b), o.interleave_w1w3(a, b))
+
+
+@pytest.mark.parametrize('tp', [1, 2, 4])
+def test_export_weights_tp_sharding_reassembles(tp):
+    """Column-parallel shards concatenate back to the full tensor, row-parallel shards partition K; sharded linear
+    outputs sum to the unsharded output (builders/_base.py:102-113)."""
+    cfg = o.ModelConfig(hidden=256, layers=1, q_heads=4, kv_heads=2, head_dim=128, inter=512, vocab=64)
+    w = o.make_synthetic_weights(cfg, seed=2)
+    shards = [loader.export_weights(cfg, w, tp, r) for r in range(tp)]
+    L = w['layers'][0]
+    D, Hq, Hkv = 128, 4, 2
+    full_q = o.unpack_u4_row(loader.pack_u4_row(L['w_qkv']['q']))
+    hq_l = Hq // tp
+    for r, s in enumerate(shards):
+        got = o.unpack_u4_row(s['layers.0.attention.w_qkv.qweight'])
+        kv0 = r * (Hkv // tp) if Hkv >= tp else r // (tp // Hkv)
+        hkv_l = max(1, Hkv // tp)
+        exp = np.concatenate([full_q[:, r * hq_l * D:(r + 1) * hq_l * D],
+                              full_q[:, Hq * D + kv0 * D: Hq * D + (kv0 + hkv_l) * D],
+                              full_q[:, (Hq + Hkv) * D + kv0 * D:(Hq + Hkv) * D + (kv0 + hkv_l) * D]], -1)
+        assert np.array_equal(got, exp)
+        assert s['layers.0.attention.w_qkv.scales'].shape == (2, exp.shape[1])
+    wo = np.concatenate([o.unpack_u4_row(s['layers.0.attention.wo.qweight']) for s in shards], 0)
+    assert np.array_equal(wo, L['wo']['q'])
+    w13 = np.concatenate([o.unpack_u4_row(s['layers.0.feed_forward.w1w3.qweight']) for s in shards], 1)
+    assert np.array_equal(w13, L['w1w3']['q'])
+    head = np.concatenate([s['output.weight'] for s in shards], 1)
+    assert np.array_equal(head, w['output'])
+    # numerics: sum of row-parallel partial products == full product
+    x = np.random.default_rng(1).standard_normal((3, 512)).astype(f16)
+    full = o.gemm_f16_f32acc(x, o.w4a16_dequant(L['w2']['q'], L['w2']['s'], L['w2']['z']))
+    part = 0
+    for r, s in enumerate(shards):
+        k0, k1 = r * 512 // tp, (r + 1) * 512 // tp
+        qq = o.unpack_u4_row(s['layers.0.feed_forward.w2.qweight'])
+        part = part + o.gemm_f16_f32acc(x[:, k0:k1], o.w4a16_dequant(qq, s['layers.0.feed_forward.w2.scales'],
+                                                                      s['layers.0.feed_forward.w2.zeros']))
+    assert np.allclose(part, full, rtol=1e-5, atol=1e-5)
+
+
+def _fabricate_llama_awq(tmp_path, cfg, w_hf):
+    from safetensors.numpy import save_file
+    tensors = {}
+
+    def put_awq(name, w_kn):   # w_kn fp16 [K, N] -> AWQ qweight/qzeros/scales
+        q, s, z, _ = o.quantize_groupwise_u4(w_kn, 128)
+        tensors[name + '.qweight'] = o.pack_awq_gemm(q)
+        tensors[name + '.qzeros'] = o.pack_awq_gemm(z.astype(np.uint8))
+        tensors[name + '.scales'] = s
+        return q, s, z
+    quant = {}
+    for k, v in w_hf.items():
+        if v.ndim == 2 and 'proj' in k:
+            quant[k] = put_awq(k, v)
+        else:
+            tensors[k + '.weight'] = v
+    save_file(tensors, os.path.join(tmp_path, 'model.safetensors'))
+    json.dump({'architectures': ['LlamaForCausalLM'], 'hidden_size': cfg.hidden, 'num_hidden_layers': cfg.layers,
+               'num_attention_heads': cfg.q_heads, 'num_key_value_heads': cfg.kv_heads, 'head_dim': cfg.head_dim,
+               'intermediate_size': cfg.inter, 'vocab_size': cfg.vocab, 'rms_norm_eps': 1e-5, 'rope_theta': 500000.0,
+               'rope_scaling': {'rope_type': 'llama3', 'factor': 8.0, 'low_freq_factor': 1.0, 'high_freq_factor': 4.0,
+                                'original_max_position_embeddings': 8192}, 'eos_token_id': 2,
+               'quantization_config': {'quant_method': 'awq', 'bits': 4, 'group_size': 128, 'zero_point': True}},
+              open(os.path.join(tmp_path, 'config.json'), 'w'))
+    return quant
+
+
+def test_hf_awq_checkpoint_reader(tmp_path):
+    rng = np.random.default_rng(0)
+    cfg = o.ModelConfig(hidden=256, layers=1, q_heads=4, kv_heads=2, head_dim=128, inter=256, vocab=96)
+    H, D = 256, 128
+    p = 'model.layers.0'
+    w_hf = {f'{p}.self_attn.q_proj': rng.standard_normal((H, 4 * D)).astype(f16) * f16(0.05),
+            f'{p}.self_attn.k_proj': rng.standard_normal((H, 2 * D)).astype(f16) * f16(0.05),
+            f'{p}.self_attn.v_proj': rng.standard_normal((H, 2 * D)).astype(f16) * f16(0.05),
+            f'{p}.self_attn.o_proj': rng.standard_normal((4 * D, H)).astype(f16) * f16(0.05),
+            f'{p}.mlp.gate_proj': rng.standard_normal((H, 256)).astype(f16) * f16(0.05),
+            f'{p}.mlp.up_proj': rng.standard_normal((H, 256)).astype(f16) * f16(0.05),
+            f'{p}.mlp.down_proj': rng.standard_normal((256, H)).astype(f16) * f16(0.05),
+            f'{p}.input_layernorm': np.ones(H, f16), f'{p}.post_attention_layernorm': np.ones(H, f16),
+            'model.embed_tokens': rng.standard_normal((96, H)).astype(f16), 'model.norm': np.ones(H, f16),
+            'lm_head': rng.standard_normal((96, H)).astype(f16)}
+    quant = _fabricate_llama_awq(str(tmp_path), cfg, w_hf)
+    mc = checkpoint.read_config(str(tmp_path))
+    assert (mc.hidden, mc.q_heads, mc.kv_heads, mc.rope.type, mc.rope.factor, mc.quantized) == (256, 4, 2, 'llama3', 8.0, True)
+    w = checkpoint.load_hf_weights(str(tmp_path), mc)
+    L = w['layers'][0]
+    qq, _, _ = quant[f'{p}.self_attn.q_proj']
+    kq, _, _ = quant[f'{p}.self_attn.k_proj']
+    vq, vs, _ = quant[f'{p}.self_attn.v_proj']
+    exp = np.concatenate([o.permute_qk_for_interleaved_rope(qq, 4, D), o.permute_qk_for_interleaved_rope(kq, 2, D), vq], -1)
+    assert np.array_equal(L['w_qkv']['q'], exp)
+    assert np.array_equal(L['w_qkv']['s'][:, -2 * D:], vs)
+    g, _, _ = quant[f'{p}.mlp.gate_proj']
+    u, _, _ = quant[f'{p}.mlp.up_proj']
+    assert np.array_equal(L['w1w3']['q'], o.interleave_w1w3(g, u))
+    assert np.array_equal(w['output'], w_hf['lm_head'].T)
+    slots = loader.export_weights(mc, w, 1, 0)
+    assert slots['layers.0.attention.w_qkv.qweight'].shape == (H, 8 * D // 8)
+    assert slots['layers.0.attention.w_qkv.qweight'].dtype == np.int32
+
+
+def test_api_surface_and_validation():
+    c = TurbomindEngineConfig(tp=8, quant_policy=4, session_len=4096, max_batch_size=128, model_format='awq')
+    assert c.quant_policy == QuantPolicy.INT4 and c.cache_block_seq_len == 64 and c.max_prefill_token_num == 8192
+    with pytest.raises(ValueError):
+        TurbomindEngineConfig(quant_policy=3)
+    with pytest.raises(AssertionError):
+        TurbomindEngineConfig(quant_policy=16)              # FP8 KV is rejected by the reference for TurboMind too
+    for bad in (dict(dp=2), dict(enable_prefix_caching=True), dict(dtype='bfloat16'), dict(model_format='fp8'),
+                dict(cache_block_seq_len=128), dict(communicator='native')):
+        with pytest.raises(NotImplementedError):
+            TurbomindEngineConfig(**bad)
+    g = GenerationConfig(max_new_tokens=7, ignore_eos=True)
+    assert g.top_k == 50 and not g.do_sample
+    with pytest.raises(NotImplementedError):
+        GenerationConfig(do_sample=True)
+    import inspect
+
+    import lmdeploy_amd
+    sig = inspect.signature(lmdeploy_amd.pipeline)
+    assert list(sig.parameters)[:2] == ['model_path', 'backend_config']
+    for m in ('infer', 'stream_infer', '__call__', 'close'):
+        assert hasattr(lmdeploy_amd.Pipeline, m)
+
+
+def test_product_code_never_imports_the_oracle():
+    """The product path must fail loudly without the HIP library -- and must not route through oracle/."""
+    bad = []
+    for root, _, files in os.walk(os.path.join(ROOT, 'lmdeploy_amd')):
+        for fn in files:
+            if fn.endswith('.py'):
+                src = open(os.path.join(root, fn)).read()
+                if re.search(r'^\s*(from|import)\s+oracle\b', src, re.M) or 'tm_oracle' in src:
+                    bad.append(fn)
+    assert not bad, bad

@@ -1,0 +1,202 @@
+"""CPU tests: the oracle against (a) golden vectors produced by the reference's own Python
+(tests/golden/reference_python.npz, generator committed next to it), (b) the reference's known-answer tests,
+(c) domain properties (round trips, split-K invariance, block-table permutation invariance)."""
+import math
+import os
+
+import numpy as np
+import pytest
+from hypothesis import given, settings
+from hypothesis import strategies as st
+
+from oracle import tm_oracle as o
+
+f16 = np.float16
+GOLD = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'reference_python.npz'))
+
+
+# ---- (a) golden vectors from the reference's Python ---------------------------------------------------------------
+def test_awq_unpack_matches_reference_weight_format():
+    assert np.array_equal(o.unpack_awq_gemm(GOLD['awq_qweight']), GOLD['awq_unpacked'])
+    assert np.array_equal(o.unpack_awq_gemm(GOLD['awq_qzeros']), GOLD['awq_zeros_unpacked'])
+    assert np.array_equal(o.pack_u4_row(GOLD['awq_unpacked']), GOLD['awq_packed_row'])
+    assert np.array_equal(o.unpack_u4_row(GOLD['awq_packed_row']), GOLD['awq_unpacked'])
+    assert np.array_equal(o.pack_awq_gemm(GOLD['awq_unpacked']), GOLD['awq_qweight'])
+
+
+def test_awq_dequant_matches_reference_formula():
+    """(q - z) * s: AWQFormat.dequant (weight_format.py:236-247) and the PyTorchEngine default backend
+    (awq_modules.py:37-46) agree with each other and with the oracle bit for bit."""
+    q, z, s = GOLD['awq_unpacked'], GOLD['awq_zeros_unpacked'].astype(f16), GOLD['awq_scales']
+    w = o.awq_dequant_ref(q, s, z)
+    assert np.array_equal(w.view(np.uint16), GOLD['awq_dequant'].view(np.uint16))
+    assert np.array_equal(w.view(np.uint16), GOLD['awq_dequantize_gemm'].view(np.uint16))
+    # TurboMind's kernel form fma(q, s, h(-z*s)) differs from (q-z)*s only by the rounding of z*s (<= half an ulp
+    # of |z*s|) plus one final rounding: an ABSOLUTE bound (near q == z the two forms cancel differently)
+    wt = o.w4a16_dequant(q, s, z).astype(np.float32)
+    zs = np.repeat(np.abs(z.astype(np.float32) * s.astype(np.float32)), 128, axis=0)
+    assert np.all(np.abs(wt - w.astype(np.float32)) <= 2.0**-10 * np.maximum(zs, np.abs(wt)) + 1e-8)
+    y = o.gemm_f16_f32acc(GOLD['awq_x'], w)
+    assert np.allclose(y, GOLD['awq_y_fp32'], rtol=1e-5, atol=1e-5)
+
+
+def test_rmsnorm_matches_reference_default_backend():
+    y = o.rmsnorm_torch_default(GOLD['norm_x'], GOLD['norm_w'], 1e-5)
+    assert np.array_equal(y.view(np.uint16), GOLD['norm_y'].view(np.uint16))
+    y2, r2 = o.rmsnorm_torch_default(GOLD['norm_x'], GOLD['norm_w'], 1e-5, GOLD['norm_res'])
+    assert np.array_equal(r2.view(np.uint16), GOLD['norm_res_out'].view(np.uint16))
+    assert np.array_equal(y2.view(np.uint16), GOLD['norm_y_res'].view(np.uint16))
+    # the TurboMind fp16-rounding form stays within one fp16 ulp of it
+    yt = o.rmsnorm(GOLD['norm_x'], GOLD['norm_w'], 1e-5)
+    d = np.abs(yt.view(np.int16).astype(np.int32) - GOLD['norm_y'].view(np.int16).astype(np.int32))
+    assert d.max() <= 1
+
+
+def test_silu_matches_reference_default_backend():
+    x = GOLD['silu_in']
+    half = x.shape[1] // 2
+    ours = o.silu_and_mul_unfused(x)
+    # reference: silu in fp16 (torch) * up; ours: fp32 silu.  <= 2 fp16 ulp
+    d = np.abs(ours.astype(np.float32) - GOLD['silu_out'].astype(np.float32))
+    assert np.all(d <= 2.0**-9 * np.abs(GOLD['silu_out'].astype(np.float32)) + 1e-4)
+    assert half == GOLD['silu_out'].shape[1]
+
+
+# ---- (b) known-answer tests of the reference ---------------------------------------------------------------------
+@pytest.mark.parametrize('bits,hi', [(8, 256), (4, 16)])
+def test_kv_round_trip_known_answer(bits, hi):
+    """kernels/attention/test_quant.cu:32-70: integer-valued data survives T -> u8/u4 -> T exactly with
+    (scale, zero) = (1, 0)."""
+    rng = np.random.default_rng(bits)
+    x = rng.integers(0, hi, (4096, 128)).astype(f16)
+    one, zero = np.ones(4096, f16), np.zeros(4096, f16)
+    q = o.kv_quantize_values(x, one, zero, bits)
+    data = q if bits == 8 else o.kv_pack_int4(q)
+    back = data if bits == 8 else o.kv_unpack_int4(data)
+    assert np.array_equal(o.kv_dequant_flatten(back, one, zero), x)
+    assert np.array_equal(o.kv_dequant_decode(back, one, zero), x)
+    # the biased u4 variant of the test: zero = -64 applied to codes offset by 64 is the same identity
+    if bits == 4:
+        assert np.array_equal(o.kv_dequant_flatten(back.astype(np.int32) + 64, one, np.full(4096, -64, f16)), x)
+
+
+def test_kv_int4_nibble_order():
+    """quantization.h:459-471: word = nibbles [q0,q2,q4,q6,q1,q3,q5,q7], LSB first."""
+    q = np.arange(8, dtype=np.uint8)[None]
+    b = o.kv_pack_int4(q)
+    word = int(b.view(np.uint32)[0, 0])
+    assert [(word >> (4 * i)) & 15 for i in range(8)] == [0, 2, 4, 6, 1, 3, 5, 7]
+
+
+def test_kv_quant_rule_and_degenerate_row():
+    x = np.zeros((2, 128), f16)
+    x[0] = f16(0.75)                              # constant row: scale 0 -> inv inf -> NaN -> q = 0
+    x[1, :] = np.linspace(-3, 5, 128).astype(f16)
+    data, prm = o.kv_quantize(x, 8)
+    assert prm[0, 0] == 0 and prm[0, 1] == f16(0.75) and not data[0].any()
+    mn, mx = x[1].min(), x[1].max()
+    assert prm[1, 1] == mn
+    assert prm[1, 0] == f16((np.float32(mx) - np.float32(mn)) * (np.float32(1) / np.float32(255)))
+    assert data[1].min() == 0 and data[1].max() in (254, 255)
+    rec = o.kv_dequant_decode(data[1:2], prm[1:2, 0], prm[1:2, 1])
+    assert np.abs(rec.astype(np.float32) - x[1].astype(np.float32)).max() <= float(prm[1, 0]) * 0.51 + 4e-3
+
+
+def test_block_layout_sizes():
+    """Llama-3-8B int8: 135168 B / layer / block, 4325376 B per block; int4 69632; fp16 262144."""
+    assert o.BlockLayout(32, 8, 128, 64, 8).layer_size == 135168
+    assert o.BlockLayout(32, 8, 128, 64, 8).block_size == 4325376
+    assert o.BlockLayout(32, 8, 128, 64, 4).layer_size == 69632
+    assert o.BlockLayout(32, 8, 128, 64, 16).layer_size == 262144
+    L = o.BlockLayout(2, 2, 128, 64, 8)
+    assert L.v_data(1, 3) == L.k_data(1, 3) + 64 * 128 and L.k_param(0, 0) == 2 * 2 * 64 * 128
+
+
+# ---- (c) properties ------------------------------------------------------------------------------------------------
+@settings(max_examples=25, deadline=None)
+@given(st.integers(0, 2**32 - 1), st.sampled_from([8, 4]))
+def test_kv_quantize_property(seed, bits):
+    rng = np.random.default_rng(seed)
+    x = (rng.standard_normal((3, 128)) * rng.uniform(0.01, 30)).astype(f16)
+    data, prm = o.kv_quantize(x, bits)
+    codes = data if bits == 8 else o.kv_unpack_int4(data)
+    assert codes.max() <= (1 << bits) - 1
+    rec = o.kv_dequant_decode(codes, prm[:, 0], prm[:, 1]).astype(np.float32)
+    step = prm[:, 0].astype(np.float32)[:, None]
+    # fp16 arithmetic in the quantiser costs a little more than half a step
+    assert np.all(np.abs(rec - x.astype(np.float32)) <= 0.75 * step + 2.0**-8 * np.abs(x.astype(np.float32)) + 1e-3)
+
+
+@pytest.mark.parametrize('splits', [1, 2, 3, 7])
+def test_split_k_invariance_and_unfused_reference(splits):
+    rng = np.random.default_rng(splits)
+    Hq, Hkv, ctx = 8, 2, 333
+    q = rng.standard_normal((Hq, 128)).astype(f16)
+    K = rng.standard_normal((Hkv, ctx, 128)).astype(f16)
+    V = rng.standard_normal((Hkv, ctx, 128)).astype(f16)
+    K[0, 100] *= f16(8)            # a spike forces the online-softmax rescale path
+    ref = o.attention_reference_unfused(q, K, V)
+    out = o.decode_attention(q, K, V, None, splits)
+    assert np.abs(out - ref).max() < 4e-3
+    assert np.abs(out.astype(np.float32) - o.decode_attention(q, K, V, None, 1).astype(np.float32)).max() < 2e-3
+
+
+def test_block_table_permutation_invariance():
+    """test_attention.cu:70-141."""
+    rng = np.random.default_rng(0)
+    L = o.BlockLayout(1, 1, 128, 64, 8)
+    k = rng.standard_normal((150, 1, 128)).astype(f16)
+    v = rng.standard_normal((150, 1, 128)).astype(f16)
+    outs = []
+    for table in ([0, 1, 2], [5, 2, 7]):
+        c = o.PagedKVCache(L, 8)
+        o.process_kv(c, table, 0, k, v, None, None, 0)
+        outs.append(c.load_dequant(table, 0, 0, 0, 150, 'decode'))
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+
+
+def test_rope_properties():
+    p = o.RopeParam(128, 500000.0, 'llama3', 8.0, 1.0, 4.0, 8192)
+    inv = o.rope_inv_freq(p)
+    base = o.rope_inv_freq(o.RopeParam(128, 500000.0))
+    assert np.allclose(inv[:8], base[:8])                    # high frequencies untouched
+    assert np.allclose(inv[-4:], base[-4:] / 8.0, rtol=1e-6)  # low frequencies divided by the factor
+    cos, sin = o.rope_cos_sin(p, np.array([0, 1, 77]))
+    x = np.random.default_rng(1).standard_normal((3, 2, 128)).astype(f16)
+    y = o.rope_apply(x, cos, sin)
+    assert np.array_equal(y[0], x[0])                       # position 0 is the identity
+    n0 = np.linalg.norm(x.astype(np.float32), axis=-1)
+    n1 = np.linalg.norm(y.astype(np.float32), axis=-1)
+    assert np.allclose(n0, n1, rtol=2e-3)                   # rotation preserves norms
+    w = np.arange(2 * 8 * 128).reshape(2, 8 * 128)
+    pw = o.permute_qk_for_interleaved_rope(w, 8, 128)
+    assert pw[0, 0] == w[0, 0] and pw[0, 1] == w[0, 64] and pw[0, 2] == w[0, 1]
+
+
+def test_quantize_groupwise_and_gated_silu():
+    rng = np.random.default_rng(5)
+    w = (rng.standard_normal((256, 64)) * 0.02).astype(f16)
+    q, s, z, d = o.quantize_groupwise_u4(w, 128)
+    assert q.max() <= 15 and z.min() >= 0 and z.max() <= 15
+    assert np.abs(d.astype(np.float32) - w.astype(np.float32)).max() <= s.astype(np.float32).max() * 0.51 + 1e-4
+    wd = o.w4a16_dequant(q, s, z)
+    assert np.abs(wd.astype(np.float32) - d.astype(np.float32)).max() <= 2.0**-9 * np.abs(d.astype(np.float32)).max() + 1e-6
+    acc = rng.standard_normal((3, 8)).astype(np.float32) * 4
+    out = o.gated_silu_epilogue(acc)
+    g, u = acc[:, 0::2], acc[:, 1::2]
+    assert np.allclose(out.astype(np.float32), g / (1 + np.exp(-g)) * u, rtol=2e-3, atol=1e-3)
+    assert np.array_equal(o.interleave_w1w3(np.ones((2, 3)), np.zeros((2, 3)))[0], [1, 0, 1, 0, 1, 0])
+
+
+def test_oracle_model_is_deterministic_and_block_table_free():
+    cfg = o.ModelConfig(hidden=128, layers=1, q_heads=2, kv_heads=1, head_dim=128, inter=256, vocab=300, kv_bits=8)
+    w = o.make_synthetic_weights(cfg, seed=0)
+    prompts = [np.arange(9) % 300, (np.arange(70) * 7) % 300]
+    runs = []
+    for _ in range(2):
+        m = o.OracleModel(cfg, w, batch=2, max_ctx=128)
+        ids, _ = m.forward(prompts)
+        ids2, lg = m.forward([[int(ids[0])], [int(ids[1])]], decode_splits=2)
+        runs.append((ids, ids2, lg))
+    assert np.array_equal(runs[0][0], runs[1][0]) and np.array_equal(runs[0][2], runs[1][2])
+    assert math.isfinite(float(np.abs(runs[0][2].astype(np.float32)).max()))

