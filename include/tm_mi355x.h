@@ -118,7 +118,8 @@ int tm_linear_create(tm_linear** out, int in_features, int out_features, int wei
  * [K][N], scales = zeros = NULL.  Performs LinearWeight::prepare (repack to MFMA-fragment order, fuse (s,-z*s)). */
 int tm_linear_prepare(tm_linear* w, const void* weight, const void* scales, const void* zeros, tm_stream_t st);
 /* y fp16 [M][N] (or [M][N/2] when gated_silu: columns interleaved (gate_j, up_j), epilogue.h:159-176).
- * nt / splits / waves: 0 = heuristic (waves per workgroup: 4 or 8).  workspace >= tm_linear_workspace() bytes when split-K may be used. */
+ * nt / splits / waves: 0 = heuristic.  waves per workgroup: 4 or 8; waves | 0x100 additionally splits K two ways
+ * inside the workgroup (8 waves).  workspace >= tm_linear_workspace() bytes when split-K may be used. */
 size_t tm_linear_workspace(const tm_linear* w, int M);
 int    tm_linear_forward(const tm_linear* w, const void* x, int ldx, void* y, int ldy, int M, int gated_silu,
                          int nt, int splits, int waves, void* workspace, tm_stream_t st);

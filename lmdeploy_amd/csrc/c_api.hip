@@ -247,8 +247,11 @@ int tm_linear_forward(const tm_linear* w, const void* x, int ldx, void* y, int l
         cfg.splits = splits;
     }
     if (waves > 0) {
-        TM_REQUIRE(waves == 4 || waves == 8, "waves in {4, 8}");
-        cfg.waves = waves;
+        // waves per workgroup (4 | 8); + 0x100 = split K two ways INSIDE the workgroup (8 waves only)
+        TM_REQUIRE((waves & 0xff) == 4 || (waves & 0xff) == 8 || (waves & 0xff) == 16,
+                   "waves in {4, 8, 16} (+0x100: two k-phases)");
+        cfg.waves   = waves & 0xff;
+        cfg.kphases = (waves & 0x100) ? 2 : 1;
     }
     TM_REQUIRE(cfg.splits <= 16, "splits <= 16");
     if (!workspace) {

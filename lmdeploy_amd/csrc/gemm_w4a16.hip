@@ -172,6 +172,7 @@ struct GemmParams {
     int             KB;            // K / 128
     int             kb_per_split;  // k-blocks (128 k) per grid.y slice
     int             epilogue;      // 0: fp16 store  1: gated silu fp16 store  2: fp32 partial slabs
+    int             rotate_k;      // per-workgroup rotation of the K walk (L2 hot-spot avoidance)
 };
 
 // m1024 / m64 hold 0x64006400 / 0x54005400 in VGPRs (made opaque by the caller): with the magic in a register
@@ -194,41 +195,54 @@ __device__ __forceinline__ half8_t dequant8(uint32_t w, half2_t s2, half2_t z2, 
     return half8_t{p0[0], p0[1], p1[0], p1[1], p2[0], p2[1], p3[0], p3[1]};
 }
 
-// One workgroup = WAVES waves x NT column tiles (16 wide) x MT row tiles (16 tall) over a slice of K.
-// K advances one k-block (128 = one quantisation group = one 16-B lane load per tile) per iteration:
-//   * weights: per-wave register ring, PF k-blocks deep (PF KiB per tile in flight per wave) -- the HBM stream
-//     is never waited on for less than PF iterations;
-//   * activations: [MB][128] fp16 per k-block through a double-buffered, XOR-swizzled LDS tile shared by all
-//     waves (global -> registers two iterations ahead -> LDS one iteration ahead), ONE barrier per iteration.
-template<int WT, int MT, int NT, int WAVES, int PF>
-__global__ __launch_bounds__(WAVES * 64) void gemm_kernel(GemmParams p)
+// One workgroup = WN x WK waves: WN column groups (NT column tiles of 16 each) x WK k-phases, MT row tiles (16 tall),
+// over a slice of K.  Per ITERATION the workgroup consumes KS*WK k-blocks (a k-block = 128 k = one quantisation
+// group = one 16-B lane load per tile): wave (wn, wk) contracts the k-blocks kb0 + (i*KS + kk)*WK + wk, kk < KS.
+// The WK partial sums are added through LDS at the end (split-K INSIDE the workgroup, no fp32 slabs in HBM).
+//   * weights: per-wave register ring, PF iterations (= PF*KS k-blocks) deep -- the HBM stream is never waited on
+//     for less than PF iterations;
+//   * activations: [KS*WK][MB][128] fp16 per iteration through a double-buffered, XOR-swizzled LDS stage shared by
+//     all waves (global -> register ring -> LDS one iteration ahead), ONE barrier per iteration.
+//   * KS > 1 exists because an iteration costs a fixed ~1200 cycles of exposed latencies (barrier, LDS round trip,
+//     waitcnt) that nothing hides while all waves of the CU move in lockstep (measured by ablation: the phases of an
+//     iteration are additive): more k-blocks per barrier amortise that chain.
+// ABL: ablation bit mask for tools/ablate_gemm.sh (timing experiments only, results are garbage):
+//   1 no dequant VALU, 2 no MFMA, 4 no LDS x reads, 8 no x staging (loads + LDS writes), 16 no weight loads in the loop
+template<int WT, int MT, int NT, int WN, int WK, int KS, int PF, int ABL = 0>
+__global__ __launch_bounds__(WN * WK * 64) void gemm_kernel(GemmParams p)
 {
-    static_assert(PF % 2 == 0, "ring depth must be even (x register sets alternate)");
+    static_assert(PF % 2 == 0, "ring depth must be even (LDS stages alternate)");
+    constexpr int WAVES   = WN * WK;
     constexpr int MB      = 16 * MT;
     constexpr int THREADS = WAVES * 64;
-    constexpr int ROWB    = 256;            // one k-block of one row
-    constexpr int BUFB    = MB * ROWB;      // one LDS stage
-    constexpr int NCHUNK  = MB * 16;        // 16-B chunks per stage
+    constexpr int ROWB    = 256;                 // one k-block of one row
+    constexpr int PHB     = MB * ROWB;           // one k-block of a stage
+    constexpr int SUBS    = KS * WK;             // k-blocks per stage
+    constexpr int BUFB    = SUBS * PHB;          // one LDS stage
+    constexpr int NCHUNK  = SUBS * MB * 16;      // 16-B chunks per stage
     constexpr int XR      = (NCHUNK + THREADS - 1) / THREADS;
-    constexpr int WV      = WT == 0 ? 1 : 4;  // u32x4 per (tile, k-block) per lane
+    constexpr int WV      = WT == 0 ? 1 : 4;     // u32x4 per (tile, k-block) per lane
     constexpr bool XFULL  = NCHUNK % THREADS == 0;  // every thread stages exactly XR chunks
 
-    extern __shared__ __attribute__((aligned(16))) char smem[];  // 2 * BUFB
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // max(2 * BUFB, reduction scratch)
 
     const int tid  = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn   = wave % WN;
+    const int wk   = wave / WN;
     const int i16  = lane & 15;
     const int g    = lane >> 4;
 
     const int ntiles = p.N / 16;
-    const int nt0    = (blockIdx.x * WAVES + wave) * NT;
+    const int nt0    = (blockIdx.x * WN + wn) * NT;
     const int m0     = blockIdx.z * MB;
     const int kb0    = blockIdx.y * p.kb_per_split;
-    const int nkb    = min(p.kb_per_split, p.KB - kb0);
+    const int nkb    = min(p.kb_per_split, p.KB - kb0);  // multiple of SUBS (host guarantees)
+    const int nit    = nkb / SUBS;
 
     // Buffer descriptors (SRD) + per-lane 32-bit byte offsets + SCALAR k-block offsets: the address math of every
-    // load in the loop is SALU-only (raw pointers cost ~10 VALU per load in 64-bit adds -- the loop is VALU-bound).
+    // load in the loop is SALU-only (raw pointers cost ~10 VALU per load in 64-bit adds).
     // Tiles past the edge are clamped: loads stay in bounds, stores are skipped.
     const auto rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.wq, 0, (int)((size_t)p.KB * ntiles * 1024 * WV), 0x00020000);
     const auto rs_s = __builtin_amdgcn_make_buffer_rsrc((void*)p.sz, 0, WT == 0 ? p.KB * ntiles * 64 : 0, 0x00020000);
@@ -252,46 +266,51 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_kernel(GemmParams p)
         }
     }
 
-    u32x4    ring[PF][NT][WV];
-    uint32_t sring[PF][NT];
+    u32x4    ring[PF][KS][NT][WV];
+    uint32_t sring[PF][KS][NT];
     u32x4    xs[PF][XR];
 
-    // x chunk q of a k-block: row q/16, 16-B chunk q%16.  Loads are UNCONDITIONAL (clamped row / chunk): a
-    // per-lane "load or zero" select makes hipcc branch around every load and drain vmcnt(0) each time.
-    // Rows past M only feed output rows that are never stored.
+    // x chunk q of a stage: k-block q/(MB*16) of the stage, row (q/16)%MB, 16-B chunk q%16.  Loads are
+    // UNCONDITIONAL (clamped): a per-lane "load or zero" select makes hipcc branch around every load and drain
+    // vmcnt(0) each time.  Rows past M only feed output rows that are never stored.
     int xoff[XR];
     int xlds[XR];
 #pragma unroll
     for (int r = 0; r < XR; ++r) {
         const int q  = tid + THREADS * r;
         const int qc = min(q, NCHUNK - 1);
-        const int m  = qc >> 4;
+        const int sb = qc / (MB * 16);
+        const int m  = (qc >> 4) % MB;
         const int ci = qc & 15;
-        xoff[r]      = (min(m0 + m, p.M - 1) * p.ldx + ci * 8) * 2;
-        xlds[r]      = q < NCHUNK ? m * ROWB + ((ci ^ (m & 15)) << 4) : -1;
+        xoff[r]      = (min(m0 + m, p.M - 1) * p.ldx + ci * 8) * 2 + sb * 256;
+        xlds[r]      = q < NCHUNK ? sb * PHB + m * ROWB + ((ci ^ (m & 15)) << 4) : -1;
     }
     uint32_t m1024 = 0x64006400u, m64 = 0x54005400u;
     asm volatile("" : "+v"(m1024), "+v"(m64));  // keep the magic numbers in VGPRs (see dequant8)
-    const int last = nkb - 1;  // k-block indices are clamped to `last`: the tail re-loads harmlessly
+    const int last = nit - 1;  // iteration indices are clamped to `last`: the ring tail re-loads harmlessly
 
 #define TM_LOAD_W(slot, i)                                                                                   \
     {                                                                                                        \
-        const int kb_ = kb0 + min((i), last);                                                                \
-        _Pragma("unroll") for (int t = 0; t < NT; ++t)                                                       \
+        const int kb_ = kb0 + min((i), last) * SUBS + wk;                                                    \
+        _Pragma("unroll") for (int kk = 0; kk < KS; ++kk)                                                    \
         {                                                                                                    \
-            _Pragma("unroll") for (int v = 0; v < WV; ++v)                                                   \
+            _Pragma("unroll") for (int t = 0; t < NT; ++t)                                                   \
             {                                                                                                \
-                ring[slot][t][v] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, woff[t] + v * 1024,           \
-                                                                         kb_ * wstride, /*nt*/ 2);           \
-            }                                                                                                \
-            if constexpr (WT == 0) {                                                                         \
-                sring[slot][t] = __builtin_amdgcn_raw_buffer_load_b32(rs_s, soff[t], kb_ * sstride, 0);      \
+                _Pragma("unroll") for (int v = 0; v < WV; ++v)                                               \
+                {                                                                                            \
+                    ring[slot][kk][t][v] = __builtin_amdgcn_raw_buffer_load_b128(                            \
+                        rs_w, woff[t] + v * 1024, (kb_ + kk * WK) * wstride, /*nt*/ 2);                      \
+                }                                                                                            \
+                if constexpr (WT == 0) {                                                                     \
+                    sring[slot][kk][t] =                                                                     \
+                        __builtin_amdgcn_raw_buffer_load_b32(rs_s, soff[t], (kb_ + kk * WK) * sstride, 0);   \
+                }                                                                                            \
             }                                                                                                \
         }                                                                                                    \
     }
 #define TM_LOAD_X(set, i)                                                                                    \
     {                                                                                                        \
-        const int kb_ = kb0 + min((i), last);                                                                \
+        const int kb_ = kb0 + min((i), last) * SUBS;                                                         \
         _Pragma("unroll") for (int r = 0; r < XR; ++r)                                                       \
         {                                                                                                    \
             xs[set][r] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, xoff[r], kb_ * 256, 0);                 \
@@ -305,7 +324,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_kernel(GemmParams p)
         }                                                                                                    \
     }
 
-    if (nkb > 0) {
+    if (nit > 0) {
         // ---- prologue --------------------------------------------------------------------------
         // Issue order matters: VMEM loads return IN ORDER, so a wait for x(i) also waits for every older
         // load.  x(i) is therefore always issued right before w(i), PF iterations ahead of its use: no
@@ -323,40 +342,104 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_kernel(GemmParams p)
         __syncthreads();
 
         // ---- main loop: branch-free body, statically unrolled over the ring --------------------------
-        // Iterations past nkb (ring padding) contract zeroed weights, so they add exactly 0.
-        for (int base = 0; base < nkb; base += PF) {
+        // Iterations past nit (ring padding) contract zeroed weights, so they add exactly 0.
+        // Software pipeline: the dequantised A operand of the next 32-k step (VALU) and its activation fragments (LDS)
+        // are produced while the MFMAs of the current step run.
+        auto dq = [&](int slot, int kk, int t, int j, bool live) -> half8_t {
+            if constexpr (WT == 0) {
+                const half2_t pr = bit_cast<half2_t>(live ? sring[slot][kk][t] : 0u);  // (s, -z*s) = 0 -> w = 0
+                if constexpr (ABL & 1) {
+                    const uint32_t rw = ring[slot][kk][t][0][j] ^ bit_cast<uint32_t>(pr);
+                    return bit_cast<half8_t>(u32x4{rw, rw, rw, rw});
+                }
+                else {
+                    return dequant8(ring[slot][kk][t][0][j], half2_t{pr[0], pr[0]}, half2_t{pr[1], pr[1]}, m1024, m64);
+                }
+            }
+            else {
+                const u32x4 wv = ring[slot][kk][t][j];
+                return bit_cast<half8_t>(live ? wv : u32x4{0u, 0u, 0u, 0u});
+            }
+        };
+        auto ldx = [&](const char* stage, int kk, int j, int mt) -> half8_t {
+            if constexpr (ABL & 4) {
+                return bit_cast<half8_t>(ring[0][0][0][0]);
+            }
+            else {
+                return *(const half8_t*)(stage + (kk * WK + wk) * PHB + (mt * 16 + i16) * ROWB + (((j * 4 + g) ^ i16) << 4));
+            }
+        };
+        half8_t wfn[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            wfn[t] = dq(0, 0, t, 0, true);
+        }
+        for (int base = 0; base < nit; base += PF) {
 #pragma unroll
             for (int u = 0; u < PF; ++u) {
-                const int  i    = base + u;
-                const bool live = i < nkb;  // wave-uniform
-                const char* xb = smem + (u & 1) * BUFB;
+                const int  i         = base + u;
+                const bool live      = i < nit;  // wave-uniform
+                const bool live_next = i + 1 < nit;
+                const char* stage    = smem + (u & 1) * BUFB;
+                half8_t     xf[MT], xfn[MT];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    half8_t xf[MT];
+                for (int mt = 0; mt < MT; ++mt) {
+                    xf[mt] = ldx(stage, 0, 0, mt);
+                }
 #pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) {
-                        xf[mt] = *(const half8_t*)(xb + (mt * 16 + i16) * ROWB + (((j * 4 + g) ^ i16) << 4));
-                    }
+                for (int s = 0; s < KS * 4; ++s) {  // s = kk*4 + j: 32-k steps of this iteration
+                    const int kk = s >> 2, j = s & 3;
+                    half8_t   wf[NT];
 #pragma unroll
                     for (int t = 0; t < NT; ++t) {
-                        half8_t wf;
-                        if constexpr (WT == 0) {
-                            const half2_t pr = bit_cast<half2_t>(live ? sring[u][t] : 0u);  // (s, -z*s) = 0 -> w = 0
-                            wf               = dequant8(ring[u][t][0][j], half2_t{pr[0], pr[0]}, half2_t{pr[1], pr[1]}, m1024, m64);
-                        }
-                        else {
-                            const u32x4 wv = ring[u][t][j];
-                            wf = bit_cast<half8_t>(live ? wv : u32x4{0u, 0u, 0u, 0u});
+                        wf[t] = wfn[t];
+                    }
+                    // produce the next step (or step 0 of the next iteration) while the MFMAs below are in flight
+                    if (s + 1 < KS * 4) {
+#pragma unroll
+                        for (int t = 0; t < NT; ++t) {
+                            wfn[t] = dq(u, (s + 1) >> 2, t, (s + 1) & 3, live);
                         }
 #pragma unroll
                         for (int mt = 0; mt < MT; ++mt) {
-                            acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf, xf[mt], acc[t][mt], 0, 0, 0);
+                            xfn[mt] = ldx(stage, (s + 1) >> 2, (s + 1) & 3, mt);
                         }
                     }
+                    else {
+#pragma unroll
+                        for (int t = 0; t < NT; ++t) {
+                            wfn[t] = dq((u + 1) % PF, 0, t, 0, live_next);
+                        }
+                    }
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) {
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt) {
+                            if constexpr (ABL & 2) {
+                                acc[t][mt][0] += (float)wf[t][0] + (float)xf[mt][0];
+                                asm volatile("" ::"v"(wf[t]), "v"(xf[mt]));
+                            }
+                            else {
+                                acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[t], xf[mt], acc[t][mt], 0, 0, 0);
+                            }
+                        }
+                    }
+                    if (s + 1 < KS * 4) {
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt) {
+                            xf[mt] = xfn[mt];
+                        }
+                    }
+                    (void)kk;
+                    (void)j;
                 }
-                TM_STORE_X((u + 1) % PF, (u + 1) & 1);  // x(i+1), issued PF-1 iterations ago, -> the other LDS stage
-                TM_LOAD_X(u, i + PF);                   // refill slot u: x first, then w (see prologue)
-                TM_LOAD_W(u, i + PF);
+                if constexpr (!(ABL & 8)) {
+                    TM_STORE_X((u + 1) % PF, (u + 1) & 1);  // x(i+1), issued PF-1 iterations ago, -> the other LDS stage
+                    TM_LOAD_X(u, i + PF);                   // refill slot u: x first, then w (see prologue)
+                }
+                if constexpr (!(ABL & 16)) {
+                    TM_LOAD_W(u, i + PF);
+                }
                 __syncthreads();
             }
         }
@@ -364,6 +447,35 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_kernel(GemmParams p)
 #undef TM_LOAD_W
 #undef TM_LOAD_X
 #undef TM_STORE_X
+
+
+    // ---- add the WK k-phase partial sums through LDS (phase 0 keeps its own in registers) ---------------
+    if constexpr (WK > 1) {
+        floatx4* red = (floatx4*)smem;  // [(wk-1)][wn][t][mt][lane]; the staging buffers are dead after the last barrier
+        if (wk > 0) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    red[((((wk - 1) * WN + wn) * NT + t) * MT + mt) * 64 + lane] = acc[t][mt];
+                }
+            }
+        }
+        __syncthreads();
+        if (wk > 0) {
+            return;
+        }
+#pragma unroll
+        for (int ph = 1; ph < WK; ++ph) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    acc[t][mt] += red[((((ph - 1) * WN + wn) * NT + t) * MT + mt) * 64 + lane];
+                }
+            }
+        }
+    }
 
     // ---- epilogue: lane holds y[m = m0+16mt+i16][n = 16(nt0+t) + 4g + r], r = 0..3 ------------------
 #pragma unroll
@@ -395,6 +507,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_kernel(GemmParams p)
         }
     }
 }
+
 
 // y = h(sum_s partial[s]) (optionally through the gated-SiLU epilogue): 4 columns per thread
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(half_t* __restrict__ y,
@@ -442,12 +555,12 @@ static int env_int(const char* name, int dflt)
 GemmConfig gemm_pick_config(const LinearWeight& w, int M)
 {
     // Heuristic (measured on MI355X with tools/tune_gemm.py): the decode GEMMs are latency /
-    // occupancy bound, so aim at ~256..512 workgroups with the widest column tile that still gets there.
-    // TM_GEMM_NT / TM_GEMM_SPLITS / TM_GEMM_WAVES override.
+    // issue bound, so aim at ~256 workgroups of 8 waves.  TM_GEMM_NT / _SPLITS / _WAVES / _KPHASES override.
     GemmConfig cfg{};
     const int  ntiles = w.N / 16;
     const int  KB     = w.K / 128;
     const int  mblk   = (M + 63) / 64;
+    cfg.kphases       = 1;
     if (w.type == 1) {
         cfg.nt     = 2;
         cfg.waves  = 4;
@@ -459,8 +572,7 @@ GemmConfig gemm_pick_config(const LinearWeight& w, int M)
         cfg.splits = 1;
     }
     else {
-        // measured (tools/tune_gemm.py, Llama-3-8B decode shapes, M=64): 8 waves x 1 tile per wave wins everywhere;
-        // split-K only until ~256 workgroups exist and never below 8 k-blocks per slice (slab traffic + reduce).
+        // split-K only until ~256 workgroups exist and never below 8 k-blocks per slice (slab traffic + reduce)
         cfg.waves = 8;
         cfg.nt    = 1;
         const int col_wgs = (ntiles + cfg.waves * cfg.nt - 1) / (cfg.waves * cfg.nt);
@@ -470,42 +582,89 @@ GemmConfig gemm_pick_config(const LinearWeight& w, int M)
         }
         cfg.splits = splits;
     }
-    cfg.nt     = env_int("TM_GEMM_NT", cfg.nt);
-    cfg.splits = env_int("TM_GEMM_SPLITS", cfg.splits);
-    cfg.waves  = env_int("TM_GEMM_WAVES", cfg.waves);
+    cfg.nt      = env_int("TM_GEMM_NT", cfg.nt);
+    cfg.splits  = env_int("TM_GEMM_SPLITS", cfg.splits);
+    cfg.waves   = env_int("TM_GEMM_WAVES", cfg.waves);
+    cfg.kphases = env_int("TM_GEMM_KPHASES", cfg.kphases);
+    cfg.kstage  = env_int("TM_GEMM_KSTAGE", 0);
     if (cfg.splits > KB) {
         cfg.splits = KB;
     }
     return cfg;
 }
 
-template<int WT, int MT, int NT, int WAVES, int PF>
+template<int WT, int MT, int NT, int WN, int WK, int KS, int PF, int ABL = 0>
 static int launch_one(const GemmParams& p, dim3 grid, hipStream_t st)
 {
-    constexpr int lds = 2 * 16 * MT * 256;
-    gemm_kernel<WT, MT, NT, WAVES, PF><<<grid, WAVES * 64, lds, st>>>(p);
+    constexpr int stage = 2 * KS * WK * 16 * MT * 256;
+    constexpr int red   = (WK - 1) * WN * NT * MT * 1024;
+    constexpr int lds   = stage > red ? stage : red;
+    static bool   attr_set = false;
+    if (lds > 64 * 1024 && !attr_set) {
+        TM_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_kernel<WT, MT, NT, WN, WK, KS, PF, ABL>,
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        attr_set = true;
+    }
+    gemm_kernel<WT, MT, NT, WN, WK, KS, PF, ABL><<<grid, WN * WK * 64, lds, st>>>(p);
     TM_HIP_CHECK(hipGetLastError());
     return 0;
 }
 
-template<int WT, int MT>
-static int launch_mt(const GemmParams& p, dim3 grid, int nt, int waves, hipStream_t st)
+// u4, 8 waves, 1 tile per wave: the decode work-horse, instantiated for every stage depth
+template<int MT, int WN, int WK>
+static int launch_u4_nt1(const GemmParams& p, dim3 grid, int ks, hipStream_t st)
 {
-    // ring depth: 8 k-blocks when the K slice is long enough to use it, else 4 (padding iterations are wasted work)
-    const bool deep = p.kb_per_split >= 16;
+    if constexpr (WK == 1) {
+      if (ks == 4) {
+        if constexpr (MT == 4) {
+            switch (env_int("TM_GEMM_ABL", 0)) {  // ablation timing experiments (tools/ablate_gemm.sh)
+                case 1: return launch_one<0, MT, 1, WN, WK, 4, 2, 1>(p, grid, st);
+                case 2: return launch_one<0, MT, 1, WN, WK, 4, 2, 2>(p, grid, st);
+                case 4: return launch_one<0, MT, 1, WN, WK, 4, 2, 4>(p, grid, st);
+                case 8: return launch_one<0, MT, 1, WN, WK, 4, 2, 8>(p, grid, st);
+                case 16: return launch_one<0, MT, 1, WN, WK, 4, 2, 16>(p, grid, st);
+                case 15: return launch_one<0, MT, 1, WN, WK, 4, 2, 15>(p, grid, st);
+                case 31: return launch_one<0, MT, 1, WN, WK, 4, 2, 31>(p, grid, st);
+                default: break;
+            }
+        }
+        return launch_one<0, MT, 1, WN, WK, 4, 2>(p, grid, st);
+      }
+    }
+    if (ks >= 2) return launch_one<0, MT, 1, WN, WK, 2, 4>(p, grid, st);
+    return p.kb_per_split / WK >= 16 ? launch_one<0, MT, 1, WN, WK, 1, 8>(p, grid, st) :
+                                       launch_one<0, MT, 1, WN, WK, 1, 4>(p, grid, st);
+}
+
+template<int WT, int MT>
+static int launch_mt(const GemmParams& p, dim3 grid, int nt, int waves, int wk, int ks, hipStream_t st)
+{
     if constexpr (WT == 1) {
-        if (nt == 1) return launch_one<1, MT, 1, 4, 4>(p, grid, st);
-        return launch_one<1, MT, 2, 4, 2>(p, grid, st);
+        if (nt == 1) return launch_one<1, MT, 1, 4, 1, 1, 4>(p, grid, st);
+        return launch_one<1, MT, 2, 4, 1, 1, 2>(p, grid, st);
     }
     else {
-        if (waves == 8) {
-            if (nt == 1) return deep ? launch_one<0, MT, 1, 8, 8>(p, grid, st) : launch_one<0, MT, 1, 8, 4>(p, grid, st);
-            return deep ? launch_one<0, MT, 2, 8, 8>(p, grid, st) : launch_one<0, MT, 2, 8, 4>(p, grid, st);
+        if (waves == 16) {  // 8 column groups x 2 k-phases: 4 waves per SIMD, same activation traffic per CU as 8x1
+            return p.kb_per_split / 2 >= 16 ? launch_one<0, MT, 1, 8, 2, 1, 8>(p, grid, st) :
+                                              launch_one<0, MT, 1, 8, 2, 1, 4>(p, grid, st);
         }
-        if (nt == 1) return deep ? launch_one<0, MT, 1, 4, 8>(p, grid, st) : launch_one<0, MT, 1, 4, 4>(p, grid, st);
-        if (nt == 2) return deep ? launch_one<0, MT, 2, 4, 8>(p, grid, st) : launch_one<0, MT, 2, 4, 4>(p, grid, st);
-        return launch_one<0, MT, 4, 4, 4>(p, grid, st);
+        if (waves == 8 && wk == 2) {
+            if (nt == 1) return launch_u4_nt1<MT, 4, 2>(p, grid, ks >= 2 ? 2 : 1, st);
+            return ks >= 2 ? launch_one<0, MT, 2, 4, 2, 2, 2>(p, grid, st) : launch_one<0, MT, 2, 4, 2, 1, 4>(p, grid, st);
+        }
+        if (waves == 8) {
+            if (nt == 1) return launch_u4_nt1<MT, 8, 1>(p, grid, ks, st);
+            return ks >= 2 ? launch_one<0, MT, 2, 8, 1, 2, 2>(p, grid, st) : launch_one<0, MT, 2, 8, 1, 1, 4>(p, grid, st);
+        }
+        if (nt == 1) return ks >= 2 ? launch_one<0, MT, 1, 4, 1, 2, 4>(p, grid, st) : launch_one<0, MT, 1, 4, 1, 1, 8>(p, grid, st);
+        if (nt == 2) return ks >= 2 ? launch_one<0, MT, 2, 4, 1, 2, 2>(p, grid, st) : launch_one<0, MT, 2, 4, 1, 1, 4>(p, grid, st);
+        return launch_one<0, MT, 4, 4, 1, 1, 4>(p, grid, st);
     }
+}
+
+static int KB_of(const LinearWeight& w)
+{
+    return w.K / 128;
 }
 
 int launch_linear(const LinearWeight& w,
@@ -531,13 +690,25 @@ int launch_linear(const LinearWeight& w,
         return 0;
     }
     int nt    = cfg.nt;
-    int waves = cfg.waves == 8 ? 8 : 4;
+    int waves = cfg.waves == 16 ? 16 : (cfg.waves == 8 ? 8 : 4);
+    int wk    = cfg.kphases == 2 || waves == 16 ? 2 : 1;
     if (w.type == 1) {
         waves = 4;
+        wk    = 1;
         nt    = nt > 2 ? 2 : nt;
+    }
+    if (waves == 4) {
+        wk = 1;
     }
     if (waves == 8 && nt > 2) {
         nt = 2;
+    }
+    if (waves == 16) {
+        nt = 1;
+        if (KB_of(w) % 2 != 0) {
+            waves = 8;
+            wk    = 1;
+        }
     }
     TM_REQUIRE(nt == 1 || nt == 2 || nt == 4, "nt in {1,2,4}");
     const int KB     = w.K / 128;
@@ -548,35 +719,64 @@ int launch_linear(const LinearWeight& w,
     }
     TM_REQUIRE(splits == 1 || workspace != nullptr, "split-K needs a workspace");
     TM_REQUIRE(!defer_reduce || splits > 1, "defer_reduce only with split-K");
+    if (KB % wk != 0) {
+        wk = 1;
+    }
 
     GemmParams p{};
-    p.x            = x;
-    p.ldx          = ldx;
-    p.wq           = (const u32x4*)w.packed;
-    p.sz           = w.sz;
-    p.y            = y;
-    p.ldy          = ldy;
-    p.partial      = workspace;
-    p.M            = M;
-    p.N            = w.N;
-    p.K            = w.K;
-    p.KB           = KB;
-    p.kb_per_split = (KB + splits - 1) / splits;
-    splits         = (KB + p.kb_per_split - 1) / p.kb_per_split;  // no empty splits
-    p.epilogue     = splits > 1 ? 2 : (gated_silu ? 1 : 0);
+    p.x        = x;
+    p.ldx      = ldx;
+    p.wq       = (const u32x4*)w.packed;
+    p.sz       = w.sz;
+    p.y        = y;
+    p.ldy      = ldy;
+    p.partial  = workspace;
+    p.M        = M;
+    p.N        = w.N;
+    p.K        = w.K;
+    p.KB       = KB;
+    p.rotate_k = 0;
+    // k-blocks per grid.y slice: whole iterations of ks*wk k-blocks, for every slice including the last one.
+    // ks (k-blocks per barrier) = the largest of {4, 2, 1} (capped by cfg.kstage) that divides the slice.
+    // measured (tools/ablate_gemm.sh): more k-blocks per barrier does NOT pay (the loop is issue-bound, not
+    // barrier-bound), so the default is 1; TM_GEMM_KSTAGE=2|4 keeps the experiment reachable.
+    int ks_cap = cfg.kstage > 0 ? cfg.kstage : 1;
+    if (w.type == 1 || (waves == 4 && nt == 4) || waves == 16) {
+        ks_cap = 1;
+    }
+    else if (wk == 2 && ks_cap > 2) {
+        ks_cap = 2;
+    }
+    int ks = 1;
+    for (int cand = ks_cap; cand >= 1; cand >>= 1) {
+        const int unit = cand * wk;
+        int       per  = (KB + splits - 1) / splits;
+        per            = (per + unit - 1) / unit * unit;
+        if (KB % unit == 0 && per <= KB) {
+            ks             = cand;
+            p.kb_per_split = per;
+            break;
+        }
+    }
+    if (p.kb_per_split == 0) {
+        p.kb_per_split = (KB + splits - 1) / splits;
+    }
+    splits     = (KB + p.kb_per_split - 1) / p.kb_per_split;  // no empty splits
+    p.epilogue = splits > 1 ? 2 : (gated_silu ? 1 : 0);
 
+    const int wn     = waves / wk;
     const int ntiles = w.N / 16;
-    dim3      grid((ntiles + waves * nt - 1) / (waves * nt), splits, (M + 16 * mt - 1) / (16 * mt));
+    dim3      grid((ntiles + wn * nt - 1) / (wn * nt), splits, (M + 16 * mt - 1) / (16 * mt));
     int       rc = 0;
     if (w.type == 0) {
-        rc = mt == 1 ? launch_mt<0, 1>(p, grid, nt, waves, st) :
-             mt == 2 ? launch_mt<0, 2>(p, grid, nt, waves, st) :
-                       launch_mt<0, 4>(p, grid, nt, waves, st);
+        rc = mt == 1 ? launch_mt<0, 1>(p, grid, nt, waves, wk, ks, st) :
+             mt == 2 ? launch_mt<0, 2>(p, grid, nt, waves, wk, ks, st) :
+                       launch_mt<0, 4>(p, grid, nt, waves, wk, ks, st);
     }
     else {
-        rc = mt == 1 ? launch_mt<1, 1>(p, grid, nt, waves, st) :
-             mt == 2 ? launch_mt<1, 2>(p, grid, nt, waves, st) :
-                       launch_mt<1, 4>(p, grid, nt, waves, st);
+        rc = mt == 1 ? launch_mt<1, 1>(p, grid, nt, waves, wk, ks, st) :
+             mt == 2 ? launch_mt<1, 2>(p, grid, nt, waves, wk, ks, st) :
+                       launch_mt<1, 4>(p, grid, nt, waves, wk, ks, st);
     }
     if (rc) {
         return rc;

@@ -97,6 +97,8 @@ struct GemmConfig {
     int nt;      // n-tiles (16 cols) per wave: 1,2,4
     int splits;  // split-K
     int waves;   // waves per workgroup: 4 or 8
+    int kphases; // split-K inside the workgroup: 1 or 2 (8 waves only)
+    int kstage;  // max k-blocks per barrier (0 = auto: 4)
 };
 // Load-time repack (reference: LinearWeight::prepare, models/linear_weight.cc:101-324)
 int    linear_weight_prepare_u4(LinearWeight& w, const int32_t* qweight /*[K][N/8]*/, const half_t* scales,

@@ -337,7 +337,7 @@ def test_w4a16_linear(tm, cuda, K, N, M):
     ref = x.astype(np.float32) @ _QCACHE[(K, N)][3]
     ws = torch.zeros(max(1, tm.tm_linear_workspace(h, M)), dtype=torch.uint8, device='cuda')
     x_d = dev(x)
-    for nt, splits, waves in ((0, 0, 0), (1, 1, 4), (2, 2, 4), (4, 4, 4), (1, 2, 8), (2, 1, 8), (2, 16, 8)):
+    for nt, splits, waves in ((0, 0, 0), (1, 1, 4), (2, 2, 4), (4, 4, 4), (1, 2, 8), (2, 1, 8), (2, 16, 8), (1, 1, 0x108), (2, 2, 0x108), (2, 4, 0x108)):
         y = torch.zeros((M, N), dtype=torch.float16, device='cuda')
         _ffi.check(tm.tm_linear_forward(h, x_d.data_ptr(), K, y.data_ptr(), N, M, 0, nt, splits, waves, ws.data_ptr(), st()))
         err = np.abs(host(y).astype(np.float32) - ref)
@@ -353,7 +353,7 @@ def test_w4a16_gated_silu(tm, cuda, K, N, M):
     x = (rng.standard_normal((M, K)) * 3).astype(f16)
     ref = o.w4a16_linear_gated_silu(x, q, s, z).astype(np.float32)
     ws = torch.zeros(max(1, tm.tm_linear_workspace(h, M)), dtype=torch.uint8, device='cuda')
-    for nt, splits, waves in ((0, 0, 0), (2, 1, 4), (4, 2, 4), (2, 2, 8)):
+    for nt, splits, waves in ((0, 0, 0), (2, 1, 4), (4, 2, 4), (2, 2, 8), (2, 1, 0x108)):
         y = torch.zeros((M, N // 2), dtype=torch.float16, device='cuda')
         _ffi.check(tm.tm_linear_forward(h, dev(x).data_ptr(), K, y.data_ptr(), N // 2, M, 1, nt, splits, waves, ws.data_ptr(), st()))
         err = np.abs(host(y).astype(np.float32) - ref)

@@ -24,6 +24,9 @@ def main():
     ap.add_argument('--m', type=int, default=64)
     ap.add_argument('--model', default='llama3_8b')
     ap.add_argument('--iters', type=int, default=30)
+    ap.add_argument('--only', default='')
+    ap.add_argument('--no-flush', action='store_true', help='leave the weights in the Infinity Cache between launches')
+    ap.add_argument('--cfg', default='', help='waves,nt,splits: time one configuration only')
     args = ap.parse_args()
     tm = _ffi.load()
     mm = MODELS[args.model]
@@ -36,6 +39,8 @@ def main():
     # a buffer larger than the 256 MiB Infinity Cache, written between timed launches, keeps weights HBM-cold
     flush = torch.empty(512 << 20, dtype=torch.uint8, device='cuda')
     for name, (K, N, gated) in shapes.items():
+        if args.only and name != args.only:
+            continue
         qw = torch.randint(-2**31, 2**31 - 1, (K, N // 8), dtype=torch.int32, device='cuda')
         s = (torch.rand((K // 128, N), device='cuda') * 1e-3 + 1e-3).half()
         z = torch.randint(0, 16, (K // 128, N), device='cuda').half()
@@ -47,14 +52,18 @@ def main():
         ws = torch.empty(max(1, tm.tm_linear_workspace(h, M)), dtype=torch.uint8, device='cuda')
         wbytes = K * N / 2 + K * N / 32
         best = None
-        for waves, nt, splits in [(w_, n_, s_) for w_ in (4, 8) for n_ in (1, 2, 4) for s_ in (1, 2, 4, 8, 16)]:
+        grid_ = [(w_, n_, s_) for w_ in (4, 8, 0x108) for n_ in (1, 2, 4) for s_ in (1, 2, 4, 8, 16)]
+        if args.cfg:
+            grid_ = [tuple(int(v, 0) for v in args.cfg.split(','))]
+        for waves, nt, splits in grid_:
             if True:
-                if splits > K // 256 or (waves == 8 and nt == 4):
+                if splits > K // 256 or (waves != 4 and nt == 4) or (waves == 4 and nt == 4 and M <= 64):
                     continue
                 ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
                       for _ in range(args.iters)]
                 for a, b in ev:
-                    flush.fill_(1)
+                    if not args.no_flush:
+                        flush.fill_(1)
                     a.record()
                     _ffi.check(tm.tm_linear_forward(h, x.data_ptr(), K, y.data_ptr(), N // (2 if gated else 1), M, gated,
                                                     nt, splits, waves, ws.data_ptr(), st))
