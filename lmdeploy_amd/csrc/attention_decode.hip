@@ -21,6 +21,7 @@
 //   * grid = (kv_heads * head_chunks, batch, splits) -> 512..2048 workgroups for the metric shape.
 #include "tm_common.h"
 #include "tm_kernels.h"
+#include <stdlib.h>
 
 namespace tmk {
 
@@ -408,8 +409,23 @@ int launch_decode_attention(const DecodeAttnParams& p, hipStream_t st)
     switch (L.bits) {
         case 16:
             return launch_bits<16>(p, st);
-        case 8:
-            return launch_bits<8>(p, st);
+        case 8: {
+            // int8 KV (the headline configuration) runs on the matrix cores; TM_ATTN_VALU=1 keeps the VALU kernel
+            // reachable for A/B measurements
+            static const bool valu = getenv("TM_ATTN_VALU") && atoi(getenv("TM_ATTN_VALU")) != 0;
+            if (valu) {
+                return launch_bits<8>(p, st);
+            }
+            int rc = launch_decode_attention_i8_mfma(p, st);
+            if (rc) {
+                return rc;
+            }
+            if (p.splits > 1) {
+                decode_reduce_kernel<<<dim3(p.q_heads, p.batch), 128, 0, st>>>(p);
+                TM_HIP_CHECK(hipGetLastError());
+            }
+            return 0;
+        }
         case 4:
             return launch_bits<4>(p, st);
     }

@@ -1,0 +1,318 @@
+// Split-K paged flash-decode for int8 KV on the matrix cores (gfx950) -- the kernel the headline metric runs.
+//
+// Same contract as attention_decode.hip (which stays the path for int4 / fp16 KV): replaces dispatchDecoding +
+// invokeReduceV3 (src/turbomind/kernels/attention/decoding.cu:12-39, attention_universal.h:355-553,
+// impl_81616.h:313-349,510-591, reduce.cu:13-226).
+//
+// Why a second kernel: the VALU version spends ~1400 wave-instructions per 16 KB of KV (dequant + dot products) and is
+// instruction-issue bound at ~45 % of the HBM roofline.  Here both contractions run on v_mfma_f32_16x16x32_f16 and
+// the per-element dequantisation disappears algebraically: with (s_t, z_t) the per-token scale / zero,
+//     S[h,t]  = sum_d q[h,d] (s_t kq[t,d] + z_t)  = s_t * (q . kq[t]) + z_t * sum_d q[h,d]
+//     O[h,d]  = sum_t P[h,t] (s_t vq[t,d] + z_t)  = sum_t (P s_t)[h,t] vq[t,d]  +  sum_t P[h,t] z_t
+// so the MFMAs contract the RAW integer codes (converted to fp16 exactly with one v_perm per two codes: 0x64bb =
+// 1024 + b; K additionally subtracts 1024 exactly, V keeps the +1024 and removes 1024 * sum_t (P s_t) at the end)
+// and the scales touch 4 values per lane per tile instead of 256.  This is NOT the reference's rounding sequence
+// (no per-element fp16 rounding of k^ / v^): results agree with it to ~1e-3 relative, inside the stated tolerance
+// (reference Compare thresholds rtol 1e-2 / atol 1e-4, kernels/attention/test_utils.h:12-14).
+//
+// Data path per wave and 64-token cache block: 16 coalesced 16-B global loads (8 whole 128-B rows per instruction)
+// -> registers (next block in flight while this one is contracted) -> wave-private LDS image [token][128 B] with the
+// 16-B chunks XOR-swizzled by (token>>1)&7 -> K operand by ds_read_b64 (token rows, conflict free), V operand by
+// ds_read_b64_tr_b8 (the hardware byte transpose: 8 tokens of one head-dim column per lane).
+// The score tile comes out of the MFMA as S^T with 4 consecutive tokens per lane; the second contraction uses the
+// k-slot mapping (g, e) -> token 4g+e (e<4) / 16+4g+(e-4), so P feeds it without any cross-lane movement and the
+// transpose-read simply addresses those rows.
+#include "tm_common.h"
+#include "tm_kernels.h"
+
+namespace tmk {
+
+typedef int v2i __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ half8_t bytes8_to_f16_plus1024(u32x2 w)
+{
+    // byte b -> fp16 bit pattern 0x64bb = 1024 + b (exact)
+    const uint32_t a0 = __builtin_amdgcn_perm(0x64646464u, w[0], 0x04010400u);
+    const uint32_t a1 = __builtin_amdgcn_perm(0x64646464u, w[0], 0x04030402u);
+    const uint32_t a2 = __builtin_amdgcn_perm(0x64646464u, w[1], 0x04010400u);
+    const uint32_t a3 = __builtin_amdgcn_perm(0x64646464u, w[1], 0x04030402u);
+    return bit_cast<half8_t>(u32x4{a0, a1, a2, a3});
+}
+
+constexpr int kWaveLds = 16384 + 512;  // K image 8 KB | V image 8 KB | (k_param, v_param) per token
+
+__global__ __launch_bounds__(256, 2) void decode_attention_i8_mfma_kernel(DecodeAttnParams p, int head_chunks, int hpw)
+{
+    constexpr int D = 128;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const KvLayout L = p.cache.layout;
+
+    const int kv_head = blockIdx.x / head_chunks;
+    const int chunk   = blockIdx.x - kv_head * head_chunks;
+    const int b       = blockIdx.y;
+    const int split   = blockIdx.z;
+    const int group   = p.q_heads / L.kv_heads;
+    const int head0   = kv_head * group + chunk * hpw;
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int i16  = lane & 15;
+    const int g    = lane >> 4;
+
+    char* Kt = smem + wave * kWaveLds;
+    char* Vt = Kt + 8192;
+    char* Pm = Kt + 16384;
+
+    const int ctx        = p.k_len[b];
+    const int tiles      = (ctx + 63) >> 6;
+    const int per_split  = (tiles + p.splits - 1) / p.splits;
+    const int tile_begin = split * per_split;
+    const int tile_end   = min(tile_begin + per_split, tiles);
+
+    // ---- q^T fragments (B operand of S^T = K q^T): lane (head = i16, g) holds q[head][32dd + 8g .. +8) -----------
+    half8_t qf[4];
+    float   q1 = 0.f;  // sum_d q[head][d]
+    {
+        const bool    hv = i16 < hpw;
+        const half_t* qp = p.q + (size_t)b * p.q_stride + (size_t)(head0 + (hv ? i16 : 0)) * D;
+#pragma unroll
+        for (int dd = 0; dd < 4; ++dd) {
+            half8_t t = *(const half8_t*)(qp + dd * 32 + g * 8);
+            if (!hv) {
+                t = half8_t{};
+            }
+            qf[dd] = t;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                q1 += (float)t[e];
+            }
+        }
+        q1 += __shfl_xor(q1, 16);
+        q1 += __shfl_xor(q1, 32);
+    }
+
+    floatx4 O[8];
+#pragma unroll
+    for (int dt = 0; dt < 8; ++dt) {
+        O[dt] = floatx4{0.f, 0.f, 0.f, 0.f};
+    }
+    float m = -INFINITY, lsum = 0.f, psum = 0.f, zacc = 0.f;  // per head column i16, partial over this lane's tokens
+    const float sc = p.scale_log2;
+
+    const uint64_t* blocks = p.cache.block_ptrs + p.cache.cu_block_nums[b];
+    const int       koff   = L.k_data(kv_head, 0);
+    const int       voff   = L.v_data(kv_head, 0);
+    const int       kpoff  = L.k_param(kv_head, 0);
+    const int       vpoff  = L.v_param(kv_head, 0);
+
+    u32x4    kreg[8], vreg[8];
+    uint32_t kpr = 0, vpr = 0;
+    auto load_tile = [&](int tile) {
+        const char* base = (const char*)blocks[tile] + p.cache.layer_offset;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const int off = ((lane >> 3) + 8 * r) * 128 + (lane & 7) * 16;
+            kreg[r]       = *(const u32x4*)(base + koff + off);
+            vreg[r]       = *(const u32x4*)(base + voff + off);
+        }
+        kpr = *(const uint32_t*)(base + kpoff + lane * 4);
+        vpr = *(const uint32_t*)(base + vpoff + lane * 4);
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const int t   = (lane >> 3) + 8 * r;
+            const int pos = t * 128 + (((lane & 7) ^ ((t >> 1) & 7)) << 4);
+            *(u32x4*)(Kt + pos) = kreg[r];
+            *(u32x4*)(Vt + pos) = vreg[r];
+        }
+        *(u32x2*)(Pm + lane * 8) = u32x2{kpr, vpr};
+    };
+
+    int tile = tile_end - 1 - wave;  // newest -> oldest, waves interleaved
+    if (tile >= tile_begin) {
+        load_tile(tile);
+    }
+    for (; tile >= tile_begin; tile -= 4) {
+        store_tile();  // wave-private LDS: in-order DS pipeline, no barrier needed
+        const int ntok = min(64, ctx - tile * 64);
+        if (tile - 4 >= tile_begin) {
+            load_tile(tile - 4);  // next block streams in while this one is contracted
+        }
+
+        // ---- S^T = K q^T on raw codes -----------------------------------------------------------------------
+        floatx4 S[4];
+        const half8_t k1024 = {(half_t)1024.f, (half_t)1024.f, (half_t)1024.f, (half_t)1024.f,
+                               (half_t)1024.f, (half_t)1024.f, (half_t)1024.f, (half_t)1024.f};
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) {
+            S[tt]       = floatx4{0.f, 0.f, 0.f, 0.f};
+            const int t = 16 * tt + i16;
+#pragma unroll
+            for (int dd = 0; dd < 4; ++dd) {
+                const int   u   = 4 * dd + g;
+                const int   off = t * 128 + ((((u >> 1) ^ ((t >> 1) & 7))) << 4) + (u & 1) * 8;
+                const u32x2 kb  = *(const u32x2*)(Kt + off);
+                const half8_t a = bytes8_to_f16_plus1024(kb) - k1024;  // exact integers 0..255
+                S[tt]           = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, qf[dd], S[tt], 0, 0, 0);
+            }
+        }
+
+        // ---- scales, mask, online softmax (lane: head column i16, tokens 16tt + 4g + r) ----------------------
+        float sv[4][4], vs[4][4], vz[4][4];
+        float tmax = -INFINITY;
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) {
+            const u32x4 pa = *(const u32x4*)(Pm + (16 * tt + 4 * g) * 8);       // tokens +0, +1
+            const u32x4 pb = *(const u32x4*)(Pm + (16 * tt + 4 * g) * 8 + 16);  // tokens +2, +3
+            const uint32_t kp[4] = {pa[0], pa[2], pb[0], pb[2]};
+            const uint32_t vp[4] = {pa[1], pa[3], pb[1], pb[3]};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const bool    valid = 16 * tt + 4 * g + r < ntok;
+                const half2_t kk    = bit_cast<half2_t>(kp[r]);
+                const half2_t vv    = bit_cast<half2_t>(vp[r]);
+                const float   s     = (float)kk[0] * S[tt][r] + (float)kk[1] * q1;
+                sv[tt][r]           = valid ? s : -INFINITY;
+                vs[tt][r]           = valid ? (float)vv[0] : 0.f;
+                vz[tt][r]           = valid ? (float)vv[1] : 0.f;
+                tmax                = fmaxf(tmax, sv[tt][r]);
+            }
+        }
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 16));
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+        const float mnew  = fmaxf(m, tmax);
+        const float alpha = (m == -INFINITY) ? 0.f : fast_exp2((m - mnew) * sc);
+        // wave-uniform: did any head's max move?  (alpha == 1 exactly otherwise)
+        if (__builtin_amdgcn_readfirstlane((int)__any(mnew != m))) {
+            lsum *= alpha;
+            psum *= alpha;
+            zacc *= alpha;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float ar = __shfl(alpha, 4 * g + r);  // O rows are heads 4g + r
+#pragma unroll
+                for (int dt = 0; dt < 8; ++dt) {
+                    O[dt][r] *= ar;
+                }
+            }
+        }
+        m = mnew;
+
+        half8_t pa[2];
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float pf = (mnew == -INFINITY) ? 0.f : fast_exp2(sv[tt][r] * sc - mnew * sc);
+                lsum += pf;
+                zacc = __builtin_fmaf(pf, vz[tt][r], zacc);
+                const half_t ph = (half_t)(pf * vs[tt][r]);
+                psum += (float)ph;
+                pa[tt >> 1][(tt & 1) * 4 + r] = ph;
+            }
+        }
+
+        // ---- O^T... O = P' V on raw codes: k-slot (g, e) -> token 32a + 4g + e (e<4) / 32a + 16 + 4g + e - 4 ----
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            const int j = i16 >> 1;
+            const int T = 32 * a + (j < 4 ? 4 * g + j : 16 + 4 * g + (j - 4));
+            const char* vrow = Vt + T * 128 + (i16 & 1) * 8;
+            const int   swz  = (T >> 1) & 7;
+#pragma unroll
+            for (int dt = 0; dt < 8; ++dt) {
+                const v2i vb = __builtin_amdgcn_ds_read_tr8_b64_v2i32(
+                    (__attribute__((address_space(3))) v2i*)(vrow + ((dt ^ swz) << 4)));
+                const half8_t bq = bytes8_to_f16_plus1024(u32x2{(uint32_t)vb[0], (uint32_t)vb[1]});
+                O[dt]            = __builtin_amdgcn_mfma_f32_16x16x32_f16(pa[a], bq, O[dt], 0, 0, 0);
+            }
+        }
+    }
+
+    // ---- per-wave totals, then merge the 4 waves through LDS ------------------------------------------------
+    lsum += __shfl_xor(lsum, 16);
+    lsum += __shfl_xor(lsum, 32);
+    psum += __shfl_xor(psum, 16);
+    psum += __shfl_xor(psum, 32);
+    zacc += __shfl_xor(zacc, 16);
+    zacc += __shfl_xor(zacc, 32);
+
+    __syncthreads();  // every wave is done with its K/V image: the region is reused for the merge
+    float* sm_o  = (float*)smem;                     // [4][16][128]
+    float* sm_ml = (float*)(smem + 4 * 16 * D * 4);  // [4][16][2]
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int   h  = 4 * g + r;
+        const float ps = __shfl(psum, h);
+        const float za = __shfl(zacc, h);
+        if (h < hpw) {
+#pragma unroll
+            for (int dt = 0; dt < 8; ++dt) {
+                sm_o[(wave * 16 + h) * D + dt * 16 + i16] = O[dt][r] - 1024.f * ps + za;
+            }
+        }
+    }
+    if (g == 0 && i16 < hpw) {
+        sm_ml[(wave * 16 + i16) * 2]     = m;
+        sm_ml[(wave * 16 + i16) * 2 + 1] = lsum;
+    }
+    __syncthreads();
+
+    for (int idx = threadIdx.x; idx < hpw * D; idx += 256) {
+        const int h = idx / D;
+        const int d = idx - h * D;
+        float     ms = -INFINITY;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            ms = fmaxf(ms, sm_ml[(w * 16 + h) * 2]);
+        }
+        float o = 0.f, l = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const float mw = sm_ml[(w * 16 + h) * 2];
+            const float wt = (mw == -INFINITY) ? 0.f : fast_exp2((mw - ms) * sc);
+            o += wt * sm_o[(w * 16 + h) * D + d];
+            l += wt * sm_ml[(w * 16 + h) * 2 + 1];
+        }
+        const int hq = head0 + h;
+        if (p.splits == 1) {
+            p.out[(size_t)b * p.q_heads * D + (size_t)hq * D + d] = (half_t)(o / l);
+        }
+        else {
+            const size_t slot         = ((size_t)b * p.q_heads + hq) * p.splits + split;
+            p.partial_o[slot * D + d] = o;
+            if (d == 0) {
+                p.partial_ml[slot * 2]     = ms;
+                p.partial_ml[slot * 2 + 1] = l;
+            }
+        }
+    }
+}
+
+int launch_decode_attention_i8_mfma(const DecodeAttnParams& p, hipStream_t st)
+{
+    const int group = p.q_heads / p.cache.layout.kv_heads;
+    int       hpw   = group;
+    while (hpw > 16) {  // largest divisor of the GQA group that fits the 16 MFMA columns
+        int d = 2;
+        while (hpw % d) {
+            ++d;
+        }
+        hpw /= d;
+    }
+    const int chunks = group / hpw;
+    dim3      grid(p.cache.layout.kv_heads * chunks, p.batch, p.splits);
+    const int lds = 4 * kWaveLds > (4 * 16 * 128 * 4 + 4 * 16 * 2 * 4) ? 4 * kWaveLds : (4 * 16 * 128 * 4 + 4 * 16 * 2 * 4);
+    static bool attr_set = false;
+    if (!attr_set) {
+        TM_HIP_CHECK(hipFuncSetAttribute((const void*)decode_attention_i8_mfma_kernel,
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        attr_set = true;
+    }
+    decode_attention_i8_mfma_kernel<<<grid, 256, lds, st>>>(p, chunks, hpw);
+    TM_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+}  // namespace tmk

@@ -64,6 +64,7 @@ struct DecodeAttnParams {
     KvCacheView   cache;
 };
 int launch_decode_attention(const DecodeAttnParams& p, hipStream_t st);
+int launch_decode_attention_i8_mfma(const DecodeAttnParams& p, hipStream_t st);  // attention_decode_mfma.hip
 size_t decode_attention_workspace_bytes(int batch, int q_heads, int head_dim, int splits);
 
 // ---- attention_prefill.hip --------------------------------------------------------------

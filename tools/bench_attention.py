@@ -1,0 +1,62 @@
+#!/usr/bin/env python
+"""Time the paged decode attention kernel at the metric shape (B=64, 32 q / 8 kv heads, int8 KV) on random cache
+contents.  python tools/bench_attention.py [--ctx 1536] [--bits 8] [--splits 1,2,4]"""
+import argparse
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from lmdeploy_amd import _ffi  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--ctx', type=int, default=1536)
+    ap.add_argument('--batch', type=int, default=64)
+    ap.add_argument('--hq', type=int, default=32)
+    ap.add_argument('--hkv', type=int, default=8)
+    ap.add_argument('--bits', type=int, default=8)
+    ap.add_argument('--splits', default='1,2,4')
+    ap.add_argument('--iters', type=int, default=20)
+    a = ap.parse_args()
+    tm = _ffi.load()
+    B, Hq, Hkv, ctx, bits = a.batch, a.hq, a.hkv, a.ctx, a.bits
+    layers = 4          # several layers so that consecutive launches touch different (cold) cache bytes
+    lsz = tm.tm_kv_layer_size(Hkv, 128, 64, bits)
+    nblk = (ctx + 63) // 64
+    pool = torch.randint(0, 255, (B * nblk, layers * lsz), dtype=torch.uint8, device='cuda')
+    # make the per-token (scale, zero) params finite fp16 values
+    pv = pool.view(B * nblk, layers, lsz)
+    if bits < 16:
+        nparam = Hkv * 2 * 64 * 4
+        prm = torch.empty((B * nblk, layers, nparam // 2), dtype=torch.float16, device='cuda').uniform_(0.01, 0.05)
+        pv[:, :, lsz - nparam:] = prm.view(torch.uint8).view(B * nblk, layers, nparam)
+    perm = torch.randperm(B * nblk)
+    ptrs = (pool.data_ptr() + perm.to(torch.int64) * layers * lsz).cuda()
+    cu = torch.arange(0, (B + 1) * nblk, nblk, dtype=torch.int32, device='cuda')
+    klen = torch.full((B,), ctx, dtype=torch.int32, device='cuda')
+    q = torch.randn((B, Hq * 128), device='cuda').half()
+    out = torch.empty((B, Hq * 128), device='cuda').half()
+    st = torch.cuda.current_stream().cuda_stream
+    bytes_per_launch = B * ctx * 2 * Hkv * (128 * bits // 8 + (4 if bits < 16 else 0))
+    for splits in [int(s) for s in a.splits.split(',')]:
+        ws = torch.empty(max(1, tm.tm_decode_attention_workspace(B, Hq, splits)), dtype=torch.uint8, device='cuda')
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.iters)]
+        for i, (e0, e1) in enumerate(ev):
+            view = _ffi.KvCache(ptrs.data_ptr(), cu.data_ptr(), (i % layers) * lsz, Hkv, 128, 64, bits)
+            e0.record()
+            _ffi.check(tm.tm_decode_attention(out.data_ptr(), q.data_ptr(), Hq * 128, klen.data_ptr(), B, Hq, 0.0, splits,
+                                              ws.data_ptr(), view, st))
+            e1.record()
+        torch.cuda.synchronize()
+        ts = sorted(x.elapsed_time(y) for x, y in ev)
+        med = ts[len(ts) // 2]
+        print(f'ctx={ctx} bits={bits} splits={splits}: {med*1e3:8.1f} us  {bytes_per_launch/(med*1e-3)/1e9:7.0f} GB/s '
+              f'({bytes_per_launch/1e6:.1f} MB/launch)  valu={os.environ.get("TM_ATTN_VALU", "0")}', flush=True)
+
+
+if __name__ == '__main__':
+    main()
