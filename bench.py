@@ -61,6 +61,7 @@ def main():
     ap.add_argument('--quant-policy', type=int, default=8)
     ap.add_argument('--profile-steps', type=int, default=8)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-graph', action='store_true', help='eager launches (rocprofv3 --pmc passes)')
     ap.add_argument('--layers', type=int, default=0, help='debug only: override the layer count (result is then INVALID)')
     args = ap.parse_args()
 
@@ -85,7 +86,7 @@ def main():
     max_new = 1 + W + K + P + 2
     eng = Engine.from_model_config(_Cfg(model), tp=world, rank=rank, device=local_rank, max_batch_size=B,
                                    session_len=S + max_new + 1, quant_policy=args.quant_policy,
-                                   max_prefill_token_num=8192, use_graph=1)
+                                   max_prefill_token_num=8192, use_graph=0 if args.no_graph else 1)
     if world > 1:
         uid = [Engine.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(uid, src=0)
@@ -142,7 +143,7 @@ def main():
             'config': {'workload': f'Llama-3-8B shapes, W4A16 AWQ g128 random weights, quant_policy={args.quant_policy} '
                                    f'KV, batch {B}, {S}-token random prompts, greedy decode, TP={world}',
                        'batch': B, 'prompt_len': S, 'ctx_first_timed_step': ctx_first, 'ctx_mean': ctx_mean,
-                       'parallelism': f'tp{world}', 'decode_splits': stats['decode_splits'], 'hipgraph': True},
+                       'parallelism': f'tp{world}', 'decode_splits': stats['decode_splits'], 'hipgraph': not args.no_graph},
             'ttft_p50_ms': round(float(np.median(ttft)), 2), 'prefill_total_s': round(prefill_s, 3),
             'prefill_tokens_per_s': round(B * S / prefill_s, 1),
             'step_roofline': {'bound': 'hbm', 'algorithmic_bytes_per_step': int(step_bytes),
@@ -154,7 +155,7 @@ def main():
             per_launch_bytes = B * ctx_prof * kv_tok / model['layers']      # one layer's KV of the whole batch
             per_launch_s = attn_ms / 1e3 / max(model['layers'], 1)          # attention (+ split-K merge) of one layer
             ach = per_launch_bytes / per_launch_s / 1e9
-            out['roofline'] = {'bound': 'hbm', 'kernel': 'decode_attention_kernel<8,4> (+decode_reduce_kernel)',
+            out['roofline'] = {'bound': 'hbm', 'kernel': 'decode_attention_i8_mfma_kernel' if args.quant_policy == 8 else 'decode_attention_kernel',
                                'achieved': round(ach, 1), 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
                                'frac': round(ach / HBM_PEAK_GBPS, 4), 'traffic': None,
                                'bytes_per_launch': int(per_launch_bytes), 'us_per_launch': round(per_launch_s * 1e6, 2),
