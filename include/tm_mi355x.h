@@ -129,6 +129,10 @@ int    tm_linear_destroy(tm_linear* w);
 int tm_quantize_groupwise(void* qweight, void* scales, void* zeros, void* dequant, const void* w, int K, int N,
                           int group_size, tm_stream_t st);
 
+/* debug / measurement: device buffer of [workgroups][4] uint64 that receives s_memrealtime stamps (100 MHz:
+ * kernel entry, loop entry, loop exit, exit) of every GEMM workgroup launched afterwards; NULL switches it off. */
+int tm_debug_set_gemm_trace(void* dev_buf);
+
 /* ----------------------------------------------------------------------------------------------
  * Engine level (static batcher around LanguageModel::Forward)
  * --------------------------------------------------------------------------------------------*/

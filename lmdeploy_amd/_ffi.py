@@ -73,6 +73,7 @@ _SIGNATURES = {
     'tm_linear_destroy': (c_int, [c_void_p]),
     'tm_quantize_groupwise': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                                       c_void_p]),
+    'tm_debug_set_gemm_trace': (c_int, [c_void_p]),
     'tm_engine_create': (c_int, [POINTER(c_void_p), POINTER(EngineConfig)]),
     'tm_engine_destroy': (c_int, [c_void_p]),
     'tm_comm_unique_id': (c_int, [c_void_p]),

@@ -159,24 +159,45 @@ __global__ __launch_bounds__(256, 2) void decode_attention_i8_mfma_kernel(Decode
         }
 
         // ---- scales, mask, online softmax (lane: head column i16, tokens 16tt + 4g + r) ----------------------
-        float sv[4][4], vs[4][4], vz[4][4];
+        // Per score: s = ks*R + kz*q1 ; p = exp2(s*c - m*c) ; L += p ; Z += p*vz ; P' = h(p*vs) ; PS += P'.
+        // Explicit fmaf() with fp16 operands lowers to v_fma_mix_f32 (no separate converts); the validity mask is
+        // only evaluated for the single partial block of a sequence (wave-uniform branch).
+        uint32_t kp[4][4], vp[4][4];
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) {
+            const u32x4 pa_ = *(const u32x4*)(Pm + (16 * tt + 4 * g) * 8);       // tokens +0, +1
+            const u32x4 pb_ = *(const u32x4*)(Pm + (16 * tt + 4 * g) * 8 + 16);  // tokens +2, +3
+            kp[tt][0] = pa_[0], kp[tt][1] = pa_[2], kp[tt][2] = pb_[0], kp[tt][3] = pb_[2];
+            vp[tt][0] = pa_[1], vp[tt][1] = pa_[3], vp[tt][2] = pb_[1], vp[tt][3] = pb_[3];
+        }
+        const bool partial = ntok < 64;  // wave-uniform: only the newest block of a sequence can be partial
+        float sv[4][4];
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const half2_t kk = bit_cast<half2_t>(kp[tt][r]);
+                sv[tt][r]        = __builtin_fmaf((float)kk[0], S[tt][r], (float)kk[1] * q1);
+            }
+        }
+        if (partial) {  // tokens past the context: score -inf, V params (0, 0) -> contribute exactly nothing
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (16 * tt + 4 * g + r >= ntok) {
+                        sv[tt][r] = -INFINITY;
+                        vp[tt][r] = 0u;
+                    }
+                }
+            }
+        }
         float tmax = -INFINITY;
 #pragma unroll
         for (int tt = 0; tt < 4; ++tt) {
-            const u32x4 pa = *(const u32x4*)(Pm + (16 * tt + 4 * g) * 8);       // tokens +0, +1
-            const u32x4 pb = *(const u32x4*)(Pm + (16 * tt + 4 * g) * 8 + 16);  // tokens +2, +3
-            const uint32_t kp[4] = {pa[0], pa[2], pb[0], pb[2]};
-            const uint32_t vp[4] = {pa[1], pa[3], pb[1], pb[3]};
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const bool    valid = 16 * tt + 4 * g + r < ntok;
-                const half2_t kk    = bit_cast<half2_t>(kp[r]);
-                const half2_t vv    = bit_cast<half2_t>(vp[r]);
-                const float   s     = (float)kk[0] * S[tt][r] + (float)kk[1] * q1;
-                sv[tt][r]           = valid ? s : -INFINITY;
-                vs[tt][r]           = valid ? (float)vv[0] : 0.f;
-                vz[tt][r]           = valid ? (float)vv[1] : 0.f;
-                tmax                = fmaxf(tmax, sv[tt][r]);
+                tmax = fmaxf(tmax, sv[tt][r]);
             }
         }
         tmax = fmaxf(tmax, __shfl_xor(tmax, 16));
@@ -198,16 +219,18 @@ __global__ __launch_bounds__(256, 2) void decode_attention_i8_mfma_kernel(Decode
             }
         }
         m = mnew;
+        const float msc = mnew * sc;  // finite: every block holds >= 1 valid token
 
         half8_t pa[2];
 #pragma unroll
         for (int tt = 0; tt < 4; ++tt) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float pf = (mnew == -INFINITY) ? 0.f : fast_exp2(sv[tt][r] * sc - mnew * sc);
+                const half2_t vv = bit_cast<half2_t>(vp[tt][r]);
+                const float   pf = fast_exp2(__builtin_fmaf(sv[tt][r], sc, -msc));
                 lsum += pf;
-                zacc = __builtin_fmaf(pf, vz[tt][r], zacc);
-                const half_t ph = (half_t)(pf * vs[tt][r]);
+                zacc            = __builtin_fmaf(pf, (float)vv[1], zacc);
+                const half_t ph = (half_t)(pf * (float)vv[0]);
                 psum += (float)ph;
                 pa[tt >> 1][(tt & 1) * 4 + r] = ph;
             }

@@ -270,6 +270,13 @@ int tm_linear_destroy(tm_linear* w)
     return 0;
 }
 
+/* debug: device buffer of [workgroups][4] uint64 receiving s_memrealtime stamps of every GEMM workgroup (NULL = off) */
+int tm_debug_set_gemm_trace(void* dev_buf)
+{
+    tmk::g_gemm_dbg = (uint64_t*)dev_buf;
+    return 0;
+}
+
 int tm_quantize_groupwise(void* qweight, void* scales, void* zeros, void* dequant, const void* w, int K, int N,
                           int group_size, tm_stream_t st)
 {

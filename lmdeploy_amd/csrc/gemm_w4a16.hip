@@ -173,6 +173,7 @@ struct GemmParams {
     int             kb_per_split;  // k-blocks (128 k) per grid.y slice
     int             epilogue;      // 0: fp16 store  1: gated silu fp16 store  2: fp32 partial slabs
     int             rotate_k;      // per-workgroup rotation of the K walk (L2 hot-spot avoidance)
+    uint64_t*       dbg;           // optional [workgroups][4] s_memrealtime stamps (100 MHz): start, loop, epilogue, end
 };
 
 // m1024 / m64 hold 0x64006400 / 0x54005400 in VGPRs (made opaque by the caller): with the magic in a register
@@ -227,6 +228,10 @@ __global__ __launch_bounds__(WN * WK * 64) void gemm_kernel(GemmParams p)
     extern __shared__ __attribute__((aligned(16))) char smem[];  // max(2 * BUFB, reduction scratch)
 
     const int tid  = threadIdx.x;
+    const int wgid = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    if (p.dbg && tid == 0) {
+        p.dbg[wgid * 4 + 0] = __builtin_amdgcn_s_memrealtime();
+    }
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wn   = wave % WN;
@@ -340,6 +345,9 @@ __global__ __launch_bounds__(WN * WK * 64) void gemm_kernel(GemmParams p)
         }
         TM_STORE_X(0, 0);
         __syncthreads();
+        if (p.dbg && tid == 0) {
+            p.dbg[wgid * 4 + 1] = __builtin_amdgcn_s_memrealtime();
+        }
 
         // ---- main loop: branch-free body, statically unrolled over the ring --------------------------
         // Iterations past nit (ring padding) contract zeroed weights, so they add exactly 0.
@@ -447,6 +455,9 @@ __global__ __launch_bounds__(WN * WK * 64) void gemm_kernel(GemmParams p)
 #undef TM_LOAD_W
 #undef TM_LOAD_X
 #undef TM_STORE_X
+    if (p.dbg && tid == 0) {
+        p.dbg[wgid * 4 + 2] = __builtin_amdgcn_s_memrealtime();
+    }
 
 
     // ---- add the WK k-phase partial sums through LDS (phase 0 keeps its own in registers) ---------------
@@ -506,6 +517,10 @@ __global__ __launch_bounds__(WN * WK * 64) void gemm_kernel(GemmParams p)
             }
         }
     }
+    if (p.dbg && tid == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        p.dbg[wgid * 4 + 3] = __builtin_amdgcn_s_memrealtime();
+    }
 }
 
 
@@ -546,6 +561,8 @@ size_t gemm_workspace_bytes(int M, int N, int splits)
     return splits > 1 ? (size_t)splits * M * N * sizeof(float) : 0;
 }
 
+uint64_t* g_gemm_dbg = nullptr;  // set through tm_debug_set_gemm_trace (timing experiments)
+
 static int env_int(const char* name, int dflt)
 {
     const char* v = getenv(name);
@@ -577,7 +594,8 @@ GemmConfig gemm_pick_config(const LinearWeight& w, int M)
         cfg.nt    = 1;
         const int col_wgs = (ntiles + cfg.waves * cfg.nt - 1) / (cfg.waves * cfg.nt);
         int       splits  = 1;
-        while (col_wgs * splits * 2 <= 256 && KB / (splits * 2) >= 8 && splits < 16) {
+        static const int min_kb = env_int("TM_GEMM_MIN_KB", 8);
+        while (col_wgs * splits * 2 <= 256 && KB / (splits * 2) >= min_kb && splits < 16) {
             splits *= 2;
         }
         cfg.splits = splits;
@@ -598,11 +616,16 @@ static int launch_one(const GemmParams& p, dim3 grid, hipStream_t st)
 {
     constexpr int stage = 2 * KS * WK * 16 * MT * 256;
     constexpr int red   = (WK - 1) * WN * NT * MT * 1024;
-    constexpr int lds   = stage > red ? stage : red;
+    constexpr int lds_need = stage > red ? stage : red;
+    // A grid of <= 256 eight-wave workgroups must land one per CU: the dispatcher otherwise co-locates two of them
+    // on one CU while others idle (measured with tm_debug_set_gemm_trace: stragglers with 2x the loop time).
+    // Requesting more than half of the 160 KB LDS makes co-residency impossible.
+    static const int exclusive = env_int("TM_GEMM_EXCLUSIVE_CU", 1);
+    const int lds = (exclusive && WN * WK >= 8 && lds_need < 84 * 1024 && grid.x * grid.y * grid.z <= 256) ? 84 * 1024 : lds_need;
     static bool   attr_set = false;
-    if (lds > 64 * 1024 && !attr_set) {
+    if (!attr_set) {
         TM_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_kernel<WT, MT, NT, WN, WK, KS, PF, ABL>,
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, lds_need > 84 * 1024 ? lds_need : 84 * 1024));
         attr_set = true;
     }
     gemm_kernel<WT, MT, NT, WN, WK, KS, PF, ABL><<<grid, WN * WK * 64, lds, st>>>(p);
@@ -736,6 +759,7 @@ int launch_linear(const LinearWeight& w,
     p.K        = w.K;
     p.KB       = KB;
     p.rotate_k = 0;
+    p.dbg      = g_gemm_dbg;
     // k-blocks per grid.y slice: whole iterations of ks*wk k-blocks, for every slice including the last one.
     // ks (k-blocks per barrier) = the largest of {4, 2, 1} (capped by cfg.kstage) that divides the slice.
     // measured (tools/ablate_gemm.sh): more k-blocks per barrier does NOT pay (the loop is issue-bound, not

@@ -113,6 +113,8 @@ GemmConfig gemm_pick_config(const LinearWeight& w, int M);
 int launch_linear(const LinearWeight& w, const half_t* x, int ldx, half_t* y, int ldy, int M, bool gated_silu,
                   GemmConfig cfg, float* workspace, bool defer_reduce, int* slabs, hipStream_t st);
 
+extern uint64_t* g_gemm_dbg;  // gemm_w4a16.hip: optional per-workgroup timing stamps (tm_debug_set_gemm_trace)
+
 // ---- misc.hip ---------------------------------------------------------------------------
 int launch_embedding(half_t* out, const half_t* table, const int* ids, int T, int H, int vocab, hipStream_t st);
 int launch_argmax(int* out_ids, half_t* out_val, const half_t* logits, int B, int V, int ld, int id_offset,

@@ -1,0 +1,56 @@
+#!/usr/bin/env python
+"""Phase breakdown of one GEMM launch from in-kernel s_memrealtime stamps (100 MHz): dispatch skew, prologue, main
+loop, epilogue per workgroup.  python tools/trace_gemm.py K N M gated nt splits waves"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from lmdeploy_amd import _ffi  # noqa: E402
+
+
+def main():
+    K, N, M, gated, nt, splits, waves = [int(v, 0) for v in sys.argv[1:8]]
+    tm = _ffi.load()
+    st = torch.cuda.current_stream().cuda_stream
+    qw = torch.randint(-2**31, 2**31 - 1, (K, N // 8), dtype=torch.int32, device='cuda')
+    s = (torch.rand((K // 128, N), device='cuda') * 1e-3 + 1e-3).half()
+    z = torch.randint(0, 16, (K // 128, N), device='cuda').half()
+    h = _ffi.C.c_void_p()
+    _ffi.check(tm.tm_linear_create(_ffi.C.byref(h), K, N, 0, 128))
+    _ffi.check(tm.tm_linear_prepare(h, qw.data_ptr(), s.data_ptr(), z.data_ptr(), st))
+    x = torch.randn((M, K), device='cuda').half()
+    y = torch.empty((M, N), device='cuda').half()
+    ws = torch.empty(max(1, tm.tm_linear_workspace(h, M)), dtype=torch.uint8, device='cuda')
+    flush = torch.empty(512 << 20, dtype=torch.uint8, device='cuda')
+    dbg = torch.zeros((8192, 4), dtype=torch.int64, device='cuda')
+    for it in range(6):
+        flush.fill_(it)
+        dbg.zero_()
+        torch.cuda.synchronize()
+        tm.tm_debug_set_gemm_trace(dbg.data_ptr())
+        _ffi.check(tm.tm_linear_forward(h, x.data_ptr(), K, y.data_ptr(), N // (2 if gated else 1), M, gated, nt, splits,
+                                        waves, ws.data_ptr(), st))
+        tm.tm_debug_set_gemm_trace(None)
+        torch.cuda.synchronize()
+        tt = dbg.cpu().numpy()
+        ids = np.nonzero(tt[:, 0] > 0)[0]
+        tt = tt[ids].astype(np.float64) / 100.0
+        tt -= tt[:, 0].min()
+        order = np.argsort(-tt[:, 3])[:6]
+        print(f'launch {it}: span {tt[:, 3].max():.2f} us; slowest workgroups (id: start/loop-begin/loop-end/end): ' +
+              '  '.join(f'{ids[i]}: {tt[i,0]:.1f}/{tt[i,1]:.1f}/{tt[i,2]:.1f}/{tt[i,3]:.1f}' for i in order))
+    t = dbg.cpu().numpy()
+    t = t[t[:, 0] > 0].astype(np.float64) / 100.0      # us
+    t0 = t[:, 0].min()
+    t -= t0
+    print(f'workgroups {len(t)}  kernel span {t[:, 3].max():.2f} us')
+    for name, a in (('start skew', t[:, 0]), ('prologue', t[:, 1] - t[:, 0]), ('main loop', t[:, 2] - t[:, 1]),
+                    ('epilogue', t[:, 3] - t[:, 2]), ('end time', t[:, 3])):
+        print(f'{name:11s} min {a.min():6.2f}  mean {a.mean():6.2f}  p90 {np.percentile(a, 90):6.2f}  max {a.max():6.2f} us')
+
+
+if __name__ == '__main__':
+    main()
