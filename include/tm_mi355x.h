@@ -98,6 +98,15 @@ size_t tm_decode_attention_workspace(int batch, int q_heads, int splits);
 int    tm_decode_attention(void* out, const void* q, int q_stride, const int* k_len, int batch, int q_heads,
                            float softmax_scale, int splits, void* workspace, const tm_kv_cache* cache,
                            tm_stream_t st);
+/* Decode attention with the reference decode kernel's fused prologue (attention_universal.h:168-330: the decode
+ * kernel itself applies RoPE to q/k and quantises + stores the new K/V).  int8 KV only.  Input is the raw QKV
+ * projection of the new token of every sequence: qkv_splits == 0 -> `qkv` is fp16 [batch][qkv_n]; qkv_splits >= 1
+ * -> `qkv` is fp32 split-K slabs [qkv_splits][batch][qkv_n] which are summed in order and rounded to fp16 first.
+ * Row layout [Q heads | K heads | V heads] x 128.  k_len INCLUDES the new token.  Cache bytes/params written are
+ * bit-identical to tm_kv_rope_store; `out` equals tm_decode_attention on that cache. */
+int tm_decode_attention_fused(void* out, const void* qkv, int qkv_splits, int qkv_n, const void* cos_sin, int max_pos,
+                              const int* k_len, int batch, int q_heads, float softmax_scale, int splits,
+                              void* workspace, const tm_kv_cache* cache, tm_stream_t st);
 /* Causal prefill attention over flattened KV (dispatchAttention).  vt is the transposed V of tm_flatten_kv. */
 int tm_prefill_attention(void* out, const void* q, int q_stride, const void* k, const void* vt, int k_stride,
                          const int* cu_q_len, const int* cu_k_off, const int* k_len, int batch, int max_q_len,

@@ -60,6 +60,8 @@ _SIGNATURES = {
     'tm_decode_attention_workspace': (c_size_t, [c_int, c_int, c_int]),
     'tm_decode_attention': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_float, c_int, c_void_p,
                                     POINTER(KvCache), c_void_p]),
+    'tm_decode_attention_fused': (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_int,
+                                          c_float, c_int, c_void_p, POINTER(KvCache), c_void_p]),
     'tm_prefill_attention': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
                                      c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p]),
     'tm_embedding': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),

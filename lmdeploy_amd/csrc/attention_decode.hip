@@ -406,6 +406,8 @@ int launch_decode_attention(const DecodeAttnParams& p, hipStream_t st)
     if (p.batch == 0) {
         return 0;
     }
+    const bool fused = p.qkv_slabs || p.qkv_f16;
+    TM_REQUIRE(!fused || L.bits == 8, "fused decode prologue: int8 KV only");
     switch (L.bits) {
         case 16:
             return launch_bits<16>(p, st);
@@ -413,7 +415,7 @@ int launch_decode_attention(const DecodeAttnParams& p, hipStream_t st)
             // int8 KV (the headline configuration) runs on the matrix cores; TM_ATTN_VALU=1 keeps the VALU kernel
             // reachable for A/B measurements
             static const bool valu = getenv("TM_ATTN_VALU") && atoi(getenv("TM_ATTN_VALU")) != 0;
-            if (valu) {
+            if (valu && !fused) {
                 return launch_bits<8>(p, st);
             }
             int rc = launch_decode_attention_i8_mfma(p, st);

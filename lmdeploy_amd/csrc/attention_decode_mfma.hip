@@ -41,6 +41,82 @@ __device__ __forceinline__ half8_t bytes8_to_f16_plus1024(u32x2 w)
 
 constexpr int kWaveLds = 16384 + 512;  // K image 8 KB | V image 8 KB | (k_param, v_param) per token
 
+// 8 consecutive columns of row b of the qkv GEMM output: fp16 result, or the in-order sum of the fp32 split-K slabs
+// rounded to fp16 exactly like the GEMM epilogue / splitk_reduce_kernel would.  Split in an issue half (all loads of
+// the first four slabs in flight, nothing consumed) and a finish half, so that the q, new-K/V and first cache-block
+// loads of the prologue overlap instead of paying one memory round trip each.
+struct QkvRaw {
+    floatx4 a0[4], a1[4];
+};
+
+__device__ __forceinline__ QkvRaw qkv_issue(const DecodeAttnParams& p, int b, int col)
+{
+    QkvRaw r;
+    if (p.qkv_splits == 0) {
+        r.a0[0] = *(const floatx4*)(p.qkv_f16 + (size_t)b * p.qkv_n + col);  // 8 halves
+        return r;
+    }
+    const size_t slab = (size_t)p.batch * p.qkv_n;
+    const float* base = p.qkv_slabs + (size_t)b * p.qkv_n + col;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float* src = base + (size_t)min(j, p.qkv_splits - 1) * slab;
+        r.a0[j]          = *(const floatx4*)src;
+        r.a1[j]          = *(const floatx4*)(src + 4);
+    }
+    return r;
+}
+
+__device__ __forceinline__ half8_t qkv_finish(const DecodeAttnParams& p, int b, int col, const QkvRaw& r)
+{
+    if (p.qkv_splits == 0) {
+        return bit_cast<half8_t>(r.a0[0]);
+    }
+    float acc[8] = {};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {  // in slab order: bit-identical to splitk_reduce_kernel
+        if (j < p.qkv_splits) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                acc[e] += r.a0[j][e];
+                acc[4 + e] += r.a1[j][e];
+            }
+        }
+    }
+    const size_t slab = (size_t)p.batch * p.qkv_n;
+    const float* base = p.qkv_slabs + (size_t)b * p.qkv_n + col;
+    for (int s = 4; s < p.qkv_splits; ++s) {  // deeper split-K than the engine uses for this projection: plain loop
+        const floatx4 a0 = *(const floatx4*)(base + s * slab);
+        const floatx4 a1 = *(const floatx4*)(base + s * slab + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            acc[e] += a0[e];
+            acc[4 + e] += a1[e];
+        }
+    }
+    half8_t o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        o[e] = (half_t)acc[e];
+    }
+    return o;
+}
+
+// interleaved-pair RoPE in fp16 (rotary_embedding.h:169-181): cs = 4 (cos, sin) pairs for these 8 channels
+__device__ __forceinline__ half8_t rope8(half8_t x, half8_t cs)
+{
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const half_t c = cs[2 * i], s = cs[2 * i + 1];
+        const half_t x0 = x[2 * i], x1 = x[2 * i + 1];
+        const half_t a0 = c * x0, a1 = s * x1, b0 = c * x1, b1 = s * x0;
+        x[2 * i]     = a0 - a1;
+        x[2 * i + 1] = b0 + b1;
+    }
+    return x;
+}
+
+template<bool FUSED>
 __global__ __launch_bounds__(256, 2) void decode_attention_i8_mfma_kernel(DecodeAttnParams p, int head_chunks, int hpw)
 {
     constexpr int D = 128;
@@ -70,10 +146,10 @@ __global__ __launch_bounds__(256, 2) void decode_attention_i8_mfma_kernel(Decode
     const int tile_end   = min(tile_begin + per_split, tiles);
 
     // ---- q^T fragments (B operand of S^T = K q^T): lane (head = i16, g) holds q[head][32dd + 8g .. +8) -----------
-    half8_t qf[4];
-    float   q1 = 0.f;  // sum_d q[head][d]
-    {
-        const bool    hv = i16 < hpw;
+    half8_t    qf[4];
+    float      q1 = 0.f;  // sum_d q[head][d]
+    const bool hv = i16 < hpw;
+    if constexpr (!FUSED) {
         const half_t* qp = p.q + (size_t)b * p.q_stride + (size_t)(head0 + (hv ? i16 : 0)) * D;
 #pragma unroll
         for (int dd = 0; dd < 4; ++dd) {
@@ -82,13 +158,7 @@ __global__ __launch_bounds__(256, 2) void decode_attention_i8_mfma_kernel(Decode
                 t = half8_t{};
             }
             qf[dd] = t;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                q1 += (float)t[e];
-            }
         }
-        q1 += __shfl_xor(q1, 16);
-        q1 += __shfl_xor(q1, 32);
     }
 
     floatx4 O[8];
@@ -129,12 +199,124 @@ __global__ __launch_bounds__(256, 2) void decode_attention_i8_mfma_kernel(Decode
         *(u32x2*)(Pm + lane * 8) = u32x2{kpr, vpr};
     };
 
-    int tile = tile_end - 1 - wave;  // newest -> oldest, waves interleaved
-    if (tile >= tile_begin) {
-        load_tile(tile);
+    // ---- fused prologue -----------------------------------------------------------------------------------------
+    // q: wave w builds the 32-channel slice dd = w (slab sum -> fp16 -> RoPE); the four slices are exchanged through
+    // LDS.  New token's K/V: wave 0 of the WG that owns the newest block, lanes 0-15 = K row, 16-31 = V row (32-63
+    // mirror them); same arithmetic as kv_rope_store_kernel (bit-exact cache bytes).  The codes go to the cache
+    // block AND, after the newest block's image has been written to LDS, are patched into that image: no global
+    // read-after-write.  All loads (q slabs, k/v slabs, RoPE rows, first cache block) are issued before any is used.
+    const bool owns_newest = FUSED && wave == 0 && tile_end == tiles && tile_end > tile_begin;
+    u32x2      nq          = {0u, 0u};
+    uint32_t   npar        = 0;
+    const int  nti         = (ctx - 1) & 63;
+    int        tile        = tile_end - 1 - wave;  // newest -> oldest, waves interleaved
+    if constexpr (FUSED) {
+        const int    pos   = min(ctx - 1, p.max_pos - 1);
+        const int    l16   = lane & 15;
+        const bool   isv   = (lane & 16) != 0;
+        const int    qcol  = (head0 + (hv ? i16 : 0)) * D + wave * 32 + g * 8;
+        const int    kvcol = (p.q_heads + (isv ? L.kv_heads : 0) + kv_head) * D + l16 * 8;
+        const QkvRaw rq    = qkv_issue(p, b, qcol);
+        half8_t      csq{}, csk{};
+        if (p.cos_sin) {
+            csq = *(const half8_t*)((const half_t*)p.cos_sin + (size_t)pos * D + wave * 32 + g * 8);
+        }
+        QkvRaw rk;
+        if (owns_newest) {  // wave-uniform
+            rk = qkv_issue(p, b, kvcol);
+            if (p.cos_sin) {
+                csk = *(const half8_t*)((const half_t*)p.cos_sin + (size_t)pos * D + l16 * 8);
+            }
+        }
+        if (tile >= tile_begin) {
+            load_tile(tile);
+        }
+        half8_t t = qkv_finish(p, b, qcol, rq);
+        if (p.cos_sin) {
+            t = rope8(t, csq);
+        }
+        if (!hv) {
+            t = half8_t{};
+        }
+        *(half8_t*)(smem + 4 * kWaveLds + (wave * 64 + lane) * 16) = t;
+        if (owns_newest) {
+            half8_t x = qkv_finish(p, b, kvcol, rk);
+            if (!isv && p.cos_sin) {
+                x = rope8(x, csk);
+            }
+            float mx = -INFINITY, mnn = -INFINITY;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                mx  = fmaxf(mx, (float)x[e]);
+                mnn = fmaxf(mnn, -(float)x[e]);
+            }
+            mx  = fmaxf(mx, dpp_f32<DPP_XOR1>(mx));
+            mx  = fmaxf(mx, dpp_f32<DPP_XOR2>(mx));
+            mx  = fmaxf(mx, dpp_f32<DPP_HMIRR>(mx));
+            mx  = fmaxf(mx, dpp_f32<DPP_ROR8>(mx));
+            mnn = fmaxf(mnn, dpp_f32<DPP_XOR1>(mnn));
+            mnn = fmaxf(mnn, dpp_f32<DPP_XOR2>(mnn));
+            mnn = fmaxf(mnn, dpp_f32<DPP_HMIRR>(mnn));
+            mnn = fmaxf(mnn, dpp_f32<DPP_ROR8>(mnn));
+            const float  mn    = -mnn;
+            const half_t scale = (half_t)((mx - mn) * (1.0f / 255.0f));
+            const half_t zero  = (half_t)mn;
+            const half_t inv   = (half_t)(1.0f / (float)scale);
+            uint32_t     qv[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const half_t d = x[e] - zero;
+                const half_t y = d * inv;
+                float        r = __builtin_rintf((float)y);
+                r              = (r == r) ? r : 0.0f;
+                r              = fminf(fmaxf(r, 0.0f), 255.0f);
+                qv[e]          = (uint32_t)r;
+            }
+            nq[0] = qv[0] | (qv[1] << 8) | (qv[2] << 16) | (qv[3] << 24);
+            nq[1] = qv[4] | (qv[5] << 8) | (qv[6] << 16) | (qv[7] << 24);
+            npar  = bit_cast<uint32_t>(half2_t{scale, zero});
+            if (lane < 32) {
+                char* blk = (char*)blocks[(ctx - 1) >> 6] + p.cache.layer_offset;
+                *(u32x2*)(blk + (isv ? L.v_data(kv_head, nti) : L.k_data(kv_head, nti)) + l16 * 8) = nq;
+                if (l16 == 0) {
+                    *(uint32_t*)(blk + (isv ? L.v_param(kv_head, nti) : L.k_param(kv_head, nti))) = npar;
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int dd = 0; dd < 4; ++dd) {
+            qf[dd] = *(const half8_t*)(smem + 4 * kWaveLds + (dd * 64 + lane) * 16);
+        }
     }
+    else {
+        if (tile >= tile_begin) {
+            load_tile(tile);
+        }
+    }
+#pragma unroll
+    for (int dd = 0; dd < 4; ++dd) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            q1 += (float)qf[dd][e];
+        }
+    }
+    q1 += __shfl_xor(q1, 16);
+    q1 += __shfl_xor(q1, 32);
+    bool patch = owns_newest;
     for (; tile >= tile_begin; tile -= 4) {
         store_tile();  // wave-private LDS: in-order DS pipeline, no barrier needed
+        if (FUSED && patch) {  // wave-uniform, first iteration of wave 0 only: the new token's codes -> LDS image
+            patch = false;
+            if (lane < 32) {
+                const int l16 = lane & 15;
+                char*     img = lane >= 16 ? Vt : Kt;
+                *(u32x2*)(img + nti * 128 + ((((l16 >> 1) ^ ((nti >> 1) & 7))) << 4) + (l16 & 1) * 8) = nq;
+                if (l16 == 0) {
+                    *(uint32_t*)(Pm + nti * 8 + (lane >= 16 ? 4 : 0)) = npar;
+                }
+            }
+        }
         const int ntok = min(64, ctx - tile * 64);
         if (tile - 4 >= tile_begin) {
             load_tile(tile - 4);  // next block streams in while this one is contracted
@@ -326,14 +508,24 @@ int launch_decode_attention_i8_mfma(const DecodeAttnParams& p, hipStream_t st)
     }
     const int chunks = group / hpw;
     dim3      grid(p.cache.layout.kv_heads * chunks, p.batch, p.splits);
-    const int lds = 4 * kWaveLds > (4 * 16 * 128 * 4 + 4 * 16 * 2 * 4) ? 4 * kWaveLds : (4 * 16 * 128 * 4 + 4 * 16 * 2 * 4);
+    // 4 wave-private images (+ 4 KB q exchange for the fused prologue); the merge buffers overlay the images
+    static_assert(4 * kWaveLds + 4096 > 4 * 16 * 128 * 4 + 4 * 16 * 2 * 4, "merge buffers must fit");
+    const int lds = 4 * kWaveLds + 4096;
     static bool attr_set = false;
     if (!attr_set) {
-        TM_HIP_CHECK(hipFuncSetAttribute((const void*)decode_attention_i8_mfma_kernel,
+        TM_HIP_CHECK(hipFuncSetAttribute((const void*)decode_attention_i8_mfma_kernel<false>,
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        TM_HIP_CHECK(hipFuncSetAttribute((const void*)decode_attention_i8_mfma_kernel<true>,
                                          hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         attr_set = true;
     }
-    decode_attention_i8_mfma_kernel<<<grid, 256, lds, st>>>(p, chunks, hpw);
+    if (p.qkv_slabs || p.qkv_f16) {
+        TM_REQUIRE(p.qkv_n % 8 == 0 && (p.qkv_splits == 0) == (p.qkv_slabs == nullptr), "fused qkv input");
+        decode_attention_i8_mfma_kernel<true><<<grid, 256, lds, st>>>(p, chunks, hpw);
+    }
+    else {
+        decode_attention_i8_mfma_kernel<false><<<grid, 256, lds, st>>>(p, chunks, hpw);
+    }
     TM_HIP_CHECK(hipGetLastError());
     return 0;
 }

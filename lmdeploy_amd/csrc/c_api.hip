@@ -163,6 +163,33 @@ int tm_decode_attention(void* out, const void* q, int q_stride, const int* k_len
     return launch_decode_attention(p, (hipStream_t)st);
 }
 
+int tm_decode_attention_fused(void* out, const void* qkv, int qkv_splits, int qkv_n, const void* cos_sin, int max_pos,
+                              const int* k_len, int batch, int q_heads, float softmax_scale, int splits,
+                              void* workspace, const tm_kv_cache* cache, tm_stream_t st)
+{
+    TM_REQUIRE(out && qkv && k_len && cache, "null pointer");
+    TM_REQUIRE(cache->bits == 8, "fused decode prologue: int8 KV only");
+    TM_REQUIRE(qkv_n == (q_heads + 2 * cache->kv_heads) * 128, "qkv_n != (q_heads + 2 kv_heads) * 128");
+    DecodeAttnParams p{};
+    p.out        = (half_t*)out;
+    p.k_len      = k_len;
+    p.batch      = batch;
+    p.q_heads    = q_heads;
+    const float s = softmax_scale > 0.f ? softmax_scale : 1.0f / std::sqrt(128.0f);
+    p.scale_log2 = s * 1.4426950408889634f;
+    p.splits     = splits < 1 ? 1 : splits;
+    p.partial_o  = (float*)workspace;
+    p.partial_ml = workspace ? (float*)workspace + (size_t)batch * q_heads * p.splits * 128 : nullptr;
+    p.cache      = to_view(cache);
+    p.qkv_slabs  = qkv_splits > 0 ? (const float*)qkv : nullptr;
+    p.qkv_f16    = qkv_splits > 0 ? nullptr : (const half_t*)qkv;
+    p.qkv_splits = qkv_splits;
+    p.qkv_n      = qkv_n;
+    p.cos_sin    = (const half2_t*)cos_sin;
+    p.max_pos    = cos_sin ? max_pos : 1 << 30;
+    return launch_decode_attention(p, (hipStream_t)st);
+}
+
 int tm_prefill_attention(void* out, const void* q, int q_stride, const void* k, const void* vt, int k_stride,
                          const int* cu_q_len, const int* cu_k_off, const int* k_len, int batch, int max_q_len,
                          int q_heads, int kv_heads, float softmax_scale, tm_stream_t st)

@@ -202,6 +202,7 @@ struct tm_engine {
     int              steps_done = 0;
 
     int            decode_splits = 1;
+    bool           fuse_qkv      = false;  // decode: qkv GEMM output -> attention kernel directly (int8 KV, MFMA kernel)
     hipGraphExec_t graph = nullptr;
     // per-kernel-category HIP event profiling (tm_engine_profile_decode)
     bool                                            prof_on = false;
@@ -371,12 +372,34 @@ static int forward(tm_engine* e, const int* d_ids, int M, int nseq, bool decode,
     const float scale_log2 = (1.0f / std::sqrt((float)e->D)) * 1.4426950408889634f;
     for (int li = 0; li < m.layers; ++li) {
         Layer& L = e->layers[li];
-        TM_PROF(P_GEMM_QKV, TM_TRY(linear_plain(e, L.qkv, e->d_x, e->hidden, e->d_qkv, e->qkv_n, M, false)));
         KvCacheView cv = cache_view(e, li);
-        TM_PROF(P_KV_STORE, TM_TRY(launch_kv_rope_store(e->d_qkv, e->q_heads, e->d_cu_q, e->d_k_len, nseq, M, e->d_rope,
-                                                       e->rope_max_pos, cv, st)));
+        // decode + int8 KV: the attention kernel consumes the qkv GEMM's raw output (fp32 split-K slabs or fp16),
+        // applies RoPE and quantises/stores the new K/V itself -> no splitk_reduce, no kv_rope_store launch
+        const bool fuse_qkv = decode && e->fuse_qkv;
+        int        qkv_slabs = 1;
+        if (fuse_qkv) {
+            GemmConfig cfg = gemm_pick_config(L.qkv.w, M);
+            if (gemm_workspace_bytes(M, L.qkv.w.N, cfg.splits) > e->gemm_ws_bytes) {
+                cfg.splits = 1;
+            }
+            TM_PROF(P_GEMM_QKV, TM_TRY(launch_linear(L.qkv.w, e->d_x, e->hidden, e->d_qkv, e->qkv_n, M, false, cfg,
+                                                     e->d_gemm_ws, cfg.splits > 1, &qkv_slabs, st)));
+        }
+        else {
+            TM_PROF(P_GEMM_QKV, TM_TRY(linear_plain(e, L.qkv, e->d_x, e->hidden, e->d_qkv, e->qkv_n, M, false)));
+            TM_PROF(P_KV_STORE, TM_TRY(launch_kv_rope_store(e->d_qkv, e->q_heads, e->d_cu_q, e->d_k_len, nseq, M, e->d_rope,
+                                                           e->rope_max_pos, cv, st)));
+        }
         if (decode) {
             DecodeAttnParams p{};
+            if (fuse_qkv) {
+                p.qkv_slabs  = qkv_slabs > 1 ? e->d_gemm_ws : nullptr;
+                p.qkv_f16    = qkv_slabs > 1 ? nullptr : e->d_qkv;
+                p.qkv_splits = qkv_slabs > 1 ? qkv_slabs : 0;
+                p.qkv_n      = e->qkv_n;
+                p.cos_sin    = e->d_rope;
+                p.max_pos    = e->rope_max_pos;
+            }
             p.q          = e->d_qkv;
             p.q_stride   = e->qkv_n;
             p.out        = e->d_attn;
@@ -919,6 +942,11 @@ int tm_engine_prefill(tm_engine* e, const int* host_ids, const int* host_lens, i
         }
     }
     e->decode_splits = std::min(std::max(splits, 1), 16);
+    {
+        const char* valu = getenv("TM_ATTN_VALU");
+        const char* fuse = getenv("TM_FUSE_QKV");
+        e->fuse_qkv      = e->cfg.quant_policy == 8 && !(valu && atoi(valu)) && !(fuse && !atoi(fuse));
+    }
     if (e->graph && (e->graph_batch != batch)) {
         (void)hipGraphExecDestroy(e->graph);
         e->graph = nullptr;

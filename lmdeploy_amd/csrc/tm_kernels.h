@@ -62,6 +62,16 @@ struct DecodeAttnParams {
     float*        partial_o;   // [B][q_heads][splits][D]
     float*        partial_ml;  // [B][q_heads][splits][2]
     KvCacheView   cache;
+    // Fused prologue (int8 MFMA kernel only): q/k/v of the new token are taken straight from the qkv GEMM output --
+    // `qkv_splits` fp32 split-K slabs [qkv_splits][B][qkv_n] (or the fp16 [B][qkv_n] result when qkv_splits == 0) --
+    // rotated, and K/V are quantised + stored by the attention kernel itself (the reference decode kernel does the
+    // same: attention_universal.h:168-330).  Replaces splitk_reduce + kv_rope_store on the decode path.
+    const float*   qkv_slabs = nullptr;
+    const half_t*  qkv_f16   = nullptr;
+    int            qkv_splits = 0;
+    int            qkv_n      = 0;
+    const half2_t* cos_sin    = nullptr;
+    int            max_pos    = 0;
 };
 int launch_decode_attention(const DecodeAttnParams& p, hipStream_t st);
 int launch_decode_attention_i8_mfma(const DecodeAttnParams& p, hipStream_t st);  // attention_decode_mfma.hip

@@ -253,6 +253,82 @@ def test_decode_attention(tm, cuda, bits, Hq, Hkv, klen, splits):
         assert np.abs(got[b] - ref64).max() < 5e-3
 
 
+@pytest.mark.parametrize('Hq,Hkv,klen,splits,qkv_splits,rope', [
+    (8, 2, [1, 64, 65, 300], 1, 0, True), (8, 2, [1, 64, 65, 300], 3, 2, True), (32, 8, [1000, 37, 128, 129], 2, 4, True),
+    (6, 1, [129, 5], 1, 1, False), (8, 1, [257], 4, 0, True), (12, 4, [513, 64], 16, 3, True), (64, 8, [77, 192], 2, 0, True),
+])
+def test_decode_attention_fused_prologue(tm, cuda, Hq, Hkv, klen, splits, qkv_splits, rope):
+    """Fused decode prologue (RoPE + K/V quantise-store inside the attention kernel) == kv_rope_store followed by
+    decode attention: cache bytes bit-exact against the oracle's process_kv, output bit-identical to the unfused
+    device sequence (same q bits, same cache bits, same kernel arithmetic)."""
+    rng = np.random.default_rng(Hq + sum(klen) + splits + qkv_splits)
+    layer = 1
+    L = o.BlockLayout(2, Hkv, 128, 64, 8)
+    B = len(klen)
+    hist = [k - 1 for k in klen]
+    # history (klen-1 tokens) through the oracle; the new token goes through the device paths
+    nblk = [(k + 63) // 64 for k in klen]
+    total = sum(nblk) + 2
+    perm = rng.permutation(total)
+    tables, off = [], 0
+    for nb in nblk:
+        tables.append(perm[off:off + nb])
+        off += nb
+    oc = o.PagedKVCache(L, total)
+    for b, n in enumerate(hist):
+        if n:
+            k = rng.standard_normal((n, Hkv, 128)).astype(f16)
+            v = rng.standard_normal((n, Hkv, 128)).astype(f16)
+            o.process_kv(oc, tables[b], layer, k, v, None, None, 0)
+    qkv_n = (Hq + 2 * Hkv) * 128
+    if qkv_splits:
+        slabs = (rng.standard_normal((qkv_splits, B, qkv_n)) / np.sqrt(qkv_splits)).astype(np.float32)
+        acc = np.zeros((B, qkv_n), np.float32)
+        for s_ in slabs:
+            acc = acc + s_                      # in-order fp32 sum, like splitk_reduce_kernel
+        qkv = acc.astype(f16)
+        qkv_in = dev(slabs)
+    else:
+        qkv = rng.standard_normal((B, qkv_n)).astype(f16)
+        qkv_in = dev(qkv.copy())
+    p = o.RopeParam(128, 500000.0, 'llama3', 8.0, 1.0, 4.0, 8192)
+    max_pos = max(klen) + 1
+    tab = rope_table(tm, max_pos, p)
+    tab_d = dev(tab)
+    klen_d = dev(np.asarray(klen, np.int32))
+    cu = np.arange(B + 1, dtype=np.int32)
+
+    # unfused device sequence
+    dc_a = DevCache(L, total, tables)
+    dc_a.upload(oc)
+    qkv_a = dev(qkv.copy())
+    _ffi.check(tm.tm_kv_rope_store(qkv_a.data_ptr(), Hq, dev(cu).data_ptr(), klen_d.data_ptr(), B, B,
+                                   tab_d.data_ptr() if rope else None, max_pos, dc_a.view(layer), st()))
+    out_a = torch.zeros((B, Hq * 128), dtype=torch.float16, device='cuda')
+    ws = torch.zeros(max(1, tm.tm_decode_attention_workspace(B, Hq, splits)), dtype=torch.uint8, device='cuda')
+    _ffi.check(tm.tm_decode_attention(out_a.data_ptr(), qkv_a.data_ptr(), qkv_n, klen_d.data_ptr(), B, Hq, 0.0, splits,
+                                      ws.data_ptr(), dc_a.view(layer), st()))
+    # fused
+    dc_b = DevCache(L, total, tables)
+    dc_b.upload(oc)
+    out_b = torch.zeros((B, Hq * 128), dtype=torch.float16, device='cuda')
+    ws_b = torch.zeros_like(ws)
+    _ffi.check(tm.tm_decode_attention_fused(out_b.data_ptr(), qkv_in.data_ptr(), qkv_splits, qkv_n,
+                                            tab_d.data_ptr() if rope else None, max_pos, klen_d.data_ptr(), B, Hq, 0.0,
+                                            splits, ws_b.data_ptr(), dc_b.view(layer), st()))
+    # oracle cache for the new token
+    for b in range(B):
+        cos, sin = o.rope_cos_sin(p, np.arange(hist[b], hist[b] + 1)) if rope else (None, None)
+        k = qkv[b:b + 1, Hq * 128:(Hq + Hkv) * 128].reshape(1, Hkv, 128)
+        v = qkv[b:b + 1, (Hq + Hkv) * 128:].reshape(1, Hkv, 128)
+        o.process_kv(oc, tables[b], layer, k, v, cos, sin, hist[b])
+    pool_a, pool_b = dc_a.download(), dc_b.download()
+    assert np.array_equal(pool_a, oc.pool)
+    assert np.array_equal(pool_b, oc.pool), f'fused cache bytes differ in {np.count_nonzero(pool_b != oc.pool)} positions'
+    ga, gb = host(out_a), host(out_b)
+    assert np.array_equal(ga.view(np.uint16), gb.view(np.uint16)), f'max diff {np.abs(ga.astype(np.float32) - gb.astype(np.float32)).max()}'
+
+
 def test_decode_attention_block_table_permutation_invariance(tm, cuda):
     """test_attention.cu:70-141: a shuffled block table must give identical output."""
     rng = np.random.default_rng(5)
