@@ -155,6 +155,8 @@ struct tm_engine {
 
     hipStream_t  stream = nullptr;
     ncclComm_t   comm   = nullptr;
+    bool         use_comm = false;  // collectives on the data path: tp > 1 (or TM_FORCE_COMM=1: single-rank communicator,
+                                    // exercises the RCCL code path on a 1-GPU box)
     std::map<std::string, Slot> slots;
     std::vector<Layer>          layers;
     half_t*      tok_embeddings = nullptr;
@@ -295,7 +297,8 @@ static KvCacheView cache_view(const tm_engine* e, int layer)
 
 static int allreduce_hidden(tm_engine* e, half_t* buf, int M)
 {
-    if (e->cfg.tp > 1) {
+    if (e->use_comm) {
+        TM_REQUIRE(e->comm != nullptr, "tm_engine_comm_init was not called");
         TM_NCCL_CHECK(ncclAllReduce(buf, buf, (size_t)M * e->hidden, ncclHalf, ncclSum, e->comm, e->stream));
     }
     return 0;
@@ -332,7 +335,7 @@ static int linear_residual_norm(tm_engine* e, LinearSlots& l, const half_t* x, i
                                 int gemm_cat)
 {
     GemmConfig cfg = gemm_pick_config(l.w, M);
-    const bool can_defer = e->cfg.tp == 1 && cfg.splits > 1
+    const bool can_defer = !e->use_comm && cfg.splits > 1
                            && gemm_workspace_bytes(M, l.w.N, cfg.splits) <= e->gemm_ws_bytes;
     if (gemm_workspace_bytes(M, l.w.N, cfg.splits) > e->gemm_ws_bytes) {
         cfg.splits = 1;
@@ -448,7 +451,7 @@ static int forward(tm_engine* e, const int* d_ids, int M, int nseq, bool decode,
     half_t* logits = e->d_logits + (size_t)slot0 * e->vocab_local;
     int*    ids    = e->d_next_ids + slot0;
     TM_PROF(P_LM_HEAD, TM_TRY(linear_plain(e, e->output, hx, e->hidden, logits, e->vocab_local, nseq, false)));
-    if (e->cfg.tp == 1) {
+    if (!e->use_comm) {
         TM_PROF(P_SAMPLE, TM_TRY(launch_argmax(ids, nullptr, logits, nseq, e->vocab_local, e->vocab_local, 0, st)));
     }
     else {
@@ -516,6 +519,10 @@ int tm_engine_create(tm_engine** out, const tm_engine_config* c)
     e->kv_heads    = std::max(1, m.kv_heads / c->tp);
     e->inter       = m.inter / c->tp;
     e->vocab_local = m.vocab / c->tp;
+    {
+        const char* fc = getenv("TM_FORCE_COMM");
+        e->use_comm    = c->tp > 1 || (fc && atoi(fc));
+    }
     e->qkv_n       = (e->q_heads + 2 * e->kv_heads) * e->D;
     TM_REQUIRE((e->inter * 1) % 128 == 0 && (e->q_heads * e->D) % 128 == 0 && m.hidden % 128 == 0,
                "K dims must be multiples of 128 after TP sharding");
@@ -552,7 +559,7 @@ int tm_comm_unique_id(void* host_out128)
 int tm_engine_comm_init(tm_engine* e, const void* host_id128)
 {
     TM_REQUIRE(e && host_id128, "null pointer");
-    if (e->cfg.tp == 1) {
+    if (!e->use_comm) {
         return 0;
     }
     ncclUniqueId id;
@@ -962,7 +969,9 @@ int tm_engine_decode(tm_engine* e, int steps)
         set_last_error("decode past max_new_tokens");
         return TM_TOO_LONG;
     }
-    const bool use_graph = e->cfg.use_graph && e->cfg.tp == 1;
+    // RCCL calls are kept out of graph capture unless TM_GRAPH_COMM=1 (untested on multi-GPU boxes)
+    const char* gc        = getenv("TM_GRAPH_COMM");
+    const bool  use_graph = e->cfg.use_graph && (!e->use_comm || (gc && atoi(gc)));
     if (use_graph && !e->graph) {
         // run one eager step first (lazy module loading etc. must not happen inside a capture)
         if (steps == 0) {

@@ -230,7 +230,9 @@ __global__ __launch_bounds__(WN * WK * 64) void gemm_kernel(GemmParams p)
     const int tid  = threadIdx.x;
     const int wgid = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
     if (p.dbg && tid == 0) {
-        p.dbg[wgid * 4 + 0] = __builtin_amdgcn_s_memrealtime();
+        p.dbg[wgid * 8 + 0] = __builtin_amdgcn_s_memrealtime();
+        // where this workgroup runs: XCC_ID (reg 20) and HW_ID (reg 4: wave/simd/pipe/cu/sh/se ids)
+        p.dbg[wgid * 8 + 4] = ((uint64_t)__builtin_amdgcn_s_getreg(20 | (31 << 11)) << 32) | (uint32_t)__builtin_amdgcn_s_getreg(4 | (31 << 11));
     }
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -346,7 +348,8 @@ __global__ __launch_bounds__(WN * WK * 64) void gemm_kernel(GemmParams p)
         TM_STORE_X(0, 0);
         __syncthreads();
         if (p.dbg && tid == 0) {
-            p.dbg[wgid * 4 + 1] = __builtin_amdgcn_s_memrealtime();
+            p.dbg[wgid * 8 + 1] = __builtin_amdgcn_s_memrealtime();
+        p.dbg[wgid * 8 + 5] = __builtin_amdgcn_s_memtime();  // shader-clock ticks: effective clock of the main loop
         }
 
         // ---- main loop: branch-free body, statically unrolled over the ring --------------------------
@@ -456,7 +459,8 @@ __global__ __launch_bounds__(WN * WK * 64) void gemm_kernel(GemmParams p)
 #undef TM_LOAD_X
 #undef TM_STORE_X
     if (p.dbg && tid == 0) {
-        p.dbg[wgid * 4 + 2] = __builtin_amdgcn_s_memrealtime();
+        p.dbg[wgid * 8 + 2] = __builtin_amdgcn_s_memrealtime();
+        p.dbg[wgid * 8 + 6] = __builtin_amdgcn_s_memtime();
     }
 
 
@@ -519,7 +523,226 @@ __global__ __launch_bounds__(WN * WK * 64) void gemm_kernel(GemmParams p)
     }
     if (p.dbg && tid == 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        p.dbg[wgid * 4 + 3] = __builtin_amdgcn_s_memrealtime();
+        p.dbg[wgid * 8 + 3] = __builtin_amdgcn_s_memrealtime();
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// Decode kernel (u4 weights, M <= 64, one row block): producer / consumer wave specialisation.
+//   * waves 0-7 (consumers): one 16-column tile each over the whole k-slice of the workgroup; packed weights and
+//     (s, -z*s) pairs stream through a PF-deep per-wave REGISTER ring (HBM -> VGPR, never through LDS);
+//   * wave 8 (producer): streams the activations k-block by k-block, global (L2) -> registers -> XOR-swizzled LDS
+//     image [MB][256 B], THREE buffers.  Its VMEM queue holds nothing but x loads, so their L2 latency is never
+//     queued behind the consumers' HBM weight loads (VMEM returns in order per wave), and the consumers carry no
+//     staging registers / instructions at all.
+// Iteration i (one k-block), ONE barrier at its top:
+//   consumers: read the step-3 fragments of x(i) (buffer i%3); for each 32-k step s: 4 MFMAs per row tile on the
+//              register-resident fragments xf[s], the dequantisation of the next step interleaved; as soon as xf[s]
+//              is dead it is re-filled with step s of x(i+1) (buffer (i+1)%3) -- every LDS read is issued >= 3 steps
+//              (a whole k-block for steps 0-2) before its use, so no MFMA ever waits on the LDS round trip;
+//   producer:  writes x(i+2) (loaded two iterations earlier) into buffer (i+2)%3 and issues the loads of x(i+4).
+// Buffer (i+2)%3 last held x(i-1), whose final reads (its step 3) were issued at the top of iteration i-1 and are
+// complete before the barrier of iteration i (the workgroup fence in __syncthreads waits lgkmcnt(0)).
+template<int MT, int PF, int NPROD>
+__global__ __launch_bounds__((8 + NPROD) * 64) void gemm_decode_kernel(GemmParams p)
+{
+    static_assert(PF % 2 == 0, "the producer loop is unrolled by two");
+    constexpr int MB   = 16 * MT;
+    constexpr int BUFB = MB * 256;  // one k-block of x
+    static_assert((MT * 4) % NPROD == 0, "producers split the k-block image evenly");
+    constexpr int XR   = MT * 4 / NPROD;  // b128 loads per producer lane per k-block
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // 3 * BUFB
+
+    const int tid  = threadIdx.x;
+    const int wgid = blockIdx.y * gridDim.x + blockIdx.x;
+    if (p.dbg && tid == 0) {
+        p.dbg[wgid * 8 + 0] = __builtin_amdgcn_s_memrealtime();
+        p.dbg[wgid * 8 + 4] = ((uint64_t)__builtin_amdgcn_s_getreg(20 | (31 << 11)) << 32) | (uint32_t)__builtin_amdgcn_s_getreg(4 | (31 << 11));
+    }
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i16  = lane & 15;
+    const int g    = lane >> 4;
+
+    const int ntiles  = p.N / 16;
+    const int kb0     = blockIdx.y * p.kb_per_split;
+    const int nkb     = min(p.kb_per_split, p.KB - kb0);
+    const int last    = nkb - 1;
+    const int nit_pad = (nkb + PF - 1) / PF * PF;  // both roles run exactly this many iterations (= barriers)
+
+    if (wave >= 8) {
+        // ---------------------------------------------------------------- producer ------------------------------
+        const auto rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)(((size_t)(p.M - 1) * p.ldx + p.K) * 2), 0x00020000);
+        int xoff[XR], xlds[XR];
+#pragma unroll
+        for (int r = 0; r < XR; ++r) {
+            const int q  = (r * NPROD + (wave - 8)) * 64 + lane;  // 16-B chunk q of the k-block image: row q/16, chunk q%16
+            const int m  = q >> 4;
+            const int ci = q & 15;
+            xoff[r]      = (min(m, p.M - 1) * p.ldx + ci * 8) * 2;  // rows past M feed output rows that are never stored
+            xlds[r]      = m * 256 + ((ci ^ (m & 15)) << 4);
+        }
+        u32x4 xa[XR], xb[XR];
+#define TM_PX_LOAD(dst, j)                                                                       \
+    {                                                                                            \
+        const int kb_ = kb0 + min((j), last);                                                    \
+        _Pragma("unroll") for (int r = 0; r < XR; ++r)                                           \
+        {                                                                                        \
+            dst[r] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, xoff[r], kb_ * 256, 0);         \
+        }                                                                                        \
+    }
+#define TM_PX_STORE(src, boff)                                                                   \
+    _Pragma("unroll") for (int r = 0; r < XR; ++r)                                               \
+    {                                                                                            \
+        *(u32x4*)(smem + (boff) + xlds[r]) = src[r];                                             \
+    }
+        TM_PX_LOAD(xa, 0);
+        TM_PX_LOAD(xb, 1);
+        TM_PX_STORE(xa, 0);
+        TM_PX_STORE(xb, BUFB);
+        TM_PX_LOAD(xa, 2);
+        TM_PX_LOAD(xb, 3);
+        __syncthreads();  // P: x(0), x(1) visible
+        int bw = 2 * BUFB;
+        for (int i = 0; i < nit_pad; i += 2) {
+            __syncthreads();  // barrier(i)
+            TM_PX_STORE(xa, bw);  // x(i+2)
+            bw = bw == 2 * BUFB ? 0 : bw + BUFB;
+            TM_PX_LOAD(xa, i + 4);
+            __syncthreads();  // barrier(i+1)
+            TM_PX_STORE(xb, bw);  // x(i+3)
+            bw = bw == 2 * BUFB ? 0 : bw + BUFB;
+            TM_PX_LOAD(xb, i + 5);
+        }
+#undef TM_PX_LOAD
+#undef TM_PX_STORE
+        return;
+    }
+
+    // -------------------------------------------------------------------- consumers -----------------------------
+    const int  nt_raw = blockIdx.x * 8 + wave;
+    const int  nt     = min(nt_raw, ntiles - 1);  // tiles past the edge are clamped: loads stay in bounds, stores are skipped
+    const auto rs_w   = __builtin_amdgcn_make_buffer_rsrc((void*)p.wq, 0, (int)((size_t)p.KB * ntiles * 1024), 0x00020000);
+    const auto rs_s   = __builtin_amdgcn_make_buffer_rsrc((void*)p.sz, 0, p.KB * ntiles * 64, 0x00020000);
+    const int  woff    = (nt * 64 + lane) * 16;
+    const int  soff    = (nt * 16 + i16) * 4;
+    const int  wstride = ntiles * 1024;
+    const int  sstride = ntiles * 64;
+
+    floatx4 acc[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        acc[mt] = floatx4{0.f, 0.f, 0.f, 0.f};
+    }
+    u32x4    ring[PF];
+    uint32_t sring[PF];
+    uint32_t m1024 = 0x64006400u, m64 = 0x54005400u;
+    asm volatile("" : "+v"(m1024), "+v"(m64));  // keep the magic numbers in VGPRs (see dequant8)
+
+#define TM_CW_LOAD(slot, i)                                                                              \
+    {                                                                                                    \
+        const int kb_ = kb0 + min((i), last);                                                            \
+        ring[slot]    = __builtin_amdgcn_raw_buffer_load_b128(rs_w, woff, kb_ * wstride, /*nt*/ 2);      \
+        sring[slot]   = __builtin_amdgcn_raw_buffer_load_b32(rs_s, soff, kb_ * sstride, 0);              \
+    }
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+        TM_CW_LOAD(u, u);
+        __builtin_amdgcn_sched_barrier(0);  // pin the issue order (see gemm_kernel's prologue)
+    }
+    int xr[4];  // fragment (step s, row tile 0) of this lane inside a k-block image
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        xr[s] = i16 * 256 + (((s * 4 + g) ^ i16) << 4);
+    }
+    __syncthreads();  // P
+    if (p.dbg && tid == 0) {
+        p.dbg[wgid * 8 + 1] = __builtin_amdgcn_s_memrealtime();
+        p.dbg[wgid * 8 + 5] = __builtin_amdgcn_s_memtime();  // shader-clock ticks: effective clock of the main loop
+    }
+    half8_t xf[4][MT];
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            xf[s][mt] = *(const half8_t*)(smem + xr[s] + mt * 4096);
+        }
+    }
+    auto dq = [&](int slot, int j, bool live) -> half8_t {
+        const half2_t pr = bit_cast<half2_t>(live ? sring[slot] : 0u);  // (s, -z*s) = 0 -> w = 0 in padded iterations
+        return dequant8(ring[slot][j], half2_t{pr[0], pr[0]}, half2_t{pr[1], pr[1]}, m1024, m64);
+    };
+    half8_t wfn   = dq(0, 0, true);
+    int     b_cur = 0, b_nxt = BUFB;
+    for (int base = 0; base < nit_pad; base += PF) {
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+            const int  i         = base + u;
+            const bool live      = i < nkb;  // wave-uniform
+            const bool live_next = i + 1 < nkb;
+            __syncthreads();  // barrier(i)
+            const char* cur = smem + b_cur;
+            const char* nxt = smem + b_nxt;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                xf[3][mt] = *(const half8_t*)(cur + xr[3] + mt * 4096);
+            }
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const half8_t wf = wfn;
+                wfn = s < 3 ? dq(u, s + 1, live) : dq((u + 1) % PF, 0, live_next);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf, xf[s][mt], acc[mt], 0, 0, 0);
+                }
+                if (s < 3) {
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) {
+                        xf[s][mt] = *(const half8_t*)(nxt + xr[s] + mt * 4096);  // x(i+1), step s
+                    }
+                }
+            }
+            TM_CW_LOAD(u, i + PF);
+            b_cur = b_nxt;
+            b_nxt = b_nxt == 2 * BUFB ? 0 : b_nxt + BUFB;
+        }
+    }
+#undef TM_CW_LOAD
+    if (p.dbg && tid == 0) {
+        p.dbg[wgid * 8 + 2] = __builtin_amdgcn_s_memrealtime();
+        p.dbg[wgid * 8 + 6] = __builtin_amdgcn_s_memtime();
+    }
+
+    // ---- epilogue: lane holds y[m = 16mt + i16][n = 16 nt + 4g + r], r = 0..3 ------------------------------------
+    if (nt_raw < ntiles) {
+        const int n = nt * 16 + g * 4;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int m = mt * 16 + i16;
+            if (m >= p.M) {
+                continue;
+            }
+            const floatx4 a = acc[mt];
+            if (p.epilogue == 2) {
+                *(floatx4*)(p.partial + ((size_t)blockIdx.y * p.M + m) * p.N + n) = a;
+            }
+            else if (p.epilogue == 1) {
+                const float s0 = a[0] / (1.0f + __builtin_expf(-a[0]));
+                const float s1 = a[2] / (1.0f + __builtin_expf(-a[2]));
+                half2_t     o  = {(half_t)(s0 * a[1]), (half_t)(s1 * a[3])};
+                *(half2_t*)(p.y + (size_t)m * p.ldy + (n >> 1)) = o;
+            }
+            else {
+                half4_t o = {(half_t)a[0], (half_t)a[1], (half_t)a[2], (half_t)a[3]};
+                *(half4_t*)(p.y + (size_t)m * p.ldy + n) = o;
+            }
+        }
+    }
+    if (p.dbg && tid == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        p.dbg[wgid * 8 + 3] = __builtin_amdgcn_s_memrealtime();
     }
 }
 
@@ -646,6 +869,10 @@ static int launch_u4_nt1(const GemmParams& p, dim3 grid, int ks, hipStream_t st)
                 case 4: return launch_one<0, MT, 1, WN, WK, 4, 2, 4>(p, grid, st);
                 case 8: return launch_one<0, MT, 1, WN, WK, 4, 2, 8>(p, grid, st);
                 case 16: return launch_one<0, MT, 1, WN, WK, 4, 2, 16>(p, grid, st);
+                case 7: return launch_one<0, MT, 1, WN, WK, 4, 2, 7>(p, grid, st);
+                case 24: return launch_one<0, MT, 1, WN, WK, 4, 2, 24>(p, grid, st);
+                case 3: return launch_one<0, MT, 1, WN, WK, 4, 2, 3>(p, grid, st);
+                case 12: return launch_one<0, MT, 1, WN, WK, 4, 2, 12>(p, grid, st);
                 case 15: return launch_one<0, MT, 1, WN, WK, 4, 2, 15>(p, grid, st);
                 case 31: return launch_one<0, MT, 1, WN, WK, 4, 2, 31>(p, grid, st);
                 default: break;
@@ -655,8 +882,37 @@ static int launch_u4_nt1(const GemmParams& p, dim3 grid, int ks, hipStream_t st)
       }
     }
     if (ks >= 2) return launch_one<0, MT, 1, WN, WK, 2, 4>(p, grid, st);
-    return p.kb_per_split / WK >= 16 ? launch_one<0, MT, 1, WN, WK, 1, 8>(p, grid, st) :
+    static const int pf = env_int("TM_GEMM_PF", 8);  // ring depth experiment (4 | 8)
+    return (p.kb_per_split / WK >= 16 && pf >= 8) ? launch_one<0, MT, 1, WN, WK, 1, 8>(p, grid, st) :
                                        launch_one<0, MT, 1, WN, WK, 1, 4>(p, grid, st);
+}
+
+template<int MT, int PF, int NPROD>
+static int launch_decode_pf(const GemmParams& p, dim3 grid, hipStream_t st)
+{
+    constexpr int lds_need = 3 * 16 * MT * 256;
+    // <= 256 workgroups must land one per CU (see launch_one): more than half of the LDS makes co-residency impossible
+    const int   lds      = grid.x * grid.y <= 256 ? 84 * 1024 : lds_need;
+    static bool attr_set = false;
+    if (!attr_set) {
+        TM_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_decode_kernel<MT, PF, NPROD>, hipFuncAttributeMaxDynamicSharedMemorySize, 84 * 1024));
+        attr_set = true;
+    }
+    gemm_decode_kernel<MT, PF, NPROD><<<grid, (8 + NPROD) * 64, lds, st>>>(p);
+    TM_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+template<int MT>
+static int launch_decode(const GemmParams& p, dim3 grid, hipStream_t st)
+{
+    static const int nprod = env_int("TM_GEMM_NPROD", 4);  // producer waves (1 | 2 | 4)
+    if constexpr (MT == 1) {
+        return nprod >= 4 ? launch_decode_pf<MT, 8, 4>(p, grid, st) : nprod == 2 ? launch_decode_pf<MT, 8, 2>(p, grid, st) : launch_decode_pf<MT, 8, 1>(p, grid, st);
+    }
+    else {
+        return nprod >= 4 ? launch_decode_pf<MT, 8, 4>(p, grid, st) : nprod == 2 ? launch_decode_pf<MT, 8, 2>(p, grid, st) : launch_decode_pf<MT, 8, 1>(p, grid, st);
+    }
 }
 
 template<int WT, int MT>
@@ -788,6 +1044,29 @@ int launch_linear(const LinearWeight& w,
     splits     = (KB + p.kb_per_split - 1) / p.kb_per_split;  // no empty splits
     p.epilogue = splits > 1 ? 2 : (gated_silu ? 1 : 0);
 
+    // TM_GEMM_V2=1: producer/consumer kernel for the decode shape.  Measured on MI355X (tools/nprod_sweep.sh): it ties
+    // the symmetric kernel (gate_up main loop 21-22 us either way, 1/2/4 producer waves alike), so it is NOT the
+    // default -- kept as the A/B arm that rules out "x staging / LDS round trips on the consumers' critical path".
+    static const int v2 = env_int("TM_GEMM_V2", 0);
+    if (v2 && w.type == 0 && M <= 64 && waves == 8 && wk == 1 && nt == 1) {
+        p.kb_per_split = (KB + splits - 1) / splits;
+        splits         = (KB + p.kb_per_split - 1) / p.kb_per_split;
+        p.epilogue     = splits > 1 ? 2 : (gated_silu ? 1 : 0);
+        dim3 grid((w.N / 16 + 7) / 8, splits, 1);
+        const int rc2 = mt == 1 ? launch_decode<1>(p, grid, st) : mt == 2 ? launch_decode<2>(p, grid, st) : launch_decode<4>(p, grid, st);
+        if (rc2) {
+            return rc2;
+        }
+        if (splits > 1 && !defer_reduce) {
+            const size_t total = (size_t)M * w.N / 4;
+            splitk_reduce_kernel<<<(total + 255) / 256, 256, 0, st>>>(y, ldy, workspace, splits, M, w.N, gated_silu ? 1 : 0);
+            TM_HIP_CHECK(hipGetLastError());
+        }
+        if (slabs) {
+            *slabs = splits;
+        }
+        return 0;
+    }
     const int wn     = waves / wk;
     const int ntiles = w.N / 16;
     dim3      grid((ntiles + wn * nt - 1) / (wn * nt), splits, (M + 16 * mt - 1) / (16 * mt));

@@ -53,6 +53,41 @@ def test_engine_matches_oracle(cuda, kv_bits, use_graph):
         assert np.array_equal(toks[safe, s], ref_toks[s][safe]), f'step {s}: greedy tokens differ'
 
 
+@pytest.mark.parametrize('graph_comm', [0, 1])
+def test_engine_collective_path_single_rank(cuda, monkeypatch, graph_comm):
+    """The tp > 1 data path (RCCL all-reduce after wo / w2, vocabulary-sharded lm_head + candidate all-gather), driven
+    on one GPU through a 1-rank communicator (TM_FORCE_COMM=1): must reproduce the collective-free engine exactly
+    (a 1-rank sum is the identity; the non-deferred split-K reduce rounds the same fp32 sums).  graph_comm=1 also
+    captures the RCCL calls into the decode hipGraph."""
+    cfg = o.ModelConfig(hidden=256, layers=2, q_heads=4, kv_heads=2, head_dim=128, inter=512, vocab=1024,
+                        kv_bits=8, rope=o.RopeParam(128, 500000.0, 'llama3', 8.0, 1.0, 4.0, 8192))
+    w = o.make_synthetic_weights(cfg, seed=5)
+    rng = np.random.default_rng(1)
+    prompts = [rng.integers(0, cfg.vocab, n).astype(np.int32) for n in (33, 64, 7)]
+
+    def run(force):
+        if force:
+            monkeypatch.setenv('TM_FORCE_COMM', '1')
+            monkeypatch.setenv('TM_GRAPH_COMM', str(graph_comm))
+        else:
+            monkeypatch.delenv('TM_FORCE_COMM', raising=False)
+        eng = Engine.from_model_config(cfg, max_batch_size=4, session_len=128, quant_policy=8, use_graph=1)
+        if force:
+            eng.comm_init(Engine.comm_unique_id())
+        eng.load_weights(export_weights(cfg, w))
+        eng.start()
+        eng.prefill(prompts, max_new_tokens=6)
+        eng.decode(5)
+        toks, lg = eng.fetch(), eng.fetch_logits()
+        eng.close()
+        return toks, lg
+
+    t0, l0 = run(False)
+    t1, l1 = run(True)
+    assert np.array_equal(t0, t1)
+    assert np.abs(l0.astype(np.float32) - l1.astype(np.float32)).max() <= 2e-3
+
+
 def test_engine_errors_are_status_codes(cuda):
     cfg = o.ModelConfig(hidden=256, layers=1, q_heads=2, kv_heads=1, head_dim=128, inter=256, vocab=512)
     eng = Engine.from_model_config(cfg, max_batch_size=2, session_len=128, quant_policy=8)

@@ -437,6 +437,57 @@ def test_w4a16_gated_silu(tm, cuda, K, N, M):
     _ffi.check(tm.tm_linear_destroy(h))
 
 
+@pytest.mark.parametrize('tp', [2, 4])
+def test_tp_sharded_ffn_sequential_shards(tm, cuda, tp):
+    """tensor-parallel numerics validated on ONE GPU -- column-parallel w1w3 (gate/up interleaved, fused
+    SiLU epilogue) and row-parallel w2 run shard by shard, the partial [M,H] outputs summed on the host (what the
+    RCCL all-reduce does), against the unsharded FFN.  Group-wise quantisation survives the row split because K/tp
+    stays a multiple of 128."""
+    rng = np.random.default_rng(tp)
+    H, I, M = 512, 1024, 64
+
+    def lin(q, s, z):
+        K, N = q.shape
+        h = _ffi.C.c_void_p()
+        _ffi.check(tm.tm_linear_create(_ffi.C.byref(h), K, N, 0, 128))
+        _ffi.check(tm.tm_linear_prepare(h, dev(o.pack_u4_row(q)).data_ptr(), dev(s).data_ptr(), dev(z).data_ptr(), st()))
+        torch.cuda.synchronize()
+        return h
+
+    def fwd(h, x, K, N, gated):
+        ws = torch.zeros(max(1, tm.tm_linear_workspace(h, M)), dtype=torch.uint8, device='cuda')
+        y = torch.zeros((M, N // 2 if gated else N), dtype=torch.float16, device='cuda')
+        _ffi.check(tm.tm_linear_forward(h, x.data_ptr(), K, y.data_ptr(), y.shape[1], M, gated, 0, 0, 0, ws.data_ptr(), st()))
+        torch.cuda.synchronize()
+        return y
+
+    w13 = (rng.standard_normal((H, 2 * I)) * (0.1 / math.sqrt(H))).astype(f16)
+    w2 = (rng.standard_normal((I, H)) * (0.1 / math.sqrt(I))).astype(f16)
+    q13, s13, z13, _ = o.quantize_groupwise_u4(w13, 128)
+    q2, s2, z2, _ = o.quantize_groupwise_u4(w2, 128)
+    x = dev(rng.standard_normal((M, H)).astype(f16))
+    h13, h2 = lin(q13, s13, z13), lin(q2, s2, z2)
+    full = host(fwd(h2, fwd(h13, x, H, 2 * I, 1), I, H, 0)).astype(np.float32)
+    part = np.zeros((M, H), np.float32)
+    for r in range(tp):
+        c = slice(r * 2 * I // tp, (r + 1) * 2 * I // tp)       # interleaved (gate, up) pairs stay together
+        k = slice(r * I // tp, (r + 1) * I // tp)
+        g = k.start // 128, k.stop // 128
+        a = lin(q13[:, c], s13[:, c], z13[:, c])
+        b = lin(q2[k], s2[g[0]:g[1]], z2[g[0]:g[1]])
+        mid = fwd(a, x, H, 2 * I // tp, 1)
+        ref_mid = host(fwd(h13, x, H, 2 * I, 1))[:, k]       # split-K depth may differ between shard and full op
+        dm = np.abs(host(mid).astype(np.float32) - ref_mid.astype(np.float32))
+        assert np.all(dm <= 1e-4 + 2.0**-9 * np.abs(ref_mid.astype(np.float32))), 'column shard != slice of the full op'
+        part += host(fwd(b, mid, I // tp, H, 0)).astype(np.float32)
+        _ffi.check(tm.tm_linear_destroy(a))
+        _ffi.check(tm.tm_linear_destroy(b))
+    err = np.abs(part - full)
+    assert np.all(err <= 2e-3 + tp * 2.0**-10 * np.abs(full)), f'max err {err.max()}'
+    _ffi.check(tm.tm_linear_destroy(h13))
+    _ffi.check(tm.tm_linear_destroy(h2))
+
+
 def test_w4a16_identity_asymmetric(tm, cuda):
     """Transpose-detecting check: x = I (first K rows) picks out rows of the dequantised weight exactly."""
     rng = np.random.default_rng(3)

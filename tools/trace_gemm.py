@@ -25,8 +25,9 @@ def main():
     y = torch.empty((M, N), device='cuda').half()
     ws = torch.empty(max(1, tm.tm_linear_workspace(h, M)), dtype=torch.uint8, device='cuda')
     flush = torch.empty(512 << 20, dtype=torch.uint8, device='cuda')
-    dbg = torch.zeros((8192, 4), dtype=torch.int64, device='cuda')
-    for it in range(6):
+    dbg = torch.zeros((8192, 8), dtype=torch.int64, device='cuda')
+    ratios = []
+    for it in range(int(os.environ.get('TRACE_LAUNCHES', '24'))):
         flush.fill_(it)
         dbg.zero_()
         torch.cuda.synchronize()
@@ -35,14 +36,24 @@ def main():
                                         waves, ws.data_ptr(), st))
         tm.tm_debug_set_gemm_trace(None)
         torch.cuda.synchronize()
-        tt = dbg.cpu().numpy()
-        ids = np.nonzero(tt[:, 0] > 0)[0]
-        tt = tt[ids].astype(np.float64) / 100.0
+        raw = dbg.cpu().numpy()
+        ids = np.nonzero(raw[:, 0] > 0)[0]
+        hw = raw[ids, 4]
+        tt = raw[ids, :4].astype(np.float64) / 100.0
         tt -= tt[:, 0].min()
-        order = np.argsort(-tt[:, 3])[:6]
-        print(f'launch {it}: span {tt[:, 3].max():.2f} us; slowest workgroups (id: start/loop-begin/loop-end/end): ' +
-              '  '.join(f'{ids[i]}: {tt[i,0]:.1f}/{tt[i,1]:.1f}/{tt[i,2]:.1f}/{tt[i,3]:.1f}' for i in order))
-    t = dbg.cpu().numpy()
+        loop = tt[:, 2] - tt[:, 1]
+        clk = (raw[ids, 6] - raw[ids, 5]).astype(np.float64) / np.maximum(loop, 1e-3)   # shader ticks per us = MHz
+        ratios.append(loop.max() / np.median(loop))
+        # physical CU of every workgroup: (xcc, se, sh, cu) from XCC_ID / HW_ID
+        xcc, hwid = (hw >> 32) & 0xf, hw & 0xffffffff
+        cu_key = (xcc << 16) | (hwid & 0xff00)
+        uniq, cnt = np.unique(cu_key, return_counts=True)
+        order = np.argsort(-loop)[:5]
+        print(f'launch {it}: span {tt[:, 3].max():.2f} us, loop clock {np.median(clk):.0f} MHz (min {clk.min():.0f}), loop max/median {ratios[-1]:.2f}, distinct CUs {len(uniq)} for {len(ids)} WGs '
+              f'(max {cnt.max()} WGs on one CU); slowest (id xcc:hwid loop_us sharing): ' +
+              '  '.join(f'{ids[i]} {xcc[i]}:{hwid[i] & 0xffff:04x} {loop[i]:.1f} x{cnt[np.searchsorted(uniq, cu_key[i])]}' for i in order))
+    print('loop max/median over launches: ' + ' '.join(f'{r:.2f}' for r in ratios))
+    t = dbg.cpu().numpy()[:, :4]
     t = t[t[:, 0] > 0].astype(np.float64) / 100.0      # us
     t0 = t[:, 0].min()
     t -= t0
