@@ -906,7 +906,7 @@ static int launch_decode_pf(const GemmParams& p, dim3 grid, hipStream_t st)
 template<int MT>
 static int launch_decode(const GemmParams& p, dim3 grid, hipStream_t st)
 {
-    static const int nprod = env_int("TM_GEMM_NPROD", 4);  // producer waves (1 | 2 | 4)
+    const int nprod = env_int("TM_GEMM_NPROD", 4);  // producer waves (1 | 2 | 4)
     if constexpr (MT == 1) {
         return nprod >= 4 ? launch_decode_pf<MT, 8, 4>(p, grid, st) : nprod == 2 ? launch_decode_pf<MT, 8, 2>(p, grid, st) : launch_decode_pf<MT, 8, 1>(p, grid, st);
     }
@@ -991,7 +991,13 @@ int launch_linear(const LinearWeight& w,
     }
     TM_REQUIRE(nt == 1 || nt == 2 || nt == 4, "nt in {1,2,4}");
     const int KB     = w.K / 128;
-    const int mt     = M <= 16 ? 1 : (M <= 32 ? 2 : 4);
+    int       mt     = M <= 16 ? 1 : (M <= 32 ? 2 : 4);
+    // prefill (many row blocks): 128-row workgroup tiles amortise each dequantised weight fragment over 8 MFMAs
+    // (one wave per SIMD, accumulators in AGPRs) -- with 64-row tiles the dequant VALU work equals the MFMA time
+    static const int mt_prefill = env_int("TM_GEMM_MT_PREFILL", 8);
+    if (w.type == 0 && waves == 4 && nt == 4 && M >= 128 && mt_prefill == 8) {
+        mt = 8;  // (a 256-row tile spills: 256 accumulator registers + fragments exceed the 512-register file)
+    }
     int       splits = cfg.splits < 1 ? 1 : cfg.splits;
     if (splits > KB) {
         splits = KB;
@@ -1047,7 +1053,7 @@ int launch_linear(const LinearWeight& w,
     // TM_GEMM_V2=1: producer/consumer kernel for the decode shape.  Measured on MI355X (tools/nprod_sweep.sh): it ties
     // the symmetric kernel (gate_up main loop 21-22 us either way, 1/2/4 producer waves alike), so it is NOT the
     // default -- kept as the A/B arm that rules out "x staging / LDS round trips on the consumers' critical path".
-    static const int v2 = env_int("TM_GEMM_V2", 0);
+    const int v2 = env_int("TM_GEMM_V2", 0);
     if (v2 && w.type == 0 && M <= 64 && waves == 8 && wk == 1 && nt == 1) {
         p.kb_per_split = (KB + splits - 1) / splits;
         splits         = (KB + p.kb_per_split - 1) / p.kb_per_split;
@@ -1071,7 +1077,10 @@ int launch_linear(const LinearWeight& w,
     const int ntiles = w.N / 16;
     dim3      grid((ntiles + wn * nt - 1) / (wn * nt), splits, (M + 16 * mt - 1) / (16 * mt));
     int       rc = 0;
-    if (w.type == 0) {
+    if (w.type == 0 && mt == 8) {
+        rc = launch_one<0, 8, 4, 4, 1, 1, 2>(p, grid, st);
+    }
+    else if (w.type == 0) {
         rc = mt == 1 ? launch_mt<0, 1>(p, grid, nt, waves, wk, ks, st) :
              mt == 2 ? launch_mt<0, 2>(p, grid, nt, waves, wk, ks, st) :
                        launch_mt<0, 4>(p, grid, nt, waves, wk, ks, st);

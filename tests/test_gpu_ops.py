@@ -422,6 +422,27 @@ def test_w4a16_linear(tm, cuda, K, N, M):
     _ffi.check(tm.tm_linear_destroy(h))
 
 
+@pytest.mark.parametrize('K,N,M,gated', [(4096, 6144, 64, 0), (1792, 4096, 33, 0), (384, 48, 3, 0), (4096, 1024, 64, 1), (1024, 2048, 17, 1)])
+@pytest.mark.parametrize('nprod', [1, 4])
+def test_w4a16_producer_consumer_kernel(tm, cuda, monkeypatch, K, N, M, gated, nprod):
+    """The producer/consumer decode kernel (TM_GEMM_V2=1, the A/B arm of DESIGN.md) against the same oracle."""
+    monkeypatch.setenv('TM_GEMM_V2', '1')
+    monkeypatch.setenv('TM_GEMM_NPROD', str(nprod))
+    rng = np.random.default_rng(K + N + M + 7)
+    h, (q, s, z) = _make_linear(tm, rng, K, N)
+    x = rng.standard_normal((M, K)).astype(f16)
+    ref = (o.w4a16_linear_gated_silu(x, q, s, z) if gated else x.astype(np.float32) @ _QCACHE[(K, N)][3]).astype(np.float32)
+    ws = torch.zeros(max(1, tm.tm_linear_workspace(h, M)), dtype=torch.uint8, device='cuda')
+    for splits in (1, 2, 3):
+        if splits > K // 128:
+            continue
+        y = torch.zeros((M, N // 2 if gated else N), dtype=torch.float16, device='cuda')
+        _ffi.check(tm.tm_linear_forward(h, dev(x).data_ptr(), K, y.data_ptr(), y.shape[1], M, gated, 1, splits, 8, ws.data_ptr(), st()))
+        err = np.abs(host(y).astype(np.float32) - ref)
+        assert np.all(err <= 2e-3 + 2.0**-9 * np.abs(ref)), f'splits={splits}: max err {err.max()}'
+    _ffi.check(tm.tm_linear_destroy(h))
+
+
 @pytest.mark.parametrize('K,N,M', [(4096, 1024, 64), (512, 256, 5), (1024, 2048, 130)])
 def test_w4a16_gated_silu(tm, cuda, K, N, M):
     rng = np.random.default_rng(K + N + M + 1)
