@@ -807,8 +807,9 @@ GemmConfig gemm_pick_config(const LinearWeight& w, int M)
         cfg.splits = 1;
     }
     else if (mblk > 1) {  // prefill: plenty of row blocks, maximise weight reuse per workgroup
-        cfg.nt     = 4;
-        cfg.waves  = 4;
+        static const int pw = env_int("TM_GEMM_PREFILL_WAVES", 8);
+        cfg.nt     = pw == 8 ? 2 : 4;
+        cfg.waves  = pw == 8 ? 8 : 4;
         cfg.splits = 1;
     }
     else {
@@ -995,7 +996,7 @@ int launch_linear(const LinearWeight& w,
     // prefill (many row blocks): 128-row workgroup tiles amortise each dequantised weight fragment over 8 MFMAs
     // (one wave per SIMD, accumulators in AGPRs) -- with 64-row tiles the dequant VALU work equals the MFMA time
     static const int mt_prefill = env_int("TM_GEMM_MT_PREFILL", 8);
-    if (w.type == 0 && waves == 4 && nt == 4 && M >= 128 && mt_prefill == 8) {
+    if (w.type == 0 && ((waves == 4 && nt == 4) || (waves == 8 && nt == 2 && wk == 1)) && M >= 128 && mt_prefill == 8) {
         mt = 8;  // (a 256-row tile spills: 256 accumulator registers + fragments exceed the 512-register file)
     }
     int       splits = cfg.splits < 1 ? 1 : cfg.splits;
@@ -1078,7 +1079,7 @@ int launch_linear(const LinearWeight& w,
     dim3      grid((ntiles + wn * nt - 1) / (wn * nt), splits, (M + 16 * mt - 1) / (16 * mt));
     int       rc = 0;
     if (w.type == 0 && mt == 8) {
-        rc = launch_one<0, 8, 4, 4, 1, 1, 2>(p, grid, st);
+        rc = waves == 8 ? launch_one<0, 8, 2, 8, 1, 1, 2>(p, grid, st) : launch_one<0, 8, 4, 4, 1, 1, 2>(p, grid, st);
     }
     else if (w.type == 0) {
         rc = mt == 1 ? launch_mt<0, 1>(p, grid, nt, waves, wk, ks, st) :
