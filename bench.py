@@ -155,9 +155,19 @@ def main():
             per_launch_bytes = B * ctx_prof * kv_tok / model['layers']      # one layer's KV of the whole batch
             per_launch_s = attn_ms / 1e3 / max(model['layers'], 1)          # attention (+ split-K merge) of one layer
             ach = per_launch_bytes / per_launch_s / 1e9
+            # HBM bytes per launch from the committed rocprofv3 FETCH_SIZE pass (tools/profile_bench.sh ->
+            # profiles/r01_attention_traffic.json; separate PMC run, scaled to this run's context length)
+            traffic, traffic_src = None, None
+            tj = os.path.join(ROOT, 'profiles', 'r01_attention_traffic.json')
+            if args.quant_policy == 8 and world == 1 and os.path.exists(tj):
+                with open(tj) as f:
+                    t = json.load(f)
+                traffic = int(t['traffic_over_algorithmic'] * per_launch_bytes)
+                traffic_src = (f"profiles/r01_attention_traffic.json: FETCH_SIZE pass at ctx {t['ctx_mean']}, "
+                               f"{t['traffic_over_algorithmic']:.3f} x algorithmic, scaled to ctx {ctx_prof}")
             out['roofline'] = {'bound': 'hbm', 'kernel': 'decode_attention_i8_mfma_kernel' if args.quant_policy == 8 else 'decode_attention_kernel',
                                'achieved': round(ach, 1), 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
-                               'frac': round(ach / HBM_PEAK_GBPS, 4), 'traffic': None,
+                               'frac': round(ach / HBM_PEAK_GBPS, 4), 'traffic': traffic, 'traffic_source': traffic_src,
                                'bytes_per_launch': int(per_launch_bytes), 'us_per_launch': round(per_launch_s * 1e6, 2),
                                'ctx': ctx_prof, 'timing': f'HIP events, {P} eager steps after the timed region'}
             out['kernel_ms_per_step'] = {k: round(v[0], 4) for k, v in prof.items()}

@@ -418,7 +418,9 @@ int launch_decode_attention(const DecodeAttnParams& p, hipStream_t st)
             if (valu && !fused) {
                 return launch_bits<8>(p, st);
             }
-            int rc = launch_decode_attention_i8_mfma(p, st);
+            DecodeAttnParams pt = p;
+            pt.dbg              = g_gemm_dbg;
+            int rc = launch_decode_attention_i8_mfma(pt, st);
             if (rc) {
                 return rc;
             }

@@ -130,6 +130,10 @@ __global__ __launch_bounds__(256, 2) void decode_attention_i8_mfma_kernel(Decode
     const int group   = p.q_heads / L.kv_heads;
     const int head0   = kv_head * group + chunk * hpw;
 
+    const int wgid = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    if (p.dbg && threadIdx.x == 0) {
+        p.dbg[wgid * 8 + 0] = __builtin_amdgcn_s_memrealtime();
+    }
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int i16  = lane & 15;
@@ -303,6 +307,9 @@ __global__ __launch_bounds__(256, 2) void decode_attention_i8_mfma_kernel(Decode
     }
     q1 += __shfl_xor(q1, 16);
     q1 += __shfl_xor(q1, 32);
+    if (p.dbg && threadIdx.x == 0) {
+        p.dbg[wgid * 8 + 1] = __builtin_amdgcn_s_memrealtime();
+    }
     bool patch = owns_newest;
     for (; tile >= tile_begin; tile -= 4) {
         store_tile();  // wave-private LDS: in-order DS pipeline, no barrier needed
@@ -435,6 +442,9 @@ __global__ __launch_bounds__(256, 2) void decode_attention_i8_mfma_kernel(Decode
         }
     }
 
+    if (p.dbg && threadIdx.x == 0) {
+        p.dbg[wgid * 8 + 2] = __builtin_amdgcn_s_memrealtime();  // wave 0 done with its blocks
+    }
     // ---- per-wave totals, then merge the 4 waves through LDS ------------------------------------------------
     lsum += __shfl_xor(lsum, 16);
     lsum += __shfl_xor(lsum, 32);
@@ -444,6 +454,9 @@ __global__ __launch_bounds__(256, 2) void decode_attention_i8_mfma_kernel(Decode
     zacc += __shfl_xor(zacc, 32);
 
     __syncthreads();  // every wave is done with its K/V image: the region is reused for the merge
+    if (p.dbg && threadIdx.x == 0) {
+        p.dbg[wgid * 8 + 5] = __builtin_amdgcn_s_memrealtime();  // all four waves done
+    }
     float* sm_o  = (float*)smem;                     // [4][16][128]
     float* sm_ml = (float*)(smem + 4 * 16 * D * 4);  // [4][16][2]
 #pragma unroll
@@ -492,6 +505,10 @@ __global__ __launch_bounds__(256, 2) void decode_attention_i8_mfma_kernel(Decode
                 p.partial_ml[slot * 2 + 1] = l;
             }
         }
+    }
+    if (p.dbg && threadIdx.x == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        p.dbg[wgid * 8 + 3] = __builtin_amdgcn_s_memrealtime();
     }
 }
 

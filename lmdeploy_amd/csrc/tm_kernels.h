@@ -72,6 +72,7 @@ struct DecodeAttnParams {
     int            qkv_n      = 0;
     const half2_t* cos_sin    = nullptr;
     int            max_pos    = 0;
+    uint64_t*      dbg        = nullptr;  // optional per-workgroup timing stamps (tm_debug_set_gemm_trace)
 };
 int launch_decode_attention(const DecodeAttnParams& p, hipStream_t st);
 int launch_decode_attention_i8_mfma(const DecodeAttnParams& p, hipStream_t st);  // attention_decode_mfma.hip

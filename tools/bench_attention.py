@@ -21,6 +21,7 @@ def main():
     ap.add_argument('--bits', type=int, default=8)
     ap.add_argument('--splits', default='1,2,4')
     ap.add_argument('--iters', type=int, default=20)
+    ap.add_argument('--trace', action='store_true')
     a = ap.parse_args()
     tm = _ffi.load()
     B, Hq, Hkv, ctx, bits = a.batch, a.hq, a.hkv, a.ctx, a.bits
@@ -42,6 +43,29 @@ def main():
     out = torch.empty((B, Hq * 128), device='cuda').half()
     st = torch.cuda.current_stream().cuda_stream
     bytes_per_launch = B * ctx * 2 * Hkv * (128 * bits // 8 + (4 if bits < 16 else 0))
+    if a.trace:
+        # in-kernel phase stamps (100 MHz): start / prologue done (q ready, first block issued) / wave 0 done /
+        # all waves done / end, per workgroup
+        splits = int(a.splits.split(',')[0])
+        ws = torch.empty(max(1, tm.tm_decode_attention_workspace(B, Hq, splits)), dtype=torch.uint8, device='cuda')
+        dbg = torch.zeros((8192, 8), dtype=torch.int64, device='cuda')
+        for it in range(4):
+            dbg.zero_()
+            torch.cuda.synchronize()
+            tm.tm_debug_set_gemm_trace(dbg.data_ptr())
+            view = _ffi.KvCache(ptrs.data_ptr(), cu.data_ptr(), (it % layers) * lsz, Hkv, 128, 64, bits)
+            _ffi.check(tm.tm_decode_attention(out.data_ptr(), q.data_ptr(), Hq * 128, klen.data_ptr(), B, Hq, 0.0, splits,
+                                              ws.data_ptr(), view, st))
+            tm.tm_debug_set_gemm_trace(None)
+            torch.cuda.synchronize()
+            raw = dbg.cpu().numpy()
+            t = raw[raw[:, 0] > 0].astype(np.float64) / 100.0
+            t0 = t[:, 0].min()
+            print(f'launch {it}: {len(t)} workgroups, span {t[:, 3].max() - t0:.2f} us')
+            for name, v in (('start skew', t[:, 0] - t0), ('prologue', t[:, 1] - t[:, 0]), ('wave0 loop', t[:, 2] - t[:, 1]),
+                            ('wait waves', t[:, 5] - t[:, 2]), ('merge+store', t[:, 3] - t[:, 5]), ('end time', t[:, 3] - t0)):
+                print(f'  {name:11s} min {v.min():6.2f}  mean {v.mean():6.2f}  p90 {np.percentile(v, 90):6.2f}  max {v.max():6.2f} us')
+        return
     for splits in [int(s) for s in a.splits.split(',')]:
         ws = torch.empty(max(1, tm.tm_decode_attention_workspace(B, Hq, splits)), dtype=torch.uint8, device='cuda')
         ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.iters)]
