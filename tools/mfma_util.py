@@ -1,6 +1,7 @@
 #!/usr/bin/env python
-"""MFMA utilisation of the GEMM kernels in a rocprofv3 run: SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs * GRBM_GUI_ACTIVE)
-from the PMC database, durations and achieved TFLOP/s from the kernel-trace database.
+"""MFMA utilisation of the GEMM kernels in a rocprofv3 run: SQ_VALU_MFMA_BUSY_CYCLES (summed over the 1024 SIMDs, PMC
+database) / (1024 * kernel duration * 2.4 GHz) with the duration from the kernel-trace database -- a lower bound, the
+chip clocks 2.0-2.2 GHz under this load (GRBM_GUI_ACTIVE is aggregated over several instances and only printed).
 usage: mfma_util.py <trace.db> <pmc.db> K N M"""
 import sqlite3
 import sys
@@ -19,7 +20,7 @@ def main():
     for name, (calls, ns) in dur.items():
         c = ctr.get(name, {})
         busy, act = c.get('SQ_VALU_MFMA_BUSY_CYCLES'), c.get('GRBM_GUI_ACTIVE')
-        util = busy / (1024.0 * act) if busy and act else float('nan')
+        util = busy / (1024.0 * ns * 2.4) if busy else float('nan')
         print(f'{name[:70]:70s} calls {calls:3d}  {ns/1e3:9.1f} us  {flop/ns/1e3:8.1f} TFLOP/s ({flop/ns/1e3/2500*100:5.1f} % of 2.5 PF)  '
               f'mfma_busy {busy or 0:.3e}  gui_active {act or 0:.3e}  MFMA util {100*util:5.1f} %')
 
