@@ -63,6 +63,9 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-graph', action='store_true', help='eager launches (rocprofv3 --pmc passes)')
     ap.add_argument('--layers', type=int, default=0, help='debug only: override the layer count (result is then INVALID)')
+    ap.add_argument('--emulate-tp', type=int, default=0,
+                    help='SURVEY 8(e) on a 1-GPU box: run ONE rank\'s shard of a TP=N job (heads / inter / vocab divided by N, '
+                         'collectives through a 1-rank RCCL communicator): per-rank kernel time only, labelled as such')
     args = ap.parse_args()
 
     import torch
@@ -81,6 +84,12 @@ def main():
     model = dict(LLAMA3_8B)
     if args.layers:
         model['layers'] = args.layers
+    emu = args.emulate_tp
+    if emu > 1:
+        assert world == 1, '--emulate-tp is a single-process measurement'
+        model.update(q_heads=model['q_heads'] // emu, kv_heads=max(1, model['kv_heads'] // emu), inter=model['inter'] // emu,
+                     vocab=model['vocab'] // emu)
+        os.environ['TM_FORCE_COMM'] = '1'      # the rank's collective code path, through a 1-rank communicator
     K, W, B, S = args.steps, args.warmup, args.batch, args.prompt_len
     P = args.profile_steps
     max_new = 1 + W + K + P + 2
@@ -91,6 +100,8 @@ def main():
         uid = [Engine.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(uid, src=0)
         eng.comm_init(uid[0])
+    elif emu > 1:
+        eng.comm_init(Engine.comm_unique_id())
     eng.init_synthetic(seed=0)          # same seed on every rank: shards are generated per rank-local shape
     eng.start()
 
@@ -150,6 +161,10 @@ def main():
                               'achieved': round(step_bytes / (dt / K) / 1e9, 1), 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
                               'frac': round(step_bytes / (dt / K) / 1e9 / HBM_PEAK_GBPS, 4)},
         }
+        if emu > 1:
+            out['metric'] = (f'PER-RANK EMULATION of TP={emu} on one GPU (one rank\'s shard, 1-rank collectives): '
+                             'decode tokens/sec of the rank-local kernels only -- not a multi-GPU result')
+            out['config']['emulated_tp'] = emu
         if prof:
             attn_ms, attn_n = prof['attention']
             per_launch_bytes = B * ctx_prof * kv_tok / model['layers']      # one layer's KV of the whole batch

@@ -747,6 +747,252 @@ __global__ __launch_bounds__((8 + NPROD) * 64) void gemm_decode_kernel(GemmParam
 }
 
 
+// ---------------------------------------------------------------------------------------------------------------
+// Ping-pong decode kernel (u4 weights, M <= 64): the two wave groups of a workgroup run OPPOSITE phases.
+// The symmetric kernel is bound by phase lockstep: all 8 waves of a CU issue their loads, LDS traffic, dequant VALU
+// work and MFMAs at the same moments, so the per-k-block times of those resources add up (ablation in DESIGN.md 3.1).
+// Here group A = waves 0-3 and group B = waves 4-7 (one wave of each group per SIMD) split K between them
+// (A: even k-blocks, B: odd k-blocks of the slice; partial sums added through LDS at the end) and alternate between
+//   P (prepare): dequantise the 2 x 4 weight fragments of the group's next k-block into registers (VALU), write the
+//                group's own activation k-block into its private LDS buffer, refill the register ring (VMEM);
+//   C (compute): 8*MT MFMAs per 32-k step on those fragments, activation fragments read from LDS one step ahead.
+// Two barriers per k-block pair keep the groups exactly one phase apart: while one wave of a SIMD owns the MFMA pipe,
+// the other one owns the VALU, LDS-write and VMEM issue ports.
+// Each wave: 2 column tiles (x fragments are reused for both), 4 waves per group -> 8 tiles = 128 columns per workgroup.
+template<int MT, int PF>
+__global__ __launch_bounds__(512) void gemm_pingpong_kernel(GemmParams p)
+{
+    constexpr int NT   = 2;
+    constexpr int MB   = 16 * MT;
+    constexpr int BUFB = MB * 256;      // one k-block of x, XOR-swizzled [MB][256 B]
+    constexpr int XC   = MT;            // 16-B chunks per thread per k-block (MB*16 chunks / 256 threads of a group)
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 groups][BUFB]; reused for the final reduction
+
+    const int tid  = threadIdx.x;
+    const int wgid = blockIdx.y * gridDim.x + blockIdx.x;
+    if (p.dbg && tid == 0) {
+        p.dbg[wgid * 8 + 0] = __builtin_amdgcn_s_memrealtime();
+        p.dbg[wgid * 8 + 4] = ((uint64_t)__builtin_amdgcn_s_getreg(20 | (31 << 11)) << 32) | (uint32_t)__builtin_amdgcn_s_getreg(4 | (31 << 11));
+    }
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp  = wave >> 2;  // 0 = A, 1 = B
+    const int wn   = wave & 3;
+    const int gtid = tid & 255;  // thread index inside the group
+    const int i16  = lane & 15;
+    const int g    = lane >> 4;
+
+    const int ntiles = p.N / 16;
+    const int kb0    = blockIdx.y * p.kb_per_split;
+    const int nkb    = min(p.kb_per_split, p.KB - kb0);  // even (host guarantees)
+    const int nsi    = nkb / 2;                          // k-block pairs: group grp contracts kb0 + 2j + grp
+    const int last   = nsi - 1;
+    const int nt_raw = (blockIdx.x * 4 + wn) * NT;
+
+    const auto rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.wq, 0, (int)((size_t)p.KB * ntiles * 1024), 0x00020000);
+    const auto rs_s = __builtin_amdgcn_make_buffer_rsrc((void*)p.sz, 0, p.KB * ntiles * 64, 0x00020000);
+    const auto rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)(((size_t)(p.M - 1) * p.ldx + p.K) * 2), 0x00020000);
+    int woff[NT], soff[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int nt = min(nt_raw + t, ntiles - 1);  // clamped: loads stay in bounds, stores are skipped
+        woff[t]      = (nt * 64 + lane) * 16;
+        soff[t]      = (nt * 16 + i16) * 4;
+    }
+    const int wstride = ntiles * 1024;
+    const int sstride = ntiles * 64;
+    int       xoff[XC], xlds[XC];
+#pragma unroll
+    for (int c = 0; c < XC; ++c) {
+        const int q  = c * 256 + gtid;  // chunk q of the group's k-block image: row q/16, chunk q%16
+        const int m  = q >> 4;
+        const int ci = q & 15;
+        xoff[c]      = (min(m, p.M - 1) * p.ldx + ci * 8) * 2;
+        xlds[c]      = grp * BUFB + m * 256 + ((ci ^ (m & 15)) << 4);
+    }
+    int xr[4];  // activation fragment (32-k step s, row tile 0) of this lane inside the group's image
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        xr[s] = grp * BUFB + i16 * 256 + (((s * 4 + g) ^ i16) << 4);
+    }
+
+    floatx4 acc[NT][MT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            acc[t][mt] = floatx4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+    u32x4    ring[PF][NT];
+    uint32_t sring[PF][NT];
+    u32x4    xs[PF][XC];
+    half8_t  wf[NT][4];
+    uint32_t m1024 = 0x64006400u, m64 = 0x54005400u;
+    asm volatile("" : "+v"(m1024), "+v"(m64));  // keep the magic numbers in VGPRs (see dequant8)
+
+#define TM_PP_LOAD(slot, j)                                                                                  \
+    {                                                                                                        \
+        const int kb_ = kb0 + 2 * min((j), last) + grp;                                                      \
+        _Pragma("unroll") for (int c = 0; c < XC; ++c)                                                       \
+        {                                                                                                    \
+            xs[slot][c] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, xoff[c], kb_ * 256, 0);                \
+        }                                                                                                    \
+        _Pragma("unroll") for (int t = 0; t < NT; ++t)                                                       \
+        {                                                                                                    \
+            ring[slot][t]  = __builtin_amdgcn_raw_buffer_load_b128(rs_w, woff[t], kb_ * wstride, /*nt*/ 2);  \
+            sring[slot][t] = __builtin_amdgcn_raw_buffer_load_b32(rs_s, soff[t], kb_ * sstride, 0);          \
+        }                                                                                                    \
+    }
+    // P(j): operands of k-block pair j for this group
+#define TM_PP_PREPARE(slot, j, live)                                                                         \
+    {                                                                                                        \
+        _Pragma("unroll") for (int t = 0; t < NT; ++t)                                                       \
+        {                                                                                                    \
+            const half2_t pr = bit_cast<half2_t>((live) ? sring[slot][t] : 0u);                              \
+            _Pragma("unroll") for (int s = 0; s < 4; ++s)                                                    \
+            {                                                                                                \
+                wf[t][s] = dequant8(ring[slot][t][s], half2_t{pr[0], pr[0]}, half2_t{pr[1], pr[1]}, m1024, m64); \
+            }                                                                                                \
+        }                                                                                                    \
+        _Pragma("unroll") for (int c = 0; c < XC; ++c)                                                       \
+        {                                                                                                    \
+            *(u32x4*)(smem + xlds[c]) = xs[slot][c];                                                         \
+        }                                                                                                    \
+        TM_PP_LOAD(slot, (j) + PF);                                                                          \
+    }
+    // C(j): contract the prepared k-block
+#define TM_PP_COMPUTE()                                                                                      \
+    {                                                                                                        \
+        half8_t xf[MT], xfn[MT];                                                                             \
+        _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                                    \
+        {                                                                                                    \
+            xf[mt] = *(const half8_t*)(smem + xr[0] + mt * 4096);                                            \
+        }                                                                                                    \
+        _Pragma("unroll") for (int s = 0; s < 4; ++s)                                                        \
+        {                                                                                                    \
+            if (s < 3) {                                                                                     \
+                _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                            \
+                {                                                                                            \
+                    xfn[mt] = *(const half8_t*)(smem + xr[s + 1] + mt * 4096);                               \
+                }                                                                                            \
+            }                                                                                                \
+            _Pragma("unroll") for (int t = 0; t < NT; ++t)                                                   \
+            {                                                                                                \
+                _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                            \
+                {                                                                                            \
+                    acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[t][s], xf[mt], acc[t][mt], 0, 0, 0); \
+                }                                                                                            \
+            }                                                                                                \
+            if (s < 3) {                                                                                     \
+                _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                            \
+                {                                                                                            \
+                    xf[mt] = xfn[mt];                                                                        \
+                }                                                                                            \
+            }                                                                                                \
+        }                                                                                                    \
+    }
+
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+        TM_PP_LOAD(u, u);
+        __builtin_amdgcn_sched_barrier(0);  // pin the issue order (see gemm_kernel's prologue)
+    }
+    if (p.dbg && tid == 0) {
+        p.dbg[wgid * 8 + 1] = __builtin_amdgcn_s_memrealtime();
+        p.dbg[wgid * 8 + 5] = __builtin_amdgcn_s_memtime();
+    }
+
+    const int nsi_pad = (nsi + PF - 1) / PF * PF;
+    if (grp == 0) {
+        for (int base = 0; base < nsi_pad; base += PF) {
+#pragma unroll
+            for (int u = 0; u < PF; ++u) {
+                const int j = base + u;
+                TM_PP_PREPARE(u, j, j < nsi);
+                __syncthreads();
+                TM_PP_COMPUTE();
+                __syncthreads();
+            }
+        }
+        __syncthreads();  // pairs with group B's trailing compute slot
+    }
+    else {
+        for (int base = 0; base < nsi_pad; base += PF) {
+#pragma unroll
+            for (int u = 0; u < PF; ++u) {
+                const int j = base + u;
+                if (j > 0) {
+                    TM_PP_COMPUTE();  // k-block pair j-1
+                }
+                __syncthreads();
+                TM_PP_PREPARE(u, j, j < nsi);
+                __syncthreads();
+            }
+        }
+        TM_PP_COMPUTE();
+        __syncthreads();
+    }
+#undef TM_PP_LOAD
+#undef TM_PP_PREPARE
+#undef TM_PP_COMPUTE
+    if (p.dbg && tid == 0) {
+        p.dbg[wgid * 8 + 2] = __builtin_amdgcn_s_memrealtime();
+        p.dbg[wgid * 8 + 6] = __builtin_amdgcn_s_memtime();
+    }
+
+    // ---- group B's partial sums -> LDS -> group A (the x images are dead after the last barrier) -----------------
+    floatx4* red = (floatx4*)smem;  // [wn][t][mt][lane]
+    if (grp == 1) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                red[((wn * NT + t) * MT + mt) * 64 + lane] = acc[t][mt];
+            }
+        }
+    }
+    __syncthreads();
+    if (grp == 1) {
+        return;
+    }
+    // ---- epilogue: lane holds y[m = 16mt + i16][n = 16(nt_raw + t) + 4g + r], r = 0..3 ---------------------------
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        if (nt_raw + t >= ntiles) {
+            continue;
+        }
+        const int n = (nt_raw + t) * 16 + g * 4;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int m = mt * 16 + i16;
+            if (m >= p.M) {
+                continue;
+            }
+            const floatx4 a = acc[t][mt] + red[((wn * NT + t) * MT + mt) * 64 + lane];
+            if (p.epilogue == 2) {
+                *(floatx4*)(p.partial + ((size_t)blockIdx.y * p.M + m) * p.N + n) = a;
+            }
+            else if (p.epilogue == 1) {
+                const float s0 = a[0] / (1.0f + __builtin_expf(-a[0]));
+                const float s1 = a[2] / (1.0f + __builtin_expf(-a[2]));
+                half2_t     o  = {(half_t)(s0 * a[1]), (half_t)(s1 * a[3])};
+                *(half2_t*)(p.y + (size_t)m * p.ldy + (n >> 1)) = o;
+            }
+            else {
+                half4_t o = {(half_t)a[0], (half_t)a[1], (half_t)a[2], (half_t)a[3]};
+                *(half4_t*)(p.y + (size_t)m * p.ldy + n) = o;
+            }
+        }
+    }
+    if (p.dbg && tid == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        p.dbg[wgid * 8 + 3] = __builtin_amdgcn_s_memrealtime();
+    }
+}
+
+
 // y = h(sum_s partial[s]) (optionally through the gated-SiLU epilogue): 4 columns per thread
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(half_t* __restrict__ y,
                                                             int ldy,
@@ -916,6 +1162,28 @@ static int launch_decode(const GemmParams& p, dim3 grid, hipStream_t st)
     }
 }
 
+template<int MT, int PF>
+static int launch_pingpong_pf(const GemmParams& p, dim3 grid, hipStream_t st)
+{
+    constexpr int lds_need = 2 * 16 * MT * 256;
+    const int     lds      = grid.x * grid.y <= 256 ? 84 * 1024 : lds_need;  // one workgroup per CU (see launch_one)
+    static bool   attr_set = false;
+    if (!attr_set) {
+        TM_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_pingpong_kernel<MT, PF>, hipFuncAttributeMaxDynamicSharedMemorySize, 84 * 1024));
+        attr_set = true;
+    }
+    gemm_pingpong_kernel<MT, PF><<<grid, 512, lds, st>>>(p);
+    TM_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+template<int MT>
+static int launch_pingpong(const GemmParams& p, dim3 grid, hipStream_t st)
+{
+    const int pf = env_int("TM_GEMM_PP_PF", 3);  // ring depth in k-block pairs (registers: 3 is the most that fits)
+    return pf <= 2 ? launch_pingpong_pf<MT, 2>(p, grid, st) : launch_pingpong_pf<MT, 3>(p, grid, st);
+}
+
 template<int WT, int MT>
 static int launch_mt(const GemmParams& p, dim3 grid, int nt, int waves, int wk, int ks, hipStream_t st)
 {
@@ -1051,6 +1319,29 @@ int launch_linear(const LinearWeight& w,
     splits     = (KB + p.kb_per_split - 1) / p.kb_per_split;  // no empty splits
     p.epilogue = splits > 1 ? 2 : (gated_silu ? 1 : 0);
 
+    // TM_GEMM_PP=1: ping-pong kernel for the decode shape (two wave groups in opposite phases, K split between them)
+    const int pp = env_int("TM_GEMM_PP", 0);
+    if (pp && w.type == 0 && M <= 64 && waves == 8 && KB % 2 == 0) {
+        int per        = (KB + splits - 1) / splits;
+        per            = (per + 1) / 2 * 2;
+        p.kb_per_split = per;
+        splits         = (KB + per - 1) / per;
+        p.epilogue     = splits > 1 ? 2 : (gated_silu ? 1 : 0);
+        dim3 grid((w.N / 16 + 7) / 8, splits, 1);
+        const int rc3 = mt == 1 ? launch_pingpong<1>(p, grid, st) : mt == 2 ? launch_pingpong<2>(p, grid, st) : launch_pingpong<4>(p, grid, st);
+        if (rc3) {
+            return rc3;
+        }
+        if (splits > 1 && !defer_reduce) {
+            const size_t total = (size_t)M * w.N / 4;
+            splitk_reduce_kernel<<<(total + 255) / 256, 256, 0, st>>>(y, ldy, workspace, splits, M, w.N, gated_silu ? 1 : 0);
+            TM_HIP_CHECK(hipGetLastError());
+        }
+        if (slabs) {
+            *slabs = splits;
+        }
+        return 0;
+    }
     // TM_GEMM_V2=1: producer/consumer kernel for the decode shape.  Measured on MI355X (tools/nprod_sweep.sh): it ties
     // the symmetric kernel (gate_up main loop 21-22 us either way, 1/2/4 producer waves alike), so it is NOT the
     // default -- kept as the A/B arm that rules out "x staging / LDS round trips on the consumers' critical path".
