@@ -196,6 +196,10 @@ def main():
             from oracle import cpu_baseline
             out['cpu_baseline'] = cpu_baseline.run(model, B, S, sample_layers=1)
         out['sample_tokens'] = toks[0, :4].tolist()
+        # RCCL prints a version banner through C stdio (fully buffered on a pipe): push it out first so that the JSON
+        # line is the LAST line of stdout
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
         print(json.dumps(out), flush=True)
     eng.close()
     if world > 1:
