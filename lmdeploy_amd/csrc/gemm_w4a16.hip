@@ -208,7 +208,8 @@ __device__ __forceinline__ half8_t dequant8(uint32_t w, half2_t s2, half2_t z2, 
 //     waitcnt) that nothing hides while all waves of the CU move in lockstep (measured by ablation: the phases of an
 //     iteration are additive): more k-blocks per barrier amortise that chain.
 // ABL: ablation bit mask for tools/ablate_gemm.sh (timing experiments only, results are garbage):
-//   1 no dequant VALU, 2 no MFMA, 4 no LDS x reads, 8 no x staging (loads + LDS writes), 16 no weight loads in the loop
+//   1 no dequant VALU, 2 no MFMA, 4 no LDS x reads, 8 no x staging (loads + LDS writes), 16 no weight loads in the loop,
+//   32 half of the activation loads, 64 half of the activation LDS writes
 template<int WT, int MT, int NT, int WN, int WK, int KS, int PF, int ABL = 0>
 __global__ __launch_bounds__(WN * WK * 64) void gemm_kernel(GemmParams p)
 {
@@ -318,13 +319,13 @@ __global__ __launch_bounds__(WN * WK * 64) void gemm_kernel(GemmParams p)
 #define TM_LOAD_X(set, i)                                                                                    \
     {                                                                                                        \
         const int kb_ = kb0 + min((i), last) * SUBS;                                                         \
-        _Pragma("unroll") for (int r = 0; r < XR; ++r)                                                       \
+        _Pragma("unroll") for (int r = 0; r < ((ABL & 32) ? (XR + 1) / 2 : XR); ++r)                         \
         {                                                                                                    \
             xs[set][r] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, xoff[r], kb_ * 256, 0);                 \
         }                                                                                                    \
     }
 #define TM_STORE_X(set, buf)                                                                                 \
-    _Pragma("unroll") for (int r = 0; r < XR; ++r)                                                           \
+    _Pragma("unroll") for (int r = 0; r < ((ABL & 64) ? (XR + 1) / 2 : XR); ++r)                             \
     {                                                                                                        \
         if (XFULL || xlds[r] >= 0) {                                                                         \
             *(u32x4*)(smem + (buf)*BUFB + xlds[r]) = xs[set][r];                                             \
@@ -1117,6 +1118,9 @@ static int launch_u4_nt1(const GemmParams& p, dim3 grid, int ks, hipStream_t st)
                 case 8: return launch_one<0, MT, 1, WN, WK, 4, 2, 8>(p, grid, st);
                 case 16: return launch_one<0, MT, 1, WN, WK, 4, 2, 16>(p, grid, st);
                 case 7: return launch_one<0, MT, 1, WN, WK, 4, 2, 7>(p, grid, st);
+                case 32: return launch_one<0, MT, 1, WN, WK, 4, 2, 32>(p, grid, st);
+                case 64: return launch_one<0, MT, 1, WN, WK, 4, 2, 64>(p, grid, st);
+                case 96: return launch_one<0, MT, 1, WN, WK, 4, 2, 96>(p, grid, st);
                 case 24: return launch_one<0, MT, 1, WN, WK, 4, 2, 24>(p, grid, st);
                 case 3: return launch_one<0, MT, 1, WN, WK, 4, 2, 3>(p, grid, st);
                 case 12: return launch_one<0, MT, 1, WN, WK, 4, 2, 12>(p, grid, st);
