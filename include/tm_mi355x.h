@@ -219,8 +219,39 @@ int tm_engine_profile_decode(tm_engine* e, int steps, float* host_ms_per_step, i
 int tm_engine_fetch(tm_engine* e, int* host_out, int* n_generated);
 /* last step's logits of the local vocab shard, fp16 [batch][vocab/tp] -> host (debug / parity tests) */
 int tm_engine_fetch_logits(tm_engine* e, void* host_out);
-/* release the batch (blocks return to the pool) */
+/* release the batch (blocks return to the pool); also ends a continuous-batching session */
 int tm_engine_release(tm_engine* e);
+
+/* ----------------------------------------------------------------------------------------------
+ * Continuous batching.  Replaces ModelRequest.forward / cancel + the engine thread's
+ * schedule-forward-update loop (bind.cpp:743-793, engine/engine.cc:434-470,770-870, model_request.cc:36-135):
+ * requests are queued, admitted in arrival order when a batch slot and enough KV blocks (prompt + max_new_tokens,
+ * 64-token blocks) are free, prefilled (chunked, <= max_prefill_token_num prompt tokens per step) and then decoded
+ * together with everything else that is running; a sequence ends on eos_id (eos_id < 0: ignore_eos), at
+ * max_new_tokens or on cancel, and its slot / blocks are reused by the next admission.  Greedy sampling.
+ * The first tm_engine_submit switches the engine into this mode (no static batch may be admitted);
+ * tm_engine_release leaves it.  The caller drives the loop: one tm_engine_step = admissions + ONE decode step.
+ * submit: 0 queued | TM_INVALID (empty prompt, max_new_tokens < 1) | TM_TOO_LONG (> session_len) |
+ *         TM_OOM (can never fit the block pool).  poll: status 0 = waiting / running, TM_FINISH, TM_CANCEL;
+ *         copies min(cap, n_tokens) generated tokens.  Unknown ids: TM_INVALID. */
+int tm_engine_submit(tm_engine* e, const int* host_ids, int n, int max_new_tokens, int eos_id, int64_t* req_id);
+int tm_engine_step(tm_engine* e, int* n_active, int* n_waiting);
+int tm_engine_poll(tm_engine* e, int64_t req_id, int* status, int* host_tokens, int cap, int* n_tokens);
+int tm_engine_cancel(tm_engine* e, int64_t req_id);
+
+/* The scheduler by itself (host-only bookkeeping: queue, slots, block accounting) -- what the engine embeds,
+ * exported so that its policy is testable without a GPU (engine/scheduler.cc:1018-1078 at the level used here). */
+typedef struct tm_sched tm_sched;
+int tm_sched_create(tm_sched** out, int max_batch, int num_blocks, int session_len);
+int tm_sched_destroy(tm_sched* s);
+int tm_sched_submit(tm_sched* s, const int* ids, int n, int max_new_tokens, int eos_id, int64_t* req_id);
+/* admit waiting requests for one step: writes up to cap (request id, slot) pairs */
+int tm_sched_admit(tm_sched* s, int token_budget, int64_t* req_ids, int* slots, int cap, int* n_admitted);
+int tm_sched_on_token(tm_sched* s, int slot, int token, int* finished);
+int tm_sched_cancel(tm_sched* s, int64_t req_id, int* released_slot);
+/* status (Request::k*), slot (-1 unless running), tokens generated, blocks held; TM_INVALID for unknown ids */
+int tm_sched_query(tm_sched* s, int64_t req_id, int* status, int* slot, int* n_generated, int* n_blocks);
+int tm_sched_counts(tm_sched* s, int* n_active, int* n_waiting, int* n_free_blocks);
 /* the engine's stream (hipStream_t) so callers can bracket it with their own events */
 tm_stream_t tm_engine_stream(tm_engine* e);
 /* introspection for benchmarks: bytes of quantised weights + scales + lm_head, KV bytes per token, #blocks */

@@ -93,6 +93,18 @@ _SIGNATURES = {
     'tm_engine_fetch': (c_int, [c_void_p, c_void_p, POINTER(c_int)]),
     'tm_engine_fetch_logits': (c_int, [c_void_p, c_void_p]),
     'tm_engine_release': (c_int, [c_void_p]),
+    'tm_engine_submit': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, POINTER(c_int64)]),
+    'tm_engine_step': (c_int, [c_void_p, POINTER(c_int), POINTER(c_int)]),
+    'tm_engine_poll': (c_int, [c_void_p, c_int64, POINTER(c_int), c_void_p, c_int, POINTER(c_int)]),
+    'tm_engine_cancel': (c_int, [c_void_p, c_int64]),
+    'tm_sched_create': (c_int, [POINTER(c_void_p), c_int, c_int, c_int]),
+    'tm_sched_destroy': (c_int, [c_void_p]),
+    'tm_sched_submit': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, POINTER(c_int64)]),
+    'tm_sched_admit': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, POINTER(c_int)]),
+    'tm_sched_on_token': (c_int, [c_void_p, c_int, c_int, POINTER(c_int)]),
+    'tm_sched_cancel': (c_int, [c_void_p, c_int64, POINTER(c_int)]),
+    'tm_sched_query': (c_int, [c_void_p, c_int64, POINTER(c_int), POINTER(c_int), POINTER(c_int), POINTER(c_int)]),
+    'tm_sched_counts': (c_int, [c_void_p, POINTER(c_int), POINTER(c_int), POINTER(c_int)]),
     'tm_engine_stream': (c_void_p, [c_void_p]),
     'tm_engine_stats': (c_int, [c_void_p, POINTER(c_int64), POINTER(c_int64), POINTER(c_int64), POINTER(c_int)]),
 }

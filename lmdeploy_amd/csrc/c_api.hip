@@ -1,5 +1,6 @@
 // C-ABI shims for the operator-level entry points declared in include/tm_mi355x.h.
 #include "../../include/tm_mi355x.h"
+#include "scheduler.h"
 #include "tm_common.h"
 #include "tm_kernels.h"
 #include <cmath>
@@ -298,6 +299,80 @@ int tm_linear_destroy(tm_linear* w)
 }
 
 /* debug: device buffer of [workgroups][4] uint64 receiving s_memrealtime stamps of every GEMM workgroup (NULL = off) */
+// ---- host-only scheduler hooks (scheduler.h) ----------------------------------------------------------------------
+struct tm_sched {
+    tmk::BatchScheduler impl;
+    tm_sched(int b, int n, int s): impl(b, n, s) {}
+};
+
+int tm_sched_create(tm_sched** out, int max_batch, int num_blocks, int session_len)
+{
+    TM_REQUIRE(out && max_batch >= 1 && num_blocks >= 1 && session_len >= 2, "bad scheduler geometry");
+    *out = new tm_sched(max_batch, num_blocks, session_len);
+    return 0;
+}
+
+int tm_sched_destroy(tm_sched* s)
+{
+    delete s;
+    return 0;
+}
+
+int tm_sched_submit(tm_sched* s, const int* ids, int n, int max_new_tokens, int eos_id, int64_t* req_id)
+{
+    TM_REQUIRE(s && req_id, "null pointer");
+    return s->impl.submit(ids, n, max_new_tokens, eos_id, req_id);
+}
+
+int tm_sched_admit(tm_sched* s, int token_budget, int64_t* req_ids, int* slots, int cap, int* n_admitted)
+{
+    TM_REQUIRE(s && req_ids && slots && n_admitted, "null pointer");
+    const auto a = s->impl.admit(token_budget);
+    TM_REQUIRE((int)a.size() <= cap, "output arrays too small");
+    for (size_t i = 0; i < a.size(); ++i) {
+        req_ids[i] = a[i].id;
+        slots[i]   = a[i].slot;
+    }
+    *n_admitted = (int)a.size();
+    return 0;
+}
+
+int tm_sched_on_token(tm_sched* s, int slot, int token, int* finished)
+{
+    TM_REQUIRE(s && finished, "null pointer");
+    *finished = s->impl.on_token(slot, token) ? 1 : 0;
+    return 0;
+}
+
+int tm_sched_cancel(tm_sched* s, int64_t req_id, int* released_slot)
+{
+    TM_REQUIRE(s, "null pointer");
+    return s->impl.cancel(req_id, released_slot);
+}
+
+int tm_sched_query(tm_sched* s, int64_t req_id, int* status, int* slot, int* n_generated, int* n_blocks)
+{
+    TM_REQUIRE(s, "null pointer");
+    const tmk::SchedRequest* r = s->impl.find(req_id);
+    if (!r) {
+        return TM_INVALID;
+    }
+    if (status) *status = r->status;
+    if (slot) *slot = r->slot;
+    if (n_generated) *n_generated = (int)r->out.size();
+    if (n_blocks) *n_blocks = (int)r->blocks.size();
+    return 0;
+}
+
+int tm_sched_counts(tm_sched* s, int* n_active, int* n_waiting, int* n_free_blocks)
+{
+    TM_REQUIRE(s, "null pointer");
+    if (n_active) *n_active = s->impl.n_active();
+    if (n_waiting) *n_waiting = s->impl.n_waiting();
+    if (n_free_blocks) *n_free_blocks = s->impl.n_free_blocks();
+    return 0;
+}
+
 int tm_debug_set_gemm_trace(void* dev_buf)
 {
     tmk::g_gemm_dbg = (uint64_t*)dev_buf;

@@ -10,12 +10,14 @@
 // fp16 [M,H] partial sums (comm/nccl/nccl.cu:356-398), lm_head sharded over the vocabulary with a
 // (value, index) all-gather instead of gathering logits.
 #include "../../include/tm_mi355x.h"
+#include "scheduler.h"
 #include "tm_common.h"
 #include "tm_kernels.h"
 #include <algorithm>
 #include <cmath>
 #include <cstring>
 #include <map>
+#include <memory>
 #include <rccl/rccl.h>
 #include <chrono>
 #include <string>
@@ -78,6 +80,15 @@ __global__ void advance_kernel(int* k_len, int batch)
 {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b < batch) {
+        k_len[b] += 1;
+    }
+}
+
+// continuous batching: only slots that hold a running sequence advance
+__global__ void advance_active_kernel(int* k_len, const int* active, int batch)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < batch && active[b]) {
         k_len[b] += 1;
     }
 }
@@ -213,6 +224,17 @@ struct tm_engine {
     std::vector<std::tuple<int, size_t, size_t>>    prof_spans;  // (category, start event, stop event)
     std::vector<float>                              h_ttft_ms;
     int            graph_batch = 0;
+    int            graph_max_new = 0;  // record_kernel's bound is a captured kernel argument
+
+    // continuous batching (tm_engine_submit / step / poll / cancel): slot-based, every decode step runs all
+    // max_batch_size slots; free slots are parked on a scratch block with k_len = 1 and never advance
+    std::unique_ptr<tmk::BatchScheduler> sched;
+    int*             d_active    = nullptr;  // [max_batch] 1 = slot holds a running sequence
+    int*             d_pf_k_len  = nullptr;  // prefill-local arrays (the decode arrays stay live during an admission)
+    int*             d_pf_cu_q   = nullptr;
+    std::vector<int> h_active, h_step_ids;
+    int              dummy_block = -1;
+    hipGraphExec_t   graph_cb    = nullptr;
 };
 
 namespace tmk {
@@ -788,6 +810,223 @@ int tm_engine_start(tm_engine* e)
     return 0;
 }
 
+// decode split heuristic: fill >= 2 workgroups per CU (GetSplitCount, kernels/attention/utils.cc:11-46); fused prologue
+static void setup_decode(tm_engine* e, int batch)
+{
+    const tm_engine_config& c = e->cfg;
+    int splits = c.decode_splits;
+    if (splits <= 0) {
+        int group = e->q_heads / e->kv_heads, hpw = 1;
+        for (int cand = 4; cand >= 1; --cand) {
+            if (group % cand == 0) {
+                hpw = cand;
+                break;
+            }
+        }
+        const int wgs = e->kv_heads * (group / hpw) * batch;
+        splits        = 1;
+        while (wgs * splits < 512 && splits < 16) {
+            splits *= 2;
+        }
+    }
+    e->decode_splits = std::min(std::max(splits, 1), 16);
+    const char* valu = getenv("TM_ATTN_VALU");
+    const char* fuse = getenv("TM_FUSE_QKV");
+    e->fuse_qkv      = e->cfg.quant_policy == 8 && !(valu && atoi(valu)) && !(fuse && !atoi(fuse));
+}
+
+// Chunked prefill of `batch` sequences into the batch slots [slot0, slot0 + batch): whole sequences,
+// <= max_prefill_token_num tokens per iteration (a sequence longer than the budget is split into history + new tokens).
+// Logits / first tokens land in d_logits / d_next_ids at slot0 + i.  Uses e->d_k_len / d_cu_q as iteration-local arrays.
+static int prefill_slots(tm_engine* e, const int* const* seq_ids, const int* host_lens, int batch, int slot0, float* ttft_ms)
+{
+    const int  budget  = e->max_tokens;
+    const auto t_start = std::chrono::steady_clock::now();
+    // Because the batch tables (block_ptrs, cu_block_nums) are indexed by the batch slot, every prefill
+    // iteration covers a contiguous range of slots [b0, b1]; the block table is offset accordingly and the
+    // logits / first tokens of the iteration land in d_logits / d_next_ids at slot b0 + i.
+    int b0 = 0;
+    int done_in_b0 = 0;  // tokens of sequence b0 already prefilled (chunked long prompt)
+    while (b0 < batch) {
+        std::vector<int> cu_q{0}, klen, koff{0}, rows, ids;
+        int b1 = b0, tokens = 0, max_q = 0, max_k = 0;
+        bool partial_last = false;
+        while (b1 < batch) {
+            const int start  = (b1 == b0) ? done_in_b0 : 0;
+            const int remain = host_lens[b1] - start;
+            const int take   = std::min(remain, budget - tokens);
+            if (take <= 0) {
+                break;
+            }
+            ids.insert(ids.end(), seq_ids[b1] + start, seq_ids[b1] + start + take);
+            tokens += take;
+            cu_q.push_back(tokens);
+            klen.push_back(start + take);
+            koff.push_back(koff.back() + ((start + take + 63) / 64) * 64);
+            rows.push_back(tokens - 1);
+            max_q = std::max(max_q, take);
+            max_k = std::max(max_k, start + take);
+            if (take < remain) {  // budget exhausted inside this sequence: it continues in the next iteration
+                done_in_b0   = start + take;
+                partial_last = true;
+                break;
+            }
+            ++b1;
+        }
+        const int nseq = (int)klen.size();
+        TM_REQUIRE(nseq >= 1, "internal: empty prefill iteration");
+        TM_REQUIRE(koff.back() <= e->kflat_stride, "internal: flatten scratch too small");
+        TM_HIP_CHECK(hipMemcpyAsync(e->d_prefill_ids, ids.data(), ids.size() * 4, hipMemcpyHostToDevice, e->stream));
+        TM_HIP_CHECK(hipMemcpyAsync(e->d_cu_q, cu_q.data(), cu_q.size() * 4, hipMemcpyHostToDevice, e->stream));
+        TM_HIP_CHECK(hipMemcpyAsync(e->d_k_len, klen.data(), klen.size() * 4, hipMemcpyHostToDevice, e->stream));
+        TM_HIP_CHECK(hipMemcpyAsync(e->d_cu_koff, koff.data(), koff.size() * 4, hipMemcpyHostToDevice, e->stream));
+        TM_HIP_CHECK(hipMemcpyAsync(e->d_rows, rows.data(), rows.size() * 4, hipMemcpyHostToDevice, e->stream));
+        // shift the block tables so that slot 0 of this iteration is sequence b0
+        uint64_t* saved_ptrs = e->d_block_ptrs;
+        e->d_block_ptrs += (size_t)(slot0 + b0) * e->max_blocks_per_seq;
+        const int rc    = forward(e, e->d_prefill_ids, tokens, nseq, false, max_q, max_k, e->kflat_stride, slot0 + b0);
+        e->d_block_ptrs = saved_ptrs;
+        if (rc) {
+            return rc;
+        }
+        // the host vectors above are pageable: make sure the async copies are done before they die
+        TM_HIP_CHECK(hipStreamSynchronize(e->stream));
+        if (ttft_ms) {
+            const float ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_start).count();
+            for (int b = b0; b < b1; ++b) {
+                ttft_ms[b] = ms;  // first token of sequence b exists once its last chunk has been processed
+            }
+        }
+        b0 = b1;  // a partially prefilled sequence (b1) is revisited with done_in_b0 tokens of history
+        if (!partial_last) {
+            done_in_b0 = 0;
+        }
+    }
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Continuous batching: request queue + slot scheduler (scheduler.h) on top of the same forward().
+// Every decode step runs all max_batch_size slots (one graph); a free slot is parked on a scratch block with
+// k_len = 1 and its token is ignored.  A scheduler step = admit waiting requests (prefill, chunked) + one decode step
+// for everything that is running (prefill-priority, like the reference's default when new requests arrive).
+// ------------------------------------------------------------------------------------------------------------------
+static int cb_enter(tm_engine* e)
+{
+    if (e->sched) {
+        return 0;
+    }
+    TM_REQUIRE(e->started, "engine not started");
+    TM_REQUIRE(e->batch == 0, "a static batch is admitted (release it first)");
+    TM_REQUIRE(e->num_blocks >= 2, "continuous batching needs at least two KV blocks");
+    TM_HIP_CHECK(hipSetDevice(e->cfg.device));
+    const int B = e->cfg.max_batch_size;
+    if (!e->d_active) {
+        TM_TRY(dmalloc(&e->d_active, (size_t)B));
+        TM_TRY(dmalloc(&e->d_pf_k_len, (size_t)B));
+        TM_TRY(dmalloc(&e->d_pf_cu_q, (size_t)B + 1));
+    }
+    e->dummy_block = (int)e->num_blocks - 1;  // parking block of the free slots; the scheduler owns the others
+    e->sched.reset(new BatchScheduler(B, (int)e->num_blocks - 1, e->cfg.session_len, e->cfg.cache_block_seq_len));
+    e->free_blocks.clear();
+    e->h_active.assign(B, 0);
+    e->h_step_ids.assign(B, 0);
+    std::vector<int>      ones(B, 1), zeros(B, 0), cu_q(B + 1);
+    std::vector<uint64_t> ptrs((size_t)B * e->max_blocks_per_seq,
+                               (uint64_t)(e->pool + (int64_t)e->dummy_block * e->block_bytes));
+    for (int b = 0; b <= B; ++b) {
+        cu_q[b] = b;
+    }
+    TM_HIP_CHECK(hipMemcpyAsync(e->d_block_ptrs, ptrs.data(), ptrs.size() * 8, hipMemcpyHostToDevice, e->stream));
+    TM_HIP_CHECK(hipMemcpyAsync(e->d_k_len, ones.data(), B * 4, hipMemcpyHostToDevice, e->stream));
+    TM_HIP_CHECK(hipMemcpyAsync(e->d_active, zeros.data(), B * 4, hipMemcpyHostToDevice, e->stream));
+    TM_HIP_CHECK(hipMemcpyAsync(e->d_ids, zeros.data(), B * 4, hipMemcpyHostToDevice, e->stream));
+    TM_HIP_CHECK(hipMemcpyAsync(e->d_cu_q, cu_q.data(), (B + 1) * 4, hipMemcpyHostToDevice, e->stream));
+    TM_HIP_CHECK(hipStreamSynchronize(e->stream));
+    e->batch = B;  // the decode step always covers every slot
+    setup_decode(e, B);
+    return 0;
+}
+
+static int decode_step_cb(tm_engine* e)
+{
+    const int B = e->cfg.max_batch_size;
+    advance_active_kernel<<<(B + 63) / 64, 64, 0, e->stream>>>(e->d_k_len, e->d_active, B);
+    TM_HIP_CHECK(hipGetLastError());
+    TM_TRY(forward(e, e->d_ids, B, B, true, 1, 0, 0, 0));
+    TM_HIP_CHECK(hipMemcpyAsync(e->d_ids, e->d_next_ids, (size_t)B * 4, hipMemcpyDeviceToDevice, e->stream));
+    return 0;
+}
+
+// park a slot again after its sequence finished / was cancelled
+static int cb_park_slot(tm_engine* e, int slot)
+{
+    const int      one = 1, zero = 0;
+    const uint64_t dp  = (uint64_t)(e->pool + (int64_t)e->dummy_block * e->block_bytes);
+    e->h_active[slot]  = 0;
+    TM_HIP_CHECK(hipMemcpyAsync(e->d_active + slot, &zero, 4, hipMemcpyHostToDevice, e->stream));
+    TM_HIP_CHECK(hipMemcpyAsync(e->d_k_len + slot, &one, 4, hipMemcpyHostToDevice, e->stream));
+    TM_HIP_CHECK(hipMemcpyAsync(e->d_block_ptrs + (size_t)slot * e->max_blocks_per_seq, &dp, 8, hipMemcpyHostToDevice, e->stream));
+    TM_HIP_CHECK(hipStreamSynchronize(e->stream));  // the sources are stack variables
+    return 0;
+}
+
+// prefill the newly admitted requests (contiguous slot runs share one chunked prefill), hand over their first tokens
+static int cb_prefill_admitted(tm_engine* e, const std::vector<SchedAdmit>& admits)
+{
+    std::vector<SchedAdmit> sorted = admits;
+    std::sort(sorted.begin(), sorted.end(), [](const SchedAdmit& a, const SchedAdmit& b) { return a.slot < b.slot; });
+    size_t i = 0;
+    while (i < sorted.size()) {
+        size_t j = i + 1;
+        while (j < sorted.size() && sorted[j].slot == sorted[j - 1].slot + 1) {
+            ++j;
+        }
+        const int               n     = (int)(j - i);
+        const int               slot0 = sorted[i].slot;
+        std::vector<const int*> ids(n);
+        std::vector<int>        lens(n);
+        std::vector<uint64_t>   ptrs((size_t)n * e->max_blocks_per_seq,
+                                     (uint64_t)(e->pool + (int64_t)e->dummy_block * e->block_bytes));
+        for (int k = 0; k < n; ++k) {
+            const SchedRequest* r = e->sched->find(sorted[i + k].id);
+            TM_REQUIRE(r && r->running, "internal: admitted request vanished");
+            ids[k]  = r->prompt.data();
+            lens[k] = (int)r->prompt.size();
+            TM_REQUIRE((int)r->blocks.size() <= e->max_blocks_per_seq, "internal: block table row too short");
+            for (size_t q = 0; q < r->blocks.size(); ++q) {
+                ptrs[(size_t)k * e->max_blocks_per_seq + q] = (uint64_t)(e->pool + (int64_t)r->blocks[q] * e->block_bytes);
+            }
+        }
+        TM_HIP_CHECK(hipMemcpyAsync(e->d_block_ptrs + (size_t)slot0 * e->max_blocks_per_seq, ptrs.data(), ptrs.size() * 8,
+                                    hipMemcpyHostToDevice, e->stream));
+        // prefill uses iteration-local k_len / cu_q arrays: the decode arrays of the running slots stay untouched
+        std::swap(e->d_k_len, e->d_pf_k_len);
+        std::swap(e->d_cu_q, e->d_pf_cu_q);
+        const int rc = prefill_slots(e, ids.data(), lens.data(), n, slot0, nullptr);
+        std::swap(e->d_k_len, e->d_pf_k_len);
+        std::swap(e->d_cu_q, e->d_pf_cu_q);
+        if (rc) {
+            return rc;
+        }
+        // decode state of the new slots: context length, current token; first tokens go to the host
+        std::vector<int> first(n), ones(n, 1);
+        TM_HIP_CHECK(hipMemcpyAsync(e->d_k_len + slot0, lens.data(), n * 4, hipMemcpyHostToDevice, e->stream));
+        TM_HIP_CHECK(hipMemcpyAsync(e->d_ids + slot0, e->d_next_ids + slot0, n * 4, hipMemcpyDeviceToDevice, e->stream));
+        TM_HIP_CHECK(hipMemcpyAsync(first.data(), e->d_next_ids + slot0, n * 4, hipMemcpyDeviceToHost, e->stream));
+        TM_HIP_CHECK(hipMemcpyAsync(e->d_active + slot0, ones.data(), n * 4, hipMemcpyHostToDevice, e->stream));
+        TM_HIP_CHECK(hipStreamSynchronize(e->stream));
+        for (int k = 0; k < n; ++k) {
+            e->h_active[slot0 + k] = 1;
+            if (e->sched->on_token(slot0 + k, first[k])) {  // finished on its first token
+                TM_TRY(cb_park_slot(e, slot0 + k));
+            }
+        }
+        i = j;
+    }
+    return 0;
+}
+
 int tm_engine_release(tm_engine* e)
 {
     TM_REQUIRE(e, "null pointer");
@@ -803,6 +1042,13 @@ int tm_engine_release(tm_engine* e)
     e->h_len.clear();
     e->batch      = 0;
     e->steps_done = 0;
+    if (e->sched) {  // leave continuous-batching mode: every block goes back to the static free list
+        e->sched.reset();
+        e->free_blocks.resize(e->num_blocks);
+        for (int64_t i = 0; i < e->num_blocks; ++i) {
+            e->free_blocks[i] = (int)(e->num_blocks - 1 - i);
+        }
+    }
     return 0;
 }
 
@@ -810,7 +1056,7 @@ int tm_engine_prefill(tm_engine* e, const int* host_ids, const int* host_lens, i
 {
     TM_REQUIRE(e && host_ids && host_lens, "null pointer");
     TM_REQUIRE(e->started, "engine not started");
-    TM_REQUIRE(e->batch == 0, "a batch is already admitted (release it first)");
+    TM_REQUIRE(e->batch == 0 && !e->sched, "a batch is already admitted (release it first)");
     TM_REQUIRE(batch >= 1 && batch <= e->cfg.max_batch_size, "1 <= batch <= max_batch_size");
     TM_REQUIRE(max_new_tokens >= 1, "max_new_tokens >= 1");
     TM_HIP_CHECK(hipSetDevice(e->cfg.device));
@@ -849,74 +1095,15 @@ int tm_engine_prefill(tm_engine* e, const int* host_ids, const int* host_lens, i
     e->h_len.assign(host_lens, host_lens + batch);
     e->steps_done = 0;
 
-    // ---- chunked prefill: whole sequences, <= max_prefill_token_num tokens per iteration ------------
-    // (a sequence longer than the budget is split into history + new tokens)
-    std::vector<int> offs(batch + 1, 0);
-    for (int b = 0; b < batch; ++b) {
-        offs[b + 1] = offs[b] + host_lens[b];
-    }
-    const int budget = e->max_tokens;
-    const auto t_start = std::chrono::steady_clock::now();
     e->h_ttft_ms.assign(batch, 0.f);
-    // Because the batch tables (block_ptrs, cu_block_nums) are indexed by the batch slot, every prefill
-    // iteration covers a contiguous range of slots [b0, b1]; the block table is offset accordingly and the
-    // logits / first tokens of the iteration land in d_logits / d_next_ids at slot b0 + i.
-    int b0 = 0;
-    int done_in_b0 = 0;  // tokens of sequence b0 already prefilled (chunked long prompt)
-    while (b0 < batch) {
-        std::vector<int> cu_q{0}, klen, koff{0}, rows, ids;
-        int b1 = b0, tokens = 0, max_q = 0, max_k = 0;
-        bool partial_last = false;
-        while (b1 < batch) {
-            const int start  = (b1 == b0) ? done_in_b0 : 0;
-            const int remain = host_lens[b1] - start;
-            const int take   = std::min(remain, budget - tokens);
-            if (take <= 0) {
-                break;
-            }
-            ids.insert(ids.end(), host_ids + offs[b1] + start, host_ids + offs[b1] + start + take);
-            tokens += take;
-            cu_q.push_back(tokens);
-            klen.push_back(start + take);
-            koff.push_back(koff.back() + ((start + take + 63) / 64) * 64);
-            rows.push_back(tokens - 1);
-            max_q = std::max(max_q, take);
-            max_k = std::max(max_k, start + take);
-            if (take < remain) {  // budget exhausted inside this sequence: it continues in the next iteration
-                done_in_b0   = start + take;
-                partial_last = true;
-                break;
-            }
-            ++b1;
+    {
+        std::vector<const int*> seq_ids(batch);
+        int                     off = 0;
+        for (int b = 0; b < batch; ++b) {
+            seq_ids[b] = host_ids + off;
+            off += host_lens[b];
         }
-        const int nseq = (int)klen.size();
-        TM_REQUIRE(nseq >= 1, "internal: empty prefill iteration");
-        TM_REQUIRE(koff.back() <= e->kflat_stride, "internal: flatten scratch too small");
-        TM_HIP_CHECK(hipMemcpyAsync(e->d_prefill_ids, ids.data(), ids.size() * 4, hipMemcpyHostToDevice, e->stream));
-        TM_HIP_CHECK(hipMemcpyAsync(e->d_cu_q, cu_q.data(), cu_q.size() * 4, hipMemcpyHostToDevice, e->stream));
-        TM_HIP_CHECK(hipMemcpyAsync(e->d_k_len, klen.data(), klen.size() * 4, hipMemcpyHostToDevice, e->stream));
-        TM_HIP_CHECK(hipMemcpyAsync(e->d_cu_koff, koff.data(), koff.size() * 4, hipMemcpyHostToDevice, e->stream));
-        TM_HIP_CHECK(hipMemcpyAsync(e->d_rows, rows.data(), rows.size() * 4, hipMemcpyHostToDevice, e->stream));
-        // shift the block tables so that slot 0 of this iteration is sequence b0
-        uint64_t* saved_ptrs = e->d_block_ptrs;
-        e->d_block_ptrs += (size_t)b0 * e->max_blocks_per_seq;
-        const int rc    = forward(e, e->d_prefill_ids, tokens, nseq, false, max_q, max_k, e->kflat_stride, b0);
-        e->d_block_ptrs = saved_ptrs;
-        if (rc) {
-            return rc;
-        }
-        // the host vectors above are pageable: make sure the async copies are done before they die
-        TM_HIP_CHECK(hipStreamSynchronize(e->stream));
-        {
-            const float ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_start).count();
-            for (int b = b0; b < b1; ++b) {
-                e->h_ttft_ms[b] = ms;  // first token of sequence b exists once its last chunk has been processed
-            }
-        }
-        b0 = b1;  // a partially prefilled sequence (b1) is revisited with done_in_b0 tokens of history
-        if (!partial_last) {
-            done_in_b0 = 0;
-        }
+        TM_TRY(prefill_slots(e, seq_ids.data(), host_lens, batch, 0, e->h_ttft_ms.data()));
     }
 
     // ---- steady-state decode layout: one token per sequence ------------------------------------------
@@ -932,29 +1119,8 @@ int tm_engine_prefill(tm_engine* e, const int* host_ids, const int* host_lens, i
     TM_HIP_CHECK(hipStreamSynchronize(e->stream));
     e->steps_done = 1;
 
-    // decode split heuristic: fill >= 2 workgroups per CU (GetSplitCount, kernels/attention/utils.cc:11-46)
-    int splits = c.decode_splits;
-    if (splits <= 0) {
-        int group = e->q_heads / e->kv_heads, hpw = 1;
-        for (int cand = 4; cand >= 1; --cand) {
-            if (group % cand == 0) {
-                hpw = cand;
-                break;
-            }
-        }
-        const int wgs = e->kv_heads * (group / hpw) * batch;
-        splits        = 1;
-        while (wgs * splits < 512 && splits < 16) {
-            splits *= 2;
-        }
-    }
-    e->decode_splits = std::min(std::max(splits, 1), 16);
-    {
-        const char* valu = getenv("TM_ATTN_VALU");
-        const char* fuse = getenv("TM_FUSE_QKV");
-        e->fuse_qkv      = e->cfg.quant_policy == 8 && !(valu && atoi(valu)) && !(fuse && !atoi(fuse));
-    }
-    if (e->graph && (e->graph_batch != batch)) {
+    setup_decode(e, batch);
+    if (e->graph && (e->graph_batch != batch || e->graph_max_new != max_new_tokens)) {
         (void)hipGraphExecDestroy(e->graph);
         e->graph = nullptr;
     }
@@ -964,6 +1130,7 @@ int tm_engine_prefill(tm_engine* e, const int* host_ids, const int* host_lens, i
 int tm_engine_decode(tm_engine* e, int steps)
 {
     TM_REQUIRE(e && e->batch > 0, "no admitted batch");
+    TM_REQUIRE(!e->sched, "continuous-batching session active: use tm_engine_step");
     TM_HIP_CHECK(hipSetDevice(e->cfg.device));
     if (e->steps_done + steps > e->max_new) {
         set_last_error("decode past max_new_tokens");
@@ -991,7 +1158,8 @@ int tm_engine_decode(tm_engine* e, int steps)
         TM_HIP_CHECK(ce);
         TM_HIP_CHECK(hipGraphInstantiate(&e->graph, g, nullptr, nullptr, 0));
         TM_HIP_CHECK(hipGraphDestroy(g));
-        e->graph_batch = e->batch;
+        e->graph_batch   = e->batch;
+        e->graph_max_new = e->max_new;
     }
     for (int i = 0; i < steps; ++i) {
         if (use_graph) {
@@ -1002,6 +1170,108 @@ int tm_engine_decode(tm_engine* e, int steps)
         }
     }
     e->steps_done += steps;
+    return 0;
+}
+
+int tm_engine_submit(tm_engine* e, const int* host_ids, int n, int max_new_tokens, int eos_id, int64_t* req_id)
+{
+    TM_REQUIRE(e && host_ids && req_id, "null pointer");
+    TM_TRY(cb_enter(e));
+    const int rc = e->sched->submit(host_ids, n, max_new_tokens, eos_id, req_id);
+    if (rc == TM_TOO_LONG) {
+        set_last_error("prompt + max_new_tokens exceeds session_len");
+    }
+    else if (rc == TM_OOM) {
+        set_last_error("request can never fit the KV block pool");
+    }
+    else if (rc) {
+        set_last_error("invalid request (empty prompt or max_new_tokens < 1)");
+    }
+    return rc;
+}
+
+int tm_engine_step(tm_engine* e, int* n_active, int* n_waiting)
+{
+    TM_REQUIRE(e, "null pointer");
+    TM_TRY(cb_enter(e));
+    TM_HIP_CHECK(hipSetDevice(e->cfg.device));
+    const int B = e->cfg.max_batch_size;
+    // 1. admission + prefill (budget = max_prefill_token_num tokens of prompts per step)
+    const std::vector<SchedAdmit> admits = e->sched->admit(e->max_tokens);
+    if (!admits.empty()) {
+        TM_TRY(cb_prefill_admitted(e, admits));
+    }
+    // 2. one decode step for everything that is running
+    if (e->sched->n_active() > 0) {
+        const char* gc        = getenv("TM_GRAPH_COMM");
+        const bool  use_graph = e->cfg.use_graph && (!e->use_comm || (gc && atoi(gc)));
+        if (use_graph && !e->graph_cb) {
+            TM_TRY(decode_step_cb(e));  // one eager step first (lazy module loading must not happen inside a capture)
+            TM_HIP_CHECK(hipStreamSynchronize(e->stream));
+            hipGraph_t g = nullptr;
+            TM_HIP_CHECK(hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal));
+            const int  rc = decode_step_cb(e);
+            hipError_t ce = hipStreamEndCapture(e->stream, &g);
+            if (rc) {
+                return rc;
+            }
+            TM_HIP_CHECK(ce);
+            TM_HIP_CHECK(hipGraphInstantiate(&e->graph_cb, g, nullptr, nullptr, 0));
+            TM_HIP_CHECK(hipGraphDestroy(g));
+        }
+        else if (use_graph) {
+            TM_HIP_CHECK(hipGraphLaunch(e->graph_cb, e->stream));
+        }
+        else {
+            TM_TRY(decode_step_cb(e));
+        }
+        TM_HIP_CHECK(hipMemcpyAsync(e->h_step_ids.data(), e->d_ids, (size_t)B * 4, hipMemcpyDeviceToHost, e->stream));
+        TM_HIP_CHECK(hipStreamSynchronize(e->stream));
+        for (int b = 0; b < B; ++b) {
+            if (e->h_active[b] && e->sched->slot_request(b) >= 0 && e->sched->on_token(b, e->h_step_ids[b])) {
+                TM_TRY(cb_park_slot(e, b));
+            }
+        }
+    }
+    if (n_active) {
+        *n_active = e->sched->n_active();
+    }
+    if (n_waiting) {
+        *n_waiting = e->sched->n_waiting();
+    }
+    return 0;
+}
+
+int tm_engine_poll(tm_engine* e, int64_t req_id, int* status, int* host_tokens, int cap, int* n_tokens)
+{
+    TM_REQUIRE(e && status && n_tokens, "null pointer");
+    TM_REQUIRE(e->sched, "no continuous-batching session (submit first)");
+    const SchedRequest* r = e->sched->find(req_id);
+    if (!r) {
+        set_last_error("unknown request id");
+        return TM_INVALID;
+    }
+    *status   = r->status;
+    *n_tokens = (int)r->out.size();
+    if (host_tokens) {
+        memcpy(host_tokens, r->out.data(), (size_t)std::min(cap, *n_tokens) * 4);
+    }
+    return 0;
+}
+
+int tm_engine_cancel(tm_engine* e, int64_t req_id)
+{
+    TM_REQUIRE(e, "null pointer");
+    TM_REQUIRE(e->sched, "no continuous-batching session (submit first)");
+    int       slot = -1;
+    const int rc   = e->sched->cancel(req_id, &slot);
+    if (rc) {
+        set_last_error("unknown request id");
+        return TM_INVALID;
+    }
+    if (slot >= 0) {
+        TM_TRY(cb_park_slot(e, slot));
+    }
     return 0;
 }
 
@@ -1108,6 +1378,14 @@ int tm_engine_destroy(tm_engine* e)
     }
     if (e->graph) {
         (void)hipGraphExecDestroy(e->graph);
+    }
+    if (e->graph_cb) {
+        (void)hipGraphExecDestroy(e->graph_cb);
+    }
+    for (void* q : {(void*)e->d_active, (void*)e->d_pf_k_len, (void*)e->d_pf_cu_q}) {
+        if (q) {
+            (void)hipFree(q);
+        }
     }
     for (auto& L : e->layers) {
         for (LinearSlots* l : {&L.qkv, &L.wo, &L.w13, &L.w2}) {

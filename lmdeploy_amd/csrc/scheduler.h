@@ -1,0 +1,218 @@
+// Continuous-batching scheduler (host side, no device code): request queue, batch slots, KV block accounting.
+//
+// Replaces, at the level this engine needs: Engine::Impl::Schedule / InternalThreadEntry
+// (src/turbomind/engine/engine.cc:434-470,770-870) and Scheduler::Schedule (engine/scheduler.cc:1018-1078):
+//   * requests are admitted in arrival order (the reference sorts by unique_id, scheduler.cc:1076-1078);
+//   * a request is admitted when a batch slot is free and the block pool can hold prompt + max_new_tokens
+//     (blocks of 64 tokens, all reserved at admission: no preemption / eviction, no prefix cache -- SURVEY 8f-1
+//     names the prefix-free variant);
+//   * the prefill token budget of one scheduler step is max_prefill_token_num (ForwardTokenResource,
+//     engine.cc:462-464); at least one waiting request is admitted per step if it fits at all;
+//   * a sequence finishes on EOS (unless ignore_eos), at max_new_tokens, or when cancelled; its slot and blocks are
+//     free for the NEXT step (status codes: Request::kFinish = 7, kCancel = 8, engine/request.h:120-131).
+// The class is pure bookkeeping so that it can be driven from CPU tests through tm_sched_* (c_api.hip) exactly as the
+// engine drives it.
+#pragma once
+
+#include <cstdint>
+#include <deque>
+#include <map>
+#include <vector>
+
+namespace tmk {
+
+struct SchedRequest {
+    int64_t          id       = 0;
+    std::vector<int> prompt;
+    int              max_new  = 0;
+    int              eos      = -1;  // < 0: never stop on a token (ignore_eos)
+    int              status   = 0;   // Request::k*: 0 = waiting / running, 7 finished, 8 cancelled
+    int              slot     = -1;  // batch slot while running
+    bool             running  = false;
+    std::vector<int> blocks;         // KV blocks owned while running
+    std::vector<int> out;            // generated tokens so far
+};
+
+struct SchedAdmit {
+    int64_t id;
+    int     slot;
+};
+
+class BatchScheduler {
+public:
+    BatchScheduler(int max_batch, int num_blocks, int session_len, int block_len = 64):
+        max_batch_(max_batch), session_len_(session_len), block_len_(block_len), slot_req_(max_batch, -1)
+    {
+        free_blocks_.resize(num_blocks);
+        for (int i = 0; i < num_blocks; ++i) {
+            free_blocks_[i] = num_blocks - 1 - i;
+        }
+        total_blocks_ = num_blocks;
+    }
+
+    // 0 = queued; 6 (kTooLong) = prompt + max_new exceeds session_len; 11 (kOutOfMemory) = can never fit the pool;
+    // 1 (kInvalid) = empty prompt / max_new < 1
+    int submit(const int* ids, int n, int max_new, int eos, int64_t* id)
+    {
+        if (n < 1 || max_new < 1 || ids == nullptr) {
+            return 1;
+        }
+        if (n + max_new > session_len_) {
+            return 6;
+        }
+        if (blocks_for(n + max_new) > total_blocks_) {
+            return 11;
+        }
+        SchedRequest r;
+        r.id      = next_id_++;
+        r.prompt.assign(ids, ids + n);
+        r.max_new = max_new;
+        r.eos     = eos;
+        waiting_.push_back(r.id);
+        if (id) {
+            *id = r.id;
+        }
+        reqs_[r.id] = std::move(r);
+        return 0;
+    }
+
+    // Admit waiting requests (arrival order) into free slots while blocks and the prefill token budget last.
+    // A request larger than the budget is admitted alone (the engine chunks its prefill).
+    std::vector<SchedAdmit> admit(int token_budget)
+    {
+        std::vector<SchedAdmit> out;
+        int                     tokens = 0;
+        while (!waiting_.empty()) {
+            SchedRequest& r = reqs_[waiting_.front()];
+            if (r.status != 0) {  // cancelled while waiting
+                waiting_.pop_front();
+                continue;
+            }
+            const int n    = (int)r.prompt.size();
+            const int need = blocks_for(n + r.max_new);
+            int       slot = -1;
+            for (int b = 0; b < max_batch_; ++b) {
+                if (slot_req_[b] < 0) {
+                    slot = b;
+                    break;
+                }
+            }
+            if (slot < 0 || need > (int)free_blocks_.size()) {
+                break;  // head-of-line blocking, like the reference: order is never changed
+            }
+            if (!out.empty() && tokens + n > token_budget) {
+                break;
+            }
+            for (int i = 0; i < need; ++i) {
+                r.blocks.push_back(free_blocks_.back());
+                free_blocks_.pop_back();
+            }
+            r.slot          = slot;
+            r.running       = true;
+            slot_req_[slot] = r.id;
+            tokens += n;
+            out.push_back({r.id, slot});
+            waiting_.pop_front();
+        }
+        return out;
+    }
+
+    // a token was produced for the sequence in `slot`; returns true if the sequence finished (slot + blocks released)
+    bool on_token(int slot, int token)
+    {
+        const int64_t id = slot_req_[slot];
+        if (id < 0) {
+            return false;
+        }
+        SchedRequest& r = reqs_[id];
+        r.out.push_back(token);
+        if ((r.eos >= 0 && token == r.eos) || (int)r.out.size() >= r.max_new) {
+            finish(r, 7);
+            return true;
+        }
+        return false;
+    }
+
+    // 0 ok; 1 unknown id.  A running sequence is released immediately (the caller deactivates its slot).
+    int cancel(int64_t id, int* released_slot)
+    {
+        auto it = reqs_.find(id);
+        if (released_slot) {
+            *released_slot = -1;
+        }
+        if (it == reqs_.end()) {
+            return 1;
+        }
+        SchedRequest& r = it->second;
+        if (r.status != 0) {
+            return 0;
+        }
+        if (r.running) {
+            if (released_slot) {
+                *released_slot = r.slot;
+            }
+            finish(r, 8);
+        }
+        else {
+            r.status = 8;
+        }
+        return 0;
+    }
+
+    const SchedRequest* find(int64_t id) const
+    {
+        auto it = reqs_.find(id);
+        return it == reqs_.end() ? nullptr : &it->second;
+    }
+    // forget a finished request (poll consumed it)
+    void erase(int64_t id)
+    {
+        auto it = reqs_.find(id);
+        if (it != reqs_.end() && it->second.status != 0) {
+            reqs_.erase(it);
+        }
+    }
+    int64_t slot_request(int slot) const { return slot_req_[slot]; }
+    int     n_active() const
+    {
+        int n = 0;
+        for (int64_t v : slot_req_) {
+            n += v >= 0;
+        }
+        return n;
+    }
+    int n_waiting() const
+    {
+        int n = 0;
+        for (int64_t id : waiting_) {
+            n += reqs_.at(id).status == 0;
+        }
+        return n;
+    }
+    int n_free_blocks() const { return (int)free_blocks_.size(); }
+    int blocks_for(int tokens) const { return (tokens + block_len_ - 1) / block_len_; }
+
+private:
+    void finish(SchedRequest& r, int status)
+    {
+        r.status = status;
+        for (int b : r.blocks) {
+            free_blocks_.push_back(b);
+        }
+        r.blocks.clear();
+        if (r.slot >= 0) {
+            slot_req_[r.slot] = -1;
+        }
+        r.running = false;
+        r.slot    = -1;
+    }
+
+    int                             max_batch_, session_len_, block_len_, total_blocks_ = 0;
+    int64_t                         next_id_ = 1;
+    std::vector<int>                free_blocks_;
+    std::vector<int64_t>            slot_req_;
+    std::deque<int64_t>             waiting_;
+    std::map<int64_t, SchedRequest> reqs_;
+};
+
+}  // namespace tmk

@@ -88,8 +88,8 @@ class Pipeline:
         return out[0] if single else out
 
     def stream_infer(self, prompts, gen_config: GenerationConfig | None = None, **kwargs):
-        """Static batching: a response is yielded when its batch has finished."""
-        yield from self._generate(list(prompts), gen_config or GenerationConfig())
+        """Responses are yielded as their sequences finish (continuous batching in the engine)."""
+        yield from self.generate_continuous(list(prompts), gen_config or GenerationConfig())
 
     def close(self):
         self.engine.close()
@@ -116,6 +116,47 @@ class Pipeline:
         return ids
 
     def _generate(self, prompts: Sequence, g: GenerationConfig):
+        if len(prompts) > self.max_batch_size:      # more work than batch slots: let the engine schedule it
+            yield from sorted(self.generate_continuous(prompts, g), key=lambda r: r.index)
+            return
+        yield from self._generate_static(prompts, g)
+
+    def generate_continuous(self, prompts: Sequence, g: GenerationConfig | None = None):
+        """Continuous batching (engine scheduler: tm_engine_submit / step / poll): any number of prompts, each request
+        leaves the batch when it stops and the next waiting one takes its slot.  Yields Responses in completion order."""
+        g = g or GenerationConfig()
+        ids = [self._encode(p) for p in prompts]
+        stop = self._stop_ids(g)
+        eos = next(iter(stop)) if len(stop) == 1 else -1       # one stop id is handled inside the engine
+        pending, out_of_engine = {}, []
+        for i, p in enumerate(ids):
+            try:
+                pending[self.engine.submit(p, g.max_new_tokens, eos)] = i
+            except _ffi.TmError as e:
+                rt = STATUS_TO_RESPONSE.get(e.status, ResponseType.INTERNAL_ENGINE_ERROR)
+                out_of_engine.append(Response('', 0, len(p), 'error', [], index=i, error_code=rt.name, error_message=str(e)))
+        yield from out_of_engine
+        try:
+            while pending:
+                self.engine.step()
+                for rid, i in list(pending.items()):
+                    st, toks = self.engine.poll(rid)
+                    toks = toks.tolist()
+                    cut = next((k for k, t in enumerate(toks) if t in stop), None)
+                    if cut is not None and st == 0:      # a stop id the engine does not know about
+                        self.engine.cancel(rid)
+                        st = 8
+                    if st == 0:
+                        continue
+                    del pending[rid]
+                    out = toks if cut is None else toks[:cut]
+                    reason = 'stop' if cut is not None else 'length'
+                    text = self.tokenizer.decode(out, skip_special_tokens=g.skip_special_tokens) if self.tokenizer else ''
+                    yield Response(text, len(out), len(ids[i]), reason, out, index=i)
+        finally:
+            self.engine.release()
+
+    def _generate_static(self, prompts: Sequence, g: GenerationConfig):
         ids = [self._encode(p) for p in prompts]
         stop = self._stop_ids(g)
         for b0 in range(0, len(ids), self.max_batch_size):

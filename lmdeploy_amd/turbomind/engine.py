@@ -114,6 +114,34 @@ class Engine:
         _ffi.check(self._lib.tm_engine_fetch_logits(self._h, out.ctypes.data))
         return out
 
+    # ---- continuous batching (tm_engine_submit / step / poll / cancel) -----------------------------
+    def submit(self, prompt: Sequence[int], max_new_tokens: int, eos_id: int = -1) -> int:
+        """Queue one request; returns its id.  eos_id < 0 = ignore_eos.  Raises TmError with the reference's status
+        code (TM_TOO_LONG, TM_OOM, TM_INVALID) when the request can never run."""
+        ids = np.ascontiguousarray(np.asarray(prompt, np.int32))
+        rid = C.c_int64(0)
+        _ffi.check(self._lib.tm_engine_submit(self._h, ids.ctypes.data, int(ids.size), int(max_new_tokens), int(eos_id),
+                                              C.byref(rid)))
+        return rid.value
+
+    def step(self):
+        """One scheduler iteration: admit + prefill waiting requests, then one decode step for everything running.
+        Returns (n_active, n_waiting) after the step."""
+        na, nw = C.c_int(0), C.c_int(0)
+        _ffi.check(self._lib.tm_engine_step(self._h, C.byref(na), C.byref(nw)))
+        return na.value, nw.value
+
+    def poll(self, req_id: int, cap: int = 0):
+        """(status, tokens generated so far) -- status 0 = waiting / running, 7 = finished, 8 = cancelled."""
+        st, n = C.c_int(0), C.c_int(0)
+        _ffi.check(self._lib.tm_engine_poll(self._h, req_id, C.byref(st), None, 0, C.byref(n)))
+        out = np.zeros(max(n.value, 1), np.int32)
+        _ffi.check(self._lib.tm_engine_poll(self._h, req_id, C.byref(st), out.ctypes.data, n.value, C.byref(n)))
+        return st.value, out[:n.value]
+
+    def cancel(self, req_id: int):
+        _ffi.check(self._lib.tm_engine_cancel(self._h, req_id))
+
     def release(self):
         _ffi.check(self._lib.tm_engine_release(self._h))
         self.batch = 0

@@ -88,6 +88,107 @@ def test_engine_collective_path_single_rank(cuda, monkeypatch, graph_comm):
     assert np.abs(l0.astype(np.float32) - l1.astype(np.float32)).max() <= 2e-3
 
 
+@pytest.mark.parametrize('slots', [1, 3])
+def test_continuous_batching_matches_static(cuda, slots):
+    """the engine scheduler (submit / step / poll / cancel).  9 requests through 1 or 3 batch slots,
+    different prompt lengths and generation lengths, one with an EOS stop, one cancelled mid-flight, one chunked prompt
+    (longer than max_prefill_token_num); slots and blocks are reused.
+    slots = 1: every request runs exactly the kernels of the static single-prompt run -> tokens must be identical.
+    slots = 3: prompts share prefill iterations, so GEMM shapes (split-K association) differ from the single-prompt
+    run in the last fp32 bits; tokens must agree up to the first position where the static run's top-2 logit margin is
+    below 5e-2 (greedy decoding is only defined up to such near ties)."""
+    cfg = o.ModelConfig(hidden=256, layers=2, q_heads=4, kv_heads=2, head_dim=128, inter=512, vocab=1024,
+                        kv_bits=8, rope=o.RopeParam(128, 500000.0, 'llama3', 8.0, 1.0, 4.0, 8192))
+    w = o.make_synthetic_weights(cfg, seed=11)
+    rng = np.random.default_rng(4)
+    lens = [70, 5, 64, 33, 150, 9, 1, 40, 17]
+    news = [6, 12, 3, 9, 5, 20, 8, 1, 10]
+    prompts = [rng.integers(0, cfg.vocab, n).astype(np.int32) for n in lens]
+    weights = export_weights(cfg, w)
+
+    # reference: every prompt alone through the static path (tokens + top-2 margin of every step)
+    eng = Engine.from_model_config(cfg, max_batch_size=slots, session_len=256, quant_policy=8, max_prefill_token_num=96)
+    eng.load_weights(weights)
+    eng.start()
+    ref, margin = [], []
+    for p, n in zip(prompts, news):
+        eng.prefill([p], max_new_tokens=n)
+        mg = []
+        for k in range(n):
+            top2 = np.sort(eng.fetch_logits()[0].astype(np.float32))[-2:]
+            mg.append(float(top2[1] - top2[0]))
+            if k + 1 < n:
+                eng.decode(1)
+        ref.append(eng.fetch()[0].copy())
+        margin.append(mg)
+        eng.release()
+
+    def check(i, toks, upto):
+        """toks must reproduce ref[i][:upto] (exactly for one slot; up to the first near tie otherwise)"""
+        assert len(toks) == upto, f'request {i}: {len(toks)} tokens, expected {upto}'
+        for k in range(upto):
+            if toks[k] != ref[i][k]:
+                assert slots > 1 and margin[i][k] < 5e-2, f'request {i} token {k}: {toks} vs {ref[i]} (margin {margin[i][k]})'
+                return
+
+    # continuous batching on the same engine object
+    eos_req, eos_tok = 5, int(ref[5][7])                      # request 5 stops at its 8th token
+    first = int(np.flatnonzero(ref[5] == eos_tok)[0])        # (or earlier, if that id occurs before)
+    ids = [eng.submit(p, n, eos_tok if i == eos_req else -1) for i, (p, n) in enumerate(zip(prompts, news))]
+    cancel_req, cancelled_at = 1, None
+    done, steps, max_active = {}, 0, 0
+    while len(done) < len(ids):
+        na, nw = eng.step()
+        max_active = max(max_active, na)
+        steps += 1
+        assert steps < 400, 'scheduler does not make progress'
+        for i, rid in enumerate(ids):
+            if i in done:
+                continue
+            st, toks = eng.poll(rid)
+            if i == cancel_req and st == 0 and len(toks) >= 4 and cancelled_at is None:
+                eng.cancel(rid)
+                cancelled_at = len(toks)
+                st, toks = eng.poll(rid)
+            if st != 0:
+                done[i] = (st, toks.copy())
+    assert max_active <= slots
+    for i, (st, toks) in done.items():
+        if i == cancel_req:
+            assert st == 8
+            check(i, toks, cancelled_at)
+        elif i == eos_req and slots == 1:
+            assert st == 7
+            check(i, toks, first + 1)
+        elif i == eos_req:
+            assert st == 7 and (toks[-1] == eos_tok or len(toks) == news[i])
+        else:
+            assert st == 7
+            check(i, toks, news[i])
+    # the session can be left and the static path used again
+    eng.release()
+    eng.prefill([prompts[0]], max_new_tokens=3)
+    eng.decode(2)
+    assert np.array_equal(eng.fetch()[0], ref[0][:3])
+    eng.close()
+
+
+def test_pipeline_continuous_generation(cuda):
+    """Pipeline: more prompts than batch slots go through the engine scheduler; results keep the prompt order."""
+    from lmdeploy_amd import GenerationConfig, TurbomindEngineConfig, pipeline
+    pipe = pipeline('synthetic:tiny', backend_config=TurbomindEngineConfig(max_batch_size=2, session_len=128, quant_policy=8))
+    rng = np.random.default_rng(0)
+    prompts = [rng.integers(0, 512, n).astype(np.int32).tolist() for n in (10, 3, 25, 7, 16)]
+    g = GenerationConfig(max_new_tokens=6, ignore_eos=True)
+    out = pipe(prompts, g)
+    assert [r.index for r in out] == list(range(5)) and all(len(r.token_ids) == 6 for r in out)
+    one = [pipe([p], g)[0].token_ids for p in prompts]       # static path, one at a time
+    assert [r.token_ids for r in out] == one
+    streamed = sorted(pipe.stream_infer(prompts, g), key=lambda r: r.index)
+    assert [r.token_ids for r in streamed] == one
+    pipe.close()
+
+
 def test_engine_errors_are_status_codes(cuda):
     cfg = o.ModelConfig(hidden=256, layers=1, q_heads=2, kv_heads=1, head_dim=128, inter=256, vocab=512)
     eng = Engine.from_model_config(cfg, max_batch_size=2, session_len=128, quant_policy=8)

@@ -1,0 +1,126 @@
+"""Continuous-batching scheduler policy (lmdeploy_amd/csrc/scheduler.h), driven on the CPU through the C-ABI hooks
+tm_sched_* exactly as the engine drives it (reference: engine/engine.cc:434-470, scheduler.cc:1018-1078):
+arrival-order admission, slot reuse, 64-token block accounting for prompt + max_new_tokens, prefill token budget,
+finish on EOS / length / cancel, reference status codes."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from lmdeploy_amd import _ffi
+
+FINISH, CANCEL, INVALID, TOO_LONG, OOM = 7, 8, 1, 6, 11
+
+
+class Sched:
+    def __init__(self, max_batch, num_blocks, session_len):
+        self.lib = _ffi.load()
+        self.h = C.c_void_p()
+        _ffi.check(self.lib.tm_sched_create(C.byref(self.h), max_batch, num_blocks, session_len))
+
+    def submit(self, n, max_new, eos=-1):
+        ids = np.arange(n, dtype=np.int32)
+        rid = C.c_int64(0)
+        rc = self.lib.tm_sched_submit(self.h, ids.ctypes.data, n, max_new, eos, C.byref(rid))
+        return rc, rid.value
+
+    def admit(self, budget=1 << 30):
+        ids, slots, n = (C.c_int64 * 64)(), (C.c_int * 64)(), C.c_int(0)
+        _ffi.check(self.lib.tm_sched_admit(self.h, budget, ids, slots, 64, C.byref(n)))
+        return [(ids[i], slots[i]) for i in range(n.value)]
+
+    def on_token(self, slot, tok):
+        f = C.c_int(0)
+        _ffi.check(self.lib.tm_sched_on_token(self.h, slot, tok, C.byref(f)))
+        return bool(f.value)
+
+    def cancel(self, rid):
+        s = C.c_int(-1)
+        rc = self.lib.tm_sched_cancel(self.h, rid, C.byref(s))
+        return rc, s.value
+
+    def query(self, rid):
+        st, slot, ng, nb = C.c_int(0), C.c_int(0), C.c_int(0), C.c_int(0)
+        rc = self.lib.tm_sched_query(self.h, rid, C.byref(st), C.byref(slot), C.byref(ng), C.byref(nb))
+        return rc, st.value, slot.value, ng.value, nb.value
+
+    def counts(self):
+        a, w, f = C.c_int(0), C.c_int(0), C.c_int(0)
+        _ffi.check(self.lib.tm_sched_counts(self.h, C.byref(a), C.byref(w), C.byref(f)))
+        return a.value, w.value, f.value
+
+    def __del__(self):
+        self.lib.tm_sched_destroy(self.h)
+
+
+def test_submit_status_codes():
+    s = Sched(max_batch=2, num_blocks=4, session_len=200)
+    assert s.submit(0, 5)[0] == INVALID
+    assert s.submit(5, 0)[0] == INVALID
+    assert s.submit(150, 51)[0] == TOO_LONG           # 201 > session_len
+    s2 = Sched(max_batch=2, num_blocks=2, session_len=1000)
+    assert s2.submit(100, 100)[0] == OOM              # 4 blocks can never fit a 2-block pool
+    rc, rid = s.submit(100, 28)
+    assert rc == 0 and rid == 1
+    assert s.query(99)[0] == INVALID
+
+
+def test_fifo_admission_slots_and_blocks():
+    s = Sched(max_batch=2, num_blocks=10, session_len=4096)
+    r = [s.submit(n, m)[1] for n, m in ((100, 28), (64, 1), (10, 10), (300, 20))]   # 2, 2, 1, 5 blocks
+    adm = s.admit()
+    assert adm == [(r[0], 0), (r[1], 1)]                     # arrival order, lowest free slot first
+    assert s.counts() == (2, 2, 10 - 2 - 2)
+    assert s.query(r[0])[4] == 2 and s.query(r[1])[4] == 2    # ceil(128/64), ceil(65/64)
+    assert s.admit() == []                                    # no free slot
+    assert s.on_token(1, 7) is True                           # max_new = 1: finished on its first token
+    assert s.query(r[1])[:4] == (0, FINISH, -1, 1)
+    assert s.counts() == (1, 2, 8)
+    assert s.admit() == [(r[2], 1)]                           # the freed slot is reused
+    # r[3] needs 5 blocks, 7 are free, but no slot: head-of-line blocked
+    assert s.admit() == []
+    for t in range(27):
+        assert s.on_token(0, t) is False
+    assert s.on_token(0, 99) is True                          # 28th token
+    assert s.admit() == [(r[3], 0)]
+    assert s.counts() == (2, 0, 10 - 1 - 5)
+
+
+def test_block_shortage_blocks_the_queue_in_order():
+    s = Sched(max_batch=4, num_blocks=4, session_len=4096)
+    a = s.submit(100, 28)[1]      # 2 blocks
+    b = s.submit(130, 62)[1]      # 3 blocks: does not fit next to a
+    c = s.submit(10, 10)[1]       # 1 block: would fit, but order is never changed (scheduler.cc:1076-1078)
+    assert s.admit() == [(a, 0)]
+    assert s.admit() == []
+    for _ in range(28):
+        fin = s.on_token(0, 1)
+    assert fin
+    assert s.admit() == [(b, 0), (c, 1)]
+
+
+def test_prefill_token_budget():
+    s = Sched(max_batch=8, num_blocks=100, session_len=4096)
+    r = [s.submit(n, 4)[1] for n in (300, 300, 300, 2000, 10)]
+    assert [x[0] for x in s.admit(budget=700)] == r[:2]       # third would exceed 700 prompt tokens
+    assert [x[0] for x in s.admit(budget=700)] == r[2:3]      # 300, then 2000 does not fit behind it
+    assert [x[0] for x in s.admit(budget=700)] == r[3:4]      # larger than the budget: admitted alone (engine chunks it)
+    assert [x[0] for x in s.admit(budget=700)] == r[4:]
+
+
+def test_eos_and_cancel():
+    s = Sched(max_batch=2, num_blocks=8, session_len=512)
+    a = s.submit(5, 50, eos=42)[1]
+    b = s.submit(5, 50)[1]                                    # eos < 0: ignore_eos
+    c = s.submit(5, 50)[1]
+    s.admit()
+    assert not s.on_token(0, 1) and not s.on_token(1, 42)     # 42 is not b's stop token
+    assert s.on_token(0, 42)                                  # EOS ends a (token included in the output)
+    assert s.query(a)[:4] == (0, FINISH, -1, 2)
+    assert s.cancel(c) == (0, -1)                             # cancelled while waiting: never admitted
+    assert s.admit() == []
+    assert s.query(c)[1] == CANCEL
+    assert s.cancel(b) == (0, 1)                              # running: slot 1 is released
+    assert s.query(b)[1] == CANCEL and s.counts() == (0, 0, 8)
+    assert s.cancel(12345)[0] == INVALID
+    assert not s.on_token(1, 3)                               # tokens of a parked slot are ignored
