@@ -164,6 +164,57 @@ def test_hf_awq_checkpoint_reader(tmp_path):
     assert slots['layers.0.attention.w_qkv.qweight'].dtype == np.int32
 
 
+def test_hf_internlm2_fp16_checkpoint_reader(tmp_path):
+    """InternLM2 on-disk format (lmdeploy/turbomind/models/internlm2.py:34-87): fused `wqkv` stored per kv
+    group as [q_0 .. q_{g-1}, k, v] x head_dim rows, unquantised fp16 ('hf' model_format), linear RoPE scaling.  The
+    reader must de-interleave it into [Q | K | V], apply the interleaved-RoPE channel permutation to Q and K, interleave
+    gate / up and hand the engine [K, N] (input-major) matrices."""
+    from safetensors.numpy import save_file
+    rng = np.random.default_rng(1)
+    H, D, Hq, Hkv, I, V = 256, 128, 4, 2, 512, 64
+    g = Hq // Hkv
+    q = rng.standard_normal((Hq * D, H)).astype(f16)           # HF linears are [out, in]
+    k = rng.standard_normal((Hkv * D, H)).astype(f16)
+    v = rng.standard_normal((Hkv * D, H)).astype(f16)
+    fused = np.concatenate([np.concatenate([q[j * g * D:(j + 1) * g * D], k[j * D:(j + 1) * D], v[j * D:(j + 1) * D]])
+                            for j in range(Hkv)])
+    p = 'model.layers.0'
+    t = {f'{p}.attention.wqkv.weight': fused, f'{p}.attention.wo.weight': rng.standard_normal((H, Hq * D)).astype(f16),
+         f'{p}.feed_forward.w1.weight': rng.standard_normal((I, H)).astype(f16),
+         f'{p}.feed_forward.w3.weight': rng.standard_normal((I, H)).astype(f16),
+         f'{p}.feed_forward.w2.weight': rng.standard_normal((H, I)).astype(f16),
+         f'{p}.attention_norm.weight': rng.standard_normal(H).astype(f16), f'{p}.ffn_norm.weight': rng.standard_normal(H).astype(f16),
+         'model.tok_embeddings.weight': rng.standard_normal((V, H)).astype(f16), 'model.norm.weight': np.ones(H, f16),
+         'output.weight': rng.standard_normal((V, H)).astype(f16)}
+    save_file(t, os.path.join(tmp_path, 'model.safetensors'))
+    json.dump({'architectures': ['InternLM2ForCausalLM'], 'hidden_size': H, 'num_hidden_layers': 1, 'num_attention_heads': Hq,
+               'num_key_value_heads': Hkv, 'head_dim': D, 'intermediate_size': I, 'vocab_size': V, 'rms_norm_eps': 1e-6, 'rope_theta': 1e6,
+               'rope_scaling': {'type': 'linear', 'factor': 2.0}, 'eos_token_id': [2, 92542]},
+              open(os.path.join(tmp_path, 'config.json'), 'w'))
+    mc = checkpoint.read_config(str(tmp_path))
+    assert (mc.arch, mc.head_dim, mc.quantized, mc.rope.type, mc.rope.factor, mc.rope.base) == ('internlm2', D, False, 'linear', 2.0, 1e6)
+    assert mc.eos_token_id == [2, 92542]
+    w = checkpoint.load_hf_weights(str(tmp_path), mc)
+    L = w['layers'][0]
+    exp = np.concatenate([o.permute_qk_for_interleaved_rope(q.T, Hq, D), o.permute_qk_for_interleaved_rope(k.T, Hkv, D), v.T], -1)
+    assert np.array_equal(L['w_qkv']['w'], exp)
+    assert np.array_equal(L['w1w3']['w'], o.interleave_w1w3(t[f'{p}.feed_forward.w1.weight'].T, t[f'{p}.feed_forward.w3.weight'].T))
+    assert np.array_equal(L['w2']['w'], t[f'{p}.feed_forward.w2.weight'].T)
+    assert np.array_equal(L['attn_norm'], t[f'{p}.attention_norm.weight'])
+    assert np.array_equal(w['output'], t['output.weight'].T) and np.array_equal(w['tok_embeddings'], t['model.tok_embeddings.weight'])
+    # TP = 2 shards of the fp16 model keep whole heads / (gate, up) pairs together
+    for r in range(2):
+        sl = loader.export_weights(mc, w, 2, r)
+        wq = sl['layers.0.attention.w_qkv.weight']
+        assert wq.shape == (H, (Hq + 2 * Hkv) * D // 2)
+        assert np.array_equal(wq[:, :Hq * D // 2], exp[:, r * Hq * D // 2:(r + 1) * Hq * D // 2])
+        assert np.array_equal(wq[:, -Hkv * D // 2:], v.T[:, r * Hkv * D // 2:(r + 1) * Hkv * D // 2])
+    with pytest.raises(NotImplementedError):
+        json.dump({'architectures': ['Qwen2MoeForCausalLM'], 'hidden_size': H, 'num_hidden_layers': 1, 'num_attention_heads': Hq,
+                   'intermediate_size': I, 'vocab_size': V}, open(os.path.join(tmp_path, 'config.json'), 'w'))
+        checkpoint.read_config(str(tmp_path))
+
+
 def test_api_surface_and_validation():
     c = TurbomindEngineConfig(tp=8, quant_policy=4, session_len=4096, max_batch_size=128, model_format='awq')
     assert c.quant_policy == QuantPolicy.INT4 and c.cache_block_seq_len == 64 and c.max_prefill_token_num == 8192

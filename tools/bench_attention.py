@@ -22,21 +22,31 @@ def main():
     ap.add_argument('--splits', default='1,2,4')
     ap.add_argument('--iters', type=int, default=20)
     ap.add_argument('--trace', action='store_true')
+    ap.add_argument('--layers', type=int, default=4, help='layers stored in the pool (32 = the engine\'s block stride)')
+    ap.add_argument('--layout', default='block', choices=['block', 'layer'],
+                    help='block: [block][layer] (reference: all layers of a block contiguous); layer: [layer][block]')
     a = ap.parse_args()
     tm = _ffi.load()
     B, Hq, Hkv, ctx, bits = a.batch, a.hq, a.hkv, a.ctx, a.bits
-    layers = 4          # several layers so that consecutive launches touch different (cold) cache bytes
+    layers = a.layers   # several layers so that consecutive launches touch different (cold) cache bytes
     lsz = tm.tm_kv_layer_size(Hkv, 128, 64, bits)
     nblk = (ctx + 63) // 64
     pool = torch.randint(0, 255, (B * nblk, layers * lsz), dtype=torch.uint8, device='cuda')
     # make the per-token (scale, zero) params finite fp16 values
-    pv = pool.view(B * nblk, layers, lsz)
+    pv = pool.view(B * nblk, layers, lsz) if a.layout == 'block' else pool.view(-1).view(layers, B * nblk, lsz)
     if bits < 16:
         nparam = Hkv * 2 * 64 * 4
-        prm = torch.empty((B * nblk, layers, nparam // 2), dtype=torch.float16, device='cuda').uniform_(0.01, 0.05)
-        pv[:, :, lsz - nparam:] = prm.view(torch.uint8).view(B * nblk, layers, nparam)
+        prm = torch.empty((pv.shape[0], pv.shape[1], nparam // 2), dtype=torch.float16, device='cuda').uniform_(0.01, 0.05)
+        pv[:, :, lsz - nparam:] = prm.view(torch.uint8).view(pv.shape[0], pv.shape[1], nparam)
     perm = torch.randperm(B * nblk)
-    ptrs = (pool.data_ptr() + perm.to(torch.int64) * layers * lsz).cuda()
+    if a.layout == 'block':
+        ptrs_of = lambda layer: (pool.data_ptr() + perm.to(torch.int64) * layers * lsz).cuda()   # + layer offset in the view
+        off_of = lambda layer: layer * lsz
+    else:   # layer-major: the same bytes, block b of layer l at (l * nblocks + b) * lsz
+        ptrs_of = lambda layer: (pool.data_ptr() + (layer * B * nblk + perm.to(torch.int64)) * lsz).cuda()
+        off_of = lambda layer: 0
+    tables = [ptrs_of(l) for l in range(layers)]
+    ptrs = tables[0]
     cu = torch.arange(0, (B + 1) * nblk, nblk, dtype=torch.int32, device='cuda')
     klen = torch.full((B,), ctx, dtype=torch.int32, device='cuda')
     q = torch.randn((B, Hq * 128), device='cuda').half()
@@ -53,7 +63,7 @@ def main():
             dbg.zero_()
             torch.cuda.synchronize()
             tm.tm_debug_set_gemm_trace(dbg.data_ptr())
-            view = _ffi.KvCache(ptrs.data_ptr(), cu.data_ptr(), (it % layers) * lsz, Hkv, 128, 64, bits)
+            view = _ffi.KvCache(tables[it % layers].data_ptr(), cu.data_ptr(), off_of(it % layers), Hkv, 128, 64, bits)
             _ffi.check(tm.tm_decode_attention(out.data_ptr(), q.data_ptr(), Hq * 128, klen.data_ptr(), B, Hq, 0.0, splits,
                                               ws.data_ptr(), view, st))
             tm.tm_debug_set_gemm_trace(None)
@@ -70,7 +80,7 @@ def main():
         ws = torch.empty(max(1, tm.tm_decode_attention_workspace(B, Hq, splits)), dtype=torch.uint8, device='cuda')
         ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.iters)]
         for i, (e0, e1) in enumerate(ev):
-            view = _ffi.KvCache(ptrs.data_ptr(), cu.data_ptr(), (i % layers) * lsz, Hkv, 128, 64, bits)
+            view = _ffi.KvCache(tables[i % layers].data_ptr(), cu.data_ptr(), off_of(i % layers), Hkv, 128, 64, bits)
             e0.record()
             _ffi.check(tm.tm_decode_attention(out.data_ptr(), q.data_ptr(), Hq * 128, klen.data_ptr(), B, Hq, 0.0, splits,
                                               ws.data_ptr(), view, st))
@@ -79,7 +89,7 @@ def main():
         ts = sorted(x.elapsed_time(y) for x, y in ev)
         med = ts[len(ts) // 2]
         print(f'ctx={ctx} bits={bits} splits={splits}: {med*1e3:8.1f} us  {bytes_per_launch/(med*1e-3)/1e9:7.0f} GB/s '
-              f'({bytes_per_launch/1e6:.1f} MB/launch)  valu={os.environ.get("TM_ATTN_VALU", "0")}', flush=True)
+              f'({bytes_per_launch/1e6:.1f} MB/launch)  layout={a.layout} layers={layers}', flush=True)
 
 
 if __name__ == '__main__':
