@@ -115,6 +115,19 @@ int tm_prefill_attention(void* out, const void* q, int q_stride, const void* k, 
 int tm_embedding(void* out, const void* table, const int* ids, int tokens, int hidden, int vocab, tm_stream_t st);
 /* greedy top-1 on fp32-cast logits (generation/sampling.cc:92-183); out_val (fp16 [batch]) may be NULL */
 int tm_argmax(int* out_ids, void* out_val, const void* logits, int batch, int vocab, int ld, tm_stream_t st);
+/* Stochastic sampling (generation/sampling.cc:92-183, logits_processor.cc:105-112, kernels/sampling_*.cu): per row
+ * logits / temperature -> keep the top_k most probable (top_k <= 0: all) -> softmax -> keep the shortest prefix whose
+ * cumulative probability exceeds top_p (>= 1: all) -> drop p < min_p * p_max -> renormalise -> first candidate whose
+ * inclusive prefix sum exceeds uniform[b] (in [0,1)).  Candidates are ordered by descending probability, ties by
+ * ascending token id.  Per-row device arrays temperature / top_k / top_p / min_p may be NULL (1, all, 1, 0).
+ * kept_out (device int[batch], may be NULL) receives the number of surviving candidates.  workspace:
+ * tm_sample_workspace(batch) bytes, ZERO on first use (every call leaves it zero again). */
+size_t tm_sample_workspace(int batch);
+int    tm_sample(int* out_ids, int* kept_out, const void* logits, int batch, int vocab, int ld, const float* temperature,
+                 const int* top_k, const float* top_p, const float* min_p, const float* uniform, void* workspace,
+                 tm_stream_t st);
+/* the engine's uniform draw: Philox4x32-10, key = request seed, counter = context length -> [0, 1) (host function) */
+float  tm_philox_uniform(uint64_t seed, uint32_t counter);
 /* unfused activation on [M][2*inter] laid out [gate | up]            (kernels/activation.cu:27-130) */
 int tm_silu_mul(void* out, const void* gate_up, int M, int inter, tm_stream_t st);
 

@@ -67,6 +67,10 @@ _SIGNATURES = {
     'tm_embedding': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     'tm_argmax': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     'tm_silu_mul': (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    'tm_sample_workspace': (c_size_t, [c_int]),
+    'tm_sample': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                          c_void_p, c_void_p]),
+    'tm_philox_uniform': (C.c_float, [C.c_uint64, C.c_uint32]),
     'tm_linear_create': (c_int, [POINTER(c_void_p), c_int, c_int, c_int, c_int]),
     'tm_linear_prepare': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     'tm_linear_workspace': (c_size_t, [c_void_p, c_int]),

@@ -299,6 +299,24 @@ int tm_linear_destroy(tm_linear* w)
 }
 
 /* debug: device buffer of [workgroups][4] uint64 receiving s_memrealtime stamps of every GEMM workgroup (NULL = off) */
+size_t tm_sample_workspace(int batch)
+{
+    return sample_workspace_bytes(batch);
+}
+
+int tm_sample(int* out_ids, int* kept_out, const void* logits, int batch, int vocab, int ld, const float* temperature,
+              const int* top_k, const float* top_p, const float* min_p, const float* uniform, void* workspace,
+              tm_stream_t st)
+{
+    return launch_sample(out_ids, kept_out, (const half_t*)logits, batch, vocab, ld, temperature, top_k, top_p, min_p,
+                         uniform, workspace, (hipStream_t)st);
+}
+
+float tm_philox_uniform(uint64_t seed, uint32_t counter)
+{
+    return philox_uniform_host(seed, counter);
+}
+
 // ---- host-only scheduler hooks (scheduler.h) ----------------------------------------------------------------------
 struct tm_sched {
     tmk::BatchScheduler impl;

@@ -1,0 +1,399 @@
+// Stochastic sampling: temperature -> top-k -> softmax -> top-p -> min-p -> draw, one token per sequence.
+//
+// Replaces: Sampling::Forward (src/turbomind/generation/sampling.cc:92-183) = invokeTopKSortFilter / invokeSoftmax +
+// invokeTopPSort (kernels/sampling_topk_kernels.cu, sampling_topp_kernels.cu), invokeTopPMinPFilter
+// (sampling_topp_kernels.cu:291-384), invokeSampling (sampling_kernels.cu:16-94), and the temperature step of the logits
+// processor (generation/logits_processor.cc:105-112).  Semantics kept: the candidates are ordered by descending
+// probability (ties: lower token id first), top-k keeps the first k, top-p keeps the shortest prefix whose cumulative
+// probability EXCEEDS top_p, min-p drops candidates below min_p * p_max, the survivors are renormalised and the token
+// is the first one whose inclusive prefix sum exceeds the uniform draw.
+//
+// MI355X design: no sort.  The logits are fp16, so a row has at most 65536 distinct values and all tokens with the
+// same fp16 logit have the same probability.  Pass A builds an INTEGER histogram over the order-preserving 16-bit key
+// of each logit (global atomics, deterministic); pass B walks the 65536 bins in descending order with fp64
+// accumulators (count x exp((v - vmax)/T)): top-k cut, normaliser, top-p cut, min-p cut and the drawn (bin, ordinal)
+// all fall out of that walk; pass C finds the ordinal-th token (in id order) carrying the drawn fp16 value.
+// 3 passes over a 256 KB row instead of a 128k-element segmented sort per row and step.  The uniform draw comes from
+// Philox4x32-10 keyed by the request's seed with the context length as counter (curand's XORWOW stream cannot be
+// reproduced, so sampling parity is defined on the filtered distribution + the draw-to-token mapping, not on curand).
+#include "tm_common.h"
+#include "tm_kernels.h"
+
+namespace tmk {
+
+constexpr int kBins = 65536;
+
+// fp16 bit pattern -> key that sorts like the value (NaN lowest)
+__device__ __forceinline__ uint32_t key_of(uint16_t h)
+{
+    if ((h & 0x7c00u) == 0x7c00u && (h & 0x03ffu)) {
+        return 0u;  // NaN
+    }
+    return (h & 0x8000u) ? (uint32_t)(uint16_t)~h : (uint32_t)(h | 0x8000u);
+}
+
+__device__ __forceinline__ float value_of_key(uint32_t key)
+{
+    const uint16_t h = (key & 0x8000u) ? (uint16_t)(key & 0x7fffu) : (uint16_t)~key;
+    return (float)bit_cast<half_t>(h);
+}
+
+// ---- pass A: integer histogram of the row ------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sample_hist_kernel(uint32_t* __restrict__ hist, const half_t* __restrict__ logits,
+                                                          int V, int ld)
+{
+    const int       b   = blockIdx.y;
+    const uint16_t* row = (const uint16_t*)(logits + (size_t)b * ld);
+    uint32_t*       h   = hist + (size_t)b * kBins;
+    for (int i = (blockIdx.x * 256 + threadIdx.x) * 8; i < V; i += gridDim.x * 256 * 8) {
+        if (i + 8 <= V) {
+            const u32x4 w = *(const u32x4*)(row + i);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                atomicAdd(h + key_of((uint16_t)(w[e] & 0xffffu)), 1u);
+                atomicAdd(h + key_of((uint16_t)(w[e] >> 16)), 1u);
+            }
+        }
+        else {
+            for (int j = i; j < V; ++j) {
+                atomicAdd(h + key_of(row[j]), 1u);
+            }
+        }
+    }
+}
+
+// block-wide exclusive scans (1024 threads), fixed combination order -> deterministic
+template<class T>
+__device__ __forceinline__ T block_exclusive_scan(T v, T* smem /*[16]*/, T* total)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    T         x    = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const T y = __shfl_up(x, d);
+        if (lane >= d) {
+            x += y;
+        }
+    }
+    if (lane == 63) {
+        smem[wave] = x;
+    }
+    __syncthreads();
+    T base = 0, tot = 0;
+    for (int w = 0; w < 16; ++w) {
+        if (w < wave) {
+            base += smem[w];
+        }
+        tot += smem[w];
+    }
+    __syncthreads();
+    *total = tot;
+    return base + x - v;
+}
+
+// ---- pass B + C: one 1024-thread workgroup per row ------------------------------------------------------------------
+// Thread t owns the 64 bins j = 64 t .. 64 t + 63 of the DESCENDING order (bin j <-> key 65535 - j).
+__global__ __launch_bounds__(1024) void sample_select_kernel(int* __restrict__ out_ids,
+                                                             uint32_t* __restrict__ hist,
+                                                             const half_t* __restrict__ logits,
+                                                             int V,
+                                                             int ld,
+                                                             const float* __restrict__ temperature,
+                                                             const int* __restrict__ top_k,
+                                                             const float* __restrict__ top_p,
+                                                             const float* __restrict__ min_p,
+                                                             const float* __restrict__ uniform,
+                                                             int* __restrict__ kept_out)
+{
+    __shared__ double   s_d[16];
+    __shared__ long long s_l[16];
+    __shared__ int      s_i[8];
+    __shared__ double   s_v[4];
+    const int  b   = blockIdx.x;
+    const int  tid = threadIdx.x;
+    uint32_t*  h   = hist + (size_t)b * kBins;
+    const float T  = temperature ? temperature[b] : 1.0f;
+    const float invT = 1.0f / (T > 0.f ? T : 1.0f);
+    long long   k_lim = (top_k && top_k[b] > 0) ? top_k[b] : (long long)V;
+    const double tp   = top_p ? (double)top_p[b] : 1.0;
+    const double mp   = min_p ? (double)min_p[b] : 0.0;
+    const double u    = uniform ? (double)uniform[b] : 0.0;
+
+    // My 64 bins are re-read from the (L2-resident) histogram in every walk instead of living in 64 + 128 registers:
+    // a 1024-thread workgroup has 128 VGPRs per lane.  bin(q) = raw count of descending bin 64 tid + q.
+    auto bin = [&](int q) -> long long { return (long long)h[kBins - 1 - (tid * 64 + q)]; };
+    long long mine  = 0;
+    int       first = kBins;  // largest value present = first non-empty bin
+    for (int q = 63; q >= 0; --q) {
+        const long long c = bin(q);
+        mine += c;
+        if (c) {
+            first = tid * 64 + q;
+        }
+    }
+    if (tid < 8) {
+        s_i[tid] = tid == 3 ? -1 : kBins;
+    }
+    __syncthreads();
+    atomicMin(&s_i[0], first);
+    __syncthreads();
+    const float vmax = value_of_key(kBins - 1 - s_i[0]);
+
+    // top-k: exactly min(k, V) candidates survive (ties inside the cut bin: lowest ids first); every walk below clips
+    // the raw counts with the running prefix: kept(q) = clamp(k_lim - run, 0, raw)
+    long long       tot_cnt;
+    const long long before = block_exclusive_scan<long long>(mine, s_l, &tot_cnt);
+    if (k_lim > tot_cnt) {
+        k_lim = tot_cnt;
+    }
+    // weight of one candidate of bin q
+    auto wq = [&](int q) -> double {
+        const float v = value_of_key(kBins - 1 - (tid * 64 + q));
+        return exp((double)((v - vmax) * invT));
+    };
+    auto clip = [](long long room, long long raw) -> long long { return room <= 0 ? 0 : (room < raw ? room : raw); };
+
+    double msum = 0.0;
+    {
+        long long run = before;
+        for (int q = 0; q < 64; ++q) {
+            const long long raw = bin(q);
+            const long long c   = clip(k_lim - run, raw);
+            run += raw;
+            if (c) {
+                msum += wq(q) * (double)c;
+            }
+        }
+    }
+    double       Z;
+    const double mbefore = block_exclusive_scan<double>(msum, s_d, &Z);
+    const double pmax    = 1.0 / Z;  // the best bin has weight exp(0) = 1
+
+    // ---- top-p: first candidate (bin j, ordinal m) whose inclusive cumulative probability exceeds top_p -------------
+    // kept = candidates up to and including it, ksum = their probability mass (s_kept / s_sum of the reference)
+    if (tid == 0) {
+        s_l[0] = k_lim;
+        s_v[0] = 1.0;
+    }
+    __syncthreads();
+    if (tp < 1.0) {
+        double    cum = mbefore / Z;
+        long long run = before, c0 = before < k_lim ? before : k_lim;
+        int       hit = -1;
+        long long hit_kept = 0;
+        double    hit_sum  = 0.0;
+        for (int q = 0; q < 64 && hit < 0; ++q) {
+            const long long raw = bin(q);
+            const long long c   = clip(k_lim - run, raw);
+            run += raw;
+            if (c) {
+                const double p   = wq(q) / Z;
+                const double end = cum + p * (double)c;
+                if (end > tp) {
+                    long long m = (long long)floor((tp - cum) / p) + 1;
+                    m           = m < 1 ? 1 : (m > c ? c : m);
+                    while (m > 1 && cum + p * (double)(m - 1) > tp) {
+                        --m;
+                    }
+                    while (m < c && !(cum + p * (double)m > tp)) {
+                        ++m;
+                    }
+                    hit      = tid * 64 + q;
+                    hit_kept = c0 + m;
+                    hit_sum  = cum + p * (double)m;
+                }
+                cum = end;
+                c0 += c;
+            }
+        }
+        if (hit >= 0) {
+            atomicMin(&s_i[1], hit);
+        }
+        __syncthreads();
+        if (hit >= 0 && s_i[1] == hit) {
+            s_l[0] = hit_kept;
+            s_v[0] = hit_sum;
+        }
+        __syncthreads();
+    }
+    long long kept = s_l[0];
+    double    ksum = s_v[0];
+    __syncthreads();
+
+    // ---- min-p: candidates with p < min_p * p_max go (they form a suffix of the descending order) -------------------
+    if (mp > 0.0) {
+        const double thr  = pmax * mp;
+        long long    run  = before, c0 = before < kept ? before : kept;
+        long long    n_ok = 0;
+        double       m_ok = 0.0;
+        for (int q = 0; q < 64; ++q) {
+            const long long raw  = bin(q);
+            const long long c    = clip(k_lim - run, raw);
+            const long long take = clip(kept - c0, c);
+            run += raw;
+            c0 += c;
+            if (take > 0) {
+                const double p = wq(q) / Z;
+                if (p >= thr) {
+                    n_ok += take;
+                    m_ok += p * (double)take;
+                }
+            }
+        }
+        long long tn;
+        double    tm;
+        (void)block_exclusive_scan<long long>(n_ok, s_l, &tn);
+        (void)block_exclusive_scan<double>(m_ok, s_d, &tm);
+        kept = tn;
+        ksum = tm;
+    }
+
+    // ---- draw: first kept candidate whose inclusive prefix sum exceeds u * ksum ---------------------------------------
+    {
+        const double target = u * ksum;
+        double       cum    = mbefore / Z;
+        long long    run = before, c0 = before < kept ? before : kept;
+        int          hit = -1, hit_m = 0, last_bin = -1, last_m = 0;
+        for (int q = 0; q < 64; ++q) {
+            const long long raw  = bin(q);
+            const long long c    = clip(k_lim - run, raw);
+            const long long take = clip(kept - c0, c);
+            run += raw;
+            c0 += c;
+            if (take > 0) {
+                const double p   = wq(q) / Z;
+                const double end = cum + p * (double)take;
+                last_bin         = tid * 64 + q;
+                last_m           = (int)take;
+                if (hit < 0 && end > target) {
+                    long long m = (long long)floor((target - cum) / p) + 1;
+                    m           = m < 1 ? 1 : (m > take ? take : m);
+                    while (m > 1 && cum + p * (double)(m - 1) > target) {
+                        --m;
+                    }
+                    while (m < take && !(cum + p * (double)m > target)) {
+                        ++m;
+                    }
+                    hit   = tid * 64 + q;
+                    hit_m = (int)m;
+                }
+                cum = end;
+            }
+        }
+        if (hit >= 0) {
+            atomicMin(&s_i[2], hit);
+        }
+        if (last_bin >= 0) {
+            atomicMax(&s_i[3], last_bin);  // fallback (rounding: nothing exceeded the target): the last kept candidate
+        }
+        __syncthreads();
+        if (hit >= 0 && s_i[2] == hit) {
+            s_i[4] = hit;
+            s_i[5] = hit_m;
+        }
+        __syncthreads();
+        if (s_i[2] == kBins && last_bin >= 0 && s_i[3] == last_bin) {
+            s_i[4] = last_bin;
+            s_i[5] = last_m;
+        }
+        __syncthreads();
+    }
+    const uint32_t sel_key = (uint32_t)(kBins - 1 - s_i[4]);
+    const int      sel_m   = s_i[5];  // 1-based ordinal among the tokens with that logit, in id order
+    if (tid == 0 && kept_out) {
+        kept_out[b] = (int)kept;
+    }
+    // the histogram is left zeroed for the next step
+    for (int q = 0; q < 64; ++q) {
+        h[kBins - 1 - (tid * 64 + q)] = 0u;
+    }
+
+    // ---- pass C: the sel_m-th token (ascending id) whose logit has the drawn value ----------------------------------
+    const uint16_t* row   = (const uint16_t*)(logits + (size_t)b * ld);
+    const int       per   = (V + 1023) / 1024;
+    const int       begin = tid * per;
+    const int       end   = min(begin + per, V);
+    long long       my    = 0;
+    for (int i = begin; i < end; ++i) {
+        my += key_of(row[i]) == sel_key;
+    }
+    long long tot;
+    const long long prior = block_exclusive_scan<long long>(my, s_l, &tot);
+    if (prior < sel_m && sel_m <= prior + my) {
+        long long seen = prior;
+        for (int i = begin; i < end; ++i) {
+            if (key_of(row[i]) == sel_key && ++seen == sel_m) {
+                out_ids[b] = i;
+                break;
+            }
+        }
+    }
+}
+
+// Philox4x32-10 (Salmon et al., SC'11): counter = (ctr, 0, 0, 0), key = seed; u = top 24 bits / 2^24 in [0, 1)
+__host__ __device__ inline float philox_uniform(uint64_t seed, uint32_t ctr)
+{
+    uint32_t c0 = ctr, c1 = 0, c2 = 0, c3 = 0;
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        const uint32_t n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        const uint32_t n3 = (uint32_t)p0;
+        c0 = n0, c1 = n1, c2 = n2, c3 = n3;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    return (float)(c0 >> 8) * (1.0f / 16777216.0f);
+}
+
+__global__ void philox_uniform_kernel(float* u, const uint64_t* seeds, const int* counters, int batch)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < batch) {
+        u[b] = philox_uniform(seeds[b], (uint32_t)counters[b]);
+    }
+}
+
+size_t sample_workspace_bytes(int batch)
+{
+    return (size_t)batch * kBins * sizeof(uint32_t);
+}
+
+int launch_sample_uniform(float* u, const uint64_t* seeds, const int* counters, int batch, hipStream_t st)
+{
+    if (batch == 0) {
+        return 0;
+    }
+    philox_uniform_kernel<<<(batch + 63) / 64, 64, 0, st>>>(u, seeds, counters, batch);
+    TM_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// workspace: batch * 65536 uint32, ZERO on entry (the kernel leaves it zero again)
+int launch_sample(int* out_ids, int* kept_out, const half_t* logits, int batch, int V, int ld, const float* temperature,
+                  const int* top_k, const float* top_p, const float* min_p, const float* uniform, void* workspace,
+                  hipStream_t st)
+{
+    TM_REQUIRE(out_ids && logits && workspace, "null pointer");
+    TM_REQUIRE(V >= 1 && ld >= V && ld % 8 == 0, "sampling: ld must be a multiple of 8 and >= vocab");
+    if (batch == 0) {
+        return 0;
+    }
+    const int chunks = std::max(1, std::min(64, (V + 2047) / 2048));
+    sample_hist_kernel<<<dim3(chunks, batch), 256, 0, st>>>((uint32_t*)workspace, logits, V, ld);
+    TM_HIP_CHECK(hipGetLastError());
+    sample_select_kernel<<<batch, 1024, 0, st>>>(out_ids, (uint32_t*)workspace, logits, V, ld, temperature, top_k, top_p,
+                                                 min_p, uniform, kept_out);
+    TM_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+float philox_uniform_host(uint64_t seed, uint32_t ctr)
+{
+    return philox_uniform(seed, ctr);
+}
+
+}  // namespace tmk

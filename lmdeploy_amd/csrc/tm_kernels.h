@@ -124,6 +124,14 @@ GemmConfig gemm_pick_config(const LinearWeight& w, int M);
 int launch_linear(const LinearWeight& w, const half_t* x, int ldx, half_t* y, int ldy, int M, bool gated_silu,
                   GemmConfig cfg, float* workspace, bool defer_reduce, int* slabs, hipStream_t st);
 
+// sampling.hip: temperature / top-k / top-p / min-p sampling without a sort (see the file header)
+size_t sample_workspace_bytes(int batch);
+int    launch_sample(int* out_ids, int* kept_out, const half_t* logits, int batch, int V, int ld, const float* temperature,
+                     const int* top_k, const float* top_p, const float* min_p, const float* uniform, void* workspace,
+                     hipStream_t st);
+int    launch_sample_uniform(float* u, const uint64_t* seeds, const int* counters, int batch, hipStream_t st);
+float  philox_uniform_host(uint64_t seed, uint32_t ctr);
+
 extern uint64_t* g_gemm_dbg;  // gemm_w4a16.hip: optional per-workgroup timing stamps (tm_debug_set_gemm_trace)
 
 // ---- misc.hip ---------------------------------------------------------------------------

@@ -798,3 +798,57 @@ class OracleModel:
         for b, n in enumerate(lens):
             self.seq_len[b] += n
         return greedy(logits), logits
+
+
+# ------------------------------------------------------------------------------------------------
+# Sampling (generation/sampling.cc:92-183; kernels/sampling_topk_kernels.cu, sampling_topp_kernels.cu:291-384,
+# sampling_kernels.cu:16-94; temperature: generation/logits_processor.cc:105-112)
+# ------------------------------------------------------------------------------------------------
+def sample_filter(logits: np.ndarray, temperature: float = 1.0, top_k: int = 0, top_p: float = 1.0, min_p: float = 0.0):
+    """One row.  Returns (token ids of the surviving candidates in sampling order, their renormalised probabilities).
+    Order: descending logit, ties by ascending token id (a stable descending sort, as cub's radix sort gives the
+    reference).  top-k keeps the first k; softmax over them; top-p keeps the shortest prefix whose cumulative
+    probability EXCEEDS top_p (sampling_topp_kernels.cu:318-338); min-p drops p < min_p * p_max (:341-369); the
+    survivors are divided by their mass (:372-382)."""
+    v = np.asarray(logits, np.float16).astype(np.float32)
+    ids = np.arange(v.size)
+    key = np.where(np.isnan(v), -np.inf, v)
+    order = np.lexsort((ids, -key))
+    k = v.size if top_k <= 0 else min(int(top_k), v.size)
+    cand = order[:k]
+    inv_t = np.float32(1.0) / np.float32(temperature if temperature > 0 else 1.0)
+    z = ((v[cand] - v[cand[0]]).astype(np.float32) * inv_t).astype(np.float32)     # fp32, like the kernel
+    w = np.exp(z.astype(np.float64))
+    p = w / w.sum()
+    kept, ksum = k, 1.0
+    if top_p < 1.0:
+        cum = np.cumsum(p)
+        hit = np.flatnonzero(cum > top_p)
+        if hit.size:
+            kept, ksum = int(hit[0]) + 1, float(cum[hit[0]])
+    if min_p > 0.0:
+        ok = p[:kept] >= p[0] * min_p
+        kept = int(ok.sum())            # a prefix, because p is non-increasing
+        ksum = float(p[:kept].sum())
+    return cand[:kept], p[:kept] / ksum
+
+
+def sample_draw(ids: np.ndarray, probs: np.ndarray, u: float) -> int:
+    """first candidate whose inclusive prefix sum exceeds u, else the last one (sampling_kernels.cu:46-63)"""
+    cum = np.cumsum(probs)
+    hit = np.flatnonzero(cum > u)
+    return int(ids[hit[0]] if hit.size else ids[-1])
+
+
+def philox_uniform(seed: int, counter: int) -> float:
+    """Philox4x32-10 (Salmon et al. 2011), counter (ctr,0,0,0), key = 64-bit seed; top 24 bits of word 0 -> [0,1)."""
+    m32 = 0xffffffff
+    c = [counter & m32, 0, 0, 0]
+    k0, k1 = seed & m32, (seed >> 32) & m32
+    for _ in range(10):
+        p0 = 0xD2511F53 * c[0]
+        p1 = 0xCD9E8D57 * c[2]
+        c = [((p1 >> 32) ^ c[1] ^ k0) & m32, p1 & m32, ((p0 >> 32) ^ c[3] ^ k1) & m32, p0 & m32]
+        k0 = (k0 + 0x9E3779B9) & m32
+        k1 = (k1 + 0xBB67AE85) & m32
+    return float(np.float32(c[0] >> 8) * np.float32(1.0 / 16777216.0))

@@ -510,6 +510,65 @@ def test_tp_sharded_ffn_sequential_shards(tm, cuda, tp):
     _ffi.check(tm.tm_linear_destroy(h2))
 
 
+@pytest.mark.parametrize('V,ld', [(1000, 1000), (4099, 4104), (128256, 128256)])
+def test_sampling_matches_oracle(tm, cuda, V, ld):
+    """tm_sample against the sort-based restatement of the reference pipeline (oracle.sample_filter / sample_draw):
+    surviving-candidate count and the drawn token for given uniform numbers, rows with different temperature / top-k /
+    top-p / min-p, logits with many exact ties (the tie order is part of the contract) and -inf (banned) entries."""
+    rng = np.random.default_rng(V)
+    rows = [dict(), dict(top_k=1), dict(top_k=40), dict(top_k=40, top_p=0.8), dict(top_p=0.9), dict(top_p=0.3, temperature=0.7),
+            dict(min_p=0.05), dict(top_k=200, top_p=0.95, min_p=0.02, temperature=1.3), dict(top_p=0.0), dict(top_k=V + 5),
+            dict(temperature=0.01), dict(top_p=0.999, temperature=2.0)]
+    B = len(rows)
+    logits = (rng.standard_normal((B, ld)) * 2.5).astype(f16)
+    logits[:, ::3] = np.round(logits[:, ::3].astype(np.float32) * 4).astype(f16) / f16(4)       # lots of exact ties
+    logits[:, 5:50:7] = f16(-np.inf)
+    logits[2, :] = f16(1.5)                                                                       # a completely flat row
+    if ld > V:
+        logits[:, V:] = f16(100.0)                                                                # padding must be ignored
+    u = rng.random(B).astype(np.float32)
+    u[0], u[4] = 0.0, np.float32(1.0 - 2.0**-24)
+    arr = lambda k, d, t: np.asarray([r.get(k, d) for r in rows], t)
+    temp, topk, topp, minp = arr('temperature', 1.0, np.float32), arr('top_k', 0, np.int32), arr('top_p', 1.0, np.float32), arr('min_p', 0.0, np.float32)
+    ws = torch.zeros(tm.tm_sample_workspace(B), dtype=torch.uint8, device='cuda')
+    out = torch.full((B,), -1, dtype=torch.int32, device='cuda')
+    kept = torch.zeros(B, dtype=torch.int32, device='cuda')
+    for rep in range(2):      # the second call checks that the workspace was left zeroed
+        _ffi.check(tm.tm_sample(out.data_ptr(), kept.data_ptr(), dev(logits).data_ptr(), B, V, ld, dev(temp).data_ptr(),
+                                dev(topk).data_ptr(), dev(topp).data_ptr(), dev(minp).data_ptr(), dev(u).data_ptr(),
+                                ws.data_ptr(), st()))
+        got, got_kept = host(out), host(kept)
+        for b, r in enumerate(rows):
+            ids, p = o.sample_filter(logits[b, :V], float(temp[b]), int(topk[b]), float(topp[b]), float(minp[b]))
+            assert got_kept[b] == len(ids), f'row {b} {r}: kept {got_kept[b]} vs {len(ids)}'
+            assert got[b] == o.sample_draw(ids, p, float(u[b])), f'row {b} {r}'
+    assert not ws.any()
+
+
+def test_sampling_distribution(tm, cuda):
+    """Statistical check of the draw: 20000 uniform numbers from the engine's Philox stream over one filtered
+    distribution reproduce its probabilities (chi-square far below the rejection threshold)."""
+    rng = np.random.default_rng(9)
+    V, N = 512, 20000
+    row = (rng.standard_normal(V) * 2).astype(f16)
+    ids, p = o.sample_filter(row, 0.9, 12, 0.97, 0.0)
+    logits = np.tile(row, (64, 1))
+    counts = np.zeros(V, np.int64)
+    ws = torch.zeros(tm.tm_sample_workspace(64), dtype=torch.uint8, device='cuda')
+    out = torch.zeros(64, dtype=torch.int32, device='cuda')
+    t, k, pp = dev(np.full(64, 0.9, np.float32)), dev(np.full(64, 12, np.int32)), dev(np.full(64, 0.97, np.float32))
+    ld = dev(logits)
+    for it in range(N // 64 + 1):
+        u = np.asarray([tm.tm_philox_uniform(1234, it * 64 + j) for j in range(64)], np.float32)
+        _ffi.check(tm.tm_sample(out.data_ptr(), None, ld.data_ptr(), 64, V, V, t.data_ptr(), k.data_ptr(), pp.data_ptr(), None,
+                                dev(u).data_ptr(), ws.data_ptr(), st()))
+        np.add.at(counts, host(out), 1)
+    n = counts.sum()
+    assert counts[np.setdiff1d(np.arange(V), ids)].sum() == 0          # nothing outside the filtered set
+    chi2 = (((counts[ids] - n * p) ** 2) / (n * p)).sum()
+    assert chi2 < 3 * len(ids) + 30, chi2                               # dof = len(ids) - 1 ~ 10; mean = dof
+
+
 def test_w4a16_identity_asymmetric(tm, cuda):
     """Transpose-detecting check: x = I (first K rows) picks out rows of the dequantised weight exactly."""
     rng = np.random.default_rng(3)

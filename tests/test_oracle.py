@@ -200,3 +200,49 @@ def test_oracle_model_is_deterministic_and_block_table_free():
         runs.append((ids, ids2, lg))
     assert np.array_equal(runs[0][0], runs[1][0]) and np.array_equal(runs[0][2], runs[1][2])
     assert math.isfinite(float(np.abs(runs[0][2].astype(np.float32)).max()))
+
+
+def test_philox_known_answer():
+    """Philox4x32-10 known-answer vectors of the Random123 distribution (kat_vectors): counter / key all zero, all
+    ones, and the digits of pi -> first output word."""
+    def word0(ctr4, key2):
+        m32 = 0xffffffff
+        c = list(ctr4)
+        k0, k1 = key2
+        for _ in range(10):
+            p0 = 0xD2511F53 * c[0]
+            p1 = 0xCD9E8D57 * c[2]
+            c = [((p1 >> 32) ^ c[1] ^ k0) & m32, p1 & m32, ((p0 >> 32) ^ c[3] ^ k1) & m32, p0 & m32]
+            k0 = (k0 + 0x9E3779B9) & m32
+            k1 = (k1 + 0xBB67AE85) & m32
+        return c
+    assert word0([0, 0, 0, 0], (0, 0)) == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
+    assert word0([0xffffffff] * 4, (0xffffffff, 0xffffffff)) == [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
+    assert word0([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], (0xa4093822, 0x299f31d0)) == \
+        [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]
+    # the oracle's (and the library's) uniform = top 24 bits of word 0
+    assert o.philox_uniform(0, 0) == float(np.float32(0x6627e8d5 >> 8) / np.float32(16777216.0))
+    from lmdeploy_amd import _ffi
+    lib = _ffi.load()
+    for seed, ctr in ((0, 0), (1234567890123, 77), (2**64 - 1, 2**32 - 1)):
+        assert lib.tm_philox_uniform(seed, ctr) == o.philox_uniform(seed, ctr)
+
+
+def test_sampling_filter_semantics():
+    logits = np.array([1.0, 3.0, 3.0, -2.0, 0.5, 3.0, 2.0], np.float16)
+    ids, p = o.sample_filter(logits)                                   # everything, descending, ties by id
+    assert ids.tolist() == [1, 2, 5, 6, 0, 4, 3] and abs(p.sum() - 1) < 1e-12
+    ids, p = o.sample_filter(logits, top_k=2)
+    assert ids.tolist() == [1, 2] and np.allclose(p, 0.5)
+    ids, p = o.sample_filter(logits, top_k=1, temperature=0.3)
+    assert ids.tolist() == [1] and p[0] == 1.0
+    full = o.sample_filter(logits)[1]
+    ids, p = o.sample_filter(logits, top_p=float(full[:2].sum()))      # cumulative must EXCEED top_p
+    assert ids.tolist() == [1, 2, 5]
+    ids, p = o.sample_filter(logits, min_p=0.2)                        # e^-1 = 0.37 stays, e^-2 = 0.135 goes
+    assert ids.tolist() == [1, 2, 5, 6]
+    cold = o.sample_filter(logits, temperature=0.25)[1]
+    assert cold[0] > full[0]                                           # lower temperature sharpens
+    assert o.sample_draw(np.array([7, 8, 9]), np.array([0.2, 0.3, 0.5]), 0.2) == 8     # prefix must exceed u
+    assert o.sample_draw(np.array([7, 8, 9]), np.array([0.2, 0.3, 0.5]), 0.999999) == 9
+    assert o.sample_draw(np.array([7, 8, 9]), np.array([0.2, 0.3, 0.5]), 0.0) == 7
