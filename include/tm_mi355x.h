@@ -232,6 +232,19 @@ int tm_engine_profile_decode(tm_engine* e, int steps, float* host_ms_per_step, i
 int tm_engine_fetch(tm_engine* e, int* host_out, int* n_generated);
 /* last step's logits of the local vocab shard, fp16 [batch][vocab/tp] -> host (debug / parity tests) */
 int tm_engine_fetch_logits(tm_engine* e, void* host_out);
+/* Per-sequence sampling parameters (GenerationConfig: temperature, top_k, top_p, min_p, random_seed;
+ * lmdeploy/messages.py:35-205).  top_k == 1 is greedy.  The uniform draw of a step is Philox(seed, context length). */
+typedef struct tm_sampling {
+    float    temperature; /* > 0 */
+    int      top_k;       /* <= 0: no top-k filter */
+    float    top_p;       /* >= 1: no top-p filter */
+    float    min_p;       /* 0: off */
+    uint64_t seed;
+} tm_sampling;
+/* Static batch: sampling parameters of the NEXT tm_engine_prefill (host array [batch], copied); NULL / never called =
+ * greedy arg-max.  Cleared by tm_engine_release.  TP > 1 supports greedy only in this round (TM_INVALID). */
+int tm_engine_set_sampling(tm_engine* e, const tm_sampling* host_params, int batch);
+
 /* release the batch (blocks return to the pool); also ends a continuous-batching session */
 int tm_engine_release(tm_engine* e);
 
@@ -248,6 +261,9 @@ int tm_engine_release(tm_engine* e);
  *         TM_OOM (can never fit the block pool).  poll: status 0 = waiting / running, TM_FINISH, TM_CANCEL;
  *         copies min(cap, n_tokens) generated tokens.  Unknown ids: TM_INVALID. */
 int tm_engine_submit(tm_engine* e, const int* host_ids, int n, int max_new_tokens, int eos_id, int64_t* req_id);
+/* like tm_engine_submit with sampling parameters (NULL = greedy) */
+int tm_engine_submit_ex(tm_engine* e, const int* host_ids, int n, int max_new_tokens, int eos_id, const tm_sampling* sampling,
+                         int64_t* req_id);
 int tm_engine_step(tm_engine* e, int* n_active, int* n_waiting);
 int tm_engine_poll(tm_engine* e, int64_t req_id, int* status, int* host_tokens, int cap, int* n_tokens);
 int tm_engine_cancel(tm_engine* e, int64_t req_id);

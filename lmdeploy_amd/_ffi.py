@@ -20,6 +20,11 @@ class TmError(RuntimeError):
         self.status = status
 
 
+class Sampling(C.Structure):
+    """struct tm_sampling"""
+    _fields_ = [('temperature', c_float), ('top_k', c_int), ('top_p', c_float), ('min_p', c_float), ('seed', c_uint64)]
+
+
 class KvCache(C.Structure):
     """struct tm_kv_cache"""
     _fields_ = [('block_ptrs', c_void_p), ('cu_block_nums', c_void_p), ('layer_offset', c_int64),
@@ -97,6 +102,8 @@ _SIGNATURES = {
     'tm_engine_fetch': (c_int, [c_void_p, c_void_p, POINTER(c_int)]),
     'tm_engine_fetch_logits': (c_int, [c_void_p, c_void_p]),
     'tm_engine_release': (c_int, [c_void_p]),
+    'tm_engine_set_sampling': (c_int, [c_void_p, c_void_p, c_int]),
+    'tm_engine_submit_ex': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, POINTER(c_int64)]),
     'tm_engine_submit': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, POINTER(c_int64)]),
     'tm_engine_step': (c_int, [c_void_p, POINTER(c_int), POINTER(c_int)]),
     'tm_engine_poll': (c_int, [c_void_p, c_int64, POINTER(c_int), c_void_p, c_int, POINTER(c_int)]),

@@ -235,6 +235,15 @@ struct tm_engine {
     std::vector<int> h_active, h_step_ids;
     int              dummy_block = -1;
     hipGraphExec_t   graph_cb    = nullptr;
+
+    // stochastic sampling (tm_engine_set_sampling / tm_engine_submit_ex); off = arg-max
+    bool      sampling_on = false, graph_sampling = false, graph_cb_sampling = false;
+    float *   d_temp = nullptr, *d_topp = nullptr, *d_minp = nullptr, *d_u = nullptr;
+    int*      d_topk = nullptr;
+    uint64_t* d_seed = nullptr;
+    void*     d_sample_ws = nullptr;
+    std::vector<tm_sampling>       h_sampling;      // static batch: parameters of the next prefill
+    std::map<int64_t, tm_sampling> cb_sampling;     // continuous batching: per request
 };
 
 namespace tmk {
@@ -473,7 +482,14 @@ static int forward(tm_engine* e, const int* d_ids, int M, int nseq, bool decode,
     half_t* logits = e->d_logits + (size_t)slot0 * e->vocab_local;
     int*    ids    = e->d_next_ids + slot0;
     TM_PROF(P_LM_HEAD, TM_TRY(linear_plain(e, e->output, hx, e->hidden, logits, e->vocab_local, nseq, false)));
-    if (!e->use_comm) {
+    if (!e->use_comm && e->sampling_on) {
+        // parameters are indexed by batch slot, the counter (context length) by the row of this forward
+        TM_PROF(P_SAMPLE, TM_TRY(launch_sample_uniform(e->d_u + slot0, e->d_seed + slot0, e->d_k_len, nseq, st)));
+        TM_PROF(P_SAMPLE, TM_TRY(launch_sample(ids, nullptr, logits, nseq, e->vocab_local, e->vocab_local, e->d_temp + slot0,
+                                               e->d_topk + slot0, e->d_topp + slot0, e->d_minp + slot0, e->d_u + slot0,
+                                               e->d_sample_ws, st)));
+    }
+    else if (!e->use_comm) {
         TM_PROF(P_SAMPLE, TM_TRY(launch_argmax(ids, nullptr, logits, nseq, e->vocab_local, e->vocab_local, 0, st)));
     }
     else {
@@ -810,6 +826,50 @@ int tm_engine_start(tm_engine* e)
     return 0;
 }
 
+// sampling state: device arrays for all slots (allocated on first use), upload of `n` slots starting at slot0
+static int sampling_upload(tm_engine* e, const tm_sampling* p, int slot0, int n)
+{
+    const int B = e->cfg.max_batch_size;
+    if (!e->d_temp) {
+        TM_REQUIRE(e->vocab_local % 8 == 0, "sampling needs vocab % 8 == 0");
+        TM_TRY(dmalloc(&e->d_temp, (size_t)B));
+        TM_TRY(dmalloc(&e->d_topp, (size_t)B));
+        TM_TRY(dmalloc(&e->d_minp, (size_t)B));
+        TM_TRY(dmalloc(&e->d_u, (size_t)B));
+        TM_TRY(dmalloc(&e->d_topk, (size_t)B));
+        TM_TRY(dmalloc(&e->d_seed, (size_t)B));
+        TM_HIP_CHECK(hipMalloc(&e->d_sample_ws, sample_workspace_bytes(B)));
+        TM_HIP_CHECK(hipMemsetAsync(e->d_sample_ws, 0, sample_workspace_bytes(B), e->stream));
+        std::vector<float>    one(B, 1.f), zero(B, 0.f);
+        std::vector<int>      k1(B, 1);
+        std::vector<uint64_t> s0(B, 0);
+        TM_HIP_CHECK(hipMemcpyAsync(e->d_temp, one.data(), B * 4, hipMemcpyHostToDevice, e->stream));
+        TM_HIP_CHECK(hipMemcpyAsync(e->d_topp, one.data(), B * 4, hipMemcpyHostToDevice, e->stream));
+        TM_HIP_CHECK(hipMemcpyAsync(e->d_minp, zero.data(), B * 4, hipMemcpyHostToDevice, e->stream));
+        TM_HIP_CHECK(hipMemcpyAsync(e->d_topk, k1.data(), B * 4, hipMemcpyHostToDevice, e->stream));
+        TM_HIP_CHECK(hipMemcpyAsync(e->d_seed, s0.data(), B * 8, hipMemcpyHostToDevice, e->stream));
+        TM_HIP_CHECK(hipStreamSynchronize(e->stream));
+    }
+    std::vector<float>    t(n), pp(n), mp(n);
+    std::vector<int>      k(n);
+    std::vector<uint64_t> sd(n);
+    for (int i = 0; i < n; ++i) {
+        TM_REQUIRE(p[i].temperature > 0.f, "sampling: temperature must be > 0");
+        t[i]  = p[i].temperature;
+        k[i]  = p[i].top_k;
+        pp[i] = p[i].top_p;
+        mp[i] = p[i].min_p;
+        sd[i] = p[i].seed;
+    }
+    TM_HIP_CHECK(hipMemcpyAsync(e->d_temp + slot0, t.data(), n * 4, hipMemcpyHostToDevice, e->stream));
+    TM_HIP_CHECK(hipMemcpyAsync(e->d_topk + slot0, k.data(), n * 4, hipMemcpyHostToDevice, e->stream));
+    TM_HIP_CHECK(hipMemcpyAsync(e->d_topp + slot0, pp.data(), n * 4, hipMemcpyHostToDevice, e->stream));
+    TM_HIP_CHECK(hipMemcpyAsync(e->d_minp + slot0, mp.data(), n * 4, hipMemcpyHostToDevice, e->stream));
+    TM_HIP_CHECK(hipMemcpyAsync(e->d_seed + slot0, sd.data(), n * 8, hipMemcpyHostToDevice, e->stream));
+    TM_HIP_CHECK(hipStreamSynchronize(e->stream));
+    return 0;
+}
+
 // decode split heuristic: fill >= 2 workgroups per CU (GetSplitCount, kernels/attention/utils.cc:11-46); fused prologue
 static void setup_decode(tm_engine* e, int batch)
 {
@@ -993,6 +1053,11 @@ static int cb_prefill_admitted(tm_engine* e, const std::vector<SchedAdmit>& admi
             TM_REQUIRE(r && r->running, "internal: admitted request vanished");
             ids[k]  = r->prompt.data();
             lens[k] = (int)r->prompt.size();
+            if (e->sampling_on) {  // greedy rows are top_k = 1 rows of the sampling kernels
+                auto              it = e->cb_sampling.find(r->id);
+                const tm_sampling sp = it == e->cb_sampling.end() ? tm_sampling{1.f, 1, 1.f, 0.f, 0} : it->second;
+                TM_TRY(sampling_upload(e, &sp, slot0 + k, 1));
+            }
             TM_REQUIRE((int)r->blocks.size() <= e->max_blocks_per_seq, "internal: block table row too short");
             for (size_t q = 0; q < r->blocks.size(); ++q) {
                 ptrs[(size_t)k * e->max_blocks_per_seq + q] = (uint64_t)(e->pool + (int64_t)r->blocks[q] * e->block_bytes);
@@ -1042,6 +1107,9 @@ int tm_engine_release(tm_engine* e)
     e->h_len.clear();
     e->batch      = 0;
     e->steps_done = 0;
+    e->h_sampling.clear();
+    e->cb_sampling.clear();
+    e->sampling_on = false;
     if (e->sched) {  // leave continuous-batching mode: every block goes back to the static free list
         e->sched.reset();
         e->free_blocks.resize(e->num_blocks);
@@ -1095,6 +1163,12 @@ int tm_engine_prefill(tm_engine* e, const int* host_ids, const int* host_lens, i
     e->h_len.assign(host_lens, host_lens + batch);
     e->steps_done = 0;
 
+    e->sampling_on = false;
+    if (!e->h_sampling.empty()) {
+        TM_REQUIRE((int)e->h_sampling.size() == batch, "tm_engine_set_sampling: batch size differs from the prefill's");
+        TM_TRY(sampling_upload(e, e->h_sampling.data(), 0, batch));
+        e->sampling_on = true;
+    }
     e->h_ttft_ms.assign(batch, 0.f);
     {
         std::vector<const int*> seq_ids(batch);
@@ -1120,7 +1194,7 @@ int tm_engine_prefill(tm_engine* e, const int* host_ids, const int* host_lens, i
     e->steps_done = 1;
 
     setup_decode(e, batch);
-    if (e->graph && (e->graph_batch != batch || e->graph_max_new != max_new_tokens)) {
+    if (e->graph && (e->graph_batch != batch || e->graph_max_new != max_new_tokens || e->graph_sampling != e->sampling_on)) {
         (void)hipGraphExecDestroy(e->graph);
         e->graph = nullptr;
     }
@@ -1158,8 +1232,9 @@ int tm_engine_decode(tm_engine* e, int steps)
         TM_HIP_CHECK(ce);
         TM_HIP_CHECK(hipGraphInstantiate(&e->graph, g, nullptr, nullptr, 0));
         TM_HIP_CHECK(hipGraphDestroy(g));
-        e->graph_batch   = e->batch;
-        e->graph_max_new = e->max_new;
+        e->graph_batch    = e->batch;
+        e->graph_max_new  = e->max_new;
+        e->graph_sampling = e->sampling_on;
     }
     for (int i = 0; i < steps; ++i) {
         if (use_graph) {
@@ -1170,6 +1245,44 @@ int tm_engine_decode(tm_engine* e, int steps)
         }
     }
     e->steps_done += steps;
+    return 0;
+}
+
+int tm_engine_set_sampling(tm_engine* e, const tm_sampling* host_params, int batch)
+{
+    TM_REQUIRE(e, "null pointer");
+    TM_REQUIRE(e->batch == 0 && !e->sched, "set the sampling parameters before tm_engine_prefill");
+    e->h_sampling.clear();
+    if (!host_params) {
+        return 0;
+    }
+    TM_REQUIRE(!e->use_comm, "stochastic sampling with tp > 1 is not supported in this round (greedy only)");
+    TM_REQUIRE(batch >= 1 && batch <= e->cfg.max_batch_size, "1 <= batch <= max_batch_size");
+    for (int i = 0; i < batch; ++i) {
+        TM_REQUIRE(host_params[i].temperature > 0.f, "sampling: temperature must be > 0");
+    }
+    e->h_sampling.assign(host_params, host_params + batch);
+    return 0;
+}
+
+int tm_engine_submit_ex(tm_engine* e, const int* host_ids, int n, int max_new_tokens, int eos_id, const tm_sampling* sampling,
+                        int64_t* req_id)
+{
+    TM_REQUIRE(e && req_id, "null pointer");
+    if (sampling) {
+        TM_REQUIRE(!e->use_comm, "stochastic sampling with tp > 1 is not supported in this round (greedy only)");
+        TM_REQUIRE(sampling->temperature > 0.f, "sampling: temperature must be > 0");
+    }
+    TM_TRY(tm_engine_submit(e, host_ids, n, max_new_tokens, eos_id, req_id));
+    if (sampling) {
+        e->cb_sampling[*req_id] = *sampling;
+        if (!e->sampling_on) {  // the first stochastic request switches the decode step to the sampling kernels
+            const int                B = e->cfg.max_batch_size;
+            std::vector<tm_sampling> greedy(B, tm_sampling{1.f, 1, 1.f, 0.f, 0});
+            TM_TRY(sampling_upload(e, greedy.data(), 0, B));
+            e->sampling_on = true;
+        }
+    }
     return 0;
 }
 
@@ -1205,6 +1318,10 @@ int tm_engine_step(tm_engine* e, int* n_active, int* n_waiting)
     if (e->sched->n_active() > 0) {
         const char* gc        = getenv("TM_GRAPH_COMM");
         const bool  use_graph = e->cfg.use_graph && (!e->use_comm || (gc && atoi(gc)));
+        if (e->graph_cb && e->graph_cb_sampling != e->sampling_on) {
+            (void)hipGraphExecDestroy(e->graph_cb);
+            e->graph_cb = nullptr;
+        }
         if (use_graph && !e->graph_cb) {
             TM_TRY(decode_step_cb(e));  // one eager step first (lazy module loading must not happen inside a capture)
             TM_HIP_CHECK(hipStreamSynchronize(e->stream));
@@ -1218,6 +1335,7 @@ int tm_engine_step(tm_engine* e, int* n_active, int* n_waiting)
             TM_HIP_CHECK(ce);
             TM_HIP_CHECK(hipGraphInstantiate(&e->graph_cb, g, nullptr, nullptr, 0));
             TM_HIP_CHECK(hipGraphDestroy(g));
+            e->graph_cb_sampling = e->sampling_on;
         }
         else if (use_graph) {
             TM_HIP_CHECK(hipGraphLaunch(e->graph_cb, e->stream));
@@ -1382,7 +1500,8 @@ int tm_engine_destroy(tm_engine* e)
     if (e->graph_cb) {
         (void)hipGraphExecDestroy(e->graph_cb);
     }
-    for (void* q : {(void*)e->d_active, (void*)e->d_pf_k_len, (void*)e->d_pf_cu_q}) {
+    for (void* q : {(void*)e->d_active, (void*)e->d_pf_k_len, (void*)e->d_pf_cu_q, (void*)e->d_temp, (void*)e->d_topp, (void*)e->d_minp,
+                    (void*)e->d_u, (void*)e->d_topk, (void*)e->d_seed, e->d_sample_ws}) {
         if (q) {
             (void)hipFree(q);
         }

@@ -47,8 +47,9 @@ STATUS_TO_RESPONSE = {
 
 @dataclass
 class GenerationConfig:
-    """Greedy decoding is the only sampling mode of the hot path (the reference forces top_k=1 when
-    do_sample=False: lmdeploy/serve/core/async_engine.py:424-428)."""
+    """Same fields and defaults as the reference (lmdeploy/messages.py:35-205).  do_sample=False is greedy (the
+    reference forces top_k=1 then: lmdeploy/serve/core/async_engine.py:424-428); do_sample=True samples with
+    temperature / top_k / top_p / min_p / random_seed on the GPU (csrc/sampling.hip)."""
     n: int = 1
     max_new_tokens: int = 512
     do_sample: bool = False
@@ -79,13 +80,27 @@ class GenerationConfig:
         assert self.top_k >= 0, 'top_k can not be a negative integer'
         assert self.temperature >= 0 and self.temperature <= 2
         assert 0 <= self.min_p <= 1
-        unsupported = {'do_sample': False, 'n': 1, 'repetition_penalty': 1.0, 'bad_words': None, 'bad_token_ids': None,
+        unsupported = {'n': 1, 'repetition_penalty': 1.0, 'bad_words': None, 'bad_token_ids': None,
                        'logprobs': None, 'response_format': None, 'logits_processors': None, 'output_logits': None,
                        'output_last_hidden_state': None, 'min_new_tokens': None}
+        if self.do_sample and self.temperature == 0:
+            raise ValueError('temperature must be > 0 when do_sample=True')
         for k, default in unsupported.items():
             if getattr(self, k) != default:
                 raise NotImplementedError(f'GenerationConfig.{k}={getattr(self, k)!r}: the MI355X hot path implements '
-                                          f'greedy decoding only')
+                                          f'greedy decoding and temperature / top-k / top-p / min-p sampling only')
+
+
+    def sampling_params(self, index: int = 0):
+        """(temperature, top_k, top_p, min_p, seed) for the engine, or None for greedy.  Every sequence of a call gets
+        its own stream: seed = random_seed (a fresh one if None) + index."""
+        if not self.do_sample or self.top_k == 1:
+            return None
+        if self.random_seed is None:
+            import random
+            self.random_seed = random.getrandbits(62)
+        return (float(self.temperature), int(self.top_k), float(self.top_p), float(self.min_p),
+                (int(self.random_seed) + index) & (2**64 - 1))
 
 
 @dataclass

@@ -131,7 +131,7 @@ class Pipeline:
         pending, out_of_engine = {}, []
         for i, p in enumerate(ids):
             try:
-                pending[self.engine.submit(p, g.max_new_tokens, eos)] = i
+                pending[self.engine.submit(p, g.max_new_tokens, eos, g.sampling_params(i))] = i
             except _ffi.TmError as e:
                 rt = STATUS_TO_RESPONSE.get(e.status, ResponseType.INTERNAL_ENGINE_ERROR)
                 out_of_engine.append(Response('', 0, len(p), 'error', [], index=i, error_code=rt.name, error_message=str(e)))
@@ -162,6 +162,7 @@ class Pipeline:
         for b0 in range(0, len(ids), self.max_batch_size):
             chunk = ids[b0:b0 + self.max_batch_size]
             try:
+                self.engine.set_sampling([g.sampling_params(b0 + i) for i in range(len(chunk))] if g.sampling_params() else None)
                 self.engine.prefill(chunk, max_new_tokens=g.max_new_tokens)
                 done = 1
                 while done < g.max_new_tokens:

@@ -74,6 +74,14 @@ class Engine:
         _ffi.check(self._lib.tm_engine_start(self._h))
 
     # ---- static batch ----------------------------------------------------------------------------
+    def set_sampling(self, params):
+        """Static batch: per-sequence (temperature, top_k, top_p, min_p, seed) tuples for the NEXT prefill; None = greedy."""
+        if not params:
+            _ffi.check(self._lib.tm_engine_set_sampling(self._h, None, 0))
+            return
+        arr = (_ffi.Sampling * len(params))(*[_ffi.Sampling(*(p if p is not None else (1.0, 1, 1.0, 0.0, 0))) for p in params])
+        _ffi.check(self._lib.tm_engine_set_sampling(self._h, arr, len(params)))
+
     def prefill(self, prompts: Sequence[Sequence[int]], max_new_tokens: int):
         lens = np.asarray([len(p) for p in prompts], np.int32)
         ids = np.concatenate([np.asarray(p, np.int32) for p in prompts]).astype(np.int32)
@@ -115,13 +123,14 @@ class Engine:
         return out
 
     # ---- continuous batching (tm_engine_submit / step / poll / cancel) -----------------------------
-    def submit(self, prompt: Sequence[int], max_new_tokens: int, eos_id: int = -1) -> int:
+    def submit(self, prompt: Sequence[int], max_new_tokens: int, eos_id: int = -1, sampling=None) -> int:
         """Queue one request; returns its id.  eos_id < 0 = ignore_eos.  Raises TmError with the reference's status
         code (TM_TOO_LONG, TM_OOM, TM_INVALID) when the request can never run."""
         ids = np.ascontiguousarray(np.asarray(prompt, np.int32))
         rid = C.c_int64(0)
-        _ffi.check(self._lib.tm_engine_submit(self._h, ids.ctypes.data, int(ids.size), int(max_new_tokens), int(eos_id),
-                                              C.byref(rid)))
+        sp = C.byref(_ffi.Sampling(*sampling)) if sampling is not None else None
+        _ffi.check(self._lib.tm_engine_submit_ex(self._h, ids.ctypes.data, int(ids.size), int(max_new_tokens), int(eos_id), sp,
+                                                 C.byref(rid)))
         return rid.value
 
     def step(self):

@@ -189,6 +189,61 @@ def test_pipeline_continuous_generation(cuda):
     pipe.close()
 
 
+def test_engine_sampling_static_and_continuous(cuda):
+    """Stochastic sampling inside the engine: every generated token must be the oracle's draw (sample_filter +
+    sample_draw with the Philox number of (seed, context length)) from the engine's own logits of that step; the same
+    seeds give the same tokens through the static path, the continuous-batching path and a second run."""
+    cfg = o.ModelConfig(hidden=256, layers=2, q_heads=4, kv_heads=2, head_dim=128, inter=512, vocab=1024,
+                        kv_bits=8, rope=o.RopeParam(128, 500000.0, 'llama3', 8.0, 1.0, 4.0, 8192))
+    w = o.make_synthetic_weights(cfg, seed=21)
+    rng = np.random.default_rng(2)
+    prompts = [rng.integers(0, cfg.vocab, n).astype(np.int32) for n in (12, 40, 7)]
+    params = [(0.9, 30, 0.95, 0.0, 111), None, (1.4, 0, 0.8, 0.02, 222)]          # row 1 stays greedy
+    steps = 6
+    eng = Engine.from_model_config(cfg, max_batch_size=3, session_len=128, quant_policy=8)
+    eng.load_weights(export_weights(cfg, w))
+    eng.start()
+
+    def run_static():
+        eng.set_sampling(params)
+        eng.prefill(prompts, max_new_tokens=steps)
+        logits = [eng.fetch_logits()]
+        for _ in range(steps - 1):
+            eng.decode(1)
+            logits.append(eng.fetch_logits())
+        toks = eng.fetch().copy()
+        eng.release()
+        return toks, logits
+
+    toks, logits = run_static()
+    for b, p in enumerate(params):
+        for s_ in range(steps):
+            row = logits[s_][b]
+            if p is None:
+                assert toks[b, s_] == int(np.argmax(row.astype(np.float32)))
+                continue
+            ids, pr = o.sample_filter(row, p[0], p[1], p[2], p[3])
+            u = o.philox_uniform(p[4], len(prompts[b]) + s_)
+            assert toks[b, s_] == o.sample_draw(ids, pr, u), f'seq {b} step {s_}'
+    toks2, _ = run_static()
+    assert np.array_equal(toks, toks2)
+    assert not np.array_equal(toks[0], toks[1])
+    # continuous batching, one request per slot run: same seeds -> same tokens
+    ids = [eng.submit(p_, steps, -1, sp) for p_, sp in zip(prompts, params)]
+    while eng.step() != (0, 0):
+        pass
+    for b, rid in enumerate(ids):
+        st, t = eng.poll(rid)
+        assert st == 7 and np.array_equal(t, toks[b]), f'request {b}: {t} vs {toks[b]}'
+    eng.release()
+    # greedy again after a sampling session
+    eng.prefill(prompts, max_new_tokens=2)
+    eng.decode(1)
+    g = eng.fetch()
+    eng.close()
+    assert g[1, 0] == toks[1, 0]
+
+
 def test_engine_errors_are_status_codes(cuda):
     cfg = o.ModelConfig(hidden=256, layers=1, q_heads=2, kv_heads=1, head_dim=128, inter=256, vocab=512)
     eng = Engine.from_model_config(cfg, max_batch_size=2, session_len=128, quant_policy=8)

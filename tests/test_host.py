@@ -228,8 +228,14 @@ def test_api_surface_and_validation():
             TurbomindEngineConfig(**bad)
     g = GenerationConfig(max_new_tokens=7, ignore_eos=True)
     assert g.top_k == 50 and not g.do_sample
+    assert g.sampling_params() is None                        # do_sample=False is greedy whatever top_k says
+    gs = GenerationConfig(do_sample=True, top_k=40, top_p=0.9, temperature=0.7, random_seed=5)
+    assert gs.sampling_params(3) == (pytest.approx(0.7), 40, pytest.approx(0.9), 0.0, 8)
+    assert GenerationConfig(do_sample=True, top_k=1).sampling_params() is None
     with pytest.raises(NotImplementedError):
-        GenerationConfig(do_sample=True)
+        GenerationConfig(repetition_penalty=1.1)
+    with pytest.raises(ValueError):
+        GenerationConfig(do_sample=True, temperature=0.0)
     import inspect
 
     import lmdeploy_amd
