@@ -994,6 +994,245 @@ __global__ __launch_bounds__(512) void gemm_pingpong_kernel(GemmParams p)
 }
 
 
+// ---------------------------------------------------------------------------------------------------------------
+// Decode kernel with LDS-DMA activation staging (u4 weights, M <= 64): like gemm_kernel<.., NT=1, WN=8, KS=1> but the
+// activations never pass through registers: every wave copies its 1 KiB pieces of the k-block image global -> LDS with
+// `buffer_load_dwordx4 ... lds` (the XOR swizzle is applied on the SOURCE address: lane L loads the chunk that belongs
+// at LDS slot L), three k-blocks ahead, into a ring of four buffers.  No x register ring (-64 VGPRs), no ds_write_b128
+// (16 x 13 LDS cycles per k-block), no x loads queued in front of the weight ring.  The DMA is issued from inline asm:
+// hipcc does not count it, so its own waits for the weight ring only become stricter (never unsafe); the completion of
+// the DMA is waited for with a counted s_waitcnt right before the barrier that publishes the buffer.
+// Fragments are register-resident per k-block and re-filled as soon as a 32-k step is done (as in gemm_decode_kernel).
+template<int MT, int PF>
+__global__ __launch_bounds__(512) void gemm_glds_kernel(GemmParams p)
+{
+    constexpr int MB   = 16 * MT;
+    constexpr int BUFB = MB * 256;       // one k-block of x
+    constexpr int NB   = 4;              // x(i) .. x(i+3) live at the same time
+    constexpr int XB   = BUFB / 1024;    // 1 KiB pieces (4 rows) per k-block image
+    constexpr int XR   = (XB + 7) / 8;   // pieces per wave
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // NB * BUFB
+
+    const int tid  = threadIdx.x;
+    const int wgid = blockIdx.y * gridDim.x + blockIdx.x;
+    if (p.dbg && tid == 0) {
+        p.dbg[wgid * 8 + 0] = __builtin_amdgcn_s_memrealtime();
+        p.dbg[wgid * 8 + 4] = ((uint64_t)__builtin_amdgcn_s_getreg(20 | (31 << 11)) << 32) | (uint32_t)__builtin_amdgcn_s_getreg(4 | (31 << 11));
+    }
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i16  = lane & 15;
+    const int g    = lane >> 4;
+
+    const int ntiles = p.N / 16;
+    const int kb0    = blockIdx.y * p.kb_per_split;
+    const int nkb    = min(p.kb_per_split, p.KB - kb0);
+    const int last   = nkb - 1;
+    const int nit_pad = (nkb + PF - 1) / PF * PF;
+
+    const int  nt_raw = blockIdx.x * 8 + wave;
+    const int  nt     = min(nt_raw, ntiles - 1);
+    const auto rs_w   = __builtin_amdgcn_make_buffer_rsrc((void*)p.wq, 0, (int)((size_t)p.KB * ntiles * 1024), 0x00020000);
+    const auto rs_s   = __builtin_amdgcn_make_buffer_rsrc((void*)p.sz, 0, p.KB * ntiles * 64, 0x00020000);
+    const auto rs_x   = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)(((size_t)(p.M - 1) * p.ldx + p.K) * 2), 0x00020000);
+    const int  woff    = (nt * 64 + lane) * 16;
+    const int  soff    = (nt * 16 + i16) * 4;
+    const int  wstride = ntiles * 1024;
+    const int  sstride = ntiles * 64;
+
+    // my pieces of a k-block image: piece blk = r*8 + wave = rows 4 blk .. 4 blk + 3; lane L lands at LDS slot L of the piece
+    int       xoff[XR];
+    unsigned  xdst[XR];
+    const int my_xr = XB >= 8 ? XR : (wave < XB ? 1 : 0);  // wave-uniform number of DMA pieces per k-block
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)smem);
+#pragma unroll
+    for (int r = 0; r < XR; ++r) {
+        const int blk = min(r * 8 + wave, XB - 1);
+        const int row = blk * 4 + (lane >> 4);
+        const int ci  = (lane & 15) ^ (row & 15);
+        xoff[r]       = (min(row, p.M - 1) * p.ldx + ci * 8) * 2;
+        xdst[r]       = lds0 + blk * 1024;
+    }
+#define TM_GL_DMA(j, buf)                                                                                          \
+    {                                                                                                              \
+        const int kbo_ = (kb0 + min((j), last)) * 256;                                                             \
+        _Pragma("unroll") for (int r = 0; r < XR; ++r)                                                             \
+        {                                                                                                          \
+            if (r < my_xr) {                                                                                       \
+                unsigned keep_;                                                                                    \
+                const unsigned dst_ = xdst[r] + (buf)*BUFB;                                                        \
+                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"                                  \
+                             "buffer_load_dwordx4 %1, %2, %4 offen lds\n\ts_mov_b32 m0, %0"                        \
+                             : "=&s"(keep_)                                                                        \
+                             : "v"(xoff[r]), "s"(rs_x), "s"(dst_), "s"(kbo_)                                       \
+                             : "memory");                                                                          \
+            }                                                                                                      \
+        }                                                                                                          \
+    }
+    // wait until at most `n_younger + my_xr * younger_dma_rounds` of my VMEM operations are outstanding
+#define TM_GL_WAIT(base)                                                                                           \
+    {                                                                                                              \
+        if (my_xr == 2) {                                                                                          \
+            asm volatile("s_waitcnt vmcnt(%0)" ::"i"((base) + 2) : "memory");                                      \
+        }                                                                                                          \
+        else if (my_xr == 1) {                                                                                     \
+            asm volatile("s_waitcnt vmcnt(%0)" ::"i"((base) + 1) : "memory");                                      \
+        }                                                                                                          \
+        else {                                                                                                     \
+            asm volatile("s_waitcnt vmcnt(%0)" ::"i"(base) : "memory");                                            \
+        }                                                                                                          \
+    }
+
+    floatx4 acc[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        acc[mt] = floatx4{0.f, 0.f, 0.f, 0.f};
+    }
+    u32x4    ring[PF];
+    uint32_t sring[PF];
+    uint32_t m1024 = 0x64006400u, m64 = 0x54005400u;
+    asm volatile("" : "+v"(m1024), "+v"(m64));
+
+#define TM_GW_LOAD(slot, i)                                                                              \
+    {                                                                                                    \
+        const int kb_ = kb0 + min((i), last);                                                            \
+        ring[slot]    = __builtin_amdgcn_raw_buffer_load_b128(rs_w, woff, kb_ * wstride, /*nt*/ 2);      \
+        sring[slot]   = __builtin_amdgcn_raw_buffer_load_b32(rs_s, soff, kb_ * sstride, 0);              \
+    }
+    // prologue: x(0..2) first (they are waited for first), then the weight ring
+    TM_GL_DMA(0, 0);
+    TM_GL_DMA(1, 1);
+    TM_GL_DMA(2, 2);
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+        TM_GW_LOAD(u, u);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    asm volatile("s_waitcnt vmcnt(%0)" ::"i"(2 * PF) : "memory");  // everything older than the ring: the three x images
+    int xr[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        xr[s] = i16 * 256 + (((s * 4 + g) ^ i16) << 4);
+    }
+    __syncthreads();
+    if (p.dbg && tid == 0) {
+        p.dbg[wgid * 8 + 1] = __builtin_amdgcn_s_memrealtime();
+        p.dbg[wgid * 8 + 5] = __builtin_amdgcn_s_memtime();
+    }
+    half8_t xf[4][MT];
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            xf[s][mt] = *(const half8_t*)(smem + xr[s] + mt * 4096);
+        }
+    }
+    auto dq = [&](int slot, int j, bool live) -> half8_t {
+        const half2_t pr = bit_cast<half2_t>(live ? sring[slot] : 0u);
+        return dequant8(ring[slot][j], half2_t{pr[0], pr[0]}, half2_t{pr[1], pr[1]}, m1024, m64);
+    };
+    half8_t wfn   = dq(0, 0, true);
+    int     b_cur = 0, b_nxt = BUFB, b_dma = 3 * BUFB;
+    // per-wave phase clocks (s_memtime ticks), only when tracing: barrier wait / compute incl. compiler waits / DMA wait
+    uint64_t t_bar = 0, t_cmp = 0, t_dma = 0;
+    for (int base = 0; base < nit_pad; base += PF) {
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+            const int  i         = base + u;
+            const bool live      = i < nkb;
+            const bool live_next = i + 1 < nkb;
+            const uint64_t c0 = p.dbg ? __builtin_amdgcn_s_memtime() : 0;
+            __syncthreads();  // barrier(i): x(i+1) published, buffer of x(i-1) free
+            const uint64_t c1 = p.dbg ? __builtin_amdgcn_s_memtime() : 0;
+            {
+                const int bufi = b_dma / BUFB;
+                TM_GL_DMA(i + 3, bufi);
+            }
+            const char* cur = smem + b_cur;
+            const char* nxt = smem + b_nxt;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                xf[3][mt] = *(const half8_t*)(cur + xr[3] + mt * 4096);
+            }
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const half8_t wf = wfn;
+                wfn = s < 3 ? dq(u, s + 1, live) : dq((u + 1) % PF, 0, live_next);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf, xf[s][mt], acc[mt], 0, 0, 0);
+                }
+                if (s < 3) {
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) {
+                        xf[s][mt] = *(const half8_t*)(nxt + xr[s] + mt * 4096);
+                    }
+                }
+            }
+            TM_GW_LOAD(u, i + PF);
+            // x(i+2) (DMA of iteration i-1) must have landed before the next barrier publishes it: younger operations of
+            // this wave = refill(i-1) 2 + DMA(i) my_xr + refill(i) 2
+            const uint64_t c2 = p.dbg ? __builtin_amdgcn_s_memtime() : 0;
+            TM_GL_WAIT(4);
+            if (p.dbg) {
+                const uint64_t c3 = __builtin_amdgcn_s_memtime();
+                t_bar += c1 - c0;
+                t_cmp += c2 - c1;
+                t_dma += c3 - c2;
+            }
+            b_cur = b_nxt;
+            b_nxt = b_nxt == 3 * BUFB ? 0 : b_nxt + BUFB;
+            b_dma = b_dma == 3 * BUFB ? 0 : b_dma + BUFB;
+        }
+    }
+#undef TM_GL_DMA
+#undef TM_GL_WAIT
+#undef TM_GW_LOAD
+    if (p.dbg && tid == 0) {
+        p.dbg[wgid * 8 + 2] = __builtin_amdgcn_s_memrealtime();
+        p.dbg[wgid * 8 + 6] = __builtin_amdgcn_s_memtime();
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no DMA may still be in flight when the workgroup's LDS is released
+    if (p.dbg && lane == 0 && (wave == 0 || wave == 5)) {
+        uint64_t* d2 = p.dbg + (size_t)(8192 + wgid * 2 + (wave ? 1 : 0)) * 8;
+        d2[0] = t_bar;
+        d2[1] = t_cmp;
+        d2[2] = t_dma;
+        d2[3] = (uint64_t)nit_pad;
+    }
+
+    if (nt_raw < ntiles) {
+        const int n = nt * 16 + g * 4;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int m = mt * 16 + i16;
+            if (m >= p.M) {
+                continue;
+            }
+            const floatx4 a = acc[mt];
+            if (p.epilogue == 2) {
+                *(floatx4*)(p.partial + ((size_t)blockIdx.y * p.M + m) * p.N + n) = a;
+            }
+            else if (p.epilogue == 1) {
+                const float s0 = a[0] / (1.0f + __builtin_expf(-a[0]));
+                const float s1 = a[2] / (1.0f + __builtin_expf(-a[2]));
+                half2_t     o  = {(half_t)(s0 * a[1]), (half_t)(s1 * a[3])};
+                *(half2_t*)(p.y + (size_t)m * p.ldy + (n >> 1)) = o;
+            }
+            else {
+                half4_t o = {(half_t)a[0], (half_t)a[1], (half_t)a[2], (half_t)a[3]};
+                *(half4_t*)(p.y + (size_t)m * p.ldy + n) = o;
+            }
+        }
+    }
+    if (p.dbg && tid == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        p.dbg[wgid * 8 + 3] = __builtin_amdgcn_s_memrealtime();
+    }
+}
+
+
 // y = h(sum_s partial[s]) (optionally through the gated-SiLU epilogue): 4 columns per thread
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(half_t* __restrict__ y,
                                                             int ldy,
@@ -1188,6 +1427,22 @@ static int launch_pingpong(const GemmParams& p, dim3 grid, hipStream_t st)
     return pf <= 2 ? launch_pingpong_pf<MT, 2>(p, grid, st) : launch_pingpong_pf<MT, 3>(p, grid, st);
 }
 
+template<int MT>
+static int launch_glds(const GemmParams& p, dim3 grid, hipStream_t st)
+{
+    constexpr int PF       = 8;
+    constexpr int lds_need = 4 * 16 * MT * 256;
+    const int     lds      = grid.x * grid.y <= 256 ? 84 * 1024 : lds_need;  // one workgroup per CU (see launch_one)
+    static bool   attr_set = false;
+    if (!attr_set) {
+        TM_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_glds_kernel<MT, PF>, hipFuncAttributeMaxDynamicSharedMemorySize, 84 * 1024));
+        attr_set = true;
+    }
+    gemm_glds_kernel<MT, PF><<<grid, 512, lds, st>>>(p);
+    TM_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
 template<int WT, int MT>
 static int launch_mt(const GemmParams& p, dim3 grid, int nt, int waves, int wk, int ks, hipStream_t st)
 {
@@ -1323,6 +1578,27 @@ int launch_linear(const LinearWeight& w,
     splits     = (KB + p.kb_per_split - 1) / p.kb_per_split;  // no empty splits
     p.epilogue = splits > 1 ? 2 : (gated_silu ? 1 : 0);
 
+    // TM_GEMM_GLDS=1: LDS-DMA activation staging for the decode shape
+    const int gl = env_int("TM_GEMM_GLDS", 0);
+    if (gl && w.type == 0 && M <= 64 && waves == 8 && wk == 1 && nt == 1) {
+        p.kb_per_split = (KB + splits - 1) / splits;
+        splits         = (KB + p.kb_per_split - 1) / p.kb_per_split;
+        p.epilogue     = splits > 1 ? 2 : (gated_silu ? 1 : 0);
+        dim3 grid((w.N / 16 + 7) / 8, splits, 1);
+        const int rc4 = mt == 1 ? launch_glds<1>(p, grid, st) : mt == 2 ? launch_glds<2>(p, grid, st) : launch_glds<4>(p, grid, st);
+        if (rc4) {
+            return rc4;
+        }
+        if (splits > 1 && !defer_reduce) {
+            const size_t total = (size_t)M * w.N / 4;
+            splitk_reduce_kernel<<<(total + 255) / 256, 256, 0, st>>>(y, ldy, workspace, splits, M, w.N, gated_silu ? 1 : 0);
+            TM_HIP_CHECK(hipGetLastError());
+        }
+        if (slabs) {
+            *slabs = splits;
+        }
+        return 0;
+    }
     // TM_GEMM_PP=1: ping-pong kernel for the decode shape (two wave groups in opposite phases, K split between them)
     const int pp = env_int("TM_GEMM_PP", 0);
     if (pp && w.type == 0 && M <= 64 && waves == 8 && KB % 2 == 0) {

@@ -25,7 +25,7 @@ def main():
     y = torch.empty((M, N), device='cuda').half()
     ws = torch.empty(max(1, tm.tm_linear_workspace(h, M)), dtype=torch.uint8, device='cuda')
     flush = torch.empty(512 << 20, dtype=torch.uint8, device='cuda')
-    dbg = torch.zeros((8192, 8), dtype=torch.int64, device='cuda')
+    dbg = torch.zeros((8192 * 4, 8), dtype=torch.int64, device='cuda')
     ratios = []
     for it in range(int(os.environ.get('TRACE_LAUNCHES', '24'))):
         flush.fill_(it)
@@ -36,7 +36,14 @@ def main():
                                         waves, ws.data_ptr(), st))
         tm.tm_debug_set_gemm_trace(None)
         torch.cuda.synchronize()
-        raw = dbg.cpu().numpy()
+        raw_all = dbg.cpu().numpy()
+        raw = raw_all[:8192]
+        ph = raw_all[8192:]
+        ph = ph[ph[:, 3] > 0].astype(np.float64)
+        if len(ph):
+            per = ph[:, :3] / ph[:, 3:4]
+            print(f'  per-iteration cycles (mean over {len(ph)} traced waves): barrier {per[:,0].mean():.0f}  compute+compiler waits {per[:,1].mean():.0f}  '
+                  f'DMA wait {per[:,2].mean():.0f}  (max barrier {per[:,0].max():.0f}, max compute {per[:,1].max():.0f})')
         ids = np.nonzero(raw[:, 0] > 0)[0]
         hw = raw[ids, 4]
         tt = raw[ids, :4].astype(np.float64) / 100.0
@@ -53,7 +60,7 @@ def main():
               f'(max {cnt.max()} WGs on one CU); slowest (id xcc:hwid loop_us sharing): ' +
               '  '.join(f'{ids[i]} {xcc[i]}:{hwid[i] & 0xffff:04x} {loop[i]:.1f} x{cnt[np.searchsorted(uniq, cu_key[i])]}' for i in order))
     print('loop max/median over launches: ' + ' '.join(f'{r:.2f}' for r in ratios))
-    t = dbg.cpu().numpy()[:, :4]
+    t = dbg.cpu().numpy()[:8192, :4]
     t = t[t[:, 0] > 0].astype(np.float64) / 100.0      # us
     t0 = t[:, 0].min()
     t -= t0
