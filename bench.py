@@ -26,6 +26,10 @@ sys.path.insert(0, ROOT)
 
 LLAMA3_8B = dict(hidden=4096, layers=32, q_heads=32, kv_heads=8, head_dim=128, inter=14336, vocab=128256,
                  rms_eps=1e-5)
+# BASELINE.json configs 3 / 4 (parity-test cases; `--model` lets the same harness time them)
+INTERNLM2_20B = dict(hidden=6144, layers=48, q_heads=48, kv_heads=8, head_dim=128, inter=16384, vocab=92544, rms_eps=1e-5)
+LLAMA3_70B = dict(hidden=8192, layers=80, q_heads=64, kv_heads=8, head_dim=128, inter=28672, vocab=128256, rms_eps=1e-5)
+MODELS = {'llama3_8b': LLAMA3_8B, 'internlm2_20b': INTERNLM2_20B, 'llama3_70b': LLAMA3_70B}
 HBM_PEAK_GBPS = 8000.0     # MI355X HBM3E spec (/opt/skills/guides/MI355X_MICROARCH.md); 6290 measured copy
 
 
@@ -63,6 +67,8 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-graph', action='store_true', help='eager launches (rocprofv3 --pmc passes)')
     ap.add_argument('--layers', type=int, default=0, help='debug only: override the layer count (result is then INVALID)')
+    ap.add_argument('--model', default='llama3_8b', choices=['llama3_8b', 'internlm2_20b', 'llama3_70b'],
+                    help='shapes to time; the headline metric is llama3_8b (anything else changes metric/config in the output)')
     ap.add_argument('--emulate-tp', type=int, default=0,
                     help='SURVEY 8(e) on a 1-GPU box: run ONE rank\'s shard of a TP=N job (heads / inter / vocab divided by N, '
                          'collectives through a 1-rank RCCL communicator): per-rank kernel time only, labelled as such')
@@ -81,7 +87,7 @@ def main():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group('gloo', rank=rank, world_size=world)   # control plane only; data plane = RCCL in C++
 
-    model = dict(LLAMA3_8B)
+    model = dict(MODELS[args.model])
     if args.layers:
         model['layers'] = args.layers
     emu = args.emulate_tp
@@ -161,6 +167,9 @@ def main():
                               'achieved': round(step_bytes / (dt / K) / 1e9, 1), 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
                               'frac': round(step_bytes / (dt / K) / 1e9 / HBM_PEAK_GBPS, 4)},
         }
+        if args.model != 'llama3_8b':
+            out['metric'] = f'decode tokens/sec, {args.model} W4A16 quant_policy={args.quant_policy} batch {B} (NOT the headline config)'
+            out['config']['workload'] = out['config']['workload'].replace('Llama-3-8B', args.model)
         if emu > 1:
             out['metric'] = (f'PER-RANK EMULATION of TP={emu} on one GPU (one rank\'s shard, 1-rank collectives): '
                              'decode tokens/sec of the rank-local kernels only -- not a multi-GPU result')
@@ -174,7 +183,7 @@ def main():
             # profiles/r01_attention_traffic.json; separate PMC run, scaled to this run's context length)
             traffic, traffic_src = None, None
             tj = os.path.join(ROOT, 'profiles', 'r01_attention_traffic.json')
-            if args.quant_policy == 8 and world == 1 and os.path.exists(tj):
+            if args.quant_policy == 8 and world == 1 and emu <= 1 and args.model == 'llama3_8b' and os.path.exists(tj):
                 with open(tj) as f:
                     t = json.load(f)
                 traffic = int(t['traffic_over_algorithmic'] * per_launch_bytes)

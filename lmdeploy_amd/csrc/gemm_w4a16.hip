@@ -1292,7 +1292,7 @@ GemmConfig gemm_pick_config(const LinearWeight& w, int M)
         cfg.waves  = 4;
         cfg.splits = 1;
     }
-    else if (mblk > 1) {  // prefill: plenty of row blocks, maximise weight reuse per workgroup
+    else if (mblk > 1 && M > 256) {  // prefill: plenty of row blocks, maximise weight reuse per workgroup
         static const int pw = env_int("TM_GEMM_PREFILL_WAVES", 8);
         cfg.nt     = pw == 8 ? 2 : 4;
         cfg.waves  = pw == 8 ? 8 : 4;
@@ -1300,9 +1300,11 @@ GemmConfig gemm_pick_config(const LinearWeight& w, int M)
     }
     else {
         // split-K only until ~256 workgroups exist and never below 8 k-blocks per slice (slab traffic + reduce)
+        // (64 < M <= 256, e.g. decode at batch 128: still weight-streaming bound -- 64-row blocks on grid.z, each block
+        // re-reads the weights through L2 / the Infinity Cache, and the workgroup count includes the row blocks)
         cfg.waves = 8;
         cfg.nt    = 1;
-        const int col_wgs = (ntiles + cfg.waves * cfg.nt - 1) / (cfg.waves * cfg.nt);
+        const int col_wgs = (ntiles + cfg.waves * cfg.nt - 1) / (cfg.waves * cfg.nt) * mblk;
         int       splits  = 1;
         static const int min_kb = env_int("TM_GEMM_MIN_KB", 8);
         while (col_wgs * splits * 2 <= 256 && KB / (splits * 2) >= min_kb && splits < 16) {

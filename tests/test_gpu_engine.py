@@ -244,6 +244,38 @@ def test_engine_sampling_static_and_continuous(cuda):
     assert g[1, 0] == toks[1, 0]
 
 
+@pytest.mark.parametrize('q_heads,kv_heads,kv_bits,hidden', [(6, 1, 8, 384), (8, 1, 4, 512), (12, 2, 16, 256)])
+def test_engine_other_config_shapes(cuda, q_heads, kv_heads, kv_bits, hidden):
+    """BASELINE.json configs 2-4 scaled down: GQA group 6 with int8 KV (InternLM2-20B: 48 q / 8 kv heads), one kv head
+    per rank with group 8 and int4 KV (Llama-3-70B at TP = 8), group 6 with fp16 KV; hidden != q_heads * head_dim as in
+    a TP shard.  Same bar as test_engine_matches_oracle."""
+    cfg = o.ModelConfig(hidden=hidden, layers=2, q_heads=q_heads, kv_heads=kv_heads, head_dim=128, inter=384, vocab=512,
+                        kv_bits=kv_bits, rope=o.RopeParam(128, 1000000.0, 'default', 1.0, 1.0, 4.0, 8192))
+    w = o.make_synthetic_weights(cfg, seed=q_heads)
+    rng = np.random.default_rng(q_heads)
+    prompts = [rng.integers(0, cfg.vocab, n).astype(np.int32) for n in (66, 3)]
+    steps = 4
+    eng = Engine.from_model_config(cfg, max_batch_size=2, session_len=128, quant_policy=0 if kv_bits == 16 else kv_bits)
+    eng.load_weights(export_weights(cfg, w))
+    eng.start()
+    eng.prefill(prompts, max_new_tokens=steps + 1)
+    logits = [eng.fetch_logits()]
+    for _ in range(steps):
+        eng.decode(1)
+        logits.append(eng.fetch_logits())
+    toks = eng.fetch()
+    eng.close()
+    om = o.OracleModel(cfg, w, batch=len(prompts), max_ctx=128)
+    ids, lg = om.forward(prompts)
+    ref = [lg]
+    for s_ in range(steps):
+        ids, lg = om.forward([[int(t)] for t in toks[:, s_]])
+        ref.append(lg)
+    for s_ in range(steps + 1):
+        d = np.abs(logits[s_].astype(np.float32) - ref[s_].astype(np.float32))
+        assert d.max() <= 3e-2, f'step {s_}: max logit diff {d.max()}'
+
+
 def test_engine_errors_are_status_codes(cuda):
     cfg = o.ModelConfig(hidden=256, layers=1, q_heads=2, kv_heads=1, head_dim=128, inter=256, vocab=512)
     eng = Engine.from_model_config(cfg, max_batch_size=2, session_len=128, quant_policy=8)

@@ -424,11 +424,15 @@ def test_w4a16_linear(tm, cuda, K, N, M):
 
 
 @pytest.mark.parametrize('K,N,M,gated', [(4096, 6144, 64, 0), (1792, 4096, 33, 0), (384, 48, 3, 0), (4096, 1024, 64, 1), (1024, 2048, 17, 1)])
-@pytest.mark.parametrize('nprod', [1, 4])
-def test_w4a16_producer_consumer_kernel(tm, cuda, monkeypatch, K, N, M, gated, nprod):
-    """The producer/consumer decode kernel (TM_GEMM_V2=1, the A/B arm of DESIGN.md) against the same oracle."""
-    monkeypatch.setenv('TM_GEMM_V2', '1')
-    monkeypatch.setenv('TM_GEMM_NPROD', str(nprod))
+@pytest.mark.parametrize('arm', ['V2:1', 'V2:4', 'PP', 'GLDS'])
+def test_w4a16_alternative_decode_kernels(tm, cuda, monkeypatch, K, N, M, gated, arm):
+    """The A/B arms of DESIGN.md 3.1 -- producer/consumer waves (TM_GEMM_V2, 1 or 4 producers), ping-pong wave groups
+    (TM_GEMM_PP), LDS-DMA activation staging (TM_GEMM_GLDS) -- against the same oracle as the default kernel."""
+    if arm.startswith('V2'):
+        monkeypatch.setenv('TM_GEMM_V2', '1')
+        monkeypatch.setenv('TM_GEMM_NPROD', arm.split(':')[1])
+    else:
+        monkeypatch.setenv('TM_GEMM_' + arm, '1')
     rng = np.random.default_rng(K + N + M + 7)
     h, (q, s, z) = _make_linear(tm, rng, K, N)
     x = rng.standard_normal((M, K)).astype(f16)
