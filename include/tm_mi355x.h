@@ -99,7 +99,7 @@ int    tm_decode_attention(void* out, const void* q, int q_stride, const int* k_
                            float softmax_scale, int splits, void* workspace, const tm_kv_cache* cache,
                            tm_stream_t st);
 /* Decode attention with the reference decode kernel's fused prologue (attention_universal.h:168-330: the decode
- * kernel itself applies RoPE to q/k and quantises + stores the new K/V).  int8 KV only.  Input is the raw QKV
+ * kernel itself applies RoPE to q/k and quantises + stores the new K/V).  int8 / int4 KV.  Input is the raw QKV
  * projection of the new token of every sequence: qkv_splits == 0 -> `qkv` is fp16 [batch][qkv_n]; qkv_splits >= 1
  * -> `qkv` is fp32 split-K slabs [qkv_splits][batch][qkv_n] which are summed in order and rounded to fp16 first.
  * Row layout [Q heads | K heads | V heads] x 128.  k_len INCLUDES the new token.  Cache bytes/params written are

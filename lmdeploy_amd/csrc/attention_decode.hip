@@ -407,7 +407,7 @@ int launch_decode_attention(const DecodeAttnParams& p, hipStream_t st)
         return 0;
     }
     const bool fused = p.qkv_slabs || p.qkv_f16;
-    TM_REQUIRE(!fused || L.bits == 8, "fused decode prologue: int8 KV only");
+    TM_REQUIRE(!fused || L.bits == 8 || L.bits == 4, "fused decode prologue: int8 / int4 KV only");
     switch (L.bits) {
         case 16:
             return launch_bits<16>(p, st);
@@ -430,8 +430,24 @@ int launch_decode_attention(const DecodeAttnParams& p, hipStream_t st)
             }
             return 0;
         }
-        case 4:
-            return launch_bits<4>(p, st);
+        case 4: {
+            // int4 KV: the same MFMA kernel, nibbles expanded to bytes on the way into LDS (TM_ATTN_VALU=1: VALU kernel)
+            static const bool valu4 = getenv("TM_ATTN_VALU") && atoi(getenv("TM_ATTN_VALU")) != 0;
+            if (valu4 && !fused) {
+                return launch_bits<4>(p, st);
+            }
+            DecodeAttnParams pt = p;
+            pt.dbg              = g_gemm_dbg;
+            int rc = launch_decode_attention_i8_mfma(pt, st);
+            if (rc) {
+                return rc;
+            }
+            if (p.splits > 1) {
+                decode_reduce_kernel<<<dim3(p.q_heads, p.batch), 128, 0, st>>>(p);
+                TM_HIP_CHECK(hipGetLastError());
+            }
+            return 0;
+        }
     }
     TM_REQUIRE(false, "kv bits in {16,8,4}");
 }

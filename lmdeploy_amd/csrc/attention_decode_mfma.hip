@@ -116,9 +116,30 @@ __device__ __forceinline__ half8_t rope8(half8_t x, half8_t cs)
     return x;
 }
 
-template<bool FUSED>
+// 32 int4 codes (16 bytes, 4 words of 8 nibbles in the cache's order [0,2,4,6,1,3,5,7], quantization.h:459-471) -> 32
+// bytes in element order: lo / hi nibbles of a word are the elements (0,4,1,5) / (2,6,3,7)
+__device__ __forceinline__ void expand_u4x32(u32x4 w, u32x4& a, u32x4& b)
+{
+    uint32_t o[8];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const uint32_t lo = w[j] & 0x0f0f0f0fu;
+        const uint32_t hi = (w[j] >> 4) & 0x0f0f0f0fu;
+        // v_perm_b32(hi, lo, sel): selector bytes 0-3 pick from lo, 4-7 from hi
+        o[2 * j]     = __builtin_amdgcn_perm(hi, lo, 0x06040200u);  // (e0, e1, e2, e3) = (lo.b0, lo.b2, hi.b0, hi.b2)
+        o[2 * j + 1] = __builtin_amdgcn_perm(hi, lo, 0x07050301u);  // (e4, e5, e6, e7) = (lo.b1, lo.b3, hi.b1, hi.b3)
+    }
+    a = u32x4{o[0], o[1], o[2], o[3]};
+    b = u32x4{o[4], o[5], o[6], o[7]};
+}
+
+// BITS = 8: the cache bytes are the codes.  BITS = 4: the block is half as large in HBM; the nibbles are expanded to
+// one byte per code when the block is written to the wave's LDS image, everything after that is the int8 path
+// (scales / zeros are per token either way, quantization.h:316-366).
+template<bool FUSED, int BITS>
 __global__ __launch_bounds__(256, 2) void decode_attention_i8_mfma_kernel(DecodeAttnParams p, int head_chunks, int hpw)
 {
+    static_assert(BITS == 8 || BITS == 4, "int8 / int4 KV");
     constexpr int D = 128;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const KvLayout L = p.cache.layout;
@@ -179,13 +200,15 @@ __global__ __launch_bounds__(256, 2) void decode_attention_i8_mfma_kernel(Decode
     const int       kpoff  = L.k_param(kv_head, 0);
     const int       vpoff  = L.v_param(kv_head, 0);
 
-    u32x4    kreg[8], vreg[8];
+    constexpr int NR = BITS == 8 ? 8 : 4;  // 16-byte loads per lane per K (V) block
+    u32x4    kreg[NR], vreg[NR];
     uint32_t kpr = 0, vpr = 0;
     auto load_tile = [&](int tile) {
         const char* base = (const char*)blocks[tile] + p.cache.layer_offset;
 #pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            const int off = ((lane >> 3) + 8 * r) * 128 + (lane & 7) * 16;
+        for (int r = 0; r < NR; ++r) {
+            // int8: token (lane/8 + 8r), 16-byte chunk lane%8 of its 128 bytes; int4: token (lane/4 + 16r), chunk lane%4 of 64
+            const int off = BITS == 8 ? ((lane >> 3) + 8 * r) * 128 + (lane & 7) * 16 : ((lane >> 2) + 16 * r) * 64 + (lane & 3) * 16;
             kreg[r]       = *(const u32x4*)(base + koff + off);
             vreg[r]       = *(const u32x4*)(base + voff + off);
         }
@@ -194,11 +217,26 @@ __global__ __launch_bounds__(256, 2) void decode_attention_i8_mfma_kernel(Decode
     };
     auto store_tile = [&]() {
 #pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            const int t   = (lane >> 3) + 8 * r;
-            const int pos = t * 128 + (((lane & 7) ^ ((t >> 1) & 7)) << 4);
-            *(u32x4*)(Kt + pos) = kreg[r];
-            *(u32x4*)(Vt + pos) = vreg[r];
+        for (int r = 0; r < NR; ++r) {
+            if constexpr (BITS == 8) {
+                const int t   = (lane >> 3) + 8 * r;
+                const int pos = t * 128 + (((lane & 7) ^ ((t >> 1) & 7)) << 4);
+                *(u32x4*)(Kt + pos) = kreg[r];
+                *(u32x4*)(Vt + pos) = vreg[r];
+            }
+            else {
+                // 32 nibbles -> the two 16-byte chunks 2c, 2c+1 of the token's 128-byte image row
+                const int t  = (lane >> 2) + 16 * r;
+                const int c  = (lane & 3) * 2;
+                const int sw = (t >> 1) & 7;
+                u32x4     a, b;
+                expand_u4x32(kreg[r], a, b);
+                *(u32x4*)(Kt + t * 128 + ((c ^ sw) << 4))       = a;
+                *(u32x4*)(Kt + t * 128 + (((c + 1) ^ sw) << 4)) = b;
+                expand_u4x32(vreg[r], a, b);
+                *(u32x4*)(Vt + t * 128 + ((c ^ sw) << 4))       = a;
+                *(u32x4*)(Vt + t * 128 + (((c + 1) ^ sw) << 4)) = b;
+            }
         }
         *(u32x2*)(Pm + lane * 8) = u32x2{kpr, vpr};
     };
@@ -263,7 +301,7 @@ __global__ __launch_bounds__(256, 2) void decode_attention_i8_mfma_kernel(Decode
             mnn = fmaxf(mnn, dpp_f32<DPP_HMIRR>(mnn));
             mnn = fmaxf(mnn, dpp_f32<DPP_ROR8>(mnn));
             const float  mn    = -mnn;
-            const half_t scale = (half_t)((mx - mn) * (1.0f / 255.0f));
+            const half_t scale = (half_t)((mx - mn) * (1.0f / (float)((1 << BITS) - 1)));
             const half_t zero  = (half_t)mn;
             const half_t inv   = (half_t)(1.0f / (float)scale);
             uint32_t     qv[8];
@@ -273,7 +311,7 @@ __global__ __launch_bounds__(256, 2) void decode_attention_i8_mfma_kernel(Decode
                 const half_t y = d * inv;
                 float        r = __builtin_rintf((float)y);
                 r              = (r == r) ? r : 0.0f;
-                r              = fminf(fmaxf(r, 0.0f), 255.0f);
+                r              = fminf(fmaxf(r, 0.0f), BITS == 8 ? 255.0f : 15.0f);
                 qv[e]          = (uint32_t)r;
             }
             nq[0] = qv[0] | (qv[1] << 8) | (qv[2] << 16) | (qv[3] << 24);
@@ -281,7 +319,14 @@ __global__ __launch_bounds__(256, 2) void decode_attention_i8_mfma_kernel(Decode
             npar  = bit_cast<uint32_t>(half2_t{scale, zero});
             if (lane < 32) {
                 char* blk = (char*)blocks[(ctx - 1) >> 6] + p.cache.layer_offset;
-                *(u32x2*)(blk + (isv ? L.v_data(kv_head, nti) : L.k_data(kv_head, nti)) + l16 * 8) = nq;
+                if constexpr (BITS == 8) {
+                    *(u32x2*)(blk + (isv ? L.v_data(kv_head, nti) : L.k_data(kv_head, nti)) + l16 * 8) = nq;
+                }
+                else {  // nibble i of the word = element [0,2,4,6,1,3,5,7][i] (quantization.h:459-471)
+                    const uint32_t w4 = qv[0] | (qv[2] << 4) | (qv[4] << 8) | (qv[6] << 12) | (qv[1] << 16) | (qv[3] << 20)
+                                        | (qv[5] << 24) | (qv[7] << 28);
+                    *(uint32_t*)(blk + (isv ? L.v_data(kv_head, nti) : L.k_data(kv_head, nti)) + l16 * 4) = w4;
+                }
                 if (l16 == 0) {
                     *(uint32_t*)(blk + (isv ? L.v_param(kv_head, nti) : L.k_param(kv_head, nti))) = npar;
                 }
@@ -530,18 +575,32 @@ int launch_decode_attention_i8_mfma(const DecodeAttnParams& p, hipStream_t st)
     const int lds = 4 * kWaveLds + 4096;
     static bool attr_set = false;
     if (!attr_set) {
-        TM_HIP_CHECK(hipFuncSetAttribute((const void*)decode_attention_i8_mfma_kernel<false>,
+        TM_HIP_CHECK(hipFuncSetAttribute((const void*)decode_attention_i8_mfma_kernel<false, 8>,
                                          hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        TM_HIP_CHECK(hipFuncSetAttribute((const void*)decode_attention_i8_mfma_kernel<true>,
+        TM_HIP_CHECK(hipFuncSetAttribute((const void*)decode_attention_i8_mfma_kernel<true, 8>,
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        TM_HIP_CHECK(hipFuncSetAttribute((const void*)decode_attention_i8_mfma_kernel<false, 4>,
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        TM_HIP_CHECK(hipFuncSetAttribute((const void*)decode_attention_i8_mfma_kernel<true, 4>,
                                          hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         attr_set = true;
     }
     if (p.qkv_slabs || p.qkv_f16) {
         TM_REQUIRE(p.qkv_n % 8 == 0 && (p.qkv_splits == 0) == (p.qkv_slabs == nullptr), "fused qkv input");
-        decode_attention_i8_mfma_kernel<true><<<grid, 256, lds, st>>>(p, chunks, hpw);
+        if (p.cache.layout.bits == 4) {
+            decode_attention_i8_mfma_kernel<true, 4><<<grid, 256, lds, st>>>(p, chunks, hpw);
+        }
+        else {
+            decode_attention_i8_mfma_kernel<true, 8><<<grid, 256, lds, st>>>(p, chunks, hpw);
+        }
     }
     else {
-        decode_attention_i8_mfma_kernel<false><<<grid, 256, lds, st>>>(p, chunks, hpw);
+        if (p.cache.layout.bits == 4) {
+            decode_attention_i8_mfma_kernel<false, 4><<<grid, 256, lds, st>>>(p, chunks, hpw);
+        }
+        else {
+            decode_attention_i8_mfma_kernel<false, 8><<<grid, 256, lds, st>>>(p, chunks, hpw);
+        }
     }
     TM_HIP_CHECK(hipGetLastError());
     return 0;

@@ -169,7 +169,7 @@ int tm_decode_attention_fused(void* out, const void* qkv, int qkv_splits, int qk
                               void* workspace, const tm_kv_cache* cache, tm_stream_t st)
 {
     TM_REQUIRE(out && qkv && k_len && cache, "null pointer");
-    TM_REQUIRE(cache->bits == 8, "fused decode prologue: int8 KV only");
+    TM_REQUIRE(cache->bits == 8 || cache->bits == 4, "fused decode prologue: int8 / int4 KV only");
     TM_REQUIRE(qkv_n == (q_heads + 2 * cache->kv_heads) * 128, "qkv_n != (q_heads + 2 kv_heads) * 128");
     DecodeAttnParams p{};
     p.out        = (half_t*)out;

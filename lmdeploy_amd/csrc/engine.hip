@@ -892,7 +892,7 @@ static void setup_decode(tm_engine* e, int batch)
     e->decode_splits = std::min(std::max(splits, 1), 16);
     const char* valu = getenv("TM_ATTN_VALU");
     const char* fuse = getenv("TM_FUSE_QKV");
-    e->fuse_qkv      = e->cfg.quant_policy == 8 && !(valu && atoi(valu)) && !(fuse && !atoi(fuse));
+    e->fuse_qkv      = (e->cfg.quant_policy == 8 || e->cfg.quant_policy == 4) && !(valu && atoi(valu)) && !(fuse && !atoi(fuse));
 }
 
 // Chunked prefill of `batch` sequences into the batch slots [slot0, slot0 + batch): whole sequences,

@@ -1008,11 +1008,11 @@ __global__ __launch_bounds__(512) void gemm_glds_kernel(GemmParams p)
 {
     constexpr int MB   = 16 * MT;
     constexpr int BUFB = MB * 256;       // one k-block of x
-    constexpr int NB   = 4;              // x(i) .. x(i+3) live at the same time
+    // four buffers: x(i) .. x(i+3) live at the same time
     constexpr int XB   = BUFB / 1024;    // 1 KiB pieces (4 rows) per k-block image
     constexpr int XR   = (XB + 7) / 8;   // pieces per wave
 
-    extern __shared__ __attribute__((aligned(16))) char smem[];  // NB * BUFB
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // 4 * BUFB
 
     const int tid  = threadIdx.x;
     const int wgid = blockIdx.y * gridDim.x + blockIdx.x;

@@ -257,13 +257,14 @@ def test_decode_attention(tm, cuda, bits, Hq, Hkv, klen, splits):
     (8, 2, [1, 64, 65, 300], 1, 0, True), (8, 2, [1, 64, 65, 300], 3, 2, True), (32, 8, [1000, 37, 128, 129], 2, 4, True),
     (6, 1, [129, 5], 1, 1, False), (8, 1, [257], 4, 0, True), (12, 4, [513, 64], 16, 3, True), (64, 8, [77, 192], 2, 0, True),
 ])
-def test_decode_attention_fused_prologue(tm, cuda, Hq, Hkv, klen, splits, qkv_splits, rope):
+@pytest.mark.parametrize('bits', [8, 4])
+def test_decode_attention_fused_prologue(tm, cuda, bits, Hq, Hkv, klen, splits, qkv_splits, rope):
     """Fused decode prologue (RoPE + K/V quantise-store inside the attention kernel) == kv_rope_store followed by
     decode attention: cache bytes bit-exact against the oracle's process_kv, output bit-identical to the unfused
     device sequence (same q bits, same cache bits, same kernel arithmetic)."""
     rng = np.random.default_rng(Hq + sum(klen) + splits + qkv_splits)
     layer = 1
-    L = o.BlockLayout(2, Hkv, 128, 64, 8)
+    L = o.BlockLayout(2, Hkv, 128, 64, bits)
     B = len(klen)
     hist = [k - 1 for k in klen]
     # history (klen-1 tokens) through the oracle; the new token goes through the device paths
