@@ -133,11 +133,14 @@ int tm_silu_mul(void* out, const void* gate_up, int M, int inter, tm_stream_t st
 
 /* ---- Linear (mirrors _tm.LinearWeight / LlamaLinear.forward_dense / QuantizeGroupwise) -------- */
 typedef struct tm_linear tm_linear;
-enum { TM_WEIGHT_U4 = 0, TM_WEIGHT_F16 = 1 };
+enum { TM_WEIGHT_U4 = 0, TM_WEIGHT_F16 = 1, TM_WEIGHT_FP8 = 2 };
 int tm_linear_create(tm_linear** out, int in_features, int out_features, int weight_type, int group_size);
 /* Boundary ("TM") layout, device pointers: qweight int32 [K][N/8] (nibble j of word c = column 8c+j,
  * lmdeploy/turbomind/weight_format.py:63-74), scales / zeros fp16 [K/g][N].  For TM_WEIGHT_F16: weight fp16
- * [K][N], scales = zeros = NULL.  Performs LinearWeight::prepare (repack to MFMA-fragment order, fuse (s,-z*s)). */
+ * [K][N], scales = zeros = NULL.  For TM_WEIGHT_FP8 (lmdeploy/turbomind/weight_format.py:349-393): weight = e4m3 bytes
+ * [K][N], scales = fp32 128x128 block scales [K/128][ceil(N/128)] (`weight_scale_inv`, transposed like the weight),
+ * zeros = NULL; w = fp16(e4m3) * fp16(scale), one rounding (the pre-sm90 weight-only path, linear_weight.cc:138-150).
+ * Performs LinearWeight::prepare (repack to MFMA-fragment order, fuse (s,-z*s)). */
 int tm_linear_prepare(tm_linear* w, const void* weight, const void* scales, const void* zeros, tm_stream_t st);
 /* y fp16 [M][N] (or [M][N/2] when gated_silu: columns interleaved (gate_j, up_j), epilogue.h:159-176).
  * nt / splits / waves: 0 = heuristic.  waves per workgroup: 4 or 8; waves | 0x100 additionally splits K two ways

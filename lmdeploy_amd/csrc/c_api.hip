@@ -236,7 +236,7 @@ int tm_silu_mul(void* out, const void* gate_up, int M, int inter, tm_stream_t st
 int tm_linear_create(tm_linear** out, int in_features, int out_features, int weight_type, int group_size)
 {
     TM_REQUIRE(out, "null pointer");
-    TM_REQUIRE(weight_type == TM_WEIGHT_U4 || weight_type == TM_WEIGHT_F16, "weight_type");
+    TM_REQUIRE(weight_type == TM_WEIGHT_U4 || weight_type == TM_WEIGHT_F16 || weight_type == TM_WEIGHT_FP8, "weight_type");
     TM_REQUIRE(in_features > 0 && out_features > 0, "shape");
     auto* l     = new tm_linear();
     l->w.K      = in_features;
@@ -254,6 +254,10 @@ int tm_linear_prepare(tm_linear* w, const void* weight, const void* scales, cons
         TM_REQUIRE(scales && zeros, "u4 weights need scales and zeros");
         return linear_weight_prepare_u4(w->w, (const int32_t*)weight, (const half_t*)scales, (const half_t*)zeros,
                                         (hipStream_t)st);
+    }
+    if (w->w.type == TM_WEIGHT_FP8) {
+        TM_REQUIRE(scales, "fp8 weights need their 128x128 block scales");
+        return linear_weight_prepare_fp8(w->w, (const uint8_t*)weight, (const float*)scales, (hipStream_t)st);
     }
     return linear_weight_prepare_f16(w->w, (const half_t*)weight, (hipStream_t)st);
 }

@@ -108,6 +108,50 @@ __global__ void repack_f16_kernel(half_t* __restrict__ out, const half_t* __rest
     *(half8_t*)(out + idx * 8) = o;
 }
 
+// fp8 (e4m3) weights [K][N] -> tiles [kb][nt][v = 0..1][64 lanes][16 B]: lane l holds column 16 nt + (l & 15) and, in
+// u32 (j & 1) * 2 .. + 1 of vector v = j >> 1, the 8 bytes k = 128 kb + 32 j + 8 (l >> 4) + 0..7 of 32-k step j
+__global__ void repack_fp8_kernel(uint8_t* __restrict__ out, const uint8_t* __restrict__ w, int K, int N)
+{
+    // one thread per 16 output bytes: idx = ((kb*NTILES + nt)*2 + v)*64 + lane
+    const size_t idx   = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t total = (size_t)K * N / 16;
+    if (idx >= total) {
+        return;
+    }
+    const int    lane = idx & 63;
+    const int    v    = (idx >> 6) & 1;
+    const size_t tile = idx >> 7;
+    const int    nt   = tile % (N / 16);
+    const int    kb   = (int)(tile / (N / 16));
+    const int    n    = nt * 16 + (lane & 15);
+    uint8_t      o[16];
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+        const int k0 = kb * 128 + (2 * v + jj) * 32 + (lane >> 4) * 8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            o[jj * 8 + e] = w[(size_t)(k0 + e) * N + n];
+        }
+    }
+    *(u32x4*)(out + idx * 16) = *(const u32x4*)o;
+}
+
+// 128 x 128 block scales (fp32 [K/128][N/128]) -> per-column group scales in the (s, 0) half2 slots of the u4 path:
+// the reference expands each block scale over its 128 output channels and casts it to the activation type
+// (BlockscaleToGroupscale, models/linear_weight.cc:138-150); w = h(f16(e4m3) * s) needs no zero point.
+__global__ void repack_sz_fp8_kernel(uint32_t* __restrict__ out, const float* __restrict__ block_scales, int KB, int N)
+{
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)KB * N) {
+        return;
+    }
+    const int     kb = (int)(idx / N);
+    const int     n  = (int)(idx % N);
+    const half_t  s  = (half_t)block_scales[(size_t)kb * ((N + 127) / 128) + n / 128];
+    const half2_t pr = {s, (half_t)0.f};
+    out[idx]         = bit_cast<uint32_t>(pr);  // [kb][nt][16] == [kb][n]
+}
+
 void linear_weight_free(LinearWeight& w)
 {
     if (w.packed) {
@@ -137,6 +181,26 @@ int linear_weight_prepare_u4(LinearWeight& w, const int32_t* qweight, const half
     TM_HIP_CHECK(hipGetLastError());
     const size_t ns = (size_t)(w.K / 128) * w.N;
     repack_sz_kernel<<<(ns + 255) / 256, 256, 0, st>>>(w.sz, scales, zeros, w.K / 128, w.N);
+    TM_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int linear_weight_prepare_fp8(LinearWeight& w, const uint8_t* weight, const float* block_scales, hipStream_t st)
+{
+    TM_REQUIRE(w.K % 128 == 0 && w.N % 16 == 0, "K % 128 == 0 and N % 16 == 0");
+    w.type         = 2;
+    w.group        = 128;
+    w.packed_bytes = (size_t)w.K * w.N;
+    w.sz_bytes     = (size_t)(w.K / 128) * w.N * 4;
+    if (!w.packed) {
+        TM_HIP_CHECK(hipMalloc(&w.packed, w.packed_bytes));
+        TM_HIP_CHECK(hipMalloc((void**)&w.sz, w.sz_bytes));
+    }
+    const size_t nv = (size_t)w.K * w.N / 16;
+    repack_fp8_kernel<<<(nv + 255) / 256, 256, 0, st>>>((uint8_t*)w.packed, weight, w.K, w.N);
+    TM_HIP_CHECK(hipGetLastError());
+    const size_t ns = (size_t)(w.K / 128) * w.N;
+    repack_sz_fp8_kernel<<<(ns + 255) / 256, 256, 0, st>>>(w.sz, block_scales, w.K / 128, w.N);
     TM_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -223,7 +287,7 @@ __global__ __launch_bounds__(WN * WK * 64) void gemm_kernel(GemmParams p)
     constexpr int BUFB    = SUBS * PHB;          // one LDS stage
     constexpr int NCHUNK  = SUBS * MB * 16;      // 16-B chunks per stage
     constexpr int XR      = (NCHUNK + THREADS - 1) / THREADS;
-    constexpr int WV      = WT == 0 ? 1 : 4;     // u32x4 per (tile, k-block) per lane
+    constexpr int WV      = WT == 0 ? 1 : (WT == 2 ? 2 : 4);  // u32x4 per (tile, k-block) per lane: u4 / fp8 / f16
     constexpr bool XFULL  = NCHUNK % THREADS == 0;  // every thread stages exactly XR chunks
 
     extern __shared__ __attribute__((aligned(16))) char smem[];  // max(2 * BUFB, reduction scratch)
@@ -253,7 +317,7 @@ __global__ __launch_bounds__(WN * WK * 64) void gemm_kernel(GemmParams p)
     // load in the loop is SALU-only (raw pointers cost ~10 VALU per load in 64-bit adds).
     // Tiles past the edge are clamped: loads stay in bounds, stores are skipped.
     const auto rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.wq, 0, (int)((size_t)p.KB * ntiles * 1024 * WV), 0x00020000);
-    const auto rs_s = __builtin_amdgcn_make_buffer_rsrc((void*)p.sz, 0, WT == 0 ? p.KB * ntiles * 64 : 0, 0x00020000);
+    const auto rs_s = __builtin_amdgcn_make_buffer_rsrc((void*)p.sz, 0, WT != 1 ? p.KB * ntiles * 64 : 0, 0x00020000);
     const auto rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)(((size_t)(p.M - 1) * p.ldx + p.K) * 2), 0x00020000);
     int woff[NT], soff[NT];
 #pragma unroll
@@ -309,7 +373,7 @@ __global__ __launch_bounds__(WN * WK * 64) void gemm_kernel(GemmParams p)
                     ring[slot][kk][t][v] = __builtin_amdgcn_raw_buffer_load_b128(                            \
                         rs_w, woff[t] + v * 1024, (kb_ + kk * WK) * wstride, /*nt*/ 2);                      \
                 }                                                                                            \
-                if constexpr (WT == 0) {                                                                     \
+                if constexpr (WT != 1) {                                                                     \
                     sring[slot][kk][t] =                                                                     \
                         __builtin_amdgcn_raw_buffer_load_b32(rs_s, soff[t], (kb_ + kk * WK) * sstride, 0);   \
                 }                                                                                            \
@@ -367,6 +431,19 @@ __global__ __launch_bounds__(WN * WK * 64) void gemm_kernel(GemmParams p)
                 else {
                     return dequant8(ring[slot][kk][t][0][j], half2_t{pr[0], pr[0]}, half2_t{pr[1], pr[1]}, m1024, m64);
                 }
+            }
+            else if constexpr (WT == 2) {
+                // e4m3 -> f16 is exact (v_cvt_scalef32_pk_f16_fp8, scale 1); w = h(f16(q) * s), one rounding
+                // (kernels/attention/quantization.h:820-846 + the group scale of kernels/gemm/transform.h)
+                const half2_t  pr = bit_cast<half2_t>(live ? sring[slot][kk][t] : 0u);
+                const half2_t  s2 = {pr[0], pr[0]};
+                const u32x4    wv = ring[slot][kk][t][j >> 1];
+                const uint32_t w0 = wv[(j & 1) * 2], w1 = wv[(j & 1) * 2 + 1];
+                const half2_t  a0 = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(w0, 1.0f, false) * s2;
+                const half2_t  a1 = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(w0, 1.0f, true) * s2;
+                const half2_t  a2 = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(w1, 1.0f, false) * s2;
+                const half2_t  a3 = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(w1, 1.0f, true) * s2;
+                return half8_t{a0[0], a0[1], a1[0], a1[1], a2[0], a2[1], a3[0], a3[1]};
             }
             else {
                 const u32x4 wv = ring[slot][kk][t][j];
@@ -1452,6 +1529,10 @@ static int launch_mt(const GemmParams& p, dim3 grid, int nt, int waves, int wk, 
         if (nt == 1) return launch_one<1, MT, 1, 4, 1, 1, 4>(p, grid, st);
         return launch_one<1, MT, 2, 4, 1, 1, 2>(p, grid, st);
     }
+    else if constexpr (WT == 2) {  // fp8: 8 waves, one tile per wave (decode) or two (prefill rows)
+        if (nt == 1) return launch_one<2, MT, 1, 8, 1, 1, 4>(p, grid, st);
+        return launch_one<2, MT, 2, 8, 1, 1, 2>(p, grid, st);
+    }
     else {
         if (waves == 16) {  // 8 column groups x 2 k-phases: 4 waves per SIMD, same activation traffic per CU as 8x1
             return p.kb_per_split / 2 >= 16 ? launch_one<0, MT, 1, 8, 2, 1, 8>(p, grid, st) :
@@ -1506,6 +1587,11 @@ int launch_linear(const LinearWeight& w,
         wk    = 1;
         nt    = nt > 2 ? 2 : nt;
     }
+    if (w.type == 2) {  // fp8: 8 waves x (1 | 2) tiles, no in-workgroup k split
+        waves = 8;
+        wk    = 1;
+        nt    = nt > 1 ? 2 : 1;
+    }
     if (waves == 4) {
         wk = 1;
     }
@@ -1557,7 +1643,7 @@ int launch_linear(const LinearWeight& w,
     // measured (tools/ablate_gemm.sh): more k-blocks per barrier does NOT pay (the loop is issue-bound, not
     // barrier-bound), so the default is 1; TM_GEMM_KSTAGE=2|4 keeps the experiment reachable.
     int ks_cap = cfg.kstage > 0 ? cfg.kstage : 1;
-    if (w.type == 1 || (waves == 4 && nt == 4) || waves == 16) {
+    if (w.type != 0 || (waves == 4 && nt == 4) || waves == 16) {
         ks_cap = 1;
     }
     else if (wk == 2 && ks_cap > 2) {
@@ -1658,6 +1744,11 @@ int launch_linear(const LinearWeight& w,
         rc = mt == 1 ? launch_mt<0, 1>(p, grid, nt, waves, wk, ks, st) :
              mt == 2 ? launch_mt<0, 2>(p, grid, nt, waves, wk, ks, st) :
                        launch_mt<0, 4>(p, grid, nt, waves, wk, ks, st);
+    }
+    else if (w.type == 2) {
+        rc = mt == 1 ? launch_mt<2, 1>(p, grid, nt, waves, wk, ks, st) :
+             mt == 2 ? launch_mt<2, 2>(p, grid, nt, waves, wk, ks, st) :
+                       launch_mt<2, 4>(p, grid, nt, waves, wk, ks, st);
     }
     else {
         rc = mt == 1 ? launch_mt<1, 1>(p, grid, nt, waves, wk, ks, st) :

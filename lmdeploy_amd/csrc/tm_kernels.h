@@ -100,9 +100,9 @@ int launch_prefill_attention(const PrefillAttnParams& p, hipStream_t st);
 // ---- gemm_w4a16.hip ---------------------------------------------------------------------
 struct LinearWeight {
     int       K = 0, N = 0, group = 128;
-    int       type = 0;          // 0 = u4 (AWQ), 1 = f16 dense
+    int       type = 0;          // 0 = u4 (AWQ), 1 = f16 dense, 2 = fp8 e4m3 with 128x128 block scales
     void*     packed = nullptr;  // fragment-ordered weights
-    uint32_t* sz     = nullptr;  // fragment-ordered (s, -z*s) half2 pairs (u4 only)
+    uint32_t* sz     = nullptr;  // fragment-ordered (s, -z*s) half2 pairs (u4), (s, 0) (fp8)
     size_t    packed_bytes = 0, sz_bytes = 0;
 };
 struct GemmConfig {
@@ -116,6 +116,8 @@ struct GemmConfig {
 int    linear_weight_prepare_u4(LinearWeight& w, const int32_t* qweight /*[K][N/8]*/, const half_t* scales,
                                 const half_t* zeros, hipStream_t st);
 int    linear_weight_prepare_f16(LinearWeight& w, const half_t* weight /*[K][N]*/, hipStream_t st);
+int    linear_weight_prepare_fp8(LinearWeight& w, const uint8_t* weight /*[K][N] e4m3*/, const float* block_scales /*[K/128][ceil(N/128)]*/,
+                                 hipStream_t st);
 void   linear_weight_free(LinearWeight& w);
 size_t gemm_workspace_bytes(int M, int N, int splits);
 GemmConfig gemm_pick_config(const LinearWeight& w, int M);

@@ -852,3 +852,61 @@ def philox_uniform(seed: int, counter: int) -> float:
         k0 = (k0 + 0x9E3779B9) & m32
         k1 = (k1 + 0xBB67AE85) & m32
     return float(np.float32(c[0] >> 8) * np.float32(1.0 / 16777216.0))
+
+
+# ------------------------------------------------------------------------------------------------
+# FP8 (e4m3fn) block-scaled weights (lmdeploy/turbomind/weight_format.py:349-393; weight-only path of
+# models/linear_weight.cc:138-150: 128x128 block scales expanded to per-column K-group scales in the activation type;
+# conversion kernels/attention/quantization.h:820-846 = exact e4m3 -> f16)
+# ------------------------------------------------------------------------------------------------
+def fp8_e4m3_to_f32(b: np.ndarray) -> np.ndarray:
+    """OCP e4m3fn: 1 sign, 4 exponent (bias 7), 3 mantissa bits; no infinities, S.1111.111 = NaN, max 448."""
+    b = np.asarray(b, np.uint8).astype(np.int32)
+    sign = np.where(b & 0x80, -1.0, 1.0)
+    e = (b >> 3) & 0xF
+    m = b & 7
+    v = np.where(e == 0, m / 8.0 * 2.0**-6, (1.0 + m / 8.0) * np.exp2(e.astype(np.float64) - 7))
+    v = np.where((e == 15) & (m == 7), np.nan, v)
+    return (sign * v).astype(np.float32)
+
+
+def fp8_e4m3_from_f32(x: np.ndarray) -> np.ndarray:
+    """round-to-nearest-even onto the e4m3fn grid, saturating at +-448 (test data generator)"""
+    grid = fp8_e4m3_to_f32(np.arange(0, 0x7F, dtype=np.uint8)).astype(np.float64)      # 0 .. 448, ascending
+    x = np.asarray(x, np.float64)
+    a = np.clip(np.abs(x), 0, 448.0)
+    hi = np.clip(np.searchsorted(grid, a, side='left'), 1, len(grid) - 1)
+    lo = hi - 1
+    dl, dh = a - grid[lo], grid[hi] - a
+    pick_hi = (dh < dl) | ((dh == dl) & (hi % 2 == 0))        # ties to the even code
+    code = np.where(pick_hi, hi, lo).astype(np.uint8)
+    return np.where(np.signbit(x), code | 0x80, code).astype(np.uint8)
+
+
+def fp8_expand_block_scales(block_scales: np.ndarray, K: int, N: int) -> np.ndarray:
+    """[K/128][ceil(N/128)] fp32 -> per-column group scales fp16 [K/128][N] (BlockscaleToGroupscale)"""
+    return np.repeat(np.asarray(block_scales, np.float32), 128, axis=1)[:, :N].astype(np.float16)
+
+
+def fp8_dequant(wq: np.ndarray, block_scales: np.ndarray) -> np.ndarray:
+    """w[k, n] = h( f16(e4m3[k, n]) * s[k/128, n] ): exact conversion, one fp16 multiply"""
+    K, N = wq.shape
+    s = fp8_expand_block_scales(block_scales, K, N)
+    v = fp8_e4m3_to_f32(wq).astype(np.float16)              # exact
+    return hmul(v, np.repeat(s, 128, axis=0)[:K])
+
+
+def fp8_quantize_blockwise(w: np.ndarray):
+    """fp16/fp32 [K, N] -> (e4m3 codes, fp32 128x128 block scales) with scale = amax / 448 (test data)"""
+    w = np.asarray(w, np.float32)
+    K, N = w.shape
+    kb, nb = (K + 127) // 128, (N + 127) // 128
+    scales = np.zeros((kb, nb), np.float32)
+    q = np.zeros((K, N), np.uint8)
+    for i in range(kb):
+        for j in range(nb):
+            blk = w[i * 128:(i + 1) * 128, j * 128:(j + 1) * 128]
+            sc = max(float(np.abs(blk).max()) / 448.0, 1e-8)
+            scales[i, j] = sc
+            q[i * 128:(i + 1) * 128, j * 128:(j + 1) * 128] = fp8_e4m3_from_f32(blk / sc)
+    return q, scales

@@ -574,6 +574,51 @@ def test_sampling_distribution(tm, cuda):
     assert chi2 < 3 * len(ids) + 30, chi2                               # dof = len(ids) - 1 ~ 10; mean = dof
 
 
+@pytest.mark.parametrize('K,N', [(512, 256), (4096, 1024), (384, 48)])
+def test_fp8_linear(tm, cuda, K, N):
+    """FP8 (e4m3, 128x128 block scales) weight-only linear (TM_WEIGHT_FP8; BASELINE config 5's weight format) against
+    the oracle: dequantised weights bit exact (identity activations), products within the u4 linear's tolerance for
+    decode- and prefill-sized M, gated SiLU epilogue."""
+    rng = np.random.default_rng(K + N)
+    w = (rng.standard_normal((K, N)) * (0.1 / math.sqrt(K))).astype(f16)
+    q, sc = o.fp8_quantize_blockwise(w)
+    q[::37, ::11] = 0x01                                  # subnormal codes
+    q[5::53, 3::7] = 0xFE                                 # -448
+    wd = o.fp8_dequant(q, sc)
+    h = _ffi.C.c_void_p()
+    _ffi.check(tm.tm_linear_create(_ffi.C.byref(h), K, N, 2, 128))
+    _ffi.check(tm.tm_linear_prepare(h, dev(q).data_ptr(), dev(sc).data_ptr(), None, st()))
+    torch.cuda.synchronize()
+    ws = torch.zeros(max(1, tm.tm_linear_workspace(h, 700)), dtype=torch.uint8, device='cuda')
+    x = np.zeros((64, K), f16)
+    rows = rng.permutation(K)[:64]
+    x[np.arange(64), rows] = 1
+    y = torch.zeros((64, N), dtype=torch.float16, device='cuda')
+    _ffi.check(tm.tm_linear_forward(h, dev(x).data_ptr(), K, y.data_ptr(), N, 64, 0, 0, 1, 0, ws.data_ptr(), st()))
+    got, exp = host(y), wd[rows]
+    normal = np.abs(exp.astype(np.float32)) >= 2.0**-14
+    bad = (got.view(np.uint16) != exp.view(np.uint16)) & normal
+    assert not bad.any(), f'dequantised fp8 weights must be bit exact: {int(bad.sum())} normal-range mismatches, e.g. {got[bad][:4]} vs {exp[bad][:4]}'
+    # fp16 subnormal products: the matrix core may flush them (the reference's mma does not define it either)
+    assert np.abs(got.astype(np.float32) - exp.astype(np.float32))[~normal].max(initial=0.0) <= 2.0**-14
+    for M in (1, 17, 64, 130, 700):
+        x = rng.standard_normal((M, K)).astype(f16)
+        ref = x.astype(np.float32) @ wd.astype(np.float32)
+        y = torch.zeros((M, N), dtype=torch.float16, device='cuda')
+        _ffi.check(tm.tm_linear_forward(h, dev(x).data_ptr(), K, y.data_ptr(), N, M, 0, 0, 0, 0, ws.data_ptr(), st()))
+        err = np.abs(host(y).astype(np.float32) - ref)
+        assert np.all(err <= 2e-3 + 2.0**-10 * np.abs(ref)), f'M={M}: max err {err.max()}'
+    if N % 32 == 0:
+        x = (rng.standard_normal((33, K)) * 3).astype(f16)
+        acc = x.astype(np.float32) @ wd.astype(np.float32)
+        ref = o.gated_silu_epilogue(acc).astype(np.float32)
+        y = torch.zeros((33, N // 2), dtype=torch.float16, device='cuda')
+        _ffi.check(tm.tm_linear_forward(h, dev(x).data_ptr(), K, y.data_ptr(), N // 2, 33, 1, 0, 0, 0, ws.data_ptr(), st()))
+        err = np.abs(host(y).astype(np.float32) - ref)
+        assert np.all(err <= 2e-3 + 2.0**-9 * np.abs(ref)), f'gated: max err {err.max()}'
+    _ffi.check(tm.tm_linear_destroy(h))
+
+
 def test_w4a16_identity_asymmetric(tm, cuda):
     """Transpose-detecting check: x = I (first K rows) picks out rows of the dequantised weight exactly."""
     rng = np.random.default_rng(3)

@@ -246,3 +246,21 @@ def test_sampling_filter_semantics():
     assert o.sample_draw(np.array([7, 8, 9]), np.array([0.2, 0.3, 0.5]), 0.2) == 8     # prefix must exceed u
     assert o.sample_draw(np.array([7, 8, 9]), np.array([0.2, 0.3, 0.5]), 0.999999) == 9
     assert o.sample_draw(np.array([7, 8, 9]), np.array([0.2, 0.3, 0.5]), 0.0) == 7
+
+
+def test_fp8_e4m3_matches_torch():
+    """e4m3fn decode / encode pinned on torch.float8_e4m3fn (an independent implementation): all 256 codes, and
+    round-to-nearest-even encoding of random values."""
+    import torch
+    codes = np.arange(256, dtype=np.uint8)
+    ref = torch.from_numpy(codes).view(torch.float8_e4m3fn).float().numpy()
+    got = o.fp8_e4m3_to_f32(codes)
+    assert np.array_equal(np.isnan(ref), np.isnan(got)) and np.array_equal(ref[~np.isnan(ref)], got[~np.isnan(got)])
+    x = (np.random.default_rng(0).standard_normal(20000) * 60).astype(np.float32)
+    enc_ref = torch.from_numpy(x).to(torch.float8_e4m3fn).view(torch.uint8).numpy()
+    inside = np.abs(x) <= 448
+    assert np.array_equal(o.fp8_e4m3_from_f32(x)[inside], enc_ref[inside])
+    w = (np.random.default_rng(1).standard_normal((256, 160)) * 0.05).astype(np.float16)
+    q, sc = o.fp8_quantize_blockwise(w)
+    d = o.fp8_dequant(q, sc).astype(np.float32)
+    assert np.abs(d - w.astype(np.float32)).max() <= np.abs(w).max() * 2.0**-3      # 3 mantissa bits
