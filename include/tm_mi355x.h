@@ -149,6 +149,25 @@ size_t tm_linear_workspace(const tm_linear* w, int M);
 int    tm_linear_forward(const tm_linear* w, const void* x, int ldx, void* y, int ldy, int M, int gated_silu,
                          int nt, int splits, int waves, void* workspace, tm_stream_t st);
 int    tm_linear_destroy(tm_linear* w);
+/* ---- Mixture-of-experts FFN block (MoeFfnLayer, models/llama/moe_ffn_layer.cc:43-53,133-325; routing
+ * kernels/gemm/moe_utils_v2.cu:355-690; grouped linear LlamaLinear.cu:67-127) -------------------------------------
+ * out[t] = sum over the top_k experts e of token t of w_e(t) * W2_e( silu(W1_e x_t) * (W3_e x_t) ), with
+ * logits = x Wg (fp32), top-k on the logits (ties: lower expert id), w = softmax over the selected experts
+ * (norm_topk != 0) or over all experts, times routed_scale.  Expert weights: weight_type TM_WEIGHT_U4 / TM_WEIGHT_FP8,
+ * boundary layouts of tm_linear_prepare; w13 = [hidden][2*inter] with (gate_j, up_j) column-interleaved, w2 =
+ * [inter][hidden].  gate: fp16 [hidden][experts].  All pointers device.  topk_ids_out / topk_w_out (device
+ * [tokens][top_k], may be NULL) expose the routing for tests. */
+typedef struct tm_moe tm_moe;
+int    tm_moe_create(tm_moe** out, int hidden, int inter, int experts, int top_k, int weight_type, int norm_topk,
+                     float routed_scale);
+int    tm_moe_set_gate(tm_moe* m, const void* gate, tm_stream_t st);
+int    tm_moe_set_expert(tm_moe* m, int expert, const void* w13_weight, const void* w13_scales, const void* w13_zeros,
+                         const void* w2_weight, const void* w2_scales, const void* w2_zeros, tm_stream_t st);
+size_t tm_moe_workspace(const tm_moe* m, int tokens);
+int    tm_moe_forward(tm_moe* m, void* out, const void* x, int tokens, void* workspace, int* topk_ids_out, float* topk_w_out,
+                      tm_stream_t st);
+int    tm_moe_destroy(tm_moe* m);
+
 /* IntegralQuantizer<half,4> (kernels/quantization.cu:384-440): w fp16 [K][N] -> qweight int32 [K][N/8],
  * scales/zeros fp16 [K/g][N], dequant fp16 [K][N] (may be NULL).  Groups run along K. */
 int tm_quantize_groupwise(void* qweight, void* scales, void* zeros, void* dequant, const void* w, int K, int N,

@@ -73,6 +73,12 @@ _SIGNATURES = {
     'tm_argmax': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     'tm_silu_mul': (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
     'tm_sample_workspace': (c_size_t, [c_int]),
+    'tm_moe_create': (c_int, [POINTER(c_void_p), c_int, c_int, c_int, c_int, c_int, c_int, c_float]),
+    'tm_moe_set_gate': (c_int, [c_void_p, c_void_p, c_void_p]),
+    'tm_moe_set_expert': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'tm_moe_workspace': (c_size_t, [c_void_p, c_int]),
+    'tm_moe_forward': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'tm_moe_destroy': (c_int, [c_void_p]),
     'tm_sample': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                           c_void_p, c_void_p]),
     'tm_philox_uniform': (C.c_float, [C.c_uint64, C.c_uint32]),

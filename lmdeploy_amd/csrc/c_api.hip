@@ -1,6 +1,13 @@
 // C-ABI shims for the operator-level entry points declared in include/tm_mi355x.h.
 #include "../../include/tm_mi355x.h"
 #include "scheduler.h"
+#define TM_TRY_RC(expr)          \
+    do {                        \
+        const int _rc = (expr); \
+        if (_rc) {              \
+            return _rc;         \
+        }                       \
+    } while (0)
 #include "tm_common.h"
 #include "tm_kernels.h"
 #include <cmath>
@@ -319,6 +326,91 @@ int tm_sample(int* out_ids, int* kept_out, const void* logits, int batch, int vo
 float tm_philox_uniform(uint64_t seed, uint32_t counter)
 {
     return philox_uniform_host(seed, counter);
+}
+
+// ---- MoE FFN block ------------------------------------------------------------------------------------------------
+struct tm_moe {
+    tmk::MoeBlock m;
+    int           type = 0;
+    bool          prepared = false;
+};
+
+int tm_moe_create(tm_moe** out, int hidden, int inter, int experts, int top_k, int weight_type, int norm_topk, float routed_scale)
+{
+    TM_REQUIRE(out, "null pointer");
+    TM_REQUIRE(weight_type == TM_WEIGHT_U4 || weight_type == TM_WEIGHT_FP8, "moe experts: u4 or fp8 weights");
+    TM_REQUIRE(hidden % 128 == 0 && inter % 128 == 0 && experts >= 1 && experts <= 64 && top_k >= 1 && top_k <= 8 && top_k <= experts,
+               "moe geometry");
+    auto* o         = new tm_moe();
+    o->m.hidden     = hidden;
+    o->m.inter      = inter;
+    o->m.experts    = experts;
+    o->m.top_k      = top_k;
+    o->m.norm_topk  = norm_topk != 0;
+    o->m.routed_scale = routed_scale;
+    o->m.w13.resize(experts);
+    o->m.w2.resize(experts);
+    for (int e = 0; e < experts; ++e) {
+        o->m.w13[e].K = hidden, o->m.w13[e].N = 2 * inter, o->m.w13[e].type = weight_type;
+        o->m.w2[e].K = inter, o->m.w2[e].N = hidden, o->m.w2[e].type = weight_type;
+    }
+    o->type = weight_type;
+    *out    = o;
+    return 0;
+}
+
+int tm_moe_set_gate(tm_moe* m, const void* gate, tm_stream_t st)
+{
+    TM_REQUIRE(m && gate, "null pointer");
+    const size_t bytes = (size_t)m->m.hidden * m->m.experts * 2;
+    if (!m->m.gate) {
+        TM_HIP_CHECK(hipMalloc((void**)&m->m.gate, bytes));
+    }
+    TM_HIP_CHECK(hipMemcpyAsync(m->m.gate, gate, bytes, hipMemcpyDeviceToDevice, (hipStream_t)st));
+    return 0;
+}
+
+int tm_moe_set_expert(tm_moe* m, int expert, const void* w13_weight, const void* w13_scales, const void* w13_zeros,
+                      const void* w2_weight, const void* w2_scales, const void* w2_zeros, tm_stream_t st)
+{
+    TM_REQUIRE(m && w13_weight && w13_scales && w2_weight && w2_scales, "null pointer");
+    TM_REQUIRE(expert >= 0 && expert < m->m.experts, "expert index");
+    m->prepared = false;
+    if (m->type == TM_WEIGHT_U4) {
+        TM_REQUIRE(w13_zeros && w2_zeros, "u4 experts need zeros");
+        TM_TRY_RC(linear_weight_prepare_u4(m->m.w13[expert], (const int32_t*)w13_weight, (const half_t*)w13_scales,
+                                           (const half_t*)w13_zeros, (hipStream_t)st));
+        return linear_weight_prepare_u4(m->m.w2[expert], (const int32_t*)w2_weight, (const half_t*)w2_scales,
+                                        (const half_t*)w2_zeros, (hipStream_t)st);
+    }
+    TM_TRY_RC(linear_weight_prepare_fp8(m->m.w13[expert], (const uint8_t*)w13_weight, (const float*)w13_scales, (hipStream_t)st));
+    return linear_weight_prepare_fp8(m->m.w2[expert], (const uint8_t*)w2_weight, (const float*)w2_scales, (hipStream_t)st);
+}
+
+size_t tm_moe_workspace(const tm_moe* m, int tokens)
+{
+    return m ? moe_workspace_bytes(m->m, tokens) : 0;
+}
+
+int tm_moe_forward(tm_moe* m, void* out, const void* x, int tokens, void* workspace, int* topk_ids_out, float* topk_w_out,
+                   tm_stream_t st)
+{
+    TM_REQUIRE(m && out && x && workspace, "null pointer");
+    if (!m->prepared) {
+        TM_TRY_RC(moe_prepare(m->m, (hipStream_t)st));
+        m->prepared = true;
+    }
+    return moe_forward(m->m, (half_t*)out, m->m.hidden, (const half_t*)x, m->m.hidden, tokens, workspace, topk_ids_out, topk_w_out,
+                       (hipStream_t)st);
+}
+
+int tm_moe_destroy(tm_moe* m)
+{
+    if (m) {
+        moe_free(m->m);
+        delete m;
+    }
+    return 0;
 }
 
 // ---- host-only scheduler hooks (scheduler.h) ----------------------------------------------------------------------

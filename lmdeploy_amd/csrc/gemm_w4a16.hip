@@ -224,6 +224,11 @@ int linear_weight_prepare_f16(LinearWeight& w, const half_t* weight, hipStream_t
 // ------------------------------------------------------------------------------------------------
 // main kernel
 // ------------------------------------------------------------------------------------------------
+struct GemmGroup {
+    const void* wq;
+    const void* sz;
+};
+
 struct GemmParams {
     const half_t*   x;
     int             ldx;
@@ -238,6 +243,13 @@ struct GemmParams {
     int             epilogue;      // 0: fp16 store  1: gated silu fp16 store  2: fp32 partial slabs
     int             rotate_k;      // per-workgroup rotation of the K walk (L2 hot-spot avoidance)
     uint64_t*       dbg;           // optional [workgroups][4] s_memrealtime stamps (100 MHz): start, loop, epilogue, end
+    // grouped (mixture-of-experts) mode: grid.z = experts x zper row blocks; expert e contracts the flat rows
+    // seg[e] .. seg[e+1] (device routing offsets) with ITS weights; x row of flat row f = row_idx ? row_idx[f] : f
+    const GemmGroup* groups;       // device [experts]: packed weight / scale pointers (nullptr = plain GEMM)
+    const int*       seg;          // device [experts + 1]
+    const int*       row_idx;      // device [flat rows] or nullptr
+    int              zper;         // row blocks per expert
+    int              x_rows;       // rows of x (bounds of the activation buffer descriptor)
 };
 
 // m1024 / m64 hold 0x64006400 / 0x54005400 in VGPRs (made opaque by the caller): with the magic in a register
@@ -308,7 +320,21 @@ __global__ __launch_bounds__(WN * WK * 64) void gemm_kernel(GemmParams p)
 
     const int ntiles = p.N / 16;
     const int nt0    = (blockIdx.x * WN + wn) * NT;
-    const int m0     = blockIdx.z * MB;
+    // plain GEMM: rows m0 .. of x / y.  Grouped: this workgroup's expert, its row segment and its weights.
+    int         m0 = blockIdx.z * MB, row0 = 0, Mloc = p.M;
+    const void* wq_base = p.wq;
+    const void* sz_base = p.sz;
+    if (p.groups) {
+        const int e  = blockIdx.z / p.zper;
+        m0           = (blockIdx.z - e * p.zper) * MB;
+        row0         = p.seg[e];
+        Mloc         = min(p.seg[e + 1] - row0, p.M);
+        wq_base      = p.groups[e].wq;
+        sz_base      = p.groups[e].sz;
+        if (m0 >= Mloc) {
+            return;  // no rows for this block (whole workgroup, before any barrier)
+        }
+    }
     const int kb0    = blockIdx.y * p.kb_per_split;
     const int nkb    = min(p.kb_per_split, p.KB - kb0);  // multiple of SUBS (host guarantees)
     const int nit    = nkb / SUBS;
@@ -316,9 +342,9 @@ __global__ __launch_bounds__(WN * WK * 64) void gemm_kernel(GemmParams p)
     // Buffer descriptors (SRD) + per-lane 32-bit byte offsets + SCALAR k-block offsets: the address math of every
     // load in the loop is SALU-only (raw pointers cost ~10 VALU per load in 64-bit adds).
     // Tiles past the edge are clamped: loads stay in bounds, stores are skipped.
-    const auto rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.wq, 0, (int)((size_t)p.KB * ntiles * 1024 * WV), 0x00020000);
-    const auto rs_s = __builtin_amdgcn_make_buffer_rsrc((void*)p.sz, 0, WT != 1 ? p.KB * ntiles * 64 : 0, 0x00020000);
-    const auto rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)(((size_t)(p.M - 1) * p.ldx + p.K) * 2), 0x00020000);
+    const auto rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)wq_base, 0, (int)((size_t)p.KB * ntiles * 1024 * WV), 0x00020000);
+    const auto rs_s = __builtin_amdgcn_make_buffer_rsrc((void*)sz_base, 0, WT != 1 ? p.KB * ntiles * 64 : 0, 0x00020000);
+    const auto rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)(((size_t)((p.groups ? p.x_rows : p.M) - 1) * p.ldx + p.K) * 2), 0x00020000);
     int woff[NT], soff[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
@@ -354,7 +380,11 @@ __global__ __launch_bounds__(WN * WK * 64) void gemm_kernel(GemmParams p)
         const int sb = qc / (MB * 16);
         const int m  = (qc >> 4) % MB;
         const int ci = qc & 15;
-        xoff[r]      = (min(m0 + m, p.M - 1) * p.ldx + ci * 8) * 2 + sb * 256;
+        int xrow     = row0 + min(m0 + m, Mloc - 1);
+        if (p.row_idx) {
+            xrow = p.row_idx[xrow];
+        }
+        xoff[r]      = (xrow * p.ldx + ci * 8) * 2 + sb * 256;
         xlds[r]      = q < NCHUNK ? sb * PHB + m * ROWB + ((ci ^ (m & 15)) << 4) : -1;
     }
     uint32_t m1024 = 0x64006400u, m64 = 0x54005400u;
@@ -579,10 +609,10 @@ __global__ __launch_bounds__(WN * WK * 64) void gemm_kernel(GemmParams p)
         const int n = (nt0 + t) * 16 + g * 4;
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
-            const int m = m0 + mt * 16 + i16;
-            if (m >= p.M) {
+            if (m0 + mt * 16 + i16 >= Mloc) {
                 continue;
             }
+            const int     m = row0 + m0 + mt * 16 + i16;  // flat output row
             const floatx4 a = acc[t][mt];
             if (p.epilogue == 2) {
                 *(floatx4*)(p.partial + ((size_t)blockIdx.y * p.M + m) * p.N + n) = a;
@@ -1767,6 +1797,71 @@ int launch_linear(const LinearWeight& w,
         *slabs = splits;  // number of fp32 slabs written (1 = direct epilogue, nothing in the workspace)
     }
     return 0;
+}
+
+// Grouped GEMM over experts (reference: LlamaLinear::Forward with idxs / offsets, models/llama/LlamaLinear.cu:67-127):
+// y[f] = x[row_idx ? row_idx[f] : f] . W_e for the flat rows f of expert e.  All experts share shape and format; the
+// descriptors (device) are built once by moe_build_groups.  m_cap = upper bound of rows per expert (tokens).
+int moe_build_groups(void** d_groups, const LinearWeight* experts, int E, hipStream_t st)
+{
+    std::vector<GemmGroup> h(E);
+    for (int e = 0; e < E; ++e) {
+        TM_REQUIRE(experts[e].packed != nullptr, "expert weight not prepared");
+        h[e] = GemmGroup{experts[e].packed, experts[e].sz};
+    }
+    if (!*d_groups) {
+        TM_HIP_CHECK(hipMalloc(d_groups, sizeof(GemmGroup) * E));
+    }
+    TM_HIP_CHECK(hipMemcpyAsync(*d_groups, h.data(), sizeof(GemmGroup) * E, hipMemcpyHostToDevice, st));
+    TM_HIP_CHECK(hipStreamSynchronize(st));
+    return 0;
+}
+
+int launch_linear_grouped(const LinearWeight& proto, const void* d_groups, int E, const half_t* x, int ldx, int x_rows,
+                          half_t* y, int ldy, int m_cap, bool gated_silu, const int* seg, const int* row_idx, hipStream_t st)
+{
+    TM_REQUIRE(proto.type == 0 || proto.type == 2, "grouped GEMM: u4 or fp8 expert weights");
+    TM_REQUIRE(ldx % 8 == 0 && (!gated_silu || proto.N % 32 == 0), "grouped GEMM: alignment");
+    if (m_cap == 0 || E == 0) {
+        return 0;
+    }
+    GemmParams p{};
+    p.x            = x;
+    p.ldx          = ldx;
+    p.y            = y;
+    p.ldy          = ldy;
+    p.M            = m_cap;
+    p.N            = proto.N;
+    p.K            = proto.K;
+    p.KB           = proto.K / 128;
+    p.kb_per_split = p.KB;
+    p.epilogue     = gated_silu ? 1 : 0;
+    p.dbg          = nullptr;
+    p.groups       = (const GemmGroup*)d_groups;
+    p.seg          = seg;
+    p.row_idx      = row_idx;
+    p.x_rows       = x_rows;
+    const int ntiles = proto.N / 16;
+    int       rc     = 0;
+    if (m_cap <= 64) {  // decode: every expert sees at most `tokens` rows -> one 8-wave x 1-tile row block
+        const int mt = m_cap <= 16 ? 1 : (m_cap <= 32 ? 2 : 4);
+        p.zper       = 1;
+        dim3 grid((ntiles + 7) / 8, 1, E);
+        if (proto.type == 0) {
+            rc = mt == 1 ? launch_one<0, 1, 1, 8, 1, 1, 4>(p, grid, st) : mt == 2 ? launch_one<0, 2, 1, 8, 1, 1, 4>(p, grid, st) :
+                                                                                    launch_one<0, 4, 1, 8, 1, 1, 4>(p, grid, st);
+        }
+        else {
+            rc = mt == 1 ? launch_one<2, 1, 1, 8, 1, 1, 4>(p, grid, st) : mt == 2 ? launch_one<2, 2, 1, 8, 1, 1, 4>(p, grid, st) :
+                                                                                    launch_one<2, 4, 1, 8, 1, 1, 4>(p, grid, st);
+        }
+    }
+    else {  // prefill: 64-row blocks x 2 tiles per wave; blocks past an expert's segment exit at once
+        p.zper = (m_cap + 63) / 64;
+        dim3 grid((ntiles + 15) / 16, 1, E * p.zper);
+        rc = proto.type == 0 ? launch_one<0, 4, 2, 8, 1, 1, 4>(p, grid, st) : launch_one<2, 4, 2, 8, 1, 1, 2>(p, grid, st);
+    }
+    return rc;
 }
 
 }  // namespace tmk

@@ -1,6 +1,7 @@
 // Internal launcher declarations (host side of every HIP kernel in this library).
 #pragma once
 #include "tm_common.h"
+#include <vector>
 
 namespace tmk {
 
@@ -133,6 +134,29 @@ int    launch_sample(int* out_ids, int* kept_out, const half_t* logits, int batc
                      hipStream_t st);
 int    launch_sample_uniform(float* u, const uint64_t* seeds, const int* counters, int batch, hipStream_t st);
 float  philox_uniform_host(uint64_t seed, uint32_t ctr);
+
+struct MoeBlock {
+    int                       hidden = 0, inter = 0, experts = 0, top_k = 0;
+    bool                      norm_topk    = true;
+    float                     routed_scale = 1.f;
+    half_t*                   gate         = nullptr;  // device fp16 [hidden][experts]
+    std::vector<LinearWeight> w13, w2;                 // per expert: gated (gate_j, up_j)-interleaved [H][2I], [I][H]
+    void *                    groups13 = nullptr, *groups2 = nullptr;
+};
+size_t moe_workspace_bytes(const MoeBlock& m, int tokens);
+int    moe_prepare(MoeBlock& m, hipStream_t st);
+int    moe_forward(const MoeBlock& m, half_t* out, int ldo, const half_t* x, int ldx, int tokens, void* workspace, int* topk_ids_out,
+                   float* topk_w_out, hipStream_t st);
+void   moe_free(MoeBlock& m);
+// mixture of experts (moe.hip, grouped GEMM in gemm_w4a16.hip)
+int moe_build_groups(void** d_groups, const LinearWeight* experts, int E, hipStream_t st);
+int launch_linear_grouped(const LinearWeight& proto, const void* d_groups, int E, const half_t* x, int ldx, int x_rows,
+                          half_t* y, int ldy, int m_cap, bool gated_silu, const int* seg, const int* row_idx, hipStream_t st);
+int launch_moe_gate(int* topk_ids, float* topk_w, float* logits_out, const half_t* x, int ldx, const half_t* wg, int T, int H,
+                    int E, int k, bool norm_topk, float routed_scale, hipStream_t st);
+int launch_moe_route(int* offsets, int* f2n, int* en2f, const int* topk_ids, int T, int E, int k, hipStream_t st);
+int launch_moe_combine(half_t* out, int ldo, const half_t* y, int ldy, const float* topk_w, const int* en2f, int T, int H, int k,
+                       hipStream_t st);
 
 extern uint64_t* g_gemm_dbg;  // gemm_w4a16.hip: optional per-workgroup timing stamps (tm_debug_set_gemm_trace)
 

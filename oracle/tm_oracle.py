@@ -910,3 +910,40 @@ def fp8_quantize_blockwise(w: np.ndarray):
             scales[i, j] = sc
             q[i * 128:(i + 1) * 128, j * 128:(j + 1) * 128] = fp8_e4m3_from_f32(blk / sc)
     return q, scales
+
+
+# ------------------------------------------------------------------------------------------------
+# Mixture of experts (models/llama/moe_ffn_layer.cc:133-325; kernels/gemm/moe_utils_v2.cu:355-690)
+# ------------------------------------------------------------------------------------------------
+def moe_gate(x: np.ndarray, gate: np.ndarray, top_k: int, norm_topk: bool = True, routed_scale: float = 1.0):
+    """x fp16 [T,H], gate fp16 [H,E] -> (logits f32 [T,E], expert ids [T,k], weights f32 [T,k]).
+    Top-k on the logits (ties: lower expert id); norm_topk: softmax over the selected experts only
+    (moe_utils_v2.cu:451-481), else over all experts; times routed_scale (:534)."""
+    logits = (x.astype(np.float32) @ gate.astype(np.float32)).astype(np.float32)
+    T, E = logits.shape
+    ids = np.zeros((T, top_k), np.int32)
+    w = np.zeros((T, top_k), np.float32)
+    for t in range(T):
+        order = np.lexsort((np.arange(E), -logits[t]))[:top_k]
+        mx = logits[t].max()
+        ex = np.exp((logits[t] - mx).astype(np.float32)).astype(np.float32)
+        denom = ex[order].sum(dtype=np.float32) if norm_topk else ex.sum(dtype=np.float32)
+        ids[t] = order
+        w[t] = ex[order] / denom * np.float32(routed_scale)
+    return logits, ids, w
+
+
+def moe_ffn(x: np.ndarray, gate: np.ndarray, experts: list, top_k: int, norm_topk: bool = True, routed_scale: float = 1.0):
+    """experts[e] = (w13 fp16 [H, 2I] with (gate_j, up_j) interleaved, w2 fp16 [I, H]) as DEQUANTISED weights.
+    out[t] = fp16( sum_j w_j * fp16( W2_e . fp16(silu(g) * u) ) ): the expert FFN is the dense FFN's arithmetic
+    (fp32 accumulation, gated-SiLU epilogue, fp16 outputs), the combine accumulates in fp32 (invokeMoeCombine)."""
+    _, ids, w = moe_gate(x, gate, top_k, norm_topk, routed_scale)
+    T, H = x.shape
+    out = np.zeros((T, H), np.float32)
+    for t in range(T):
+        for j in range(top_k):
+            w13, w2 = experts[ids[t, j]]
+            act = gated_silu_epilogue(gemm_f16_f32acc(x[t:t + 1], w13))
+            y = gemm_f16_f32acc(act, w2).astype(np.float16)
+            out[t] += w[t, j] * y[0].astype(np.float32)
+    return out.astype(np.float16), ids, w

@@ -619,6 +619,50 @@ def test_fp8_linear(tm, cuda, K, N):
     _ffi.check(tm.tm_linear_destroy(h))
 
 
+@pytest.mark.parametrize('wtype,T', [('fp8', 5), ('fp8', 64), ('fp8', 300), ('u4', 37)])
+def test_moe_ffn(tm, cuda, wtype, T):
+    """MoE FFN block (router + top-2 of 8 + grouped expert GEMMs + combine; BASELINE config 5 scaled down) against the
+    oracle: identical routing (expert ids), weights to 1e-5, output within the dense FFN's tolerance.  T = 300 runs
+    the prefill-shaped grouped GEMM (row blocks per expert), the others the decode shape."""
+    rng = np.random.default_rng(T)
+    H, I, E, k = 256, 384, 8, 2
+    x = rng.standard_normal((T, H)).astype(f16)
+    gate = (rng.standard_normal((H, E)) * 0.2).astype(f16)
+    h = _ffi.C.c_void_p()
+    _ffi.check(tm.tm_moe_create(_ffi.C.byref(h), H, I, E, k, 2 if wtype == 'fp8' else 0, 1, 1.0))
+    _ffi.check(tm.tm_moe_set_gate(h, dev(gate).data_ptr(), st()))
+    experts = []
+    for e in range(E):
+        w1 = (rng.standard_normal((H, I)) * (0.1 / math.sqrt(H))).astype(f16)
+        w3 = (rng.standard_normal((H, I)) * (0.1 / math.sqrt(H))).astype(f16)
+        w2 = (rng.standard_normal((I, H)) * (0.1 / math.sqrt(I))).astype(f16)
+        w13 = o.interleave_w1w3(w1, w3)
+        if wtype == 'fp8':
+            q13, s13 = o.fp8_quantize_blockwise(w13)
+            q2, s2 = o.fp8_quantize_blockwise(w2)
+            experts.append((o.fp8_dequant(q13, s13), o.fp8_dequant(q2, s2)))
+            _ffi.check(tm.tm_moe_set_expert(h, e, dev(q13).data_ptr(), dev(s13).data_ptr(), None, dev(q2).data_ptr(),
+                                            dev(s2).data_ptr(), None, st()))
+        else:
+            q13, s13, z13, _ = o.quantize_groupwise_u4(w13, 128)
+            q2, s2, z2, _ = o.quantize_groupwise_u4(w2, 128)
+            experts.append((o.w4a16_dequant(q13, s13, z13), o.w4a16_dequant(q2, s2, z2)))
+            _ffi.check(tm.tm_moe_set_expert(h, e, dev(o.pack_u4_row(q13)).data_ptr(), dev(s13).data_ptr(), dev(z13).data_ptr(),
+                                            dev(o.pack_u4_row(q2)).data_ptr(), dev(s2).data_ptr(), dev(z2).data_ptr(), st()))
+    torch.cuda.synchronize()
+    ws = torch.zeros(tm.tm_moe_workspace(h, T), dtype=torch.uint8, device='cuda')
+    out = torch.zeros((T, H), dtype=torch.float16, device='cuda')
+    ids_d = torch.zeros((T, k), dtype=torch.int32, device='cuda')
+    w_d = torch.zeros((T, k), dtype=torch.float32, device='cuda')
+    _ffi.check(tm.tm_moe_forward(h, out.data_ptr(), dev(x).data_ptr(), T, ws.data_ptr(), ids_d.data_ptr(), w_d.data_ptr(), st()))
+    ref, ids, w = o.moe_ffn(x, gate, experts, k)
+    assert np.array_equal(host(ids_d), ids), 'routing differs'
+    assert np.abs(host(w_d) - w).max() <= 1e-5
+    err = np.abs(host(out).astype(np.float32) - ref.astype(np.float32))
+    assert np.all(err <= 3e-3 + 2.0**-8 * np.abs(ref.astype(np.float32))), f'max err {err.max()}'
+    _ffi.check(tm.tm_moe_destroy(h))
+
+
 def test_w4a16_identity_asymmetric(tm, cuda):
     """Transpose-detecting check: x = I (first K rows) picks out rows of the dequantised weight exactly."""
     rng = np.random.default_rng(3)
