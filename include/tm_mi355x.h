@@ -188,7 +188,11 @@ typedef struct tm_model_config {
     float rope_factor, rope_low_freq_factor, rope_high_freq_factor;
     int   rope_original_max_position;
     int   group_size;   /* 128 */
-    int   weight_type;  /* TM_WEIGHT_U4 (AWQ) or TM_WEIGHT_F16 for the decoder linears; lm_head is always fp16 */
+    int   weight_type;  /* TM_WEIGHT_U4 (AWQ), TM_WEIGHT_F16 or TM_WEIGHT_FP8 for the decoder linears; lm_head is fp16 */
+    /* mixture of experts (0 experts = dense FFN): every layer's FFN is a router + `moe_experts` expert FFNs of width
+     * `inter` (sharded over tp like the dense FFN), `moe_top_k` per token (Mixtral: 8 / 2, norm_topk = 1) */
+    int   moe_experts, moe_top_k, moe_norm_topk;
+    float moe_routed_scale;
 } tm_model_config;
 
 typedef struct tm_engine_config {

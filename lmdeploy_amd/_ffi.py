@@ -37,7 +37,8 @@ class ModelConfig(C.Structure):
                 ('inter', c_int), ('vocab', c_int), ('rms_eps', c_float), ('rope_base', c_float),
                 ('rope_type', c_int), ('rope_factor', c_float), ('rope_low_freq_factor', c_float),
                 ('rope_high_freq_factor', c_float), ('rope_original_max_position', c_int), ('group_size', c_int),
-                ('weight_type', c_int)]
+                ('weight_type', c_int), ('moe_experts', c_int), ('moe_top_k', c_int), ('moe_norm_topk', c_int),
+                ('moe_routed_scale', c_float)]
 
 
 class EngineConfig(C.Structure):

@@ -76,6 +76,29 @@ __global__ void fill_normal_kernel(half_t* out, size_t n, float mean, float stdd
     }
 }
 
+__global__ void fill_fp8_kernel(uint8_t* out, size_t n, uint64_t seed)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        uint64_t z = (i + 1) * 0x9E3779B97F4A7C15ull + seed * 0xD1B54A32D192ED03ull;
+        z          = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z          = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        uint8_t b  = (uint8_t)(z >> 33);
+        if ((b & 0x7f) == 0x7f) {
+            b &= 0xf7;  // never NaN
+        }
+        out[i] = b;
+    }
+}
+
+__global__ void fill_const_f32_kernel(float* out, size_t n, float v)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        out[i] = v;
+    }
+}
+
 __global__ void advance_kernel(int* k_len, int batch)
 {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
@@ -152,6 +175,10 @@ struct Layer {
     LinearSlots qkv, wo, w13, w2;
     half_t*     attn_norm = nullptr;
     half_t*     ffn_norm  = nullptr;
+    // mixture of experts: the dense w13 / w2 are unused; gate slot + per-expert slots feed `moe`
+    bool                     is_moe = false;
+    std::vector<LinearSlots> ex13, ex2;
+    MoeBlock                 moe;
 };
 
 }  // namespace tmk
@@ -242,6 +269,7 @@ struct tm_engine {
     int*      d_topk = nullptr;
     uint64_t* d_seed = nullptr;
     void*     d_sample_ws = nullptr;
+    void*     d_moe_ws    = nullptr;  // routing tables + expert activations of one forward (moe_workspace_bytes)
     std::vector<tm_sampling>       h_sampling;      // static batch: parameters of the next prefill
     std::map<int64_t, tm_sampling> cb_sampling;     // continuous batching: per request
 };
@@ -253,6 +281,8 @@ static int64_t slot_bytes_linear(const tm_engine* e, int K, int N, const char* p
     if (!strcmp(part, "qweight")) return (int64_t)K * N / 2;
     if (!strcmp(part, "scales") || !strcmp(part, "zeros")) return (int64_t)(K / e->cfg.model.group_size) * N * 2;
     if (!strcmp(part, "weight")) return (int64_t)K * N * 2;
+    if (!strcmp(part, "weight_fp8")) return (int64_t)K * N;
+    if (!strcmp(part, "scales_fp8")) return (int64_t)(K / 128) * ((N + 127) / 128) * 4;
     return 0;
 }
 
@@ -267,6 +297,10 @@ static void add_linear(tm_engine* e, LinearSlots& l, const std::string& prefix, 
         for (const char* part : {"qweight", "scales", "zeros"}) {
             e->slots[prefix + "." + part].bytes = slot_bytes_linear(e, K, N, part);
         }
+    }
+    else if (type == TM_WEIGHT_FP8) {  // e4m3 [K][N] + fp32 128x128 block scales (weight_format.py:349-393)
+        e->slots[prefix + ".weight"].bytes = slot_bytes_linear(e, K, N, "weight_fp8");
+        e->slots[prefix + ".scales"].bytes = slot_bytes_linear(e, K, N, "scales_fp8");
     }
     else {
         e->slots[prefix + ".weight"].bytes = slot_bytes_linear(e, K, N, "weight");
@@ -301,6 +335,16 @@ static int prepare_linear(tm_engine* e, LinearSlots& l)
         TM_TRY(linear_weight_prepare_u4(l.w, (const int32_t*)q.dev, (const half_t*)s.dev, (const half_t*)z.dev, e->stream));
         TM_HIP_CHECK(hipStreamSynchronize(e->stream));
         for (Slot* p : {&q, &s, &z}) {
+            TM_HIP_CHECK(hipFree(p->dev));
+            p->dev = nullptr;
+        }
+    }
+    else if (l.w.type == TM_WEIGHT_FP8) {
+        Slot &w = e->slots[l.prefix + ".weight"], &s = e->slots[l.prefix + ".scales"];
+        TM_REQUIRE(w.filled && s.filled, "weight not loaded: " + l.prefix);
+        TM_TRY(linear_weight_prepare_fp8(l.w, (const uint8_t*)w.dev, (const float*)s.dev, e->stream));
+        TM_HIP_CHECK(hipStreamSynchronize(e->stream));
+        for (Slot* p : {&w, &s}) {
             TM_HIP_CHECK(hipFree(p->dev));
             p->dev = nullptr;
         }
@@ -468,8 +512,17 @@ static int forward(tm_engine* e, const int* d_ids, int M, int nseq, bool decode,
             TM_PROF(P_ATTN, TM_TRY(launch_prefill_attention(p, st)));
         }
         TM_TRY(linear_residual_norm(e, L.wo, e->d_attn, e->q_heads * e->D, M, L.ffn_norm, P_GEMM_O));
-        TM_PROF(P_GEMM_GATE_UP, TM_TRY(linear_plain(e, L.w13, e->d_x, e->hidden, e->d_act, e->inter, M, true)));
         const half_t* next_norm = li + 1 < m.layers ? e->layers[li + 1].attn_norm : e->final_norm;
+        if (L.is_moe) {
+            // router + grouped expert FFNs + combine -> d_tmp, then (all-reduce +) residual + RMSNorm as for the dense FFN
+            TM_PROF(P_GEMM_GATE_UP, TM_TRY(moe_forward(L.moe, e->d_tmp, e->hidden, e->d_x, e->hidden, M, e->d_moe_ws, nullptr,
+                                                       nullptr, st)));
+            TM_PROF(P_ALLREDUCE, TM_TRY(allreduce_hidden(e, e->d_tmp, M)));
+            TM_PROF(P_RES_NORM, TM_TRY(launch_residual_rmsnorm(e->d_x, e->d_resid, e->d_tmp, nullptr, 0, nullptr, next_norm,
+                                                               m.rms_eps, M, e->hidden, st)));
+            continue;
+        }
+        TM_PROF(P_GEMM_GATE_UP, TM_TRY(linear_plain(e, L.w13, e->d_x, e->hidden, e->d_act, e->inter, M, true)));
         TM_TRY(linear_residual_norm(e, L.w2, e->d_act, e->inter, M, next_norm, P_GEMM_DOWN));
     }
     // last-token hidden states -> logits -> greedy
@@ -545,7 +598,7 @@ int tm_engine_create(tm_engine** out, const tm_engine_config* c)
     TM_REQUIRE(c->quant_policy == 0 || c->quant_policy == 4 || c->quant_policy == 8,
                "quant_policy in {0,4,8} (lmdeploy/messages.py:351-358)");
     TM_REQUIRE(c->cache_block_seq_len == 64, "cache_block_seq_len must be 64");
-    TM_REQUIRE(m.weight_type == TM_WEIGHT_U4 || m.weight_type == TM_WEIGHT_F16, "weight_type");
+    TM_REQUIRE(m.weight_type == TM_WEIGHT_U4 || m.weight_type == TM_WEIGHT_F16 || m.weight_type == TM_WEIGHT_FP8, "weight_type");
     TM_REQUIRE(c->max_batch_size >= 1 && c->max_batch_size <= 1024 && c->session_len >= 1,
                "1 <= max_batch_size <= 1024, session_len >= 1");
     TM_HIP_CHECK(hipSetDevice(c->device));
@@ -564,6 +617,9 @@ int tm_engine_create(tm_engine** out, const tm_engine_config* c)
     e->qkv_n       = (e->q_heads + 2 * e->kv_heads) * e->D;
     TM_REQUIRE((e->inter * 1) % 128 == 0 && (e->q_heads * e->D) % 128 == 0 && m.hidden % 128 == 0,
                "K dims must be multiples of 128 after TP sharding");
+    TM_REQUIRE(m.moe_experts == 0 || (m.moe_experts <= 64 && m.moe_top_k >= 1 && m.moe_top_k <= 8 && m.moe_top_k <= m.moe_experts
+                                      && m.weight_type != TM_WEIGHT_F16),
+               "moe: 1 <= top_k <= experts <= 64, top_k <= 8, u4 or fp8 expert weights");
     TM_HIP_CHECK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
 
     e->layers.resize(m.layers);
@@ -572,8 +628,21 @@ int tm_engine_create(tm_engine** out, const tm_engine_config* c)
         Layer&            L = e->layers[i];
         add_linear(e, L.qkv, p + ".attention.w_qkv", m.hidden, e->qkv_n, m.weight_type);
         add_linear(e, L.wo, p + ".attention.wo", e->q_heads * e->D, m.hidden, m.weight_type);
-        add_linear(e, L.w13, p + ".feed_forward.w1w3", m.hidden, 2 * e->inter, m.weight_type);
-        add_linear(e, L.w2, p + ".feed_forward.w2", e->inter, m.hidden, m.weight_type);
+        if (m.moe_experts > 0) {
+            L.is_moe = true;
+            L.ex13.resize(m.moe_experts);
+            L.ex2.resize(m.moe_experts);
+            e->slots[p + ".moe_ffn.gate.weight"].bytes = (int64_t)m.hidden * m.moe_experts * 2;  // fp16 [H][E], replicated
+            for (int x = 0; x < m.moe_experts; ++x) {
+                const std::string q = p + ".moe_ffn.experts." + std::to_string(x);
+                add_linear(e, L.ex13[x], q + ".w1w3", m.hidden, 2 * e->inter, m.weight_type);
+                add_linear(e, L.ex2[x], q + ".w2", e->inter, m.hidden, m.weight_type);
+            }
+        }
+        else {
+            add_linear(e, L.w13, p + ".feed_forward.w1w3", m.hidden, 2 * e->inter, m.weight_type);
+            add_linear(e, L.w2, p + ".feed_forward.w2", e->inter, m.hidden, m.weight_type);
+        }
         e->slots[p + ".attention_norm.weight"].bytes = (int64_t)m.hidden * 2;
         e->slots[p + ".ffn_norm.weight"].bytes       = (int64_t)m.hidden * 2;
     }
@@ -650,6 +719,20 @@ int tm_engine_init_synthetic(tm_engine* e, uint64_t seed)
             w->filled = true;
             return 0;
         }
+        if (l.w.type == TM_WEIGHT_FP8) {
+            // random e4m3 codes (no NaN), one constant block scale: E|code value| ~ 30 -> weights ~ 0.1 / sqrt(K)
+            Slot *w = nullptr, *sc = nullptr;
+            TM_TRY(ensure_slot(e, l.prefix + ".weight", &w));
+            TM_TRY(ensure_slot(e, l.prefix + ".scales", &sc));
+            fill_fp8_kernel<<<(n + 255) / 256, 256, 0, e->stream>>>((uint8_t*)w->dev, n, ++sd);
+            TM_HIP_CHECK(hipGetLastError());
+            const size_t nsc = (size_t)sc->bytes / 4;
+            fill_const_f32_kernel<<<(nsc + 255) / 256, 256, 0, e->stream>>>((float*)sc->dev, nsc, 0.0027f / std::sqrt((float)l.w.K));
+            TM_HIP_CHECK(hipGetLastError());
+            w->filled = sc->filled = true;
+            TM_TRY(prepare_linear(e, l));
+            return 0;
+        }
         if (n > master_elems) {
             if (master) {
                 TM_HIP_CHECK(hipStreamSynchronize(e->stream));
@@ -682,8 +765,17 @@ int tm_engine_init_synthetic(tm_engine* e, uint64_t seed)
         Layer&            L = e->layers[i];
         TM_TRY(linear(L.qkv));
         TM_TRY(linear(L.wo));
-        TM_TRY(linear(L.w13));
-        TM_TRY(linear(L.w2));
+        if (L.is_moe) {
+            TM_TRY(vec(p + ".moe_ffn.gate.weight", (size_t)m.hidden * m.moe_experts, 0.f, 0.05f));
+            for (int x = 0; x < m.moe_experts; ++x) {
+                TM_TRY(linear(L.ex13[x]));
+                TM_TRY(linear(L.ex2[x]));
+            }
+        }
+        else {
+            TM_TRY(linear(L.w13));
+            TM_TRY(linear(L.w2));
+        }
         TM_TRY(vec(p + ".attention_norm.weight", m.hidden, 1.f, 0.02f));
         TM_TRY(vec(p + ".ffn_norm.weight", m.hidden, 1.f, 0.02f));
     }
@@ -714,9 +806,42 @@ int tm_engine_process_weights(tm_engine* e)
     for (int i = 0; i < m.layers; ++i) {
         const std::string p = "layers." + std::to_string(i);
         Layer&            L = e->layers[i];
-        for (LinearSlots* l : {&L.qkv, &L.wo, &L.w13, &L.w2}) {
+        for (LinearSlots* l : {&L.qkv, &L.wo}) {
             if (!l->w.packed) {
                 TM_TRY(prepare_linear(e, *l));
+            }
+        }
+        if (L.is_moe) {
+            L.moe.hidden       = m.hidden;
+            L.moe.inter        = e->inter;
+            L.moe.experts      = m.moe_experts;
+            L.moe.top_k        = m.moe_top_k;
+            L.moe.norm_topk    = m.moe_norm_topk != 0;
+            L.moe.routed_scale = m.moe_routed_scale > 0.f ? m.moe_routed_scale : 1.f;
+            L.moe.w13.resize(m.moe_experts);
+            L.moe.w2.resize(m.moe_experts);
+            for (int x = 0; x < m.moe_experts; ++x) {
+                for (LinearSlots* l : {&L.ex13[x], &L.ex2[x]}) {
+                    if (!l->w.packed) {
+                        TM_TRY(prepare_linear(e, *l));
+                    }
+                }
+                L.moe.w13[x] = L.ex13[x].w;  // the MoE block owns the packed weights from here on
+                L.moe.w2[x]  = L.ex2[x].w;
+                L.ex13[x].w.packed = nullptr, L.ex13[x].w.sz = nullptr;
+                L.ex2[x].w.packed = nullptr, L.ex2[x].w.sz = nullptr;
+            }
+            Slot& g = e->slots[p + ".moe_ffn.gate.weight"];
+            TM_REQUIRE(g.filled, "weight not loaded: " + p + ".moe_ffn.gate.weight");
+            L.moe.gate = (half_t*)g.dev;  // used in place (freed by moe_free)
+            g.dev      = nullptr;
+            TM_TRY(moe_prepare(L.moe, e->stream));
+        }
+        else {
+            for (LinearSlots* l : {&L.w13, &L.w2}) {
+                if (!l->w.packed) {
+                    TM_TRY(prepare_linear(e, *l));
+                }
             }
         }
         TM_TRY(norm(p + ".attention_norm.weight", &L.attn_norm));
@@ -760,6 +885,9 @@ int tm_engine_start(tm_engine* e)
     // split-K workspace: decode-sized problems only (M <= 64 rows x widest N x 16 slabs)
     e->gemm_ws_bytes = (size_t)16 * 64 * std::max(std::max(e->qkv_n, 2 * e->inter), e->hidden) * sizeof(float);
     TM_HIP_CHECK(hipMalloc((void**)&e->d_gemm_ws, e->gemm_ws_bytes));
+    if (m.moe_experts > 0) {
+        TM_HIP_CHECK(hipMalloc(&e->d_moe_ws, moe_workspace_bytes(e->layers[0].moe, e->max_tokens)));
+    }
     // prefill scratch: every sequence padded to a multiple of 64 keys
     e->kflat_stride = ((e->max_tokens + c.session_len + 63) / 64) * 64 + 64 * (std::min(B, e->max_tokens) + 1);
     TM_TRY(dmalloc(&e->d_kflat, (size_t)e->kv_heads * e->kflat_stride * e->D));
@@ -1476,6 +1604,12 @@ int tm_engine_stats(tm_engine* e, int64_t* weight_bytes, int64_t* kv_bytes_per_t
         for (const LinearSlots* l : {&L.qkv, &L.wo, &L.w13, &L.w2}) {
             wb += (int64_t)l->w.packed_bytes + (int64_t)l->w.sz_bytes;
         }
+        if (L.is_moe) {
+            for (int x = 0; x < L.moe.experts; ++x) {
+                wb += (int64_t)L.moe.w13[x].packed_bytes + (int64_t)L.moe.w13[x].sz_bytes + (int64_t)L.moe.w2[x].packed_bytes
+                      + (int64_t)L.moe.w2[x].sz_bytes;
+            }
+        }
     }
     wb += (int64_t)e->output.w.packed_bytes;
     if (weight_bytes) *weight_bytes = wb;
@@ -1510,6 +1644,18 @@ int tm_engine_destroy(tm_engine* e)
         for (LinearSlots* l : {&L.qkv, &L.wo, &L.w13, &L.w2}) {
             linear_weight_free(l->w);
         }
+        for (auto& l : L.ex13) {
+            linear_weight_free(l.w);
+        }
+        for (auto& l : L.ex2) {
+            linear_weight_free(l.w);
+        }
+        if (L.is_moe) {
+            moe_free(L.moe);
+        }
+    }
+    if (e->d_moe_ws) {
+        (void)hipFree(e->d_moe_ws);
     }
     linear_weight_free(e->output.w);
     for (auto& kv : e->slots) {

@@ -23,7 +23,9 @@ def make_model_config(cfg, weight_type: int = 0) -> _ffi.ModelConfig:
     r = cfg.rope
     return _ffi.ModelConfig(cfg.hidden, cfg.layers, cfg.q_heads, cfg.kv_heads, cfg.head_dim, cfg.inter, cfg.vocab,
                             cfg.rms_eps, r.base, _ROPE_TYPES[r.type], r.factor, r.low_freq_factor, r.high_freq_factor,
-                            r.original_max_position_embeddings, cfg.group, weight_type)
+                            r.original_max_position_embeddings, cfg.group, weight_type,
+                            int(getattr(cfg, 'moe_experts', 0) or 0), int(getattr(cfg, 'moe_top_k', 0) or 0),
+                            int(bool(getattr(cfg, 'moe_norm_topk', True))), float(getattr(cfg, 'moe_routed_scale', 1.0)))
 
 
 class Engine:

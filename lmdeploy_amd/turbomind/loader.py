@@ -54,6 +54,9 @@ def _shard_linear(lin: dict, kind: str, tp: int, rank: int, group: int, col_slic
     """lin: {'q','s','z'} (u4 as uint8 [K,N], fp16 [K/g,N]) or {'w'} fp16 [K,N].
     kind 'col': take `col_slices` (list of (lo,hi)) of the output dim; 'row': split the input dim evenly."""
     out = {}
+    if 'f8' in lin:
+        assert tp == 1, 'fp8 block-scaled weights: TP sharding of the 128x128 scale blocks is not implemented in this loader'
+        return dict(lin)
     if kind == 'col':
         for k, t in lin.items():
             out[k] = np.concatenate([_cols(t, lo, hi) for lo, hi in col_slices], axis=-1)
@@ -71,6 +74,9 @@ def _emit(slots: dict, prefix: str, lin: dict):
         slots[prefix + '.qweight'] = np.ascontiguousarray(pack_u4_row(lin['q']))
         slots[prefix + '.scales'] = np.ascontiguousarray(lin['s'], dtype=np.float16)
         slots[prefix + '.zeros'] = np.ascontiguousarray(lin['z'], dtype=np.float16)
+    elif 'f8' in lin:        # e4m3 codes [K,N] + fp32 128x128 block scales (lmdeploy/turbomind/weight_format.py:349-393)
+        slots[prefix + '.weight'] = np.ascontiguousarray(lin['f8'], dtype=np.uint8)
+        slots[prefix + '.scales'] = np.ascontiguousarray(lin['bs'], dtype=np.float32)
     else:
         slots[prefix + '.weight'] = np.ascontiguousarray(lin['w'], dtype=np.float16)
 
@@ -99,9 +105,16 @@ def export_weights(cfg, weights: dict, tp: int = 1, rank: int = 0) -> dict:
         p = f'layers.{li}'
         _emit(slots, p + '.attention.w_qkv', _shard_linear(L['w_qkv'], 'col', tp, rank, G, qkv_slices))
         _emit(slots, p + '.attention.wo', _shard_linear(L['wo'], 'row', tp, rank, G))
-        _emit(slots, p + '.feed_forward.w1w3',
-              _shard_linear(L['w1w3'], 'col', tp, rank, G, [(2 * rank * i_l, 2 * (rank + 1) * i_l)]))
-        _emit(slots, p + '.feed_forward.w2', _shard_linear(L['w2'], 'row', tp, rank, G))
+        if 'experts' in L:     # mixture of experts: replicated router, every expert sharded like the dense FFN
+            slots[p + '.moe_ffn.gate.weight'] = np.ascontiguousarray(L['moe_gate'], dtype=np.float16)
+            for x, E_ in enumerate(L['experts']):
+                q = f'{p}.moe_ffn.experts.{x}'
+                _emit(slots, q + '.w1w3', _shard_linear(E_['w1w3'], 'col', tp, rank, G, [(2 * rank * i_l, 2 * (rank + 1) * i_l)]))
+                _emit(slots, q + '.w2', _shard_linear(E_['w2'], 'row', tp, rank, G))
+        else:
+            _emit(slots, p + '.feed_forward.w1w3',
+                  _shard_linear(L['w1w3'], 'col', tp, rank, G, [(2 * rank * i_l, 2 * (rank + 1) * i_l)]))
+            _emit(slots, p + '.feed_forward.w2', _shard_linear(L['w2'], 'row', tp, rank, G))
         slots[p + '.attention_norm.weight'] = np.ascontiguousarray(L['attn_norm'], dtype=np.float16)
         slots[p + '.ffn_norm.weight'] = np.ascontiguousarray(L['ffn_norm'], dtype=np.float16)
     slots['tok_embeddings.weight'] = np.ascontiguousarray(weights['tok_embeddings'], dtype=np.float16)

@@ -676,6 +676,12 @@ class ModelConfig:
     group: int = 128
     kv_bits: int = 8
     block_len: int = 64
+    # BASELINE config 5: fp8 block-scaled weights, mixture-of-experts FFN (0 experts = dense)
+    weight_format: str = 'u4'          # 'u4' (AWQ g128) | 'fp8' (e4m3, 128x128 block scales)
+    moe_experts: int = 0
+    moe_top_k: int = 0
+    moe_norm_topk: bool = True
+    moe_routed_scale: float = 1.0
 
 
 LLAMA3_8B = dict(hidden=4096, layers=32, q_heads=32, kv_heads=8, head_dim=128, inter=14336, vocab=128256,
@@ -702,6 +708,9 @@ def make_synthetic_weights(cfg: ModelConfig, seed: int = 0, quantized: bool = Tr
         w = (rng.standard_normal((K, N), dtype=f32) * (0.1 / math.sqrt(K))).astype(f16)
         if not quantized:
             return dict(w=w)
+        if cfg.weight_format == 'fp8':
+            f8, bs = fp8_quantize_blockwise(w)
+            return dict(f8=f8, bs=bs)
         q, s, z, _ = quantize_groupwise_u4(w, cfg.group)
         return dict(q=q, s=s, z=z)
 
@@ -712,8 +721,9 @@ def make_synthetic_weights(cfg: ModelConfig, seed: int = 0, quantized: bool = Tr
             w_qkv=lin(H, nq + 2 * nkv),
             wo=lin(nq, H),
             ffn_norm=(1 + 0.02 * rng.standard_normal(H, dtype=f32)).astype(f16),
-            w1w3=lin(H, 2 * I),
-            w2=lin(I, H),
+            **(dict(moe_gate=(0.2 * rng.standard_normal((H, cfg.moe_experts), dtype=f32)).astype(f16),
+                    experts=[dict(w1w3=lin(H, 2 * I), w2=lin(I, H)) for _ in range(cfg.moe_experts)])
+               if cfg.moe_experts else dict(w1w3=lin(H, 2 * I), w2=lin(I, H))),
         ))
     return dict(
         tok_embeddings=(0.02 * rng.standard_normal((cfg.vocab, H), dtype=f32)).astype(f16),
@@ -723,8 +733,18 @@ def make_synthetic_weights(cfg: ModelConfig, seed: int = 0, quantized: bool = Tr
     )
 
 
-def _linear(x, W, group, gated=False):
+def _dense_weight(W, group):
     if 'q' in W:
+        return w4a16_dequant(W['q'], W['s'], W['z'], group)
+    if 'f8' in W:
+        return fp8_dequant(W['f8'], W['bs'])
+    return W['w']
+
+
+def _linear(x, W, group, gated=False):
+    if 'f8' in W:
+        acc = gemm_f16_f32acc(x, fp8_dequant(W['f8'], W['bs']))
+    elif 'q' in W:
         acc = gemm_f16_f32acc(x, w4a16_dequant(W['q'], W['s'], W['z'], group))
     else:
         acc = gemm_f16_f32acc(x, W['w'])
@@ -789,8 +809,12 @@ class OracleModel:
                     attn[sl] = prefill_attention(q, Kf, Vf, hist, self.c).reshape(n, -1)
             o = _linear(attn, Lw['wo'], cfg.group)
             resid, x = residual_rmsnorm(resid, o, Lw['ffn_norm'], cfg.rms_eps)
-            act = _linear(x, Lw['w1w3'], cfg.group, gated=True)
-            d = _linear(act, Lw['w2'], cfg.group)
+            if cfg.moe_experts:
+                ex = [(_dense_weight(E_['w1w3'], cfg.group), _dense_weight(E_['w2'], cfg.group)) for E_ in Lw['experts']]
+                d, _, _ = moe_ffn(x, Lw['moe_gate'], ex, cfg.moe_top_k, cfg.moe_norm_topk, cfg.moe_routed_scale)
+            else:
+                act = _linear(x, Lw['w1w3'], cfg.group, gated=True)
+                d = _linear(act, Lw['w2'], cfg.group)
             nxt = self.w['layers'][li + 1]['attn_norm'] if li + 1 < cfg.layers else self.w['norm']
             resid, x = residual_rmsnorm(resid, d, nxt, cfg.rms_eps)
         last = np.array([offs[b + 1] - 1 for b in range(len(lens)) if lens[b] > 0])

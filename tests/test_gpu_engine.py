@@ -276,6 +276,39 @@ def test_engine_other_config_shapes(cuda, q_heads, kv_heads, kv_bits, hidden):
         assert d.max() <= 3e-2, f'step {s_}: max logit diff {d.max()}'
 
 
+@pytest.mark.parametrize('fmt', ['fp8', 'u4'])
+def test_engine_moe_matches_oracle(cuda, fmt):
+    """BASELINE config 5 scaled down: mixture-of-experts decoder (router, top-2 of 4 experts, grouped expert GEMMs,
+    combine) with fp8 block-scaled (or AWQ) weights in every linear, int8 KV; prefill (grouped GEMM with row blocks) +
+    decode against the oracle model.  Same bar as test_engine_matches_oracle."""
+    cfg = o.ModelConfig(hidden=256, layers=2, q_heads=4, kv_heads=2, head_dim=128, inter=256, vocab=512, kv_bits=8,
+                        rope=o.RopeParam(128, 1000000.0, 'default', 1.0, 1.0, 4.0, 8192), weight_format=fmt,
+                        moe_experts=4, moe_top_k=2)
+    w = o.make_synthetic_weights(cfg, seed=5)
+    rng = np.random.default_rng(8)
+    prompts = [rng.integers(0, cfg.vocab, n).astype(np.int32) for n in (70, 9, 33)]
+    steps = 4
+    eng = Engine.from_model_config(cfg, weight_type=2 if fmt == 'fp8' else 0, max_batch_size=3, session_len=128, quant_policy=8)
+    eng.load_weights(export_weights(cfg, w))
+    eng.start()
+    eng.prefill(prompts, max_new_tokens=steps + 1)
+    logits = [eng.fetch_logits()]
+    for _ in range(steps):
+        eng.decode(1)
+        logits.append(eng.fetch_logits())
+    toks = eng.fetch()
+    eng.close()
+    om = o.OracleModel(cfg, w, batch=len(prompts), max_ctx=128)
+    ids, lg = om.forward(prompts)
+    ref = [lg]
+    for s_ in range(steps):
+        ids, lg = om.forward([[int(t)] for t in toks[:, s_]])
+        ref.append(lg)
+    for s_ in range(steps + 1):
+        d = np.abs(logits[s_].astype(np.float32) - ref[s_].astype(np.float32))
+        assert d.max() <= 3e-2, f'step {s_}: max logit diff {d.max()}'
+
+
 def test_engine_errors_are_status_codes(cuda):
     cfg = o.ModelConfig(hidden=256, layers=1, q_heads=2, kv_heads=1, head_dim=128, inter=256, vocab=512)
     eng = Engine.from_model_config(cfg, max_batch_size=2, session_len=128, quant_policy=8)
