@@ -29,7 +29,10 @@ LLAMA3_8B = dict(hidden=4096, layers=32, q_heads=32, kv_heads=8, head_dim=128, i
 # BASELINE.json configs 3 / 4 (parity-test cases; `--model` lets the same harness time them)
 INTERNLM2_20B = dict(hidden=6144, layers=48, q_heads=48, kv_heads=8, head_dim=128, inter=16384, vocab=92544, rms_eps=1e-5)
 LLAMA3_70B = dict(hidden=8192, layers=80, q_heads=64, kv_heads=8, head_dim=128, inter=28672, vocab=128256, rms_eps=1e-5)
-MODELS = {'llama3_8b': LLAMA3_8B, 'internlm2_20b': INTERNLM2_20B, 'llama3_70b': LLAMA3_70B}
+# config 5: Mixtral-8x7B, fp8 block-scaled weights, 8 experts / top-2 (TP = 2 in BASELINE.json; --emulate-tp 2 = one rank)
+MIXTRAL_8X7B = dict(hidden=4096, layers=32, q_heads=32, kv_heads=8, head_dim=128, inter=14336, vocab=32000, rms_eps=1e-5,
+                    moe_experts=8, moe_top_k=2, weight_type=2)
+MODELS = {'llama3_8b': LLAMA3_8B, 'internlm2_20b': INTERNLM2_20B, 'llama3_70b': LLAMA3_70B, 'mixtral_8x7b': MIXTRAL_8X7B}
 HBM_PEAK_GBPS = 8000.0     # MI355X HBM3E spec (/opt/skills/guides/MI355X_MICROARCH.md); 6290 measured copy
 
 
@@ -67,7 +70,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-graph', action='store_true', help='eager launches (rocprofv3 --pmc passes)')
     ap.add_argument('--layers', type=int, default=0, help='debug only: override the layer count (result is then INVALID)')
-    ap.add_argument('--model', default='llama3_8b', choices=['llama3_8b', 'internlm2_20b', 'llama3_70b'],
+    ap.add_argument('--model', default='llama3_8b', choices=['llama3_8b', 'internlm2_20b', 'llama3_70b', 'mixtral_8x7b'],
                     help='shapes to time; the headline metric is llama3_8b (anything else changes metric/config in the output)')
     ap.add_argument('--emulate-tp', type=int, default=0,
                     help='SURVEY 8(e) on a 1-GPU box: run ONE rank\'s shard of a TP=N job (heads / inter / vocab divided by N, '
@@ -99,7 +102,8 @@ def main():
     K, W, B, S = args.steps, args.warmup, args.batch, args.prompt_len
     P = args.profile_steps
     max_new = 1 + W + K + P + 2
-    eng = Engine.from_model_config(_Cfg(model), tp=world, rank=rank, device=local_rank, max_batch_size=B,
+    weight_type = int(model.pop('weight_type', 0))
+    eng = Engine.from_model_config(_Cfg(model), weight_type=weight_type, tp=world, rank=rank, device=local_rank, max_batch_size=B,
                                    session_len=S + max_new + 1, quant_policy=args.quant_policy,
                                    max_prefill_token_num=8192, use_graph=0 if args.no_graph else 1)
     if world > 1:
@@ -148,6 +152,10 @@ def main():
     ctx_prof = S + 1 + W + K + (P - 1) / 2.0
     toks = eng.fetch()
     stats = eng.stats()
+    if weight_type != 0 or model.get('moe_experts'):
+        # formats other than AWQ u4 / MoE: the weight bytes are what the engine actually streams (packed weights + scales +
+        # lm_head); with batch 64 and top-2 of 8 every expert is hit every step
+        step_bytes = stats['weight_bytes'] + B * ctx_mean * kv_tok
 
     if rank == 0:
         ms_step = dt / K * 1e3
