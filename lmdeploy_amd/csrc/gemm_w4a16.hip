@@ -1818,7 +1818,8 @@ int moe_build_groups(void** d_groups, const LinearWeight* experts, int E, hipStr
 }
 
 int launch_linear_grouped(const LinearWeight& proto, const void* d_groups, int E, const half_t* x, int ldx, int x_rows,
-                          half_t* y, int ldy, int m_cap, bool gated_silu, const int* seg, const int* row_idx, hipStream_t st)
+                          half_t* y, int ldy, int m_cap, int m_hint, bool gated_silu, const int* seg, const int* row_idx,
+                          hipStream_t st)
 {
     TM_REQUIRE(proto.type == 0 || proto.type == 2, "grouped GEMM: u4 or fp8 expert weights");
     TM_REQUIRE(ldx % 8 == 0 && (!gated_silu || proto.N % 32 == 0), "grouped GEMM: alignment");
@@ -1843,10 +1844,14 @@ int launch_linear_grouped(const LinearWeight& proto, const void* d_groups, int E
     p.x_rows       = x_rows;
     const int ntiles = proto.N / 16;
     int       rc     = 0;
-    if (m_cap <= 64) {  // decode: every expert sees at most `tokens` rows -> one 8-wave x 1-tile row block
-        const int mt = m_cap <= 16 ? 1 : (m_cap <= 32 ? 2 : 4);
-        p.zper       = 1;
-        dim3 grid((ntiles + 7) / 8, 1, E);
+    if (m_cap <= 64) {
+        // decode: an expert sees at most `tokens` rows but typically tokens * top_k / experts (m_hint): the row tile is
+        // sized for twice that, the (rare) overflow goes to further row blocks -- a 64-row tile for ~16 real rows would
+        // spend 3/4 of the MFMA and LDS work on clamped duplicates
+        const int want = std::min(m_cap, std::max(1, 2 * m_hint));
+        const int mt   = want <= 16 ? 1 : (want <= 32 ? 2 : 4);
+        p.zper         = (m_cap + 16 * mt - 1) / (16 * mt);
+        dim3 grid((ntiles + 7) / 8, 1, E * p.zper);
         if (proto.type == 0) {
             rc = mt == 1 ? launch_one<0, 1, 1, 8, 1, 1, 4>(p, grid, st) : mt == 2 ? launch_one<0, 2, 1, 8, 1, 1, 4>(p, grid, st) :
                                                                                     launch_one<0, 4, 1, 8, 1, 1, 4>(p, grid, st);

@@ -269,8 +269,9 @@ int moe_forward(const MoeBlock& m, half_t* out, int ldo, const half_t* x, int ld
     TM_TRY_RC(launch_moe_gate(ids, tw, nullptr, x, ldx, m.gate, tokens, m.hidden, m.experts, m.top_k, m.norm_topk, m.routed_scale, st));
     TM_TRY_RC(launch_moe_route(offs, f2n, en2f, ids, tokens, m.experts, m.top_k, st));
     // expert FFNs: gathered rows of x -> act (gated SiLU fused) -> y2, both grouped over the experts
-    TM_TRY_RC(launch_linear_grouped(m.w13[0], m.groups13, m.experts, x, ldx, tokens, act, m.inter, tokens, true, offs, f2n, st));
-    TM_TRY_RC(launch_linear_grouped(m.w2[0], m.groups2, m.experts, act, m.inter, (int)pairs, y2, m.hidden, tokens, false, offs,
+    const int hint = (int)((pairs + m.experts - 1) / m.experts);  // expected rows per expert
+    TM_TRY_RC(launch_linear_grouped(m.w13[0], m.groups13, m.experts, x, ldx, tokens, act, m.inter, tokens, hint, true, offs, f2n, st));
+    TM_TRY_RC(launch_linear_grouped(m.w2[0], m.groups2, m.experts, act, m.inter, (int)pairs, y2, m.hidden, tokens, hint, false, offs,
                                     nullptr, st));
     TM_TRY_RC(launch_moe_combine(out, ldo, y2, m.hidden, tw, en2f, tokens, m.hidden, m.top_k, st));
     if (topk_ids_out) {

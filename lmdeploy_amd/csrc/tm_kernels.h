@@ -151,7 +151,8 @@ void   moe_free(MoeBlock& m);
 // mixture of experts (moe.hip, grouped GEMM in gemm_w4a16.hip)
 int moe_build_groups(void** d_groups, const LinearWeight* experts, int E, hipStream_t st);
 int launch_linear_grouped(const LinearWeight& proto, const void* d_groups, int E, const half_t* x, int ldx, int x_rows,
-                          half_t* y, int ldy, int m_cap, bool gated_silu, const int* seg, const int* row_idx, hipStream_t st);
+                          half_t* y, int ldy, int m_cap, int m_hint, bool gated_silu, const int* seg, const int* row_idx,
+                          hipStream_t st);
 int launch_moe_gate(int* topk_ids, float* topk_w, float* logits_out, const half_t* x, int ldx, const half_t* wg, int T, int H,
                     int E, int k, bool norm_topk, float routed_scale, hipStream_t st);
 int launch_moe_route(int* offsets, int* f2n, int* en2f, const int* topk_ids, int T, int E, int k, hipStream_t st);
