@@ -286,7 +286,7 @@ __device__ __forceinline__ half8_t dequant8(uint32_t w, half2_t s2, half2_t z2, 
 // ABL: ablation bit mask for tools/ablate_gemm.sh (timing experiments only, results are garbage):
 //   1 no dequant VALU, 2 no MFMA, 4 no LDS x reads, 8 no x staging (loads + LDS writes), 16 no weight loads in the loop,
 //   32 half of the activation loads, 64 half of the activation LDS writes
-template<int WT, int MT, int NT, int WN, int WK, int KS, int PF, int ABL = 0>
+template<int WT, int MT, int NT, int WN, int WK, int KS, int PF, int ABL = 0, bool GRP = false>
 __global__ __launch_bounds__(WN * WK * 64) void gemm_kernel(GemmParams p)
 {
     static_assert(PF % 2 == 0, "ring depth must be even (LDS stages alternate)");
@@ -324,7 +324,7 @@ __global__ __launch_bounds__(WN * WK * 64) void gemm_kernel(GemmParams p)
     int         m0 = blockIdx.z * MB, row0 = 0, Mloc = p.M;
     const void* wq_base = p.wq;
     const void* sz_base = p.sz;
-    if (p.groups) {
+    if constexpr (GRP) {  // compile-time: the plain kernel keeps its exact instruction stream
         const int e  = blockIdx.z / p.zper;
         m0           = (blockIdx.z - e * p.zper) * MB;
         row0         = p.seg[e];
@@ -344,7 +344,7 @@ __global__ __launch_bounds__(WN * WK * 64) void gemm_kernel(GemmParams p)
     // Tiles past the edge are clamped: loads stay in bounds, stores are skipped.
     const auto rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)wq_base, 0, (int)((size_t)p.KB * ntiles * 1024 * WV), 0x00020000);
     const auto rs_s = __builtin_amdgcn_make_buffer_rsrc((void*)sz_base, 0, WT != 1 ? p.KB * ntiles * 64 : 0, 0x00020000);
-    const auto rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)(((size_t)((p.groups ? p.x_rows : p.M) - 1) * p.ldx + p.K) * 2), 0x00020000);
+    const auto rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)(((size_t)((GRP ? p.x_rows : p.M) - 1) * p.ldx + p.K) * 2), 0x00020000);
     int woff[NT], soff[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
@@ -381,7 +381,7 @@ __global__ __launch_bounds__(WN * WK * 64) void gemm_kernel(GemmParams p)
         const int m  = (qc >> 4) % MB;
         const int ci = qc & 15;
         int xrow     = row0 + min(m0 + m, Mloc - 1);
-        if (p.row_idx) {
+        if (GRP && p.row_idx) {
             xrow = p.row_idx[xrow];
         }
         xoff[r]      = (xrow * p.ldx + ci * 8) * 2 + sb * 256;
@@ -1430,7 +1430,7 @@ GemmConfig gemm_pick_config(const LinearWeight& w, int M)
     return cfg;
 }
 
-template<int WT, int MT, int NT, int WN, int WK, int KS, int PF, int ABL = 0>
+template<int WT, int MT, int NT, int WN, int WK, int KS, int PF, int ABL = 0, bool GRP = false>
 static int launch_one(const GemmParams& p, dim3 grid, hipStream_t st)
 {
     constexpr int stage = 2 * KS * WK * 16 * MT * 256;
@@ -1443,11 +1443,11 @@ static int launch_one(const GemmParams& p, dim3 grid, hipStream_t st)
     const int lds = (exclusive && WN * WK >= 8 && lds_need < 84 * 1024 && grid.x * grid.y * grid.z <= 256) ? 84 * 1024 : lds_need;
     static bool   attr_set = false;
     if (!attr_set) {
-        TM_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_kernel<WT, MT, NT, WN, WK, KS, PF, ABL>,
+        TM_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_kernel<WT, MT, NT, WN, WK, KS, PF, ABL, GRP>,
                                          hipFuncAttributeMaxDynamicSharedMemorySize, lds_need > 84 * 1024 ? lds_need : 84 * 1024));
         attr_set = true;
     }
-    gemm_kernel<WT, MT, NT, WN, WK, KS, PF, ABL><<<grid, WN * WK * 64, lds, st>>>(p);
+    gemm_kernel<WT, MT, NT, WN, WK, KS, PF, ABL, GRP><<<grid, WN * WK * 64, lds, st>>>(p);
     TM_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -1853,18 +1853,18 @@ int launch_linear_grouped(const LinearWeight& proto, const void* d_groups, int E
         p.zper         = (m_cap + 16 * mt - 1) / (16 * mt);
         dim3 grid((ntiles + 7) / 8, 1, E * p.zper);
         if (proto.type == 0) {
-            rc = mt == 1 ? launch_one<0, 1, 1, 8, 1, 1, 4>(p, grid, st) : mt == 2 ? launch_one<0, 2, 1, 8, 1, 1, 4>(p, grid, st) :
-                                                                                    launch_one<0, 4, 1, 8, 1, 1, 4>(p, grid, st);
+            rc = mt == 1 ? launch_one<0, 1, 1, 8, 1, 1, 4, 0, true>(p, grid, st) : mt == 2 ? launch_one<0, 2, 1, 8, 1, 1, 4, 0, true>(p, grid, st) :
+                                                                                    launch_one<0, 4, 1, 8, 1, 1, 4, 0, true>(p, grid, st);
         }
         else {
-            rc = mt == 1 ? launch_one<2, 1, 1, 8, 1, 1, 4>(p, grid, st) : mt == 2 ? launch_one<2, 2, 1, 8, 1, 1, 4>(p, grid, st) :
-                                                                                    launch_one<2, 4, 1, 8, 1, 1, 4>(p, grid, st);
+            rc = mt == 1 ? launch_one<2, 1, 1, 8, 1, 1, 4, 0, true>(p, grid, st) : mt == 2 ? launch_one<2, 2, 1, 8, 1, 1, 4, 0, true>(p, grid, st) :
+                                                                                    launch_one<2, 4, 1, 8, 1, 1, 4, 0, true>(p, grid, st);
         }
     }
     else {  // prefill: 64-row blocks x 2 tiles per wave; blocks past an expert's segment exit at once
         p.zper = (m_cap + 63) / 64;
         dim3 grid((ntiles + 15) / 16, 1, E * p.zper);
-        rc = proto.type == 0 ? launch_one<0, 4, 2, 8, 1, 1, 4>(p, grid, st) : launch_one<2, 4, 2, 8, 1, 1, 2>(p, grid, st);
+        rc = proto.type == 0 ? launch_one<0, 4, 2, 8, 1, 1, 4, 0, true>(p, grid, st) : launch_one<2, 4, 2, 8, 1, 1, 2, 0, true>(p, grid, st);
     }
     return rc;
 }
