@@ -294,6 +294,26 @@ int tm_engine_step(tm_engine* e, int* n_active, int* n_waiting);
 int tm_engine_poll(tm_engine* e, int64_t req_id, int* status, int* host_tokens, int cap, int* n_tokens);
 int tm_engine_cancel(tm_engine* e, int64_t req_id);
 
+/* Engine thread (the reference's Engine::Impl::InternalThreadEntry, engine/engine.cc:770-870, + the Gateway signal
+ * thread that runs the Python callback, bind.cpp:942-952).  After tm_engine_serve_start an engine-owned thread runs
+ * the schedule -> forward -> update loop whenever a request is queued or running, and sleeps otherwise;
+ * submit / submit_ex / poll / cancel / wait may then be called from ANY thread (they are serialised against the loop by
+ * the engine's mutex; without the loop they are serialised against each other the same way).  tm_engine_step returns
+ * TM_CONFLICT while the loop runs.  `on_update` (may be NULL) is called ON THE ENGINE THREAD, outside the engine lock,
+ * after every scheduler step, once per token produced in that step (a newly admitted request gets its first token
+ * from the prefill and its second from the decode pass of the same step), with the request's status at that token
+ * (0 = streaming, TM_FINISH) and its number of generated tokens so far; it is never called again for a request
+ * after a non-zero status (the reference's callback contract, turbomind.py:808-812).  It may call poll / submit / cancel.
+ * A device error inside the loop ends every unfinished request with TM_FAIL, stops the loop and is reported by
+ * tm_engine_serve_stop (return code + tm_last_error).  serve_stop joins the thread; requests that are still queued or
+ * running stay where they are (a later serve_start or tm_engine_step continues them). */
+typedef void (*tm_request_cb)(void* user, int64_t req_id, int status, int n_tokens);
+int tm_engine_serve_start(tm_engine* e, tm_request_cb on_update, void* user);
+int tm_engine_serve_stop(tm_engine* e);
+/* block until request req_id has more than `have_tokens` generated tokens or a non-zero status, or until timeout_ms
+ * elapsed (timeout_ms < 0: no timeout); returns the poll result.  Needs the engine thread (TM_INVALID otherwise). */
+int tm_engine_wait(tm_engine* e, int64_t req_id, int have_tokens, int timeout_ms, int* status, int* n_tokens);
+
 /* The scheduler by itself (host-only bookkeeping: queue, slots, block accounting) -- what the engine embeds,
  * exported so that its policy is testable without a GPU (engine/scheduler.cc:1018-1078 at the level used here). */
 typedef struct tm_sched tm_sched;
@@ -307,6 +327,8 @@ int tm_sched_cancel(tm_sched* s, int64_t req_id, int* released_slot);
 /* status (Request::k*), slot (-1 unless running), tokens generated, blocks held; TM_INVALID for unknown ids */
 int tm_sched_query(tm_sched* s, int64_t req_id, int* status, int* slot, int* n_generated, int* n_blocks);
 int tm_sched_counts(tm_sched* s, int* n_active, int* n_waiting, int* n_free_blocks);
+/* every unfinished request ends with `status` (the engine uses TM_FAIL after a device error) */
+int tm_sched_abort_all(tm_sched* s, int status);
 /* the engine's stream (hipStream_t) so callers can bracket it with their own events */
 tm_stream_t tm_engine_stream(tm_engine* e);
 /* introspection for benchmarks: bytes of quantised weights + scales + lm_head, KV bytes per token, #blocks */

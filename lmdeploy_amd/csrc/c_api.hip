@@ -487,6 +487,14 @@ int tm_sched_counts(tm_sched* s, int* n_active, int* n_waiting, int* n_free_bloc
     return 0;
 }
 
+int tm_sched_abort_all(tm_sched* s, int status)
+{
+    TM_REQUIRE(s, "null pointer");
+    TM_REQUIRE(status != 0, "abort status must be non-zero");
+    s->impl.abort_all(status);
+    return 0;
+}
+
 int tm_debug_set_gemm_trace(void* dev_buf)
 {
     tmk::g_gemm_dbg = (uint64_t*)dev_buf;

@@ -14,11 +14,15 @@
 #include "tm_common.h"
 #include "tm_kernels.h"
 #include <algorithm>
+#include <atomic>
 #include <cmath>
+#include <condition_variable>
 #include <cstring>
 #include <map>
 #include <memory>
+#include <mutex>
 #include <rccl/rccl.h>
+#include <thread>
 #include <chrono>
 #include <string>
 #include <tuple>
@@ -272,7 +276,39 @@ struct tm_engine {
     void*     d_moe_ws    = nullptr;  // routing tables + expert activations of one forward (moe_workspace_bytes)
     std::vector<tm_sampling>       h_sampling;      // static batch: parameters of the next prefill
     std::map<int64_t, tm_sampling> cb_sampling;     // continuous batching: per request
+
+    // engine thread (tm_engine_serve_start): runs step_locked() while requests exist.  `mu` serialises the scheduler
+    // and every device-side effect of submit / step / poll / cancel; API callers announce themselves in api_waiting so
+    // that the loop (which re-locks immediately) lets them in between two steps.
+    std::mutex              mu;
+    std::condition_variable cv_work, cv_out;
+    std::thread             loop;
+    std::atomic<int>        api_waiting{0};
+    std::atomic<bool>       loop_on{false};
+    bool                    loop_stop = false;
+    int                     loop_rc   = 0;
+    std::string             loop_err;
+    tm_request_cb           on_update      = nullptr;
+    void*                   on_update_user = nullptr;
 };
+
+namespace {
+// lock of an API call: counted, so that the engine thread yields to callers between steps
+struct ApiLock {
+    tm_engine*                   e;
+    std::unique_lock<std::mutex> lk;
+    explicit ApiLock(tm_engine* eng): e(eng), lk(eng->mu, std::defer_lock)
+    {
+        e->api_waiting.fetch_add(1);
+        lk.lock();
+        e->api_waiting.fetch_sub(1);
+    }
+};
+struct StepUpdate {
+    int64_t id;
+    int     status, n_tokens;
+};
+}  // namespace
 
 namespace tmk {
 
@@ -1160,7 +1196,7 @@ static int cb_park_slot(tm_engine* e, int slot)
 }
 
 // prefill the newly admitted requests (contiguous slot runs share one chunked prefill), hand over their first tokens
-static int cb_prefill_admitted(tm_engine* e, const std::vector<SchedAdmit>& admits)
+static int cb_prefill_admitted(tm_engine* e, const std::vector<SchedAdmit>& admits, std::vector<StepUpdate>* updates)
 {
     std::vector<SchedAdmit> sorted = admits;
     std::sort(sorted.begin(), sorted.end(), [](const SchedAdmit& a, const SchedAdmit& b) { return a.slot < b.slot; });
@@ -1211,7 +1247,13 @@ static int cb_prefill_admitted(tm_engine* e, const std::vector<SchedAdmit>& admi
         TM_HIP_CHECK(hipStreamSynchronize(e->stream));
         for (int k = 0; k < n; ++k) {
             e->h_active[slot0 + k] = 1;
-            if (e->sched->on_token(slot0 + k, first[k])) {  // finished on its first token
+            const int64_t rid      = e->sched->slot_request(slot0 + k);
+            const bool    finished = e->sched->on_token(slot0 + k, first[k]);
+            if (updates) {
+                const SchedRequest* r = e->sched->find(rid);
+                updates->push_back({rid, r->status, (int)r->out.size()});
+            }
+            if (finished) {  // finished on its first token
                 TM_TRY(cb_park_slot(e, slot0 + k));
             }
         }
@@ -1222,6 +1264,10 @@ static int cb_prefill_admitted(tm_engine* e, const std::vector<SchedAdmit>& admi
 
 int tm_engine_release(tm_engine* e)
 {
+    if (e && e->loop_on.load()) {
+        set_last_error("the engine thread is running (tm_engine_serve_stop first)");
+        return TM_CONFLICT;
+    }
     TM_REQUIRE(e, "null pointer");
     if (e->stream) {
         TM_HIP_CHECK(hipStreamSynchronize(e->stream));
@@ -1250,6 +1296,10 @@ int tm_engine_release(tm_engine* e)
 
 int tm_engine_prefill(tm_engine* e, const int* host_ids, const int* host_lens, int batch, int max_new_tokens)
 {
+    if (e && e->loop_on.load()) {
+        set_last_error("the engine thread is running (tm_engine_serve_stop first)");
+        return TM_CONFLICT;
+    }
     TM_REQUIRE(e && host_ids && host_lens, "null pointer");
     TM_REQUIRE(e->started, "engine not started");
     TM_REQUIRE(e->batch == 0 && !e->sched, "a batch is already admitted (release it first)");
@@ -1331,6 +1381,10 @@ int tm_engine_prefill(tm_engine* e, const int* host_ids, const int* host_lens, i
 
 int tm_engine_decode(tm_engine* e, int steps)
 {
+    if (e && e->loop_on.load()) {
+        set_last_error("the engine thread is running (tm_engine_serve_stop first)");
+        return TM_CONFLICT;
+    }
     TM_REQUIRE(e && e->batch > 0, "no admitted batch");
     TM_REQUIRE(!e->sched, "continuous-batching session active: use tm_engine_step");
     TM_HIP_CHECK(hipSetDevice(e->cfg.device));
@@ -1393,30 +1447,8 @@ int tm_engine_set_sampling(tm_engine* e, const tm_sampling* host_params, int bat
     return 0;
 }
 
-int tm_engine_submit_ex(tm_engine* e, const int* host_ids, int n, int max_new_tokens, int eos_id, const tm_sampling* sampling,
-                        int64_t* req_id)
+static int submit_locked(tm_engine* e, const int* host_ids, int n, int max_new_tokens, int eos_id, int64_t* req_id)
 {
-    TM_REQUIRE(e && req_id, "null pointer");
-    if (sampling) {
-        TM_REQUIRE(!e->use_comm, "stochastic sampling with tp > 1 is not supported in this round (greedy only)");
-        TM_REQUIRE(sampling->temperature > 0.f, "sampling: temperature must be > 0");
-    }
-    TM_TRY(tm_engine_submit(e, host_ids, n, max_new_tokens, eos_id, req_id));
-    if (sampling) {
-        e->cb_sampling[*req_id] = *sampling;
-        if (!e->sampling_on) {  // the first stochastic request switches the decode step to the sampling kernels
-            const int                B = e->cfg.max_batch_size;
-            std::vector<tm_sampling> greedy(B, tm_sampling{1.f, 1, 1.f, 0.f, 0});
-            TM_TRY(sampling_upload(e, greedy.data(), 0, B));
-            e->sampling_on = true;
-        }
-    }
-    return 0;
-}
-
-int tm_engine_submit(tm_engine* e, const int* host_ids, int n, int max_new_tokens, int eos_id, int64_t* req_id)
-{
-    TM_REQUIRE(e && host_ids && req_id, "null pointer");
     TM_TRY(cb_enter(e));
     const int rc = e->sched->submit(host_ids, n, max_new_tokens, eos_id, req_id);
     if (rc == TM_TOO_LONG) {
@@ -1431,16 +1463,47 @@ int tm_engine_submit(tm_engine* e, const int* host_ids, int n, int max_new_token
     return rc;
 }
 
-int tm_engine_step(tm_engine* e, int* n_active, int* n_waiting)
+int tm_engine_submit_ex(tm_engine* e, const int* host_ids, int n, int max_new_tokens, int eos_id, const tm_sampling* sampling,
+                        int64_t* req_id)
 {
-    TM_REQUIRE(e, "null pointer");
+    TM_REQUIRE(e && host_ids && req_id, "null pointer");
+    if (sampling) {
+        TM_REQUIRE(!e->use_comm, "stochastic sampling with tp > 1 is not supported in this round (greedy only)");
+        TM_REQUIRE(sampling->temperature > 0.f, "sampling: temperature must be > 0");
+    }
+    {
+        ApiLock lock(e);
+        TM_HIP_CHECK(hipSetDevice(e->cfg.device));
+        TM_TRY(submit_locked(e, host_ids, n, max_new_tokens, eos_id, req_id));
+        if (sampling) {
+            e->cb_sampling[*req_id] = *sampling;
+            if (!e->sampling_on) {  // the first stochastic request switches the decode step to the sampling kernels
+                const int                B = e->cfg.max_batch_size;
+                std::vector<tm_sampling> greedy(B, tm_sampling{1.f, 1, 1.f, 0.f, 0});
+                TM_TRY(sampling_upload(e, greedy.data(), 0, B));
+                e->sampling_on = true;
+            }
+        }
+    }
+    e->cv_work.notify_one();
+    return 0;
+}
+
+int tm_engine_submit(tm_engine* e, const int* host_ids, int n, int max_new_tokens, int eos_id, int64_t* req_id)
+{
+    return tm_engine_submit_ex(e, host_ids, n, max_new_tokens, eos_id, nullptr, req_id);
+}
+
+// one scheduler step; the caller holds e->mu.  `updates` (optional): requests that produced a token / finished
+static int step_locked(tm_engine* e, int* n_active, int* n_waiting, std::vector<StepUpdate>* updates)
+{
     TM_TRY(cb_enter(e));
     TM_HIP_CHECK(hipSetDevice(e->cfg.device));
     const int B = e->cfg.max_batch_size;
     // 1. admission + prefill (budget = max_prefill_token_num tokens of prompts per step)
     const std::vector<SchedAdmit> admits = e->sched->admit(e->max_tokens);
     if (!admits.empty()) {
-        TM_TRY(cb_prefill_admitted(e, admits));
+        TM_TRY(cb_prefill_admitted(e, admits, updates));
     }
     // 2. one decode step for everything that is running
     if (e->sched->n_active() > 0) {
@@ -1474,7 +1537,16 @@ int tm_engine_step(tm_engine* e, int* n_active, int* n_waiting)
         TM_HIP_CHECK(hipMemcpyAsync(e->h_step_ids.data(), e->d_ids, (size_t)B * 4, hipMemcpyDeviceToHost, e->stream));
         TM_HIP_CHECK(hipStreamSynchronize(e->stream));
         for (int b = 0; b < B; ++b) {
-            if (e->h_active[b] && e->sched->slot_request(b) >= 0 && e->sched->on_token(b, e->h_step_ids[b])) {
+            const int64_t id = e->sched->slot_request(b);
+            if (!e->h_active[b] || id < 0) {
+                continue;
+            }
+            const bool finished = e->sched->on_token(b, e->h_step_ids[b]);
+            if (updates) {
+                const SchedRequest* r = e->sched->find(id);
+                updates->push_back({id, r->status, (int)r->out.size()});
+            }
+            if (finished) {
                 TM_TRY(cb_park_slot(e, b));
             }
         }
@@ -1488,9 +1560,19 @@ int tm_engine_step(tm_engine* e, int* n_active, int* n_waiting)
     return 0;
 }
 
-int tm_engine_poll(tm_engine* e, int64_t req_id, int* status, int* host_tokens, int cap, int* n_tokens)
+int tm_engine_step(tm_engine* e, int* n_active, int* n_waiting)
 {
-    TM_REQUIRE(e && status && n_tokens, "null pointer");
+    TM_REQUIRE(e, "null pointer");
+    if (e->loop_on.load()) {
+        set_last_error("the engine thread owns the scheduler loop (tm_engine_serve_stop first)");
+        return TM_CONFLICT;
+    }
+    ApiLock lock(e);
+    return step_locked(e, n_active, n_waiting, nullptr);
+}
+
+static int poll_locked(tm_engine* e, int64_t req_id, int* status, int* host_tokens, int cap, int* n_tokens)
+{
     TM_REQUIRE(e->sched, "no continuous-batching session (submit first)");
     const SchedRequest* r = e->sched->find(req_id);
     if (!r) {
@@ -1500,25 +1582,144 @@ int tm_engine_poll(tm_engine* e, int64_t req_id, int* status, int* host_tokens, 
     *status   = r->status;
     *n_tokens = (int)r->out.size();
     if (host_tokens) {
-        memcpy(host_tokens, r->out.data(), (size_t)std::min(cap, *n_tokens) * 4);
+        memcpy(host_tokens, r->out.data(), (size_t)std::max(0, std::min(cap, *n_tokens)) * 4);
     }
     return 0;
+}
+
+int tm_engine_poll(tm_engine* e, int64_t req_id, int* status, int* host_tokens, int cap, int* n_tokens)
+{
+    TM_REQUIRE(e && status && n_tokens, "null pointer");
+    ApiLock lock(e);
+    return poll_locked(e, req_id, status, host_tokens, cap, n_tokens);
 }
 
 int tm_engine_cancel(tm_engine* e, int64_t req_id)
 {
     TM_REQUIRE(e, "null pointer");
-    TM_REQUIRE(e->sched, "no continuous-batching session (submit first)");
-    int       slot = -1;
-    const int rc   = e->sched->cancel(req_id, &slot);
-    if (rc) {
-        set_last_error("unknown request id");
-        return TM_INVALID;
+    {
+        ApiLock lock(e);
+        TM_REQUIRE(e->sched, "no continuous-batching session (submit first)");
+        int       slot = -1;
+        const int rc   = e->sched->cancel(req_id, &slot);
+        if (rc) {
+            set_last_error("unknown request id");
+            return TM_INVALID;
+        }
+        if (slot >= 0) {
+            TM_HIP_CHECK(hipSetDevice(e->cfg.device));
+            TM_TRY(cb_park_slot(e, slot));
+        }
     }
-    if (slot >= 0) {
-        TM_TRY(cb_park_slot(e, slot));
+    e->cv_out.notify_all();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// The engine thread: schedule -> forward -> update while requests exist, asleep otherwise.
+// ------------------------------------------------------------------------------------------------------------------
+static void serve_loop(tm_engine* e)
+{
+    (void)hipSetDevice(e->cfg.device);
+    std::vector<StepUpdate> updates;
+    for (;;) {
+        while (e->api_waiting.load() > 0) {  // callers queue on the mutex: let them in before the next step
+            std::this_thread::yield();
+        }
+        std::unique_lock<std::mutex> lk(e->mu);
+        e->cv_work.wait(lk, [&] { return e->loop_stop || (e->sched && e->sched->n_active() + e->sched->n_waiting() > 0); });
+        if (e->loop_stop) {
+            break;
+        }
+        updates.clear();
+        const int rc = step_locked(e, nullptr, nullptr, &updates);
+        if (rc) {  // device error: nothing that is queued or running can finish
+            e->loop_rc  = rc;
+            e->loop_err = tm_last_error();
+            updates.clear();
+            if (e->sched) {
+                const int B = e->cfg.max_batch_size;
+                for (int b = 0; b < B; ++b) {
+                    e->h_active[b] = 0;
+                }
+                e->sched->abort_all(TM_FAIL);
+            }
+            lk.unlock();
+            e->cv_out.notify_all();
+            break;
+        }
+        lk.unlock();
+        e->cv_out.notify_all();
+        if (e->on_update) {
+            for (const StepUpdate& u : updates) {
+                e->on_update(e->on_update_user, u.id, u.status, u.n_tokens);
+            }
+        }
+    }
+}
+
+int tm_engine_serve_start(tm_engine* e, tm_request_cb on_update, void* user)
+{
+    TM_REQUIRE(e, "null pointer");
+    TM_REQUIRE(e->started, "engine not started");
+    if (e->loop_on.load()) {
+        set_last_error("the engine thread is already running");
+        return TM_CONFLICT;
+    }
+    {
+        ApiLock lock(e);
+        TM_HIP_CHECK(hipSetDevice(e->cfg.device));
+        TM_TRY(cb_enter(e));  // fails while a static batch is admitted
+        e->on_update      = on_update;
+        e->on_update_user = user;
+        e->loop_stop      = false;
+        e->loop_rc        = 0;
+        e->loop_err.clear();
+    }
+    e->loop = std::thread(serve_loop, e);
+    e->loop_on.store(true);
+    return 0;
+}
+
+int tm_engine_serve_stop(tm_engine* e)
+{
+    TM_REQUIRE(e, "null pointer");
+    if (!e->loop_on.load()) {
+        return 0;
+    }
+    {
+        ApiLock lock(e);
+        e->loop_stop = true;
+    }
+    e->cv_work.notify_all();
+    if (e->loop.joinable()) {
+        e->loop.join();
+    }
+    e->loop_on.store(false);
+    e->cv_out.notify_all();
+    if (e->loop_rc) {
+        set_last_error("engine thread: " + e->loop_err);
+        return e->loop_rc;
     }
     return 0;
+}
+
+int tm_engine_wait(tm_engine* e, int64_t req_id, int have_tokens, int timeout_ms, int* status, int* n_tokens)
+{
+    TM_REQUIRE(e && status && n_tokens, "null pointer");
+    TM_REQUIRE(e->loop_on.load(), "tm_engine_wait needs the engine thread (tm_engine_serve_start)");
+    ApiLock    lock(e);
+    const auto ready = [&] {
+        const SchedRequest* r = e->sched ? e->sched->find(req_id) : nullptr;
+        return !r || r->status != 0 || (int)r->out.size() > have_tokens || e->loop_rc != 0 || e->loop_stop;
+    };
+    if (timeout_ms < 0) {
+        e->cv_out.wait(lock.lk, ready);
+    }
+    else {
+        e->cv_out.wait_for(lock.lk, std::chrono::milliseconds(timeout_ms), ready);
+    }
+    return poll_locked(e, req_id, status, nullptr, 0, n_tokens);
 }
 
 int tm_engine_prefill_times(tm_engine* e, float* host_ms)
@@ -1531,6 +1732,10 @@ int tm_engine_prefill_times(tm_engine* e, float* host_ms)
 
 int tm_engine_profile_decode(tm_engine* e, int steps, float* host_ms_per_step, int* host_launches_per_step)
 {
+    if (e && e->loop_on.load()) {
+        set_last_error("the engine thread is running (tm_engine_serve_stop first)");
+        return TM_CONFLICT;
+    }
     TM_REQUIRE(e && host_ms_per_step && e->batch > 0 && steps >= 1, "arguments");
     TM_HIP_CHECK(hipSetDevice(e->cfg.device));
     if (e->steps_done + steps > e->max_new) {
@@ -1624,6 +1829,7 @@ int tm_engine_destroy(tm_engine* e)
     if (!e) {
         return 0;
     }
+    (void)tm_engine_serve_stop(e);
     (void)hipSetDevice(e->cfg.device);
     if (e->stream) {
         (void)hipStreamSynchronize(e->stream);

@@ -159,6 +159,25 @@ public:
         return 0;
     }
 
+    // the engine cannot continue (device error): every unfinished request ends with `status` (Request::kFail = 5);
+    // slots and blocks return to the pool
+    void abort_all(int status)
+    {
+        for (auto& kv : reqs_) {
+            SchedRequest& r = kv.second;
+            if (r.status != 0) {
+                continue;
+            }
+            if (r.running) {
+                finish(r, status);
+            }
+            else {
+                r.status = status;
+            }
+        }
+        waiting_.clear();
+    }
+
     const SchedRequest* find(int64_t id) const
     {
         auto it = reqs_.find(id);

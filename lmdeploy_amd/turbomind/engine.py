@@ -146,12 +146,35 @@ class Engine:
         """(status, tokens generated so far) -- status 0 = waiting / running, 7 = finished, 8 = cancelled."""
         st, n = C.c_int(0), C.c_int(0)
         _ffi.check(self._lib.tm_engine_poll(self._h, req_id, C.byref(st), None, 0, C.byref(n)))
-        out = np.zeros(max(n.value, 1), np.int32)
-        _ffi.check(self._lib.tm_engine_poll(self._h, req_id, C.byref(st), out.ctypes.data, n.value, C.byref(n)))
-        return st.value, out[:n.value]
+        cap = n.value  # the engine thread may append between the two calls: copy what the first call saw
+        out = np.zeros(max(cap, 1), np.int32)
+        _ffi.check(self._lib.tm_engine_poll(self._h, req_id, C.byref(st), out.ctypes.data, cap, C.byref(n)))
+        return st.value, out[:min(cap, n.value)]
 
     def cancel(self, req_id: int):
         _ffi.check(self._lib.tm_engine_cancel(self._h, req_id))
+
+    # -- engine thread (the reference's InternalThreadEntry + signal thread): submit / poll / cancel / wait from any thread
+    def serve_start(self, on_update=None):
+        """Start the engine-owned scheduler thread.  on_update(req_id, status, n_tokens) runs ON THAT THREAD once per
+        step for every request that produced a token or finished (ctypes takes the GIL for the call)."""
+        if on_update is not None:
+            proto = C.CFUNCTYPE(None, C.c_void_p, C.c_int64, C.c_int, C.c_int)
+            self._cb_keepalive = proto(lambda _u, rid, st, n: on_update(int(rid), int(st), int(n)))
+            cb = C.cast(self._cb_keepalive, C.c_void_p)
+        else:
+            self._cb_keepalive, cb = None, None
+        _ffi.check(self._lib.tm_engine_serve_start(self._h, cb, None))
+
+    def serve_stop(self):
+        _ffi.check(self._lib.tm_engine_serve_stop(self._h))
+
+    def wait(self, req_id: int, have_tokens: int = 0, timeout_ms: int = -1):
+        """Block (GIL released) until the request has more than have_tokens tokens or a non-zero status.
+        Returns (status, n_tokens)."""
+        st, n = C.c_int(0), C.c_int(0)
+        _ffi.check(self._lib.tm_engine_wait(self._h, req_id, int(have_tokens), int(timeout_ms), C.byref(st), C.byref(n)))
+        return st.value, n.value
 
     def release(self):
         _ffi.check(self._lib.tm_engine_release(self._h))

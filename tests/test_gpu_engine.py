@@ -173,6 +173,105 @@ def test_continuous_batching_matches_static(cuda, slots):
     eng.close()
 
 
+def test_engine_thread_serving(cuda):
+    """The engine thread (tm_engine_serve_start; reference: Engine::Impl::InternalThreadEntry + the signal thread's
+    callback contract, engine.cc:770-870, turbomind.py:808-812): 9 requests submitted concurrently from 3 Python
+    threads into 3 slots while the loop runs; every thread streams its requests with tm_engine_wait; one request is
+    cancelled mid-flight.  Tokens must match the static single-prompt run up to the first greedy near tie; the callback
+    sees every token exactly once, in order, and nothing after a non-zero status; step / prefill are refused
+    (TM_CONFLICT) while the thread runs; after serve_stop the caller-driven loop works again."""
+    import threading
+    from lmdeploy_amd._ffi import TmError
+    cfg = o.ModelConfig(hidden=256, layers=2, q_heads=4, kv_heads=2, head_dim=128, inter=512, vocab=1024,
+                        kv_bits=8, rope=o.RopeParam(128, 500000.0, 'llama3', 8.0, 1.0, 4.0, 8192))
+    w = o.make_synthetic_weights(cfg, seed=11)
+    rng = np.random.default_rng(4)
+    lens = [70, 5, 64, 33, 150, 9, 1, 40, 17]
+    news = [6, 12, 3, 9, 5, 20, 8, 1, 10]
+    prompts = [rng.integers(0, cfg.vocab, n).astype(np.int32) for n in lens]
+    eng = Engine.from_model_config(cfg, max_batch_size=3, session_len=256, quant_policy=8, max_prefill_token_num=96)
+    eng.load_weights(export_weights(cfg, w))
+    eng.start()
+    ref, margin = [], []
+    for p, n in zip(prompts, news):
+        eng.prefill([p], max_new_tokens=n)
+        mg = []
+        for k in range(n):
+            top2 = np.sort(eng.fetch_logits()[0].astype(np.float32))[-2:]
+            mg.append(float(top2[1] - top2[0]))
+            if k + 1 < n:
+                eng.decode(1)
+        ref.append(eng.fetch()[0].copy())
+        margin.append(mg)
+        eng.release()
+
+    events = {}                                   # req id -> [(status, n_tokens)] as seen by the callback
+    def on_update(rid, st, n):
+        events.setdefault(rid, []).append((st, n))
+    eng.serve_start(on_update)
+    with pytest.raises(TmError) as ei:
+        eng.step()
+    assert ei.value.status == 2
+    with pytest.raises(TmError) as ei:
+        eng.prefill([prompts[0]], max_new_tokens=2)
+    assert ei.value.status == 2
+
+    cancel_req = 5
+    results, rids, errors = {}, {}, []
+    def client(mine):
+        try:
+            for i in mine:
+                rids[i] = eng.submit(prompts[i], news[i])
+            for i in mine:
+                have, st = 0, 0
+                while st == 0:
+                    st, n = eng.wait(rids[i], have, timeout_ms=20000)
+                    assert n > have or st != 0, 'wait timed out'
+                    have = n
+                    if i == cancel_req and st == 0 and n >= 4:
+                        eng.cancel(rids[i])
+                results[i] = eng.poll(rids[i])
+        except Exception as ex:                  # surfaced by the main thread
+            errors.append(ex)
+    threads = [threading.Thread(target=client, args=(list(range(k, 9, 3)),)) for k in range(3)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(120)
+    assert not errors, errors
+    assert all(not t.is_alive() for t in threads)
+    eng.serve_stop()
+
+    for i in range(9):
+        st, toks = results[i]
+        if i == cancel_req:
+            assert st == 8 and 4 <= len(toks) < news[i]
+            upto = len(toks)
+        else:
+            assert st == 7 and len(toks) == news[i]
+            upto = news[i]
+        for k in range(upto):
+            if toks[k] != ref[i][k]:
+                assert margin[i][k] < 5e-2, f'request {i} token {k}: {toks} vs {ref[i]} (margin {margin[i][k]})'
+                break
+        ev = events[rids[i]]
+        ns = [n for _, n in ev]
+        assert ns == list(range(1, len(ns) + 1)), f'callback token counts of request {i}: {ns}'
+        assert all(s_ == 0 for s_, _ in ev[:-1])
+        if i != cancel_req:
+            assert ev[-1] == (7, news[i])
+        else:
+            assert ev[-1][0] == 0 and len(ev) <= len(toks)     # cancel is reported to the caller, not via callback
+
+    # the caller-driven loop continues on the same session after the thread stopped
+    rid = eng.submit(prompts[1], 4)
+    while eng.poll(rid)[0] == 0:
+        eng.step()
+    assert len(eng.poll(rid)[1]) == 4
+    eng.release()
+    eng.close()
+
+
 def test_pipeline_continuous_generation(cuda):
     """Pipeline: more prompts than batch slots go through the engine scheduler; results keep the prompt order."""
     from lmdeploy_amd import GenerationConfig, TurbomindEngineConfig, pipeline

@@ -49,6 +49,9 @@ class Sched:
         _ffi.check(self.lib.tm_sched_counts(self.h, C.byref(a), C.byref(w), C.byref(f)))
         return a.value, w.value, f.value
 
+    def abort_all(self, status):
+        return self.lib.tm_sched_abort_all(self.h, status)
+
     def __del__(self):
         self.lib.tm_sched_destroy(self.h)
 
@@ -124,3 +127,22 @@ def test_eos_and_cancel():
     assert s.query(b)[1] == CANCEL and s.counts() == (0, 0, 8)
     assert s.cancel(12345)[0] == INVALID
     assert not s.on_token(1, 3)                               # tokens of a parked slot are ignored
+
+
+def test_abort_all_fails_everything_unfinished():
+    """Device error in the engine thread: running and queued requests end with kFail (5), finished ones keep their
+    status, slots and blocks return to the pool and new requests are admitted again."""
+    FAIL = 5
+    s = Sched(max_batch=2, num_blocks=6, session_len=256)
+    ids = [s.submit(10, 5)[1] for _ in range(4)]
+    assert [a[0] for a in s.admit()] == ids[:2]
+    for _ in range(5):
+        s.on_token(0, 1)                                  # request 0 finishes by length
+    assert s.query(ids[0])[1] == FINISH
+    assert s.abort_all(0) != 0                            # status must be non-zero
+    assert s.abort_all(FAIL) == 0
+    assert [s.query(i)[1] for i in ids] == [FINISH, FAIL, FAIL, FAIL]
+    assert s.counts() == (0, 0, 6)
+    assert not s.on_token(1, 3)                           # the aborted slot no longer belongs to a request
+    rc, rid = s.submit(70, 5)
+    assert rc == 0 and s.admit() == [(rid, 0)] and s.counts() == (1, 0, 4)
