@@ -128,6 +128,27 @@ int    tm_sample(int* out_ids, int* kept_out, const void* logits, int batch, int
                  tm_stream_t st);
 /* the engine's uniform draw: Philox4x32-10, key = request seed, counter = context length -> [0, 1) (host function) */
 float  tm_philox_uniform(uint64_t seed, uint32_t counter);
+
+/* Logits processors ahead of arg-max / sampling: repetition penalty -> bad ids -> min-length ban of the end ids
+ * (LogitsProcessor::Forward, generation/logits_processor.cc:66-115; kernels/sampling_penalty_kernels.cu:137-215,
+ * kernels/ban_bad_words.cu:51-95 single-token case).  In place on fp16 logits [batch][ld] (columns vocab_offset ..
+ * vocab_offset + vocab of the global vocabulary; ld and vocab_offset multiples of 8):
+ *   seen     device u32 [batch][seen_words]: bit id%32 of word id/32 set = token id occurs in the sequence (prompt +
+ *            generated); maintained with tm_seen_update (the reference rebuilds it from token_ids_ptrs every step)
+ *   rep      device float [batch]  repetition penalty (1 = off): seen ids get l < 0 ? l*p : l/p
+ *   ban      device int [batch][TM_MAX_BAD_IDS]  ids that get -65504 (-1 = unused; ids <= 0 are skipped, as upstream)
+ *   end      device int [batch][1 + TM_MAX_STOP_IDS]  eos / stop ids, banned while k_len + 1 < min_len (ids <= 0 skipped)
+ *   k_len    device int [batch]  context length of this forward; min_len = prompt length + min_new_tokens
+ * The fp32 result is rounded to fp16 once (the reference keeps fp32 logits from here on).
+ * tm_seen_update: OR the tokens ids[0..n_tokens) into the masks; cu_q NULL: token t belongs to row t (decode),
+ * else rows are the packed prefill sequences cu_q[r] .. cu_q[r+1]. */
+#define TM_MAX_BAD_IDS 32
+#define TM_MAX_STOP_IDS 8
+int tm_seen_update(void* seen, int seen_words, const int* ids, const int* cu_q, int nseq, int n_tokens, int vocab,
+                   tm_stream_t st);
+int tm_logits_process(void* logits, int batch, int vocab, int ld, int vocab_offset, const void* seen, int seen_words,
+                      const float* rep, const int* ban, const int* end, const int* k_len, const int* min_len,
+                      tm_stream_t st);
 /* unfused activation on [M][2*inter] laid out [gate | up]            (kernels/activation.cu:27-130) */
 int tm_silu_mul(void* out, const void* gate_up, int M, int inter, tm_stream_t st);
 
@@ -270,6 +291,21 @@ typedef struct tm_sampling {
 /* Static batch: sampling parameters of the NEXT tm_engine_prefill (host array [batch], copied); NULL / never called =
  * greedy arg-max.  Cleared by tm_engine_release.  TP > 1 supports greedy only in this round (TM_INVALID). */
 int tm_engine_set_sampling(tm_engine* e, const tm_sampling* host_params, int batch);
+/* Per-sequence logits processors (GenerationConfig: repetition_penalty, min_new_tokens, bad_token_ids,
+ * stop_token_ids; applied in the reference's order, see tm_logits_process).  stop ids end a sequence of the
+ * continuous-batching path like its eos id and are banned with it until min_new_tokens tokens exist; the static
+ * batch has no engine-side stop (the caller cuts), there they only matter for min_new_tokens. */
+typedef struct tm_logits_param {
+    float repetition_penalty; /* > 0; 1 = off */
+    int   min_new_tokens;     /* 0 = off */
+    int   n_bad_ids;
+    int   bad_ids[TM_MAX_BAD_IDS];
+    int   n_stop_ids;
+    int   stop_ids[TM_MAX_STOP_IDS];
+} tm_logits_param;
+/* Static batch: parameters of the NEXT tm_engine_prefill (host array [batch], copied); NULL = none.  Cleared by
+ * tm_engine_release.  Works with tp > 1 (each rank processes its vocabulary shard). */
+int tm_engine_set_logits_params(tm_engine* e, const tm_logits_param* host_params, int batch);
 
 /* release the batch (blocks return to the pool); also ends a continuous-batching session */
 int tm_engine_release(tm_engine* e);
@@ -290,6 +326,9 @@ int tm_engine_submit(tm_engine* e, const int* host_ids, int n, int max_new_token
 /* like tm_engine_submit with sampling parameters (NULL = greedy) */
 int tm_engine_submit_ex(tm_engine* e, const int* host_ids, int n, int max_new_tokens, int eos_id, const tm_sampling* sampling,
                          int64_t* req_id);
+/* ... and logits-processor parameters (NULL = none) */
+int tm_engine_submit_gen(tm_engine* e, const int* host_ids, int n, int max_new_tokens, int eos_id, const tm_sampling* sampling,
+                         const tm_logits_param* logits_param, int64_t* req_id);
 int tm_engine_step(tm_engine* e, int* n_active, int* n_waiting);
 int tm_engine_poll(tm_engine* e, int64_t req_id, int* status, int* host_tokens, int cap, int* n_tokens);
 int tm_engine_cancel(tm_engine* e, int64_t req_id);

@@ -25,6 +25,24 @@ class Sampling(C.Structure):
     _fields_ = [('temperature', c_float), ('top_k', c_int), ('top_p', c_float), ('min_p', c_float), ('seed', c_uint64)]
 
 
+MAX_BAD_IDS, MAX_STOP_IDS = 32, 8
+
+
+class LogitsParam(C.Structure):
+    """struct tm_logits_param"""
+    _fields_ = [('repetition_penalty', c_float), ('min_new_tokens', c_int), ('n_bad_ids', c_int),
+                ('bad_ids', c_int * MAX_BAD_IDS), ('n_stop_ids', c_int), ('stop_ids', c_int * MAX_STOP_IDS)]
+
+    @classmethod
+    def make(cls, repetition_penalty=1.0, min_new_tokens=0, bad_ids=(), stop_ids=()):
+        bad_ids, stop_ids = list(bad_ids or ()), list(stop_ids or ())
+        if len(bad_ids) > MAX_BAD_IDS or len(stop_ids) > MAX_STOP_IDS:
+            raise ValueError(f'at most {MAX_BAD_IDS} bad ids and {MAX_STOP_IDS} stop ids per sequence')
+        p = cls(float(repetition_penalty), int(min_new_tokens or 0), len(bad_ids), (c_int * MAX_BAD_IDS)(*bad_ids),
+                len(stop_ids), (c_int * MAX_STOP_IDS)(*stop_ids))
+        return p
+
+
 class KvCache(C.Structure):
     """struct tm_kv_cache"""
     _fields_ = [('block_ptrs', c_void_p), ('cu_block_nums', c_void_p), ('layer_offset', c_int64),
@@ -110,6 +128,11 @@ _SIGNATURES = {
     'tm_engine_fetch_logits': (c_int, [c_void_p, c_void_p]),
     'tm_engine_release': (c_int, [c_void_p]),
     'tm_engine_set_sampling': (c_int, [c_void_p, c_void_p, c_int]),
+    'tm_engine_set_logits_params': (c_int, [c_void_p, c_void_p, c_int]),
+    'tm_engine_submit_gen': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, POINTER(c_int64)]),
+    'tm_seen_update': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    'tm_logits_process': (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                                  c_void_p, c_void_p]),
     'tm_engine_submit_ex': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, POINTER(c_int64)]),
     'tm_engine_submit': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, POINTER(c_int64)]),
     'tm_engine_step': (c_int, [c_void_p, POINTER(c_int), POINTER(c_int)]),

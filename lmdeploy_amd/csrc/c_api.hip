@@ -328,6 +328,22 @@ float tm_philox_uniform(uint64_t seed, uint32_t counter)
     return philox_uniform_host(seed, counter);
 }
 
+int tm_seen_update(void* seen, int seen_words, const int* ids, const int* cu_q, int nseq, int n_tokens, int vocab,
+                   tm_stream_t st)
+{
+    TM_REQUIRE(seen && ids && seen_words >= 1 && nseq >= 1 && (int64_t)seen_words * 32 >= vocab, "seen_update: arguments");
+    return launch_seen_update((uint32_t*)seen, seen_words, ids, cu_q, nseq, n_tokens, vocab, (hipStream_t)st);
+}
+
+int tm_logits_process(void* logits, int batch, int vocab, int ld, int vocab_offset, const void* seen, int seen_words,
+                      const float* rep, const int* ban, const int* end, const int* k_len, const int* min_len, tm_stream_t st)
+{
+    TM_REQUIRE(logits && seen && rep && ban && end && k_len && min_len, "null pointer");
+    static_assert(kMaxBadIds == TM_MAX_BAD_IDS && kMaxEndIds == 1 + TM_MAX_STOP_IDS, "header constants");
+    return launch_logits_process((half_t*)logits, batch, vocab, ld, vocab_offset, (const uint32_t*)seen, seen_words, rep,
+                                 ban, end, k_len, min_len, (hipStream_t)st);
+}
+
 // ---- MoE FFN block ------------------------------------------------------------------------------------------------
 struct tm_moe {
     tmk::MoeBlock m;

@@ -277,6 +277,17 @@ struct tm_engine {
     std::vector<tm_sampling>       h_sampling;      // static batch: parameters of the next prefill
     std::map<int64_t, tm_sampling> cb_sampling;     // continuous batching: per request
 
+    // logits processors (tm_engine_set_logits_params / tm_engine_submit_gen): repetition penalty, bad ids, min length;
+    // off = arg-max / sampling see the raw lm_head output.  d_seen = persistent "token occurs in the sequence" bitmask
+    // per batch slot over the GLOBAL vocabulary.
+    bool      logits_on = false, graph_logits = false, graph_cb_logits = false;
+    uint32_t* d_seen     = nullptr;
+    int       seen_words = 0;
+    float*    d_lp_rep    = nullptr;
+    int *     d_lp_minlen = nullptr, *d_lp_ban = nullptr, *d_lp_end = nullptr;
+    std::vector<tm_logits_param>       h_logits;   // static batch: parameters of the next prefill
+    std::map<int64_t, tm_logits_param> cb_logits;  // continuous batching: per request
+
     // engine thread (tm_engine_serve_start): runs step_locked() while requests exist.  `mu` serialises the scheduler
     // and every device-side effect of submit / step / poll / cancel; API callers announce themselves in api_waiting so
     // that the loop (which re-locks immediately) lets them in between two steps.
@@ -571,6 +582,16 @@ static int forward(tm_engine* e, const int* d_ids, int M, int nseq, bool decode,
     half_t* logits = e->d_logits + (size_t)slot0 * e->vocab_local;
     int*    ids    = e->d_next_ids + slot0;
     TM_PROF(P_LM_HEAD, TM_TRY(linear_plain(e, e->output, hx, e->hidden, logits, e->vocab_local, nseq, false)));
+    if (e->logits_on) {
+        // the tokens this forward consumed join the slots' seen masks, then penalty / bans on the (local) logits
+        uint32_t* seen = e->d_seen + (size_t)slot0 * e->seen_words;
+        TM_PROF(P_SAMPLE, TM_TRY(launch_seen_update(seen, e->seen_words, d_ids, decode ? nullptr : e->d_cu_q, nseq, M, m.vocab, st)));
+        TM_PROF(P_SAMPLE, TM_TRY(launch_logits_process(logits, nseq, e->vocab_local, e->vocab_local,
+                                                       e->vocab_local < m.vocab ? e->cfg.rank * e->vocab_local : 0, seen,
+                                                       e->seen_words, e->d_lp_rep + slot0, e->d_lp_ban + slot0 * kMaxBadIds,
+                                                       e->d_lp_end + slot0 * kMaxEndIds, e->d_k_len, e->d_lp_minlen + slot0,
+                                                       st)));
+    }
     if (!e->use_comm && e->sampling_on) {
         // parameters are indexed by batch slot, the counter (context length) by the row of this forward
         TM_PROF(P_SAMPLE, TM_TRY(launch_sample_uniform(e->d_u + slot0, e->d_seed + slot0, e->d_k_len, nseq, st)));
@@ -1034,6 +1055,61 @@ static int sampling_upload(tm_engine* e, const tm_sampling* p, int slot0, int n)
     return 0;
 }
 
+// logits-processor state of `n` slots starting at slot0: parameters + cleared seen masks.  eos[i] (may be < 0) joins the
+// stop ids as an end id; prompt_len[i] turns min_new_tokens into the context-length threshold of the kernel.
+static const tm_logits_param kNoLogitsParam = {1.f, 0, 0, {0}, 0, {0}};
+
+static int logits_param_check(const tm_logits_param& p)
+{
+    TM_REQUIRE(p.repetition_penalty > 0.f, "repetition_penalty must be > 0");
+    TM_REQUIRE(p.min_new_tokens >= 0, "min_new_tokens must be >= 0");
+    TM_REQUIRE(p.n_bad_ids >= 0 && p.n_bad_ids <= TM_MAX_BAD_IDS, "0 <= n_bad_ids <= TM_MAX_BAD_IDS");
+    TM_REQUIRE(p.n_stop_ids >= 0 && p.n_stop_ids <= TM_MAX_STOP_IDS, "0 <= n_stop_ids <= TM_MAX_STOP_IDS");
+    return 0;
+}
+
+static int logits_upload(tm_engine* e, const tm_logits_param* p, const int* prompt_len, const int* eos, int slot0, int n)
+{
+    const int B = e->cfg.max_batch_size;
+    if (!e->d_seen) {
+        TM_REQUIRE(e->vocab_local % 8 == 0, "logits processors need (local) vocab % 8 == 0");
+        e->seen_words = (e->cfg.model.vocab + 31) / 32;
+        TM_TRY(dmalloc(&e->d_seen, (size_t)B * e->seen_words));
+        TM_TRY(dmalloc(&e->d_lp_rep, (size_t)B));
+        TM_TRY(dmalloc(&e->d_lp_minlen, (size_t)B));
+        TM_TRY(dmalloc(&e->d_lp_ban, (size_t)B * kMaxBadIds));
+        TM_TRY(dmalloc(&e->d_lp_end, (size_t)B * kMaxEndIds));
+        std::vector<float> one(B, 1.f);
+        TM_HIP_CHECK(hipMemcpyAsync(e->d_lp_rep, one.data(), B * 4, hipMemcpyHostToDevice, e->stream));
+        TM_HIP_CHECK(hipMemsetAsync(e->d_lp_minlen, 0, (size_t)B * 4, e->stream));
+        TM_HIP_CHECK(hipMemsetAsync(e->d_lp_ban, 0xff, (size_t)B * kMaxBadIds * 4, e->stream));
+        TM_HIP_CHECK(hipMemsetAsync(e->d_lp_end, 0xff, (size_t)B * kMaxEndIds * 4, e->stream));
+        TM_HIP_CHECK(hipMemsetAsync(e->d_seen, 0, (size_t)B * e->seen_words * 4, e->stream));
+        TM_HIP_CHECK(hipStreamSynchronize(e->stream));
+    }
+    std::vector<float> r(n);
+    std::vector<int>   ml(n), ban((size_t)n * kMaxBadIds, -1), end((size_t)n * kMaxEndIds, -1);
+    for (int i = 0; i < n; ++i) {
+        TM_TRY(logits_param_check(p[i]));
+        r[i]  = p[i].repetition_penalty;
+        ml[i] = p[i].min_new_tokens > 0 ? prompt_len[i] + p[i].min_new_tokens : 0;
+        for (int k = 0; k < p[i].n_bad_ids; ++k) {
+            ban[(size_t)i * kMaxBadIds + k] = p[i].bad_ids[k];
+        }
+        end[(size_t)i * kMaxEndIds] = eos ? eos[i] : -1;
+        for (int k = 0; k < p[i].n_stop_ids; ++k) {
+            end[(size_t)i * kMaxEndIds + 1 + k] = p[i].stop_ids[k];
+        }
+    }
+    TM_HIP_CHECK(hipMemcpyAsync(e->d_lp_rep + slot0, r.data(), n * 4, hipMemcpyHostToDevice, e->stream));
+    TM_HIP_CHECK(hipMemcpyAsync(e->d_lp_minlen + slot0, ml.data(), n * 4, hipMemcpyHostToDevice, e->stream));
+    TM_HIP_CHECK(hipMemcpyAsync(e->d_lp_ban + (size_t)slot0 * kMaxBadIds, ban.data(), ban.size() * 4, hipMemcpyHostToDevice, e->stream));
+    TM_HIP_CHECK(hipMemcpyAsync(e->d_lp_end + (size_t)slot0 * kMaxEndIds, end.data(), end.size() * 4, hipMemcpyHostToDevice, e->stream));
+    TM_HIP_CHECK(hipMemsetAsync(e->d_seen + (size_t)slot0 * e->seen_words, 0, (size_t)n * e->seen_words * 4, e->stream));
+    TM_HIP_CHECK(hipStreamSynchronize(e->stream));
+    return 0;
+}
+
 // decode split heuristic: fill >= 2 workgroups per CU (GetSplitCount, kernels/attention/utils.cc:11-46); fused prologue
 static void setup_decode(tm_engine* e, int batch)
 {
@@ -1222,6 +1298,11 @@ static int cb_prefill_admitted(tm_engine* e, const std::vector<SchedAdmit>& admi
                 const tm_sampling sp = it == e->cb_sampling.end() ? tm_sampling{1.f, 1, 1.f, 0.f, 0} : it->second;
                 TM_TRY(sampling_upload(e, &sp, slot0 + k, 1));
             }
+            if (e->logits_on) {  // slots without parameters run the processors as no-ops
+                auto                  it = e->cb_logits.find(r->id);
+                const tm_logits_param lp = it == e->cb_logits.end() ? kNoLogitsParam : it->second;
+                TM_TRY(logits_upload(e, &lp, &lens[k], &r->eos, slot0 + k, 1));
+            }
             TM_REQUIRE((int)r->blocks.size() <= e->max_blocks_per_seq, "internal: block table row too short");
             for (size_t q = 0; q < r->blocks.size(); ++q) {
                 ptrs[(size_t)k * e->max_blocks_per_seq + q] = (uint64_t)(e->pool + (int64_t)r->blocks[q] * e->block_bytes);
@@ -1284,6 +1365,9 @@ int tm_engine_release(tm_engine* e)
     e->h_sampling.clear();
     e->cb_sampling.clear();
     e->sampling_on = false;
+    e->h_logits.clear();
+    e->cb_logits.clear();
+    e->logits_on = false;
     if (e->sched) {  // leave continuous-batching mode: every block goes back to the static free list
         e->sched.reset();
         e->free_blocks.resize(e->num_blocks);
@@ -1347,6 +1431,12 @@ int tm_engine_prefill(tm_engine* e, const int* host_ids, const int* host_lens, i
         TM_TRY(sampling_upload(e, e->h_sampling.data(), 0, batch));
         e->sampling_on = true;
     }
+    e->logits_on = false;
+    if (!e->h_logits.empty()) {
+        TM_REQUIRE((int)e->h_logits.size() == batch, "tm_engine_set_logits_params: batch size differs from the prefill's");
+        TM_TRY(logits_upload(e, e->h_logits.data(), host_lens, nullptr, 0, batch));
+        e->logits_on = true;
+    }
     e->h_ttft_ms.assign(batch, 0.f);
     {
         std::vector<const int*> seq_ids(batch);
@@ -1372,7 +1462,8 @@ int tm_engine_prefill(tm_engine* e, const int* host_ids, const int* host_lens, i
     e->steps_done = 1;
 
     setup_decode(e, batch);
-    if (e->graph && (e->graph_batch != batch || e->graph_max_new != max_new_tokens || e->graph_sampling != e->sampling_on)) {
+    if (e->graph && (e->graph_batch != batch || e->graph_max_new != max_new_tokens || e->graph_sampling != e->sampling_on
+                     || e->graph_logits != e->logits_on)) {
         (void)hipGraphExecDestroy(e->graph);
         e->graph = nullptr;
     }
@@ -1417,6 +1508,7 @@ int tm_engine_decode(tm_engine* e, int steps)
         e->graph_batch    = e->batch;
         e->graph_max_new  = e->max_new;
         e->graph_sampling = e->sampling_on;
+        e->graph_logits   = e->logits_on;
     }
     for (int i = 0; i < steps; ++i) {
         if (use_graph) {
@@ -1447,6 +1539,22 @@ int tm_engine_set_sampling(tm_engine* e, const tm_sampling* host_params, int bat
     return 0;
 }
 
+int tm_engine_set_logits_params(tm_engine* e, const tm_logits_param* host_params, int batch)
+{
+    TM_REQUIRE(e, "null pointer");
+    TM_REQUIRE(e->batch == 0 && !e->sched, "set the logits-processor parameters before tm_engine_prefill");
+    e->h_logits.clear();
+    if (!host_params) {
+        return 0;
+    }
+    TM_REQUIRE(batch >= 1 && batch <= e->cfg.max_batch_size, "1 <= batch <= max_batch_size");
+    for (int i = 0; i < batch; ++i) {
+        TM_TRY(logits_param_check(host_params[i]));
+    }
+    e->h_logits.assign(host_params, host_params + batch);
+    return 0;
+}
+
 static int submit_locked(tm_engine* e, const int* host_ids, int n, int max_new_tokens, int eos_id, int64_t* req_id)
 {
     TM_TRY(cb_enter(e));
@@ -1466,7 +1574,16 @@ static int submit_locked(tm_engine* e, const int* host_ids, int n, int max_new_t
 int tm_engine_submit_ex(tm_engine* e, const int* host_ids, int n, int max_new_tokens, int eos_id, const tm_sampling* sampling,
                         int64_t* req_id)
 {
+    return tm_engine_submit_gen(e, host_ids, n, max_new_tokens, eos_id, sampling, nullptr, req_id);
+}
+
+int tm_engine_submit_gen(tm_engine* e, const int* host_ids, int n, int max_new_tokens, int eos_id, const tm_sampling* sampling,
+                         const tm_logits_param* logits_param, int64_t* req_id)
+{
     TM_REQUIRE(e && host_ids && req_id, "null pointer");
+    if (logits_param) {
+        TM_TRY(logits_param_check(*logits_param));
+    }
     if (sampling) {
         TM_REQUIRE(!e->use_comm, "stochastic sampling with tp > 1 is not supported in this round (greedy only)");
         TM_REQUIRE(sampling->temperature > 0.f, "sampling: temperature must be > 0");
@@ -1482,6 +1599,17 @@ int tm_engine_submit_ex(tm_engine* e, const int* host_ids, int n, int max_new_to
                 std::vector<tm_sampling> greedy(B, tm_sampling{1.f, 1, 1.f, 0.f, 0});
                 TM_TRY(sampling_upload(e, greedy.data(), 0, B));
                 e->sampling_on = true;
+            }
+        }
+        if (logits_param) {
+            e->cb_logits[*req_id] = *logits_param;
+            e->sched->set_stop_ids(*req_id, logits_param->stop_ids, logits_param->n_stop_ids);
+            if (!e->logits_on) {  // the first such request switches the decode step to the processor kernels
+                const int                    B = e->cfg.max_batch_size;
+                std::vector<tm_logits_param> none(B, kNoLogitsParam);
+                std::vector<int>             zeros(B, 0);
+                TM_TRY(logits_upload(e, none.data(), zeros.data(), nullptr, 0, B));
+                e->logits_on = true;
             }
         }
     }
@@ -1509,7 +1637,7 @@ static int step_locked(tm_engine* e, int* n_active, int* n_waiting, std::vector<
     if (e->sched->n_active() > 0) {
         const char* gc        = getenv("TM_GRAPH_COMM");
         const bool  use_graph = e->cfg.use_graph && (!e->use_comm || (gc && atoi(gc)));
-        if (e->graph_cb && e->graph_cb_sampling != e->sampling_on) {
+        if (e->graph_cb && (e->graph_cb_sampling != e->sampling_on || e->graph_cb_logits != e->logits_on)) {
             (void)hipGraphExecDestroy(e->graph_cb);
             e->graph_cb = nullptr;
         }
@@ -1527,6 +1655,7 @@ static int step_locked(tm_engine* e, int* n_active, int* n_waiting, std::vector<
             TM_HIP_CHECK(hipGraphInstantiate(&e->graph_cb, g, nullptr, nullptr, 0));
             TM_HIP_CHECK(hipGraphDestroy(g));
             e->graph_cb_sampling = e->sampling_on;
+            e->graph_cb_logits   = e->logits_on;
         }
         else if (use_graph) {
             TM_HIP_CHECK(hipGraphLaunch(e->graph_cb, e->stream));
@@ -1841,7 +1970,8 @@ int tm_engine_destroy(tm_engine* e)
         (void)hipGraphExecDestroy(e->graph_cb);
     }
     for (void* q : {(void*)e->d_active, (void*)e->d_pf_k_len, (void*)e->d_pf_cu_q, (void*)e->d_temp, (void*)e->d_topp, (void*)e->d_minp,
-                    (void*)e->d_u, (void*)e->d_topk, (void*)e->d_seed, e->d_sample_ws}) {
+                    (void*)e->d_u, (void*)e->d_topk, (void*)e->d_seed, e->d_sample_ws, (void*)e->d_seen, (void*)e->d_lp_rep,
+                    (void*)e->d_lp_minlen, (void*)e->d_lp_ban, (void*)e->d_lp_end}) {
         if (q) {
             (void)hipFree(q);
         }

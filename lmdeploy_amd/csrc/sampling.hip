@@ -396,4 +396,132 @@ float philox_uniform_host(uint64_t seed, uint32_t ctr)
     return philox_uniform(seed, ctr);
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Logits processors: repetition penalty -> bad ids -> min-length ban of the end ids (the reference's order,
+// generation/logits_processor.cc:66-115; temperature is part of the sampler above).
+//   * repetition penalty (RepetitionPenaltyKernel, kernels/sampling_penalty_kernels.cu:137-175): every token id that
+//     occurs in the sequence so far (prompt + generated, each id once) gets  l < 0 ? l * p : l / p.  The reference
+//     rebuilds a bitmask of the whole history in shared memory every step; here the bitmask of a batch slot is
+//     PERSISTENT in HBM ([slot][ceil(vocab / 32)] words), cleared at admission and extended by seen_update_kernel with
+//     the tokens each forward consumes -- one atomicOr per new token instead of a pass over the history.
+//   * bad ids (BanBadWordsKernel single-token case, kernels/ban_bad_words.cu:51-95): l = -max, ids <= 0 are skipped
+//     like in the reference.
+//   * min length (batchApplyMinLengthPenalty, sampling_penalty_kernels.cu:198-215): end ids (> 0) are banned while
+//     k_len + 1 < min_len, k_len = context length of this forward, min_len = prompt length + min_new_tokens.
+// The reference processes fp32 copies of the fp16 logits; here the result is rounded back to fp16 once (the sampler
+// and arg-max consume fp16): penalised values differ from the reference's by at most half an fp16 ulp.
+// ------------------------------------------------------------------------------------------------------------------
+__global__ void seen_update_kernel(uint32_t* __restrict__ seen, int words, const int* __restrict__ ids,
+                                   const int* __restrict__ cu_q, int nseq, int n_tokens, int vocab)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_tokens) {
+        return;
+    }
+    int row = t;
+    if (cu_q) {  // packed prefill rows: sequence of token t = last r with cu_q[r] <= t
+        int lo = 0, hi = nseq - 1;
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (cu_q[mid] <= t) {
+                lo = mid;
+            }
+            else {
+                hi = mid - 1;
+            }
+        }
+        row = lo;
+    }
+    const int id = ids[t];
+    if (id >= 0 && id < vocab) {
+        atomicOr(&seen[(size_t)row * words + (id >> 5)], 1u << (id & 31));
+    }
+}
+
+constexpr int kLpBlock = 2048;  // logits per workgroup (256 threads x 8)
+
+__global__ __launch_bounds__(256) void logits_process_kernel(half_t* __restrict__ logits, int V, int ld, int vocab_offset,
+                                                             const uint32_t* __restrict__ seen, int words,
+                                                             const float* __restrict__ rep, const int* __restrict__ ban,
+                                                             const int* __restrict__ end, const int* __restrict__ k_len,
+                                                             const int* __restrict__ min_len)
+{
+    __shared__ uint32_t banned[kLpBlock / 32];
+    const int row  = blockIdx.y;
+    const int base = blockIdx.x * kLpBlock;  // local column of this workgroup's first logit
+    const int tid  = threadIdx.x;
+    if (tid < kLpBlock / 32) {
+        banned[tid] = 0;
+    }
+    __syncthreads();
+    // the (few) banned ids of this row that fall into this workgroup's range
+    const bool ban_end = k_len[row] + 1 < min_len[row];
+    if (tid < kMaxBadIds + kMaxEndIds) {
+        const int id = tid < kMaxBadIds ? ban[row * kMaxBadIds + tid] : (ban_end ? end[row * kMaxEndIds + tid - kMaxBadIds] : -1);
+        const int c  = id - vocab_offset - base;
+        if (id > 0 && c >= 0 && c < kLpBlock && base + c < V) {
+            atomicOr(&banned[c >> 5], 1u << (c & 31));
+        }
+    }
+    __syncthreads();
+    const int c0 = base + tid * 8;
+    if (c0 >= V) {
+        return;
+    }
+    const float    p    = rep[row];
+    const bool     on   = p != 1.f && p > 0.f;
+    const int      gid  = vocab_offset + c0;  // multiple of 8: the eight ids share one mask word
+    const uint32_t smsk = on ? (seen[(size_t)row * words + (gid >> 5)] >> (gid & 31)) & 0xffu : 0u;
+    const uint32_t bmsk = (banned[(tid * 8) >> 5] >> ((tid * 8) & 31)) & 0xffu;
+    if (!(smsk | bmsk)) {
+        return;
+    }
+    half_t* lp = logits + (size_t)row * ld + c0;
+    if (c0 + 8 <= V) {
+        half8_t v = *(const half8_t*)lp;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            float x = (float)v[i];
+            if (smsk >> i & 1) {
+                x = x < 0.f ? x * p : x / p;
+            }
+            v[i] = (bmsk >> i & 1) ? (half_t)-65504.f : (half_t)x;
+        }
+        *(half8_t*)lp = v;
+    }
+    else {
+        for (int i = 0; c0 + i < V; ++i) {
+            float x = (float)lp[i];
+            if (smsk >> i & 1) {
+                x = x < 0.f ? x * p : x / p;
+            }
+            lp[i] = (bmsk >> i & 1) ? (half_t)-65504.f : (half_t)x;
+        }
+    }
+}
+
+int launch_seen_update(uint32_t* seen, int words, const int* ids, const int* cu_q, int nseq, int n_tokens, int vocab,
+                       hipStream_t st)
+{
+    if (n_tokens <= 0) {
+        return 0;
+    }
+    seen_update_kernel<<<(n_tokens + 255) / 256, 256, 0, st>>>(seen, words, ids, cu_q, nseq, n_tokens, vocab);
+    TM_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int launch_logits_process(half_t* logits, int batch, int V, int ld, int vocab_offset, const uint32_t* seen, int words,
+                          const float* rep, const int* ban, const int* end, const int* k_len, const int* min_len,
+                          hipStream_t st)
+{
+    TM_REQUIRE(batch >= 1 && V >= 1 && ld >= V, "logits_process: shape");
+    TM_REQUIRE(ld % 8 == 0 && vocab_offset % 8 == 0, "logits_process: row stride and vocabulary offset must be multiples of 8");
+    TM_REQUIRE((int64_t)words * 32 >= (int64_t)vocab_offset + V, "logits_process: seen mask narrower than the vocabulary");
+    dim3 grid((V + kLpBlock - 1) / kLpBlock, batch);
+    logits_process_kernel<<<grid, 256, 0, st>>>(logits, V, ld, vocab_offset, seen, words, rep, ban, end, k_len, min_len);
+    TM_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
 }  // namespace tmk

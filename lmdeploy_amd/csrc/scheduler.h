@@ -26,6 +26,7 @@ struct SchedRequest {
     std::vector<int> prompt;
     int              max_new  = 0;
     int              eos      = -1;  // < 0: never stop on a token (ignore_eos)
+    std::vector<int> stops;          // further ids that end the sequence (GenerationConfig.stop_token_ids)
     int              status   = 0;   // Request::k*: 0 = waiting / running, 7 finished, 8 cancelled
     int              slot     = -1;  // batch slot while running
     bool             running  = false;
@@ -126,11 +127,26 @@ public:
         }
         SchedRequest& r = reqs_[id];
         r.out.push_back(token);
-        if ((r.eos >= 0 && token == r.eos) || (int)r.out.size() >= r.max_new) {
+        bool stop = r.eos >= 0 && token == r.eos;
+        for (int sid : r.stops) {
+            stop = stop || token == sid;
+        }
+        if (stop || (int)r.out.size() >= r.max_new) {
             finish(r, 7);
             return true;
         }
         return false;
+    }
+
+    // additional stop ids of a queued / running request; 1 = unknown id
+    int set_stop_ids(int64_t id, const int* ids, int n)
+    {
+        auto it = reqs_.find(id);
+        if (it == reqs_.end()) {
+            return 1;
+        }
+        it->second.stops.assign(ids, ids + (n > 0 ? n : 0));
+        return 0;
     }
 
     // 0 ok; 1 unknown id.  A running sequence is released immediately (the caller deactivates its slot).

@@ -135,6 +135,16 @@ int    launch_sample(int* out_ids, int* kept_out, const half_t* logits, int batc
 int    launch_sample_uniform(float* u, const uint64_t* seeds, const int* counters, int batch, hipStream_t st);
 float  philox_uniform_host(uint64_t seed, uint32_t ctr);
 
+// logits processors (sampling.hip): persistent per-slot "token seen" bitmask, repetition penalty, banned ids,
+// min-length ban of the end ids.  ban = [batch][kMaxBadIds], end = [batch][kMaxEndIds], padded with -1.
+constexpr int kMaxBadIds = 32;  // = TM_MAX_BAD_IDS
+constexpr int kMaxEndIds = 9;   // eos id + TM_MAX_STOP_IDS
+int launch_seen_update(uint32_t* seen, int words, const int* ids, const int* cu_q, int nseq, int n_tokens, int vocab,
+                       hipStream_t st);
+int launch_logits_process(half_t* logits, int batch, int V, int ld, int vocab_offset, const uint32_t* seen, int words,
+                          const float* rep, const int* ban, const int* end, const int* k_len, const int* min_len,
+                          hipStream_t st);
+
 struct MoeBlock {
     int                       hidden = 0, inter = 0, experts = 0, top_k = 0;
     bool                      norm_topk    = true;

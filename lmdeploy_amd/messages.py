@@ -80,16 +80,25 @@ class GenerationConfig:
         assert self.top_k >= 0, 'top_k can not be a negative integer'
         assert self.temperature >= 0 and self.temperature <= 2
         assert 0 <= self.min_p <= 1
-        unsupported = {'n': 1, 'repetition_penalty': 1.0, 'bad_words': None, 'bad_token_ids': None,
-                       'logprobs': None, 'response_format': None, 'logits_processors': None, 'output_logits': None,
-                       'output_last_hidden_state': None, 'min_new_tokens': None}
+        assert self.repetition_penalty > 0, 'repetition_penalty must be > 0'
+        unsupported = {'n': 1, 'bad_words': None, 'logprobs': None, 'response_format': None, 'logits_processors': None,
+                       'output_logits': None, 'output_last_hidden_state': None}
         if self.do_sample and self.temperature == 0:
             raise ValueError('temperature must be > 0 when do_sample=True')
         for k, default in unsupported.items():
             if getattr(self, k) != default:
                 raise NotImplementedError(f'GenerationConfig.{k}={getattr(self, k)!r}: the MI355X hot path implements '
-                                          f'greedy decoding and temperature / top-k / top-p / min-p sampling only')
+                                          f'greedy decoding, temperature / top-k / top-p / min-p sampling, repetition '
+                                          f'penalty, min_new_tokens, bad_token_ids and stop_token_ids only')
 
+
+    def logits_params(self, stop_ids=()):
+        """dict for the engine's logits processors (tm_logits_param), or None when every processor is off.
+        stop_ids: the ids that end the sequence besides the engine-side eos id (banned until min_new_tokens)."""
+        if self.repetition_penalty == 1.0 and not self.bad_token_ids and not self.min_new_tokens:
+            return None
+        return dict(repetition_penalty=float(self.repetition_penalty), min_new_tokens=int(self.min_new_tokens or 0),
+                    bad_ids=list(self.bad_token_ids or ()), stop_ids=list(stop_ids))
 
     def sampling_params(self, index: int = 0):
         """(temperature, top_k, top_p, min_p, seed) for the engine, or None for greedy.  Every sequence of a call gets

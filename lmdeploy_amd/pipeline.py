@@ -127,11 +127,17 @@ class Pipeline:
         g = g or GenerationConfig()
         ids = [self._encode(p) for p in prompts]
         stop = self._stop_ids(g)
-        eos = next(iter(stop)) if len(stop) == 1 else -1       # one stop id is handled inside the engine
+        # stop ids live inside the engine (eos id + up to 8 more); beyond that the loop below cuts on the host
+        stop_l = sorted(stop)
+        in_engine = stop_l if len(stop_l) <= 1 + _ffi.MAX_STOP_IDS else []
+        eos = in_engine[0] if in_engine else -1
+        lp = g.logits_params(in_engine[1:])
+        if lp is None and len(in_engine) > 1:
+            lp = dict(stop_ids=in_engine[1:])
         pending, out_of_engine = {}, []
         for i, p in enumerate(ids):
             try:
-                pending[self.engine.submit(p, g.max_new_tokens, eos, g.sampling_params(i))] = i
+                pending[self.engine.submit(p, g.max_new_tokens, eos, g.sampling_params(i), lp)] = i
             except _ffi.TmError as e:
                 rt = STATUS_TO_RESPONSE.get(e.status, ResponseType.INTERNAL_ENGINE_ERROR)
                 out_of_engine.append(Response('', 0, len(p), 'error', [], index=i, error_code=rt.name, error_message=str(e)))
@@ -163,6 +169,8 @@ class Pipeline:
             chunk = ids[b0:b0 + self.max_batch_size]
             try:
                 self.engine.set_sampling([g.sampling_params(b0 + i) for i in range(len(chunk))] if g.sampling_params() else None)
+                lp = g.logits_params(sorted(stop)[:_ffi.MAX_STOP_IDS])
+                self.engine.set_logits_params([lp] * len(chunk) if lp else None)
                 self.engine.prefill(chunk, max_new_tokens=g.max_new_tokens)
                 done = 1
                 while done < g.max_new_tokens:

@@ -84,6 +84,16 @@ class Engine:
         arr = (_ffi.Sampling * len(params))(*[_ffi.Sampling(*(p if p is not None else (1.0, 1, 1.0, 0.0, 0))) for p in params])
         _ffi.check(self._lib.tm_engine_set_sampling(self._h, arr, len(params)))
 
+    def set_logits_params(self, params):
+        """Static batch: per-sequence dicts (repetition_penalty, min_new_tokens, bad_ids, stop_ids) or _ffi.LogitsParam for
+        the NEXT prefill; None / empty = no logits processors."""
+        if not params:
+            _ffi.check(self._lib.tm_engine_set_logits_params(self._h, None, 0))
+            return
+        items = [p if isinstance(p, _ffi.LogitsParam) else _ffi.LogitsParam.make(**(p or {})) for p in params]
+        arr = (_ffi.LogitsParam * len(items))(*items)
+        _ffi.check(self._lib.tm_engine_set_logits_params(self._h, arr, len(items)))
+
     def prefill(self, prompts: Sequence[Sequence[int]], max_new_tokens: int):
         lens = np.asarray([len(p) for p in prompts], np.int32)
         ids = np.concatenate([np.asarray(p, np.int32) for p in prompts]).astype(np.int32)
@@ -125,14 +135,18 @@ class Engine:
         return out
 
     # ---- continuous batching (tm_engine_submit / step / poll / cancel) -----------------------------
-    def submit(self, prompt: Sequence[int], max_new_tokens: int, eos_id: int = -1, sampling=None) -> int:
-        """Queue one request; returns its id.  eos_id < 0 = ignore_eos.  Raises TmError with the reference's status
-        code (TM_TOO_LONG, TM_OOM, TM_INVALID) when the request can never run."""
+    def submit(self, prompt: Sequence[int], max_new_tokens: int, eos_id: int = -1, sampling=None, logits=None) -> int:
+        """Queue one request; returns its id.  eos_id < 0 = ignore_eos.  sampling = (temperature, top_k, top_p, min_p,
+        seed) or None (greedy); logits = dict(repetition_penalty, min_new_tokens, bad_ids, stop_ids) or None.  Raises
+        TmError with the reference's status code (TM_TOO_LONG, TM_OOM, TM_INVALID) when the request can never run."""
         ids = np.ascontiguousarray(np.asarray(prompt, np.int32))
         rid = C.c_int64(0)
         sp = C.byref(_ffi.Sampling(*sampling)) if sampling is not None else None
-        _ffi.check(self._lib.tm_engine_submit_ex(self._h, ids.ctypes.data, int(ids.size), int(max_new_tokens), int(eos_id), sp,
-                                                 C.byref(rid)))
+        if logits is not None and not isinstance(logits, _ffi.LogitsParam):
+            logits = _ffi.LogitsParam.make(**logits)
+        lp = C.byref(logits) if logits is not None else None
+        _ffi.check(self._lib.tm_engine_submit_gen(self._h, ids.ctypes.data, int(ids.size), int(max_new_tokens), int(eos_id), sp,
+                                                  lp, C.byref(rid)))
         return rid.value
 
     def step(self):

@@ -55,8 +55,17 @@ def _shard_linear(lin: dict, kind: str, tp: int, rank: int, group: int, col_slic
     kind 'col': take `col_slices` (list of (lo,hi)) of the output dim; 'row': split the input dim evenly."""
     out = {}
     if 'f8' in lin:
-        assert tp == 1, 'fp8 block-scaled weights: TP sharding of the 128x128 scale blocks is not implemented in this loader'
-        return dict(lin)
+        # e4m3 codes [K,N] + fp32 scales of 128x128 blocks [K/128, ceil(N/128)]: a shard must keep whole blocks
+        f8, bs = lin['f8'], lin['bs']
+        if kind == 'col':
+            assert all(lo % 128 == 0 and (hi % 128 == 0 or hi == f8.shape[1]) for lo, hi in col_slices), \
+                'fp8 column shards must be aligned to the 128-column scale blocks'
+            return {'f8': np.concatenate([f8[:, lo:hi] for lo, hi in col_slices], axis=1),
+                    'bs': np.concatenate([bs[:, lo // 128:(hi + 127) // 128] for lo, hi in col_slices], axis=1)}
+        K = f8.shape[0]
+        assert K % tp == 0 and (K // tp) % 128 == 0, 'fp8 row-parallel shards must keep whole 128-row scale blocks'
+        lo, hi = rank * (K // tp), (rank + 1) * (K // tp)
+        return {'f8': f8[lo:hi], 'bs': bs[lo // 128:hi // 128]}
     if kind == 'col':
         for k, t in lin.items():
             out[k] = np.concatenate([_cols(t, lo, hi) for lo, hi in col_slices], axis=-1)

@@ -828,6 +828,37 @@ class OracleModel:
 # Sampling (generation/sampling.cc:92-183; kernels/sampling_topk_kernels.cu, sampling_topp_kernels.cu:291-384,
 # sampling_kernels.cu:16-94; temperature: generation/logits_processor.cc:105-112)
 # ------------------------------------------------------------------------------------------------
+def logits_process(logits, seen_ids, repetition_penalty=1.0, bad_ids=(), end_ids=(), k_len=0, min_len=0, vocab_offset=0):
+    """Logits processors of ONE sequence, in the reference's order (LogitsProcessor::Forward,
+    src/turbomind/generation/logits_processor.cc:66-115):
+      1. repetition penalty (RepetitionPenaltyKernel, kernels/sampling_penalty_kernels.cu:137-175): every id that occurs
+         in `seen_ids` (prompt + generated so far, each id once):  l < 0 ? l * p : l / p   in fp32;
+      2. bad ids (BanBadWordsKernel single-token case, kernels/ban_bad_words.cu:51-95): l = -max; ids <= 0 skipped;
+      3. min length (batchApplyMinLengthPenalty, sampling_penalty_kernels.cu:198-215): end ids (> 0) get -max while
+         k_len + 1 < min_len  (k_len = sequence length of this step, min_len = prompt length + min_new_tokens).
+    logits: fp16 [V] = columns vocab_offset .. vocab_offset + V of the vocabulary.  Returns fp16 [V]: the reference keeps
+    the fp32 values, the MI355X path rounds them to fp16 once (its sampler consumes fp16), -max = -65504."""
+    l16 = np.asarray(logits, np.float16)
+    V = l16.shape[0]
+    x = l16.astype(np.float32)
+    p = np.float32(repetition_penalty)
+    if p != 1 and p > 0:
+        ids = np.unique(np.asarray(seen_ids, np.int64)) - vocab_offset
+        ids = ids[(ids >= 0) & (ids < V)]
+        v = x[ids]
+        x[ids] = np.where(v < 0, v * p, v / p).astype(np.float32)
+    with np.errstate(over='ignore'):
+        out = x.astype(np.float16)
+    ban = [int(t) for t in bad_ids if t > 0]
+    if k_len + 1 < min_len:
+        ban += [int(t) for t in end_ids if t > 0]
+    for t in ban:
+        c = t - vocab_offset
+        if 0 <= c < V:
+            out[c] = np.float16(-65504.0)
+    return out
+
+
 def sample_filter(logits: np.ndarray, temperature: float = 1.0, top_k: int = 0, top_p: float = 1.0, min_p: float = 0.0):
     """One row.  Returns (token ids of the surviving candidates in sampling order, their renormalised probabilities).
     Order: descending logit, ties by ascending token id (a stable descending sort, as cub's radix sort gives the

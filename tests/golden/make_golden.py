@@ -95,6 +95,43 @@ def main():
 
     np.savez_compressed(os.path.join(OUT, 'reference_python.npz'), **out)
     print('wrote', os.path.join(OUT, 'reference_python.npz'), {k: v.shape for k, v in out.items()})
+    logits_process_golden()
+
+
+def logits_process_golden():
+    """reference_logits_process.npz: lmdeploy/pytorch/engine/logits_process.py:24-65 (_process_bad_words_,
+    _process_repetition_penalty_) -- the PyTorchEngine's restatement of the TurboMind kernels' formulas
+    (kernels/sampling_penalty_kernels.cu:137-175, ban_bad_words.cu:51-95), run on fp32 scores.  Its module-level
+    imports (lmdeploy.messages, pytorch.envs, SchedulerSequence, guided decoding) are stubbed; only the two leaf
+    functions are called."""
+    for name, path in (('lmdeploy.pytorch.engine', f'{REF}/lmdeploy/pytorch/engine'),):
+        m = types.ModuleType(name)
+        m.__path__ = [path]
+        sys.modules[name] = m
+    for name, attrs in (('lmdeploy.messages', ['LogitsProcessor']), ('lmdeploy.pytorch.envs', []),
+                        ('lmdeploy.pytorch.messages', ['SchedulerSequence']),
+                        ('lmdeploy.pytorch.engine.guided_process', ['GuidedDecodingManager'])):
+        m = types.ModuleType(name)
+        for a_ in attrs:
+            setattr(m, a_, object)
+        sys.modules[name] = m
+    sys.modules['lmdeploy.pytorch'].envs = sys.modules['lmdeploy.pytorch.envs']
+    lp = importlib.import_module('lmdeploy.pytorch.engine.logits_process')
+    g = torch.Generator().manual_seed(77)
+    B, V, L = 4, 512, 40
+    logits16 = (torch.randn(B, V, generator=g) * 3).to(torch.float16)
+    ids = torch.randint(0, V, (B, L), generator=g)
+    ids[1, 10:] = ids[1, 3]                                  # repeated ids are penalised once
+    penalty = torch.tensor([1.3, 0.7, 1.0, 2.5])
+    scores = logits16.float().clone()
+    lp._process_repetition_penalty_(scores, ids, penalty)
+    bad = torch.tensor([[5, 17, -1], [3, -1, -1], [-1, -1, -1], [100, 200, 511]])
+    banned = scores.clone()
+    lp._process_bad_words_(banned, bad, bad >= 0)
+    np.savez_compressed(os.path.join(OUT, 'reference_logits_process.npz'), logits=logits16.numpy(), ids=ids.numpy(),
+                        penalty=penalty.numpy(), penalised_fp32=scores.numpy(), bad=bad.numpy(),
+                        banned_mask=torch.isinf(banned).numpy())
+    print('wrote', os.path.join(OUT, 'reference_logits_process.npz'))
 
 
 if __name__ == '__main__':

@@ -205,9 +205,12 @@ def test_engine_thread_serving(cuda):
         margin.append(mg)
         eng.release()
 
-    events = {}                                   # req id -> [(status, n_tokens)] as seen by the callback
+    events, cancel = {}, {}                       # req id -> [(status, n_tokens)] as seen by the callback
     def on_update(rid, st, n):
         events.setdefault(rid, []).append((st, n))
+        if cancel.get('rid') == rid and n >= 4 and st == 0 and 'done' not in cancel:
+            cancel['done'] = n
+            eng.cancel(rid)                       # API calls are allowed from the callback (engine thread, lock not held)
     eng.serve_start(on_update)
     with pytest.raises(TmError) as ei:
         eng.step()
@@ -222,14 +225,14 @@ def test_engine_thread_serving(cuda):
         try:
             for i in mine:
                 rids[i] = eng.submit(prompts[i], news[i])
+                if i == cancel_req:
+                    cancel['rid'] = rids[i]
             for i in mine:
                 have, st = 0, 0
                 while st == 0:
                     st, n = eng.wait(rids[i], have, timeout_ms=20000)
                     assert n > have or st != 0, 'wait timed out'
                     have = n
-                    if i == cancel_req and st == 0 and n >= 4:
-                        eng.cancel(rids[i])
                 results[i] = eng.poll(rids[i])
         except Exception as ex:                  # surfaced by the main thread
             errors.append(ex)
@@ -269,6 +272,92 @@ def test_engine_thread_serving(cuda):
         eng.step()
     assert len(eng.poll(rid)[1]) == 4
     eng.release()
+    eng.close()
+
+
+def test_engine_logits_processors(cuda):
+    """Repetition penalty / bad ids / min_new_tokens + stop ids inside the engine (static and continuous batching).
+    Exact: the processed logits of the first generated token equal oracle.logits_process(raw logits of the plain run,
+    prompt, ...) bit for bit, and every token is the arg-max of the processed logits the engine reports for its step;
+    default parameters reproduce the plain run; the continuous-batching path reproduces the static one.
+    Properties: banned ids never appear; with a huge penalty no token of the prompt or the output repeats; stop ids
+    cannot appear before min_new_tokens and end the request afterwards."""
+    cfg = o.ModelConfig(hidden=256, layers=2, q_heads=4, kv_heads=2, head_dim=128, inter=512, vocab=1024,
+                        kv_bits=8, rope=o.RopeParam(128, 500000.0, 'llama3', 8.0, 1.0, 4.0, 8192))
+    w = o.make_synthetic_weights(cfg, seed=31)
+    rng = np.random.default_rng(6)
+    prompts = [rng.integers(1, cfg.vocab, n).astype(np.int32) for n in (12, 70, 33)]
+    N = 12
+    eng = Engine.from_model_config(cfg, max_batch_size=3, session_len=256, quant_policy=8, max_prefill_token_num=64)
+    eng.load_weights(export_weights(cfg, w))
+    eng.start()
+
+    def run_static(params):
+        """tokens [3][N] and the (processed) logits of every step"""
+        eng.set_logits_params(params)
+        eng.prefill(prompts, max_new_tokens=N)
+        logits = [eng.fetch_logits().copy()]
+        for _ in range(N - 1):
+            eng.decode(1)
+            logits.append(eng.fetch_logits().copy())
+        toks = eng.fetch().copy()
+        eng.release()
+        for b in range(3):
+            for k in range(N):
+                row = logits[k][b].astype(np.float32)
+                assert row[toks[b, k]] == row.max(), (b, k)
+        return toks, logits
+
+    base, base_logits = run_static(None)
+    same, _ = run_static([dict()] * 3)                                    # processors on, every parameter neutral
+    assert np.array_equal(same, base)
+
+    # first-token exactness + properties
+    bad = [[int(base[b, 0]), int(base[b, 1])] for b in range(3)]
+    params = [dict(repetition_penalty=1.7, bad_ids=bad[0]), dict(repetition_penalty=0.8, bad_ids=bad[1], min_new_tokens=5,
+              stop_ids=[int(base[1, 2])]), dict(repetition_penalty=1e4, bad_ids=bad[2])]
+    toks, logits = run_static(params)
+    for b, pr in enumerate(params):
+        end = pr.get('stop_ids', [])
+        ref = o.logits_process(base_logits[0][b], prompts[b], pr['repetition_penalty'], pr['bad_ids'], end,
+                               k_len=len(prompts[b]), min_len=len(prompts[b]) + pr.get('min_new_tokens', 0) if end else 0)
+        assert np.array_equal(logits[0][b].view(np.uint16), ref.view(np.uint16)), b
+        assert not set(bad[b]) & set(toks[b].tolist())
+    assert int(base[1, 2]) not in toks[1, :4].tolist()                    # banned for the first 4 of min_new_tokens = 5
+    seq2 = prompts[2].tolist() + toks[2].tolist()
+    assert len(set(toks[2].tolist())) == N and not set(toks[2].tolist()) & set(prompts[2].tolist()), seq2
+
+    # continuous batching = static (one request at a time through one slot keeps the GEMM shapes identical)
+    eng1 = Engine.from_model_config(cfg, max_batch_size=1, session_len=256, quant_policy=8, max_prefill_token_num=64)
+    eng1.load_weights(export_weights(cfg, w))
+    eng1.start()
+    for b, pr in enumerate(params):
+        eng1.set_logits_params([pr])
+        eng1.prefill([prompts[b]], max_new_tokens=N)
+        eng1.decode(N - 1)
+        want = eng1.fetch()[0].copy()
+        eng1.release()
+        rid = eng1.submit(prompts[b], N, -1, None, pr)
+        while eng1.poll(rid)[0] == 0:
+            eng1.step()
+        got = eng1.poll(rid)[1]
+        assert np.array_equal(got, want[:len(got)]), b                    # the scheduler may stop early on a stop id
+        assert len(got) == N or int(got[-1]) in pr.get('stop_ids', []), b
+        eng1.release()
+    # stop id + min_new_tokens in the scheduler: the plain run's 1st token as stop id ends the request at once ...
+    stop = int(base[0, 0])
+    rid = eng1.submit(prompts[0], N, -1, None, dict(stop_ids=[stop]))
+    while eng1.poll(rid)[0] == 0:
+        eng1.step()
+    assert eng1.poll(rid)[1].tolist() == [stop]
+    # ... unless min_new_tokens bans it: at least 4 tokens, none of the first 3 is the stop id
+    rid = eng1.submit(prompts[0], N, stop, None, dict(min_new_tokens=4))
+    while eng1.poll(rid)[0] == 0:
+        eng1.step()
+    out = eng1.poll(rid)[1].tolist()
+    assert len(out) >= 4 and stop not in out[:3] and (out[-1] == stop or len(out) == N)
+    eng1.release()
+    eng1.close()
     eng.close()
 
 

@@ -550,6 +550,51 @@ def test_sampling_matches_oracle(tm, cuda, V, ld):
     assert not ws.any()
 
 
+@pytest.mark.parametrize('V,ld,off', [(1000, 1000, 0), (4099, 4104, 0), (128256, 128256, 0), (16032, 16032, 16032)])
+def test_logits_process_matches_oracle(tm, cuda, V, ld, off):
+    """tm_seen_update + tm_logits_process against oracle.logits_process, bit exact: seen masks built from a packed
+    prefill (cu_q rows) plus decode-style single tokens, rows with / without penalty, bad ids, min-length bans that are
+    active / expired, ids <= 0 (never banned), a vocabulary shard (off > 0: the mask covers the global vocabulary)."""
+    rng = np.random.default_rng(V + off)
+    vocab = off + V if off else V
+    rows = [dict(p=1.3), dict(p=0.6, bad=[5, 17, 0]), dict(), dict(p=2.5, end=[off + 7, off + V - 1], k=10, ml=14),
+            dict(bad=[off + 3], end=[off + 11, 0, off + 12], k=13, ml=14), dict(p=1.0001, bad=list(range(off + 100, off + 132)))]
+    B = len(rows)
+    words = (vocab + 31) // 32
+    lens = [int(rng.integers(1, 300)) for _ in range(B)]
+    prompt = [rng.integers(0, vocab, n).astype(np.int32) for n in lens]
+    last = rng.integers(0, vocab, B).astype(np.int32)
+    cu_q = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    seen = torch.zeros((B, words), dtype=torch.int32, device='cuda')
+    _ffi.check(tm.tm_seen_update(seen.data_ptr(), words, dev(np.concatenate(prompt)).data_ptr(), dev(cu_q).data_ptr(), B,
+                                 int(cu_q[-1]), vocab, st()))
+    _ffi.check(tm.tm_seen_update(seen.data_ptr(), words, dev(last).data_ptr(), None, B, B, vocab, st()))
+    want = np.zeros((B, words), np.uint32)
+    for b in range(B):
+        for t in list(prompt[b]) + [last[b]]:
+            want[b, t >> 5] |= np.uint32(1) << np.uint32(t & 31)
+    assert np.array_equal(host(seen).view(np.uint32), want)
+
+    logits = (rng.standard_normal((B, ld)) * 4).astype(f16)
+    logits[:, 1::97] = f16(-60000.0)                                     # penalised to -inf in fp16
+    ban = np.full((B, 32), -1, np.int32)
+    end = np.full((B, 9), -1, np.int32)
+    for b, r in enumerate(rows):
+        ban[b, :len(r.get('bad', []))] = r.get('bad', [])
+        end[b, :len(r.get('end', []))] = r.get('end', [])
+    arr = lambda k, d, t: np.asarray([r.get(k, d) for r in rows], t)
+    rep, k_len, min_len = arr('p', 1.0, np.float32), arr('k', 5, np.int32), arr('ml', 0, np.int32)
+    d_logits = dev(logits).clone()
+    _ffi.check(tm.tm_logits_process(d_logits.data_ptr(), B, V, ld, off, seen.data_ptr(), words, dev(rep).data_ptr(),
+                                    dev(ban).data_ptr(), dev(end).data_ptr(), dev(k_len).data_ptr(), dev(min_len).data_ptr(), st()))
+    got = host(d_logits)
+    for b, r in enumerate(rows):
+        ref = o.logits_process(logits[b, :V], list(prompt[b]) + [last[b]], float(rep[b]), r.get('bad', []), r.get('end', []),
+                               int(k_len[b]), int(min_len[b]), vocab_offset=off)
+        assert np.array_equal(got[b, :V].view(np.uint16), ref.view(np.uint16)), f'row {b} {r}'
+        assert np.array_equal(got[b, V:].view(np.uint16), logits[b, V:].view(np.uint16))      # padding untouched
+
+
 def test_sampling_distribution(tm, cuda):
     """Statistical check of the draw: 20000 uniform numbers from the engine's Philox stream over one filtered
     distribution reproduce its probabilities (chi-square far below the rejection threshold)."""

@@ -102,6 +102,35 @@ def test_export_weights_tp_sharding_reassembles(tp):
     assert np.allclose(part, full, rtol=1e-5, atol=1e-5)
 
 
+@pytest.mark.parametrize('tp', [1, 2])
+def test_export_weights_fp8_moe_tp_sharding(tp):
+    """BASELINE config 5's format side (Mixtral, fp8 128x128 block scales, TP = 2): column shards of w_qkv / w1w3 and row
+    shards of wo / w2 keep whole scale blocks -- the dequantised shard equals the slice of the dequantised full weight,
+    for the attention linears and every expert; the router is replicated."""
+    cfg = o.ModelConfig(hidden=256, layers=1, q_heads=4, kv_heads=2, head_dim=128, inter=256, vocab=64, weight_format='fp8',
+                        moe_experts=4, moe_top_k=2)
+    w = o.make_synthetic_weights(cfg, seed=3)
+    L = w['layers'][0]
+    shards = [loader.export_weights(cfg, w, tp, r) for r in range(tp)]
+    deq = lambda s, name: o.fp8_dequant(s[name + '.weight'], s[name + '.scales'])
+    full = lambda lin: o.fp8_dequant(lin['f8'], lin['bs'])
+    wo = np.concatenate([deq(s, 'layers.0.attention.wo') for s in shards], 0)
+    assert np.array_equal(wo.view(np.uint16), full(L['wo']).view(np.uint16))
+    D, Hq, Hkv = 128, 4, 2
+    fq = full(L['w_qkv'])
+    for r, s in enumerate(shards):
+        hq_l, hkv_l = Hq // tp, Hkv // tp
+        exp = np.concatenate([fq[:, r * hq_l * D:(r + 1) * hq_l * D], fq[:, (Hq + r * hkv_l) * D:(Hq + (r + 1) * hkv_l) * D],
+                              fq[:, (Hq + Hkv + r * hkv_l) * D:(Hq + Hkv + (r + 1) * hkv_l) * D]], 1)
+        assert np.array_equal(deq(s, 'layers.0.attention.w_qkv').view(np.uint16), exp.view(np.uint16))
+        assert np.array_equal(s['layers.0.moe_ffn.gate.weight'], L['moe_gate'])
+    for x, E in enumerate(L['experts']):
+        w13 = np.concatenate([deq(s, f'layers.0.moe_ffn.experts.{x}.w1w3') for s in shards], 1)
+        assert np.array_equal(w13.view(np.uint16), full(E['w1w3']).view(np.uint16))
+        w2 = np.concatenate([deq(s, f'layers.0.moe_ffn.experts.{x}.w2') for s in shards], 0)
+        assert np.array_equal(w2.view(np.uint16), full(E['w2']).view(np.uint16))
+
+
 def _fabricate_llama_awq(tmp_path, cfg, w_hf):
     from safetensors.numpy import save_file
     tensors = {}
@@ -232,8 +261,15 @@ def test_api_surface_and_validation():
     gs = GenerationConfig(do_sample=True, top_k=40, top_p=0.9, temperature=0.7, random_seed=5)
     assert gs.sampling_params(3) == (pytest.approx(0.7), 40, pytest.approx(0.9), 0.0, 8)
     assert GenerationConfig(do_sample=True, top_k=1).sampling_params() is None
+    assert g.logits_params() is None
+    gp = GenerationConfig(repetition_penalty=1.1, min_new_tokens=3, bad_token_ids=[7, 9])
+    assert gp.logits_params([2]) == dict(repetition_penalty=pytest.approx(1.1), min_new_tokens=3, bad_ids=[7, 9], stop_ids=[2])
+    lp = _ffi.LogitsParam.make(**gp.logits_params([2]))
+    assert (lp.n_bad_ids, lp.bad_ids[1], lp.n_stop_ids, lp.stop_ids[0], lp.min_new_tokens) == (2, 9, 1, 2, 3)
+    with pytest.raises(ValueError):
+        _ffi.LogitsParam.make(bad_ids=list(range(40)))
     with pytest.raises(NotImplementedError):
-        GenerationConfig(repetition_penalty=1.1)
+        GenerationConfig(bad_words=['x'])
     with pytest.raises(ValueError):
         GenerationConfig(do_sample=True, temperature=0.0)
     import inspect

@@ -264,3 +264,37 @@ def test_fp8_e4m3_matches_torch():
     q, sc = o.fp8_quantize_blockwise(w)
     d = o.fp8_dequant(q, sc).astype(np.float32)
     assert np.abs(d - w.astype(np.float32)).max() <= np.abs(w).max() * 2.0**-3      # 3 mantissa bits
+
+
+def test_logits_process_matches_reference_python():
+    """Repetition penalty / bad ids against the committed outputs of the reference's own Python
+    (lmdeploy/pytorch/engine/logits_process.py:24-65, run by tests/golden/make_golden.py): the oracle equals the
+    reference's fp32 result rounded to fp16 once, bit for bit; banned ids are exactly the reference's."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'reference_logits_process.npz'))
+    for b in range(g['logits'].shape[0]):
+        got = o.logits_process(g['logits'][b], g['ids'][b], float(g['penalty'][b]))
+        assert np.array_equal(got.view(np.uint16), g['penalised_fp32'][b].astype(np.float16).view(np.uint16)), b
+        bad = [int(t) for t in g['bad'][b] if t >= 0]
+        got = o.logits_process(g['logits'][b], g['ids'][b], float(g['penalty'][b]), bad_ids=bad)
+        assert np.array_equal(got == np.float16(-65504), g['banned_mask'][b]), b
+
+
+def test_logits_process_semantics():
+    """The TurboMind kernels' details (sampling_penalty_kernels.cu:137-215, ban_bad_words.cu:51-95): each seen id is
+    penalised once; ids <= 0 are never banned; end ids are banned while k_len + 1 < min_len; a vocabulary shard
+    (vocab_offset) gives the corresponding slice of the full result."""
+    l = np.array([1.0, -2.0, 3.0, 0.5, -1.0, 4.0, 0.25, -0.5], np.float16)
+    got = o.logits_process(l, [1, 2, 2, 2, 7], 2.0)
+    assert got.tolist() == [1.0, -4.0, 1.5, 0.5, -1.0, 4.0, 0.25, -1.0]
+    assert np.array_equal(o.logits_process(l, [1, 2], 1.0), l)
+    got = o.logits_process(l, [], 1.0, bad_ids=[0, 3, -1, 100], end_ids=[0, 5], k_len=4, min_len=6)
+    assert got[0] == 1.0 and got[3] == -65504 and got[5] == -65504 and got[4] == -1.0
+    assert o.logits_process(l, [], 1.0, end_ids=[5], k_len=5, min_len=6)[5] == 4.0        # 5 + 1 < 6 is false
+    rng = np.random.default_rng(0)
+    full = (rng.standard_normal(64) * 3).astype(np.float16)
+    seen = rng.integers(0, 64, 30)
+    whole = o.logits_process(full, seen, 1.7, bad_ids=[9, 40], end_ids=[33], k_len=1, min_len=9)
+    parts = [o.logits_process(full[c:c + 32], seen, 1.7, bad_ids=[9, 40], end_ids=[33], k_len=1, min_len=9, vocab_offset=c)
+             for c in (0, 32)]
+    assert np.array_equal(np.concatenate(parts).view(np.uint16), whole.view(np.uint16))
