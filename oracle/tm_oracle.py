@@ -21,7 +21,12 @@ Pinning status (see DESIGN.md "Oracle"):
   * KV int8/int4 round trip ............. pinned by the reference's known-answer
     test `src/turbomind/kernels/attention/test_quant.cu:32-70` (exact round trip
     of integer-valued data with (scale,zero) = (1,0) / (1,-64)).
-  * KV min/max -> (scale, zero) rule, RoPE, attention, u4 GEMM numerics:
+  * RoPE (Llama-3 inv_freq, cos/sin, application), MoE router, FP8 block
+    dequant, sampling filters, logits processors: pinned against the reference's
+    Python (`pytorch/backends/default/{rotary_embedding,apply_rotary_emb,moe}.py`,
+    `turbomind/weight_format.py:349-384`, `pytorch/engine/logits_process.py:24-96`)
+    via tests/golden/reference_python2.npz and reference_logits_process.npz.
+  * KV min/max -> (scale, zero) rule, attention, u4 GEMM rounding order:
     "parity unpinned" beyond the properties the reference tests state (no
     known-answer vectors exist in the reference and its CUDA code cannot run
     here); the restatement follows the cited lines.

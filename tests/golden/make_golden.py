@@ -96,6 +96,82 @@ def main():
     np.savez_compressed(os.path.join(OUT, 'reference_python.npz'), **out)
     print('wrote', os.path.join(OUT, 'reference_python.npz'), {k: v.shape for k, v in out.items()})
     logits_process_golden()
+    more_golden(wf)
+
+
+def more_golden(wf):
+    """reference_python2.npz: further leaf functions of the reference's Python.
+      * Llama-3 RoPE: backends/default/rotary_embedding.py:141-172 (inv_freq) + :51-78 (cos/sin) and the rotate-half
+        application backends/default/apply_rotary_emb.py:48-77 (the HF channel layout the loader permutes away);
+      * MoE router: backends/default/moe.py:7-33 (softmax -> top-k) + the Mixtral renormalisation w / sum(w);
+      * FP8 block-scaled dequant: lmdeploy/turbomind/weight_format.py:349-384 (FP8Format.dequant);
+      * sampling filters on sorted scores: pytorch/engine/logits_process.py:68-96 (top-k, top-p, min-p)."""
+    import math
+    out = {}
+    g = torch.Generator().manual_seed(4321)
+    # ---- RoPE ---------------------------------------------------------------------------------------------------
+    rot = importlib.import_module('lmdeploy.pytorch.backends.default.rotary_embedding')
+    impl = rot.Llama3RotaryEmbeddingImpl(128, 500000.0, 8.0, 1.0, 4.0, 8192)
+    out['rope_llama3_inv_freq'] = impl.inv_freq.float().numpy()
+    pos = torch.tensor([[0, 1, 5, 63, 1023, 4097, 8191]])
+    cos, sin = impl.forward(torch.zeros(1, dtype=torch.float16), pos)
+    out['rope_pos'] = pos[0].numpy()
+    out['rope_cos'] = cos[0].numpy()          # [T, 128] = [freqs | freqs], fp16
+    out['rope_sin'] = sin[0].numpy()
+    plain = rot.RotaryEmbeddingImpl(128, 10000.0, 1.0)
+    out['rope_default_inv_freq'] = plain.inv_freq.float().numpy()
+    ar = importlib.import_module('lmdeploy.pytorch.backends.default.apply_rotary_emb')
+    q = torch.randn((7, 4, 128), generator=g).to(torch.float16)
+    k = torch.randn((7, 2, 128), generator=g).to(torch.float16)
+    out['rope_q'], out['rope_k'] = q.numpy().copy(), k.numpy().copy()
+    qe, ke = ar.DefaultApplyRotaryEmbImpl().forward(q.clone(), k.clone(), cos[0], sin[0], inplace=False)
+    out['rope_q_out'], out['rope_k_out'] = qe.numpy(), ke.numpy()
+    # ---- MoE router ---------------------------------------------------------------------------------------------
+    moe = importlib.import_module('lmdeploy.pytorch.backends.default.moe')
+    logits = (torch.randn((33, 8), generator=g) * 2).to(torch.float16).float()      # fp16-representable router logits
+    wts, ids = moe.DefaultSoftmaxTopKImpl(2).forward(logits)
+    out['moe_logits'] = logits.numpy()
+    out['moe_topk_ids'] = ids.numpy()
+    out['moe_topk_softmax'] = wts.numpy()
+    out['moe_topk_renorm'] = (wts / wts.sum(-1, keepdim=True)).numpy()
+    # ---- FP8 ----------------------------------------------------------------------------------------------------
+    base = types.ModuleType('lmdeploy.turbomind.builders._base')
+    base._CPP_TO_TORCH = {'fp16': torch.float16}
+    pkg = types.ModuleType('lmdeploy.turbomind.builders')
+    pkg.__path__ = []
+    sys.modules['lmdeploy.turbomind.builders'] = pkg
+    sys.modules['lmdeploy.turbomind.builders._base'] = base
+    codes = torch.randint(0, 256, (256, 384), generator=g, dtype=torch.int32).to(torch.uint8)
+    codes[(codes & 0x7f) == 0x7f] = 0x3c                       # no NaN codes
+    scales = torch.rand((2, 3), generator=g) * 0.02 + 1e-3
+    deq = wf.FP8Format().dequant({'weight': codes, 'scales': scales}, 'fp16')['weight']
+    out['fp8_codes'], out['fp8_block_scales'], out['fp8_dequant'] = codes.numpy(), scales.numpy(), deq.numpy()
+    # ---- sampling filters ---------------------------------------------------------------------------------------
+    lp = importlib.import_module('lmdeploy.pytorch.engine.logits_process')
+    V = 200
+    rows = []
+    for _ in range(6):
+        perm = torch.randperm(V, generator=g)
+        rows.append((torch.linspace(-6, 6, V)[perm] * 1.0).to(torch.float16))      # distinct values: no tie order
+    scores16 = torch.stack(rows)
+    temperature = torch.tensor([1.0, 0.7, 1.3, 1.0, 0.5, 2.0])
+    topk = torch.tensor([V, 40, 10, 5, V, 60])
+    topp = torch.tensor([1.0, 0.9, 0.5, 1.0, 0.8, 0.95])
+    minp = torch.tensor([0.0, 0.0, 0.0, 0.1, 0.05, 0.02])
+    sc = scores16.float() / temperature[:, None]
+    sc, order = sc.sort(1, descending=True)
+    lp._filter_topk_sorted_(sc, topk)
+    lp._filter_topp_sorted_(sc, topp)
+    lp._filter_minp_sorted_(sc, minp)
+    kept = torch.isfinite(sc)
+    out['samp_logits'] = scores16.numpy()
+    out['samp_temperature'], out['samp_topk'], out['samp_topp'], out['samp_minp'] = (temperature.numpy(), topk.numpy(),
+                                                                                    topp.numpy(), minp.numpy())
+    out['samp_order'] = order.numpy()
+    out['samp_kept'] = kept.numpy()
+    out['samp_probs'] = sc.softmax(-1).numpy()
+    np.savez_compressed(os.path.join(OUT, 'reference_python2.npz'), **out)
+    print('wrote', os.path.join(OUT, 'reference_python2.npz'), {k: v.shape for k, v in out.items()})
 
 
 def logits_process_golden():

@@ -298,3 +298,76 @@ def test_logits_process_semantics():
     parts = [o.logits_process(full[c:c + 32], seen, 1.7, bad_ids=[9, 40], end_ids=[33], k_len=1, min_len=9, vocab_offset=c)
              for c in (0, 32)]
     assert np.array_equal(np.concatenate(parts).view(np.uint16), whole.view(np.uint16))
+
+
+def _golden2():
+    import os
+    return np.load(os.path.join(os.path.dirname(__file__), 'golden', 'reference_python2.npz'))
+
+
+def test_rope_matches_reference_python():
+    """Llama-3 RoPE against the reference's Python (backends/default/rotary_embedding.py:51-78,141-172 and
+    apply_rotary_emb.py:48-77, outputs committed by make_golden.py).
+      * inv_freq: TurboMind's exp2f / smooth-clamp form (attention_weight.cc:37-93) equals the HF piecewise form to fp32
+        rounding (rel 4e-6); the unscaled default base likewise;
+      * cos / sin tables (fp16): within 1e-3 (the angle is an fp32 product of up to 8191 rad);
+      * application: the interleaved-pair rotation on loader-permuted channels equals the reference's rotate-half
+        rotation on HF-ordered channels BIT FOR BIT given the same cos / sin (same fp16 op sequence)."""
+    g = _golden2()
+    p = o.RopeParam(128, 500000.0, 'llama3', 8.0, 1.0, 4.0, 8192)
+    inv = o.rope_inv_freq(p)
+    assert np.allclose(inv, g['rope_llama3_inv_freq'], rtol=4e-6, atol=0)
+    assert np.allclose(o.rope_inv_freq(o.RopeParam(128, 10000.0, 'default', 1.0, 1.0, 4.0, 8192)), g['rope_default_inv_freq'],
+                       rtol=4e-6, atol=0)
+    cos, sin = o.rope_cos_sin(p, g['rope_pos'])
+    assert np.abs(cos.astype(np.float32) - g['rope_cos'][:, :64].astype(np.float32)).max() <= 1e-3
+    assert np.abs(sin.astype(np.float32) - g['rope_sin'][:, :64].astype(np.float32)).max() <= 1e-3
+    assert np.array_equal(g['rope_cos'][:, :64], g['rope_cos'][:, 64:])          # [freqs | freqs]
+    c, s_ = g['rope_cos'][:, :64], g['rope_sin'][:, :64]
+    for x, want, heads in ((g['rope_q'], g['rope_q_out'], 4), (g['rope_k'], g['rope_k_out'], 2)):
+        T = x.shape[0]
+        inter = o.permute_qk_for_interleaved_rope(x.reshape(T, heads * 128), heads, 128).reshape(T, heads, 128)
+        got = o.rope_apply(inter, c, s_)
+        want_inter = o.permute_qk_for_interleaved_rope(want.reshape(T, heads * 128), heads, 128).reshape(T, heads, 128)
+        assert np.array_equal(got.view(np.uint16), want_inter.view(np.uint16))
+
+
+def test_moe_gate_matches_reference_python():
+    """Router against backends/default/moe.py:7-33 (softmax over all experts -> top-k) + Mixtral's renormalisation:
+    same experts in the same order; norm_topk weights = renormalised top-k softmax, plain weights = the softmax."""
+    g = _golden2()
+    logits = g['moe_logits']
+    x = logits.astype(np.float16)
+    assert np.array_equal(x.astype(np.float32), logits)
+    eye = np.eye(8, dtype=np.float16)
+    lg, ids, w = o.moe_gate(x, eye, 2, norm_topk=True)
+    assert np.array_equal(lg, logits) and np.array_equal(ids, g['moe_topk_ids'])
+    assert np.allclose(w, g['moe_topk_renorm'], rtol=2e-6, atol=0)
+    _, ids2, w2 = o.moe_gate(x, eye, 2, norm_topk=False)
+    assert np.array_equal(ids2, g['moe_topk_ids']) and np.allclose(w2, g['moe_topk_softmax'], rtol=2e-6, atol=0)
+
+
+def test_fp8_dequant_matches_reference_weight_format():
+    """FP8Format.dequant (lmdeploy/turbomind/weight_format.py:349-384): e4m3 decode x 128x128 block scale.  The
+    reference multiplies in fp32 and rounds to fp16 once; the kernel's recipe (oracle.fp8_dequant) rounds the scale to
+    fp16 first and multiplies in fp16 -- two roundings, so the results agree to 2^-10 relative (one fp16 ulp), and
+    exactly when the block scale is a power of two."""
+    g = _golden2()
+    got = o.fp8_dequant(g['fp8_codes'], g['fp8_block_scales']).astype(np.float32)
+    ref = g['fp8_dequant'].astype(np.float32)
+    assert np.all(np.abs(got - ref) <= np.abs(ref) * 2.0**-10 + 1e-7)
+    pow2 = np.array([[2.0**-6, 2.0**-7, 2.0**-5], [2.0**-8, 2.0**-6, 2.0**-4]], np.float32)
+    exact = (o.fp8_e4m3_to_f32(g['fp8_codes']) * np.repeat(np.repeat(pow2, 128, 0), 128, 1)).astype(np.float16)
+    assert np.array_equal(o.fp8_dequant(g['fp8_codes'], pow2).view(np.uint16), exact.view(np.uint16))
+
+
+def test_sampling_filters_match_reference_python():
+    """top-k -> top-p -> min-p on descending scores against pytorch/engine/logits_process.py:68-96 (committed outputs):
+    the same surviving candidates in the same order and the same renormalised probabilities."""
+    g = _golden2()
+    for b in range(g['samp_logits'].shape[0]):
+        ids, p = o.sample_filter(g['samp_logits'][b], float(g['samp_temperature'][b]), int(g['samp_topk'][b]),
+                                 float(g['samp_topp'][b]), float(g['samp_minp'][b]))
+        kept = g['samp_kept'][b]
+        assert ids.tolist() == g['samp_order'][b][kept].tolist(), b
+        assert np.allclose(p, g['samp_probs'][b][kept], rtol=1e-4, atol=1e-7), b
