@@ -176,7 +176,8 @@ int    tm_linear_destroy(tm_linear* w);
  * logits = x Wg (fp32), top-k on the logits (ties: lower expert id), w = softmax over the selected experts
  * (norm_topk != 0) or over all experts, times routed_scale.  Expert weights: weight_type TM_WEIGHT_U4 / TM_WEIGHT_FP8,
  * boundary layouts of tm_linear_prepare; w13 = [hidden][2*inter] with (gate_j, up_j) column-interleaved, w2 =
- * [inter][hidden].  gate: fp16 [hidden][experts].  All pointers device.  topk_ids_out / topk_w_out (device
+ * [inter][hidden].  FP8 w13: w1 and w3 are block-quantised separately in a checkpoint, so the scale row of w13 is
+ * [w1's inter/128 blocks | w3's inter/128 blocks] (inter % 128 == 0) -- also for the engine's *.w1w3.scales slots.  gate: fp16 [hidden][experts].  All pointers device.  topk_ids_out / topk_w_out (device
  * [tokens][top_k], may be NULL) expose the routing for tests. */
 typedef struct tm_moe tm_moe;
 int    tm_moe_create(tm_moe** out, int hidden, int inter, int experts, int top_k, int weight_type, int norm_topk,

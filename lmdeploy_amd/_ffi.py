@@ -171,6 +171,13 @@ def load():
     if not os.path.exists(_LIB_PATH):
         raise ImportError(f'{_LIB_PATH} not found: build it with `python -c "import __graft_entry__ as g; g.build()"` '
                           f'or `make -C lmdeploy_amd/csrc`. There is no CPU fallback.')
+    # Load order: PyTorch-ROCm bundles its own libamdhip64 / libhsa-runtime64; when this library (linked against
+    # /opt/rocm) is loaded FIRST and torch later, the process ends up with mismatched runtimes and aborts at exit
+    # ("double free or corruption").  torch first is the order every GPU test and bench run uses.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(_LIB_PATH, mode=C.RTLD_GLOBAL)
     for name, (res, args) in _SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the .so does not export a declared symbol

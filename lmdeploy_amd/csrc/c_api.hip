@@ -264,7 +264,7 @@ int tm_linear_prepare(tm_linear* w, const void* weight, const void* scales, cons
     }
     if (w->w.type == TM_WEIGHT_FP8) {
         TM_REQUIRE(scales, "fp8 weights need their 128x128 block scales");
-        return linear_weight_prepare_fp8(w->w, (const uint8_t*)weight, (const float*)scales, (hipStream_t)st);
+        return linear_weight_prepare_fp8(w->w, (const uint8_t*)weight, (const float*)scales, false, (hipStream_t)st);
     }
     return linear_weight_prepare_f16(w->w, (const half_t*)weight, (hipStream_t)st);
 }
@@ -399,8 +399,8 @@ int tm_moe_set_expert(tm_moe* m, int expert, const void* w13_weight, const void*
         return linear_weight_prepare_u4(m->m.w2[expert], (const int32_t*)w2_weight, (const half_t*)w2_scales,
                                         (const half_t*)w2_zeros, (hipStream_t)st);
     }
-    TM_TRY_RC(linear_weight_prepare_fp8(m->m.w13[expert], (const uint8_t*)w13_weight, (const float*)w13_scales, (hipStream_t)st));
-    return linear_weight_prepare_fp8(m->m.w2[expert], (const uint8_t*)w2_weight, (const float*)w2_scales, (hipStream_t)st);
+    TM_TRY_RC(linear_weight_prepare_fp8(m->m.w13[expert], (const uint8_t*)w13_weight, (const float*)w13_scales, true, (hipStream_t)st));
+    return linear_weight_prepare_fp8(m->m.w2[expert], (const uint8_t*)w2_weight, (const float*)w2_scales, false, (hipStream_t)st);
 }
 
 size_t tm_moe_workspace(const tm_moe* m, int tokens)

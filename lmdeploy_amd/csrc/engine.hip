@@ -389,7 +389,8 @@ static int prepare_linear(tm_engine* e, LinearSlots& l)
     else if (l.w.type == TM_WEIGHT_FP8) {
         Slot &w = e->slots[l.prefix + ".weight"], &s = e->slots[l.prefix + ".scales"];
         TM_REQUIRE(w.filled && s.filled, "weight not loaded: " + l.prefix);
-        TM_TRY(linear_weight_prepare_fp8(l.w, (const uint8_t*)w.dev, (const float*)s.dev, e->stream));
+        const bool gated = l.prefix.size() >= 5 && l.prefix.compare(l.prefix.size() - 5, 5, ".w1w3") == 0;
+        TM_TRY(linear_weight_prepare_fp8(l.w, (const uint8_t*)w.dev, (const float*)s.dev, gated, e->stream));
         TM_HIP_CHECK(hipStreamSynchronize(e->stream));
         for (Slot* p : {&w, &s}) {
             TM_HIP_CHECK(hipFree(p->dev));

@@ -139,7 +139,10 @@ __global__ void repack_fp8_kernel(uint8_t* __restrict__ out, const uint8_t* __re
 // 128 x 128 block scales (fp32 [K/128][N/128]) -> per-column group scales in the (s, 0) half2 slots of the u4 path:
 // the reference expands each block scale over its 128 output channels and casts it to the activation type
 // (BlockscaleToGroupscale, models/linear_weight.cc:138-150); w = h(f16(e4m3) * s) needs no zero point.
-__global__ void repack_sz_fp8_kernel(uint32_t* __restrict__ out, const float* __restrict__ block_scales, int KB, int N)
+// gated = the fused w1w3 linear with (gate_j, up_j)-interleaved columns: w1 and w3 are block-quantised SEPARATELY in a
+// checkpoint, so the scale row is [w1's inter/128 blocks | w3's inter/128 blocks] and column n = 2j + which reads block
+// which * inter/128 + j/128 (the interleave of ffn.py:31-34 applied to the expanded per-column scales).
+__global__ void repack_sz_fp8_kernel(uint32_t* __restrict__ out, const float* __restrict__ block_scales, int KB, int N, int gated)
 {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (size_t)KB * N) {
@@ -147,7 +150,9 @@ __global__ void repack_sz_fp8_kernel(uint32_t* __restrict__ out, const float* __
     }
     const int     kb = (int)(idx / N);
     const int     n  = (int)(idx % N);
-    const half_t  s  = (half_t)block_scales[(size_t)kb * ((N + 127) / 128) + n / 128];
+    const int     nb = (N + 127) / 128;
+    const int     b  = gated ? (n & 1) * (nb / 2) + (n >> 1) / 128 : n / 128;
+    const half_t  s  = (half_t)block_scales[(size_t)kb * nb + b];
     const half2_t pr = {s, (half_t)0.f};
     out[idx]         = bit_cast<uint32_t>(pr);  // [kb][nt][16] == [kb][n]
 }
@@ -185,9 +190,10 @@ int linear_weight_prepare_u4(LinearWeight& w, const int32_t* qweight, const half
     return 0;
 }
 
-int linear_weight_prepare_fp8(LinearWeight& w, const uint8_t* weight, const float* block_scales, hipStream_t st)
+int linear_weight_prepare_fp8(LinearWeight& w, const uint8_t* weight, const float* block_scales, bool gated_scales, hipStream_t st)
 {
     TM_REQUIRE(w.K % 128 == 0 && w.N % 16 == 0, "K % 128 == 0 and N % 16 == 0");
+    TM_REQUIRE(!gated_scales || w.N % 256 == 0, "fp8 w1w3: inter must be a multiple of the 128-column scale block");
     w.type         = 2;
     w.group        = 128;
     w.packed_bytes = (size_t)w.K * w.N;
@@ -200,7 +206,7 @@ int linear_weight_prepare_fp8(LinearWeight& w, const uint8_t* weight, const floa
     repack_fp8_kernel<<<(nv + 255) / 256, 256, 0, st>>>((uint8_t*)w.packed, weight, w.K, w.N);
     TM_HIP_CHECK(hipGetLastError());
     const size_t ns = (size_t)(w.K / 128) * w.N;
-    repack_sz_fp8_kernel<<<(ns + 255) / 256, 256, 0, st>>>(w.sz, block_scales, w.K / 128, w.N);
+    repack_sz_fp8_kernel<<<(ns + 255) / 256, 256, 0, st>>>(w.sz, block_scales, w.K / 128, w.N, gated_scales ? 1 : 0);
     TM_HIP_CHECK(hipGetLastError());
     return 0;
 }

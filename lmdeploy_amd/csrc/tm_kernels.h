@@ -118,7 +118,7 @@ int    linear_weight_prepare_u4(LinearWeight& w, const int32_t* qweight /*[K][N/
                                 const half_t* zeros, hipStream_t st);
 int    linear_weight_prepare_f16(LinearWeight& w, const half_t* weight /*[K][N]*/, hipStream_t st);
 int    linear_weight_prepare_fp8(LinearWeight& w, const uint8_t* weight /*[K][N] e4m3*/, const float* block_scales /*[K/128][ceil(N/128)]*/,
-                                 hipStream_t st);
+                                 bool gated_scales /* w1w3: scale row = [w1 blocks | w3 blocks] for interleaved columns */, hipStream_t st);
 void   linear_weight_free(LinearWeight& w);
 size_t gemm_workspace_bytes(int M, int N, int splits);
 GemmConfig gemm_pick_config(const LinearWeight& w, int M);

@@ -178,8 +178,9 @@ class TurbomindEngineConfig:
             raise NotImplementedError('quant_policy=TURBO_QUANT')
         if self.dtype == 'bfloat16':
             raise NotImplementedError('dtype=bfloat16: the AWQ path is fp16 (lmdeploy/turbomind/converter.py:40-48)')
-        if self.model_format not in (None, 'awq', 'hf'):
-            raise NotImplementedError(f'model_format={self.model_format!r}: only "awq" (W4A16 g128) and "hf" (fp16)')
+        if self.model_format not in (None, 'awq', 'hf', 'fp8'):
+            raise NotImplementedError(f'model_format={self.model_format!r}: only "awq" (W4A16 g128), "fp8" (e4m3, 128x128 '
+                                      f'block scales) and "hf" (fp16)')
         if self.cache_block_seq_len != 64:
             raise NotImplementedError('cache_block_seq_len must be 64')
         unsupported = {'dp': 1, 'cp': 1, 'ep': 1, 'attn_tp_size': None, 'attn_cp_size': None, 'attn_dp_size': None,

@@ -47,15 +47,19 @@ class Pipeline:
         synthetic = model_path.startswith('synthetic:')
         if synthetic:
             self.model_cfg = checkpoint.ModelConfig(**SYNTHETIC[model_path.split(':', 1)[1]],
-                                                    quantized=cfg.model_format != 'hf')
+                                                    quantized=cfg.model_format != 'hf',
+                                                    weight_format={'hf': 'f16', 'fp8': 'fp8'}.get(cfg.model_format, 'u4'))
         else:
             self.model_cfg = checkpoint.read_config(model_path)
-            if cfg.model_format == 'awq' and not self.model_cfg.quantized:
-                raise ValueError('model_format="awq" but the checkpoint has no AWQ quantization_config')
+            have = self.model_cfg.weight_format if self.model_cfg.quantized else 'f16'
+            if cfg.model_format in ('awq', 'fp8') and {'awq': 'u4', 'fp8': 'fp8'}[cfg.model_format] != have:
+                raise ValueError(f'model_format="{cfg.model_format}" but the checkpoint\'s quantization_config says {have} '
+                                 f'(lmdeploy/turbomind/converter.py:174-176)')
         session_len = cfg.session_len or self.model_cfg.max_position_embeddings
         devices = cfg.devices or list(range(cfg.tp))
         self.engine = Engine.from_model_config(
-            self.model_cfg, weight_type=0 if self.model_cfg.quantized else 1, tp=cfg.tp, rank=rank,
+            self.model_cfg, weight_type={'u4': 0, 'f16': 1, 'fp8': 2}[self.model_cfg.weight_format if self.model_cfg.quantized
+                                                                        else 'f16'], tp=cfg.tp, rank=rank,
             device=devices[rank % len(devices)], max_batch_size=cfg.max_batch_size or 64, session_len=session_len,
             quant_policy=int(cfg.quant_policy), cache_max_entry_count=cfg.cache_max_entry_count,
             max_prefill_token_num=cfg.max_prefill_token_num or 8192)

@@ -57,6 +57,14 @@ def _shard_linear(lin: dict, kind: str, tp: int, rank: int, group: int, col_slic
     if 'f8' in lin:
         # e4m3 codes [K,N] + fp32 scales of 128x128 blocks [K/128, ceil(N/128)]: a shard must keep whole blocks
         f8, bs = lin['f8'], lin['bs']
+        if lin.get('gated'):
+            # fused w1w3, (gate_j, up_j)-interleaved codes, scale row = [w1 blocks | w3 blocks]: rank r owns the inter
+            # columns [r*I/tp, (r+1)*I/tp) of both halves
+            (lo, hi), = col_slices
+            assert kind == 'col' and lo % 256 == 0 and hi % 256 == 0, 'fp8 w1w3 shards must keep whole 128-column blocks'
+            half = bs.shape[1] // 2
+            b0, b1 = lo // 256, hi // 256
+            return {'f8': f8[:, lo:hi], 'bs': np.concatenate([bs[:, b0:b1], bs[:, half + b0:half + b1]], axis=1), 'gated': True}
         if kind == 'col':
             assert all(lo % 128 == 0 and (hi % 128 == 0 or hi == f8.shape[1]) for lo, hi in col_slices), \
                 'fp8 column shards must be aligned to the 128-column scale blocks'

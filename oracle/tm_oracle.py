@@ -719,6 +719,17 @@ def make_synthetic_weights(cfg: ModelConfig, seed: int = 0, quantized: bool = Tr
         q, s, z, _ = quantize_groupwise_u4(w, cfg.group)
         return dict(q=q, s=s, z=z)
 
+    def lin13(K, I2):
+        """fused w1w3 [K, 2I], (gate_j, up_j) interleaved.  fp8: w1 and w3 are block-quantised separately (as in a
+        checkpoint); codes interleaved, scale row = [w1 blocks | w3 blocks] ('gated' layout)"""
+        if not (quantized and cfg.weight_format == 'fp8'):
+            return lin(K, I2)
+        w = (rng.standard_normal((K, I2), dtype=f32) * (0.1 / math.sqrt(K))).astype(f16)
+        (g8, gs), (u8, us) = fp8_quantize_blockwise(w[:, 0::2]), fp8_quantize_blockwise(w[:, 1::2])
+        f8 = np.empty((K, I2), np.uint8)
+        f8[:, 0::2], f8[:, 1::2] = g8, u8
+        return dict(f8=f8, bs=np.concatenate([gs, us], axis=1), gated=True)
+
     layers = []
     for _ in range(cfg.layers):
         layers.append(dict(
@@ -727,8 +738,8 @@ def make_synthetic_weights(cfg: ModelConfig, seed: int = 0, quantized: bool = Tr
             wo=lin(nq, H),
             ffn_norm=(1 + 0.02 * rng.standard_normal(H, dtype=f32)).astype(f16),
             **(dict(moe_gate=(0.2 * rng.standard_normal((H, cfg.moe_experts), dtype=f32)).astype(f16),
-                    experts=[dict(w1w3=lin(H, 2 * I), w2=lin(I, H)) for _ in range(cfg.moe_experts)])
-               if cfg.moe_experts else dict(w1w3=lin(H, 2 * I), w2=lin(I, H))),
+                    experts=[dict(w1w3=lin13(H, 2 * I), w2=lin(I, H)) for _ in range(cfg.moe_experts)])
+               if cfg.moe_experts else dict(w1w3=lin13(H, 2 * I), w2=lin(I, H))),
         ))
     return dict(
         tok_embeddings=(0.02 * rng.standard_normal((cfg.vocab, H), dtype=f32)).astype(f16),
@@ -742,13 +753,13 @@ def _dense_weight(W, group):
     if 'q' in W:
         return w4a16_dequant(W['q'], W['s'], W['z'], group)
     if 'f8' in W:
-        return fp8_dequant(W['f8'], W['bs'])
+        return fp8_dequant(W['f8'], W['bs'], W.get('gated', False))
     return W['w']
 
 
 def _linear(x, W, group, gated=False):
     if 'f8' in W:
-        acc = gemm_f16_f32acc(x, fp8_dequant(W['f8'], W['bs']))
+        acc = gemm_f16_f32acc(x, fp8_dequant(W['f8'], W['bs'], W.get('gated', False)))
     elif 'q' in W:
         acc = gemm_f16_f32acc(x, w4a16_dequant(W['q'], W['s'], W['z'], group))
     else:
@@ -943,15 +954,26 @@ def fp8_e4m3_from_f32(x: np.ndarray) -> np.ndarray:
     return np.where(np.signbit(x), code | 0x80, code).astype(np.uint8)
 
 
-def fp8_expand_block_scales(block_scales: np.ndarray, K: int, N: int) -> np.ndarray:
-    """[K/128][ceil(N/128)] fp32 -> per-column group scales fp16 [K/128][N] (BlockscaleToGroupscale)"""
-    return np.repeat(np.asarray(block_scales, np.float32), 128, axis=1)[:, :N].astype(np.float16)
+def fp8_expand_block_scales(block_scales: np.ndarray, K: int, N: int, gated: bool = False) -> np.ndarray:
+    """[K/128][ceil(N/128)] fp32 -> per-column group scales fp16 [K/128][N] (BlockscaleToGroupscale,
+    models/linear_weight.cc:138-150).  gated: the fused w1w3 linear with (gate_j, up_j)-interleaved columns whose scale
+    row is [w1's inter/128 blocks | w3's inter/128 blocks] (w1 / w3 are block-quantised separately in a checkpoint;
+    the interleave of builders/ffn.py:31-34 acts on the expanded per-column scales)."""
+    bs = np.asarray(block_scales, np.float32)
+    if not gated:
+        return np.repeat(bs, 128, axis=1)[:, :N].astype(np.float16)
+    assert N % 256 == 0 and bs.shape[1] == N // 128
+    half = bs.shape[1] // 2
+    out = np.empty((bs.shape[0], N), np.float32)
+    out[:, 0::2] = np.repeat(bs[:, :half], 128, axis=1)
+    out[:, 1::2] = np.repeat(bs[:, half:], 128, axis=1)
+    return out.astype(np.float16)
 
 
-def fp8_dequant(wq: np.ndarray, block_scales: np.ndarray) -> np.ndarray:
+def fp8_dequant(wq: np.ndarray, block_scales: np.ndarray, gated: bool = False) -> np.ndarray:
     """w[k, n] = h( f16(e4m3[k, n]) * s[k/128, n] ): exact conversion, one fp16 multiply"""
     K, N = wq.shape
-    s = fp8_expand_block_scales(block_scales, K, N)
+    s = fp8_expand_block_scales(block_scales, K, N, gated)
     v = fp8_e4m3_to_f32(wq).astype(np.float16)              # exact
     return hmul(v, np.repeat(s, 128, axis=0)[:K])
 

@@ -683,9 +683,11 @@ def test_moe_ffn(tm, cuda, wtype, T):
         w2 = (rng.standard_normal((I, H)) * (0.1 / math.sqrt(I))).astype(f16)
         w13 = o.interleave_w1w3(w1, w3)
         if wtype == 'fp8':
-            q13, s13 = o.fp8_quantize_blockwise(w13)
+            # w1 / w3 block-quantised separately (as in a checkpoint): interleaved codes, scale row [w1 blocks | w3 blocks]
+            (q1, s1), (q3, s3) = o.fp8_quantize_blockwise(w1), o.fp8_quantize_blockwise(w3)
+            q13, s13 = o.interleave_w1w3(q1, q3), np.concatenate([s1, s3], axis=1)
             q2, s2 = o.fp8_quantize_blockwise(w2)
-            experts.append((o.fp8_dequant(q13, s13), o.fp8_dequant(q2, s2)))
+            experts.append((o.fp8_dequant(q13, s13, gated=True), o.fp8_dequant(q2, s2)))
             _ffi.check(tm.tm_moe_set_expert(h, e, dev(q13).data_ptr(), dev(s13).data_ptr(), None, dev(q2).data_ptr(),
                                             dev(s2).data_ptr(), None, st()))
         else:

@@ -112,8 +112,8 @@ def test_export_weights_fp8_moe_tp_sharding(tp):
     w = o.make_synthetic_weights(cfg, seed=3)
     L = w['layers'][0]
     shards = [loader.export_weights(cfg, w, tp, r) for r in range(tp)]
-    deq = lambda s, name: o.fp8_dequant(s[name + '.weight'], s[name + '.scales'])
-    full = lambda lin: o.fp8_dequant(lin['f8'], lin['bs'])
+    deq = lambda s, name: o.fp8_dequant(s[name + '.weight'], s[name + '.scales'], gated=name.endswith('w1w3'))
+    full = lambda lin: o.fp8_dequant(lin['f8'], lin['bs'], lin.get('gated', False))
     wo = np.concatenate([deq(s, 'layers.0.attention.wo') for s in shards], 0)
     assert np.array_equal(wo.view(np.uint16), full(L['wo']).view(np.uint16))
     D, Hq, Hkv = 128, 4, 2
@@ -244,6 +244,85 @@ def test_hf_internlm2_fp16_checkpoint_reader(tmp_path):
         checkpoint.read_config(str(tmp_path))
 
 
+def test_hf_mixtral_fp8_checkpoint_reader(tmp_path):
+    """BASELINE config 5's on-disk format: a Mixtral checkpoint with block-128 FP8 weights (float8_e4m3fn `.weight`
+    [out, in] + fp32 `.weight_scale_inv` [out/128, in/128], bf16 norms / router / embeddings; reference:
+    lmdeploy/turbomind/models/mixtral.py:57-106, weight_format.py:349-384).  The reader must transpose codes and scales,
+    keep the scales through the RoPE channel permutation (one block = one head), fuse QKV, interleave w1 / w3 codes with the
+    [w1 blocks | w3 blocks] scale row, and the dequantised result must equal the reference formula on the HF tensors;
+    TP = 2 shards of the export reassemble."""
+    import torch
+    from safetensors.torch import save_file
+    g = torch.Generator().manual_seed(5)
+    H, D, Hq, Hkv, I, V, E = 256, 128, 4, 2, 256, 64, 4
+
+    def fp8_linear(out_f, in_f):
+        w = torch.randn((out_f, in_f), generator=g) * 0.05
+        sc = torch.zeros((out_f // 128, in_f // 128))
+        q = torch.zeros((out_f, in_f), dtype=torch.float8_e4m3fn)
+        for i in range(out_f // 128):
+            for j in range(in_f // 128):
+                blk = w[i * 128:(i + 1) * 128, j * 128:(j + 1) * 128]
+                sc[i, j] = blk.abs().max() / 448.0
+                q[i * 128:(i + 1) * 128, j * 128:(j + 1) * 128] = (blk / sc[i, j]).to(torch.float8_e4m3fn)
+        return q, sc
+
+    def ref_dequant(q, sc):      # FP8Format.dequant on the HF orientation, then [in, out]
+        full = q.float() * sc.repeat_interleave(128, 0).repeat_interleave(128, 1)
+        return full.to(torch.float16).numpy().T
+
+    t, hf = {}, {}
+    p = 'model.layers.0'
+    names = {f'{p}.self_attn.q_proj': (Hq * D, H), f'{p}.self_attn.k_proj': (Hkv * D, H), f'{p}.self_attn.v_proj': (Hkv * D, H),
+             f'{p}.self_attn.o_proj': (H, Hq * D)}
+    for x in range(E):
+        names.update({f'{p}.block_sparse_moe.experts.{x}.w1': (I, H), f'{p}.block_sparse_moe.experts.{x}.w3': (I, H),
+                      f'{p}.block_sparse_moe.experts.{x}.w2': (H, I)})
+    for n, (o_f, i_f) in names.items():
+        q, sc = fp8_linear(o_f, i_f)
+        t[n + '.weight'], t[n + '.weight_scale_inv'] = q, sc
+        hf[n] = ref_dequant(q, sc)
+    gate = (torch.randn((E, H), generator=g) * 0.2).to(torch.bfloat16)
+    t[f'{p}.block_sparse_moe.gate.weight'] = gate
+    t[f'{p}.input_layernorm.weight'] = torch.ones(H, dtype=torch.bfloat16)
+    t[f'{p}.post_attention_layernorm.weight'] = (1 + 0.1 * torch.randn(H, generator=g)).to(torch.bfloat16)
+    t['model.embed_tokens.weight'] = torch.randn((V, H), generator=g).to(torch.bfloat16)
+    t['model.norm.weight'] = torch.ones(H, dtype=torch.bfloat16)
+    t['lm_head.weight'] = torch.randn((V, H), generator=g).to(torch.bfloat16)
+    save_file(t, os.path.join(tmp_path, 'model.safetensors'))
+    json.dump({'architectures': ['MixtralForCausalLM'], 'hidden_size': H, 'num_hidden_layers': 1, 'num_attention_heads': Hq,
+               'num_key_value_heads': Hkv, 'head_dim': D, 'intermediate_size': I, 'vocab_size': V, 'rms_norm_eps': 1e-5,
+               'rope_theta': 1e6, 'num_local_experts': E, 'num_experts_per_tok': 2, 'eos_token_id': 2,
+               'quantization_config': {'quant_method': 'fp8', 'fmt': 'e4m3', 'weight_block_size': [128, 128]}},
+              open(os.path.join(tmp_path, 'config.json'), 'w'))
+    mc = checkpoint.read_config(str(tmp_path))
+    assert (mc.weight_format, mc.quantized, mc.moe_experts, mc.moe_top_k, mc.arch) == ('fp8', True, E, 2, 'llama')
+    w = checkpoint.load_hf_weights(str(tmp_path), mc)
+    L = w['layers'][0]
+    close = lambda a, b: np.all(np.abs(a.astype(np.float32) - b.astype(np.float32)) <= np.abs(b.astype(np.float32)) * 2.0**-10 + 1e-7)
+    deq = lambda lin: o.fp8_dequant(lin['f8'], lin['bs'], lin.get('gated', False))
+    exp_qkv = np.concatenate([o.permute_qk_for_interleaved_rope(hf[f'{p}.self_attn.q_proj'], Hq, D),
+                              o.permute_qk_for_interleaved_rope(hf[f'{p}.self_attn.k_proj'], Hkv, D), hf[f'{p}.self_attn.v_proj']], -1)
+    assert L['w_qkv']['f8'].shape == (H, (Hq + 2 * Hkv) * D) and L['w_qkv']['bs'].shape == (2, Hq + 2 * Hkv)
+    assert close(deq(L['w_qkv']), exp_qkv) and close(deq(L['wo']), hf[f'{p}.self_attn.o_proj'])
+    assert np.array_equal(L['moe_gate'], gate.float().numpy().astype(f16).T)
+    for x in range(E):
+        e = f'{p}.block_sparse_moe.experts.{x}'
+        assert L['experts'][x]['w1w3']['gated'] and L['experts'][x]['w1w3']['bs'].shape == (2, 2 * I // 128)
+        assert close(deq(L['experts'][x]['w1w3']), o.interleave_w1w3(hf[e + '.w1'], hf[e + '.w3']))
+        assert close(deq(L['experts'][x]['w2']), hf[e + '.w2'])
+    assert np.array_equal(w['ffn_norm'] if 'ffn_norm' in w else L['ffn_norm'], t[f'{p}.post_attention_layernorm.weight'].float().numpy().astype(f16))
+    slots = [loader.export_weights(mc, w, 2, r) for r in range(2)]
+    assert slots[0]['layers.0.moe_ffn.experts.3.w1w3.weight'].dtype == np.uint8
+    assert slots[0]['layers.0.moe_ffn.experts.3.w1w3.scales'].shape == (2, 2) and slots[0]['layers.0.moe_ffn.experts.3.w1w3.scales'].dtype == np.float32
+    sd = lambda s_, n: o.fp8_dequant(s_[n + '.weight'], s_[n + '.scales'], gated=n.endswith('w1w3'))
+    w13 = np.concatenate([sd(s_, 'layers.0.moe_ffn.experts.3.w1w3') for s_ in slots], 1)
+    assert np.array_equal(w13.view(np.uint16), deq(L['experts'][3]['w1w3']).view(np.uint16))
+    from lmdeploy_amd.turbomind.engine import make_model_config
+    c = make_model_config(mc, 2)
+    assert (c.weight_type, c.moe_experts, c.moe_top_k, c.moe_norm_topk) == (2, E, 2, 1)
+
+
 def test_api_surface_and_validation():
     c = TurbomindEngineConfig(tp=8, quant_policy=4, session_len=4096, max_batch_size=128, model_format='awq')
     assert c.quant_policy == QuantPolicy.INT4 and c.cache_block_seq_len == 64 and c.max_prefill_token_num == 8192
@@ -251,7 +330,8 @@ def test_api_surface_and_validation():
         TurbomindEngineConfig(quant_policy=3)
     with pytest.raises(AssertionError):
         TurbomindEngineConfig(quant_policy=16)              # FP8 KV is rejected by the reference for TurboMind too
-    for bad in (dict(dp=2), dict(enable_prefix_caching=True), dict(dtype='bfloat16'), dict(model_format='fp8'),
+    assert TurbomindEngineConfig(model_format='fp8').model_format == 'fp8'
+    for bad in (dict(dp=2), dict(enable_prefix_caching=True), dict(dtype='bfloat16'), dict(model_format='gptq'),
                 dict(cache_block_seq_len=128), dict(communicator='native')):
         with pytest.raises(NotImplementedError):
             TurbomindEngineConfig(**bad)
