@@ -531,6 +531,13 @@ __global__ __launch_bounds__(WN * WK * 64) void gemm_kernel(GemmParams p)
                         }
                     }
                     else {
+                        if constexpr ((ABL & 128) != 0) {
+                            // The first fragment of the NEXT iteration reads the ring slot that was refilled at the end of
+                            // the PREVIOUS iteration.  Unpinned, the scheduler hoists this VALU to the top of the
+                            // iteration -- a few hundred cycles after the loads were issued -- and the waitcnt pass
+                            // has to drain vmcnt(0) there (ISA: one full memory round trip per trip of the loop).
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
 #pragma unroll
                         for (int t = 0; t < NT; ++t) {
                             wfn[t] = dq((u + 1) % PF, 0, t, 0, live_next);
@@ -1774,7 +1781,9 @@ int launch_linear(const LinearWeight& w,
     dim3      grid((ntiles + wn * nt - 1) / (wn * nt), splits, (M + 16 * mt - 1) / (16 * mt));
     int       rc = 0;
     if (w.type == 0 && mt == 8) {
-        rc = waves == 8 ? launch_one<0, 8, 2, 8, 1, 1, 2>(p, grid, st) : launch_one<0, 8, 4, 4, 1, 1, 2>(p, grid, st);
+        static const int xpin = env_int("TM_GEMM_XPIN", 1);  // pinned next-iteration dequant (see the main loop): +2..6 % at M = 8192
+        rc = waves == 8 ? (xpin ? launch_one<0, 8, 2, 8, 1, 1, 2, 128>(p, grid, st) : launch_one<0, 8, 2, 8, 1, 1, 2>(p, grid, st)) :
+                          launch_one<0, 8, 4, 4, 1, 1, 2>(p, grid, st);
     }
     else if (w.type == 0) {
         rc = mt == 1 ? launch_mt<0, 1>(p, grid, nt, waves, wk, ks, st) :
