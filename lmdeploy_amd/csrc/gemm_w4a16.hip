@@ -1782,8 +1782,14 @@ int launch_linear(const LinearWeight& w,
     int       rc = 0;
     if (w.type == 0 && mt == 8) {
         static const int xpin = env_int("TM_GEMM_XPIN", 1);  // pinned next-iteration dequant (see the main loop): +2..6 % at M = 8192
-        rc = waves == 8 ? (xpin ? launch_one<0, 8, 2, 8, 1, 1, 2, 128>(p, grid, st) : launch_one<0, 8, 2, 8, 1, 1, 2>(p, grid, st)) :
-                          launch_one<0, 8, 4, 4, 1, 1, 2>(p, grid, st);
+        static const int pks = env_int("TM_GEMM_PREFILL_KS", 1);  // k-blocks per LDS stage (= per barrier)
+        if (waves == 8 && pks == 2 && p.kb_per_split % 2 == 0) {
+            rc = launch_one<0, 8, 2, 8, 1, 2, 2, 128>(p, grid, st);
+        }
+        else {
+            rc = waves == 8 ? (xpin ? launch_one<0, 8, 2, 8, 1, 1, 2, 128>(p, grid, st) : launch_one<0, 8, 2, 8, 1, 1, 2>(p, grid, st)) :
+                              launch_one<0, 8, 4, 4, 1, 1, 2>(p, grid, st);
+        }
     }
     else if (w.type == 0) {
         rc = mt == 1 ? launch_mt<0, 1>(p, grid, nt, waves, wk, ks, st) :
