@@ -59,6 +59,9 @@ def algorithmic_bytes(m, batch, ctx, kv_bits, tp):
 
 
 def main():
+    # multi-process GPU work on this pool needs dmabuf IPC (RCCL's P2P setup fails with the legacy mode:
+    # "hipIpcGetMemHandle: invalid argument"); already exported on the driver's boxes, kept here for hand launches
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=512)

@@ -1817,6 +1817,10 @@ int tm_engine_serve_stop(tm_engine* e)
     if (!e->loop_on.load()) {
         return 0;
     }
+    if (e->loop.joinable() && std::this_thread::get_id() == e->loop.get_id()) {
+        set_last_error("tm_engine_serve_stop called from the engine thread (inside the on_update callback)");
+        return TM_CONFLICT;  // the thread cannot join itself
+    }
     {
         ApiLock lock(e);
         e->loop_stop = true;
