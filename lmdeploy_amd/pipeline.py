@@ -91,9 +91,13 @@ class Pipeline:
             out.append(res)
         return out[0] if single else out
 
-    def stream_infer(self, prompts, gen_config: GenerationConfig | None = None, **kwargs):
-        """Responses are yielded as their sequences finish (continuous batching in the engine)."""
-        yield from self.generate_continuous(list(prompts), gen_config or GenerationConfig())
+    def stream_infer(self, prompts, gen_config: GenerationConfig | None = None, stream_response: bool = True, **kwargs):
+        """Streaming generation through the engine scheduler (lmdeploy/pipeline.py:145-178).  stream_response=True
+        (the reference's default): after every scheduler step one Response per request that produced tokens, carrying the
+        NEW token ids (`token_ids`), the total generated so far (`generate_token_len`) and `finish_reason` None until the
+        request ends ('stop' | 'length'); the stop token itself is never part of the output.  stream_response=False: one
+        final Response per request, in completion order."""
+        yield from self.generate_continuous(list(prompts), gen_config or GenerationConfig(), stream=stream_response)
 
     def close(self):
         self.engine.close()
@@ -125,9 +129,10 @@ class Pipeline:
             return
         yield from self._generate_static(prompts, g)
 
-    def generate_continuous(self, prompts: Sequence, g: GenerationConfig | None = None):
+    def generate_continuous(self, prompts: Sequence, g: GenerationConfig | None = None, stream: bool = False):
         """Continuous batching (engine scheduler: tm_engine_submit / step / poll): any number of prompts, each request
-        leaves the batch when it stops and the next waiting one takes its slot.  Yields Responses in completion order."""
+        leaves the batch when it stops and the next waiting one takes its slot.  Yields Responses in completion order
+        (stream=False) or incremental Responses after every scheduler step (stream=True, see stream_infer)."""
         g = g or GenerationConfig()
         ids = [self._encode(p) for p in prompts]
         stop = self._stop_ids(g)
@@ -138,7 +143,7 @@ class Pipeline:
         lp = g.logits_params(in_engine[1:])
         if lp is None and len(in_engine) > 1:
             lp = dict(stop_ids=in_engine[1:])
-        pending, out_of_engine = {}, []
+        pending, out_of_engine, sent = {}, [], {}
         for i, p in enumerate(ids):
             try:
                 pending[self.engine.submit(p, g.max_new_tokens, eos, g.sampling_params(i), lp)] = i
@@ -156,11 +161,20 @@ class Pipeline:
                     if cut is not None and st == 0:      # a stop id the engine does not know about
                         self.engine.cancel(rid)
                         st = 8
-                    if st == 0:
-                        continue
-                    del pending[rid]
                     out = toks if cut is None else toks[:cut]
-                    reason = 'stop' if cut is not None else 'length'
+                    if st == 0 and not stream:
+                        continue
+                    reason = None if st == 0 else ('stop' if cut is not None else 'length')
+                    if st != 0:
+                        del pending[rid]
+                    if stream:          # the delta since the last Response of this request
+                        new = out[sent.get(rid, 0):]
+                        sent[rid] = len(out)
+                        if not new and st == 0:
+                            continue
+                        text = self.tokenizer.decode(new, skip_special_tokens=g.skip_special_tokens) if self.tokenizer else ''
+                        yield Response(text, len(out), len(ids[i]), reason, new, index=i)
+                        continue
                     text = self.tokenizer.decode(out, skip_special_tokens=g.skip_special_tokens) if self.tokenizer else ''
                     yield Response(text, len(out), len(ids[i]), reason, out, index=i)
         finally:

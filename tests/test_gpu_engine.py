@@ -372,8 +372,24 @@ def test_pipeline_continuous_generation(cuda):
     assert [r.index for r in out] == list(range(5)) and all(len(r.token_ids) == 6 for r in out)
     one = [pipe([p], g)[0].token_ids for p in prompts]       # static path, one at a time
     assert [r.token_ids for r in out] == one
-    streamed = sorted(pipe.stream_infer(prompts, g), key=lambda r: r.index)
+    streamed = sorted(pipe.stream_infer(prompts, g, stream_response=False), key=lambda r: r.index)
     assert [r.token_ids for r in streamed] == one
+    # token streaming (the reference's default): deltas accumulate to the same outputs, lengths grow monotonically,
+    # exactly one final Response per request
+    acc, last_len, finals = {i: [] for i in range(5)}, {}, []
+    for r in pipe.stream_infer(prompts, g):
+        acc[r.index] += r.token_ids
+        assert r.generate_token_len == len(acc[r.index]) and (r.generate_token_len > last_len.get(r.index, 0) or r.finish_reason)
+        last_len[r.index] = r.generate_token_len
+        if r.finish_reason is not None:
+            finals.append(r.index)
+    assert [acc[i] for i in range(5)] == one and sorted(finals) == list(range(5))
+    # stop ids inside the engine: the first request's 3rd token as stop id cuts every output at its first occurrence
+    stop = one[0][2]
+    gs = GenerationConfig(max_new_tokens=6, ignore_eos=True, stop_token_ids=[stop])
+    for r, full in zip(sorted(pipe.stream_infer(prompts, gs, stream_response=False), key=lambda r: r.index), one):
+        want = full[:full.index(stop)] if stop in full else full
+        assert r.token_ids == want and r.finish_reason == ('stop' if stop in full else 'length')
     pipe.close()
 
 
