@@ -1417,6 +1417,19 @@ GemmConfig gemm_pick_config(const LinearWeight& w, int M)
         cfg.nt     = pw == 8 ? 2 : 4;
         cfg.waves  = pw == 8 ? 8 : 4;
         cfg.splits = 1;
+        // mid-size M (a continuous-batching admission, a short prompt): 128-row x 256-column tiles give fewer than
+        // 256 workgroups for the narrow linears (wo / w2 / w_qkv) -- split K until the chip is covered, >= 8
+        // k-blocks per slice.  Measured (tools/tune_gemm.py --m 512 | 1024): w2 171.6 -> 71.8 us and wo 56.5 -> ~28 us
+        // at M = 512, w2 182.8 -> 123.0 us at M = 1024; M >= 2048 never splits.
+        static const int psplit = env_int("TM_GEMM_PREFILL_SPLIT", 1);
+        if (psplit && w.type == 0) {
+            const int wgs = (ntiles + 15) / 16 * ((M + 127) / 128);
+            int       sp  = 1;
+            while (wgs * sp * 2 <= 256 && KB / (sp * 2) >= 8 && KB % (sp * 2) == 0) {
+                sp *= 2;
+            }
+            cfg.splits = sp;
+        }
     }
     else {
         // split-K only until ~256 workgroups exist and never below 8 k-blocks per slice (slab traffic + reduce)

@@ -424,6 +424,28 @@ def test_w4a16_linear(tm, cuda, K, N, M):
     _ffi.check(tm.tm_linear_destroy(h))
 
 
+@pytest.mark.parametrize('K,N,gated', [(4096, 6144, 0), (1792, 4096, 0), (1024, 512, 0), (4096, 1024, 1), (1024, 2048, 1)])
+@pytest.mark.parametrize('M', [257, 300, 512, 1000, 2500])
+def test_w4a16_linear_prefill_tiles(tm, cuda, K, N, M, gated):
+    """The prefill-shaped path (M > 256): 128-row x 256-column workgroup tiles (MT = 8), ragged last row block, the
+    automatic split-K of mid-size M (fewer than 256 workgroups otherwise) and explicit split counts, plain and gated-SiLU
+    epilogues -- same oracle and tolerance as the decode shapes."""
+    rng = np.random.default_rng(K + N + M + 11)
+    h, (q, s, z) = _make_linear(tm, rng, K, N)
+    x = rng.standard_normal((M, K)).astype(f16)
+    ref = (o.w4a16_linear_gated_silu(x, q, s, z) if gated else x.astype(np.float32) @ _QCACHE[(K, N)][3]).astype(np.float32)
+    ws = torch.zeros(max(1, tm.tm_linear_workspace(h, M)), dtype=torch.uint8, device='cuda')
+    x_d = dev(x)
+    for nt, splits, waves in ((0, 0, 0), (2, 1, 8), (2, 2, 8), (2, 4, 8), (4, 1, 4)):
+        if splits > K // 128:
+            continue
+        y = torch.zeros((M, N // 2 if gated else N), dtype=torch.float16, device='cuda')
+        _ffi.check(tm.tm_linear_forward(h, x_d.data_ptr(), K, y.data_ptr(), y.shape[1], M, gated, nt, splits, waves, ws.data_ptr(), st()))
+        err = np.abs(host(y).astype(np.float32) - ref)
+        assert np.all(err <= 2e-3 + 2.0**-9 * np.abs(ref)), f'nt={nt} splits={splits} waves={waves}: max err {err.max()}'
+    _ffi.check(tm.tm_linear_destroy(h))
+
+
 @pytest.mark.parametrize('K,N,M,gated', [(4096, 6144, 64, 0), (1792, 4096, 33, 0), (384, 48, 3, 0), (4096, 1024, 64, 1), (1024, 2048, 17, 1)])
 @pytest.mark.parametrize('arm', ['V2:1', 'V2:4', 'PP', 'GLDS'])
 def test_w4a16_alternative_decode_kernels(tm, cuda, monkeypatch, K, N, M, gated, arm):
