@@ -1444,6 +1444,15 @@ GemmConfig gemm_pick_config(const LinearWeight& w, int M)
             splits *= 2;
         }
         cfg.splits = splits;
+        // 2+ row blocks (batch 65..256) and a wide N (w1w3): four-wave workgroups of 2 tiles per wave, no split -- >= 448
+        // small workgroups, two per CU that run out of phase.  Measured with tools/tune_gemm.py --m 128 | 256 on the
+        // Llama-3-8B / InternLM2-20B shapes: 78.3 -> 69.0 us, 54.5 -> 47.6 us (M = 128), 165.6 -> 131.9 us, 111.0 -> 88.5 us
+        // (M = 256).  (Splitting K further for the long-K w2 was measured too and is slower.)
+        static const int mid = env_int("TM_GEMM_MID_M", 1);
+        if (mid && mblk > 1 && w.type == 0 && (ntiles + 7) / 8 * mblk >= 448 && splits == 1) {
+            cfg.waves = 4;
+            cfg.nt    = 2;
+        }
     }
     cfg.nt      = env_int("TM_GEMM_NT", cfg.nt);
     cfg.splits  = env_int("TM_GEMM_SPLITS", cfg.splits);
