@@ -1444,6 +1444,21 @@ GemmConfig gemm_pick_config(const LinearWeight& w, int M)
             splits *= 2;
         }
         cfg.splits = splits;
+        // one row block (batch <= 64), K <= 8192: 4 column groups x 2 k-phases per workgroup (64 columns, the two phases
+        // take alternate k-blocks and are summed through LDS) -- tools/tune_gemm.py --m 64 finds it 4-7 % ahead of 8 column
+        // groups for w_qkv / wo / w1w3 in isolation; in the model (bench.py --steps 128, same box, back to back):
+        // wo 11.6 -> 11.0 us, w_qkv 14.0 -> 13.8 us, w1w3 27.8 -> 27.6 us, step 3.733 -> 3.705 ms
+        static const int dkp = env_int("TM_GEMM_DECODE_KP", 1);
+        if (dkp && mblk == 1 && w.type == 0 && KB <= 64 && KB % 2 == 0) {
+            cfg.kphases = 2;
+            cfg.nt      = (ntiles + 3) / 4 > 256 ? 2 : 1;
+            const int c2 = (ntiles + 4 * cfg.nt - 1) / (4 * cfg.nt);
+            int       s2 = 1;
+            while (c2 * s2 * 2 <= 256 && KB / (s2 * 2) >= min_kb && (KB / (s2 * 2)) % 2 == 0 && s2 < 16) {
+                s2 *= 2;
+            }
+            cfg.splits = s2;
+        }
         // 2+ row blocks (batch 65..256) and a wide N (w1w3): four-wave workgroups of 2 tiles per wave, no split -- >= 448
         // small workgroups, two per CU that run out of phase.  Measured with tools/tune_gemm.py --m 128 | 256 on the
         // Llama-3-8B / InternLM2-20B shapes: 78.3 -> 69.0 us, 54.5 -> 47.6 us (M = 128), 165.6 -> 131.9 us, 111.0 -> 88.5 us
