@@ -90,3 +90,41 @@ def test_tp2_sharded_forward_matches_unsharded():
     if top2[1] - top2[0] > 2e-2:          # no near tie: the greedy token must agree
         assert ret['token'] == int(tok[0])
     assert ret['x'].shape == (12, 256)
+
+
+def _moe_worker(rank, world, port, cfg, w, x, ret):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    s = loader.export_weights(cfg, w, world, rank)
+    p = 'layers.0.moe_ffn'
+    deq = lambda n: o.fp8_dequant(s[n + '.weight'], s[n + '.scales'], gated=n.endswith('w1w3'))
+    experts = [(deq(f'{p}.experts.{e}.w1w3'), deq(f'{p}.experts.{e}.w2')) for e in range(cfg.moe_experts)]
+    part = o.moe_ffn(x, s[p + '.gate.weight'], experts, cfg.moe_top_k, cfg.moe_norm_topk, cfg.moe_routed_scale)[0]
+    full = _allreduce_f16(np.asarray(part, f16))                  # the engine's all-reduce after the MoE combine
+    if rank == 0:
+        ret['out'] = full
+        ret['w13_shape'] = s[f'{p}.experts.0.w1w3.weight'].shape
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_tp2_moe_fp8_block_matches_unsharded():
+    """BASELINE config 5's plan (Mixtral, fp8 block scales, TP = 2): replicated router, every expert's w1w3 column-
+    sharded (interleaved codes, [w1 blocks | w3 blocks] scale rows) and w2 row-sharded by the product loader; each rank
+    runs the MoE block on its shard, the partial outputs are summed where the engine calls RCCL -- must reproduce the
+    unsharded block (routing is identical on every rank because the router is replicated)."""
+    cfg = o.ModelConfig(hidden=256, layers=1, q_heads=4, kv_heads=2, head_dim=128, inter=256, vocab=64, weight_format='fp8',
+                        moe_experts=4, moe_top_k=2)
+    w = o.make_synthetic_weights(cfg, seed=9)
+    x = (np.random.default_rng(3).standard_normal((9, 256)) * 0.5).astype(f16)
+    L = w['layers'][0]
+    experts = [(o.fp8_dequant(E['w1w3']['f8'], E['w1w3']['bs'], True), o.fp8_dequant(E['w2']['f8'], E['w2']['bs']))
+               for E in L['experts']]
+    ref = np.asarray(o.moe_ffn(x, L['moe_gate'], experts, 2)[0], np.float32)
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_moe_worker, args=(2, _free_port(), cfg, w, x, ret), nprocs=2, join=True)
+    assert tuple(ret['w13_shape']) == (256, 256)                    # [hidden, 2 * inter / tp]
+    got = ret['out'].astype(np.float32)
+    assert np.all(np.abs(got - ref) <= 1e-2 * np.abs(ref) + 2e-3), np.abs(got - ref).max()
