@@ -1,9 +1,10 @@
 """`lmdeploy.pipeline()` surface over the MI355X engine.
 
 Reference: lmdeploy/api.py:15-82 (pipeline), lmdeploy/pipeline.py:33-183,317-327 (Pipeline.infer / __call__ /
-stream_infer / close).  The reference routes through AsyncEngine + a continuous-batching scheduler; here the
-caller of the hot path is a static batcher (SURVEY 8f item 1 is the "next" row): prompts are processed in batches of
-at most `max_batch_size`, every batch = chunked prefill + greedy decode.
+stream_infer / close).  The reference routes through AsyncEngine + its continuous-batching scheduler; here up to
+`max_batch_size` prompts run as one static batch (chunked prefill + decode, the configuration BASELINE.json's metric is
+quoted on), more prompts -- and every stream_infer call -- go through the engine's scheduler (tm_engine_submit / step /
+poll: requests leave the batch when they stop, waiting ones take their slots).
 """
 from __future__ import annotations
 

@@ -1,0 +1,185 @@
+"""Host logic of the `pipeline()` surface on the CPU: the Pipeline class driven through a FAKE engine (same method
+surface as lmdeploy_amd.turbomind.engine.Engine, deterministic tokens, the scheduler's slot / status behaviour), so that
+batching, result ordering, stop handling, streaming deltas and error mapping are covered without a GPU.  The real
+engine behind the same calls is covered by tests/test_gpu_engine.py."""
+import sys
+
+import numpy as np
+import pytest
+
+import lmdeploy_amd
+from lmdeploy_amd import GenerationConfig, TurbomindEngineConfig, _ffi
+
+P = sys.modules['lmdeploy_amd.pipeline']      # the module (the package attribute `pipeline` is the factory function)
+
+VOCAB = 1024
+
+
+def _tok(prompt, k):
+    """token k of the continuation of `prompt`: a pure function of the prompt, like greedy decoding"""
+    return int((int(np.sum(prompt)) * 31 + 7 * k + 3) % VOCAB)
+
+
+class FakeEngine:
+    instances = []
+
+    def __init__(self, max_batch_size, session_len):
+        self.B, self.session_len = max_batch_size, session_len
+        self.reqs, self.next_id, self.static = {}, 1, None
+        self.sampling, self.logits, self.released = None, None, 0
+        FakeEngine.instances.append(self)
+
+    @classmethod
+    def from_model_config(cls, cfg, weight_type=0, **kw):
+        return cls(kw['max_batch_size'], kw['session_len'])
+
+    # ---- life cycle -------------------------------------------------------------------------
+    def init_synthetic(self, seed=0): pass
+    def start(self): pass
+    def close(self): pass
+
+    # ---- static batch -----------------------------------------------------------------------
+    def set_sampling(self, p): self.sampling = p
+    def set_logits_params(self, p): self.logits = p
+
+    def prefill(self, prompts, max_new_tokens):
+        assert len(prompts) <= self.B
+        if any(len(p) + max_new_tokens > self.session_len for p in prompts):
+            raise _ffi.TmError(6, 'too long')
+        self.static = [list(map(int, p)) for p in prompts]
+        self.max_new, self.done = max_new_tokens, 1
+
+    def decode(self, n): self.done += n
+
+    def fetch(self):
+        return np.asarray([[_tok(p, k) for k in range(self.done)] for p in self.static], np.int32)
+
+    def release(self):
+        self.static, self.reqs, self.released = None, {}, self.released + 1
+
+    # ---- scheduler --------------------------------------------------------------------------
+    def submit(self, prompt, max_new, eos_id=-1, sampling=None, logits=None):
+        if len(prompt) + max_new > self.session_len:
+            raise _ffi.TmError(6, 'prompt + max_new_tokens exceeds session_len')
+        stops = {eos_id} | set((logits or {}).get('stop_ids', []) if isinstance(logits, dict) else [])
+        rid, self.next_id = self.next_id, self.next_id + 1
+        self.reqs[rid] = dict(prompt=list(map(int, prompt)), max_new=max_new, stops=stops - {-1}, out=[], status=0, slot=None,
+                              logits=logits)
+        return rid
+
+    def step(self):
+        running = [r for r in self.reqs.values() if r['status'] == 0 and r['slot'] is not None]
+        for r in self.reqs.values():                       # arrival-order admission into free slots
+            if r['status'] == 0 and r['slot'] is None and len(running) < self.B:
+                r['slot'] = True
+                running.append(r)
+        for r in running:
+            t = _tok(r['prompt'], len(r['out']))
+            r['out'].append(t)
+            if t in r['stops'] or len(r['out']) >= r['max_new']:
+                r['status'], r['slot'] = 7, None
+        act = sum(1 for r in self.reqs.values() if r['status'] == 0 and r['slot'] is not None)
+        wait = sum(1 for r in self.reqs.values() if r['status'] == 0 and r['slot'] is None)
+        return act, wait
+
+    def poll(self, rid):
+        r = self.reqs[rid]
+        return r['status'], np.asarray(r['out'], np.int32)
+
+    def cancel(self, rid):
+        r = self.reqs[rid]
+        if r['status'] == 0:
+            r['status'], r['slot'] = 8, None
+
+
+@pytest.fixture
+def pipe(monkeypatch):
+    monkeypatch.setattr(P, 'Engine', FakeEngine)
+    FakeEngine.instances.clear()
+    p = P.Pipeline('synthetic:tiny', backend_config=TurbomindEngineConfig(max_batch_size=2, session_len=64, quant_policy=8))
+    yield p
+    p.close()
+
+
+def _expect(prompt, n, stops=()):
+    out = []
+    for k in range(n):
+        t = _tok(prompt, k)
+        if t in stops:
+            return out, 'stop'
+        out.append(t)
+    return out, 'length'
+
+
+def test_static_and_scheduled_batches_agree_and_keep_order(pipe):
+    rng = np.random.default_rng(0)
+    prompts = [rng.integers(0, VOCAB, n).tolist() for n in (5, 9, 3, 12, 7)]
+    g = GenerationConfig(max_new_tokens=6, ignore_eos=True)
+    two = pipe(prompts[:2], g)                                   # <= max_batch_size: one static batch
+    assert [r.token_ids for r in two] == [_expect(p, 6)[0] for p in prompts[:2]]
+    out = pipe(prompts, g)                                       # more prompts than slots: the engine scheduler
+    assert [r.index for r in out] == list(range(5))
+    assert [r.token_ids for r in out] == [_expect(p, 6)[0] for p in prompts]
+    assert all(r.finish_reason == 'length' and r.generate_token_len == 6 and r.input_token_len == len(p)
+               for r, p in zip(out, prompts))
+    single = pipe(prompts[0], g)                                 # a single token-id prompt returns a single Response
+    assert single.token_ids == _expect(prompts[0], 6)[0]
+    assert FakeEngine.instances[0].released >= 3                 # every call hands its blocks back
+
+
+def test_stop_ids_static_scheduled_and_beyond_the_engine_limit(pipe):
+    rng = np.random.default_rng(1)
+    prompts = [rng.integers(0, VOCAB, n).tolist() for n in (4, 6, 8)]
+    stop = _tok(prompts[0], 2)
+    g = GenerationConfig(max_new_tokens=8, ignore_eos=True, stop_token_ids=[stop])
+    for res in (pipe(prompts[:2], g), pipe(prompts, g)):
+        for r, p in zip(res, prompts):
+            want, reason = _expect(p, 8, {stop})
+            assert (r.token_ids, r.finish_reason) == (want, reason)
+            assert stop not in r.token_ids                           # the stop token is never part of the output
+    # more stop ids than the engine takes (1 + 8): the pipeline cuts on the host and cancels the request
+    many = [stop] + [VOCAB + i for i in range(12)]
+    res = pipe(prompts, GenerationConfig(max_new_tokens=8, ignore_eos=True, stop_token_ids=many))
+    assert [r.token_ids for r in res] == [_expect(p, 8, {stop})[0] for p in prompts]
+    eng = FakeEngine.instances[0]
+    assert eng.logits is None or eng.logits == [None]                # static path: no processors were requested
+
+
+def test_streaming_deltas_and_final_responses(pipe):
+    rng = np.random.default_rng(2)
+    prompts = [rng.integers(0, VOCAB, n).tolist() for n in (3, 5, 7, 9)]
+    g = GenerationConfig(max_new_tokens=5, ignore_eos=True)
+    acc, finals, steps_seen = {i: [] for i in range(4)}, [], 0
+    for r in pipe.stream_infer(prompts, g):
+        steps_seen += 1
+        acc[r.index] += r.token_ids
+        assert r.generate_token_len == len(acc[r.index])
+        if r.finish_reason is not None:
+            finals.append(r.index)
+    assert [acc[i] for i in range(4)] == [_expect(p, 5)[0] for p in prompts]
+    assert sorted(finals) == [0, 1, 2, 3] and steps_seen == 4 * 5         # one Response per request per step
+    assert finals[:2] == [0, 1]                                          # two slots: the first two finish first
+    whole = sorted(pipe.stream_infer(prompts, g, stream_response=False), key=lambda r: r.index)
+    assert [r.token_ids for r in whole] == [acc[i] for i in range(4)]
+
+
+def test_errors_become_responses_and_processors_reach_the_engine(pipe):
+    g = GenerationConfig(max_new_tokens=8, ignore_eos=True, repetition_penalty=1.2, min_new_tokens=2, bad_token_ids=[5])
+    ok, too_long = list(range(10)), list(range(60))                        # 60 + 8 > session_len 64
+    res = pipe([ok, too_long, ok], g)
+    assert [r.index for r in res] == [0, 1, 2]
+    assert res[1].finish_reason == 'error' and res[1].error_code == 'INPUT_LENGTH_ERROR' and res[1].token_ids == []
+    assert res[0].token_ids == res[2].token_ids == _expect(ok, 8)[0]
+    lp = g.logits_params([])
+    assert lp == dict(repetition_penalty=pytest.approx(1.2), min_new_tokens=2, bad_ids=[5], stop_ids=[])
+    # the scheduler path hands the processors of the GenerationConfig to the engine with every request ...
+    eng = FakeEngine.instances[0]
+    seen = []
+    real_submit = eng.submit
+    eng.submit = lambda *a, **k: (seen.append(a[4] if len(a) > 4 else k.get('logits')), real_submit(*a, **k))[1]
+    pipe([ok, ok, ok], g)
+    assert seen == [lp, lp, lp]
+    pipe([ok], g)                                                           # ... the static path through set_logits_params
+    assert eng.logits == [lp]
+    with pytest.raises(NotImplementedError):
+        P.Pipeline('synthetic:tiny', backend_config=TurbomindEngineConfig(), chat_template_config=object())
