@@ -81,7 +81,7 @@ class GenerationConfig:
         assert self.temperature >= 0 and self.temperature <= 2
         assert 0 <= self.min_p <= 1
         assert self.repetition_penalty > 0, 'repetition_penalty must be > 0'
-        unsupported = {'n': 1, 'bad_words': None, 'logprobs': None, 'response_format': None, 'logits_processors': None,
+        unsupported = {'n': 1, 'logprobs': None, 'response_format': None, 'logits_processors': None,
                        'output_logits': None, 'output_last_hidden_state': None}
         if self.do_sample and self.temperature == 0:
             raise ValueError('temperature must be > 0 when do_sample=True')
@@ -91,6 +91,38 @@ class GenerationConfig:
                                           f'greedy decoding, temperature / top-k / top-p / min-p sampling, repetition '
                                           f'penalty, min_new_tokens, bad_token_ids and stop_token_ids only')
 
+
+    def convert_stop_bad_words_to_ids(self, tokenizer):
+        """stop_words / bad_words -> stop_token_ids / bad_token_ids, the reference's rule (lmdeploy/messages.py:154-174,
+        lmdeploy/tokenizer.py:152-187,539-547): a word must encode to exactly ONE token (multi-token words cannot be
+        used and are skipped with a warning); it then stands for every vocabulary entry whose token string contains it
+        (' ' matches the sentencepiece '\u2581'); more than 5 candidates are narrowed to the ids that decode to exactly
+        the word, at most 5.  `tokenizer`: a HF tokenizer (encode / get_vocab / decode)."""
+        import warnings
+
+        def ids_of(words, what):
+            if words is None:
+                return []
+            assert isinstance(words, list) and all(isinstance(w_, str) for w_ in words), f'{what} must be a list of str'
+            vocab = tokenizer.get_vocab()
+            out = []
+            for word in words:
+                enc = tokenizer.encode(word, add_special_tokens=False)
+                if len(enc) != 1:
+                    warnings.warn(f'{what}: {word!r} encodes to {len(enc)} tokens; only single-token words can be used')
+                    continue
+                key = '\u2581' if word == ' ' else word
+                idx = sorted(i for tok, i in vocab.items() if key in tok)
+                if len(idx) > 5:
+                    idx = [i for i in idx if tokenizer.decode([i]) == word][:5]
+                out += idx or enc
+            return out
+
+        stop = ids_of(self.stop_words, 'stop_words') + list(self.stop_token_ids or [])
+        bad = ids_of(self.bad_words, 'bad_words') + list(self.bad_token_ids or [])
+        self.stop_token_ids = sorted(set(stop)) or None
+        self.bad_token_ids = sorted(set(bad)) or None
+        self.stop_words = self.bad_words = None          # consumed
 
     def logits_params(self, stop_ids=()):
         """dict for the engine's logits processors (tm_logits_param), or None when every processor is off.

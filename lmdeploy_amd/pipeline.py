@@ -124,7 +124,18 @@ class Pipeline:
             ids |= set(e if isinstance(e, (list, tuple)) else [e])
         return ids
 
+    def _resolve_words(self, g: GenerationConfig):
+        """stop_words / bad_words need the tokenizer (lmdeploy/serve/core/async_engine.py converts them per request)"""
+        if g.stop_words or g.bad_words:
+            if self.tokenizer is None:
+                raise ValueError('stop_words / bad_words need a tokenizer in the model directory; pass stop_token_ids / '
+                                 'bad_token_ids instead')
+            g.convert_stop_bad_words_to_ids(self.tokenizer)
+        if g.bad_token_ids and len(g.bad_token_ids) > _ffi.MAX_BAD_IDS:
+            raise ValueError(f'at most {_ffi.MAX_BAD_IDS} bad token ids per request')
+
     def _generate(self, prompts: Sequence, g: GenerationConfig):
+        self._resolve_words(g)
         if len(prompts) > self.max_batch_size:      # more work than batch slots: let the engine schedule it
             yield from sorted(self.generate_continuous(prompts, g), key=lambda r: r.index)
             return
@@ -135,6 +146,7 @@ class Pipeline:
         leaves the batch when it stops and the next waiting one takes its slot.  Yields Responses in completion order
         (stream=False) or incremental Responses after every scheduler step (stream=True, see stream_infer)."""
         g = g or GenerationConfig()
+        self._resolve_words(g)
         ids = [self._encode(p) for p in prompts]
         stop = self._stop_ids(g)
         # stop ids live inside the engine (eos id + up to 8 more); beyond that the loop below cuts on the host

@@ -349,7 +349,19 @@ def test_api_surface_and_validation():
     with pytest.raises(ValueError):
         _ffi.LogitsParam.make(bad_ids=list(range(40)))
     with pytest.raises(NotImplementedError):
-        GenerationConfig(bad_words=['x'])
+        GenerationConfig(logprobs=3)
+
+    class Tok:          # a tiny HF-like tokenizer: one token per known word
+        vocab = {'<s>': 0, 'foo': 1, '\u2581foo': 2, 'food': 3, 'bar': 4, '\u2581': 5, 'a\u2581': 6, 'x': 7}
+
+        def get_vocab(self): return dict(self.vocab)
+        def encode(self, w, add_special_tokens=False): return [5] if w == ' ' else [self.vocab[w]] if w in self.vocab else [7, 7]
+        def decode(self, ids): return next(k for k, v in self.vocab.items() if v == ids[0])
+    gw = GenerationConfig(stop_words=['foo', 'not-a-token'], bad_words=['bar', ' '], stop_token_ids=[9], bad_token_ids=[4])
+    with pytest.warns(UserWarning, match='not-a-token'):
+        gw.convert_stop_bad_words_to_ids(Tok())
+    assert gw.stop_token_ids == [1, 2, 3, 9]                  # every vocabulary entry that contains 'foo' + the given id
+    assert gw.bad_token_ids == [4, 5, 6] and gw.stop_words is None and gw.bad_words is None
     with pytest.raises(ValueError):
         GenerationConfig(do_sample=True, temperature=0.0)
     import inspect
