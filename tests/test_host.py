@@ -361,7 +361,7 @@ def test_api_surface_and_validation():
     with pytest.warns(UserWarning, match='not-a-token'):
         gw.convert_stop_bad_words_to_ids(Tok())
     assert gw.stop_token_ids == [1, 2, 3, 9]                  # every vocabulary entry that contains 'foo' + the given id
-    assert gw.bad_token_ids == [4, 5, 6] and gw.stop_words is None and gw.bad_words is None
+    assert gw.bad_token_ids == [2, 4, 5, 6] and gw.stop_words is None and gw.bad_words is None     # ' ' = every '\u2581' token
     with pytest.raises(ValueError):
         GenerationConfig(do_sample=True, temperature=0.0)
     import inspect
