@@ -73,6 +73,15 @@ class GenerationConfig:
     output_logits: Literal['all', 'generation'] = None
     output_last_hidden_state: Literal['all', 'generation'] = None
     include_stop_str_in_output: bool = False
+    # fields of the reference that belong to subsystems outside the hot path (PPL scoring, prefix-cache control,
+    # PD-disaggregation migration, expert-routing dumps, n-gram repetition filter): accepted at their defaults only
+    return_ppl: bool = False
+    with_cache: bool = False
+    preserve_cache: bool = False
+    migration_request: Any = None
+    return_routed_experts: bool = False
+    repetition_ngram_size: int = 0
+    repetition_ngram_threshold: int = 0
 
     def __post_init__(self):
         assert isinstance(self.n, int) and self.n > 0, 'n is not a positive integer'
@@ -82,7 +91,9 @@ class GenerationConfig:
         assert 0 <= self.min_p <= 1
         assert self.repetition_penalty > 0, 'repetition_penalty must be > 0'
         unsupported = {'n': 1, 'logprobs': None, 'response_format': None, 'logits_processors': None,
-                       'output_logits': None, 'output_last_hidden_state': None}
+                       'output_logits': None, 'output_last_hidden_state': None, 'return_ppl': False, 'with_cache': False,
+                       'preserve_cache': False, 'migration_request': None, 'return_routed_experts': False,
+                       'repetition_ngram_size': 0, 'repetition_ngram_threshold': 0}
         if self.do_sample and self.temperature == 0:
             raise ValueError('temperature must be > 0 when do_sample=True')
         for k, default in unsupported.items():
@@ -238,5 +249,7 @@ class Response:
     logits: Any = None
     last_hidden_state: Any = None
     index: int = 0
+    routed_experts: Any = None
+    cached_tokens: int = 0
     error_code: str | None = None
     error_message: str | None = None

@@ -97,6 +97,7 @@ def main():
     print('wrote', os.path.join(OUT, 'reference_python.npz'), {k: v.shape for k, v in out.items()})
     logits_process_golden()
     more_golden(wf)
+    api_fields_golden()
 
 
 def more_golden(wf):
@@ -172,6 +173,25 @@ def more_golden(wf):
     out['samp_probs'] = sc.softmax(-1).numpy()
     np.savez_compressed(os.path.join(OUT, 'reference_python2.npz'), **out)
     print('wrote', os.path.join(OUT, 'reference_python2.npz'), {k: v.shape for k, v in out.items()})
+
+
+def api_fields_golden():
+    """reference_api_fields.json: field names and default expressions of the user-facing dataclasses
+    (lmdeploy/messages.py: GenerationConfig, TurbomindEngineConfig, Response), read with `ast` (the module itself
+    cannot be imported here: pydantic / transformers glue)."""
+    import ast
+    import json
+    tree = ast.parse(open(f'{REF}/lmdeploy/messages.py').read())
+    out = {}
+    for n in tree.body:
+        if isinstance(n, ast.ClassDef) and n.name in ('GenerationConfig', 'TurbomindEngineConfig', 'Response'):
+            fields = {}      # dataclass semantics: a re-annotated name keeps its first position, the last default wins
+            for st in n.body:
+                if isinstance(st, ast.AnnAssign):
+                    fields[st.target.id] = ast.unparse(st.value) if st.value is not None else None
+            out[n.name] = [[k, v] for k, v in fields.items()]
+    json.dump(out, open(os.path.join(OUT, 'reference_api_fields.json'), 'w'), indent=1)
+    print('wrote', os.path.join(OUT, 'reference_api_fields.json'), {k: len(v) for k, v in out.items()})
 
 
 def logits_process_golden():

@@ -373,6 +373,24 @@ def test_api_surface_and_validation():
         assert hasattr(lmdeploy_amd.Pipeline, m)
 
 
+def test_dataclass_fields_match_the_reference():
+    """Drop-in surface: GenerationConfig / TurbomindEngineConfig / Response carry every field of the reference's
+    dataclasses (lmdeploy/messages.py, listed by tests/golden/make_golden.py -> reference_api_fields.json) in the same
+    order with the same default expressions, so positional and keyword construction written for lmdeploy works."""
+    import ast
+    import inspect
+
+    import lmdeploy_amd.messages as M
+    ref = json.load(open(os.path.join(os.path.dirname(__file__), 'golden', 'reference_api_fields.json')))
+    tree = ast.parse(inspect.getsource(M))
+    ours = {n.name: [[st.target.id, ast.unparse(st.value) if st.value is not None else None]
+                     for st in n.body if isinstance(st, ast.AnnAssign)] for n in tree.body if isinstance(n, ast.ClassDef)}
+    for cls, fields in ref.items():
+        assert [f[0] for f in ours[cls]] == [f[0] for f in fields], cls
+        for (name, dflt), (_, rdflt) in zip(ours[cls], fields):
+            assert dflt == rdflt or (name, rdflt) in (('migration_request', 'None'),), (cls, name, dflt, rdflt)
+
+
 def test_product_code_never_imports_the_oracle():
     """The product path must fail loudly without the HIP library -- and must not route through oracle/."""
     bad = []
