@@ -134,7 +134,10 @@ class Pipeline:
         if g.bad_token_ids and len(g.bad_token_ids) > _ffi.MAX_BAD_IDS:
             raise ValueError(f'at most {_ffi.MAX_BAD_IDS} bad token ids per request')
 
-    def _generate(self, prompts: Sequence, g: GenerationConfig):
+    def _generate(self, prompts: Sequence, g):
+        if isinstance(g, (list, tuple)):            # one GenerationConfig per prompt (lmdeploy/pipeline.py:97-143)
+            yield from sorted(self.generate_continuous(prompts, g), key=lambda r: r.index)
+            return
         self._resolve_words(g)
         if len(prompts) > self.max_batch_size:      # more work than batch slots: let the engine schedule it
             yield from sorted(self.generate_continuous(prompts, g), key=lambda r: r.index)
@@ -145,21 +148,29 @@ class Pipeline:
         """Continuous batching (engine scheduler: tm_engine_submit / step / poll): any number of prompts, each request
         leaves the batch when it stops and the next waiting one takes its slot.  Yields Responses in completion order
         (stream=False) or incremental Responses after every scheduler step (stream=True, see stream_infer)."""
-        g = g or GenerationConfig()
-        self._resolve_words(g)
         ids = [self._encode(p) for p in prompts]
-        stop = self._stop_ids(g)
-        # stop ids live inside the engine (eos id + up to 8 more); beyond that the loop below cuts on the host
-        stop_l = sorted(stop)
-        in_engine = stop_l if len(stop_l) <= 1 + _ffi.MAX_STOP_IDS else []
-        eos = in_engine[0] if in_engine else -1
-        lp = g.logits_params(in_engine[1:])
-        if lp is None and len(in_engine) > 1:
-            lp = dict(stop_ids=in_engine[1:])
+        if isinstance(g, (list, tuple)):            # per-request generation configs: every request carries its own
+            if len(g) != len(ids):
+                raise ValueError(f'{len(g)} generation configs for {len(ids)} prompts')
+            gs = [gi or GenerationConfig() for gi in g]
+        else:
+            gs = [g or GenerationConfig()] * len(ids)
+        stops = []
         pending, out_of_engine, sent = {}, [], {}
         for i, p in enumerate(ids):
+            gi = gs[i]
+            self._resolve_words(gi)
+            stop = self._stop_ids(gi)
+            stops.append(stop)
+            # stop ids live inside the engine (eos id + up to 8 more); beyond that the loop below cuts on the host
+            stop_l = sorted(stop)
+            in_engine = stop_l if len(stop_l) <= 1 + _ffi.MAX_STOP_IDS else []
+            eos = in_engine[0] if in_engine else -1
+            lp = gi.logits_params(in_engine[1:])
+            if lp is None and len(in_engine) > 1:
+                lp = dict(stop_ids=in_engine[1:])
             try:
-                pending[self.engine.submit(p, g.max_new_tokens, eos, g.sampling_params(i), lp)] = i
+                pending[self.engine.submit(p, gi.max_new_tokens, eos, gi.sampling_params(i), lp)] = i
             except _ffi.TmError as e:
                 rt = STATUS_TO_RESPONSE.get(e.status, ResponseType.INTERNAL_ENGINE_ERROR)
                 out_of_engine.append(Response('', 0, len(p), 'error', [], index=i, error_code=rt.name, error_message=str(e)))
@@ -170,6 +181,7 @@ class Pipeline:
                 for rid, i in list(pending.items()):
                     st, toks = self.engine.poll(rid)
                     toks = toks.tolist()
+                    g, stop = gs[i], stops[i]
                     cut = next((k for k, t in enumerate(toks) if t in stop), None)
                     if cut is not None and st == 0:      # a stop id the engine does not know about
                         self.engine.cancel(rid)

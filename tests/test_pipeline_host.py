@@ -183,3 +183,18 @@ def test_errors_become_responses_and_processors_reach_the_engine(pipe):
     assert eng.logits == [lp]
     with pytest.raises(NotImplementedError):
         P.Pipeline('synthetic:tiny', backend_config=TurbomindEngineConfig(), chat_template_config=object())
+
+
+def test_one_generation_config_per_prompt(pipe):
+    """infer(prompts, [gen_config, ...]) (lmdeploy/pipeline.py:97-143): every request runs with its own limits / stops."""
+    rng = np.random.default_rng(5)
+    prompts = [rng.integers(0, VOCAB, n).tolist() for n in (4, 6, 8)]
+    stop = _tok(prompts[1], 1)
+    gs = [GenerationConfig(max_new_tokens=3, ignore_eos=True), GenerationConfig(max_new_tokens=9, ignore_eos=True, stop_token_ids=[stop]),
+          GenerationConfig(max_new_tokens=5, ignore_eos=True)]
+    res = pipe(prompts, gs)
+    assert [r.index for r in res] == [0, 1, 2]
+    assert res[0].token_ids == _expect(prompts[0], 3)[0] and res[2].token_ids == _expect(prompts[2], 5)[0]
+    assert (res[1].token_ids, res[1].finish_reason) == _expect(prompts[1], 9, {stop})
+    with pytest.raises(ValueError):
+        pipe(prompts, gs[:2])
