@@ -107,7 +107,6 @@ def more_golden(wf):
       * MoE router: backends/default/moe.py:7-33 (softmax -> top-k) + the Mixtral renormalisation w / sum(w);
       * FP8 block-scaled dequant: lmdeploy/turbomind/weight_format.py:349-384 (FP8Format.dequant);
       * sampling filters on sorted scores: pytorch/engine/logits_process.py:68-96 (top-k, top-p, min-p)."""
-    import math
     out = {}
     g = torch.Generator().manual_seed(4321)
     # ---- RoPE ---------------------------------------------------------------------------------------------------

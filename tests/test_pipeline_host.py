@@ -7,7 +7,7 @@ import sys
 import numpy as np
 import pytest
 
-import lmdeploy_amd
+import lmdeploy_amd  # noqa: F401  (loads lmdeploy_amd.pipeline into sys.modules)
 from lmdeploy_amd import GenerationConfig, TurbomindEngineConfig, _ffi
 
 P = sys.modules['lmdeploy_amd.pipeline']      # the module (the package attribute `pipeline` is the factory function)
