@@ -333,6 +333,9 @@ int tm_engine_submit_gen(tm_engine* e, const int* host_ids, int n, int max_new_t
 int tm_engine_step(tm_engine* e, int* n_active, int* n_waiting);
 int tm_engine_poll(tm_engine* e, int64_t req_id, int* status, int* host_tokens, int cap, int* n_tokens);
 int tm_engine_cancel(tm_engine* e, int64_t req_id);
+/* drop the record of a FINISHED request (status != 0) once its tokens were read: a long-lived serving session would
+ * otherwise keep every prompt / output until tm_engine_release.  TM_INVALID: unknown id or still queued / running. */
+int tm_engine_forget(tm_engine* e, int64_t req_id);
 
 /* Engine thread (the reference's Engine::Impl::InternalThreadEntry, engine/engine.cc:770-870, + the Gateway signal
  * thread that runs the Python callback, bind.cpp:942-952).  After tm_engine_serve_start an engine-owned thread runs
@@ -369,6 +372,8 @@ int tm_sched_query(tm_sched* s, int64_t req_id, int* status, int* slot, int* n_g
 int tm_sched_counts(tm_sched* s, int* n_active, int* n_waiting, int* n_free_blocks);
 /* every unfinished request ends with `status` (the engine uses TM_FAIL after a device error) */
 int tm_sched_abort_all(tm_sched* s, int status);
+/* forget a finished request; TM_INVALID for unknown / unfinished ids */
+int tm_sched_forget(tm_sched* s, int64_t req_id);
 /* the engine's stream (hipStream_t) so callers can bracket it with their own events */
 tm_stream_t tm_engine_stream(tm_engine* e);
 /* introspection for benchmarks: bytes of quantised weights + scales + lm_head, KV bytes per token, #blocks */

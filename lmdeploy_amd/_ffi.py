@@ -138,6 +138,8 @@ _SIGNATURES = {
     'tm_engine_step': (c_int, [c_void_p, POINTER(c_int), POINTER(c_int)]),
     'tm_engine_poll': (c_int, [c_void_p, c_int64, POINTER(c_int), c_void_p, c_int, POINTER(c_int)]),
     'tm_engine_cancel': (c_int, [c_void_p, c_int64]),
+    'tm_engine_forget': (c_int, [c_void_p, c_int64]),
+    'tm_sched_forget': (c_int, [c_void_p, c_int64]),
     'tm_engine_serve_start': (c_int, [c_void_p, c_void_p, c_void_p]),
     'tm_engine_serve_stop': (c_int, [c_void_p]),
     'tm_engine_wait': (c_int, [c_void_p, c_int64, c_int, c_int, POINTER(c_int), POINTER(c_int)]),

@@ -503,6 +503,16 @@ int tm_sched_counts(tm_sched* s, int* n_active, int* n_waiting, int* n_free_bloc
     return 0;
 }
 
+int tm_sched_forget(tm_sched* s, int64_t req_id)
+{
+    TM_REQUIRE(s, "null pointer");
+    if (!s->impl.erase(req_id)) {
+        set_last_error("unknown or unfinished request id");
+        return TM_INVALID;
+    }
+    return 0;
+}
+
 int tm_sched_abort_all(tm_sched* s, int status)
 {
     TM_REQUIRE(s, "null pointer");

@@ -1745,6 +1745,20 @@ int tm_engine_cancel(tm_engine* e, int64_t req_id)
     return 0;
 }
 
+int tm_engine_forget(tm_engine* e, int64_t req_id)
+{
+    TM_REQUIRE(e, "null pointer");
+    ApiLock lock(e);
+    TM_REQUIRE(e->sched, "no continuous-batching session (submit first)");
+    if (!e->sched->erase(req_id)) {
+        set_last_error("unknown or unfinished request id");
+        return TM_INVALID;
+    }
+    e->cb_sampling.erase(req_id);
+    e->cb_logits.erase(req_id);
+    return 0;
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // The engine thread: schedule -> forward -> update while requests exist, asleep otherwise.
 // ------------------------------------------------------------------------------------------------------------------

@@ -84,11 +84,12 @@ public:
         std::vector<SchedAdmit> out;
         int                     tokens = 0;
         while (!waiting_.empty()) {
-            SchedRequest& r = reqs_[waiting_.front()];
-            if (r.status != 0) {  // cancelled while waiting
+            auto it = reqs_.find(waiting_.front());
+            if (it == reqs_.end() || it->second.status != 0) {  // cancelled (and possibly forgotten) while waiting
                 waiting_.pop_front();
                 continue;
             }
+            SchedRequest& r = it->second;
             const int n    = (int)r.prompt.size();
             const int need = blocks_for(n + r.max_new);
             int       slot = -1;
@@ -199,14 +200,23 @@ public:
         auto it = reqs_.find(id);
         return it == reqs_.end() ? nullptr : &it->second;
     }
-    // forget a finished request (poll consumed it)
-    void erase(int64_t id)
+    // forget a finished request (poll consumed it); false: unknown id or the request is still queued / running
+    bool erase(int64_t id)
     {
         auto it = reqs_.find(id);
-        if (it != reqs_.end() && it->second.status != 0) {
-            reqs_.erase(it);
+        if (it == reqs_.end() || it->second.status == 0) {
+            return false;
         }
+        reqs_.erase(it);
+        for (auto w = waiting_.begin(); w != waiting_.end(); ++w) {  // a request cancelled while it was waiting
+            if (*w == id) {
+                waiting_.erase(w);
+                break;
+            }
+        }
+        return true;
     }
+    size_t n_records() const { return reqs_.size(); }
     int64_t slot_request(int slot) const { return slot_req_[slot]; }
     int     n_active() const
     {
@@ -220,7 +230,8 @@ public:
     {
         int n = 0;
         for (int64_t id : waiting_) {
-            n += reqs_.at(id).status == 0;
+            auto it = reqs_.find(id);
+            n += it != reqs_.end() && it->second.status == 0;
         }
         return n;
     }

@@ -168,6 +168,10 @@ class Engine:
     def cancel(self, req_id: int):
         _ffi.check(self._lib.tm_engine_cancel(self._h, req_id))
 
+    def forget(self, req_id: int):
+        """Drop the record of a finished request (long-lived serving sessions; release() drops everything)."""
+        _ffi.check(self._lib.tm_engine_forget(self._h, req_id))
+
     # -- engine thread (the reference's InternalThreadEntry + signal thread): submit / poll / cancel / wait from any thread
     def serve_start(self, on_update=None):
         """Start the engine-owned scheduler thread.  on_update(req_id, status, n_tokens) runs ON THAT THREAD once per

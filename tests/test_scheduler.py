@@ -52,6 +52,9 @@ class Sched:
     def abort_all(self, status):
         return self.lib.tm_sched_abort_all(self.h, status)
 
+    def forget(self, rid):
+        return self.lib.tm_sched_forget(self.h, rid)
+
     def __del__(self):
         self.lib.tm_sched_destroy(self.h)
 
@@ -146,3 +149,18 @@ def test_abort_all_fails_everything_unfinished():
     assert not s.on_token(1, 3)                           # the aborted slot no longer belongs to a request
     rc, rid = s.submit(70, 5)
     assert rc == 0 and s.admit() == [(rid, 0)] and s.counts() == (1, 0, 4)
+
+
+def test_forget_drops_only_finished_requests():
+    """Long-lived sessions: a finished (or cancelled) request's record can be dropped, a queued or running one cannot;
+    ids are never reused."""
+    s = Sched(max_batch=1, num_blocks=4, session_len=128)
+    a, b = s.submit(5, 2)[1], s.submit(5, 2)[1]
+    assert s.admit() == [(a, 0)]
+    assert s.forget(a) == INVALID and s.forget(b) == INVALID and s.forget(12345) == INVALID
+    s.on_token(0, 1)
+    assert s.on_token(0, 1)                                # a finished by length
+    assert s.forget(a) == 0 and s.query(a)[0] == INVALID   # gone
+    assert s.cancel(b)[0] == 0 and s.forget(b) == 0        # cancelled while waiting
+    rc, c = s.submit(5, 1)
+    assert rc == 0 and c not in (a, b) and s.admit() == [(c, 0)]
