@@ -164,3 +164,94 @@ def test_forget_drops_only_finished_requests():
     assert s.cancel(b)[0] == 0 and s.forget(b) == 0        # cancelled while waiting
     rc, c = s.submit(5, 1)
     assert rc == 0 and c not in (a, b) and s.admit() == [(c, 0)]
+
+
+@pytest.mark.parametrize('seed', range(6))
+def test_random_operation_sequences_keep_the_invariants(seed):
+    """Randomised submit / admit / token / cancel / forget sequences against a Python model of the policy: block
+    conservation (free + held = pool), at most one request per slot, arrival-order admission, terminal statuses never
+    change, forgotten ids disappear, the counters agree with the model at every step."""
+    rng = np.random.default_rng(seed)
+    B, NB, SL = int(rng.integers(1, 5)), int(rng.integers(3, 12)), 256
+    s = Sched(max_batch=B, num_blocks=NB, session_len=SL)
+    blocks = lambda n: (n + 63) // 64
+    model = {}                       # id -> dict(n, max_new, eos, status, slot, out, blocks)
+    order, slots = [], [None] * B    # waiting ids in arrival order; slot -> id
+    for step in range(400):
+        op = rng.choice(['submit', 'admit', 'token', 'token', 'token', 'cancel', 'forget'])
+        if op == 'submit':
+            n, mx = int(rng.integers(1, 200)), int(rng.integers(1, 80))
+            eos = int(rng.integers(0, 4)) if rng.random() < 0.5 else -1
+            rc, rid = s.submit(n, mx, eos)
+            if n + mx > SL:
+                assert rc == TOO_LONG
+            elif blocks(n + mx) > NB:
+                assert rc == OOM
+            else:
+                assert rc == 0 and rid not in model
+                model[rid] = dict(n=n, max_new=mx, eos=eos, status=0, slot=None, out=0, blocks=0)
+                order.append(rid)
+        elif op == 'admit':
+            budget = int(rng.integers(1, 400))
+            got = s.admit(budget)
+            want, tokens = [], 0
+            free = NB - sum(m['blocks'] for m in model.values())
+            while order:
+                rid = order[0]
+                if rid not in model or model[rid]['status'] != 0:
+                    order.pop(0)
+                    continue
+                m = model[rid]
+                need = blocks(m['n'] + m['max_new'])
+                slot = next((i for i, v in enumerate(slots) if v is None), None)
+                if slot is None or need > free or (want and tokens + m['n'] > budget):
+                    break
+                slots[slot], m['slot'], m['blocks'] = rid, slot, need
+                free -= need
+                tokens += m['n']
+                want.append((rid, slot))
+                order.pop(0)
+            assert got == want, (step, got, want)
+        elif op == 'token':
+            slot = int(rng.integers(0, B))
+            tok = int(rng.integers(0, 4))
+            fin = s.on_token(slot, tok)
+            rid = slots[slot]
+            if rid is None:
+                assert not fin
+            else:
+                m = model[rid]
+                m['out'] += 1
+                done = (m['eos'] >= 0 and tok == m['eos']) or m['out'] >= m['max_new']
+                assert fin == done
+                if done:
+                    m.update(status=FINISH, slot=None, blocks=0)
+                    slots[slot] = None
+        elif op == 'cancel' and model:
+            rid = int(rng.choice(list(model)))
+            rc, rel = s.cancel(rid)
+            m = model[rid]
+            assert rc == 0
+            if m['status'] == 0:
+                assert rel == (m['slot'] if m['slot'] is not None else -1)
+                if m['slot'] is not None:
+                    slots[m['slot']] = None
+                m.update(status=CANCEL, slot=None, blocks=0)
+            else:
+                assert rel == -1
+        elif op == 'forget' and model:
+            rid = int(rng.choice(list(model)))
+            rc = s.forget(rid)
+            if model[rid]['status'] == 0:
+                assert rc == INVALID
+            else:
+                assert rc == 0
+                del model[rid]
+        # the counters and every record agree with the model
+        na, nw, nf = s.counts()
+        assert na == sum(v is not None for v in slots) <= B
+        assert nw == sum(1 for r in order if r in model and model[r]['status'] == 0)
+        assert nf == NB - sum(m['blocks'] for m in model.values())
+        for rid, m in model.items():
+            rc, st, slot, ng, nb = s.query(rid)
+            assert (rc, st, slot, ng, nb) == (0, m['status'], -1 if m['slot'] is None else m['slot'], m['out'], m['blocks']), (step, rid)
