@@ -244,6 +244,66 @@ def test_hf_internlm2_fp16_checkpoint_reader(tmp_path):
         checkpoint.read_config(str(tmp_path))
 
 
+def test_hf_internlm2_awq_checkpoint_reader(tmp_path):
+    """BASELINE config 3's on-disk format (InternLM2-20B AWQ): the fused `wqkv` of models/internlm2.py:34-87 as an AWQ
+    linear -- `qweight` / `qzeros` int32 in AutoAWQ's nibble order and `scales`, all laid out per kv group as
+    [q_0 .. q_{g-1}, k, v] along the output dim.  The reader must de-interleave codes, scales AND zeros the same way,
+    apply the RoPE channel permutation to all three, and the dequantised [Q | K | V] must equal the dequantised HF
+    tensors bit for bit."""
+    from safetensors.numpy import save_file
+    rng = np.random.default_rng(3)
+    H, D, Hq, Hkv, I, V = 256, 128, 4, 2, 256, 64
+    g = Hq // Hkv
+    tensors, deq = {}, {}
+
+    def put_awq(name, w_kn):                       # fp16 [K, N] (TM orientation) -> AWQ tensors; dequantised copy kept
+        q, sc, z, _ = o.quantize_groupwise_u4(w_kn, 128)
+        tensors[name + '.qweight'] = o.pack_awq_gemm(q)
+        tensors[name + '.qzeros'] = o.pack_awq_gemm(z.astype(np.uint8))
+        tensors[name + '.scales'] = sc
+        deq[name] = o.w4a16_dequant(q, sc, z)
+
+    q_w = (rng.standard_normal((H, Hq * D)) * 0.05).astype(f16)
+    k_w = (rng.standard_normal((H, Hkv * D)) * 0.05).astype(f16)
+    v_w = (rng.standard_normal((H, Hkv * D)) * 0.05).astype(f16)
+    fused = np.concatenate([np.concatenate([q_w[:, j * g * D:(j + 1) * g * D], k_w[:, j * D:(j + 1) * D], v_w[:, j * D:(j + 1) * D]], 1)
+                            for j in range(Hkv)], 1)
+    p = 'model.layers.0'
+    put_awq(f'{p}.attention.wqkv', fused)
+    put_awq(f'{p}.attention.wo', (rng.standard_normal((Hq * D, H)) * 0.05).astype(f16))
+    put_awq(f'{p}.feed_forward.w1', (rng.standard_normal((H, I)) * 0.05).astype(f16))
+    put_awq(f'{p}.feed_forward.w3', (rng.standard_normal((H, I)) * 0.05).astype(f16))
+    put_awq(f'{p}.feed_forward.w2', (rng.standard_normal((I, H)) * 0.05).astype(f16))
+    tensors.update({f'{p}.attention_norm.weight': np.ones(H, f16), f'{p}.ffn_norm.weight': np.ones(H, f16),
+                    'model.tok_embeddings.weight': rng.standard_normal((V, H)).astype(f16), 'model.norm.weight': np.ones(H, f16),
+                    'output.weight': rng.standard_normal((V, H)).astype(f16)})
+    save_file(tensors, os.path.join(tmp_path, 'model.safetensors'))
+    json.dump({'architectures': ['InternLM2ForCausalLM'], 'hidden_size': H, 'num_hidden_layers': 1, 'num_attention_heads': Hq,
+               'num_key_value_heads': Hkv, 'head_dim': D, 'intermediate_size': I, 'vocab_size': V, 'rms_norm_eps': 1e-6, 'rope_theta': 1e6,
+               'quantization_config': {'quant_method': 'awq', 'bits': 4, 'group_size': 128, 'zero_point': True, 'version': 'gemm'}},
+              open(os.path.join(tmp_path, 'config.json'), 'w'))
+    mc = checkpoint.read_config(str(tmp_path))
+    assert (mc.arch, mc.quantized, mc.weight_format) == ('internlm2', True, 'u4')
+    w = checkpoint.load_hf_weights(str(tmp_path), mc)
+    L = w['layers'][0]
+    got = o.w4a16_dequant(L['w_qkv']['q'], L['w_qkv']['s'], L['w_qkv']['z'])
+    # the expected [Q | K | V]: split the dequantised fused tensor per kv group, then the interleaved-RoPE permutation
+    dq = deq[f'{p}.attention.wqkv'].reshape(H, Hkv, g + 2, D)
+    eq = dq[:, :, :g].reshape(H, Hq * D)
+    ek, ev = dq[:, :, g].reshape(H, Hkv * D), dq[:, :, g + 1].reshape(H, Hkv * D)
+    exp = np.concatenate([o.permute_qk_for_interleaved_rope(eq, Hq, D), o.permute_qk_for_interleaved_rope(ek, Hkv, D), ev], 1)
+    assert np.array_equal(got.view(np.uint16), exp.view(np.uint16))
+    w13 = o.w4a16_dequant(L['w1w3']['q'], L['w1w3']['s'], L['w1w3']['z'])
+    assert np.array_equal(w13.view(np.uint16), o.interleave_w1w3(deq[f'{p}.feed_forward.w1'], deq[f'{p}.feed_forward.w3']).view(np.uint16))
+    slots = loader.export_weights(mc, w, 2, 1)                                   # rank 1 of TP = 2
+    sq = o.w4a16_dequant(o.unpack_u4_row(slots['layers.0.attention.w_qkv.qweight']), slots['layers.0.attention.w_qkv.scales'],
+                         slots['layers.0.attention.w_qkv.zeros'])
+    hq_l, hkv_l = Hq // 2, Hkv // 2
+    exp1 = np.concatenate([exp[:, hq_l * D:2 * hq_l * D], exp[:, (Hq + hkv_l) * D:(Hq + 2 * hkv_l) * D],
+                           exp[:, (Hq + Hkv + hkv_l) * D:(Hq + Hkv + 2 * hkv_l) * D]], 1)
+    assert np.array_equal(sq.view(np.uint16), exp1.view(np.uint16))
+
+
 def test_hf_mixtral_fp8_checkpoint_reader(tmp_path):
     """BASELINE config 5's on-disk format: a Mixtral checkpoint with block-128 FP8 weights (float8_e4m3fn `.weight`
     [out, in] + fp32 `.weight_scale_inv` [out/128, in/128], bf16 norms / router / embeddings; reference:
