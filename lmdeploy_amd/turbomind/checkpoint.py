@@ -89,6 +89,17 @@ def read_config(model_path: str) -> ModelConfig:
             rope = RopeConfig(D, rope.base, 'linear', float(rs['factor']))
         elif t not in (None, 'default'):
             raise NotImplementedError(f'rope_scaling type {t}')
+    # eos ids: config.json + generation_config.json (GenerationConfig.update_from_hf_gen_cfg, lmdeploy/messages.py:176-199)
+    eos = c.get('eos_token_id')
+    gpath = os.path.join(model_path, 'generation_config.json')
+    if os.path.exists(gpath):
+        with open(gpath) as f:
+            ge = json.load(f).get('eos_token_id')
+        if ge is not None:
+            merged = list(eos if isinstance(eos, (list, tuple)) else ([] if eos is None else [eos]))
+            merged += [t for t in (ge if isinstance(ge, (list, tuple)) else [ge]) if t not in merged]
+            eos = merged if len(merged) > 1 else merged[0]
+    c = dict(c, eos_token_id=eos)
     return ModelConfig(hidden=H, layers=c['num_hidden_layers'], q_heads=heads,
                        kv_heads=c.get('num_key_value_heads', heads), head_dim=D, inter=c['intermediate_size'],
                        vocab=c['vocab_size'], rms_eps=float(c.get('rms_norm_eps', 1e-5)), rope=rope, arch=kind,

@@ -283,7 +283,9 @@ def test_hf_internlm2_awq_checkpoint_reader(tmp_path):
                'quantization_config': {'quant_method': 'awq', 'bits': 4, 'group_size': 128, 'zero_point': True, 'version': 'gemm'}},
               open(os.path.join(tmp_path, 'config.json'), 'w'))
     mc = checkpoint.read_config(str(tmp_path))
-    assert (mc.arch, mc.quantized, mc.weight_format) == ('internlm2', True, 'u4')
+    assert (mc.arch, mc.quantized, mc.weight_format) == ('internlm2', True, 'u4') and mc.eos_token_id is None
+    json.dump({'eos_token_id': [2, 92542]}, open(os.path.join(tmp_path, 'generation_config.json'), 'w'))
+    assert checkpoint.read_config(str(tmp_path)).eos_token_id == [2, 92542]      # generation_config.json joins in
     w = checkpoint.load_hf_weights(str(tmp_path), mc)
     L = w['layers'][0]
     got = o.w4a16_dequant(L['w_qkv']['q'], L['w_qkv']['s'], L['w_qkv']['z'])
