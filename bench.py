@@ -58,6 +58,38 @@ def algorithmic_bytes(m, batch, ctx, kv_bits, tp):
     return (w + batch * ctx * kv_tok) / tp, kv_tok / tp
 
 
+def self_launch(n: int) -> int:
+    """Spawn ranks 0..n-1 of this script (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment, exactly what
+    torch.distributed.run would set), forward rank 0's stdout (the JSON line) and everybody's stderr.  Returns the
+    first non-zero exit code; a rank that dies takes the others down with it (they would hang in a collective)."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    alive = set(range(n))
+    while alive:
+        for r in sorted(alive):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            alive.discard(r)
+            if code != 0 and rc == 0:
+                rc = code
+                print(f'bench.py: rank {r} exited with {code}; stopping the other ranks', file=sys.stderr)
+                for q in alive:
+                    procs[q].terminate()
+        time.sleep(0.05)
+    return rc
+
+
 def main():
     # multi-process GPU work on this pool needs dmabuf IPC (RCCL's P2P setup fails with the legacy mode:
     # "hipIpcGetMemHandle: invalid argument"); already exported on the driver's boxes, kept here for hand launches
@@ -79,6 +111,10 @@ def main():
                     help='SURVEY 8(e) on a 1-GPU box: run ONE rank\'s shard of a TP=N job (heads / inter / vocab divided by N, '
                          'collectives through a 1-rank RCCL communicator): per-rank kernel time only, labelled as such')
     args = ap.parse_args()
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # plain `python bench.py --gpus N`: bring up the N ranks of this node ourselves, one process per GPU (the
+        # reference starts all ranks of a node from one call too: lmdeploy/turbomind/turbomind.py:191-217)
+        sys.exit(self_launch(args.gpus))
 
     import torch
     import torch.distributed as dist
@@ -87,7 +123,8 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
+    if world != args.gpus:
+        sys.exit(f'bench.py: --gpus {args.gpus} but the launcher set WORLD_SIZE={world}')
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
@@ -171,7 +208,7 @@ def main():
             'config': {'workload': f'Llama-3-8B shapes, W4A16 AWQ g128 random weights, quant_policy={args.quant_policy} '
                                    f'KV, batch {B}, {S}-token random prompts, greedy decode, TP={world}',
                        'batch': B, 'prompt_len': S, 'ctx_first_timed_step': ctx_first, 'ctx_mean': ctx_mean,
-                       'parallelism': f'tp{world}', 'decode_splits': stats['decode_splits'], 'hipgraph': not args.no_graph},
+                       'parallelism': f'tp{world}', 'rccl_ranks': world if world > 1 else 0, 'decode_splits': stats['decode_splits'], 'hipgraph': not args.no_graph},
             'ttft_p50_ms': round(float(np.median(ttft)), 2), 'prefill_total_s': round(prefill_s, 3),
             'prefill_tokens_per_s': round(B * S / prefill_s, 1),
             'step_roofline': {'bound': 'hbm', 'algorithmic_bytes_per_step': int(step_bytes),

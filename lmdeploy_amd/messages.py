@@ -138,9 +138,12 @@ class GenerationConfig:
     def logits_params(self, stop_ids=()):
         """dict for the engine's logits processors (tm_logits_param), or None when every processor is off.
         stop_ids: the ids that end the sequence besides the engine-side eos id (banned until min_new_tokens)."""
-        if self.repetition_penalty == 1.0 and not self.bad_token_ids and not self.min_new_tokens:
+        # greedy requests run with repetition_penalty 1.0 whatever the field says -- the reference resets it together
+        # with top_k / temperature (lmdeploy/serve/core/async_engine.py:424-430); bad ids and min_new_tokens stay on
+        rep = float(self.repetition_penalty) if self.do_sample else 1.0
+        if rep == 1.0 and not self.bad_token_ids and not self.min_new_tokens:
             return None
-        return dict(repetition_penalty=float(self.repetition_penalty), min_new_tokens=int(self.min_new_tokens or 0),
+        return dict(repetition_penalty=rep, min_new_tokens=int(self.min_new_tokens or 0),
                     bad_ids=list(self.bad_token_ids or ()), stop_ids=list(stop_ids))
 
     def sampling_params(self, index: int = 0):

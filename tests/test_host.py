@@ -404,7 +404,7 @@ def test_api_surface_and_validation():
     assert gs.sampling_params(3) == (pytest.approx(0.7), 40, pytest.approx(0.9), 0.0, 8)
     assert GenerationConfig(do_sample=True, top_k=1).sampling_params() is None
     assert g.logits_params() is None
-    gp = GenerationConfig(repetition_penalty=1.1, min_new_tokens=3, bad_token_ids=[7, 9])
+    gp = GenerationConfig(do_sample=True, repetition_penalty=1.1, min_new_tokens=3, bad_token_ids=[7, 9])
     assert gp.logits_params([2]) == dict(repetition_penalty=pytest.approx(1.1), min_new_tokens=3, bad_ids=[7, 9], stop_ids=[2])
     lp = _ffi.LogitsParam.make(**gp.logits_params([2]))
     assert (lp.n_bad_ids, lp.bad_ids[1], lp.n_stop_ids, lp.stop_ids[0], lp.min_new_tokens) == (2, 9, 1, 2, 3)

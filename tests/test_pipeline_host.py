@@ -171,7 +171,11 @@ def test_errors_become_responses_and_processors_reach_the_engine(pipe):
     assert res[1].finish_reason == 'error' and res[1].error_code == 'INPUT_LENGTH_ERROR' and res[1].token_ids == []
     assert res[0].token_ids == res[2].token_ids == _expect(ok, 8)[0]
     lp = g.logits_params([])
-    assert lp == dict(repetition_penalty=pytest.approx(1.2), min_new_tokens=2, bad_ids=[5], stop_ids=[])
+    # greedy (do_sample=False): the penalty is reset to 1.0 like the reference does (async_engine.py:424-430) ...
+    assert lp == dict(repetition_penalty=pytest.approx(1.0), min_new_tokens=2, bad_ids=[5], stop_ids=[])
+    assert GenerationConfig(repetition_penalty=1.2).logits_params([]) is None
+    # ... and reaches the engine only for sampling requests
+    assert GenerationConfig(do_sample=True, repetition_penalty=1.2).logits_params([7])['repetition_penalty'] == pytest.approx(1.2)
     # the scheduler path hands the processors of the GenerationConfig to the engine with every request ...
     eng = FakeEngine.instances[0]
     seen = []
