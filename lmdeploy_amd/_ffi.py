@@ -126,6 +126,7 @@ _SIGNATURES = {
     'tm_engine_profile_decode': (c_int, [c_void_p, c_int, c_void_p, c_void_p]),
     'tm_engine_fetch': (c_int, [c_void_p, c_void_p, POINTER(c_int)]),
     'tm_engine_fetch_logits': (c_int, [c_void_p, c_void_p]),
+    'tm_engine_debug_read': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int64]),
     'tm_engine_release': (c_int, [c_void_p]),
     'tm_engine_set_sampling': (c_int, [c_void_p, c_void_p, c_int]),
     'tm_engine_set_logits_params': (c_int, [c_void_p, c_void_p, c_int]),

@@ -285,6 +285,19 @@ int tm_linear_forward(const tm_linear* w, const void* x, int ldx, void* y, int l
     if (splits > 0) {
         cfg.splits = splits;
     }
+    if (nt > 0 || (waves > 0 && !(waves & 0x200))) {
+        cfg.d32_shape = -1;  // an explicit tiling of the general kernel
+        if (splits <= 0) {
+            cfg.splits = gemm_pick_config_general(w->w, M).splits;
+        }
+    }
+    if (waves > 0 && (waves & 0x200)) {
+        // 0x200 + shape: the decode kernel (gemm_decode.hip) with an explicit workgroup shape; M <= 64, u4, N % 32 == 0
+        TM_REQUIRE(dec32_supported(w->w, M), "decode kernel: u4 weights, M <= 64, N % 32 == 0");
+        cfg.d32_shape = waves & 0xff;
+        TM_REQUIRE(cfg.d32_shape <= 3, "decode kernel shape 0..3");
+        waves = 0;
+    }
     if (waves > 0) {
         // waves per workgroup (4 | 8); + 0x100 = split K two ways INSIDE the workgroup (8 waves only)
         TM_REQUIRE((waves & 0xff) == 4 || (waves & 0xff) == 8 || (waves & 0xff) == 16,

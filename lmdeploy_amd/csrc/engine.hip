@@ -1943,6 +1943,25 @@ int tm_engine_fetch_logits(tm_engine* e, void* host_out)
     return 0;
 }
 
+int tm_engine_debug_read(tm_engine* e, int what, int a, int b, void* host_out, int64_t bytes)
+{
+    TM_REQUIRE(e && host_out && e->started, "null pointer / engine not started");
+    TM_HIP_CHECK(hipStreamSynchronize(e->stream));
+    if (what == 0) {  // residual stream of the last forward: rows [0, a)
+        TM_REQUIRE(a >= 1 && a <= e->max_tokens && bytes == (int64_t)a * e->hidden * 2, "residual rows / byte count");
+        TM_HIP_CHECK(hipMemcpy(host_out, e->d_resid, (size_t)bytes, hipMemcpyDeviceToHost));
+        return 0;
+    }
+    if (what == 1) {  // KV block b of static-batch sequence a (all layers, the reference's block byte layout)
+        TM_REQUIRE(a >= 0 && a < (int)e->h_blocks.size() && b >= 0 && b < (int)e->h_blocks[a].size(), "sequence / block index");
+        TM_REQUIRE(bytes == (int64_t)e->block_bytes, "byte count must be the block size");
+        TM_HIP_CHECK(hipMemcpy(host_out, e->pool + (int64_t)e->h_blocks[a][b] * e->block_bytes, (size_t)bytes, hipMemcpyDeviceToHost));
+        return 0;
+    }
+    set_last_error("tm_engine_debug_read: unknown selector");
+    return 1;
+}
+
 tm_stream_t tm_engine_stream(tm_engine* e)
 {
     return e ? (tm_stream_t)e->stream : nullptr;

@@ -1,0 +1,531 @@
+// W4A16 decode GEMM (M <= 64 rows) for gfx950: the weight-streaming kernel of the decode step.
+//
+// Replaces: LlamaLinear::Forward -> gemm::Gemm::Run for the decode batch (src/turbomind/models/llama/LlamaLinear.cu:140-216,
+//           kernels/gemm/gemm.cu:257-344; tile family kernels/gemm/arch/config_sm80_s16816.h:108-136), dequant
+//           kernels/gemm/transform.h:34-74, gated-SiLU epilogue kernels/gemm/epilogue.h:159-176.
+// Arithmetic is the one of gemm_w4a16.hip: w = h(fma(h(q), s, h(-z*s))), fp32 MFMA accumulation, one rounding to fp16.
+//
+// Why a second kernel (round-1 measurements): with 8 waves per CU moving in lockstep through one barrier
+// per k-block, the per-CU costs of a 16-column x 128-k weight tile ADD UP -- HBM 109 clk (at 10 B/clk/CU), MFMA 64,
+// x fragments out of LDS 64, dequant VALU 26..52, x staging -- to ~290 clk, which is what was measured (0.19 of the
+// HBM roofline).  This kernel is built so that they overlap instead:
+//   * v_mfma_f32_32x32x16_f16, Y^T = W^T X^T: a wave owns 32 columns and all M rows, so one x fragment read from LDS
+//     feeds 32 columns instead of 16 -> half the LDS read volume per weight byte (32 clk per tile);
+//   * 16 waves per CU (4 per SIMD, <= 128 VGPRs): while one wave's MFMAs occupy a SIMD's matrix pipe the other three
+//     dequantise / read LDS / wait for HBM -- in-order issue inside a wave no longer serialises the phases;
+//   * the workgroup = CG column groups x WK k-phases: 128 columns per CU keep >= 224 workgroups alive for the wide
+//     w1w3 while the 4 k-phases are summed ON CHIP (through LDS, once per kernel) instead of through fp32 slabs;
+//   * x goes global -> registers -> LDS in stages of S k-blocks, double buffered, ONE barrier per stage (not per
+//     k-block); the loads of stage t+1 are issued at the top of stage t and written after its compute;
+//   * weights + (s, -z*s) of one (k-block, 32-column group) are ONE contiguous 2176-byte unit (layout "P32" below):
+//     one buffer descriptor, scalar unit offsets, `nt` loads into a per-wave register ring PF k-blocks deep;
+//   * epilogue: the WK partial tiles meet in LDS (XOR-swizzled, conflict-free), all threads then sum them in a fixed
+//     order and store whole row segments (256..512 B) -- fp16, gated-SiLU fp16, or fp32 split-K slabs.
+//
+// Layout P32 (built once by repack_p32_kernel at load, LinearWeight::prepare's role, models/linear_weight.cc:101-324):
+//   unit (kb, cg) at byte ((kb * N/32) + cg) * 2176:
+//     [0, 2048)    dword d = (p*64 + lane)*4 + jj  (p = 0..1, jj = 0..3): j = 4p + jj is the 16-k step of the k-block,
+//                  lane l holds column 32cg + (l & 31), k = 128kb + 16j + 8(l >> 5) + e, e = 0..7 in nibble order
+//                  [k0,k2,k4,k6,k1,k3,k5,k7] -- exactly the A operand of v_mfma_f32_32x32x16_f16 (A[i = l&31][k = 8(l>>5)+e]);
+//     [2048, 2176) 32 x (s, -z*s) half2 pairs of the group's columns.
+#include "tm_common.h"
+#include "tm_kernels.h"
+#include <stdlib.h>
+#include <type_traits>
+
+namespace tmk {
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+constexpr int kP32Unit = 2176;
+
+__global__ void repack_p32_kernel(uint32_t* __restrict__ out, const int32_t* __restrict__ qw, const half_t* __restrict__ scales,
+                                  const half_t* __restrict__ zeros, int K, int N)
+{
+    const size_t idx   = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int    ncg   = N / 32;
+    const size_t total = (size_t)(K / 128) * ncg * (kP32Unit / 4);
+    if (idx >= total) {
+        return;
+    }
+    const size_t unit = idx / (kP32Unit / 4);
+    const int    d    = (int)(idx % (kP32Unit / 4));
+    const int    cg   = (int)(unit % ncg);
+    const int    kb   = (int)(unit / ncg);
+    if (d >= 512) {  // (s, -z*s), one fp16 rounding of the product (cast.cu:151-156)
+        const int    n  = cg * 32 + (d - 512);
+        const half_t s  = scales[(size_t)kb * N + n];
+        const half_t z  = zeros[(size_t)kb * N + n];
+        const half_t zs = (-z) * s;
+        out[idx]        = bit_cast<uint32_t>(half2_t{s, zs});
+        return;
+    }
+    const int jj   = d & 3;
+    const int lane = (d >> 2) & 63;
+    const int p    = d >> 8;
+    const int j    = 4 * p + jj;
+    const int n    = cg * 32 + (lane & 31);
+    const int k0   = kb * 128 + 16 * j + 8 * (lane >> 5);
+    uint32_t  w    = 0;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const uint32_t word = (uint32_t)qw[(size_t)(k0 + e) * (N / 8) + (n >> 3)];
+        const uint32_t q    = (word >> (4 * (n & 7))) & 15u;
+        const int      nib  = (e & 1) ? 4 + (e >> 1) : (e >> 1);
+        w |= q << (4 * nib);
+    }
+    out[idx] = w;
+}
+
+size_t p32_bytes(int K, int N)
+{
+    return (size_t)(K / 128) * (N / 32) * kP32Unit;
+}
+
+int launch_repack_p32(void* out, const int32_t* qweight, const half_t* scales, const half_t* zeros, int K, int N, hipStream_t st)
+{
+    const size_t total = p32_bytes(K, N) / 4;
+    repack_p32_kernel<<<(unsigned)((total + 255) / 256), 256, 0, st>>>((uint32_t*)out, qweight, scales, zeros, K, N);
+    TM_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+struct Dec32Params {
+    const half_t* x;
+    int           ldx;
+    const void*   wp;  // P32 units
+    half_t*       y;
+    int           ldy;
+    float*        partial;  // [splits][M][N] fp32 slabs (epilogue 2)
+    int           M, N, K, KB, ncg;
+    int           kb_per_split;
+    int           epilogue;  // 0: fp16   1: gated SiLU fp16 (N/2 columns)   2: fp32 slab of split blockIdx.y
+};
+
+__device__ __forceinline__ half8_t dequant8_p32(uint32_t w, half2_t s2, half2_t z2, uint32_t m1024, uint32_t m64)
+{
+    // same arithmetic as dequant8 of gemm_w4a16.hip (quantization.h:503-524 magic numbers, exact subtract, one fma)
+    const half2_t  k1024 = {(half_t)1024.0f, (half_t)1024.0f};
+    const half2_t  k64   = {(half_t)64.0f, (half_t)64.0f};
+    const uint32_t hi    = w >> 8;
+    half2_t        p0    = bit_cast<half2_t>((w & 0x000f000fu) | m1024) - k1024;
+    half2_t        p1    = bit_cast<half2_t>((w & 0x00f000f0u) | m64) - k64;
+    half2_t        p2    = bit_cast<half2_t>((hi & 0x000f000fu) | m1024) - k1024;
+    half2_t        p3    = bit_cast<half2_t>((hi & 0x00f000f0u) | m64) - k64;
+    p0                   = h2_fma(p0, s2, z2);
+    p1                   = h2_fma(p1, s2, z2);
+    p2                   = h2_fma(p2, s2, z2);
+    p3                   = h2_fma(p3, s2, z2);
+    return half8_t{p0[0], p0[1], p1[0], p1[1], p2[0], p2[1], p3[0], p3[1]};
+}
+
+template<int N, class F, int I = 0>
+__device__ __forceinline__ void static_for(F&& f)
+{
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<N, F, I + 1>(static_cast<F&&>(f));
+    }
+}
+
+// MH: 32-row halves of the batch (1: M <= 32, 2: M <= 64).  CG x WK waves.  S k-blocks per LDS stage (S % WK == 0).
+// PF: ring depth in k-blocks per wave, a multiple of 2 * S / WK (the unrolled body covers PF / (S / WK) stages, an even
+// number, so that ring slots and the LDS buffer parity are compile-time constants).
+// ABL (timing experiments only, results are garbage): 1 no dequant, 2 no MFMA, 4 no LDS fragment reads, 8 no x staging,
+// 16 no weight loads inside the loop.
+template<int MH, int CG, int WK, int S, int PF, int ABL = 0>
+__global__ __launch_bounds__(CG* WK * 64) void gemm_dec32_kernel(Dec32Params p)
+{
+    constexpr int WAVES = CG * WK;
+    constexpr int T     = WAVES * 64;
+    constexpr int ROWS  = 32 * MH;
+    constexpr int KBB   = ROWS * 256;  // LDS bytes of one k-block of x
+    constexpr int STG   = S * KBB;     // one stage
+    constexpr int BPS   = S / WK;      // k-blocks per wave per stage
+    constexpr int UNR   = PF / BPS;    // stages per unrolled body
+    constexpr int NCH   = S * ROWS * 16;
+    constexpr int XR    = NCH / T;
+    static_assert(S % WK == 0 && PF % BPS == 0 && UNR % 2 == 0 && NCH % T == 0, "tile parameters");
+    constexpr int REDB = WK * ROWS * CG * 128;  // reduction image: [wk][row][CG * 32 floats]
+    static_assert(REDB <= 2 * STG || REDB <= 160 * 1024, "reduction image must fit");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid  = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int cgl  = wave % CG;
+    const int wk   = wave / CG;
+    const int l31  = lane & 31;
+    const int half = lane >> 5;
+
+    const int cg  = blockIdx.x * CG + cgl;
+    const int cgc = min(cg, p.ncg - 1);
+    const int kb0 = blockIdx.y * p.kb_per_split;
+    const int nkb = min(p.kb_per_split, p.KB - kb0);
+    const int nst = (nkb + S - 1) / S;
+
+    const auto rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.wp, 0, (int)((size_t)p.KB * p.ncg * kP32Unit), 0x00020000);
+    const auto rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)(((size_t)(p.M - 1) * p.ldx + p.K) * 2), 0x00020000);
+    const int  vw   = lane * 16;
+    const int  vs   = 2048 + l31 * 4;
+
+    floatx16 acc[MH];
+#pragma unroll
+    for (int h = 0; h < MH; ++h) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            acc[h][r] = 0.f;
+        }
+    }
+
+    u32x4    ring[PF][2];
+    uint32_t sring[PF];
+    u32x4    xr[XR];
+    int      xoff[XR], xlds[XR];
+#pragma unroll
+    for (int r = 0; r < XR; ++r) {
+        const int q   = tid + T * r;
+        const int kbi = q / (ROWS * 16);
+        const int row = (q >> 4) % ROWS;
+        const int ch  = q & 15;
+        xoff[r]       = (min(row, p.M - 1) * p.ldx + ch * 8) * 2 + kbi * 256;
+        xlds[r]       = kbi * KBB + row * 256 + ((ch ^ (row & 15)) << 4);
+    }
+    // B fragment of 16-k step j: row (l & 31) [+ 32], 16-byte chunk 2j + half, XOR-swizzled by the row
+    int coff[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        coff[j] = l31 * 256 + (((2 * j + half) ^ (l31 & 15)) << 4);
+    }
+    uint32_t m1024 = 0x64006400u, m64 = 0x54005400u;
+    asm volatile("" : "+v"(m1024), "+v"(m64));  // magic numbers in VGPRs: one v_and_or_b32 per pair
+
+    // block `b` (relative to kb0) of this wave -> unit offset; blocks past the slice are clamped (their scales are zeroed)
+#define D32_LOAD_W(slot, b)                                                                                       \
+    {                                                                                                             \
+        const int uo_ = ((kb0 + min((b), nkb - 1)) * p.ncg + cgc) * kP32Unit;                                     \
+        ring[slot][0] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, vw, uo_, /*nt*/ 2);                           \
+        ring[slot][1] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, vw + 1024, uo_, /*nt*/ 2);                    \
+        sring[slot]   = __builtin_amdgcn_raw_buffer_load_b32(rs_w, vs, uo_, 0);                                   \
+    }
+#define D32_LOAD_X(t)                                                                                             \
+    _Pragma("unroll") for (int r = 0; r < XR; ++r)                                                                \
+    {                                                                                                             \
+        xr[r] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, xoff[r], (kb0 + (t)*S) * 256, 0);                     \
+    }
+#define D32_STORE_X(buf)                                                                                          \
+    _Pragma("unroll") for (int r = 0; r < XR; ++r)                                                                \
+    {                                                                                                             \
+        *(u32x4*)(smem + (buf)*STG + xlds[r]) = xr[r];                                                            \
+    }
+
+    if (nst > 0) {
+        // VMEM returns in order, so the ISSUE order decides what every counted wait also waits for.  Steady state at the
+        // top of stage t (oldest first): weights of stage t .. t+UNR-2, x of stage t+1, weights of stage t+UNR-1.  The
+        // prologue builds exactly that queue (hipcc merges the loop-entry edge and the back edge conservatively: a
+        // prologue with fewer loads in flight than the steady state turns every wait of the loop into vmcnt(0)).
+        D32_LOAD_X(0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < UNR - 1; ++u) {
+#pragma unroll
+            for (int i = 0; i < BPS; ++i) {
+                D32_LOAD_W(u * BPS + i, u * S + wk + i * WK);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        D32_STORE_X(0);
+        __builtin_amdgcn_sched_barrier(0);
+        D32_LOAD_X(1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < BPS; ++i) {
+            D32_LOAD_W((UNR - 1) * BPS + i, (UNR - 1) * S + wk + i * WK);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();
+
+        // one stage = compute on buffer (u & 1) with ring slots u*BPS.. , then staging + refills, then the barrier
+        auto stage = [&](auto U, const int t) __attribute__((always_inline)) {
+            constexpr int u = decltype(U)::value;
+            const int buf = u & 1;  // UNR is even: parity of t
+#pragma unroll
+            for (int i = 0; i < BPS; ++i) {
+                const int     slot = u * BPS + i;
+                const int     kbi  = wk + i * WK;
+                const int     b    = t * S + kbi;
+                const bool    live = b < nkb;
+                const half2_t pr   = bit_cast<half2_t>(live ? sring[slot] : 0u);
+                const half2_t s2   = {pr[0], pr[0]};
+                const half2_t z2   = {pr[1], pr[1]};
+                const char*   xb   = smem + buf * STG + kbi * KBB;
+                half8_t       bq[MH], bn[MH];
+#pragma unroll
+                for (int h = 0; h < MH; ++h) {
+                    bq[h] = (ABL & 4) ? bit_cast<half8_t>(ring[slot][1]) : *(const half8_t*)(xb + h * 8192 + coff[0]);
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const uint32_t wj = ring[slot][j >> 2][j & 3];
+                    half8_t        a;
+                    if constexpr (ABL & 1) {
+                        const uint32_t rw = wj ^ bit_cast<uint32_t>(pr);
+                        a                 = bit_cast<half8_t>(u32x4{rw, rw, rw, rw});
+                    }
+                    else {
+                        a = dequant8_p32(wj, s2, z2, m1024, m64);
+                    }
+                    if (j + 1 < 8) {  // fragments of the next 16-k step: one step of LDS latency hidden per wave
+#pragma unroll
+                        for (int h = 0; h < MH; ++h) {
+                            bn[h] = (ABL & 4) ? bit_cast<half8_t>(ring[slot][0]) : *(const half8_t*)(xb + h * 8192 + coff[j + 1]);
+                        }
+                    }
+#pragma unroll
+                    for (int h = 0; h < MH; ++h) {
+                        if constexpr (ABL & 2) {
+                            acc[h][0] += (float)a[0] + (float)bq[h][0];
+                            asm volatile("" ::"v"(a), "v"(bq[h]));
+                        }
+                        else {
+                            acc[h] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bq[h], acc[h], 0, 0, 0);
+                        }
+                    }
+                    if (j + 1 < 8) {
+#pragma unroll
+                        for (int h = 0; h < MH; ++h) {
+                            bq[h] = bn[h];
+                        }
+                    }
+                }
+            }
+            // x of stage t+1 (loaded one stage ago) -> the other buffer; then the loads of stage t+2 into the same
+            // registers, then this stage's ring slots are refilled for stage t+UNR.  All unconditional: past the last
+            // stage the x descriptor returns zeros / the weight unit is clamped and nobody reads the result, while a
+            // branch around a load makes the waitcnt pass assume the not-taken path (every later counted wait then
+            // over-waits by the skipped loads).
+            if constexpr (!(ABL & 8)) {
+                D32_STORE_X(buf ^ 1);
+                D32_LOAD_X(t + 2);
+            }
+            if constexpr (!(ABL & 16)) {
+#pragma unroll
+                for (int i = 0; i < BPS; ++i) {
+                    D32_LOAD_W(u * BPS + i, (t + UNR) * S + wk + i * WK);
+                }
+            }
+            __syncthreads();
+        };
+        // Whole unrolled bodies first, WITHOUT an exit inside: with a `break` between the stages of a body hipcc sees a
+        // path "stage u=0 -> latch -> stage u=0" (it cannot know the loop ends there) on which slot 0 was refilled a
+        // moment ago, and drains vmcnt(0) at the top of every body (seen in the ISA).  The remainder runs once.
+        int t0 = 0;
+        for (; t0 + UNR <= nst; t0 += UNR) {
+            static_for<UNR>([&](auto U) { stage(U, t0 + decltype(U)::value); });
+        }
+        static_for<UNR>([&](auto U) {
+            if (t0 + decltype(U)::value < nst) {  // uniform over the workgroup
+                stage(U, t0 + decltype(U)::value);
+            }
+        });
+    }
+#undef D32_LOAD_W
+#undef D32_LOAD_X
+#undef D32_STORE_X
+
+    // ---- the WK k-phase partial tiles meet in LDS: red[wk][row][c4 ^ (row & 7)] (floatx4 units, CG*8 per row) --------
+    // lane holds, per half h and register r: row m = 32h + (l & 31), column 32 cgl + 8 (r >> 2) + 4 (l >> 5) + (r & 3)
+    {
+        constexpr int C4 = CG * 8;  // floatx4 units per row
+        floatx4*      red = (floatx4*)smem;
+#pragma unroll
+        for (int h = 0; h < MH; ++h) {
+            const int m = 32 * h + l31;
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int c4 = cgl * 8 + 2 * g4 + half;
+                red[(wk * ROWS + m) * C4 + (c4 ^ (m & 7))] =
+                    floatx4{acc[h][4 * g4], acc[h][4 * g4 + 1], acc[h][4 * g4 + 2], acc[h][4 * g4 + 3]};
+            }
+        }
+        __syncthreads();
+        constexpr int NE = ROWS * C4;  // floatx4 elements of the output tile
+        const int     ncol0 = blockIdx.x * CG * 32;
+#pragma unroll
+        for (int e0 = 0; e0 < NE; e0 += T) {
+            const int e = e0 + tid;
+            if (NE % T != 0 && e >= NE) {
+                break;
+            }
+            const int m  = e / C4;
+            const int c4 = e % C4;
+            floatx4   a  = red[m * C4 + (c4 ^ (m & 7))];
+#pragma unroll
+            for (int k = 1; k < WK; ++k) {  // fixed order: deterministic
+                a += red[(k * ROWS + m) * C4 + (c4 ^ (m & 7))];
+            }
+            const int n = ncol0 + c4 * 4;
+            if (m >= p.M || n >= p.N) {
+                continue;
+            }
+            if (p.epilogue == 2) {
+                *(floatx4*)(p.partial + ((size_t)blockIdx.y * p.M + m) * p.N + n) = a;
+            }
+            else if (p.epilogue == 1) {
+                const float s0 = a[0] / (1.0f + __builtin_expf(-a[0]));
+                const float s1 = a[2] / (1.0f + __builtin_expf(-a[2]));
+                half2_t     o  = {(half_t)(s0 * a[1]), (half_t)(s1 * a[3])};
+                *(half2_t*)(p.y + (size_t)m * p.ldy + (n >> 1)) = o;
+            }
+            else {
+                half4_t o = {(half_t)a[0], (half_t)a[1], (half_t)a[2], (half_t)a[3]};
+                *(half4_t*)(p.y + (size_t)m * p.ldy + n) = o;
+            }
+        }
+    }
+}
+
+static int env_int2(const char* name, int dflt)
+{
+    const char* v = getenv(name);
+    return v ? atoi(v) : dflt;
+}
+
+template<int MH, int CG, int WK, int S, int PF, int ABL = 0>
+static int launch_dec32_one(const Dec32Params& p, dim3 grid, hipStream_t st)
+{
+    constexpr int stage = 2 * S * 32 * MH * 256;
+    constexpr int red   = WK * 32 * MH * CG * 128;
+    constexpr int lds   = stage > red ? stage : red;
+    static bool   attr_set[16] = {};
+    int           dev = 0;
+    (void)hipGetDevice(&dev);
+    if (!attr_set[dev & 15]) {
+        TM_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_dec32_kernel<MH, CG, WK, S, PF, ABL>,
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        attr_set[dev & 15] = true;
+    }
+    gemm_dec32_kernel<MH, CG, WK, S, PF, ABL><<<grid, CG * WK * 64, lds, st>>>(p);
+    TM_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+template<int MH>
+static int launch_dec32_shape(const Dec32Params& p, dim3 grid, int shape, hipStream_t st)
+{
+    switch (shape) {
+        case 0: {  // 4 column groups x 4 k-phases, one k-block per wave per stage, ring 2 / 4
+            const int pf = env_int2("TM_D32_PF", 2);  // (read per launch: tools/bench_gemm.py flips it)
+            if constexpr (MH == 2) {
+                switch (env_int2("TM_D32_ABL", 0)) {  // timing experiments
+                    case 1: return launch_dec32_one<MH, 4, 4, 4, 4, 1>(p, grid, st);
+                    case 2: return launch_dec32_one<MH, 4, 4, 4, 4, 2>(p, grid, st);
+                    case 4: return launch_dec32_one<MH, 4, 4, 4, 4, 4>(p, grid, st);
+                    case 8: return launch_dec32_one<MH, 4, 4, 4, 4, 8>(p, grid, st);
+                    case 16: return launch_dec32_one<MH, 4, 4, 4, 4, 16>(p, grid, st);
+                    case 7: return launch_dec32_one<MH, 4, 4, 4, 4, 7>(p, grid, st);
+                    case 15: return launch_dec32_one<MH, 4, 4, 4, 4, 15>(p, grid, st);
+                    case 31: return launch_dec32_one<MH, 4, 4, 4, 4, 31>(p, grid, st);
+                    default: break;
+                }
+            }
+            return pf <= 2 ? launch_dec32_one<MH, 4, 4, 4, 2>(p, grid, st) : launch_dec32_one<MH, 4, 4, 4, 4>(p, grid, st);
+        }
+        case 1:  // 8 column groups x 2 k-phases (256 columns per workgroup), two k-blocks per wave per stage
+            return launch_dec32_one<MH, 8, 2, 4, 4>(p, grid, st);
+        case 2:  // 8 waves: 4 column groups x 2 k-phases
+            return launch_dec32_one<MH, 4, 2, 4, 4>(p, grid, st);
+        case 3:  // 8 waves: 2 column groups x 4 k-phases (64 columns per workgroup)
+            return launch_dec32_one<MH, 2, 4, 4, 2>(p, grid, st);
+        default: break;
+    }
+    set_last_error("gemm_dec32: unknown shape");
+    return 1;
+}
+
+// shape -> (column groups, k-blocks per stage)
+static void dec32_shape_dims(int shape, int* cg, int* s)
+{
+    static const int cgs[4] = {4, 8, 4, 2};
+    *cg = cgs[shape & 3];
+    *s  = 4;
+}
+
+bool dec32_supported(const LinearWeight& w, int M)
+{
+    static const int on = env_int2("TM_GEMM_D32", 1);
+    return on && w.type == 0 && w.packed32 != nullptr && M >= 1 && M <= 64 && w.N % 32 == 0 && w.K % 128 == 0;
+}
+
+// Tiling for the decode GEMM: `shape` (see launch_dec32_shape) and the split-K count.  One workgroup per CU (128 KB of
+// LDS): take the widest split that keeps <= 256 workgroups and >= one stage (4 k-blocks) per slice.
+void dec32_pick(const LinearWeight& w, int M, int* shape_out, int* splits_out)
+{
+    const int ncg = w.N / 32;
+    const int KB  = w.K / 128;
+    int       shape = env_int2("TM_D32_SHAPE", -1);
+    if (shape < 0) {
+        shape = 0;
+    }
+    int cgn, S;
+    dec32_shape_dims(shape, &cgn, &S);
+    const int col_wgs = (ncg + cgn - 1) / cgn;
+    int       splits  = 1;
+    static const int min_kb = env_int2("TM_D32_MIN_KB", 4);
+    for (int s = 2; s <= 16; ++s) {  // the engine's slab workspace holds 16 splits
+        int per = (KB + s - 1) / s;
+        per     = (per + S - 1) / S * S;
+        const int eff = (KB + per - 1) / per;  // splits after rounding the slice to whole stages
+        if (eff != s) {
+            continue;
+        }
+        if (col_wgs * s <= 256 && per >= min_kb) {
+            splits = s;
+        }
+    }
+    splits      = env_int2("TM_D32_SPLITS", splits);
+    *shape_out  = shape;
+    *splits_out = splits < 1 ? 1 : (splits > KB ? KB : splits);
+}
+
+// y / slabs as launch_linear: *slabs_out = number of fp32 slabs written into `workspace` (1 = direct epilogue)
+int launch_linear_dec32(const LinearWeight& w, const half_t* x, int ldx, half_t* y, int ldy, int M, bool gated_silu, int shape,
+                        int splits, float* workspace, int* slabs_out, hipStream_t st)
+{
+    TM_REQUIRE(w.packed32 != nullptr && w.N % 32 == 0, "decode GEMM: P32 layout missing");
+    TM_REQUIRE(M >= 1 && M <= 64, "decode GEMM: 1 <= M <= 64");
+    TM_REQUIRE(ldx % 8 == 0, "x rows must be 16-byte aligned");
+    int cgn, S;
+    dec32_shape_dims(shape, &cgn, &S);
+    Dec32Params p{};
+    p.x       = x;
+    p.ldx     = ldx;
+    p.wp      = w.packed32;
+    p.y       = y;
+    p.ldy     = ldy;
+    p.partial = workspace;
+    p.M       = M;
+    p.N       = w.N;
+    p.K       = w.K;
+    p.KB      = w.K / 128;
+    p.ncg     = w.N / 32;
+    int per   = (p.KB + splits - 1) / splits;
+    per       = (per + S - 1) / S * S;
+    per       = per > p.KB ? p.KB : per;
+    splits    = (p.KB + per - 1) / per;
+    TM_REQUIRE(splits == 1 || workspace != nullptr, "split-K needs a workspace");
+    p.kb_per_split = per;
+    p.epilogue     = splits > 1 ? 2 : (gated_silu ? 1 : 0);
+    dim3      grid((p.ncg + cgn - 1) / cgn, splits, 1);
+    const int rc = M <= 32 ? launch_dec32_shape<1>(p, grid, shape, st) : launch_dec32_shape<2>(p, grid, shape, st);
+    if (rc) {
+        return rc;
+    }
+    if (slabs_out) {
+        *slabs_out = splits;
+    }
+    return 0;
+}
+
+}  // namespace tmk

@@ -165,8 +165,12 @@ void linear_weight_free(LinearWeight& w)
     if (w.sz) {
         (void)hipFree(w.sz);
     }
-    w.packed = nullptr;
-    w.sz     = nullptr;
+    if (w.packed32) {
+        (void)hipFree(w.packed32);
+    }
+    w.packed   = nullptr;
+    w.sz       = nullptr;
+    w.packed32 = nullptr;
 }
 
 int linear_weight_prepare_u4(LinearWeight& w, const int32_t* qweight, const half_t* scales, const half_t* zeros,
@@ -187,6 +191,13 @@ int linear_weight_prepare_u4(LinearWeight& w, const int32_t* qweight, const half
     const size_t ns = (size_t)(w.K / 128) * w.N;
     repack_sz_kernel<<<(ns + 255) / 256, 256, 0, st>>>(w.sz, scales, zeros, w.K / 128, w.N);
     TM_HIP_CHECK(hipGetLastError());
+    if (w.N % 32 == 0) {  // the decode kernel's layout (gemm_decode.hip)
+        w.packed32_bytes = p32_bytes(w.K, w.N);
+        if (!w.packed32) {
+            TM_HIP_CHECK(hipMalloc(&w.packed32, w.packed32_bytes));
+        }
+        return launch_repack_p32(w.packed32, qweight, scales, zeros, w.K, w.N, st);
+    }
     return 0;
 }
 
@@ -1400,6 +1411,19 @@ static int env_int(const char* name, int dflt)
 
 GemmConfig gemm_pick_config(const LinearWeight& w, int M)
 {
+    if (dec32_supported(w, M)) {  // decode batch: the weight-streaming kernel of gemm_decode.hip
+        GemmConfig cfg{};
+        dec32_pick(w, M, &cfg.d32_shape, &cfg.splits);
+        cfg.nt      = 2;
+        cfg.waves   = 16;
+        cfg.kphases = 1;
+        return cfg;
+    }
+    return gemm_pick_config_general(w, M);
+}
+
+GemmConfig gemm_pick_config_general(const LinearWeight& w, int M)
+{
     // Heuristic (measured on MI355X with tools/tune_gemm.py): the decode GEMMs are latency /
     // issue bound, so aim at ~256 workgroups of 8 waves.  TM_GEMM_NT / _SPLITS / _WAVES / _KPHASES override.
     GemmConfig cfg{};
@@ -1657,6 +1681,24 @@ int launch_linear(const LinearWeight& w,
     TM_REQUIRE(ldx % 8 == 0, "x rows must be 16-byte aligned");
     TM_REQUIRE(!gated_silu || w.N % 32 == 0, "gated epilogue needs N % 32 == 0");
     if (M == 0) {
+        return 0;
+    }
+    if (cfg.d32_shape >= 0 && dec32_supported(w, M)) {
+        int       nslab = 1;
+        const int sp    = workspace ? (cfg.splits < 1 ? 1 : cfg.splits) : 1;
+        TM_REQUIRE(!defer_reduce || sp > 1, "defer_reduce only with split-K");
+        const int rc = launch_linear_dec32(w, x, ldx, y, ldy, M, gated_silu, cfg.d32_shape, sp, workspace, &nslab, st);
+        if (rc) {
+            return rc;
+        }
+        if (nslab > 1 && !defer_reduce) {
+            const size_t total = (size_t)M * w.N / 4;
+            splitk_reduce_kernel<<<(total + 255) / 256, 256, 0, st>>>(y, ldy, workspace, nslab, M, w.N, gated_silu ? 1 : 0);
+            TM_HIP_CHECK(hipGetLastError());
+        }
+        if (slabs) {
+            *slabs = nslab;
+        }
         return 0;
     }
     int nt    = cfg.nt;

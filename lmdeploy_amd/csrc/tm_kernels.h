@@ -105,6 +105,10 @@ struct LinearWeight {
     void*     packed = nullptr;  // fragment-ordered weights
     uint32_t* sz     = nullptr;  // fragment-ordered (s, -z*s) half2 pairs (u4), (s, 0) (fp8)
     size_t    packed_bytes = 0, sz_bytes = 0;
+    // u4 only, N % 32 == 0: the decode kernel's layout (gemm_decode.hip, "P32": 2176-byte units of 32 columns x 128 k
+    // with their (s, -z*s) pairs); `packed` / `sz` stay the layout of the M > 64 kernels
+    void*     packed32 = nullptr;
+    size_t    packed32_bytes = 0;
 };
 struct GemmConfig {
     int nt;      // n-tiles (16 cols) per wave: 1,2,4
@@ -112,6 +116,7 @@ struct GemmConfig {
     int waves;   // waves per workgroup: 4 or 8
     int kphases; // split-K inside the workgroup: 1 or 2 (8 waves only)
     int kstage;  // max k-blocks per barrier (0 = auto: 4)
+    int d32_shape = -1;  // >= 0: the decode kernel of gemm_decode.hip with this workgroup shape (M <= 64, u4, N % 32 == 0)
 };
 // Load-time repack (reference: LinearWeight::prepare, models/linear_weight.cc:101-324)
 int    linear_weight_prepare_u4(LinearWeight& w, const int32_t* qweight /*[K][N/8]*/, const half_t* scales,
@@ -121,11 +126,20 @@ int    linear_weight_prepare_fp8(LinearWeight& w, const uint8_t* weight /*[K][N]
                                  bool gated_scales /* w1w3: scale row = [w1 blocks | w3 blocks] for interleaved columns */, hipStream_t st);
 void   linear_weight_free(LinearWeight& w);
 size_t gemm_workspace_bytes(int M, int N, int splits);
-GemmConfig gemm_pick_config(const LinearWeight& w, int M);
+GemmConfig gemm_pick_config(const LinearWeight& w, int M);          // decode kernel when it applies, else ...
+GemmConfig gemm_pick_config_general(const LinearWeight& w, int M);  // ... the tiling of gemm_kernel (gemm_w4a16.hip)
 // y[M][N (or N/2 if gated)] = x[M][K] . W ; if cfg.splits > 1 fp32 slabs land in `workspace` and, unless
 // `defer_reduce`, a reduce kernel writes y.
 int launch_linear(const LinearWeight& w, const half_t* x, int ldx, half_t* y, int ldy, int M, bool gated_silu,
                   GemmConfig cfg, float* workspace, bool defer_reduce, int* slabs, hipStream_t st);
+
+// ---- gemm_decode.hip: W4A16 decode GEMM (M <= 64), 32x32x16 MFMA, 16 waves per CU ------------------------------
+size_t p32_bytes(int K, int N);
+int    launch_repack_p32(void* out, const int32_t* qweight, const half_t* scales, const half_t* zeros, int K, int N, hipStream_t st);
+bool   dec32_supported(const LinearWeight& w, int M);
+void   dec32_pick(const LinearWeight& w, int M, int* shape_out, int* splits_out);
+int    launch_linear_dec32(const LinearWeight& w, const half_t* x, int ldx, half_t* y, int ldy, int M, bool gated_silu, int shape,
+                           int splits, float* workspace, int* slabs_out, hipStream_t st);
 
 // sampling.hip: temperature / top-k / top-p / min-p sampling without a sort (see the file header)
 size_t sample_workspace_bytes(int batch);

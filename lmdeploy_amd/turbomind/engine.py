@@ -134,6 +134,18 @@ class Engine:
         _ffi.check(self._lib.tm_engine_fetch_logits(self._h, out.ctypes.data))
         return out
 
+    def fetch_residual(self, rows: int) -> np.ndarray:
+        """parity tests: the residual stream of the last forward, fp16 [rows][hidden]"""
+        out = np.zeros((rows, self.cfg.model.hidden), np.float16)
+        _ffi.check(self._lib.tm_engine_debug_read(self._h, 0, rows, 0, out.ctypes.data, out.nbytes))
+        return out
+
+    def fetch_kv_block(self, seq: int, block: int) -> np.ndarray:
+        """parity tests: the bytes of KV block `block` of static-batch sequence `seq` (all layers)"""
+        out = np.zeros(self.stats()['kv_bytes_per_token'] * 64, np.uint8)
+        _ffi.check(self._lib.tm_engine_debug_read(self._h, 1, seq, block, out.ctypes.data, out.nbytes))
+        return out
+
     # ---- continuous batching (tm_engine_submit / step / poll / cancel) -----------------------------
     def submit(self, prompt: Sequence[int], max_new_tokens: int, eos_id: int = -1, sampling=None, logits=None) -> int:
         """Queue one request; returns its id.  eos_id < 0 = ignore_eos.  sampling = (temperature, top_k, top_p, min_p,

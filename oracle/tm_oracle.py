@@ -758,12 +758,9 @@ def _dense_weight(W, group):
 
 
 def _linear(x, W, group, gated=False):
-    if 'f8' in W:
-        acc = gemm_f16_f32acc(x, fp8_dequant(W['f8'], W['bs'], W.get('gated', False)))
-    elif 'q' in W:
-        acc = gemm_f16_f32acc(x, w4a16_dequant(W['q'], W['s'], W['z'], group))
-    else:
-        acc = gemm_f16_f32acc(x, W['w'])
+    if '_dense' not in W:      # dequantise once per weight (full-width parity tests re-use a layer for several forwards)
+        W['_dense'] = np.asarray(_dense_weight(W, group), f16).astype(f32)
+    acc = np.asarray(x, f16).astype(f32) @ W['_dense']
     return gated_silu_epilogue(acc) if gated else acc.astype(f16)
 
 
@@ -834,6 +831,7 @@ class OracleModel:
             nxt = self.w['layers'][li + 1]['attn_norm'] if li + 1 < cfg.layers else self.w['norm']
             resid, x = residual_rmsnorm(resid, d, nxt, cfg.rms_eps)
         last = np.array([offs[b + 1] - 1 for b in range(len(lens)) if lens[b] > 0])
+        self.last_resid = resid                                           # residual stream after the last layer [T, H]
         logits = lm_head(x[last], self.w['output'])
         for b, n in enumerate(lens):
             self.seq_len[b] += n

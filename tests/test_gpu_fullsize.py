@@ -1,0 +1,311 @@
+"""GPU parity at the FULL sizes of BASELINE.json's configurations ("parity stops at toy sizes"): every
+(K, N) of the Llama-3-8B / InternLM2-20B / Llama-3-70B-TP8 linears at the decode batch, decode attention at batch 64
+with ragged 1024..2047-token contexts (32-block tables), and one full-width decoder layer against the oracle model.
+Shapes follow the reference's linear test bed (tests/turbomind/linear/models.yaml:10-57) and its attention test
+(kernels/attention/test_attention.cu:70-141,611-630); tolerances are the ones of tests/test_gpu_ops.py.
+
+To keep the CPU side of these tests in seconds, quantised weights and cache contents are drawn directly as random codes +
+random (scale, zero) parameters -- every byte pattern is a legal state of the formats -- instead of being quantised from
+fp16 data by the (slow, pure-numpy) oracle quantisers; the dequantisation rules under test are unchanged."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from lmdeploy_amd import _ffi
+from oracle import tm_oracle as o
+from tests.gpu_helpers import DevCache, dev, host, st
+
+pytestmark = pytest.mark.gpu
+f16 = np.float16
+
+
+def _random_awq(rng, K, N):
+    """random u4 codes, fp16 scales ~ the magnitude of N(0, 0.1/sqrt(K)) weights, integer zero points (AWQ zeros are
+    integers 0..15 stored as fp16).  Returns (qweight int32 [K, N/8] boundary layout, scales, zeros, dequantised fp32)."""
+    q = rng.integers(0, 16, (K, N), dtype=np.uint8)
+    s = (rng.uniform(0.5, 1.5, (K // 128, N)) * (0.1 / math.sqrt(K)) * (6.0 / 15.0)).astype(f16)
+    z = rng.integers(4, 12, (K // 128, N)).astype(f16)
+    packed = (q[:, 0::2] | (q[:, 1::2] << 4)).astype(np.uint8).view('<i4')      # nibble j of word c = element 8c + j
+    # w = h(fma(h(q), s, h(-z*s))): q*s and h(-z*s) are multiples of ulp(s) below 32*s, so their fp32 sum is exact and
+    # the cast below is the single rounding of the fma (checked against the oracle's fp64 form in the test below)
+    zs = ((-z.astype(np.float32)) * s.astype(np.float32)).astype(f16).astype(np.float32)
+    wd = (q.reshape(K // 128, 128, N).astype(np.float32) * s.astype(np.float32)[:, None, :] + zs[:, None, :]).astype(f16)
+    return packed, s, z, wd.reshape(K, N).astype(np.float32), q
+
+
+def test_fast_dequant_equals_oracle():
+    rng = np.random.default_rng(0)
+    packed, s, z, wd, q = _random_awq(rng, 256, 64)
+    assert np.array_equal(o.unpack_u4_row(packed), q)
+    assert np.array_equal(wd.astype(f16).view(np.uint16), o.w4a16_dequant(q, s, z).view(np.uint16))
+
+
+_LIN = {}
+
+
+def _linear(tm, K, N):
+    if (K, N) not in _LIN:
+        rng = np.random.default_rng(K * 31 + N)
+        packed, s, z, wd, _ = _random_awq(rng, K, N)
+        h = _ffi.C.c_void_p()
+        _ffi.check(tm.tm_linear_create(_ffi.C.byref(h), K, N, 0, 128))
+        _ffi.check(tm.tm_linear_prepare(h, dev(packed).data_ptr(), dev(s).data_ptr(), dev(z).data_ptr(), st()))
+        torch.cuda.synchronize()
+        _LIN.clear()                       # one full-size weight resident at a time
+        _LIN[(K, N)] = (h, wd)
+    return _LIN[(K, N)]
+
+
+# (K, N, gated): Llama-3-8B w1w3 / w2 / wo / w_qkv, InternLM2-20B w1w3 / w2, Llama-3-70B per TP=8 rank w1w3 / w2 / wo
+FULL_SHAPES = [(4096, 28672, 1), (14336, 4096, 0), (4096, 4096, 0), (4096, 6144, 0), (6144, 32768, 1), (16384, 6144, 0),
+               (8192, 7168, 1), (3584, 8192, 0), (1024, 8192, 0)]
+
+
+@pytest.mark.parametrize('K,N,gated', FULL_SHAPES)
+@pytest.mark.parametrize('M', [64, 128])
+def test_w4a16_linear_full_size(tm, cuda, K, N, gated, M):
+    """heuristic tiling (what the engine and bench.py run: the decode kernel with its split count at M = 64, the general
+    kernel's two row blocks at M = 128), then every workgroup shape of the decode kernel with explicit split counts"""
+    h, wd = _linear(tm, K, N)
+    rng = np.random.default_rng(K + N + M)
+    x = rng.standard_normal((M, K)).astype(f16)
+    acc = x.astype(np.float32) @ wd
+    ref = (o.gated_silu_epilogue(acc) if gated else acc.astype(f16)).astype(np.float32)
+    tol = 2e-3 + 2.0**-9 * np.abs(ref)
+    ws = torch.zeros(max(1, tm.tm_linear_workspace(h, M)), dtype=torch.uint8, device='cuda')
+    x_d = dev(x)
+    cases = [(0, 0, 0)]
+    if M <= 64:
+        cases += [(0, sp, 0x200 | shape) for shape in range(4) for sp in (1, 2, 7)]
+    else:
+        cases += [(1, 2, 8), (2, 1, 8)]
+    for nt, splits, waves in cases:
+        y = torch.zeros((M, N // 2 if gated else N), dtype=torch.float16, device='cuda')
+        _ffi.check(tm.tm_linear_forward(h, x_d.data_ptr(), K, y.data_ptr(), y.shape[1], M, gated, nt, splits, waves,
+                                        ws.data_ptr(), st()))
+        err = np.abs(host(y).astype(np.float32) - ref)
+        assert np.all(err <= tol), f'nt={nt} splits={splits} waves={waves:#x}: max err {err.max()} at {np.argmax(err - tol)}'
+
+
+@pytest.mark.parametrize('K,N', [(4096, 28672), (14336, 4096)])
+def test_w4a16_linearity_full_size(tm, cuda, K, N):
+    """size-independent property at the headline shapes: the kernel is linear in x up to fp16 output rounding, and a
+    one-hot x returns the dequantised weight row bit for bit (the A = I check with an asymmetric B)."""
+    h, wd = _linear(tm, K, N)
+    M = 64
+    ws = torch.zeros(max(1, tm.tm_linear_workspace(h, M)), dtype=torch.uint8, device='cuda')
+    rng = np.random.default_rng(N)
+    rows = rng.integers(0, K, M)
+    x = np.zeros((M, K), f16)
+    x[np.arange(M), rows] = 1.0
+    y = torch.zeros((M, N), dtype=torch.float16, device='cuda')
+    _ffi.check(tm.tm_linear_forward(h, dev(x).data_ptr(), K, y.data_ptr(), N, M, 0, 0, 0, 0, ws.data_ptr(), st()))
+    assert np.array_equal(host(y).view(np.uint16), wd[rows].astype(f16).view(np.uint16)), 'one-hot rows must return W bit for bit'
+    a = rng.standard_normal((M, K)).astype(f16)
+    ya, y2a = torch.zeros_like(y), torch.zeros_like(y)
+    _ffi.check(tm.tm_linear_forward(h, dev(a).data_ptr(), K, ya.data_ptr(), N, M, 0, 0, 0, 0, ws.data_ptr(), st()))
+    _ffi.check(tm.tm_linear_forward(h, dev((2 * a).astype(f16)).data_ptr(), K, y2a.data_ptr(), N, M, 0, 0, 0, 0, ws.data_ptr(), st()))
+    assert np.array_equal((2 * host(ya)).astype(f16).view(np.uint16), host(y2a).view(np.uint16)), 'f(2x) == 2 f(x) exactly'
+
+
+# ------------------------------------------------------------------------------------------------
+def _random_cache(rng, L, klen):
+    """a pool whose blocks hold random codes and random (scale, zero) parameters, and shuffled block tables"""
+    nblk = [(k + 63) // 64 for k in klen]
+    total = sum(nblk) + 5
+    perm = rng.permutation(total)
+    tables, off = [], 0
+    for nb in nblk:
+        tables.append(perm[off:off + nb])
+        off += nb
+    oc = o.PagedKVCache(L, total)
+    if L.bits == 16:
+        oc.pool[:] = (rng.standard_normal(oc.pool.size // 2)).astype(f16).view(np.uint8).reshape(oc.pool.shape)
+        return oc, tables, total
+    oc.pool[:] = rng.integers(0, 256, oc.pool.shape, dtype=np.uint8)
+    data = L.kv_heads * 2 * L.head_data_size
+    npar = L.kv_heads * 2 * L.block_len
+    qmax = 255.0 if L.bits == 8 else 15.0
+    for layer in range(L.layers):
+        base = L.layer_offset(layer) + data
+        scale = rng.uniform(4.0, 8.0, (total, npar)) / qmax            # a row spans about [-3, 3] .. [-4, 4]
+        zero = -scale * qmax * rng.uniform(0.4, 0.6, (total, npar))
+        par = np.stack([scale, zero], -1).astype(f16)                 # (scale, zero) pairs, block.h:126-219
+        oc.pool[:, base:base + npar * 4] = par.view(np.uint8).reshape(total, npar * 4)
+    return oc, tables, total
+
+
+@pytest.mark.parametrize('bits', [8, 4])
+@pytest.mark.parametrize('Hq,Hkv', [(32, 8), (64, 8)])
+def test_decode_attention_batch64_ragged_1k_2k(tm, cuda, bits, Hq, Hkv):
+    """B = 64 sequences of 1024..2047 cached tokens (17..32 blocks per table, shuffled pool), the engine's split count and a
+    forced 4-way split, GQA 4 and 8.  The oracle checks the longest, the shortest and 10 random sequences in full."""
+    rng = np.random.default_rng(bits * 100 + Hq)
+    B, layer = 64, 1
+    klen = rng.integers(1024, 2048, B).tolist()
+    klen[0], klen[1] = 2047, 1024
+    L = o.BlockLayout(2, Hkv, 128, 64, bits)
+    oc, tables, total = _random_cache(rng, L, klen)
+    q = rng.standard_normal((B, Hq * 128)).astype(f16)
+    dc = DevCache(L, total, tables)
+    dc.upload(oc)
+    klen_d = dev(np.asarray(klen, np.int32))
+    check = [0, 1] + rng.choice(np.arange(2, B), 10, replace=False).tolist()
+    refs = {}
+    for b in check:
+        Ks, Vs = [], []
+        for hd in range(Hkv):
+            kd, vd = oc.load_dequant(tables[b], layer, hd, 0, klen[b], 'decode')
+            Ks.append(kd)
+            Vs.append(vd)
+        refs[b] = o.decode_attention(q[b].reshape(Hq, 128), np.stack(Ks), np.stack(Vs), None, 1).astype(np.float32)
+    outs = []
+    for splits in (1, 4):
+        out = torch.zeros((B, Hq * 128), dtype=torch.float16, device='cuda')
+        ws = torch.zeros(max(1, tm.tm_decode_attention_workspace(B, Hq, splits)), dtype=torch.uint8, device='cuda')
+        _ffi.check(tm.tm_decode_attention(out.data_ptr(), dev(q).data_ptr(), Hq * 128, klen_d.data_ptr(), B, Hq, 0.0, splits,
+                                          ws.data_ptr(), dc.view(layer), st()))
+        got = host(out).reshape(B, Hq, 128).astype(np.float32)
+        assert np.isfinite(got).all()
+        for b in check:
+            err = np.abs(got[b] - refs[b])
+            assert np.all(err <= 1e-2 * np.abs(refs[b]) + 2e-3), f'splits {splits} seq {b} (ctx {klen[b]}): max err {err.max()}'
+        outs.append(got)
+    # every sequence, not only the sampled ones: the two split counts are independent evaluations of the same softmax
+    assert np.abs(outs[0] - outs[1]).max() <= 4e-3
+
+
+def test_block_table_permutation_at_32_blocks(tm, cuda):
+    """test_attention.cu:70-141 at the headline geometry: 64 sequences x 32 blocks, int8 -- moving every block to another
+    place of the pool (and permuting the tables with it) must not change one output bit."""
+    rng = np.random.default_rng(11)
+    B, Hq, Hkv = 64, 32, 8
+    klen = [2048 - int(x) for x in rng.integers(0, 64, B)]
+    L = o.BlockLayout(1, Hkv, 128, 64, 8)
+    oc, tables, total = _random_cache(rng, L, klen)
+    q = dev(rng.standard_normal((B, Hq * 128)).astype(f16))
+    klen_d = dev(np.asarray(klen, np.int32))
+    outs = []
+    for trial in range(2):
+        if trial == 1:
+            perm = rng.permutation(total)
+            pool2 = np.zeros_like(oc.pool)
+            pool2[perm] = oc.pool
+            oc.pool = pool2
+            tables = [perm[t] for t in tables]
+        dc = DevCache(L, total, tables)
+        dc.upload(oc)
+        out = torch.zeros((B, Hq * 128), dtype=torch.float16, device='cuda')
+        _ffi.check(tm.tm_decode_attention(out.data_ptr(), q.data_ptr(), Hq * 128, klen_d.data_ptr(), B, Hq, 0.0, 1, None,
+                                          dc.view(0), st()))
+        outs.append(host(out).copy())
+    assert np.array_equal(outs[0].view(np.uint16), outs[1].view(np.uint16))
+
+
+def test_kv_round_trip_batch64_ctx2048(tm, cuda):
+    """size-independent property at full batch: ProcessKV (quantise + scatter, here 64 x 2048 tokens x 8 heads, int8) then
+    FlattenKV (gather + dequantise) returns every value within one quantisation step, and integer-valued rows on the
+    quantiser's grid return exactly (the reference's own round-trip test, test_quant.cu:32-70, at scale)."""
+    rng = np.random.default_rng(21)
+    B, n, Hq, Hkv = 64, 2048, 0, 8
+    L = o.BlockLayout(1, Hkv, 128, 64, 8)
+    nblk = n // 64
+    total = B * nblk
+    tables = [rng.permutation(total)[b * nblk:(b + 1) * nblk] for b in range(B)] if False else None
+    perm = rng.permutation(total)
+    tables = [perm[b * nblk:(b + 1) * nblk] for b in range(B)]
+    dc = DevCache(L, total, tables)
+    T = B * n
+    # integer-valued K rows spanning exactly [0, 255] (scale 1, zero 0 -> exact codes), gaussian V rows
+    kv = torch.empty((T, 2 * Hkv * 128), dtype=torch.float16, device='cuda')
+    g = torch.Generator(device='cuda').manual_seed(5)
+    kint = torch.randint(0, 256, (T, Hkv, 128), generator=g, device='cuda', dtype=torch.int32)
+    kint[:, :, 0] = 0
+    kint[:, :, 1] = 255
+    kv[:, :Hkv * 128] = kint.reshape(T, -1).to(torch.float16)
+    vv = torch.randn((T, Hkv * 128), generator=g, device='cuda', dtype=torch.float32)
+    kv[:, Hkv * 128:] = vv.to(torch.float16)
+    cu = torch.arange(0, T + 1, n, dtype=torch.int32, device='cuda')
+    klen = torch.full((B,), n, dtype=torch.int32, device='cuda')
+    _ffi.check(tm.tm_kv_rope_store(kv.data_ptr(), Hq, cu.data_ptr(), klen.data_ptr(), B, T, None, 0, dc.view(0), st()))
+    stride = B * n
+    kf = torch.zeros((Hkv, stride, 128), dtype=torch.float16, device='cuda')
+    vf = torch.zeros((Hkv, stride, 128), dtype=torch.float16, device='cuda')
+    cu_k = torch.arange(0, stride + 1, n, dtype=torch.int32, device='cuda')
+    _ffi.check(tm.tm_flatten_kv(kf.data_ptr(), vf.data_ptr(), 0, cu_k.data_ptr(), klen.data_ptr(), B, n, stride, dc.view(0), st()))
+    torch.cuda.synchronize()
+    k_back = kf.permute(1, 0, 2).reshape(T, Hkv * 128)
+    assert torch.equal(k_back, kv[:, :Hkv * 128]), 'integer rows on the quantiser grid must round-trip exactly'
+    v_src = kv[:, Hkv * 128:].float().reshape(T, Hkv, 128)
+    v_back = vf.permute(1, 0, 2).float()
+    step = (v_src.amax(-1) - v_src.amin(-1)) / 255.0
+    assert bool(((v_back - v_src).abs() <= 0.75 * step[..., None] + 2e-3).all())
+
+
+# ------------------------------------------------------------------------------------------------
+def test_full_width_layer_engine_vs_oracle(cuda):
+    """One decoder layer at the Llama-3-8B width (H = 4096, 32 q / 8 kv heads, inter 14336, int8 KV): prefill of 256 tokens
+    (three ragged prompts) + 4 decode steps through the C++ engine against the oracle model -- logits and greedy tokens
+    of every step, the RESIDUAL STREAM after the layer, and the KV-cache BYTES the engine wrote (codes within one step of
+    the oracle's, (scale, zero) within one fp16 ulp: the K/V inputs differ from the oracle's in the last fp32 bits of the
+    qkv GEMM's accumulation order, so the bit-exact contract of the quantiser itself is gated at operator level)."""
+    from lmdeploy_amd.turbomind.engine import Engine
+    from lmdeploy_amd.turbomind.loader import export_weights
+    from tests.gpu_helpers import ulp_diff_f16
+
+    cfg = o.ModelConfig(hidden=4096, layers=1, q_heads=32, kv_heads=8, head_dim=128, inter=14336, vocab=2048, kv_bits=8,
+                        rope=o.RopeParam(128, 500000.0, 'llama3', 8.0, 1.0, 4.0, 8192))
+    w = o.make_synthetic_weights(cfg, seed=7)
+    rng = np.random.default_rng(2)
+    lens = (100, 64, 92)
+    prompts = [rng.integers(0, cfg.vocab, n).astype(np.int32) for n in lens]
+    steps = 4
+    eng = Engine.from_model_config(cfg, max_batch_size=3, session_len=192, quant_policy=8, max_prefill_token_num=256, use_graph=1)
+    eng.load_weights(export_weights(cfg, w))
+    eng.start()
+    eng.prefill(prompts, max_new_tokens=steps + 1)
+    logits = [eng.fetch_logits()]
+    resid = [eng.fetch_residual(sum(lens))]
+    for _ in range(steps):
+        eng.decode(1)
+        logits.append(eng.fetch_logits())
+        resid.append(eng.fetch_residual(len(lens)))
+    toks = eng.fetch()
+    blocks = [[eng.fetch_kv_block(b, i) for i in range((lens[b] + steps + 63) // 64)] for b in range(len(lens))]
+    eng.close()
+
+    om = o.OracleModel(cfg, w, batch=len(prompts), max_ctx=192)
+    ids, lg = om.forward(prompts)
+    ref_logits, ref_toks, ref_resid = [lg], [ids], [om.last_resid]
+    cur = toks[:, 0]
+    for s in range(steps):
+        ids, lg = om.forward([[int(t)] for t in cur])
+        ref_logits.append(lg)
+        ref_toks.append(ids)
+        ref_resid.append(om.last_resid)
+        cur = toks[:, s + 1]
+    for s in range(steps + 1):
+        d = np.abs(logits[s].astype(np.float32) - ref_logits[s].astype(np.float32))
+        assert d.max() <= 3e-2, f'step {s}: max logit diff {d.max()}'
+        top2 = np.sort(ref_logits[s].astype(np.float32), -1)[:, -2:]
+        safe = (top2[:, 1] - top2[:, 0]) > 6e-2
+        assert np.array_equal(toks[safe, s], ref_toks[s][safe]), f'step {s}: greedy tokens differ'
+        r, rr = resid[s].astype(np.float32), ref_resid[s].astype(np.float32)
+        assert r.shape == rr.shape
+        assert np.all(np.abs(r - rr) <= 4e-3 + 2.0**-9 * np.abs(rr)), f'step {s}: residual stream max diff {np.abs(r - rr).max()}'
+    # KV bytes of layer 0: data region [Hkv][K,V][64][128] codes, then [Hkv][K,V][64] (scale, zero) fp16 pairs
+    L = om.layout
+    data = L.kv_heads * 2 * L.head_data_size
+    for b, n in enumerate(lens):
+        n_tok = n + steps
+        for i, got in enumerate(blocks[b]):
+            ref = om.cache.pool[om.tables[b][i]]
+            valid = min(64, n_tok - 64 * i)
+            gc = got[:data].reshape(L.kv_heads * 2, 64, 128)[:, :valid].astype(np.int32)
+            rc = ref[:data].reshape(L.kv_heads * 2, 64, 128)[:, :valid].astype(np.int32)
+            assert np.abs(gc - rc).max() <= 1 and (gc != rc).mean() < 0.03, f'seq {b} block {i}: codes differ ({(gc != rc).mean():.4f})'
+            gp = got[data:data + L.kv_heads * 2 * 256].view(np.float16).reshape(L.kv_heads * 2, 64, 2)[:, :valid]
+            rp = ref[data:data + L.kv_heads * 2 * 256].view(np.float16).reshape(L.kv_heads * 2, 64, 2)[:, :valid]
+            assert ulp_diff_f16(gp, rp).max() <= 1, f'seq {b} block {i}: (scale, zero) differ'
