@@ -90,6 +90,45 @@ def self_launch(n: int) -> int:
     return rc
 
 
+def measure_attention_traffic(args, ctx_prof):
+    """HBM bytes per launch of the decode-attention kernel, measured NOW: a child run of this script under
+    `rocprofv3 --pmc FETCH_SIZE` (its own pass, no tracing domains) with the same batch / KV format, two layers, eager
+    launches, and a prompt length that puts the mean context of its decode steps at `ctx_prof`.  FETCH_SIZE is corrected
+    as /opt/skills/guides/MI355X_MICROARCH.md (HBM section) prescribes for gfx950: KiB -> bytes, x 2 for wide coalesced
+    streaming reads.  Returns (bytes_per_launch | None, description)."""
+    import glob
+    import shutil
+    import sqlite3
+    import subprocess
+    import tempfile
+    prof = shutil.which('rocprofv3') or ('/opt/rocm/bin/rocprofv3' if os.path.exists('/opt/rocm/bin/rocprofv3') else None)
+    if prof is None:
+        return None, 'rocprofv3 not found'
+    steps, warm = 6, 1
+    s_child = max(64, int(round(ctx_prof - 1 - (warm + steps - 1) / 2.0)))
+    tmp = tempfile.mkdtemp(prefix='tm_pmc_', dir='/tmp')
+    cmd = [prof, '--pmc', 'FETCH_SIZE', '-d', tmp, '-o', 'pmc', '--', sys.executable, os.path.abspath(__file__), '--traffic-child',
+           '--steps', str(steps), '--warmup', str(warm), '--profile-steps', '0', '--no-cpu-baseline', '--no-graph', '--layers', '2',
+           '--batch', str(args.batch), '--prompt-len', str(s_child), '--quant-policy', str(args.quant_policy), '--model', args.model]
+    try:
+        subprocess.run(cmd, cwd='/tmp', env=dict(os.environ, TMPDIR='/tmp'), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
+                       timeout=300, check=True)
+        dbs = glob.glob(os.path.join(tmp, '**', '*_results.db'), recursive=True)
+        db = sqlite3.connect(dbs[0])
+        mean_kib, n = list(db.execute("select avg(value), count(*) from counters_collection where kernel_name like "
+                                      "'%decode_attention%' and counter_name = 'FETCH_SIZE'"))[0]
+        db.close()
+        if not n:
+            return None, 'no decode_attention dispatches in the PMC pass'
+        ctx_child = s_child + 1 + (warm + steps - 1) / 2.0
+        return int(mean_kib * 1024.0 * 2.0), (f'rocprofv3 --pmc FETCH_SIZE child run of this bench ({n} launches, 2 layers, eager, mean ctx '
+                                              f'{ctx_child}): mean FETCH_SIZE {mean_kib:.0f} KiB x 1024 x 2 (gfx950 correction)')
+    except Exception as e:   # noqa: BLE001 -- a failed profiler pass must not take the bench line down
+        return None, f'PMC pass failed: {type(e).__name__}'
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def main():
     # multi-process GPU work on this pool needs dmabuf IPC (RCCL's P2P setup fails with the legacy mode:
     # "hipIpcGetMemHandle: invalid argument"); already exported on the driver's boxes, kept here for hand launches
@@ -107,6 +146,9 @@ def main():
     ap.add_argument('--layers', type=int, default=0, help='debug only: override the layer count (result is then INVALID)')
     ap.add_argument('--model', default='llama3_8b', choices=['llama3_8b', 'internlm2_20b', 'llama3_70b', 'mixtral_8x7b'],
                     help='shapes to time; the headline metric is llama3_8b (anything else changes metric/config in the output)')
+    ap.add_argument('--no-traffic', action='store_true', help='skip the rocprofv3 --pmc FETCH_SIZE child run (roofline.traffic = null)')
+    ap.add_argument('--no-full-run', action='store_true', help='skip the continuation to 1024 generated tokens (value_full_run)')
+    ap.add_argument('--traffic-child', action='store_true', help=argparse.SUPPRESS)
     ap.add_argument('--emulate-tp', type=int, default=0,
                     help='SURVEY 8(e) on a 1-GPU box: run ONE rank\'s shard of a TP=N job (heads / inter / vocab divided by N, '
                          'collectives through a 1-rank RCCL communicator): per-rank kernel time only, labelled as such')
@@ -141,7 +183,9 @@ def main():
         os.environ['TM_FORCE_COMM'] = '1'      # the rank's collective code path, through a 1-rank communicator
     K, W, B, S = args.steps, args.warmup, args.batch, args.prompt_len
     P = args.profile_steps
-    max_new = 1 + W + K + P + 2
+    child = args.traffic_child
+    full_run = (not args.no_full_run) and not child and 1 + W + K < 1024     # continue to 1024 generated tokens after the timed region
+    max_new = max(1 + W + K + P + 2, (1024 + P + 2) if full_run else 0)
     weight_type = int(model.pop('weight_type', 0))
     eng = Engine.from_model_config(_Cfg(model), weight_type=weight_type, tp=world, rank=rank, device=local_rank, max_batch_size=B,
                                    session_len=S + max_new + 1, quant_policy=args.quant_policy,
@@ -190,6 +234,24 @@ def main():
     # ---- per-kernel durations: HIP events on the engine stream, eager steps right after the timed region ----
     prof = eng.profile_decode(P) if P > 0 else {}
     ctx_prof = S + 1 + W + K + (P - 1) / 2.0
+    # ---- the rest of the 1k-out window (64 x 1024 generated tokens, steady state without the first steps):
+    # the timed K steps sit at the CHEAP end of the run (shortest contexts), so also report the rate over everything
+    # from the first timed step to the 1024th generated token (the P eager profile steps advance the context but are
+    # not part of either time)
+    full = None
+    if full_run:
+        R = 1024 - (1 + W + K + P)
+        barrier()
+        t0 = time.perf_counter()
+        eng.decode(R)
+        barrier()
+        dt_r = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([dt_r], dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt_r = float(tt.item())
+        full = dict(value=round(B * (K + R) / (dt + dt_r), 1), steps=K + R, ctx_first=ctx_first, ctx_last=S + 1024,
+                    ms_per_step=round((dt + dt_r) / (K + R) * 1e3, 4))
     toks = eng.fetch()
     stats = eng.stats()
     if weight_type != 0 or model.get('moe_experts'):
@@ -227,16 +289,10 @@ def main():
             per_launch_bytes = B * ctx_prof * kv_tok / model['layers']      # one layer's KV of the whole batch
             per_launch_s = attn_ms / 1e3 / max(model['layers'], 1)          # attention (+ split-K merge) of one layer
             ach = per_launch_bytes / per_launch_s / 1e9
-            # HBM bytes per launch from the committed rocprofv3 FETCH_SIZE pass (tools/profile_bench.sh ->
-            # profiles/r01_attention_traffic.json; separate PMC run, scaled to this run's context length)
-            traffic, traffic_src = None, None
-            tj = os.path.join(ROOT, 'profiles', 'r01_attention_traffic.json')
-            if args.quant_policy == 8 and world == 1 and emu <= 1 and args.model == 'llama3_8b' and os.path.exists(tj):
-                with open(tj) as f:
-                    t = json.load(f)
-                traffic = int(t['traffic_over_algorithmic'] * per_launch_bytes)
-                traffic_src = (f"profiles/r01_attention_traffic.json: FETCH_SIZE pass at ctx {t['ctx_mean']}, "
-                               f"{t['traffic_over_algorithmic']:.3f} x algorithmic, scaled to ctx {ctx_prof}")
+            # HBM bytes per launch: measured in THIS run by a rocprofv3 --pmc FETCH_SIZE child pass (null if unavailable)
+            traffic, traffic_src = None, 'skipped'
+            if not args.no_traffic and not child and world == 1:
+                traffic, traffic_src = measure_attention_traffic(args, ctx_prof)
             out['roofline'] = {'bound': 'hbm', 'kernel': 'decode_attention_i8_mfma_kernel' if args.quant_policy == 8 else 'decode_attention_kernel',
                                'achieved': round(ach, 1), 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
                                'frac': round(ach / HBM_PEAK_GBPS, 4), 'traffic': traffic, 'traffic_source': traffic_src,
@@ -249,9 +305,14 @@ def main():
                                     'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
                                     'frac': round(wbytes / (gemm_ms / 1e3) / 1e9 / HBM_PEAK_GBPS, 4),
                                     'bytes_per_step': int(wbytes)}
-        if not args.no_cpu_baseline and world == 1:
+        if full is not None:
+            out['value_full_run'] = full
+            out['value_full_run']['step_roofline_frac'] = round(
+                algorithmic_bytes(model, B, (full['ctx_first'] + full['ctx_last']) / 2.0, kv_bits, world)[0] / (full['ms_per_step'] / 1e3) / 1e9
+                / HBM_PEAK_GBPS, 4) if weight_type == 0 and not model.get('moe_experts') else None
+        if not args.no_cpu_baseline and world == 1 and not child:
             from oracle import cpu_baseline
-            out['cpu_baseline'] = cpu_baseline.run(model, B, S, sample_layers=1)
+            out['cpu_baseline'] = cpu_baseline.run(model, B, S, sample_layers=2)
         out['sample_tokens'] = toks[0, :4].tolist()
         # RCCL prints a version banner through C stdio (fully buffered on a pipe): push it out first so that the JSON
         # line is the LAST line of stdout

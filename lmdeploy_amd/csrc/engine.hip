@@ -197,6 +197,14 @@ struct tm_engine {
 
     hipStream_t  stream = nullptr;
     ncclComm_t   comm   = nullptr;
+    // tensor-parallel collectives run on their own stream, forked from / joined to the engine stream by events (inside
+    // a hipGraph capture the pair becomes a parallel branch): while RCCL moves the partial sums over xGMI the engine
+    // stream pulls the NEXT linear's weights towards the Infinity Cache (weight_prefetch_kernel)
+    hipStream_t  comm_stream = nullptr;
+    hipEvent_t   ev_fork = nullptr, ev_join = nullptr;
+    bool         comm_overlap = true;    // TM_COMM_STREAM=0: collectives on the engine stream (round-1 behaviour)
+    bool         comm_prefetch = true;   // TM_COMM_PREFETCH=0: no weight prefetch under the collective
+    bool         graph_comm_failed = false;  // capturing the RCCL calls failed once: stay eager
     bool         use_comm = false;  // collectives on the data path: tp > 1 (or TM_FORCE_COMM=1: single-rank communicator,
                                     // exercises the RCCL code path on a 1-GPU box)
     std::map<std::string, Slot> slots;
@@ -418,12 +426,56 @@ static KvCacheView cache_view(const tm_engine* e, int layer)
     return v;
 }
 
-static int allreduce_hidden(tm_engine* e, half_t* buf, int M)
+// Touch the weights a following linear will stream (decode layout when M <= 64) so that they are on their way into the
+// 256 MB Infinity Cache / L2 while the collective is in flight; results are discarded.
+__global__ __launch_bounds__(256) void weight_prefetch_kernel(const u32x4* __restrict__ p, size_t n16)
 {
-    if (e->use_comm) {
-        TM_REQUIRE(e->comm != nullptr, "tm_engine_comm_init was not called");
-        TM_NCCL_CHECK(ncclAllReduce(buf, buf, (size_t)M * e->hidden, ncclHalf, ncclSum, e->comm, e->stream));
+    u32x4 a = {0u, 0u, 0u, 0u};
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) {
+        const u32x4 v = __builtin_nontemporal_load(p + i);
+        a ^= v;
     }
+    asm volatile("" ::"v"(a));
+}
+
+static int launch_weight_prefetch(const LinearWeight* w, int M, hipStream_t st)
+{
+    if (!w) {
+        return 0;
+    }
+    const void* p     = (M <= 64 && w->packed32) ? w->packed32 : w->packed;
+    size_t      bytes = (M <= 64 && w->packed32) ? w->packed32_bytes : w->packed_bytes;
+    bytes             = std::min(bytes, (size_t)64 << 20);
+    if (!p || bytes < 16) {
+        return 0;
+    }
+    const size_t n16 = bytes / 16;
+    const int    grid = (int)std::min<size_t>((n16 + 255) / 256, 512);
+    weight_prefetch_kernel<<<grid, 256, 0, st>>>((const u32x4*)p, n16);
+    TM_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// fp16 sum of the row-parallel partial outputs over the TP group (comm/nccl/nccl.cu:356-398 calls ncclAllReduce on the
+// compute stream; here it runs on the side stream, the engine stream meanwhile prefetches `next`'s weights)
+static int allreduce_hidden(tm_engine* e, half_t* buf, int M, const LinearWeight* next = nullptr)
+{
+    if (!e->use_comm) {
+        return 0;
+    }
+    TM_REQUIRE(e->comm != nullptr, "tm_engine_comm_init was not called");
+    if (!e->comm_overlap || !e->comm_stream) {
+        TM_NCCL_CHECK(ncclAllReduce(buf, buf, (size_t)M * e->hidden, ncclHalf, ncclSum, e->comm, e->stream));
+        return 0;
+    }
+    TM_HIP_CHECK(hipEventRecord(e->ev_fork, e->stream));
+    TM_HIP_CHECK(hipStreamWaitEvent(e->comm_stream, e->ev_fork, 0));
+    TM_NCCL_CHECK(ncclAllReduce(buf, buf, (size_t)M * e->hidden, ncclHalf, ncclSum, e->comm, e->comm_stream));
+    TM_HIP_CHECK(hipEventRecord(e->ev_join, e->comm_stream));
+    if (e->comm_prefetch) {
+        TM_TRY(launch_weight_prefetch(next, M, e->stream));
+    }
+    TM_HIP_CHECK(hipStreamWaitEvent(e->stream, e->ev_join, 0));
     return 0;
 }
 
@@ -455,7 +507,7 @@ static size_t prof_event(tm_engine* e)
 
 // row-parallel linear followed by (all-reduce +) residual + RMSNorm
 static int linear_residual_norm(tm_engine* e, LinearSlots& l, const half_t* x, int ldx, int M, const half_t* norm_w,
-                                int gemm_cat)
+                                int gemm_cat, const LinearWeight* next = nullptr)
 {
     GemmConfig cfg = gemm_pick_config(l.w, M);
     const bool can_defer = !e->use_comm && cfg.splits > 1
@@ -472,7 +524,7 @@ static int linear_residual_norm(tm_engine* e, LinearSlots& l, const half_t* x, i
         return 0;
     }
     TM_REQUIRE(!can_defer || slabs == 1, "internal: deferred reduce without slabs");
-    TM_PROF(P_ALLREDUCE, TM_TRY(allreduce_hidden(e, e->d_tmp, M)));
+    TM_PROF(P_ALLREDUCE, TM_TRY(allreduce_hidden(e, e->d_tmp, M, next)));
     TM_PROF(P_RES_NORM, TM_TRY(launch_residual_rmsnorm(e->d_x, e->d_resid, e->d_tmp, nullptr, 0, nullptr, norm_w,
                                                        e->cfg.model.rms_eps, M, e->hidden, e->stream)));
     return 0;
@@ -559,19 +611,20 @@ static int forward(tm_engine* e, const int* d_ids, int M, int nseq, bool decode,
             p.scale_log2 = scale_log2;
             TM_PROF(P_ATTN, TM_TRY(launch_prefill_attention(p, st)));
         }
-        TM_TRY(linear_residual_norm(e, L.wo, e->d_attn, e->q_heads * e->D, M, L.ffn_norm, P_GEMM_O));
-        const half_t* next_norm = li + 1 < m.layers ? e->layers[li + 1].attn_norm : e->final_norm;
+        TM_TRY(linear_residual_norm(e, L.wo, e->d_attn, e->q_heads * e->D, M, L.ffn_norm, P_GEMM_O, L.is_moe ? nullptr : &L.w13.w));
+        const half_t*       next_norm = li + 1 < m.layers ? e->layers[li + 1].attn_norm : e->final_norm;
+        const LinearWeight* next_lin  = li + 1 < m.layers ? &e->layers[li + 1].qkv.w : &e->output.w;
         if (L.is_moe) {
             // router + grouped expert FFNs + combine -> d_tmp, then (all-reduce +) residual + RMSNorm as for the dense FFN
             TM_PROF(P_GEMM_GATE_UP, TM_TRY(moe_forward(L.moe, e->d_tmp, e->hidden, e->d_x, e->hidden, M, e->d_moe_ws, nullptr,
                                                        nullptr, st)));
-            TM_PROF(P_ALLREDUCE, TM_TRY(allreduce_hidden(e, e->d_tmp, M)));
+            TM_PROF(P_ALLREDUCE, TM_TRY(allreduce_hidden(e, e->d_tmp, M, next_lin)));
             TM_PROF(P_RES_NORM, TM_TRY(launch_residual_rmsnorm(e->d_x, e->d_resid, e->d_tmp, nullptr, 0, nullptr, next_norm,
                                                                m.rms_eps, M, e->hidden, st)));
             continue;
         }
         TM_PROF(P_GEMM_GATE_UP, TM_TRY(linear_plain(e, L.w13, e->d_x, e->hidden, e->d_act, e->inter, M, true)));
-        TM_TRY(linear_residual_norm(e, L.w2, e->d_act, e->inter, M, next_norm, P_GEMM_DOWN));
+        TM_TRY(linear_residual_norm(e, L.w2, e->d_act, e->inter, M, next_norm, P_GEMM_DOWN, next_lin));
     }
     // last-token hidden states -> logits -> greedy
     const half_t* hx = e->d_x;
@@ -608,7 +661,17 @@ static int forward(tm_engine* e, const int* d_ids, int M, int nseq, bool decode,
                              e->cfg.rank * e->vocab_local, st));
         pack_candidates_kernel<<<(nseq + 63) / 64, 64, 0, st>>>(e->d_cand, ids, e->d_argmax_val, nseq);
         TM_HIP_CHECK(hipGetLastError());
-        TM_NCCL_CHECK(ncclAllGather(e->d_cand, e->d_cand_all, (size_t)nseq * 2, ncclFloat, e->comm, st));
+        // the same communicator is only ever driven from ONE stream (the side stream when it exists)
+        if (e->comm_overlap && e->comm_stream) {
+            TM_HIP_CHECK(hipEventRecord(e->ev_fork, st));
+            TM_HIP_CHECK(hipStreamWaitEvent(e->comm_stream, e->ev_fork, 0));
+            TM_NCCL_CHECK(ncclAllGather(e->d_cand, e->d_cand_all, (size_t)nseq * 2, ncclFloat, e->comm, e->comm_stream));
+            TM_HIP_CHECK(hipEventRecord(e->ev_join, e->comm_stream));
+            TM_HIP_CHECK(hipStreamWaitEvent(st, e->ev_join, 0));
+        }
+        else {
+            TM_NCCL_CHECK(ncclAllGather(e->d_cand, e->d_cand_all, (size_t)nseq * 2, ncclFloat, e->comm, st));
+        }
         pick_kernel<<<(nseq + 63) / 64, 64, 0, st>>>(ids, e->d_cand_all, e->cfg.tp, nseq);
         TM_HIP_CHECK(hipGetLastError());
     }
@@ -731,6 +794,15 @@ int tm_engine_comm_init(tm_engine* e, const void* host_id128)
     memcpy(&id, host_id128, sizeof(id));
     TM_HIP_CHECK(hipSetDevice(e->cfg.device));
     TM_NCCL_CHECK(ncclCommInitRank(&e->comm, e->cfg.tp, id, e->cfg.rank));
+    const char* cs   = getenv("TM_COMM_STREAM");
+    const char* cp   = getenv("TM_COMM_PREFETCH");
+    e->comm_overlap  = !(cs && !atoi(cs));
+    e->comm_prefetch = !(cp && !atoi(cp));
+    if (e->comm_overlap && !e->comm_stream) {
+        TM_HIP_CHECK(hipStreamCreateWithFlags(&e->comm_stream, hipStreamNonBlocking));
+        TM_HIP_CHECK(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
+        TM_HIP_CHECK(hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming));
+    }
     return 0;
 }
 
@@ -886,8 +958,8 @@ int tm_engine_process_weights(tm_engine* e)
                 }
                 L.moe.w13[x] = L.ex13[x].w;  // the MoE block owns the packed weights from here on
                 L.moe.w2[x]  = L.ex2[x].w;
-                L.ex13[x].w.packed = nullptr, L.ex13[x].w.sz = nullptr;
-                L.ex2[x].w.packed = nullptr, L.ex2[x].w.sz = nullptr;
+                L.ex13[x].w.packed = nullptr, L.ex13[x].w.sz = nullptr, L.ex13[x].w.packed32 = nullptr;
+                L.ex2[x].w.packed = nullptr, L.ex2[x].w.sz = nullptr, L.ex2[x].w.packed32 = nullptr;
             }
             Slot& g = e->slots[p + ".moe_ffn.gate.weight"];
             TM_REQUIRE(g.filled, "weight not loaded: " + p + ".moe_ffn.gate.weight");
@@ -1471,6 +1543,54 @@ int tm_engine_prefill(tm_engine* e, const int* host_ids, const int* host_lens, i
     return 0;
 }
 
+// hipGraph capture of one decode step.  Steps that contain RCCL calls (tp > 1) are captured too -- a TP = 8 step is
+// ~290 launches + 65 collectives, far too many for eager launches -- but defensively: if the capture or the instantiation
+// fails (RCCL build without graph support, ...) the engine falls back to eager steps for good instead of failing.
+static bool graph_enabled(const tm_engine* e)
+{
+    if (!e->cfg.use_graph) {
+        return false;
+    }
+    if (!e->use_comm) {
+        return true;
+    }
+    const char* gc = getenv("TM_GRAPH_COMM");  // default on; TM_GRAPH_COMM=0 keeps collectives out of graphs
+    return !(gc && !atoi(gc)) && !e->graph_comm_failed;
+}
+
+static int capture_step(tm_engine* e, int (*step)(tm_engine*), hipGraphExec_t* exec)
+{
+    *exec        = nullptr;
+    hipGraph_t g = nullptr;
+    hipError_t be = hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal);
+    int        rc = be == hipSuccess ? step(e) : 0;
+    hipError_t ce = be == hipSuccess ? hipStreamEndCapture(e->stream, &g) : be;
+    hipError_t ie = hipSuccess;
+    if (rc == 0 && ce == hipSuccess) {
+        ie = hipGraphInstantiate(exec, g, nullptr, nullptr, 0);
+    }
+    if (g) {
+        (void)hipGraphDestroy(g);
+    }
+    if (rc == 0 && ce == hipSuccess && ie == hipSuccess) {
+        return 0;
+    }
+    *exec = nullptr;
+    if (e->use_comm) {  // collectives inside: give up on graphs, keep running
+        (void)hipGetLastError();
+        e->graph_comm_failed = true;
+        fprintf(stderr, "[tm] hipGraph capture of the tensor-parallel decode step failed (rc %d, capture %s, instantiate %s): "
+                        "falling back to eager launches\n", rc, hipGetErrorString(ce), hipGetErrorString(ie));
+        return 0;
+    }
+    if (rc) {
+        return rc;
+    }
+    TM_HIP_CHECK(ce);
+    TM_HIP_CHECK(ie);
+    return 0;
+}
+
 int tm_engine_decode(tm_engine* e, int steps)
 {
     if (e && e->loop_on.load()) {
@@ -1484,10 +1604,7 @@ int tm_engine_decode(tm_engine* e, int steps)
         set_last_error("decode past max_new_tokens");
         return TM_TOO_LONG;
     }
-    // RCCL calls are kept out of graph capture unless TM_GRAPH_COMM=1 (untested on multi-GPU boxes)
-    const char* gc        = getenv("TM_GRAPH_COMM");
-    const bool  use_graph = e->cfg.use_graph && (!e->use_comm || (gc && atoi(gc)));
-    if (use_graph && !e->graph) {
+    if (graph_enabled(e) && !e->graph) {
         // run one eager step first (lazy module loading etc. must not happen inside a capture)
         if (steps == 0) {
             return 0;
@@ -1496,23 +1613,14 @@ int tm_engine_decode(tm_engine* e, int steps)
         TM_HIP_CHECK(hipStreamSynchronize(e->stream));
         e->steps_done += 1;
         steps -= 1;
-        hipGraph_t g = nullptr;
-        TM_HIP_CHECK(hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal));
-        int rc = decode_step(e);
-        hipError_t ce = hipStreamEndCapture(e->stream, &g);
-        if (rc) {
-            return rc;
-        }
-        TM_HIP_CHECK(ce);
-        TM_HIP_CHECK(hipGraphInstantiate(&e->graph, g, nullptr, nullptr, 0));
-        TM_HIP_CHECK(hipGraphDestroy(g));
+        TM_TRY(capture_step(e, decode_step, &e->graph));
         e->graph_batch    = e->batch;
         e->graph_max_new  = e->max_new;
         e->graph_sampling = e->sampling_on;
         e->graph_logits   = e->logits_on;
     }
     for (int i = 0; i < steps; ++i) {
-        if (use_graph) {
+        if (graph_enabled(e) && e->graph) {
             TM_HIP_CHECK(hipGraphLaunch(e->graph, e->stream));
         }
         else {
@@ -1636,29 +1744,18 @@ static int step_locked(tm_engine* e, int* n_active, int* n_waiting, std::vector<
     }
     // 2. one decode step for everything that is running
     if (e->sched->n_active() > 0) {
-        const char* gc        = getenv("TM_GRAPH_COMM");
-        const bool  use_graph = e->cfg.use_graph && (!e->use_comm || (gc && atoi(gc)));
         if (e->graph_cb && (e->graph_cb_sampling != e->sampling_on || e->graph_cb_logits != e->logits_on)) {
             (void)hipGraphExecDestroy(e->graph_cb);
             e->graph_cb = nullptr;
         }
-        if (use_graph && !e->graph_cb) {
+        if (graph_enabled(e) && !e->graph_cb) {
             TM_TRY(decode_step_cb(e));  // one eager step first (lazy module loading must not happen inside a capture)
             TM_HIP_CHECK(hipStreamSynchronize(e->stream));
-            hipGraph_t g = nullptr;
-            TM_HIP_CHECK(hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal));
-            const int  rc = decode_step_cb(e);
-            hipError_t ce = hipStreamEndCapture(e->stream, &g);
-            if (rc) {
-                return rc;
-            }
-            TM_HIP_CHECK(ce);
-            TM_HIP_CHECK(hipGraphInstantiate(&e->graph_cb, g, nullptr, nullptr, 0));
-            TM_HIP_CHECK(hipGraphDestroy(g));
+            TM_TRY(capture_step(e, decode_step_cb, &e->graph_cb));
             e->graph_cb_sampling = e->sampling_on;
             e->graph_cb_logits   = e->logits_on;
         }
-        else if (use_graph) {
+        else if (graph_enabled(e) && e->graph_cb) {
             TM_HIP_CHECK(hipGraphLaunch(e->graph_cb, e->stream));
         }
         else {
@@ -2048,6 +2145,11 @@ int tm_engine_destroy(tm_engine* e)
     }
     if (e->comm) {
         (void)ncclCommDestroy(e->comm);
+        if (e->comm_stream) {
+            (void)hipStreamDestroy(e->comm_stream);
+            (void)hipEventDestroy(e->ev_fork);
+            (void)hipEventDestroy(e->ev_join);
+        }
     }
     if (e->stream) {
         (void)hipStreamDestroy(e->stream);

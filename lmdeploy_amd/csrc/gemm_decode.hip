@@ -100,6 +100,8 @@ struct Dec32Params {
     int           M, N, K, KB, ncg;
     int           kb_per_split;
     int           epilogue;  // 0: fp16   1: gated SiLU fp16 (N/2 columns)   2: fp32 slab of split blockIdx.y
+    uint64_t*     dbg;       // optional [workgroups][8] s_memrealtime stamps (tm_debug_set_gemm_trace): start, loop, epilogue, end,
+                             // hw id, -, -, after the k-phase reduction barrier
 };
 
 __device__ __forceinline__ half8_t dequant8_p32(uint32_t w, half2_t s2, half2_t z2, uint32_t m1024, uint32_t m64)
@@ -131,6 +133,9 @@ __device__ __forceinline__ void static_for(F&& f)
 // MH: 32-row halves of the batch (1: M <= 32, 2: M <= 64).  CG x WK waves.  S k-blocks per LDS stage (S % WK == 0).
 // PF: ring depth in k-blocks per wave, a multiple of 2 * S / WK (the unrolled body covers PF / (S / WK) stages, an even
 // number, so that ring slots and the LDS buffer parity are compile-time constants).
+// ABL high bits select structure variants (results stay correct): 0x100 x staging by LDS-DMA (buffer_load ... lds, no
+// VGPR round trip, no ds_write: asynchronous, overlaps the stage's compute), 0x200 scheduling fence that keeps the LDS
+// fragment reads of step j+1 ahead of the MFMAs of step j, 0x400 s_setprio around the MFMAs.
 // ABL (timing experiments only, results are garbage): 1 no dequant, 2 no MFMA, 4 no LDS fragment reads, 8 no x staging,
 // 16 no weight loads inside the loop.
 template<int MH, int CG, int WK, int S, int PF, int ABL = 0>
@@ -152,6 +157,14 @@ __global__ __launch_bounds__(CG* WK * 64) void gemm_dec32_kernel(Dec32Params p)
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid  = threadIdx.x;
+    const int wgid = blockIdx.y * gridDim.x + blockIdx.x;
+    if (p.dbg && tid == 0) {
+        p.dbg[wgid * 8 + 0] = __builtin_amdgcn_s_memrealtime();
+        p.dbg[wgid * 8 + 4] = ((uint64_t)__builtin_amdgcn_s_getreg(20 | (31 << 11)) << 32) | (uint32_t)__builtin_amdgcn_s_getreg(4 | (31 << 11));
+    }
+    if constexpr (ABL & 32) {  // launch cost only
+        return;
+    }
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int cgl  = wave % CG;
@@ -201,6 +214,39 @@ __global__ __launch_bounds__(CG* WK * 64) void gemm_dec32_kernel(Dec32Params p)
     uint32_t m1024 = 0x64006400u, m64 = 0x54005400u;
     asm volatile("" : "+v"(m1024), "+v"(m64));  // magic numbers in VGPRs: one v_and_or_b32 per pair
 
+    // LDS-DMA staging: a stage image = S * ROWS / 4 pieces of 1 KiB (4 rows x 256 B), piece pc = r * WAVES + wave.  The
+    // DMA writes lane L to slot L of the piece (wave-linear), so the XOR swizzle sits on the SOURCE address: lane L
+    // fetches chunk (L & 15) ^ (row & 15) of row 4 pc + (L >> 4).
+    constexpr bool DMA = (ABL & 0x100) != 0;
+    constexpr int  NPC = S * ROWS / 4;
+    constexpr int  DR  = NPC / WAVES;
+    static_assert(!DMA || NPC % WAVES == 0, "DMA pieces per wave");
+    int            doff[DMA ? DR : 1];
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)smem);
+    if constexpr (DMA) {
+#pragma unroll
+        for (int r = 0; r < DR; ++r) {
+            const int pc  = r * WAVES + wave;
+            const int kbi = pc / (ROWS / 4);
+            const int row = (pc % (ROWS / 4)) * 4 + (lane >> 4);
+            const int ch  = (lane & 15) ^ (row & 15);
+            doff[r]       = (min(row, p.M - 1) * p.ldx + ch * 8) * 2 + kbi * 256;
+        }
+    }
+    // one DMA instruction per piece; M0 = LDS byte address of the piece (saved / restored: the compiler owns M0)
+#define D32_DMA_X(t, buf)                                                                                         \
+    _Pragma("unroll") for (int r = 0; r < DR; ++r)                                                                \
+    {                                                                                                             \
+        unsigned       keep_;                                                                                     \
+        const unsigned dst_ = lds0 + (buf)*STG + (r * WAVES + wave) * 1024;                                       \
+        const int      so_  = (kb0 + (t)*S) * 256;                                                                \
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"                                       \
+                     "buffer_load_dwordx4 %1, %2, %4 offen lds\n\ts_mov_b32 m0, %0"                               \
+                     : "=&s"(keep_)                                                                               \
+                     : "v"(doff[r]), "s"(rs_x), "s"(dst_), "s"(so_)                                               \
+                     : "memory");                                                                                 \
+    }
+
     // block `b` (relative to kb0) of this wave -> unit offset; blocks past the slice are clamped (their scales are zeroed)
 #define D32_LOAD_W(slot, b)                                                                                       \
     {                                                                                                             \
@@ -225,31 +271,57 @@ __global__ __launch_bounds__(CG* WK * 64) void gemm_dec32_kernel(Dec32Params p)
         // top of stage t (oldest first): weights of stage t .. t+UNR-2, x of stage t+1, weights of stage t+UNR-1.  The
         // prologue builds exactly that queue (hipcc merges the loop-entry edge and the back edge conservatively: a
         // prologue with fewer loads in flight than the steady state turns every wait of the loop into vmcnt(0)).
-        D32_LOAD_X(0);
-        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (DMA) {
+            // queue: x(0) DMA pieces, then the whole weight ring; the DMA is invisible to hipcc's waitcnt pass, so its
+            // completion is waited for by hand: everything older than the 3 * PF ring loads
+            D32_DMA_X(0, 0);
 #pragma unroll
-        for (int u = 0; u < UNR - 1; ++u) {
+            for (int q = 0; q < PF; ++q) {
+                D32_LOAD_W(q, (q / BPS) * S + wk + (q % BPS) * WK);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            asm volatile("s_waitcnt vmcnt(%0)" ::"i"(3 * PF) : "memory");
+        }
+        else {
+            D32_LOAD_X(0);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < UNR - 1; ++u) {
+#pragma unroll
+                for (int i = 0; i < BPS; ++i) {
+                    D32_LOAD_W(u * BPS + i, u * S + wk + i * WK);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            D32_STORE_X(0);
+            __builtin_amdgcn_sched_barrier(0);
+            D32_LOAD_X(1);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < BPS; ++i) {
-                D32_LOAD_W(u * BPS + i, u * S + wk + i * WK);
+                D32_LOAD_W((UNR - 1) * BPS + i, (UNR - 1) * S + wk + i * WK);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-        D32_STORE_X(0);
-        __builtin_amdgcn_sched_barrier(0);
-        D32_LOAD_X(1);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int i = 0; i < BPS; ++i) {
-            D32_LOAD_W((UNR - 1) * BPS + i, (UNR - 1) * S + wk + i * WK);
-            __builtin_amdgcn_sched_barrier(0);
-        }
         __syncthreads();
+        if (p.dbg && tid == 0) {
+            p.dbg[wgid * 8 + 1] = __builtin_amdgcn_s_memrealtime();
+        }
 
         // one stage = compute on buffer (u & 1) with ring slots u*BPS.. , then staging + refills, then the barrier
         auto stage = [&](auto U, const int t) __attribute__((always_inline)) {
             constexpr int u = decltype(U)::value;
             const int buf = u & 1;  // UNR is even: parity of t
+            if constexpr (DMA && !(ABL & 8)) {
+                // First make hipcc wait for this stage's ring slots HERE (their first use), then start the DMA of stage
+                // t+1 into the other buffer: the waitcnt pass does not see the DMA, so any of its counted waits that came
+                // after these instructions would also wait for them.  The DMA lands while the stage computes.
+#pragma unroll
+                for (int i = 0; i < BPS; ++i) {
+                    asm volatile("" ::"v"(ring[u * BPS + i][0]), "v"(ring[u * BPS + i][1]), "v"(sring[u * BPS + i]));
+                }
+                D32_DMA_X(t + 1, buf ^ 1);
+            }
 #pragma unroll
             for (int i = 0; i < BPS; ++i) {
                 const int     slot = u * BPS + i;
@@ -281,6 +353,12 @@ __global__ __launch_bounds__(CG* WK * 64) void gemm_dec32_kernel(Dec32Params p)
                         for (int h = 0; h < MH; ++h) {
                             bn[h] = (ABL & 4) ? bit_cast<half8_t>(ring[slot][0]) : *(const half8_t*)(xb + h * 8192 + coff[j + 1]);
                         }
+                        if constexpr (ABL & 0x200) {
+                            __builtin_amdgcn_sched_barrier(0x7f);  // everything but DS instructions may cross
+                        }
+                    }
+                    if constexpr (ABL & 0x400) {
+                        __builtin_amdgcn_s_setprio(1);
                     }
 #pragma unroll
                     for (int h = 0; h < MH; ++h) {
@@ -291,6 +369,9 @@ __global__ __launch_bounds__(CG* WK * 64) void gemm_dec32_kernel(Dec32Params p)
                         else {
                             acc[h] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bq[h], acc[h], 0, 0, 0);
                         }
+                    }
+                    if constexpr (ABL & 0x400) {
+                        __builtin_amdgcn_s_setprio(0);
                     }
                     if (j + 1 < 8) {
 #pragma unroll
@@ -305,7 +386,7 @@ __global__ __launch_bounds__(CG* WK * 64) void gemm_dec32_kernel(Dec32Params p)
             // stage the x descriptor returns zeros / the weight unit is clamped and nobody reads the result, while a
             // branch around a load makes the waitcnt pass assume the not-taken path (every later counted wait then
             // over-waits by the skipped loads).
-            if constexpr (!(ABL & 8)) {
+            if constexpr (!DMA && !(ABL & 8)) {
                 D32_STORE_X(buf ^ 1);
                 D32_LOAD_X(t + 2);
             }
@@ -314,6 +395,10 @@ __global__ __launch_bounds__(CG* WK * 64) void gemm_dec32_kernel(Dec32Params p)
                 for (int i = 0; i < BPS; ++i) {
                     D32_LOAD_W(u * BPS + i, (t + UNR) * S + wk + i * WK);
                 }
+            }
+            if constexpr (DMA && !(ABL & 8)) {
+                // my DMA pieces of stage t+1 have landed when at most the 3 * BPS refills issued after them are in flight
+                asm volatile("s_waitcnt vmcnt(%0)" ::"i"((ABL & 16) ? 0 : 3 * BPS) : "memory");
             }
             __syncthreads();
         };
@@ -330,10 +415,20 @@ __global__ __launch_bounds__(CG* WK * 64) void gemm_dec32_kernel(Dec32Params p)
             }
         });
     }
+#undef D32_DMA_X
 #undef D32_LOAD_W
 #undef D32_LOAD_X
 #undef D32_STORE_X
 
+    if (p.dbg && tid == 0) {
+        p.dbg[wgid * 8 + 2] = __builtin_amdgcn_s_memrealtime();
+    }
+    if constexpr (ABL & 64) {  // no epilogue
+        if (acc[0][0] == 12345.f) {
+            p.y[tid] = (half_t)acc[0][1];
+        }
+        return;
+    }
     // ---- the WK k-phase partial tiles meet in LDS: red[wk][row][c4 ^ (row & 7)] (floatx4 units, CG*8 per row) --------
     // lane holds, per half h and register r: row m = 32h + (l & 31), column 32 cgl + 8 (r >> 2) + 4 (l >> 5) + (r & 3)
     {
@@ -350,6 +445,9 @@ __global__ __launch_bounds__(CG* WK * 64) void gemm_dec32_kernel(Dec32Params p)
             }
         }
         __syncthreads();
+        if (p.dbg && tid == 0) {
+            p.dbg[wgid * 8 + 7] = __builtin_amdgcn_s_memrealtime();
+        }
         constexpr int NE = ROWS * C4;  // floatx4 elements of the output tile
         const int     ncol0 = blockIdx.x * CG * 32;
 #pragma unroll
@@ -384,6 +482,10 @@ __global__ __launch_bounds__(CG* WK * 64) void gemm_dec32_kernel(Dec32Params p)
             }
         }
     }
+    if (p.dbg && tid == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        p.dbg[wgid * 8 + 3] = __builtin_amdgcn_s_memrealtime();
+    }
 }
 
 static int env_int2(const char* name, int dflt)
@@ -411,33 +513,40 @@ static int launch_dec32_one(const Dec32Params& p, dim3 grid, hipStream_t st)
     return 0;
 }
 
+// D = the default structure: LDS-DMA staging of x (measured on MI355X, tools/trace_dec32.py: the w1w3 main loop
+// 16.5 -> 15.3 us against register staging + ds_write; the LDS-read fence and s_setprio variants measured neutral)
+constexpr int kD32Mode = 0x100;
+
 template<int MH>
 static int launch_dec32_shape(const Dec32Params& p, dim3 grid, int shape, hipStream_t st)
 {
+    const int abl = env_int2("TM_D32_ABL", -1);  // timing / structure experiments (tools/trace_dec32.py, tools/bench_gemm.py)
     switch (shape) {
-        case 0: {  // 4 column groups x 4 k-phases, one k-block per wave per stage, ring 2 / 4
-            const int pf = env_int2("TM_D32_PF", 2);  // (read per launch: tools/bench_gemm.py flips it)
+        case 0: {  // 16 waves: 4 column groups x 4 k-phases, one k-block per wave per stage
             if constexpr (MH == 2) {
-                switch (env_int2("TM_D32_ABL", 0)) {  // timing experiments
-                    case 1: return launch_dec32_one<MH, 4, 4, 4, 4, 1>(p, grid, st);
-                    case 2: return launch_dec32_one<MH, 4, 4, 4, 4, 2>(p, grid, st);
-                    case 4: return launch_dec32_one<MH, 4, 4, 4, 4, 4>(p, grid, st);
-                    case 8: return launch_dec32_one<MH, 4, 4, 4, 4, 8>(p, grid, st);
-                    case 16: return launch_dec32_one<MH, 4, 4, 4, 4, 16>(p, grid, st);
-                    case 7: return launch_dec32_one<MH, 4, 4, 4, 4, 7>(p, grid, st);
-                    case 15: return launch_dec32_one<MH, 4, 4, 4, 4, 15>(p, grid, st);
-                    case 31: return launch_dec32_one<MH, 4, 4, 4, 4, 31>(p, grid, st);
+                switch (abl) {
+#define D32_CASE(v) case v: return launch_dec32_one<MH, 4, 4, 4, 2, v>(p, grid, st)
+                    D32_CASE(0); D32_CASE(0x200); D32_CASE(0x300); D32_CASE(0x400); D32_CASE(0x500); D32_CASE(0x700);
+                    D32_CASE(1); D32_CASE(2); D32_CASE(4); D32_CASE(8); D32_CASE(16); D32_CASE(7); D32_CASE(15); D32_CASE(31);
+                    D32_CASE(32); D32_CASE(64); D32_CASE(95); D32_CASE(24); D32_CASE(25); D32_CASE(26); D32_CASE(27);
+                    D32_CASE(28); D32_CASE(29); D32_CASE(30); D32_CASE(0x107); D32_CASE(0x118); D32_CASE(0x11f);
+#undef D32_CASE
                     default: break;
                 }
+                if (env_int2("TM_D32_PF", 2) >= 4) {
+                    return launch_dec32_one<MH, 4, 4, 4, 4, kD32Mode>(p, grid, st);
+                }
             }
-            return pf <= 2 ? launch_dec32_one<MH, 4, 4, 4, 2>(p, grid, st) : launch_dec32_one<MH, 4, 4, 4, 4>(p, grid, st);
+            return launch_dec32_one<MH, 4, 4, 4, 2, kD32Mode>(p, grid, st);
         }
-        case 1:  // 8 column groups x 2 k-phases (256 columns per workgroup), two k-blocks per wave per stage
-            return launch_dec32_one<MH, 8, 2, 4, 4>(p, grid, st);
+        case 1:  // 16 waves: 8 column groups x 2 k-phases (256 columns per workgroup), two k-blocks per wave per stage
+            return launch_dec32_one<MH, 8, 2, 4, 4, kD32Mode>(p, grid, st);
         case 2:  // 8 waves: 4 column groups x 2 k-phases
-            return launch_dec32_one<MH, 4, 2, 4, 4>(p, grid, st);
+            if (abl == 32) return launch_dec32_one<MH, 4, 2, 4, 4, 32>(p, grid, st);
+            if (abl == 0) return launch_dec32_one<MH, 4, 2, 4, 4, 0>(p, grid, st);
+            return launch_dec32_one<MH, 4, 2, 4, 4, kD32Mode>(p, grid, st);
         case 3:  // 8 waves: 2 column groups x 4 k-phases (64 columns per workgroup)
-            return launch_dec32_one<MH, 2, 4, 4, 2>(p, grid, st);
+            return launch_dec32_one<MH, 2, 4, 4, 2, kD32Mode>(p, grid, st);
         default: break;
     }
     set_last_error("gemm_dec32: unknown shape");
@@ -517,6 +626,7 @@ int launch_linear_dec32(const LinearWeight& w, const half_t* x, int ldx, half_t*
     TM_REQUIRE(splits == 1 || workspace != nullptr, "split-K needs a workspace");
     p.kb_per_split = per;
     p.epilogue     = splits > 1 ? 2 : (gated_silu ? 1 : 0);
+    p.dbg          = g_gemm_dbg;
     dim3      grid((p.ncg + cgn - 1) / cgn, splits, 1);
     const int rc = M <= 32 ? launch_dec32_shape<1>(p, grid, shape, st) : launch_dec32_shape<2>(p, grid, shape, st);
     if (rc) {

@@ -10,7 +10,9 @@ reference PyTorchEngine's pure-torch "default" op backend, restated from:
   * attention: torch.nn.functional.scaled_dot_product_attention over a contiguous (dequantised int8) KV cache --
     the default backend has no attention op.
 It times a BOUNDED sample of the bench workload (same model shapes, same batch, same context): `sample_layers`
-decoder layers + lm_head for one decode step, and extrapolates to the full layer count.
+decoder layers + lm_head for one decode step -- one untimed warm-up pass, then up to `passes` timed passes (fewer when
+`budget_s` seconds of timed work are used up; at least one), median per-layer time -- and extrapolates to the full
+layer count.  tests/test_oracle.py pins _awq_linear / _rmsnorm on the reference-generated golden vectors.
 """
 from __future__ import annotations
 
@@ -44,7 +46,8 @@ def _rope(x, cos, sin):
     return torch.cat([x1 * cos - x2 * sin, x2 * cos + x1 * sin], -1)
 
 
-def run(model: dict, batch: int, ctx: int, sample_layers: int = 1, seed: int = 0, threads: int | None = None) -> dict:
+def run(model: dict, batch: int, ctx: int, sample_layers: int = 2, seed: int = 0, threads: int | None = None,
+        passes: int = 3, budget_s: float = 25.0) -> dict:
     threads = threads or os.cpu_count() or 1
     torch.set_num_threads(threads)
     g = torch.Generator().manual_seed(seed)
@@ -94,16 +97,25 @@ def run(model: dict, batch: int, ctx: int, sample_layers: int = 1, seed: int = 0
         return x, resid
 
     with torch.no_grad():
-        t0 = time.perf_counter()
-        for L in layers:
-            x, resid = layer_fwd(L, x, resid)
-        t_layers = time.perf_counter() - t0
-        t0 = time.perf_counter()
-        logits = (x.float() @ w_out.float())
-        logits.argmax(-1)
-        t_head = time.perf_counter() - t0
-    step_s = t_layers / sample_layers * model['layers'] + t_head
+        layer_fwd(layers[0], x, resid)                       # warm-up: allocator, thread pool, page faults
+        (x.float() @ w_out.float()).argmax(-1)
+        per_layer, per_head = [], []
+        t_begin = time.perf_counter()
+        for _ in range(max(1, passes)):
+            xx, rr = x, resid
+            t0 = time.perf_counter()
+            for L in layers:
+                xx, rr = layer_fwd(L, xx, rr)
+            per_layer.append((time.perf_counter() - t0) / sample_layers)
+            t0 = time.perf_counter()
+            (xx.float() @ w_out.float()).argmax(-1)
+            per_head.append(time.perf_counter() - t0)
+            if time.perf_counter() - t_begin > budget_s:
+                break
+    t_layer = sorted(per_layer)[len(per_layer) // 2]
+    t_head = sorted(per_head)[len(per_head) // 2]
+    step_s = t_layer * model['layers'] + t_head
     return dict(value=batch / step_s, unit='tokens/s', cores=threads, kind='port',
                 sample=(f'{sample_layers} of {model["layers"]} decoder layers + lm_head, one decode step, batch {batch}, '
-                        f'ctx {ctx}, int8 KV; fp32 contraction on CPU; extrapolated to {model["layers"]} layers '
-                        f'({t_layers:.2f}s layers + {t_head:.2f}s head measured)'))
+                        f'ctx {ctx}, int8 KV; 1 warm-up + {len(per_layer)} timed passes (median {t_layer:.2f} s / layer, '
+                        f'{t_head:.2f} s head); fp32 contraction on CPU; extrapolated to {model["layers"]} layers'))

@@ -471,6 +471,28 @@ def test_w4a16_alternative_decode_kernels(tm, cuda, monkeypatch, K, N, M, gated,
     _ffi.check(tm.tm_linear_destroy(h))
 
 
+@pytest.mark.parametrize('K,N,M,gated', [(4096, 6144, 64, 0), (1792, 4096, 33, 0), (256, 64, 40, 0), (4096, 1024, 64, 1), (1024, 2048, 50, 1)])
+@pytest.mark.parametrize('mode', [0, 0x200, 0x300, 0x400, 0x500, 0x700])
+def test_w4a16_decode_kernel_modes(tm, cuda, monkeypatch, K, N, M, gated, mode):
+    """Structure variants of the decode kernel (gemm_decode.hip): register staging + ds_write of the activations (0; the
+    default is LDS-DMA, 0x100), the LDS read scheduling fence (0x200), s_setprio around the MFMAs (0x400) and their
+    combinations -- same oracle, same tolerance."""
+    monkeypatch.setenv('TM_D32_ABL', str(mode))
+    rng = np.random.default_rng(K + N + M + mode)
+    h, (q, s, z) = _make_linear(tm, rng, K, N)
+    x = rng.standard_normal((M, K)).astype(f16)
+    ref = (o.w4a16_linear_gated_silu(x, q, s, z) if gated else x.astype(np.float32) @ _QCACHE[(K, N)][3]).astype(np.float32)
+    ws = torch.zeros(max(1, tm.tm_linear_workspace(h, M)), dtype=torch.uint8, device='cuda')
+    for splits in (1, 2, 3):
+        if splits > max(1, K // 512):
+            continue
+        y = torch.zeros((M, N // 2 if gated else N), dtype=torch.float16, device='cuda')
+        _ffi.check(tm.tm_linear_forward(h, dev(x).data_ptr(), K, y.data_ptr(), y.shape[1], M, gated, 0, splits, 0x200, ws.data_ptr(), st()))
+        err = np.abs(host(y).astype(np.float32) - ref)
+        assert np.all(err <= 2e-3 + 2.0**-9 * np.abs(ref)), f'mode {mode:#x} splits={splits}: max err {err.max()}'
+    _ffi.check(tm.tm_linear_destroy(h))
+
+
 @pytest.mark.parametrize('K,N,M', [(4096, 1024, 64), (512, 256, 5), (1024, 2048, 130)])
 def test_w4a16_gated_silu(tm, cuda, K, N, M):
     rng = np.random.default_rng(K + N + M + 1)

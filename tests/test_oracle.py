@@ -371,3 +371,27 @@ def test_sampling_filters_match_reference_python():
         kept = g['samp_kept'][b]
         assert ids.tolist() == g['samp_order'][b][kept].tolist(), b
         assert np.allclose(p, g['samp_probs'][b][kept], rtol=1e-4, atol=1e-7), b
+
+
+def test_cpu_baseline_port_matches_reference_golden_vectors():
+    """bench.py's `cpu_baseline` leg is a torch-CPU port of the reference PyTorchEngine's default-backend ops
+    (oracle/cpu_baseline.py); its building blocks must reproduce the vectors generated from the reference itself."""
+    import torch
+    from oracle import cpu_baseline as cb
+    q = torch.from_numpy(GOLD['awq_unpacked'].copy())
+    s = torch.from_numpy(GOLD['awq_scales'].copy())
+    z = torch.from_numpy(GOLD['awq_zeros_unpacked'].astype(f16))
+    x = torch.from_numpy(GOLD['awq_x'].copy())
+    y = cb._awq_linear(x, q, s, z, 128).numpy()
+    ref = GOLD['awq_y_fp32'].astype(f16)                       # x @ ((q - z) * s) in fp32, cast once
+    assert np.array_equal(y.view(np.uint16), ref.view(np.uint16))
+    yn, _ = cb._rmsnorm(torch.from_numpy(GOLD['norm_x'].copy()), torch.from_numpy(GOLD['norm_w'].copy()), 1e-5)
+    assert np.array_equal(yn.numpy().view(np.uint16), GOLD['norm_y'].view(np.uint16))
+    yr, rr = cb._rmsnorm(torch.from_numpy(GOLD['norm_x'].copy()), torch.from_numpy(GOLD['norm_w'].copy()), 1e-5,
+                         torch.from_numpy(GOLD['norm_res'].copy()))
+    assert np.array_equal(rr.numpy().view(np.uint16), GOLD['norm_res_out'].view(np.uint16))
+    assert np.array_equal(yr.numpy().view(np.uint16), GOLD['norm_y_res'].view(np.uint16))
+    # and the whole baseline runs (tiny shapes, one pass): a number comes out, the sample is described
+    tiny = dict(hidden=256, layers=2, q_heads=2, kv_heads=1, head_dim=128, inter=256, vocab=512)
+    r = cb.run(tiny, batch=2, ctx=65, sample_layers=2, passes=2, threads=2)
+    assert r['value'] > 0 and r['kind'] == 'port' and '2 of 2 decoder layers' in r['sample'] and 'warm-up' in r['sample']

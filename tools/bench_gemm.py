@@ -25,9 +25,11 @@ def main():
     ap.add_argument('--m', type=int, default=64)
     ap.add_argument('--reps', type=int, default=20)
     ap.add_argument('--only', default='')
-    ap.add_argument('--variants', default='old,d0,d0pf4,d1,d2,d3')
+    ap.add_argument('--variants', default='d0,d0pf4,d1,d2,d3')
     ap.add_argument('--splits', default='0', help='comma list of split counts to try for the d* variants (0 = heuristic)')
     ap.add_argument('--json', default='')
+    ap.add_argument('--same', action='store_true', help='every launch of a graph uses the SAME weight: Infinity-Cache-resident after the first replay')
+    ap.add_argument('--abl-shape', type=int, default=0)
     args = ap.parse_args()
     tm = _ffi.load()
     C = _ffi.C
@@ -65,7 +67,7 @@ def main():
                 if 'pf4' in variant:
                     env['TM_D32_PF'] = '4'
             elif variant.startswith('abl'):
-                waves = 0x200
+                waves = 0x200 | args.abl_shape
                 env['TM_D32_ABL'] = variant[3:]
             for k, v in env.items():
                 os.environ[k] = v
@@ -79,7 +81,7 @@ def main():
             with torch.cuda.graph(graph):
                 st = torch.cuda.current_stream().cuda_stream
                 for h in handles:
-                    launch(h, st)
+                    launch(handles[0] if args.same else h, st)
             for k in env:
                 del os.environ[k]
             graph.replay()
