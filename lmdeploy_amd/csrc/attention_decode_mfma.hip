@@ -9,9 +9,12 @@
 // the per-element dequantisation disappears algebraically: with (s_t, z_t) the per-token scale / zero,
 //     S[h,t]  = sum_d q[h,d] (s_t kq[t,d] + z_t)  = s_t * (q . kq[t]) + z_t * sum_d q[h,d]
 //     O[h,d]  = sum_t P[h,t] (s_t vq[t,d] + z_t)  = sum_t (P s_t)[h,t] vq[t,d]  +  sum_t P[h,t] z_t
-// so the MFMAs contract the RAW integer codes (converted to fp16 exactly with one v_perm per two codes: 0x64bb =
-// 1024 + b; K additionally subtracts 1024 exactly, V keeps the +1024 and removes 1024 * sum_t (P s_t) at the end)
-// and the scales touch 4 values per lane per tile instead of 256.  This is NOT the reference's rounding sequence
+// so the MFMAs contract the RAW integer codes -- turned into fp16 with ONE v_perm per two codes and no arithmetic at
+// all: the byte b becomes the fp16 SUBNORMAL 0x00bb = b * 2^-24, which the matrix core multiplies exactly; the factor
+// 2^24 is folded into the K scale and into the final O -- and the scales touch 4 values per lane per tile instead of
+// 256.  (Round 1 used 0x64bb = 1024 + b and removed 1024 * sum_t (P s_t) at the end: the full-size parity test of
+// round 2 found the cancellation -- O ~ 1031 * sum P against a signal of ~7 * sum P for int4 -- costing up to 9e-3
+// absolute on 3 of 2048 (sequence, head) pairs at ctx ~1.6k; the subnormal form has no bias and is also cheaper.)  This is NOT the reference's rounding sequence
 // (no per-element fp16 rounding of k^ / v^): results agree with it to ~1e-3 relative, inside the stated tolerance
 // (reference Compare thresholds rtol 1e-2 / atol 1e-4, kernels/attention/test_utils.h:12-14).
 //
@@ -29,15 +32,18 @@ namespace tmk {
 
 typedef int v2i __attribute__((ext_vector_type(2)));
 
-__device__ __forceinline__ half8_t bytes8_to_f16_plus1024(u32x2 w)
+// byte b -> fp16 bit pattern 0x00bb: the SUBNORMAL b * 2^-24, exact, no bias to remove afterwards (selector byte 0x0c =
+// constant 0x00).  The f16 MFMA consumes subnormal inputs exactly (checked by the parity tests: a flush would zero every
+// score), so both contractions run on code * 2^-24 and the factor 2^24 is folded into the K scale / the final O.
+__device__ __forceinline__ half8_t bytes8_to_f16_subnormal(u32x2 w)
 {
-    // byte b -> fp16 bit pattern 0x64bb = 1024 + b (exact)
-    const uint32_t a0 = __builtin_amdgcn_perm(0x64646464u, w[0], 0x04010400u);
-    const uint32_t a1 = __builtin_amdgcn_perm(0x64646464u, w[0], 0x04030402u);
-    const uint32_t a2 = __builtin_amdgcn_perm(0x64646464u, w[1], 0x04010400u);
-    const uint32_t a3 = __builtin_amdgcn_perm(0x64646464u, w[1], 0x04030402u);
+    const uint32_t a0 = __builtin_amdgcn_perm(0u, w[0], 0x0c010c00u);
+    const uint32_t a1 = __builtin_amdgcn_perm(0u, w[0], 0x0c030c02u);
+    const uint32_t a2 = __builtin_amdgcn_perm(0u, w[1], 0x0c010c00u);
+    const uint32_t a3 = __builtin_amdgcn_perm(0u, w[1], 0x0c030c02u);
     return bit_cast<half8_t>(u32x4{a0, a1, a2, a3});
 }
+constexpr float kTwo24 = 16777216.0f;
 
 constexpr int kWaveLds = 16384 + 512;  // K image 8 KB | V image 8 KB | (k_param, v_param) per token
 
@@ -191,7 +197,7 @@ __global__ __launch_bounds__(256, 2) void decode_attention_i8_mfma_kernel(Decode
     for (int dt = 0; dt < 8; ++dt) {
         O[dt] = floatx4{0.f, 0.f, 0.f, 0.f};
     }
-    float m = -INFINITY, lsum = 0.f, psum = 0.f, zacc = 0.f;  // per head column i16, partial over this lane's tokens
+    float m = -INFINITY, lsum = 0.f, zacc = 0.f;  // per head column i16, partial over this lane's tokens
     const float sc = p.scale_log2;
 
     const uint64_t* blocks = p.cache.block_ptrs + p.cache.cu_block_nums[b];
@@ -376,8 +382,6 @@ __global__ __launch_bounds__(256, 2) void decode_attention_i8_mfma_kernel(Decode
 
         // ---- S^T = K q^T on raw codes -----------------------------------------------------------------------
         floatx4 S[4];
-        const half8_t k1024 = {(half_t)1024.f, (half_t)1024.f, (half_t)1024.f, (half_t)1024.f,
-                               (half_t)1024.f, (half_t)1024.f, (half_t)1024.f, (half_t)1024.f};
 #pragma unroll
         for (int tt = 0; tt < 4; ++tt) {
             S[tt]       = floatx4{0.f, 0.f, 0.f, 0.f};
@@ -387,13 +391,13 @@ __global__ __launch_bounds__(256, 2) void decode_attention_i8_mfma_kernel(Decode
                 const int   u   = 4 * dd + g;
                 const int   off = t * 128 + ((((u >> 1) ^ ((t >> 1) & 7))) << 4) + (u & 1) * 8;
                 const u32x2 kb  = *(const u32x2*)(Kt + off);
-                const half8_t a = bytes8_to_f16_plus1024(kb) - k1024;  // exact integers 0..255
+                const half8_t a = bytes8_to_f16_subnormal(kb);  // code * 2^-24, exact
                 S[tt]           = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, qf[dd], S[tt], 0, 0, 0);
             }
         }
 
         // ---- scales, mask, online softmax (lane: head column i16, tokens 16tt + 4g + r) ----------------------
-        // Per score: s = ks*R + kz*q1 ; p = exp2(s*c - m*c) ; L += p ; Z += p*vz ; P' = h(p*vs) ; PS += P'.
+        // Per score: s = ks*2^24*R + kz*q1 ; p = exp2(s*c - m*c) ; L += p ; Z += p*vz ; P' = h(p*vs).
         // Explicit fmaf() with fp16 operands lowers to v_fma_mix_f32 (no separate converts); the validity mask is
         // only evaluated for the single partial block of a sequence (wave-uniform branch).
         uint32_t kp[4][4], vp[4][4];
@@ -411,7 +415,7 @@ __global__ __launch_bounds__(256, 2) void decode_attention_i8_mfma_kernel(Decode
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const half2_t kk = bit_cast<half2_t>(kp[tt][r]);
-                sv[tt][r]        = __builtin_fmaf((float)kk[0], S[tt][r], (float)kk[1] * q1);
+                sv[tt][r]        = __builtin_fmaf((float)kk[0] * kTwo24, S[tt][r], (float)kk[1] * q1);
             }
         }
         if (partial) {  // tokens past the context: score -inf, V params (0, 0) -> contribute exactly nothing
@@ -441,7 +445,6 @@ __global__ __launch_bounds__(256, 2) void decode_attention_i8_mfma_kernel(Decode
         // wave-uniform: did any head's max move?  (alpha == 1 exactly otherwise)
         if (__builtin_amdgcn_readfirstlane((int)__any(mnew != m))) {
             lsum *= alpha;
-            psum *= alpha;
             zacc *= alpha;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -464,9 +467,7 @@ __global__ __launch_bounds__(256, 2) void decode_attention_i8_mfma_kernel(Decode
                 const float   pf = fast_exp2(__builtin_fmaf(sv[tt][r], sc, -msc));
                 lsum += pf;
                 zacc            = __builtin_fmaf(pf, (float)vv[1], zacc);
-                const half_t ph = (half_t)(pf * (float)vv[0]);
-                psum += (float)ph;
-                pa[tt >> 1][(tt & 1) * 4 + r] = ph;
+                pa[tt >> 1][(tt & 1) * 4 + r] = (half_t)(pf * (float)vv[0]);
             }
         }
 
@@ -481,7 +482,7 @@ __global__ __launch_bounds__(256, 2) void decode_attention_i8_mfma_kernel(Decode
             for (int dt = 0; dt < 8; ++dt) {
                 const v2i vb = __builtin_amdgcn_ds_read_tr8_b64_v2i32(
                     (__attribute__((address_space(3))) v2i*)(vrow + ((dt ^ swz) << 4)));
-                const half8_t bq = bytes8_to_f16_plus1024(u32x2{(uint32_t)vb[0], (uint32_t)vb[1]});
+                const half8_t bq = bytes8_to_f16_subnormal(u32x2{(uint32_t)vb[0], (uint32_t)vb[1]});
                 O[dt]            = __builtin_amdgcn_mfma_f32_16x16x32_f16(pa[a], bq, O[dt], 0, 0, 0);
             }
         }
@@ -493,8 +494,6 @@ __global__ __launch_bounds__(256, 2) void decode_attention_i8_mfma_kernel(Decode
     // ---- per-wave totals, then merge the 4 waves through LDS ------------------------------------------------
     lsum += __shfl_xor(lsum, 16);
     lsum += __shfl_xor(lsum, 32);
-    psum += __shfl_xor(psum, 16);
-    psum += __shfl_xor(psum, 32);
     zacc += __shfl_xor(zacc, 16);
     zacc += __shfl_xor(zacc, 32);
 
@@ -507,12 +506,11 @@ __global__ __launch_bounds__(256, 2) void decode_attention_i8_mfma_kernel(Decode
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int   h  = 4 * g + r;
-        const float ps = __shfl(psum, h);
         const float za = __shfl(zacc, h);
         if (h < hpw) {
 #pragma unroll
             for (int dt = 0; dt < 8; ++dt) {
-                sm_o[(wave * 16 + h) * D + dt * 16 + i16] = O[dt][r] - 1024.f * ps + za;
+                sm_o[(wave * 16 + h) * D + dt * 16 + i16] = __builtin_fmaf(O[dt][r], kTwo24, za);
             }
         }
     }

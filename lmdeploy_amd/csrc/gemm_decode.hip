@@ -157,7 +157,7 @@ __global__ __launch_bounds__(CG* WK * 64) void gemm_dec32_kernel(Dec32Params p)
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid  = threadIdx.x;
-    const int wgid = blockIdx.y * gridDim.x + blockIdx.x;
+    const int wgid = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
     if (p.dbg && tid == 0) {
         p.dbg[wgid * 8 + 0] = __builtin_amdgcn_s_memrealtime();
         p.dbg[wgid * 8 + 4] = ((uint64_t)__builtin_amdgcn_s_getreg(20 | (31 << 11)) << 32) | (uint32_t)__builtin_amdgcn_s_getreg(4 | (31 << 11));
@@ -177,9 +177,13 @@ __global__ __launch_bounds__(CG* WK * 64) void gemm_dec32_kernel(Dec32Params p)
     const int kb0 = blockIdx.y * p.kb_per_split;
     const int nkb = min(p.kb_per_split, p.KB - kb0);
     const int nst = (nkb + S - 1) / S;
+    // row block (prefill: M > ROWS): rows m0 .. m0 + Mloc of x / y; the x descriptor starts at row m0
+    const int m0   = blockIdx.z * ROWS;
+    const int Mloc = min(ROWS, p.M - m0);
 
     const auto rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.wp, 0, (int)((size_t)p.KB * p.ncg * kP32Unit), 0x00020000);
-    const auto rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)(((size_t)(p.M - 1) * p.ldx + p.K) * 2), 0x00020000);
+    const auto rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x + (size_t)m0 * p.ldx), 0,
+                                                        (int)(((size_t)(Mloc - 1) * p.ldx + p.K) * 2), 0x00020000);
     const int  vw   = lane * 16;
     const int  vs   = 2048 + l31 * 4;
 
@@ -202,7 +206,7 @@ __global__ __launch_bounds__(CG* WK * 64) void gemm_dec32_kernel(Dec32Params p)
         const int kbi = q / (ROWS * 16);
         const int row = (q >> 4) % ROWS;
         const int ch  = q & 15;
-        xoff[r]       = (min(row, p.M - 1) * p.ldx + ch * 8) * 2 + kbi * 256;
+        xoff[r]       = (min(row, Mloc - 1) * p.ldx + ch * 8) * 2 + kbi * 256;
         xlds[r]       = kbi * KBB + row * 256 + ((ch ^ (row & 15)) << 4);
     }
     // B fragment of 16-k step j: row (l & 31) [+ 32], 16-byte chunk 2j + half, XOR-swizzled by the row
@@ -230,7 +234,7 @@ __global__ __launch_bounds__(CG* WK * 64) void gemm_dec32_kernel(Dec32Params p)
             const int kbi = pc / (ROWS / 4);
             const int row = (pc % (ROWS / 4)) * 4 + (lane >> 4);
             const int ch  = (lane & 15) ^ (row & 15);
-            doff[r]       = (min(row, p.M - 1) * p.ldx + ch * 8) * 2 + kbi * 256;
+            doff[r]       = (min(row, Mloc - 1) * p.ldx + ch * 8) * 2 + kbi * 256;
         }
     }
     // one DMA instruction per piece; M0 = LDS byte address of the piece (saved / restored: the compiler owns M0)
@@ -464,21 +468,22 @@ __global__ __launch_bounds__(CG* WK * 64) void gemm_dec32_kernel(Dec32Params p)
                 a += red[(k * ROWS + m) * C4 + (c4 ^ (m & 7))];
             }
             const int n = ncol0 + c4 * 4;
-            if (m >= p.M || n >= p.N) {
+            if (m >= Mloc || n >= p.N) {
                 continue;
             }
+            const size_t mg = (size_t)m0 + m;  // row of y
             if (p.epilogue == 2) {
-                *(floatx4*)(p.partial + ((size_t)blockIdx.y * p.M + m) * p.N + n) = a;
+                *(floatx4*)(p.partial + ((size_t)blockIdx.y * p.M + mg) * p.N + n) = a;
             }
             else if (p.epilogue == 1) {
                 const float s0 = a[0] / (1.0f + __builtin_expf(-a[0]));
                 const float s1 = a[2] / (1.0f + __builtin_expf(-a[2]));
                 half2_t     o  = {(half_t)(s0 * a[1]), (half_t)(s1 * a[3])};
-                *(half2_t*)(p.y + (size_t)m * p.ldy + (n >> 1)) = o;
+                *(half2_t*)(p.y + mg * p.ldy + (n >> 1)) = o;
             }
             else {
                 half4_t o = {(half_t)a[0], (half_t)a[1], (half_t)a[2], (half_t)a[3]};
-                *(half4_t*)(p.y + (size_t)m * p.ldy + n) = o;
+                *(half4_t*)(p.y + mg * p.ldy + n) = o;
             }
         }
     }
@@ -521,6 +526,17 @@ template<int MH>
 static int launch_dec32_shape(const Dec32Params& p, dim3 grid, int shape, hipStream_t st)
 {
     const int abl = env_int2("TM_D32_ABL", -1);  // timing / structure experiments (tools/trace_dec32.py, tools/bench_gemm.py)
+    if constexpr (MH == 4) {
+        // row blocks of 128 rows x 256 columns, 8 waves of 32 columns over the whole k slice (M > 64): every dequantised
+        // weight fragment feeds 4 MFMAs, every x fragment read from LDS feeds 32 columns
+        if (shape != 4) {
+            set_last_error("gemm_dec32: the 128-row tile is shape 4");
+            return 1;
+        }
+        if (abl == 0) return launch_dec32_one<4, 8, 1, 2, 4, 0>(p, grid, st);
+        return launch_dec32_one<4, 8, 1, 2, 4, kD32Mode>(p, grid, st);
+    }
+    else
     switch (shape) {
         case 0: {  // 16 waves: 4 column groups x 4 k-phases, one k-block per wave per stage
             if constexpr (MH == 2) {
@@ -556,15 +572,16 @@ static int launch_dec32_shape(const Dec32Params& p, dim3 grid, int shape, hipStr
 // shape -> (column groups, k-blocks per stage)
 static void dec32_shape_dims(int shape, int* cg, int* s)
 {
-    static const int cgs[4] = {4, 8, 4, 2};
-    *cg = cgs[shape & 3];
-    *s  = 4;
+    static const int cgs[5] = {4, 8, 4, 2, 8};
+    *cg = cgs[shape < 0 || shape > 4 ? 0 : shape];
+    *s  = shape == 4 ? 2 : 4;
 }
 
 bool dec32_supported(const LinearWeight& w, int M)
 {
-    static const int on = env_int2("TM_GEMM_D32", 1);
-    return on && w.type == 0 && w.packed32 != nullptr && M >= 1 && M <= 64 && w.N % 32 == 0 && w.K % 128 == 0;
+    static const int on     = env_int2("TM_GEMM_D32", 1);
+    static const int on_big = env_int2("TM_GEMM_D32_PREFILL", 1);  // M > 64: the 128-row tile of the same kernel
+    return on && (M <= 64 || on_big) && w.type == 0 && w.packed32 != nullptr && M >= 1 && w.N % 32 == 0 && w.K % 128 == 0;
 }
 
 // Tiling for the decode GEMM: `shape` (see launch_dec32_shape) and the split-K count.  One workgroup per CU (128 KB of
@@ -574,12 +591,15 @@ void dec32_pick(const LinearWeight& w, int M, int* shape_out, int* splits_out)
     const int ncg = w.N / 32;
     const int KB  = w.K / 128;
     int       shape = env_int2("TM_D32_SHAPE", -1);
-    if (shape < 0) {
+    if (shape < 0 || shape > 3) {
         shape = 0;
+    }
+    if (M > 64) {
+        shape = 4;
     }
     int cgn, S;
     dec32_shape_dims(shape, &cgn, &S);
-    const int col_wgs = (ncg + cgn - 1) / cgn;
+    const int col_wgs = (ncg + cgn - 1) / cgn * ((M + 127) / 128);
     int       splits  = 1;
     static const int min_kb = env_int2("TM_D32_MIN_KB", 4);
     for (int s = 2; s <= 16; ++s) {  // the engine's slab workspace holds 16 splits
@@ -589,7 +609,7 @@ void dec32_pick(const LinearWeight& w, int M, int* shape_out, int* splits_out)
         if (eff != s) {
             continue;
         }
-        if (col_wgs * s <= 256 && per >= min_kb) {
+        if (col_wgs * s <= 256 && per >= (M > 64 ? 8 : min_kb)) {
             splits = s;
         }
     }
@@ -603,7 +623,7 @@ int launch_linear_dec32(const LinearWeight& w, const half_t* x, int ldx, half_t*
                         int splits, float* workspace, int* slabs_out, hipStream_t st)
 {
     TM_REQUIRE(w.packed32 != nullptr && w.N % 32 == 0, "decode GEMM: P32 layout missing");
-    TM_REQUIRE(M >= 1 && M <= 64, "decode GEMM: 1 <= M <= 64");
+    TM_REQUIRE(M >= 1 && (M <= 64) == (shape != 4), "decode GEMM: shapes 0..3 take M <= 64, shape 4 takes M > 64");
     TM_REQUIRE(ldx % 8 == 0, "x rows must be 16-byte aligned");
     int cgn, S;
     dec32_shape_dims(shape, &cgn, &S);
@@ -627,8 +647,10 @@ int launch_linear_dec32(const LinearWeight& w, const half_t* x, int ldx, half_t*
     p.kb_per_split = per;
     p.epilogue     = splits > 1 ? 2 : (gated_silu ? 1 : 0);
     p.dbg          = g_gemm_dbg;
-    dim3      grid((p.ncg + cgn - 1) / cgn, splits, 1);
-    const int rc = M <= 32 ? launch_dec32_shape<1>(p, grid, shape, st) : launch_dec32_shape<2>(p, grid, shape, st);
+    dim3      grid((p.ncg + cgn - 1) / cgn, splits, shape == 4 ? (M + 127) / 128 : 1);
+    const int rc = shape == 4 ? launch_dec32_shape<4>(p, grid, shape, st) :
+                   M <= 32    ? launch_dec32_shape<1>(p, grid, shape, st) :
+                                launch_dec32_shape<2>(p, grid, shape, st);
     if (rc) {
         return rc;
     }

@@ -154,15 +154,20 @@ def test_decode_attention_batch64_ragged_1k_2k(tm, cuda, bits, Hq, Hkv):
     dc = DevCache(L, total, tables)
     dc.upload(oc)
     klen_d = dev(np.asarray(klen, np.int32))
-    check = [0, 1] + rng.choice(np.arange(2, B), 10, replace=False).tolist()
-    refs = {}
-    for b in check:
+    # EVERY sequence against the reference's unfused fp64 oracle (kernels/attention/reference.cu:252-367 restated); the
+    # longest, the shortest and 6 random ones additionally against the fp16-flow oracle.  (Round 2: sampling 12 of 64
+    # sequences let a cancellation error of the int4 path -- 9e-3 on 3 of 2048 (sequence, head) pairs -- slip through.)
+    check = [0, 1] + rng.choice(np.arange(2, B), 6, replace=False).tolist()
+    refs, refs64 = {}, {}
+    for b in range(B):
         Ks, Vs = [], []
         for hd in range(Hkv):
             kd, vd = oc.load_dequant(tables[b], layer, hd, 0, klen[b], 'decode')
             Ks.append(kd)
             Vs.append(vd)
-        refs[b] = o.decode_attention(q[b].reshape(Hq, 128), np.stack(Ks), np.stack(Vs), None, 1).astype(np.float32)
+        refs64[b] = o.attention_reference_unfused(q[b].reshape(Hq, 128), np.stack(Ks), np.stack(Vs)).astype(np.float32)
+        if b in check:
+            refs[b] = o.decode_attention(q[b].reshape(Hq, 128), np.stack(Ks), np.stack(Vs), None, 1).astype(np.float32)
     outs = []
     for splits in (1, 4):
         out = torch.zeros((B, Hq * 128), dtype=torch.float16, device='cuda')
@@ -171,12 +176,14 @@ def test_decode_attention_batch64_ragged_1k_2k(tm, cuda, bits, Hq, Hkv):
                                           ws.data_ptr(), dc.view(layer), st()))
         got = host(out).reshape(B, Hq, 128).astype(np.float32)
         assert np.isfinite(got).all()
+        for b in range(B):
+            err = np.abs(got[b] - refs64[b])
+            assert np.all(err <= 1e-2 * np.abs(refs64[b]) + 3e-3), f'splits {splits} seq {b} (ctx {klen[b]}): max err {err.max()} vs fp64'
         for b in check:
             err = np.abs(got[b] - refs[b])
             assert np.all(err <= 1e-2 * np.abs(refs[b]) + 2e-3), f'splits {splits} seq {b} (ctx {klen[b]}): max err {err.max()}'
         outs.append(got)
-    # every sequence, not only the sampled ones: the two split counts are independent evaluations of the same softmax
-    assert np.all(np.abs(outs[0] - outs[1]) <= 1e-2 * np.abs(outs[0]) + 4e-3)
+    assert np.all(np.abs(outs[0] - outs[1]) <= 2e-2 * np.abs(outs[0]) + 4e-3)     # each within 1e-2 |ref| + 2e-3 of the oracle
 
 
 def test_block_table_permutation_at_32_blocks(tm, cuda):

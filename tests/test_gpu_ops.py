@@ -436,7 +436,7 @@ def test_w4a16_linear_prefill_tiles(tm, cuda, K, N, M, gated):
     ref = (o.w4a16_linear_gated_silu(x, q, s, z) if gated else x.astype(np.float32) @ _QCACHE[(K, N)][3]).astype(np.float32)
     ws = torch.zeros(max(1, tm.tm_linear_workspace(h, M)), dtype=torch.uint8, device='cuda')
     x_d = dev(x)
-    for nt, splits, waves in ((0, 0, 0), (2, 1, 8), (2, 2, 8), (2, 4, 8), (4, 1, 4)):
+    for nt, splits, waves in ((0, 0, 0), (0, 1, 0x204), (0, 2, 0x204), (0, 3, 0x204), (2, 1, 8), (2, 2, 8), (2, 4, 8), (4, 1, 4)):
         if splits > K // 128:
             continue
         y = torch.zeros((M, N // 2 if gated else N), dtype=torch.float16, device='cuda')

@@ -39,7 +39,7 @@ def main():
         if args.only and name not in args.only.split(','):
             continue
         wbytes = K * N // 2 + (K // 128) * N * 4
-        L = max(4, int(600e6 // wbytes) + 1)
+        L = max(4, int(600e6 // wbytes) + 1) if M <= 256 else 2
         g = torch.Generator(device='cuda').manual_seed(1)
         handles = []
         for _ in range(L):
@@ -61,6 +61,8 @@ def main():
             nt, waves = 0, 0
             if variant == 'old':
                 nt, waves = 1, 0x108           # round-1 default: 4 column groups x 2 k-phases, 8 waves
+            elif variant == 'oldp':
+                nt, waves = 2, 8               # round-1 prefill tile: 8 waves x 2 tiles, 128-row blocks
             elif variant.startswith('d'):
                 shape = int(variant[1])
                 waves = 0x200 | shape
@@ -108,7 +110,8 @@ def main():
                 r = dict(gemm=name, K=K, N=N, M=M, variant=variant, splits=sp, us_median=round(med, 2), us_min=round(mn, 2),
                          gbps=round(wbytes / med / 1e3, 1), launches=L)
                 results.append(r)
-                print(f"{name:8s} K={K:6d} N={N:6d} {variant:8s} splits={sp:2d}  {med:7.2f} us (min {mn:7.2f})  {wbytes / med / 1e3:7.1f} GB/s", flush=True)
+                tf = 2.0 * M * K * N / med / 1e6
+                print(f"{name:8s} K={K:6d} N={N:6d} M={M:5d} {variant:8s} splits={sp:2d}  {med:8.2f} us (min {mn:8.2f})  {wbytes / med / 1e3:7.1f} GB/s  {tf:7.1f} TF/s", flush=True)
         for h in handles:
             tm.tm_linear_destroy(h)
         del x, y, ws
