@@ -100,6 +100,9 @@ struct Dec32Params {
     int           M, N, K, KB, ncg;
     int           kb_per_split;
     int           epilogue;  // 0: fp16   1: gated SiLU fp16 (N/2 columns)   2: fp32 slab of split blockIdx.y
+    int           rotate;    // 1: workgroup w walks its k stages starting at stage (w mod stages) -- the workgroups of a launch then
+                             // read DIFFERENT parts of x (and of the weight stream) at any moment instead of hammering the same
+                             // 64 KB of x from every CU at once
     uint64_t*     dbg;       // optional [workgroups][8] s_memrealtime stamps (tm_debug_set_gemm_trace): start, loop, epilogue, end,
                              // hw id, -, -, after the k-phase reduction barrier
 };
@@ -177,6 +180,12 @@ __global__ __launch_bounds__(CG* WK * 64) void gemm_dec32_kernel(Dec32Params p)
     const int kb0 = blockIdx.y * p.kb_per_split;
     const int nkb = min(p.kb_per_split, p.KB - kb0);
     const int nst = (nkb + S - 1) / S;
+    // logical stage t of this workgroup -> stage of the k slice (rotated start, see Dec32Params::rotate)
+    const int rot0 = (p.rotate && nst > 1) ? (int)((blockIdx.x + blockIdx.z * 7u) % (unsigned)nst) : 0;
+    auto      phys = [&](int t) {
+        int r = min(t, nst - 1) + rot0;
+        return r >= nst ? r - nst : r;
+    };
     // row block (prefill: M > ROWS): rows m0 .. m0 + Mloc of x / y; the x descriptor starts at row m0
     const int m0   = blockIdx.z * ROWS;
     const int Mloc = min(ROWS, p.M - m0);
@@ -278,32 +287,32 @@ __global__ __launch_bounds__(CG* WK * 64) void gemm_dec32_kernel(Dec32Params p)
         if constexpr (DMA) {
             // queue: x(0) DMA pieces, then the whole weight ring; the DMA is invisible to hipcc's waitcnt pass, so its
             // completion is waited for by hand: everything older than the 3 * PF ring loads
-            D32_DMA_X(0, 0);
+            D32_DMA_X(phys(0), 0);
 #pragma unroll
             for (int q = 0; q < PF; ++q) {
-                D32_LOAD_W(q, (q / BPS) * S + wk + (q % BPS) * WK);
+                D32_LOAD_W(q, phys(q / BPS) * S + wk + (q % BPS) * WK);
                 __builtin_amdgcn_sched_barrier(0);
             }
             asm volatile("s_waitcnt vmcnt(%0)" ::"i"(3 * PF) : "memory");
         }
         else {
-            D32_LOAD_X(0);
+            D32_LOAD_X(phys(0));
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int u = 0; u < UNR - 1; ++u) {
 #pragma unroll
                 for (int i = 0; i < BPS; ++i) {
-                    D32_LOAD_W(u * BPS + i, u * S + wk + i * WK);
+                    D32_LOAD_W(u * BPS + i, phys(u) * S + wk + i * WK);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
             D32_STORE_X(0);
             __builtin_amdgcn_sched_barrier(0);
-            D32_LOAD_X(1);
+            D32_LOAD_X(phys(1));
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < BPS; ++i) {
-                D32_LOAD_W((UNR - 1) * BPS + i, (UNR - 1) * S + wk + i * WK);
+                D32_LOAD_W((UNR - 1) * BPS + i, phys(UNR - 1) * S + wk + i * WK);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -324,18 +333,62 @@ __global__ __launch_bounds__(CG* WK * 64) void gemm_dec32_kernel(Dec32Params p)
                 for (int i = 0; i < BPS; ++i) {
                     asm volatile("" ::"v"(ring[u * BPS + i][0]), "v"(ring[u * BPS + i][1]), "v"(sring[u * BPS + i]));
                 }
-                D32_DMA_X(t + 1, buf ^ 1);
+                D32_DMA_X(phys(t + 1), buf ^ 1);
             }
 #pragma unroll
             for (int i = 0; i < BPS; ++i) {
                 const int     slot = u * BPS + i;
                 const int     kbi  = wk + i * WK;
-                const int     b    = t * S + kbi;
+                const int     b    = phys(t) * S + kbi;
                 const bool    live = b < nkb;
                 const half2_t pr   = bit_cast<half2_t>(live ? sring[slot] : 0u);
                 const half2_t s2   = {pr[0], pr[0]};
                 const half2_t z2   = {pr[1], pr[1]};
                 const char*   xb   = smem + buf * STG + kbi * KBB;
+                if constexpr ((ABL & 0x800) != 0) {
+                    // Explicit fragment pipeline: hipcc schedules a compiler-visible LDS read right in front of the MFMA
+                    // that consumes it (seen in the ISA -- every 16-k step then exposes one LDS round trip per wave), so the
+                    // reads are inline asm here: step j+1's fragments are requested before step j's MFMAs, and a counted
+                    // lgkmcnt that names its registers (no use can be hoisted above it) retires step j's.
+                    half8_t        f0[MH], f1[MH];
+                    const unsigned xa = lds0 + buf * STG + kbi * KBB;
+                    auto           rd = [&](half8_t(&f)[MH], int j) __attribute__((always_inline)) {
+                        const unsigned ad = xa + (unsigned)coff[j];
+#pragma unroll
+                        for (int h = 0; h < MH; ++h) {
+                            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(f[h]) : "v"(ad), "i"(h * 8192));
+                        }
+                    };
+                    auto wt = [&](half8_t(&f)[MH], auto N) __attribute__((always_inline)) {
+                        constexpr int n = decltype(N)::value;
+                        if constexpr (MH == 1) {
+                            asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(f[0]) : "i"(n));
+                        }
+                        else if constexpr (MH == 2) {
+                            asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(f[0]), "+v"(f[1]) : "i"(n));
+                        }
+                        else {
+                            asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]) : "i"(n));
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    };
+                    rd(f0, 0);
+                    static_for<8>([&](auto J) {
+                        constexpr int  j  = decltype(J)::value;
+                        half8_t(&cur)[MH] = (j & 1) ? f1 : f0;
+                        half8_t(&nxt)[MH] = (j & 1) ? f0 : f1;
+                        if constexpr (j + 1 < 8) {
+                            rd(nxt, j + 1);
+                        }
+                        const half8_t a = dequant8_p32(ring[slot][j >> 2][j & 3], s2, z2, m1024, m64);
+                        wt(cur, std::integral_constant<int, (j + 1 < 8) ? MH : 0>{});
+#pragma unroll
+                        for (int h = 0; h < MH; ++h) {
+                            acc[h] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, cur[h], acc[h], 0, 0, 0);
+                        }
+                    });
+                }
+                else {
                 half8_t       bq[MH], bn[MH];
 #pragma unroll
                 for (int h = 0; h < MH; ++h) {
@@ -367,8 +420,7 @@ __global__ __launch_bounds__(CG* WK * 64) void gemm_dec32_kernel(Dec32Params p)
 #pragma unroll
                     for (int h = 0; h < MH; ++h) {
                         if constexpr (ABL & 2) {
-                            acc[h][0] += (float)a[0] + (float)bq[h][0];
-                            asm volatile("" ::"v"(a), "v"(bq[h]));
+                            asm volatile("" ::"v"(a), "v"(bq[h]));  // operands stay live, no matrix work
                         }
                         else {
                             acc[h] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bq[h], acc[h], 0, 0, 0);
@@ -384,6 +436,7 @@ __global__ __launch_bounds__(CG* WK * 64) void gemm_dec32_kernel(Dec32Params p)
                         }
                     }
                 }
+                }
             }
             // x of stage t+1 (loaded one stage ago) -> the other buffer; then the loads of stage t+2 into the same
             // registers, then this stage's ring slots are refilled for stage t+UNR.  All unconditional: past the last
@@ -392,12 +445,12 @@ __global__ __launch_bounds__(CG* WK * 64) void gemm_dec32_kernel(Dec32Params p)
             // over-waits by the skipped loads).
             if constexpr (!DMA && !(ABL & 8)) {
                 D32_STORE_X(buf ^ 1);
-                D32_LOAD_X(t + 2);
+                D32_LOAD_X(phys(t + 2));
             }
             if constexpr (!(ABL & 16)) {
 #pragma unroll
                 for (int i = 0; i < BPS; ++i) {
-                    D32_LOAD_W(u * BPS + i, (t + UNR) * S + wk + i * WK);
+                    D32_LOAD_W(u * BPS + i, phys(t + UNR) * S + wk + i * WK);
                 }
             }
             if constexpr (DMA && !(ABL & 8)) {
@@ -518,9 +571,12 @@ static int launch_dec32_one(const Dec32Params& p, dim3 grid, hipStream_t st)
     return 0;
 }
 
-// D = the default structure: LDS-DMA staging of x (measured on MI355X, tools/trace_dec32.py: the w1w3 main loop
-// 16.5 -> 15.3 us against register staging + ds_write; the LDS-read fence and s_setprio variants measured neutral)
-constexpr int kD32Mode = 0x100;
+// The default structure: LDS-DMA staging of x + the explicit fragment pipeline (measured on MI355X, tools/trace_dec32.py /
+// tools/bench_gemm.py: w1w3 main loop at M = 64 16.5 us with register staging + ds_write -> 15.3 us with the DMA -> 14.9 us
+// with the inline-asm fragment reads; M = 8192: 1.03 -> 1.09 PF/s; the LDS-read scheduling fence and s_setprio variants
+// measured neutral, the rotated k walk neutral at M = 64 and -5..-10 % at M = 8192: it breaks the L2 reuse of the weights
+// between row blocks)
+constexpr int kD32Mode = 0x900;
 
 template<int MH>
 static int launch_dec32_shape(const Dec32Params& p, dim3 grid, int shape, hipStream_t st)
@@ -534,6 +590,13 @@ static int launch_dec32_shape(const Dec32Params& p, dim3 grid, int shape, hipStr
             return 1;
         }
         if (abl == 0) return launch_dec32_one<4, 8, 1, 2, 4, 0>(p, grid, st);
+        if (abl == 0x100) return launch_dec32_one<4, 8, 1, 2, 4, 0x100>(p, grid, st);
+        if (abl == 0x101) return launch_dec32_one<4, 8, 1, 2, 4, 0x101>(p, grid, st);  // timing: no dequant
+        if (abl == 0x104) return launch_dec32_one<4, 8, 1, 2, 4, 0x104>(p, grid, st);  // no LDS fragment reads
+        if (abl == 0x108) return launch_dec32_one<4, 8, 1, 2, 4, 0x108>(p, grid, st);  // no x staging
+        if (abl == 0x10d) return launch_dec32_one<4, 8, 1, 2, 4, 0x10d>(p, grid, st);  // MFMA + weight loads only
+        if (abl == 0x11d) return launch_dec32_one<4, 8, 1, 2, 4, 0x11d>(p, grid, st);  // MFMA only
+        if (abl == 0x102) return launch_dec32_one<4, 8, 1, 2, 4, 0x102>(p, grid, st);  // no MFMA
         return launch_dec32_one<4, 8, 1, 2, 4, kD32Mode>(p, grid, st);
     }
     else
@@ -546,6 +609,7 @@ static int launch_dec32_shape(const Dec32Params& p, dim3 grid, int shape, hipStr
                     D32_CASE(1); D32_CASE(2); D32_CASE(4); D32_CASE(8); D32_CASE(16); D32_CASE(7); D32_CASE(15); D32_CASE(31);
                     D32_CASE(32); D32_CASE(64); D32_CASE(95); D32_CASE(24); D32_CASE(25); D32_CASE(26); D32_CASE(27);
                     D32_CASE(28); D32_CASE(29); D32_CASE(30); D32_CASE(0x107); D32_CASE(0x118); D32_CASE(0x11f);
+                    D32_CASE(0x100); D32_CASE(0x918); D32_CASE(0x800);
 #undef D32_CASE
                     default: break;
                 }
@@ -647,6 +711,7 @@ int launch_linear_dec32(const LinearWeight& w, const half_t* x, int ldx, half_t*
     p.kb_per_split = per;
     p.epilogue     = splits > 1 ? 2 : (gated_silu ? 1 : 0);
     p.dbg          = g_gemm_dbg;
+    p.rotate       = env_int2("TM_D32_ROTATE", 0);
     dim3      grid((p.ncg + cgn - 1) / cgn, splits, shape == 4 ? (M + 127) / 128 : 1);
     const int rc = shape == 4 ? launch_dec32_shape<4>(p, grid, shape, st) :
                    M <= 32    ? launch_dec32_shape<1>(p, grid, shape, st) :

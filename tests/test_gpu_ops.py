@@ -472,11 +472,11 @@ def test_w4a16_alternative_decode_kernels(tm, cuda, monkeypatch, K, N, M, gated,
 
 
 @pytest.mark.parametrize('K,N,M,gated', [(4096, 6144, 64, 0), (1792, 4096, 33, 0), (256, 64, 40, 0), (4096, 1024, 64, 1), (1024, 2048, 50, 1)])
-@pytest.mark.parametrize('mode', [0, 0x200, 0x300, 0x400, 0x500, 0x700])
+@pytest.mark.parametrize('mode', [0, 0x100, 0x200, 0x300, 0x400, 0x500, 0x700, 0x800])
 def test_w4a16_decode_kernel_modes(tm, cuda, monkeypatch, K, N, M, gated, mode):
-    """Structure variants of the decode kernel (gemm_decode.hip): register staging + ds_write of the activations (0; the
-    default is LDS-DMA, 0x100), the LDS read scheduling fence (0x200), s_setprio around the MFMAs (0x400) and their
-    combinations -- same oracle, same tolerance."""
+    """Structure variants of the decode kernel (gemm_decode.hip): register staging + ds_write of the activations (0),
+    LDS-DMA staging (0x100), the LDS read scheduling fence (0x200), s_setprio around the MFMAs (0x400), the inline-asm
+    fragment pipeline without the DMA (0x800) and combinations (the default is 0x900) -- same oracle, same tolerance."""
     monkeypatch.setenv('TM_D32_ABL', str(mode))
     rng = np.random.default_rng(K + N + M + mode)
     h, (q, s, z) = _make_linear(tm, rng, K, N)
@@ -488,6 +488,25 @@ def test_w4a16_decode_kernel_modes(tm, cuda, monkeypatch, K, N, M, gated, mode):
             continue
         y = torch.zeros((M, N // 2 if gated else N), dtype=torch.float16, device='cuda')
         _ffi.check(tm.tm_linear_forward(h, dev(x).data_ptr(), K, y.data_ptr(), y.shape[1], M, gated, 0, splits, 0x200, ws.data_ptr(), st()))
+        err = np.abs(host(y).astype(np.float32) - ref)
+        assert np.all(err <= 2e-3 + 2.0**-9 * np.abs(ref)), f'mode {mode:#x} splits={splits}: max err {err.max()}'
+    _ffi.check(tm.tm_linear_destroy(h))
+
+
+@pytest.mark.parametrize('K,N,M,gated', [(4096, 6144, 300, 0), (1792, 4096, 129, 0), (1024, 2048, 1000, 1)])
+@pytest.mark.parametrize('mode', [0, 0x100])
+def test_w4a16_row_block_tile_modes(tm, cuda, monkeypatch, K, N, M, gated, mode):
+    """the 128-row tile of the decode kernel (M > 64) with register staging (0) and with LDS-DMA + compiler-scheduled
+    fragment reads (0x100); the default (LDS-DMA + the explicit fragment pipeline) is covered by the prefill-tile test"""
+    monkeypatch.setenv('TM_D32_ABL', str(mode))
+    rng = np.random.default_rng(K + N + M + mode)
+    h, (q, s, z) = _make_linear(tm, rng, K, N)
+    x = rng.standard_normal((M, K)).astype(f16)
+    ref = (o.w4a16_linear_gated_silu(x, q, s, z) if gated else x.astype(np.float32) @ _QCACHE[(K, N)][3]).astype(np.float32)
+    ws = torch.zeros(max(1, tm.tm_linear_workspace(h, M)), dtype=torch.uint8, device='cuda')
+    for splits in (1, 2):
+        y = torch.zeros((M, N // 2 if gated else N), dtype=torch.float16, device='cuda')
+        _ffi.check(tm.tm_linear_forward(h, dev(x).data_ptr(), K, y.data_ptr(), y.shape[1], M, gated, 0, splits, 0x204, ws.data_ptr(), st()))
         err = np.abs(host(y).astype(np.float32) - ref)
         assert np.all(err <= 2e-3 + 2.0**-9 * np.abs(ref)), f'mode {mode:#x} splits={splits}: max err {err.max()}'
     _ffi.check(tm.tm_linear_destroy(h))

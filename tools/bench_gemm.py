@@ -69,7 +69,7 @@ def main():
                 if 'pf4' in variant:
                     env['TM_D32_PF'] = '4'
             elif variant.startswith('abl'):
-                waves = 0x200 | args.abl_shape
+                waves = 0x200 | (4 if M > 64 else args.abl_shape)
                 env['TM_D32_ABL'] = variant[3:]
             for k, v in env.items():
                 os.environ[k] = v
