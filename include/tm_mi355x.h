@@ -169,6 +169,18 @@ int tm_linear_prepare(tm_linear* w, const void* weight, const void* scales, cons
 size_t tm_linear_workspace(const tm_linear* w, int M);
 int    tm_linear_forward(const tm_linear* w, const void* x, int ldx, void* y, int ldy, int M, int gated_silu,
                          int nt, int splits, int waves, void* workspace, tm_stream_t st);
+/* FP8 x FP8 linear on the fp8 matrix cores -- the reference's path for e4m3 weights on fp8 tensor cores:
+ * LlamaLinear::Forward quantises the activations per row and 128-channel group (QuantizeSymm,
+ * src/turbomind/kernels/quantization.cu:28-125, called at models/llama/LlamaLinear.cu:67-93) and runs the fp8 GEMM with
+ * both scale sets.  tm_quant_fp8_rows = QuantizeSymm (codes [M][K] e4m3, scales fp32 [K/128][ldsx]);
+ * tm_linear_forward_fp8 = quantise + GEMM (+ split-K reduce); workspace >= tm_linear_fp8_workspace(w, M) bytes. */
+/* the fused w1w3 linear of an fp8 checkpoint: (gate_j, up_j)-interleaved e4m3 columns whose block-scale row is
+ * [w1's inter/128 blocks | w3's inter/128 blocks] (w1 / w3 are quantised separately; lmdeploy/turbomind/builders/ffn.py:31-34) */
+int    tm_linear_prepare_fp8_gated(tm_linear* w, const void* weight, const void* scales, tm_stream_t st);
+size_t tm_linear_fp8_workspace(const tm_linear* w, int M);
+int    tm_quant_fp8_rows(void* xq, float* sx, const void* x, int ldx, int M, int K, int ldsx, tm_stream_t st);
+int    tm_linear_forward_fp8(const tm_linear* w, const void* x, int ldx, void* y, int ldy, int M, int gated_silu, int splits,
+                             void* workspace, tm_stream_t st);
 int    tm_linear_destroy(tm_linear* w);
 /* ---- Mixture-of-experts FFN block (MoeFfnLayer, models/llama/moe_ffn_layer.cc:43-53,133-325; routing
  * kernels/gemm/moe_utils_v2.cu:355-690; grouped linear LlamaLinear.cu:67-127) -------------------------------------

@@ -107,6 +107,10 @@ _SIGNATURES = {
     'tm_linear_forward': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
                                   c_void_p, c_void_p]),
     'tm_linear_destroy': (c_int, [c_void_p]),
+    'tm_linear_prepare_fp8_gated': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
+    'tm_linear_fp8_workspace': (c_size_t, [c_void_p, c_int]),
+    'tm_quant_fp8_rows': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    'tm_linear_forward_fp8': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     'tm_quantize_groupwise': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                                       c_void_p]),
     'tm_debug_set_gemm_trace': (c_int, [c_void_p]),

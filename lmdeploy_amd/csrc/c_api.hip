@@ -313,6 +313,53 @@ int tm_linear_forward(const tm_linear* w, const void* x, int ldx, void* y, int l
                          nullptr, (hipStream_t)st);
 }
 
+int tm_linear_prepare_fp8_gated(tm_linear* w, const void* weight, const void* scales, tm_stream_t st)
+{
+    TM_REQUIRE(w && weight && scales, "null pointer");
+    TM_REQUIRE(w->w.type == TM_WEIGHT_FP8, "tm_linear_prepare_fp8_gated: fp8 weights only");
+    return linear_weight_prepare_fp8(w->w, (const uint8_t*)weight, (const float*)scales, true, (hipStream_t)st);
+}
+
+size_t tm_linear_fp8_workspace(const tm_linear* w, int M)
+{
+    if (!w) {
+        return 0;
+    }
+    return (fp8_act_workspace_bytes(M, w->w.K) + 255) / 256 * 256 + gemm_workspace_bytes(M, w->w.N, 16);
+}
+
+int tm_quant_fp8_rows(void* xq, float* sx, const void* x, int ldx, int M, int K, int ldsx, tm_stream_t st)
+{
+    TM_REQUIRE(xq && sx && x, "null pointer");
+    return launch_quant_fp8_rows((uint8_t*)xq, sx, (const half_t*)x, ldx, M, K, ldsx, (hipStream_t)st);
+}
+
+int tm_linear_forward_fp8(const tm_linear* w, const void* x, int ldx, void* y, int ldy, int M, int gated_silu, int splits,
+                          void* workspace, tm_stream_t st)
+{
+    TM_REQUIRE(w && x && y && workspace, "null pointer");
+    TM_REQUIRE(fp8_mfma_supported(w->w), "fp8 x fp8 linear: e4m3 weights, N % 32 == 0 (TM_FP8_MFMA=0 disables the path)");
+    TM_REQUIRE(splits >= 0 && splits <= 16, "0 <= splits <= 16");
+    const int K    = w->w.K;
+    uint8_t*  xq   = (uint8_t*)workspace;
+    const int ldsx = (M + 3) / 4 * 4;
+    float*    sx   = (float*)(xq + (size_t)M * K);
+    float*    slab = (float*)((char*)workspace + (fp8_act_workspace_bytes(M, K) + 255) / 256 * 256);
+    int       rc   = launch_quant_fp8_rows(xq, sx, (const half_t*)x, ldx, M, K, ldsx, (hipStream_t)st);
+    if (rc) {
+        return rc;
+    }
+    int nslab = 1;
+    rc        = launch_linear_fp8(w->w, xq, sx, ldsx, (half_t*)y, ldy, M, gated_silu != 0, splits, slab, &nslab, (hipStream_t)st);
+    if (rc) {
+        return rc;
+    }
+    if (nslab > 1) {
+        return launch_splitk_reduce((half_t*)y, ldy, slab, nslab, M, w->w.N, gated_silu != 0, (hipStream_t)st);
+    }
+    return 0;
+}
+
 int tm_linear_destroy(tm_linear* w)
 {
     if (w) {

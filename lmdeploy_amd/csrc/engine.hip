@@ -958,8 +958,8 @@ int tm_engine_process_weights(tm_engine* e)
                 }
                 L.moe.w13[x] = L.ex13[x].w;  // the MoE block owns the packed weights from here on
                 L.moe.w2[x]  = L.ex2[x].w;
-                L.ex13[x].w.packed = nullptr, L.ex13[x].w.sz = nullptr, L.ex13[x].w.packed32 = nullptr;
-                L.ex2[x].w.packed = nullptr, L.ex2[x].w.sz = nullptr, L.ex2[x].w.packed32 = nullptr;
+                L.ex13[x].w.packed = nullptr, L.ex13[x].w.sz = nullptr, L.ex13[x].w.packed32 = nullptr, L.ex13[x].w.packed8 = nullptr;
+                L.ex2[x].w.packed = nullptr, L.ex2[x].w.sz = nullptr, L.ex2[x].w.packed32 = nullptr, L.ex2[x].w.packed8 = nullptr;
             }
             Slot& g = e->slots[p + ".moe_ffn.gate.weight"];
             TM_REQUIRE(g.filled, "weight not loaded: " + p + ".moe_ffn.gate.weight");

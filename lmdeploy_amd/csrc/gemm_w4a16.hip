@@ -168,6 +168,10 @@ void linear_weight_free(LinearWeight& w)
     if (w.packed32) {
         (void)hipFree(w.packed32);
     }
+    if (w.packed8) {
+        (void)hipFree(w.packed8);
+    }
+    w.packed8 = nullptr;
     w.packed   = nullptr;
     w.sz       = nullptr;
     w.packed32 = nullptr;
@@ -219,6 +223,13 @@ int linear_weight_prepare_fp8(LinearWeight& w, const uint8_t* weight, const floa
     const size_t ns = (size_t)(w.K / 128) * w.N;
     repack_sz_fp8_kernel<<<(ns + 255) / 256, 256, 0, st>>>(w.sz, block_scales, w.K / 128, w.N, gated_scales ? 1 : 0);
     TM_HIP_CHECK(hipGetLastError());
+    if (w.N % 32 == 0) {  // the fp8 x fp8 kernel's layout (gemm_fp8.hip)
+        w.packed8_bytes = p8_bytes(w.K, w.N);
+        if (!w.packed8) {
+            TM_HIP_CHECK(hipMalloc(&w.packed8, w.packed8_bytes));
+        }
+        return launch_repack_p8(w.packed8, weight, block_scales, w.K, w.N, gated_scales, st);
+    }
     return 0;
 }
 
@@ -1394,6 +1405,14 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(half_t* __restrict__
         half4_t o = {(half_t)a[0], (half_t)a[1], (half_t)a[2], (half_t)a[3]};
         *(half4_t*)(y + (size_t)m * ldy + n) = o;
     }
+}
+
+int launch_splitk_reduce(half_t* y, int ldy, const float* partial, int splits, int M, int N, bool gated, hipStream_t st)
+{
+    const size_t total = (size_t)M * N / 4;
+    splitk_reduce_kernel<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(y, ldy, partial, splits, M, N, gated ? 1 : 0);
+    TM_HIP_CHECK(hipGetLastError());
+    return 0;
 }
 
 size_t gemm_workspace_bytes(int M, int N, int splits)

@@ -236,6 +236,9 @@ size_t moe_workspace_bytes(const MoeBlock& m, int tokens)
     b += pairs * m.inter * 2;        // act  [pairs][I]
     b  = (b + 255) / 256 * 256;
     b += pairs * m.hidden * 2;       // y2   [pairs][H]
+    b  = (b + 255) / 256 * 256;
+    // fp8 x fp8 experts: codes + scales of x (per token) and of the gated-SiLU output (per (token, expert) row)
+    b += fp8_act_workspace_bytes(tokens, m.hidden) + fp8_act_workspace_bytes((int)pairs, m.inter);
     return b + 256;
 }
 
@@ -244,6 +247,21 @@ int moe_prepare(MoeBlock& m, hipStream_t st)
     TM_REQUIRE((int)m.w13.size() == m.experts && (int)m.w2.size() == m.experts && m.gate, "moe: gate and every expert must be set");
     TM_TRY_RC(moe_build_groups(&m.groups13, m.w13.data(), m.experts, st));
     TM_TRY_RC(moe_build_groups(&m.groups2, m.w2.data(), m.experts, st));
+    if (fp8_mfma_supported(m.w13[0]) && fp8_mfma_supported(m.w2[0])) {  // device tables of the experts' P8 unit pointers
+        std::vector<const void*> h13(m.experts), h2(m.experts);
+        for (int e = 0; e < m.experts; ++e) {
+            TM_REQUIRE(m.w13[e].packed8 && m.w2[e].packed8, "moe: fp8 expert without its P8 image");
+            h13[e] = m.w13[e].packed8;
+            h2[e]  = m.w2[e].packed8;
+        }
+        if (!m.groups13_p8) {
+            TM_HIP_CHECK(hipMalloc(&m.groups13_p8, sizeof(void*) * m.experts));
+            TM_HIP_CHECK(hipMalloc(&m.groups2_p8, sizeof(void*) * m.experts));
+        }
+        TM_HIP_CHECK(hipMemcpyAsync(m.groups13_p8, h13.data(), sizeof(void*) * m.experts, hipMemcpyHostToDevice, st));
+        TM_HIP_CHECK(hipMemcpyAsync(m.groups2_p8, h2.data(), sizeof(void*) * m.experts, hipMemcpyHostToDevice, st));
+        TM_HIP_CHECK(hipStreamSynchronize(st));
+    }
     return 0;
 }
 
@@ -270,9 +288,30 @@ int moe_forward(const MoeBlock& m, half_t* out, int ldo, const half_t* x, int ld
     TM_TRY_RC(launch_moe_route(offs, f2n, en2f, ids, tokens, m.experts, m.top_k, st));
     // expert FFNs: gathered rows of x -> act (gated SiLU fused) -> y2, both grouped over the experts
     const int hint = (int)((pairs + m.experts - 1) / m.experts);  // expected rows per expert
-    TM_TRY_RC(launch_linear_grouped(m.w13[0], m.groups13, m.experts, x, ldx, tokens, act, m.inter, tokens, hint, true, offs, f2n, st));
-    TM_TRY_RC(launch_linear_grouped(m.w2[0], m.groups2, m.experts, act, m.inter, (int)pairs, y2, m.hidden, tokens, hint, false, offs,
-                                    nullptr, st));
+    if (m.groups13_p8) {
+        // e4m3 experts on the fp8 matrix cores (the reference's fp8 path: QuantizeSymm + fp8 GEMM, LlamaLinear.cu:67-127):
+        // x is quantised once per token, the gated-SiLU output once per (token, expert) row
+        o                  = (o + pairs * m.hidden * 2 + 255) / 256 * 256;
+        uint8_t*     xq    = (uint8_t*)(w + o);
+        const int    ldsx1 = (tokens + 3) / 4 * 4;
+        float*       sx1   = (float*)(xq + (size_t)tokens * m.hidden);
+        o                  = (o + fp8_act_workspace_bytes(tokens, m.hidden) + 255) / 256 * 256;
+        uint8_t*     aq    = (uint8_t*)(w + o);
+        const int    ldsx2 = ((int)pairs + 3) / 4 * 4;
+        float*       sx2   = (float*)(aq + pairs * m.inter);
+        TM_REQUIRE(ldx == m.hidden || tokens == 1, "moe fp8: x must be row-contiguous");
+        TM_TRY_RC(launch_quant_fp8_rows(xq, sx1, x, ldx, tokens, m.hidden, ldsx1, st));
+        TM_TRY_RC(launch_linear_fp8_grouped(m.w13[0], m.groups13_p8, m.experts, xq, sx1, ldsx1, tokens, act, m.inter, tokens, hint, true,
+                                            offs, f2n, st));
+        TM_TRY_RC(launch_quant_fp8_rows(aq, sx2, act, m.inter, (int)pairs, m.inter, ldsx2, st));
+        TM_TRY_RC(launch_linear_fp8_grouped(m.w2[0], m.groups2_p8, m.experts, aq, sx2, ldsx2, (int)pairs, y2, m.hidden, tokens, hint, false,
+                                            offs, nullptr, st));
+    }
+    else {
+        TM_TRY_RC(launch_linear_grouped(m.w13[0], m.groups13, m.experts, x, ldx, tokens, act, m.inter, tokens, hint, true, offs, f2n, st));
+        TM_TRY_RC(launch_linear_grouped(m.w2[0], m.groups2, m.experts, act, m.inter, (int)pairs, y2, m.hidden, tokens, hint, false, offs,
+                                        nullptr, st));
+    }
     TM_TRY_RC(launch_moe_combine(out, ldo, y2, m.hidden, tw, en2f, tokens, m.hidden, m.top_k, st));
     if (topk_ids_out) {
         TM_HIP_CHECK(hipMemcpyAsync(topk_ids_out, ids, pairs * 4, hipMemcpyDeviceToDevice, st));
@@ -291,13 +330,14 @@ void moe_free(MoeBlock& m)
     for (auto& l : m.w2) {
         linear_weight_free(l);
     }
-    for (void* q : {(void*)m.gate, m.groups13, m.groups2}) {
+    for (void* q : {(void*)m.gate, m.groups13, m.groups2, m.groups13_p8, m.groups2_p8}) {
         if (q) {
             (void)hipFree(q);
         }
     }
     m.gate = nullptr;
     m.groups13 = m.groups2 = nullptr;
+    m.groups13_p8 = m.groups2_p8 = nullptr;
 }
 
 }  // namespace tmk

@@ -109,6 +109,10 @@ struct LinearWeight {
     // with their (s, -z*s) pairs); `packed` / `sz` stay the layout of the M > 64 kernels
     void*     packed32 = nullptr;
     size_t    packed32_bytes = 0;
+    // fp8 only, N % 32 == 0: the fp8 x fp8 kernel's layout (gemm_fp8.hip, "P8": 4224-byte units of 32 columns x 128 k with
+    // their even / odd column block scales)
+    void*     packed8 = nullptr;
+    size_t    packed8_bytes = 0;
 };
 struct GemmConfig {
     int nt;      // n-tiles (16 cols) per wave: 1,2,4
@@ -126,6 +130,7 @@ int    linear_weight_prepare_fp8(LinearWeight& w, const uint8_t* weight /*[K][N]
                                  bool gated_scales /* w1w3: scale row = [w1 blocks | w3 blocks] for interleaved columns */, hipStream_t st);
 void   linear_weight_free(LinearWeight& w);
 size_t gemm_workspace_bytes(int M, int N, int splits);
+int    launch_splitk_reduce(half_t* y, int ldy, const float* partial, int splits, int M, int N, bool gated, hipStream_t st);
 GemmConfig gemm_pick_config(const LinearWeight& w, int M);          // decode kernel when it applies, else ...
 GemmConfig gemm_pick_config_general(const LinearWeight& w, int M);  // ... the tiling of gemm_kernel (gemm_w4a16.hip)
 // y[M][N (or N/2 if gated)] = x[M][K] . W ; if cfg.splits > 1 fp32 slabs land in `workspace` and, unless
@@ -140,6 +145,18 @@ bool   dec32_supported(const LinearWeight& w, int M);
 void   dec32_pick(const LinearWeight& w, int M, int* shape_out, int* splits_out);
 int    launch_linear_dec32(const LinearWeight& w, const half_t* x, int ldx, half_t* y, int ldy, int M, bool gated_silu, int shape,
                            int splits, float* workspace, int* slabs_out, hipStream_t st);
+
+// ---- gemm_fp8.hip: fp8 x fp8 linear on v_mfma_f32_32x32x16_fp8_fp8 (activations quantised per row and 128 channels) ---
+size_t p8_bytes(int K, int N);
+int    launch_repack_p8(void* out, const uint8_t* weight, const float* block_scales, int K, int N, bool gated, hipStream_t st);
+bool   fp8_mfma_supported(const LinearWeight& w);
+size_t fp8_act_workspace_bytes(int rows, int K);
+int    launch_quant_fp8_rows(uint8_t* xq, float* sx, const half_t* x, int ldx, int M, int K, int ldsx, hipStream_t st);
+int    launch_linear_fp8(const LinearWeight& w, const uint8_t* xq, const float* sx, int ldsx, half_t* y, int ldy, int M, bool gated_silu,
+                         int splits, float* workspace, int* slabs_out, hipStream_t st);
+int    launch_linear_fp8_grouped(const LinearWeight& proto, const void* d_groups, int E, const uint8_t* xq, const float* sx, int ldsx,
+                                 int x_rows, half_t* y, int ldy, int m_cap, int m_hint, bool gated_silu, const int* seg,
+                                 const int* row_idx, hipStream_t st);
 
 // sampling.hip: temperature / top-k / top-p / min-p sampling without a sort (see the file header)
 size_t sample_workspace_bytes(int batch);
@@ -166,6 +183,7 @@ struct MoeBlock {
     half_t*                   gate         = nullptr;  // device fp16 [hidden][experts]
     std::vector<LinearWeight> w13, w2;                 // per expert: gated (gate_j, up_j)-interleaved [H][2I], [I][H]
     void *                    groups13 = nullptr, *groups2 = nullptr;
+    void *                    groups13_p8 = nullptr, *groups2_p8 = nullptr;  // fp8 experts: P8 unit pointers (gemm_fp8.hip)
 };
 size_t moe_workspace_bytes(const MoeBlock& m, int tokens);
 int    moe_prepare(MoeBlock& m, hipStream_t st);

@@ -687,6 +687,9 @@ class ModelConfig:
     moe_top_k: int = 0
     moe_norm_topk: bool = True
     moe_routed_scale: float = 1.0
+    # fp8 experts contracted on fp8 matrix cores with on-the-fly activation quantisation (the reference's fp8 GEMM path,
+    # LlamaLinear.cu:67-127) instead of the weight-only dequant path; attention / dense linears stay weight-only
+    moe_fp8_act: bool = False
 
 
 LLAMA3_8B = dict(hidden=4096, layers=32, q_heads=32, kv_heads=8, head_dim=128, inter=14336, vocab=128256,
@@ -822,7 +825,10 @@ class OracleModel:
                     attn[sl] = prefill_attention(q, Kf, Vf, hist, self.c).reshape(n, -1)
             o = _linear(attn, Lw['wo'], cfg.group)
             resid, x = residual_rmsnorm(resid, o, Lw['ffn_norm'], cfg.rms_eps)
-            if cfg.moe_experts:
+            if cfg.moe_experts and cfg.moe_fp8_act and cfg.weight_format == 'fp8':
+                exq = [((E_['w1w3']['f8'], E_['w1w3']['bs']), (E_['w2']['f8'], E_['w2']['bs'])) for E_ in Lw['experts']]
+                d, _, _ = moe_ffn_fp8(x, Lw['moe_gate'], exq, cfg.moe_top_k, cfg.moe_norm_topk, cfg.moe_routed_scale)
+            elif cfg.moe_experts:
                 ex = [(_dense_weight(E_['w1w3'], cfg.group), _dense_weight(E_['w2'], cfg.group)) for E_ in Lw['experts']]
                 d, _, _ = moe_ffn(x, Lw['moe_gate'], ex, cfg.moe_top_k, cfg.moe_norm_topk, cfg.moe_routed_scale)
             else:
@@ -990,6 +996,79 @@ def fp8_quantize_blockwise(w: np.ndarray):
             scales[i, j] = sc
             q[i * 128:(i + 1) * 128, j * 128:(j + 1) * 128] = fp8_e4m3_from_f32(blk / sc)
     return q, scales
+
+
+# ------------------------------------------------------------------------------------------------
+# FP8 x FP8 linear: what the reference runs for e4m3 weights on fp8 matrix cores (SM90+) and what the MI355X path runs on
+# v_mfma_f32_32x32x16_fp8_fp8.  The activations are quantised on the fly, per row and per group of 128 input channels
+# (QuantizeSymm, src/turbomind/kernels/quantization.cu:28-63, called from LlamaLinear::GetOperandA,
+# models/llama/LlamaLinear.cu:67-93):  absmax = max(|x|) over the group, clamped to 1e-8;  scale = absmax / 448;
+# q = e4m3_rne_sat(f32(x) * (448 / absmax)).  The GEMM contracts codes with codes in fp32, one k-group (128) at a time, and
+# adds partial * (scale_x[m, g] * scale_w[g, n]) -- the weight scale is the fp32 128x128 block scale, NOT rounded to the
+# activation type as in the weight-only path above.
+# Unpinned to the last bit: the CUDA file is built with --use_fast_math (448 / absmax may differ by an ulp there).
+# ------------------------------------------------------------------------------------------------
+def fp8_quant_rows(x: np.ndarray, group: int = 128):
+    """x fp16 [M, K] -> (codes uint8 [M, K], scales fp32 [K/group, M]) (column-major scales, quantization.cu:50-52)"""
+    x = np.asarray(x, np.float16).astype(np.float32)
+    M, K = x.shape
+    assert K % group == 0
+    g = x.reshape(M, K // group, group)
+    absmax = np.maximum(np.abs(g).max(axis=2), np.float32(1e-8)).astype(np.float32)
+    scale = (absmax / np.float32(448.0)).astype(np.float32)
+    inv = (np.float32(448.0) / absmax).astype(np.float32)
+    q = fp8_e4m3_from_f32((g * inv[:, :, None]).astype(np.float32))
+    return q.reshape(M, K), np.ascontiguousarray(scale.T)
+
+
+def fp8_block_scales_f32(block_scales: np.ndarray, K: int, N: int, gated: bool = False) -> np.ndarray:
+    """[K/128][ceil(N/128)] fp32 -> per-column fp32 scales [K/128][N] (the gated interleave of fp8_expand_block_scales, no
+    rounding)"""
+    bs = np.asarray(block_scales, np.float32)
+    if not gated:
+        return np.repeat(bs, 128, axis=1)[:, :N]
+    assert N % 256 == 0 and bs.shape[1] == N // 128
+    half = bs.shape[1] // 2
+    out = np.empty((bs.shape[0], N), np.float32)
+    out[:, 0::2] = np.repeat(bs[:, :half], 128, axis=1)
+    out[:, 1::2] = np.repeat(bs[:, half:], 128, axis=1)
+    return out
+
+
+def fp8_act_linear_acc(x: np.ndarray, wq: np.ndarray, block_scales: np.ndarray, gated_scales: bool = False) -> np.ndarray:
+    """fp32 accumulators of the fp8 x fp8 linear: sum_g (xq_g . wq_g) * sx[g, m] * sw[g, n]"""
+    K, N = wq.shape
+    xq, sx = fp8_quant_rows(x)
+    a = fp8_e4m3_to_f32(xq)
+    w = fp8_e4m3_to_f32(wq)
+    sw = fp8_block_scales_f32(block_scales, K, N, gated_scales)
+    acc = np.zeros((a.shape[0], N), np.float32)
+    for g in range(K // 128):
+        part = a[:, g * 128:(g + 1) * 128] @ w[g * 128:(g + 1) * 128]
+        acc += part * (sx[g][:, None] * sw[g][None, :])
+    return acc
+
+
+def fp8_act_linear(x, wq, block_scales, gated: bool = False) -> np.ndarray:
+    """fp16 output (gated: the fused w1w3 linear with the gated-SiLU epilogue on the fp32 accumulators)"""
+    acc = fp8_act_linear_acc(x, wq, block_scales, gated)
+    return gated_silu_epilogue(acc) if gated else acc.astype(f16)
+
+
+def moe_ffn_fp8(x: np.ndarray, gate: np.ndarray, experts_q: list, top_k: int, norm_topk: bool = True, routed_scale: float = 1.0):
+    """moe_ffn with the fp8 x fp8 expert linears: experts_q[e] = ((w13 codes, w13 block scales), (w2 codes, w2 block scales));
+    the activations of BOTH expert projections are quantised per row and 128-channel group (x once per token, the
+    gated-SiLU output once per (token, expert) row)."""
+    _, ids, w = moe_gate(x, gate, top_k, norm_topk, routed_scale)
+    T, H = x.shape
+    out = np.zeros((T, H), np.float32)
+    for t in range(T):
+        for j in range(top_k):
+            (q13, s13), (q2, s2) = experts_q[ids[t, j]]
+            act = fp8_act_linear(x[t:t + 1], q13, s13, gated=True)
+            y = fp8_act_linear(act, q2, s2)
+            out[t] += w[t, j] * y[0].astype(np.float32)
+    return out.astype(np.float16), ids, w
 
 
 # ------------------------------------------------------------------------------------------------

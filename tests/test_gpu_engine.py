@@ -487,7 +487,7 @@ def test_engine_moe_matches_oracle(cuda, fmt):
     decode against the oracle model.  Same bar as test_engine_matches_oracle."""
     cfg = o.ModelConfig(hidden=256, layers=2, q_heads=4, kv_heads=2, head_dim=128, inter=256, vocab=512, kv_bits=8,
                         rope=o.RopeParam(128, 1000000.0, 'default', 1.0, 1.0, 4.0, 8192), weight_format=fmt,
-                        moe_experts=4, moe_top_k=2)
+                        moe_experts=4, moe_top_k=2, moe_fp8_act=True)   # fp8 experts run on the fp8 matrix cores
     w = o.make_synthetic_weights(cfg, seed=5)
     rng = np.random.default_rng(8)
     prompts = [rng.integers(0, cfg.vocab, n).astype(np.int32) for n in (70, 9, 33)]

@@ -727,16 +727,88 @@ def test_fp8_linear(tm, cuda, K, N):
     _ffi.check(tm.tm_linear_destroy(h))
 
 
-@pytest.mark.parametrize('wtype,T', [('fp8', 5), ('fp8', 64), ('fp8', 300), ('u4', 37)])
-def test_moe_ffn(tm, cuda, wtype, T):
+def test_fp8_quant_rows_bit_exact(tm, cuda):
+    """QuantizeSymm (kernels/quantization.cu:28-125): e4m3 codes and fp32 scales per (row, 128 channels) -- integer /
+    byte outputs, bit exact against the oracle, including an all-zero group (absmax clamp), a constant group, values at
+    the fp16 extremes and fp16 subnormals."""
+    rng = np.random.default_rng(17)
+    M, K = 37, 1024
+    x = (rng.standard_normal((M, K)) * rng.uniform(0.01, 30.0, (M, 1))).astype(f16)
+    x[3, 128:256] = 0
+    x[4, :128] = f16(0.75)
+    x[5, 7] = f16(65504.0)
+    x[6, 256:384] = (rng.standard_normal(128) * 1e-6).astype(f16)
+    ldsx = (M + 3) // 4 * 4
+    xq = torch.zeros((M, K), dtype=torch.uint8, device='cuda')
+    sx = torch.zeros((K // 128, ldsx), dtype=torch.float32, device='cuda')
+    _ffi.check(tm.tm_quant_fp8_rows(xq.data_ptr(), sx.data_ptr(), dev(x).data_ptr(), K, M, K, ldsx, st()))
+    q_ref, s_ref = o.fp8_quant_rows(x)
+    assert np.array_equal(host(sx)[:, :M].view(np.uint32), s_ref.view(np.uint32)), 'activation scales must be bit exact'
+    got = host(xq)
+    assert np.array_equal(got, q_ref), f'{int((got != q_ref).sum())} codes differ'
+
+
+@pytest.mark.parametrize('K,N', [(512, 256), (4096, 1024), (384, 64)])
+def test_fp8_mfma_linear(tm, cuda, K, N):
+    """fp8 x fp8 linear on v_mfma_f32_32x32x16_fp8_fp8 (gemm_fp8.hip) against the oracle's restatement of the reference's
+    fp8 GEMM path (activation quantisation per row and 128 channels + fp32 block-scaled accumulation): both sides contract
+    the SAME codes, so the tolerance is the u4 linear's (accumulation order only); split-K, row blocks, gated SiLU."""
+    rng = np.random.default_rng(K * 3 + N)
+    w = (rng.standard_normal((K, N)) * (0.1 / math.sqrt(K))).astype(f16)
+    q, sc = o.fp8_quantize_blockwise(w)
+    q[::37, ::11] = 0x01
+    q[5::53, 3::7] = 0xFE
+    h = _ffi.C.c_void_p()
+    _ffi.check(tm.tm_linear_create(_ffi.C.byref(h), K, N, 2, 128))
+    _ffi.check(tm.tm_linear_prepare(h, dev(q).data_ptr(), dev(sc).data_ptr(), None, st()))
+    torch.cuda.synchronize()
+    for M in (1, 17, 33, 64, 130):
+        x = (rng.standard_normal((M, K)) * rng.uniform(0.2, 4.0, (M, 1))).astype(f16)
+        ref = o.fp8_act_linear(x, q, sc).astype(np.float32)
+        ws = torch.zeros(tm.tm_linear_fp8_workspace(h, M), dtype=torch.uint8, device='cuda')
+        for splits in (0, 1, 2, 3):
+            if splits > max(1, K // 512):
+                continue
+            y = torch.zeros((M, N), dtype=torch.float16, device='cuda')
+            _ffi.check(tm.tm_linear_forward_fp8(h, dev(x).data_ptr(), K, y.data_ptr(), N, M, 0, splits, ws.data_ptr(), st()))
+            err = np.abs(host(y).astype(np.float32) - ref)
+            assert np.all(err <= 2e-3 + 2.0**-9 * np.abs(ref)), f'M={M} splits={splits}: max err {err.max()}'
+    if N % 256 == 0:   # the fused w1w3 form: (gate_j, up_j)-interleaved columns, scale row [w1 blocks | w3 blocks]
+        w1, w3 = w[:, :N // 2], w[:, N // 2:]
+        (q1, s1), (q3, s3) = o.fp8_quantize_blockwise(w1), o.fp8_quantize_blockwise(w3)
+        q13, s13 = o.interleave_w1w3(q1, q3), np.concatenate([s1, s3], axis=1)
+        hg = _ffi.C.c_void_p()
+        _ffi.check(tm.tm_linear_create(_ffi.C.byref(hg), K, N, 2, 128))
+        _ffi.check(tm.tm_linear_prepare_fp8_gated(hg, dev(q13).data_ptr(), dev(s13).data_ptr(), st()))
+        torch.cuda.synchronize()
+        x = (rng.standard_normal((40, K)) * 2).astype(f16)
+        ref = o.fp8_act_linear(x, q13, s13, gated=True).astype(np.float32)
+        ws = torch.zeros(tm.tm_linear_fp8_workspace(hg, 40), dtype=torch.uint8, device='cuda')
+        y = torch.zeros((40, N // 2), dtype=torch.float16, device='cuda')
+        _ffi.check(tm.tm_linear_forward_fp8(hg, dev(x).data_ptr(), K, y.data_ptr(), N // 2, 40, 1, 1, ws.data_ptr(), st()))
+        err = np.abs(host(y).astype(np.float32) - ref)
+        assert np.all(err <= 2e-3 + 2.0**-8 * np.abs(ref)), f'gated: max err {err.max()}'
+        _ffi.check(tm.tm_linear_destroy(hg))
+    _ffi.check(tm.tm_linear_destroy(h))
+
+
+@pytest.mark.parametrize('wtype,T', [('fp8', 5), ('fp8', 64), ('fp8', 300), ('u4', 37), ('fp8wo', 5), ('fp8wo', 300)])
+def test_moe_ffn(tm, cuda, monkeypatch, wtype, T):
     """MoE FFN block (router + top-2 of 8 + grouped expert GEMMs + combine; BASELINE config 5 scaled down) against the
     oracle: identical routing (expert ids), weights to 1e-5, output within the dense FFN's tolerance.  T = 300 runs
     the prefill-shaped grouped GEMM (row blocks per expert), the others the decode shape."""
+    # 'fp8': e4m3 experts on the fp8 matrix cores with on-the-fly activation quantisation (the default for fp8 experts);
+    # 'fp8wo': the weight-only dequant path (TM_FP8_MFMA=0)
+    mfma = wtype == 'fp8'
+    if wtype == 'fp8wo':
+        monkeypatch.setenv('TM_FP8_MFMA', '0')
+        wtype = 'fp8'
     rng = np.random.default_rng(T)
     H, I, E, k = 256, 384, 8, 2
     x = rng.standard_normal((T, H)).astype(f16)
     gate = (rng.standard_normal((H, E)) * 0.2).astype(f16)
     h = _ffi.C.c_void_p()
+    experts_q = []
     _ffi.check(tm.tm_moe_create(_ffi.C.byref(h), H, I, E, k, 2 if wtype == 'fp8' else 0, 1, 1.0))
     _ffi.check(tm.tm_moe_set_gate(h, dev(gate).data_ptr(), st()))
     experts = []
@@ -751,6 +823,7 @@ def test_moe_ffn(tm, cuda, wtype, T):
             q13, s13 = o.interleave_w1w3(q1, q3), np.concatenate([s1, s3], axis=1)
             q2, s2 = o.fp8_quantize_blockwise(w2)
             experts.append((o.fp8_dequant(q13, s13, gated=True), o.fp8_dequant(q2, s2)))
+            experts_q.append(((q13, s13), (q2, s2)))
             _ffi.check(tm.tm_moe_set_expert(h, e, dev(q13).data_ptr(), dev(s13).data_ptr(), None, dev(q2).data_ptr(),
                                             dev(s2).data_ptr(), None, st()))
         else:
@@ -765,11 +838,14 @@ def test_moe_ffn(tm, cuda, wtype, T):
     ids_d = torch.zeros((T, k), dtype=torch.int32, device='cuda')
     w_d = torch.zeros((T, k), dtype=torch.float32, device='cuda')
     _ffi.check(tm.tm_moe_forward(h, out.data_ptr(), dev(x).data_ptr(), T, ws.data_ptr(), ids_d.data_ptr(), w_d.data_ptr(), st()))
-    ref, ids, w = o.moe_ffn(x, gate, experts, k)
+    ref, ids, w = o.moe_ffn_fp8(x, gate, experts_q, k) if mfma else o.moe_ffn(x, gate, experts, k)
     assert np.array_equal(host(ids_d), ids), 'routing differs'
     assert np.abs(host(w_d) - w).max() <= 1e-5
     err = np.abs(host(out).astype(np.float32) - ref.astype(np.float32))
-    assert np.all(err <= 3e-3 + 2.0**-8 * np.abs(ref.astype(np.float32))), f'max err {err.max()}'
+    # fp8 x fp8: the gated-SiLU rows are re-quantised to e4m3 (one code step = 2^-3 relative); an fp32-order difference that
+    # flips an fp16 ulp of such a row can move a code, hence the wider relative term
+    tol = (4e-3 + 2.0**-6 * np.abs(ref.astype(np.float32))) if mfma else (3e-3 + 2.0**-8 * np.abs(ref.astype(np.float32)))
+    assert np.all(err <= tol), f'max err {err.max()}'
     _ffi.check(tm.tm_moe_destroy(h))
 
 
