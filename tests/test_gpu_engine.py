@@ -173,6 +173,53 @@ def test_continuous_batching_matches_static(cuda, slots):
     eng.close()
 
 
+@pytest.mark.parametrize('kv_bits', [8, 4])
+def test_continuous_batching_matches_oracle(cuda, kv_bits):
+    """The scheduler path against the ORACLE (not against the engine's own static path): 8 requests of different prompt and
+    generation lengths through 3 batch slots (admissions join a running batch, slots and KV blocks are reused, one prompt
+    is chunked); every request's token stream is replayed through the oracle model alone (batch 1, teacher-forced with
+    the engine's tokens) and every engine token must be the arg-max of the oracle's logits wherever the oracle's top-2
+    margin exceeds the end-to-end logit tolerance (3e-2, as in test_engine_matches_oracle)."""
+    cfg = o.ModelConfig(hidden=256, layers=2, q_heads=4, kv_heads=2, head_dim=128, inter=512, vocab=1024,
+                        kv_bits=kv_bits, rope=o.RopeParam(128, 500000.0, 'llama3', 8.0, 1.0, 4.0, 8192))
+    w = o.make_synthetic_weights(cfg, seed=13)
+    rng = np.random.default_rng(6)
+    lens = [70, 5, 64, 33, 150, 9, 1, 40]
+    news = [6, 12, 3, 9, 5, 14, 8, 2]
+    prompts = [rng.integers(0, cfg.vocab, n).astype(np.int32) for n in lens]
+    eng = Engine.from_model_config(cfg, max_batch_size=3, session_len=256, quant_policy=kv_bits, max_prefill_token_num=96)
+    eng.load_weights(export_weights(cfg, w))
+    eng.start()
+    ids = [eng.submit(p, n, -1) for p, n in zip(prompts, news)]
+    done, steps = {}, 0
+    while len(done) < len(ids):
+        eng.step()
+        steps += 1
+        assert steps < 400, 'scheduler does not make progress'
+        for i, rid in enumerate(ids):
+            if i not in done:
+                st, toks = eng.poll(rid)
+                if st != 0:
+                    done[i] = (st, toks.copy())
+    eng.close()
+    checked = 0
+    for i, (st, toks) in done.items():
+        assert st == 7 and len(toks) == news[i], f'request {i}: status {st}, {len(toks)} tokens'
+        om = o.OracleModel(cfg, w, batch=1, max_ctx=256)
+        feed = [prompts[i]]
+        for k in range(news[i]):
+            _, lg = om.forward(feed)
+            row = lg[0].astype(np.float32)
+            top2 = np.sort(row)[-2:]
+            if top2[1] - top2[0] > 6e-2:
+                assert int(toks[k]) == int(np.argmax(row)), f'request {i} token {k}: engine {toks[k]} oracle {np.argmax(row)}'
+                checked += 1
+            else:   # near tie: the engine's token must at least be one of the two leaders
+                assert row[int(toks[k])] >= top2[0] - 3e-2
+            feed = [[int(toks[k])]]
+    assert checked >= sum(news) // 2
+
+
 def test_engine_thread_serving(cuda):
     """The engine thread (tm_engine_serve_start; reference: Engine::Impl::InternalThreadEntry + the signal thread's
     callback contract, engine.cc:770-870, turbomind.py:808-812): 9 requests submitted concurrently from 3 Python
