@@ -194,6 +194,12 @@ def main():
         uid = [Engine.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(uid, src=0)
         eng.comm_init(uid[0])
+        if os.environ.get('TM_COMM', 'rccl') == 'native':     # fused P2P all-reduce + norm for the decode steps (opt-in)
+            def gather(h):
+                out = [None] * world
+                dist.all_gather_object(out, h)
+                return out
+            eng.comm_native_setup(gather, rows=max(B, 1))
     elif emu > 1:
         eng.comm_init(Engine.comm_unique_id())
     eng.init_synthetic(seed=0)          # same seed on every rank: shards are generated per rank-local shape

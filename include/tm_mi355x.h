@@ -207,6 +207,27 @@ int    tm_moe_destroy(tm_moe* m);
 int tm_quantize_groupwise(void* qweight, void* scales, void* zeros, void* dequant, const void* w, int K, int N,
                           int group_size, tm_stream_t st);
 
+/* ---- native point-to-point communicator (the reference's comm/cuda_ipc backend; RCCL stays the default) ----------------
+ * Fused one-shot all-reduce + residual + RMSNorm over peer-mapped segments: replaces AllreduceResidualBiasRMSnorm
+ * (src/turbomind/comm/cuda_ipc/fused_allreduce.cu:406-500, exchange as in allreduce.cu:249-343) and, for the lm_head's
+ * (value, index) candidates, AllGather (comm/cuda_ipc/allgather.cu).  Every rank owns a symmetric segment of
+ * tm_p2p_segment_bytes(rows, H) bytes -- [256 B of flags | tile 0 | tile 1], a tile = rows x H fp16 -- that its peers
+ * map: tm_p2p_segment_create allocates it (zeroed) and returns a 64-byte IPC handle, tm_p2p_segment_open maps a peer's
+ * handle (another PROCESS: one process per GPU), tm_p2p_segment_close unmaps (opened = 1) or frees (opened = 0).
+ * segs[r] = rank r's segment as seen from this rank (segs[me] = the local one); state = 4 zeroed local words (the rank's call
+ * counter and tickets).  Every rank must issue the same sequence of tm_p2p_* calls.
+ * tm_p2p_allreduce_norm: y = RMSNorm(resid += fp16(sum_r partial_r)), M <= rows; rank-ordered fp32 sum, so every rank
+ * holds the same bits.  tm_p2p_allgather: dst[r][0..words) = rank r's src (32-bit words, words * 4 <= tile bytes).
+ * A rank that waits longer than ~1 s for a peer gives up, writes the call number into state[3] and returns garbage. */
+size_t tm_p2p_segment_bytes(int rows, int H);
+int tm_p2p_segment_create(size_t bytes, void** dev_ptr, void* handle64);
+int tm_p2p_segment_open(const void* handle64, void** dev_ptr);
+int tm_p2p_segment_close(void* dev_ptr, int opened);
+int tm_p2p_allreduce_norm(void* const* segs, int tp, int me, void* state, int rows, const void* partial, void* y, void* resid,
+                          const void* weight, float eps, int M, int H, tm_stream_t st);
+int tm_p2p_allgather(void* const* segs, int tp, int me, void* state, int rows, int H, const void* src, void* dst, int words,
+                     tm_stream_t st);
+
 /* debug / measurement: device buffer of [workgroups][4] uint64 that receives s_memrealtime stamps (100 MHz:
  * kernel entry, loop entry, loop exit, exit) of every GEMM workgroup launched afterwards; NULL switches it off. */
 int tm_debug_set_gemm_trace(void* dev_buf);
@@ -253,6 +274,10 @@ int tm_engine_destroy(tm_engine* e);
  * (torch.distributed / TCPStore), then every rank calls tm_engine_comm_init. */
 int tm_comm_unique_id(void* host_out128);
 int tm_engine_comm_init(tm_engine* e, const void* host_id128);
+/* native communicator (opt-in; see tm_p2p_* below): export = allocate this rank's segment, return its IPC handle; import =
+ * map the tp ranks' handles (rank order) and route the row-parallel all-reduces of forwards with <= rows tokens through it */
+int tm_engine_comm_native_export(tm_engine* e, int rows, void* handle64);              /* after tm_engine_comm_init */
+int tm_engine_comm_native_import(tm_engine* e, const void* handles, int count);        /* count = tp handles, rank order */
 
 /* Weight hand-off: named Param slots, already TP-sharded / QKV-fused / w1w3-interleaved by the loader
  * (lmdeploy/turbomind/builders/_base.py:72-113).  Names: "layers.{i}.attention.w_qkv.{qweight,scales,zeros}",

@@ -114,6 +114,15 @@ _SIGNATURES = {
     'tm_quantize_groupwise': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                                       c_void_p]),
     'tm_debug_set_gemm_trace': (c_int, [c_void_p]),
+    'tm_engine_comm_native_export': (c_int, [c_void_p, c_int, c_void_p]),
+    'tm_engine_comm_native_import': (c_int, [c_void_p, c_void_p, c_int]),
+    'tm_p2p_segment_create': (c_int, [c_size_t, POINTER(c_void_p), c_void_p]),
+    'tm_p2p_segment_open': (c_int, [c_void_p, POINTER(c_void_p)]),
+    'tm_p2p_segment_close': (c_int, [c_void_p, c_int]),
+    'tm_p2p_segment_bytes': (c_size_t, [c_int, c_int]),
+    'tm_p2p_allreduce_norm': (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int,
+                               c_int, c_void_p]),
+    'tm_p2p_allgather': (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p]),
     'tm_engine_create': (c_int, [POINTER(c_void_p), POINTER(EngineConfig)]),
     'tm_engine_destroy': (c_int, [c_void_p]),
     'tm_comm_unique_id': (c_int, [c_void_p]),

@@ -10,6 +10,7 @@
     } while (0)
 #include "tm_common.h"
 #include "tm_kernels.h"
+#include <string.h>
 #include <cmath>
 #include <vector>
 
@@ -579,6 +580,85 @@ int tm_sched_abort_all(tm_sched* s, int status)
     TM_REQUIRE(status != 0, "abort status must be non-zero");
     s->impl.abort_all(status);
     return 0;
+}
+
+/* ---- native P2P communicator pieces (comm_p2p.hip) --------------------------------------------------------------------- */
+int tm_p2p_segment_create(size_t bytes, void** dev_ptr, void* handle64)
+{
+    TM_REQUIRE(dev_ptr && handle64 && bytes > 0, "null pointer");
+    static_assert(sizeof(hipIpcMemHandle_t) == 64, "IPC handle size");
+    void* p = nullptr;
+    // flags are polled mid-kernel by other devices: fine-grained (uncached across devices) memory when the runtime offers it
+    if (hipExtMallocWithFlags(&p, bytes, hipDeviceMallocFinegrained) != hipSuccess) {
+        (void)hipGetLastError();
+        TM_HIP_CHECK(hipMalloc(&p, bytes));
+    }
+    TM_HIP_CHECK(hipMemset(p, 0, bytes));
+    TM_HIP_CHECK(hipDeviceSynchronize());
+    hipIpcMemHandle_t h;
+    TM_HIP_CHECK(hipIpcGetMemHandle(&h, p));
+    memcpy(handle64, &h, sizeof(h));
+    *dev_ptr = p;
+    return 0;
+}
+
+int tm_p2p_segment_open(const void* handle64, void** dev_ptr)
+{
+    TM_REQUIRE(dev_ptr && handle64, "null pointer");
+    hipIpcMemHandle_t h;
+    memcpy(&h, handle64, sizeof(h));
+    TM_HIP_CHECK(hipIpcOpenMemHandle(dev_ptr, h, hipIpcMemLazyEnablePeerAccess));
+    return 0;
+}
+
+int tm_p2p_segment_close(void* dev_ptr, int opened)
+{
+    if (!dev_ptr) {
+        return 0;
+    }
+    if (opened) {
+        TM_HIP_CHECK(hipIpcCloseMemHandle(dev_ptr));
+    }
+    else {
+        TM_HIP_CHECK(hipFree(dev_ptr));
+    }
+    return 0;
+}
+
+size_t tm_p2p_segment_bytes(int rows, int H)
+{
+    return 256 + 2 * (size_t)rows * (size_t)H * sizeof(half_t);
+}
+
+static void p2p_tables(void* const* segs, int tp, half_t** data, uint32_t** flags)
+{
+    for (int r = 0; r < tp && r < 8; ++r) {
+        flags[r] = (uint32_t*)segs[r];
+        data[r]  = (half_t*)((char*)segs[r] + 256);
+    }
+}
+
+int tm_p2p_allreduce_norm(void* const* segs, int tp, int me, void* state, int rows, const void* partial, void* y, void* resid,
+                          const void* weight, float eps, int M, int H, tm_stream_t st)
+{
+    TM_REQUIRE(segs && state && partial && y && resid && weight, "null pointer");
+    TM_REQUIRE(tp >= 1 && tp <= 8, "p2p: 1 <= tp <= 8");
+    half_t*   data[8];
+    uint32_t* flags[8];
+    p2p_tables(segs, tp, data, flags);
+    return launch_p2p_allreduce_norm(data, flags, tp, me, (uint32_t*)state, (size_t)rows * H, (const half_t*)partial, (half_t*)y,
+                                     (half_t*)resid, (const half_t*)weight, eps, M, H, (hipStream_t)st);
+}
+
+int tm_p2p_allgather(void* const* segs, int tp, int me, void* state, int rows, int H, const void* src, void* dst, int words,
+                     tm_stream_t st)
+{
+    TM_REQUIRE(segs && state && src && dst, "null pointer");
+    TM_REQUIRE(tp >= 1 && tp <= 8, "p2p: 1 <= tp <= 8");
+    half_t*   data[8];
+    uint32_t* flags[8];
+    p2p_tables(segs, tp, data, flags);
+    return launch_p2p_allgather(data, flags, tp, me, (uint32_t*)state, (size_t)rows * H, src, dst, words, (hipStream_t)st);
 }
 
 int tm_debug_set_gemm_trace(void* dev_buf)

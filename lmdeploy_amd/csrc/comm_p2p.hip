@@ -1,0 +1,266 @@
+// Fused all-reduce + residual + RMSNorm over peer-mapped buffers (xGMI point-to-point), the TM_COMM=native arm beside RCCL.
+//
+// Replaces: AllreduceResidualBiasRMSnorm of the native communicator -- src/turbomind/comm/cuda_ipc/fused_allreduce.cu:406-500
+//           (one kernel: reduce the ranks' partial [M,H] tiles, add the residual, RMSNorm) with the one-shot exchange of
+//           comm/cuda_ipc/allreduce.cu:249-343 (every rank reads every peer's buffer; for messages <= 1 MB the latency of ONE
+//           exchange beats reduce-scatter + all-gather).  RCCL's ring needs 2(tp-1) hops of >= 2 us each for a 512 KB message
+//           and a separate norm launch; here a decode all-reduce is one launch and one exchange.
+// Arithmetic: h = fp16( sum over ranks r = 0..tp-1 (in rank order, fp32) of partial_r )   -- the same association on every
+//             rank, so all ranks hold bit-identical hidden states;
+//             then exactly rmsnorm_kernel<1>: r = h(resid + h); inv = rsqrt(mean f32(r)^2 + eps); y = h(h(f32(r) * inv) * w).
+//
+// Protocol (one launch per rank, the same grid everywhere; `partial` is the local [M][H] tile the preceding GEMM wrote):
+//   0. every workgroup copies its row of `partial` into buffer (epoch & 1) of the rank's symmetric segment -- the buffer is
+//      chosen ON THE DEVICE from the rank's call counter, so hipGraph replays, chunked prefills and interleaved all-gathers
+//      keep the strict alternation the reuse argument below needs without any host-side bookkeeping;
+//   1. every workgroup makes its XCD's L2 write the tile back at SYSTEM scope (release fence) and takes a ticket; the
+//      workgroup that draws the last ticket stores the call's epoch into slot [me] of EVERY peer's flag array;
+//   2. every workgroup polls its OWN flag array (relaxed system-scope loads + s_sleep, bounded) until all tp slots show
+//      the epoch, then one system-scope acquire;
+//   3. one workgroup per token row sums the tp partial rows (peer rows come over xGMI with non-temporal 16-byte loads),
+//      adds the residual, normalises, stores residual + normed row locally;
+//   4. the workgroup with the last exit ticket advances the rank's epoch word.
+// No trailing barrier: a rank can only pass step 2 of call c+1 after every peer has ENTERED call c+1, i.e. finished reading
+// buffer (c & 1) -- by the time this rank overwrites that buffer (step 0 of call c+2) nobody reads it any more.
+// p2p_allgather_kernel runs the same steps 0-2 and 4 around a copy of every rank's n bytes (the lm_head's (value, index)
+// candidates); every rank issues the same sequence of calls, so both kernels share the epoch counter.
+// Every spin is bounded: on a timeout the kernel records the epoch in state[3] and carries on (wrong numbers, no hang).
+//
+// Status: protocol and arithmetic run on ONE GPU only in this round -- tests/test_gpu_p2p.py (tp ranks = tp streams, and tp
+// PROCESSES that map each other's segments through IPC handles) and tests/test_gpu_tp.py (a tp = 2 engine as two processes
+// on cuda:0, no RCCL) -- plus the CPU restatement oracle.p2p_allreduce_norm.  The xGMI hop itself (system-scope visibility
+// between devices) has not run on multi-GPU hardware: RCCL stays the default, TM_COMM=native opts in.
+#include "tm_common.h"
+#include "tm_kernels.h"
+
+namespace tmk {
+
+struct P2pParams {
+    half_t*       data[8];   // the two-tile region of rank r's segment (peer-mapped; [me] = local)
+    uint32_t*     flags[8];  // flag array [8] of rank r, peer-mapped
+    int           tp, me;
+    uint32_t*     state;    // local: [0] epoch of the last finished call, [1] entry tickets, [2] exit tickets, [3] timeout mark
+    size_t        tile;     // elements between buffer 0 and buffer 1
+    const half_t* partial;  // [M][H] this rank's partial sums (local)
+    half_t*       y;        // [M][H] normed output (local)
+    half_t*       resid;    // [M][H] residual stream (local, in place)
+    const half_t* weight;
+    float         eps;
+    int           M, H;
+    const uint32_t* src;    // all-gather: n words of this rank
+    uint32_t*       dst;    // all-gather: [tp][n] words
+    int             n;
+};
+
+constexpr uint32_t kSpinLimit = 1u << 20;  // ~1 s of polling
+
+// steps 1 + 2; the caller's writes into its own segment buffer precede (a __syncthreads in between)
+__device__ __forceinline__ void p2p_publish_and_wait(const P2pParams& p, uint32_t epoch)
+{
+    const int tid = threadIdx.x;
+    if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");  // system scope: this XCD's dirty lines of the tile leave the L2
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const uint32_t t = __hip_atomic_fetch_add(p.state + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (t == gridDim.x - 1) {  // every workgroup (hence every XCD that ran one) has written back
+            __hip_atomic_store(p.state + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int r = 0; r < p.tp; ++r) {
+                __hip_atomic_store(p.flags[r] + p.me, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
+    }
+    if (tid < p.tp) {
+        uint32_t spins = 0;
+        // ">= epoch" (wrap-safe), not "== epoch": a peer that has already left this call may have published the NEXT epoch
+        // before this workgroup got to look (it can be one call ahead, never two: see the reuse argument in the header)
+        while ((int32_t)(__hip_atomic_load(p.flags[p.me] + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - epoch) < 0) {
+            __builtin_amdgcn_s_sleep(2);
+            if (++spins > kSpinLimit) {
+                __hip_atomic_store(p.state + 3, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");  // system scope
+    }
+    __syncthreads();
+}
+
+// step 4
+__device__ __forceinline__ void p2p_exit(const P2pParams& p, uint32_t epoch)
+{
+    if (threadIdx.x == 0) {
+        const uint32_t t = __hip_atomic_fetch_add(p.state + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (t == gridDim.x - 1) {
+            __hip_atomic_store(p.state + 2, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(p.state, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+template<int NV>
+__global__ __launch_bounds__(512) void p2p_allreduce_norm_kernel(P2pParams p)
+{
+    __shared__ float    red[8];
+    __shared__ uint32_t s_epoch;
+    const int tid = threadIdx.x;
+    if (tid == 0) {
+        s_epoch = __hip_atomic_load(p.state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
+    }
+    __syncthreads();
+    const uint32_t epoch = s_epoch;
+    const size_t   boff  = (size_t)(epoch & 1) * p.tile;
+
+    const int row  = blockIdx.x;
+    const int nvec = p.H / 8;
+    half8_t   wv[NV], r[NV];
+    size_t    off[NV];
+    bool      ok[NV];
+    // ---- 0. own partial row -> own segment; the loads that do not depend on the peers are issued here as well -------------
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int vi = tid + i * blockDim.x;
+        ok[i]        = vi < nvec;
+        const int vc = ok[i] ? vi : nvec - 1;
+        off[i]       = (size_t)row * p.H + (size_t)vc * 8;
+        const half8_t mine = *(const half8_t*)(p.partial + off[i]);
+        wv[i]        = *(const half8_t*)(p.weight + (size_t)vc * 8);
+        r[i]         = *(const half8_t*)(p.resid + off[i]);
+        if (ok[i]) {
+            *(half8_t*)(p.data[p.me] + boff + off[i]) = mine;
+        }
+    }
+    __syncthreads();
+    // ---- 1 + 2 ------------------------------------------------------------------------------------------------------------
+    p2p_publish_and_wait(p, epoch);
+
+    // ---- 3. reduce + residual + RMSNorm of row blockIdx.x (rmsnorm_kernel<1> arithmetic) ---------------------------------
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        float acc[8] = {};
+        for (int q = 0; q < p.tp; ++q) {  // rank order: the same association on every rank
+            const u32x4   raw = __builtin_nontemporal_load((const u32x4*)(p.data[q] + boff + off[i]));
+            const half8_t v   = bit_cast<half8_t>(raw);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                acc[e] += (float)v[e];
+            }
+        }
+        half8_t h;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            h[e] = (half_t)acc[e];
+        }
+        r[i] = r[i] + h;
+        if (ok[i]) {
+            *(half8_t*)(p.resid + off[i]) = r[i];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float f = (float)r[i][e];
+                ss            = __builtin_fmaf(f, f, ss);
+            }
+        }
+    }
+    ss = group_sum<64>(ss);
+    if ((tid & 63) == 0) {
+        red[tid >> 6] = ss;
+    }
+    __syncthreads();
+    float tot = 0.f;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) {
+        tot += red[w];
+    }
+    const float inv = 1.0f / __builtin_sqrtf(tot / (float)p.H + p.eps);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        if (ok[i]) {
+            half8_t o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const half_t n = (half_t)((float)r[i][e] * inv);
+                o[e]           = n * wv[i][e];
+            }
+            *(half8_t*)(p.y + off[i]) = o;
+        }
+    }
+    p2p_exit(p, epoch);
+}
+
+// all-gather of n 32-bit words per rank through the same segments (one workgroup)
+__global__ __launch_bounds__(256) void p2p_allgather_kernel(P2pParams p)
+{
+    __shared__ uint32_t s_epoch;
+    const int tid = threadIdx.x;
+    if (tid == 0) {
+        s_epoch = __hip_atomic_load(p.state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
+    }
+    __syncthreads();
+    const uint32_t epoch = s_epoch;
+    const size_t   boff  = (size_t)(epoch & 1) * p.tile;
+    uint32_t*      mine  = (uint32_t*)(p.data[p.me] + boff);
+    for (int i = tid; i < p.n; i += blockDim.x) {
+        mine[i] = p.src[i];
+    }
+    __syncthreads();
+    p2p_publish_and_wait(p, epoch);
+    for (int q = 0; q < p.tp; ++q) {
+        const uint32_t* theirs = (const uint32_t*)(p.data[q] + boff);
+        for (int i = tid; i < p.n; i += blockDim.x) {
+            p.dst[(size_t)q * p.n + i] = __builtin_nontemporal_load(theirs + i);
+        }
+    }
+    p2p_exit(p, epoch);
+}
+
+// data[r]: the two-tile region (2 * tile elements) of rank r's segment, flags[r]: its flag array, both as mapped by THIS rank
+// (index me = local pointers); state: 4 zero-initialised local words; partial: this rank's [M][H] sums, M <= tile / H rows
+int launch_p2p_allreduce_norm(half_t* const* data, uint32_t* const* flags, int tp, int me, uint32_t* state, size_t tile,
+                              const half_t* partial, half_t* y, half_t* resid, const half_t* weight, float eps, int M, int H,
+                              hipStream_t st)
+{
+    TM_REQUIRE(tp >= 1 && tp <= 8 && me >= 0 && me < tp, "p2p all-reduce: 1 <= tp <= 8");
+    TM_REQUIRE(H % 8 == 0 && H <= 8192, "p2p all-reduce: H % 8 == 0, H <= 8192");
+    TM_REQUIRE((size_t)M * H <= tile && tile % 8 == 0, "p2p all-reduce: the tile does not fit the segment buffer");
+    if (M == 0) {
+        return 0;
+    }
+    P2pParams p{};
+    for (int r = 0; r < tp; ++r) {
+        p.data[r]  = data[r];
+        p.flags[r] = flags[r];
+    }
+    p.tp = tp, p.me = me, p.state = state, p.tile = tile, p.partial = partial, p.y = y, p.resid = resid, p.weight = weight;
+    p.eps = eps, p.M = M, p.H = H;
+    const int nvec = H / 8;
+    int       t    = (nvec + 63) / 64 * 64;
+    t              = t > 512 ? 512 : t;
+    if ((nvec + t - 1) / t == 1) {
+        p2p_allreduce_norm_kernel<1><<<M, t, 0, st>>>(p);
+    }
+    else {
+        p2p_allreduce_norm_kernel<2><<<M, t, 0, st>>>(p);
+    }
+    TM_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int launch_p2p_allgather(half_t* const* data, uint32_t* const* flags, int tp, int me, uint32_t* state, size_t tile, const void* src,
+                         void* dst, int words, hipStream_t st)
+{
+    TM_REQUIRE(tp >= 1 && tp <= 8 && me >= 0 && me < tp, "p2p all-gather: 1 <= tp <= 8");
+    TM_REQUIRE((size_t)words * 2 <= tile, "p2p all-gather: message larger than the segment buffer");
+    if (words == 0) {
+        return 0;
+    }
+    P2pParams p{};
+    for (int r = 0; r < tp; ++r) {
+        p.data[r]  = data[r];
+        p.flags[r] = flags[r];
+    }
+    p.tp = tp, p.me = me, p.state = state, p.tile = tile, p.src = (const uint32_t*)src, p.dst = (uint32_t*)dst, p.n = words;
+    p2p_allgather_kernel<<<1, 256, 0, st>>>(p);
+    TM_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+}  // namespace tmk

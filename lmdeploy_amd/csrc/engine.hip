@@ -202,6 +202,13 @@ struct tm_engine {
     // stream pulls the NEXT linear's weights towards the Infinity Cache (weight_prefetch_kernel)
     hipStream_t  comm_stream = nullptr;
     hipEvent_t   ev_fork = nullptr, ev_join = nullptr;
+    // native communicator (TM_COMM=native, comm_p2p.hip): this rank's symmetric segment [flags 256 B | tile 0 | tile 1] and the
+    // peers' mappings of theirs; serves the row-parallel all-reduces of forwards with M <= p2p_rows, RCCL the rest
+    void*        p2p_seg = nullptr;
+    void*        p2p_peer[8] = {};
+    uint32_t*    p2p_state = nullptr;
+    int          p2p_rows = 0;
+    bool         p2p_ready = false;
     bool         comm_overlap = true;    // TM_COMM_STREAM=0: collectives on the engine stream (round-1 behaviour)
     bool         comm_prefetch = true;   // TM_COMM_PREFETCH=0: no weight prefetch under the collective
     bool         graph_comm_failed = false;  // capturing the RCCL calls failed once: stay eager
@@ -505,6 +512,39 @@ static size_t prof_event(tm_engine* e)
         }                                                                                          \
     } while (0)
 
+static void p2p_tables(tm_engine* e, half_t** data, uint32_t** flags)
+{
+    for (int r = 0; r < e->cfg.tp; ++r) {
+        char* base = (char*)(r == e->cfg.rank ? e->p2p_seg : e->p2p_peer[r]);
+        flags[r]   = (uint32_t*)base;
+        data[r]    = (half_t*)(base + 256);
+    }
+}
+
+// d_x = RMSNorm(d_resid += sum over ranks of d_tmp): one fused P2P launch per <= p2p_rows rows on the native communicator
+// (any M when there is no RCCL communicator to fall back to), else RCCL all-reduce + the residual-norm kernel
+static int reduce_residual_norm(tm_engine* e, int M, const half_t* norm_w, const LinearWeight* next)
+{
+    if (e->p2p_ready && (M <= e->p2p_rows || !e->comm)) {
+        half_t*   data[8];
+        uint32_t* flags[8];
+        p2p_tables(e, data, flags);
+        const size_t tile = (size_t)e->p2p_rows * e->hidden;
+        for (int m0 = 0; m0 < M; m0 += e->p2p_rows) {
+            const int    rows = std::min(e->p2p_rows, M - m0);
+            const size_t off  = (size_t)m0 * e->hidden;
+            TM_PROF(P_ALLREDUCE, TM_TRY(launch_p2p_allreduce_norm(data, flags, e->cfg.tp, e->cfg.rank, e->p2p_state, tile, e->d_tmp + off,
+                                                                  e->d_x + off, e->d_resid + off, norm_w, e->cfg.model.rms_eps, rows,
+                                                                  e->hidden, e->stream)));
+        }
+        return 0;
+    }
+    TM_PROF(P_ALLREDUCE, TM_TRY(allreduce_hidden(e, e->d_tmp, M, next)));
+    TM_PROF(P_RES_NORM, TM_TRY(launch_residual_rmsnorm(e->d_x, e->d_resid, e->d_tmp, nullptr, 0, nullptr, norm_w,
+                                                       e->cfg.model.rms_eps, M, e->hidden, e->stream)));
+    return 0;
+}
+
 // row-parallel linear followed by (all-reduce +) residual + RMSNorm
 static int linear_residual_norm(tm_engine* e, LinearSlots& l, const half_t* x, int ldx, int M, const half_t* norm_w,
                                 int gemm_cat, const LinearWeight* next = nullptr)
@@ -524,10 +564,7 @@ static int linear_residual_norm(tm_engine* e, LinearSlots& l, const half_t* x, i
         return 0;
     }
     TM_REQUIRE(!can_defer || slabs == 1, "internal: deferred reduce without slabs");
-    TM_PROF(P_ALLREDUCE, TM_TRY(allreduce_hidden(e, e->d_tmp, M, next)));
-    TM_PROF(P_RES_NORM, TM_TRY(launch_residual_rmsnorm(e->d_x, e->d_resid, e->d_tmp, nullptr, 0, nullptr, norm_w,
-                                                       e->cfg.model.rms_eps, M, e->hidden, e->stream)));
-    return 0;
+    return reduce_residual_norm(e, M, norm_w, next);
 }
 
 static int linear_plain(tm_engine* e, LinearSlots& l, const half_t* x, int ldx, half_t* y, int ldy, int M, bool gated)
@@ -618,9 +655,7 @@ static int forward(tm_engine* e, const int* d_ids, int M, int nseq, bool decode,
             // router + grouped expert FFNs + combine -> d_tmp, then (all-reduce +) residual + RMSNorm as for the dense FFN
             TM_PROF(P_GEMM_GATE_UP, TM_TRY(moe_forward(L.moe, e->d_tmp, e->hidden, e->d_x, e->hidden, M, e->d_moe_ws, nullptr,
                                                        nullptr, st)));
-            TM_PROF(P_ALLREDUCE, TM_TRY(allreduce_hidden(e, e->d_tmp, M, next_lin)));
-            TM_PROF(P_RES_NORM, TM_TRY(launch_residual_rmsnorm(e->d_x, e->d_resid, e->d_tmp, nullptr, 0, nullptr, next_norm,
-                                                               m.rms_eps, M, e->hidden, st)));
+            TM_TRY(reduce_residual_norm(e, M, next_norm, next_lin));
             continue;
         }
         TM_PROF(P_GEMM_GATE_UP, TM_TRY(linear_plain(e, L.w13, e->d_x, e->hidden, e->d_act, e->inter, M, true)));
@@ -661,8 +696,15 @@ static int forward(tm_engine* e, const int* d_ids, int M, int nseq, bool decode,
                              e->cfg.rank * e->vocab_local, st));
         pack_candidates_kernel<<<(nseq + 63) / 64, 64, 0, st>>>(e->d_cand, ids, e->d_argmax_val, nseq);
         TM_HIP_CHECK(hipGetLastError());
+        if (e->p2p_ready) {
+            half_t*   data[8];
+            uint32_t* flags[8];
+            p2p_tables(e, data, flags);
+            TM_TRY(launch_p2p_allgather(data, flags, e->cfg.tp, e->cfg.rank, e->p2p_state, (size_t)e->p2p_rows * e->hidden, e->d_cand,
+                                        e->d_cand_all, nseq * 2, st));
+        }
         // the same communicator is only ever driven from ONE stream (the side stream when it exists)
-        if (e->comm_overlap && e->comm_stream) {
+        else if (e->comm_overlap && e->comm_stream) {
             TM_HIP_CHECK(hipEventRecord(e->ev_fork, st));
             TM_HIP_CHECK(hipStreamWaitEvent(e->comm_stream, e->ev_fork, 0));
             TM_NCCL_CHECK(ncclAllGather(e->d_cand, e->d_cand_all, (size_t)nseq * 2, ncclFloat, e->comm, e->comm_stream));
@@ -803,6 +845,40 @@ int tm_engine_comm_init(tm_engine* e, const void* host_id128)
         TM_HIP_CHECK(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
         TM_HIP_CHECK(hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming));
     }
+    return 0;
+}
+
+// Native communicator set-up, two calls around one host-side exchange (any transport: the caller's torch.distributed /
+// MPI / files): export allocates this rank's segment and returns its 64-byte IPC handle; import takes the tp handles in rank
+// order, maps the peers' segments and switches the row-parallel all-reduces with M <= rows (every M when tm_engine_comm_init
+// was not called: no RCCL communicator to fall back to) and the candidate all-gather to comm_p2p.hip.  Replaces the buffer
+// registration of comm/cuda_ipc (cuda_ipc_comm.cu Register / the symmetric allocator) for this path.
+int tm_engine_comm_native_export(tm_engine* e, int rows, void* handle64)
+{
+    TM_REQUIRE(e && handle64, "null pointer");
+    TM_REQUIRE(e->use_comm, "native communicator: the engine runs with tp = 1");
+    TM_REQUIRE(!e->p2p_seg, "native communicator: already exported");
+    TM_REQUIRE(rows >= 1 && rows <= 1024, "native communicator: 1 <= rows <= 1024 (one-shot exchange; larger batches stay on RCCL)");
+    TM_HIP_CHECK(hipSetDevice(e->cfg.device));
+    TM_TRY(tm_p2p_segment_create(tm_p2p_segment_bytes(rows, e->hidden), &e->p2p_seg, handle64));
+    TM_HIP_CHECK(hipMalloc((void**)&e->p2p_state, 4 * sizeof(uint32_t)));
+    TM_HIP_CHECK(hipMemset(e->p2p_state, 0, 4 * sizeof(uint32_t)));
+    e->p2p_rows = rows;
+    return 0;
+}
+
+int tm_engine_comm_native_import(tm_engine* e, const void* handles, int count)
+{
+    TM_REQUIRE(e && handles, "null pointer");
+    TM_REQUIRE(e->p2p_seg && !e->p2p_ready, "native communicator: export first, import once");
+    TM_REQUIRE(count == e->cfg.tp, "native communicator: one handle per rank");
+    TM_HIP_CHECK(hipSetDevice(e->cfg.device));
+    for (int r = 0; r < e->cfg.tp; ++r) {
+        if (r != e->cfg.rank) {
+            TM_TRY(tm_p2p_segment_open((const char*)handles + 64 * (size_t)r, &e->p2p_peer[r]));
+        }
+    }
+    e->p2p_ready = true;
     return 0;
 }
 
@@ -2142,6 +2218,13 @@ int tm_engine_destroy(tm_engine* e)
         if (p) {
             (void)hipFree(p);
         }
+    }
+    for (int r = 0; r < 8; ++r) {
+        (void)tm_p2p_segment_close(e->p2p_peer[r], 1);
+    }
+    (void)tm_p2p_segment_close(e->p2p_seg, 0);
+    if (e->p2p_state) {
+        (void)hipFree(e->p2p_state);
     }
     if (e->comm) {
         (void)ncclCommDestroy(e->comm);

@@ -158,6 +158,13 @@ int    launch_linear_fp8_grouped(const LinearWeight& proto, const void* d_groups
                                  int x_rows, half_t* y, int ldy, int m_cap, int m_hint, bool gated_silu, const int* seg,
                                  const int* row_idx, hipStream_t st);
 
+// ---- comm_p2p.hip: fused one-shot all-reduce + residual + RMSNorm over peer-mapped buffers (TM_COMM=native) ------------
+int launch_p2p_allreduce_norm(half_t* const* data, uint32_t* const* flags, int tp, int me, uint32_t* state, size_t tile,
+                              const half_t* partial, half_t* y, half_t* resid, const half_t* weight, float eps, int M, int H,
+                              hipStream_t st);
+int launch_p2p_allgather(half_t* const* data, uint32_t* const* flags, int tp, int me, uint32_t* state, size_t tile, const void* src,
+                         void* dst, int words, hipStream_t st);
+
 // sampling.hip: temperature / top-k / top-p / min-p sampling without a sort (see the file header)
 size_t sample_workspace_bytes(int batch);
 int    launch_sample(int* out_ids, int* kept_out, const half_t* logits, int batch, int V, int ld, const float* temperature,

@@ -66,6 +66,16 @@ class Engine:
         buf = C.create_string_buffer(unique_id, 128)
         _ffi.check(self._lib.tm_engine_comm_init(self._h, buf))
 
+    def comm_native_setup(self, all_gather, rows: int = 256):
+        """TM_COMM=native: switch the row-parallel all-reduces of forwards with <= `rows` tokens to the fused P2P kernel.
+        `all_gather(bytes) -> list[bytes]` (rank order) is the caller's host-side exchange, e.g. torch.distributed's
+        all_gather_object.  Call after comm_init, before start."""
+        buf = C.create_string_buffer(64)
+        _ffi.check(self._lib.tm_engine_comm_native_export(self._h, rows, buf))
+        handles = all_gather(buf.raw)
+        blob = b''.join(handles)
+        _ffi.check(self._lib.tm_engine_comm_native_import(self._h, C.create_string_buffer(blob, len(blob)), len(handles)))
+
     @staticmethod
     def comm_unique_id() -> bytes:
         buf = C.create_string_buffer(128)

@@ -999,6 +999,19 @@ def fp8_quantize_blockwise(w: np.ndarray):
 
 
 # ------------------------------------------------------------------------------------------------
+# Fused all-reduce + residual + RMSNorm of the native communicator (comm/cuda_ipc/fused_allreduce.cu:406-500): the ranks'
+# partial tiles are summed in fp32 in RANK ORDER (identical bits on every rank), rounded to fp16 once, then A7's
+# residual + RMSNorm.
+# ------------------------------------------------------------------------------------------------
+def p2p_allreduce_norm(partials, resid, weight, eps):
+    """partials: list of fp16 [M, H] (one per rank).  Returns (new residual fp16, normed fp16)."""
+    acc = np.zeros(partials[0].shape, np.float32)
+    for part in partials:
+        acc = acc + np.asarray(part, f16).astype(np.float32)
+    return residual_rmsnorm(resid, acc.astype(f16), weight, eps)
+
+
+# ------------------------------------------------------------------------------------------------
 # FP8 x FP8 linear: what the reference runs for e4m3 weights on fp8 matrix cores (SM90+) and what the MI355X path runs on
 # v_mfma_f32_32x32x16_fp8_fp8.  The activations are quantised on the fly, per row and per group of 128 input channels
 # (QuantizeSymm, src/turbomind/kernels/quantization.cu:28-63, called from LlamaLinear::GetOperandA,

@@ -179,7 +179,8 @@ def test_continuous_batching_matches_oracle(cuda, kv_bits):
     generation lengths through 3 batch slots (admissions join a running batch, slots and KV blocks are reused, one prompt
     is chunked); every request's token stream is replayed through the oracle model alone (batch 1, teacher-forced with
     the engine's tokens) and every engine token must be the arg-max of the oracle's logits wherever the oracle's top-2
-    margin exceeds the end-to-end logit tolerance (3e-2, as in test_engine_matches_oracle)."""
+    margin exceeds 1.5e-2 -- the synthetic model's logits have sigma = 0.1, the engine's measured logit error is a few
+    1e-3 -- and within 1e-2 of the oracle's best logit everywhere else (near ties)."""
     cfg = o.ModelConfig(hidden=256, layers=2, q_heads=4, kv_heads=2, head_dim=128, inter=512, vocab=1024,
                         kv_bits=kv_bits, rope=o.RopeParam(128, 500000.0, 'llama3', 8.0, 1.0, 4.0, 8192))
     w = o.make_synthetic_weights(cfg, seed=13)
@@ -211,13 +212,13 @@ def test_continuous_batching_matches_oracle(cuda, kv_bits):
             _, lg = om.forward(feed)
             row = lg[0].astype(np.float32)
             top2 = np.sort(row)[-2:]
-            if top2[1] - top2[0] > 6e-2:
+            if top2[1] - top2[0] > 1.5e-2:
                 assert int(toks[k]) == int(np.argmax(row)), f'request {i} token {k}: engine {toks[k]} oracle {np.argmax(row)}'
                 checked += 1
-            else:   # near tie: the engine's token must at least be one of the two leaders
-                assert row[int(toks[k])] >= top2[0] - 3e-2
+            else:   # near tie: the engine's token must score within the tolerance of the oracle's best
+                assert row[int(toks[k])] >= top2[1] - 1e-2
             feed = [[int(toks[k])]]
-    assert checked >= sum(news) // 2
+    assert checked >= sum(news) // 3
 
 
 def test_engine_thread_serving(cuda):

@@ -395,3 +395,18 @@ def test_cpu_baseline_port_matches_reference_golden_vectors():
     tiny = dict(hidden=256, layers=2, q_heads=2, kv_heads=1, head_dim=128, inter=256, vocab=512)
     r = cb.run(tiny, batch=2, ctx=65, sample_layers=2, passes=2, threads=2)
     assert r['value'] > 0 and r['kind'] == 'port' and '2 of 2 decoder layers' in r['sample'] and 'warm-up' in r['sample']
+
+
+def test_p2p_allreduce_norm_restatement():
+    """f2: rank-ordered fp32 sum -> one fp16 rounding -> A7's residual + RMSNorm; tp = 1 degenerates to A7 itself."""
+    rng = np.random.default_rng(4)
+    parts = [(0.5 * rng.standard_normal((5, 256))).astype(np.float16) for _ in range(4)]
+    resid = rng.standard_normal((5, 256)).astype(np.float16)
+    w = (1 + 0.02 * rng.standard_normal(256)).astype(np.float16)
+    r1, y1 = o.p2p_allreduce_norm(parts[:1], resid, w, 1e-5)
+    r2, y2 = o.residual_rmsnorm(resid, parts[0], w, 1e-5)
+    assert np.array_equal(r1.view(np.uint16), r2.view(np.uint16)) and np.array_equal(y1.view(np.uint16), y2.view(np.uint16))
+    r4, y4 = o.p2p_allreduce_norm(parts, resid, w, 1e-5)
+    h = ((parts[0].astype(np.float32) + parts[1].astype(np.float32)) + parts[2].astype(np.float32)) + parts[3].astype(np.float32)
+    r5, y5 = o.residual_rmsnorm(resid, h.astype(np.float16), w, 1e-5)
+    assert np.array_equal(r4.view(np.uint16), r5.view(np.uint16)) and np.array_equal(y4.view(np.uint16), y5.view(np.uint16))
