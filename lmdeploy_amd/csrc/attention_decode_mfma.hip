@@ -571,8 +571,10 @@ int launch_decode_attention_i8_mfma(const DecodeAttnParams& p, hipStream_t st)
     // 4 wave-private images (+ 4 KB q exchange for the fused prologue); the merge buffers overlay the images
     static_assert(4 * kWaveLds + 4096 > 4 * 16 * 128 * 4 + 4 * 16 * 2 * 4, "merge buffers must fit");
     const int lds = 4 * kWaveLds + 4096;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static bool attr_set[16] = {};  // the raised dynamic-LDS limit is a per-device function attribute
+    int         dev = 0;
+    (void)hipGetDevice(&dev);
+    if (!attr_set[dev & 15]) {
         TM_HIP_CHECK(hipFuncSetAttribute((const void*)decode_attention_i8_mfma_kernel<false, 8>,
                                          hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         TM_HIP_CHECK(hipFuncSetAttribute((const void*)decode_attention_i8_mfma_kernel<true, 8>,
@@ -581,7 +583,7 @@ int launch_decode_attention_i8_mfma(const DecodeAttnParams& p, hipStream_t st)
                                          hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         TM_HIP_CHECK(hipFuncSetAttribute((const void*)decode_attention_i8_mfma_kernel<true, 4>,
                                          hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        attr_set = true;
+        attr_set[dev & 15] = true;
     }
     if (p.qkv_slabs || p.qkv_f16) {
         TM_REQUIRE(p.qkv_n % 8 == 0 && (p.qkv_splits == 0) == (p.qkv_slabs == nullptr), "fused qkv input");

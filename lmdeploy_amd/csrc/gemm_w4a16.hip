@@ -670,711 +670,6 @@ __global__ __launch_bounds__(WN * WK * 64) void gemm_kernel(GemmParams p)
     }
 }
 
-
-// ---------------------------------------------------------------------------------------------------------------
-// Decode kernel (u4 weights, M <= 64, one row block): producer / consumer wave specialisation.
-//   * waves 0-7 (consumers): one 16-column tile each over the whole k-slice of the workgroup; packed weights and
-//     (s, -z*s) pairs stream through a PF-deep per-wave REGISTER ring (HBM -> VGPR, never through LDS);
-//   * wave 8 (producer): streams the activations k-block by k-block, global (L2) -> registers -> XOR-swizzled LDS
-//     image [MB][256 B], THREE buffers.  Its VMEM queue holds nothing but x loads, so their L2 latency is never
-//     queued behind the consumers' HBM weight loads (VMEM returns in order per wave), and the consumers carry no
-//     staging registers / instructions at all.
-// Iteration i (one k-block), ONE barrier at its top:
-//   consumers: read the step-3 fragments of x(i) (buffer i%3); for each 32-k step s: 4 MFMAs per row tile on the
-//              register-resident fragments xf[s], the dequantisation of the next step interleaved; as soon as xf[s]
-//              is dead it is re-filled with step s of x(i+1) (buffer (i+1)%3) -- every LDS read is issued >= 3 steps
-//              (a whole k-block for steps 0-2) before its use, so no MFMA ever waits on the LDS round trip;
-//   producer:  writes x(i+2) (loaded two iterations earlier) into buffer (i+2)%3 and issues the loads of x(i+4).
-// Buffer (i+2)%3 last held x(i-1), whose final reads (its step 3) were issued at the top of iteration i-1 and are
-// complete before the barrier of iteration i (the workgroup fence in __syncthreads waits lgkmcnt(0)).
-template<int MT, int PF, int NPROD>
-__global__ __launch_bounds__((8 + NPROD) * 64) void gemm_decode_kernel(GemmParams p)
-{
-    static_assert(PF % 2 == 0, "the producer loop is unrolled by two");
-    constexpr int MB   = 16 * MT;
-    constexpr int BUFB = MB * 256;  // one k-block of x
-    static_assert((MT * 4) % NPROD == 0, "producers split the k-block image evenly");
-    constexpr int XR   = MT * 4 / NPROD;  // b128 loads per producer lane per k-block
-
-    extern __shared__ __attribute__((aligned(16))) char smem[];  // 3 * BUFB
-
-    const int tid  = threadIdx.x;
-    const int wgid = blockIdx.y * gridDim.x + blockIdx.x;
-    if (p.dbg && tid == 0) {
-        p.dbg[wgid * 8 + 0] = __builtin_amdgcn_s_memrealtime();
-        p.dbg[wgid * 8 + 4] = ((uint64_t)__builtin_amdgcn_s_getreg(20 | (31 << 11)) << 32) | (uint32_t)__builtin_amdgcn_s_getreg(4 | (31 << 11));
-    }
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int i16  = lane & 15;
-    const int g    = lane >> 4;
-
-    const int ntiles  = p.N / 16;
-    const int kb0     = blockIdx.y * p.kb_per_split;
-    const int nkb     = min(p.kb_per_split, p.KB - kb0);
-    const int last    = nkb - 1;
-    const int nit_pad = (nkb + PF - 1) / PF * PF;  // both roles run exactly this many iterations (= barriers)
-
-    if (wave >= 8) {
-        // ---------------------------------------------------------------- producer ------------------------------
-        const auto rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)(((size_t)(p.M - 1) * p.ldx + p.K) * 2), 0x00020000);
-        int xoff[XR], xlds[XR];
-#pragma unroll
-        for (int r = 0; r < XR; ++r) {
-            const int q  = (r * NPROD + (wave - 8)) * 64 + lane;  // 16-B chunk q of the k-block image: row q/16, chunk q%16
-            const int m  = q >> 4;
-            const int ci = q & 15;
-            xoff[r]      = (min(m, p.M - 1) * p.ldx + ci * 8) * 2;  // rows past M feed output rows that are never stored
-            xlds[r]      = m * 256 + ((ci ^ (m & 15)) << 4);
-        }
-        u32x4 xa[XR], xb[XR];
-#define TM_PX_LOAD(dst, j)                                                                       \
-    {                                                                                            \
-        const int kb_ = kb0 + min((j), last);                                                    \
-        _Pragma("unroll") for (int r = 0; r < XR; ++r)                                           \
-        {                                                                                        \
-            dst[r] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, xoff[r], kb_ * 256, 0);         \
-        }                                                                                        \
-    }
-#define TM_PX_STORE(src, boff)                                                                   \
-    _Pragma("unroll") for (int r = 0; r < XR; ++r)                                               \
-    {                                                                                            \
-        *(u32x4*)(smem + (boff) + xlds[r]) = src[r];                                             \
-    }
-        TM_PX_LOAD(xa, 0);
-        TM_PX_LOAD(xb, 1);
-        TM_PX_STORE(xa, 0);
-        TM_PX_STORE(xb, BUFB);
-        TM_PX_LOAD(xa, 2);
-        TM_PX_LOAD(xb, 3);
-        __syncthreads();  // P: x(0), x(1) visible
-        int bw = 2 * BUFB;
-        for (int i = 0; i < nit_pad; i += 2) {
-            __syncthreads();  // barrier(i)
-            TM_PX_STORE(xa, bw);  // x(i+2)
-            bw = bw == 2 * BUFB ? 0 : bw + BUFB;
-            TM_PX_LOAD(xa, i + 4);
-            __syncthreads();  // barrier(i+1)
-            TM_PX_STORE(xb, bw);  // x(i+3)
-            bw = bw == 2 * BUFB ? 0 : bw + BUFB;
-            TM_PX_LOAD(xb, i + 5);
-        }
-#undef TM_PX_LOAD
-#undef TM_PX_STORE
-        return;
-    }
-
-    // -------------------------------------------------------------------- consumers -----------------------------
-    const int  nt_raw = blockIdx.x * 8 + wave;
-    const int  nt     = min(nt_raw, ntiles - 1);  // tiles past the edge are clamped: loads stay in bounds, stores are skipped
-    const auto rs_w   = __builtin_amdgcn_make_buffer_rsrc((void*)p.wq, 0, (int)((size_t)p.KB * ntiles * 1024), 0x00020000);
-    const auto rs_s   = __builtin_amdgcn_make_buffer_rsrc((void*)p.sz, 0, p.KB * ntiles * 64, 0x00020000);
-    const int  woff    = (nt * 64 + lane) * 16;
-    const int  soff    = (nt * 16 + i16) * 4;
-    const int  wstride = ntiles * 1024;
-    const int  sstride = ntiles * 64;
-
-    floatx4 acc[MT];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-        acc[mt] = floatx4{0.f, 0.f, 0.f, 0.f};
-    }
-    u32x4    ring[PF];
-    uint32_t sring[PF];
-    uint32_t m1024 = 0x64006400u, m64 = 0x54005400u;
-    asm volatile("" : "+v"(m1024), "+v"(m64));  // keep the magic numbers in VGPRs (see dequant8)
-
-#define TM_CW_LOAD(slot, i)                                                                              \
-    {                                                                                                    \
-        const int kb_ = kb0 + min((i), last);                                                            \
-        ring[slot]    = __builtin_amdgcn_raw_buffer_load_b128(rs_w, woff, kb_ * wstride, /*nt*/ 2);      \
-        sring[slot]   = __builtin_amdgcn_raw_buffer_load_b32(rs_s, soff, kb_ * sstride, 0);              \
-    }
-#pragma unroll
-    for (int u = 0; u < PF; ++u) {
-        TM_CW_LOAD(u, u);
-        __builtin_amdgcn_sched_barrier(0);  // pin the issue order (see gemm_kernel's prologue)
-    }
-    int xr[4];  // fragment (step s, row tile 0) of this lane inside a k-block image
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-        xr[s] = i16 * 256 + (((s * 4 + g) ^ i16) << 4);
-    }
-    __syncthreads();  // P
-    if (p.dbg && tid == 0) {
-        p.dbg[wgid * 8 + 1] = __builtin_amdgcn_s_memrealtime();
-        p.dbg[wgid * 8 + 5] = __builtin_amdgcn_s_memtime();  // shader-clock ticks: effective clock of the main loop
-    }
-    half8_t xf[4][MT];
-#pragma unroll
-    for (int s = 0; s < 3; ++s) {
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            xf[s][mt] = *(const half8_t*)(smem + xr[s] + mt * 4096);
-        }
-    }
-    auto dq = [&](int slot, int j, bool live) -> half8_t {
-        const half2_t pr = bit_cast<half2_t>(live ? sring[slot] : 0u);  // (s, -z*s) = 0 -> w = 0 in padded iterations
-        return dequant8(ring[slot][j], half2_t{pr[0], pr[0]}, half2_t{pr[1], pr[1]}, m1024, m64);
-    };
-    half8_t wfn   = dq(0, 0, true);
-    int     b_cur = 0, b_nxt = BUFB;
-    for (int base = 0; base < nit_pad; base += PF) {
-#pragma unroll
-        for (int u = 0; u < PF; ++u) {
-            const int  i         = base + u;
-            const bool live      = i < nkb;  // wave-uniform
-            const bool live_next = i + 1 < nkb;
-            __syncthreads();  // barrier(i)
-            const char* cur = smem + b_cur;
-            const char* nxt = smem + b_nxt;
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                xf[3][mt] = *(const half8_t*)(cur + xr[3] + mt * 4096);
-            }
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                const half8_t wf = wfn;
-                wfn = s < 3 ? dq(u, s + 1, live) : dq((u + 1) % PF, 0, live_next);
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt) {
-                    acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf, xf[s][mt], acc[mt], 0, 0, 0);
-                }
-                if (s < 3) {
-#pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) {
-                        xf[s][mt] = *(const half8_t*)(nxt + xr[s] + mt * 4096);  // x(i+1), step s
-                    }
-                }
-            }
-            TM_CW_LOAD(u, i + PF);
-            b_cur = b_nxt;
-            b_nxt = b_nxt == 2 * BUFB ? 0 : b_nxt + BUFB;
-        }
-    }
-#undef TM_CW_LOAD
-    if (p.dbg && tid == 0) {
-        p.dbg[wgid * 8 + 2] = __builtin_amdgcn_s_memrealtime();
-        p.dbg[wgid * 8 + 6] = __builtin_amdgcn_s_memtime();
-    }
-
-    // ---- epilogue: lane holds y[m = 16mt + i16][n = 16 nt + 4g + r], r = 0..3 ------------------------------------
-    if (nt_raw < ntiles) {
-        const int n = nt * 16 + g * 4;
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            const int m = mt * 16 + i16;
-            if (m >= p.M) {
-                continue;
-            }
-            const floatx4 a = acc[mt];
-            if (p.epilogue == 2) {
-                *(floatx4*)(p.partial + ((size_t)blockIdx.y * p.M + m) * p.N + n) = a;
-            }
-            else if (p.epilogue == 1) {
-                const float s0 = a[0] / (1.0f + __builtin_expf(-a[0]));
-                const float s1 = a[2] / (1.0f + __builtin_expf(-a[2]));
-                half2_t     o  = {(half_t)(s0 * a[1]), (half_t)(s1 * a[3])};
-                *(half2_t*)(p.y + (size_t)m * p.ldy + (n >> 1)) = o;
-            }
-            else {
-                half4_t o = {(half_t)a[0], (half_t)a[1], (half_t)a[2], (half_t)a[3]};
-                *(half4_t*)(p.y + (size_t)m * p.ldy + n) = o;
-            }
-        }
-    }
-    if (p.dbg && tid == 0) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        p.dbg[wgid * 8 + 3] = __builtin_amdgcn_s_memrealtime();
-    }
-}
-
-
-// ---------------------------------------------------------------------------------------------------------------
-// Ping-pong decode kernel (u4 weights, M <= 64): the two wave groups of a workgroup run OPPOSITE phases.
-// The symmetric kernel is bound by phase lockstep: all 8 waves of a CU issue their loads, LDS traffic, dequant VALU
-// work and MFMAs at the same moments, so the per-k-block times of those resources add up (ablation in DESIGN.md 3.1).
-// Here group A = waves 0-3 and group B = waves 4-7 (one wave of each group per SIMD) split K between them
-// (A: even k-blocks, B: odd k-blocks of the slice; partial sums added through LDS at the end) and alternate between
-//   P (prepare): dequantise the 2 x 4 weight fragments of the group's next k-block into registers (VALU), write the
-//                group's own activation k-block into its private LDS buffer, refill the register ring (VMEM);
-//   C (compute): 8*MT MFMAs per 32-k step on those fragments, activation fragments read from LDS one step ahead.
-// Two barriers per k-block pair keep the groups exactly one phase apart: while one wave of a SIMD owns the MFMA pipe,
-// the other one owns the VALU, LDS-write and VMEM issue ports.
-// Each wave: 2 column tiles (x fragments are reused for both), 4 waves per group -> 8 tiles = 128 columns per workgroup.
-template<int MT, int PF>
-__global__ __launch_bounds__(512) void gemm_pingpong_kernel(GemmParams p)
-{
-    constexpr int NT   = 2;
-    constexpr int MB   = 16 * MT;
-    constexpr int BUFB = MB * 256;      // one k-block of x, XOR-swizzled [MB][256 B]
-    constexpr int XC   = MT;            // 16-B chunks per thread per k-block (MB*16 chunks / 256 threads of a group)
-
-    extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 groups][BUFB]; reused for the final reduction
-
-    const int tid  = threadIdx.x;
-    const int wgid = blockIdx.y * gridDim.x + blockIdx.x;
-    if (p.dbg && tid == 0) {
-        p.dbg[wgid * 8 + 0] = __builtin_amdgcn_s_memrealtime();
-        p.dbg[wgid * 8 + 4] = ((uint64_t)__builtin_amdgcn_s_getreg(20 | (31 << 11)) << 32) | (uint32_t)__builtin_amdgcn_s_getreg(4 | (31 << 11));
-    }
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int grp  = wave >> 2;  // 0 = A, 1 = B
-    const int wn   = wave & 3;
-    const int gtid = tid & 255;  // thread index inside the group
-    const int i16  = lane & 15;
-    const int g    = lane >> 4;
-
-    const int ntiles = p.N / 16;
-    const int kb0    = blockIdx.y * p.kb_per_split;
-    const int nkb    = min(p.kb_per_split, p.KB - kb0);  // even (host guarantees)
-    const int nsi    = nkb / 2;                          // k-block pairs: group grp contracts kb0 + 2j + grp
-    const int last   = nsi - 1;
-    const int nt_raw = (blockIdx.x * 4 + wn) * NT;
-
-    const auto rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.wq, 0, (int)((size_t)p.KB * ntiles * 1024), 0x00020000);
-    const auto rs_s = __builtin_amdgcn_make_buffer_rsrc((void*)p.sz, 0, p.KB * ntiles * 64, 0x00020000);
-    const auto rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)(((size_t)(p.M - 1) * p.ldx + p.K) * 2), 0x00020000);
-    int woff[NT], soff[NT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        const int nt = min(nt_raw + t, ntiles - 1);  // clamped: loads stay in bounds, stores are skipped
-        woff[t]      = (nt * 64 + lane) * 16;
-        soff[t]      = (nt * 16 + i16) * 4;
-    }
-    const int wstride = ntiles * 1024;
-    const int sstride = ntiles * 64;
-    int       xoff[XC], xlds[XC];
-#pragma unroll
-    for (int c = 0; c < XC; ++c) {
-        const int q  = c * 256 + gtid;  // chunk q of the group's k-block image: row q/16, chunk q%16
-        const int m  = q >> 4;
-        const int ci = q & 15;
-        xoff[c]      = (min(m, p.M - 1) * p.ldx + ci * 8) * 2;
-        xlds[c]      = grp * BUFB + m * 256 + ((ci ^ (m & 15)) << 4);
-    }
-    int xr[4];  // activation fragment (32-k step s, row tile 0) of this lane inside the group's image
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-        xr[s] = grp * BUFB + i16 * 256 + (((s * 4 + g) ^ i16) << 4);
-    }
-
-    floatx4 acc[NT][MT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            acc[t][mt] = floatx4{0.f, 0.f, 0.f, 0.f};
-        }
-    }
-    u32x4    ring[PF][NT];
-    uint32_t sring[PF][NT];
-    u32x4    xs[PF][XC];
-    half8_t  wf[NT][4];
-    uint32_t m1024 = 0x64006400u, m64 = 0x54005400u;
-    asm volatile("" : "+v"(m1024), "+v"(m64));  // keep the magic numbers in VGPRs (see dequant8)
-
-#define TM_PP_LOAD(slot, j)                                                                                  \
-    {                                                                                                        \
-        const int kb_ = kb0 + 2 * min((j), last) + grp;                                                      \
-        _Pragma("unroll") for (int c = 0; c < XC; ++c)                                                       \
-        {                                                                                                    \
-            xs[slot][c] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, xoff[c], kb_ * 256, 0);                \
-        }                                                                                                    \
-        _Pragma("unroll") for (int t = 0; t < NT; ++t)                                                       \
-        {                                                                                                    \
-            ring[slot][t]  = __builtin_amdgcn_raw_buffer_load_b128(rs_w, woff[t], kb_ * wstride, /*nt*/ 2);  \
-            sring[slot][t] = __builtin_amdgcn_raw_buffer_load_b32(rs_s, soff[t], kb_ * sstride, 0);          \
-        }                                                                                                    \
-    }
-    // P(j): operands of k-block pair j for this group
-#define TM_PP_PREPARE(slot, j, live)                                                                         \
-    {                                                                                                        \
-        _Pragma("unroll") for (int t = 0; t < NT; ++t)                                                       \
-        {                                                                                                    \
-            const half2_t pr = bit_cast<half2_t>((live) ? sring[slot][t] : 0u);                              \
-            _Pragma("unroll") for (int s = 0; s < 4; ++s)                                                    \
-            {                                                                                                \
-                wf[t][s] = dequant8(ring[slot][t][s], half2_t{pr[0], pr[0]}, half2_t{pr[1], pr[1]}, m1024, m64); \
-            }                                                                                                \
-        }                                                                                                    \
-        _Pragma("unroll") for (int c = 0; c < XC; ++c)                                                       \
-        {                                                                                                    \
-            *(u32x4*)(smem + xlds[c]) = xs[slot][c];                                                         \
-        }                                                                                                    \
-        TM_PP_LOAD(slot, (j) + PF);                                                                          \
-    }
-    // C(j): contract the prepared k-block
-#define TM_PP_COMPUTE()                                                                                      \
-    {                                                                                                        \
-        half8_t xf[MT], xfn[MT];                                                                             \
-        _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                                    \
-        {                                                                                                    \
-            xf[mt] = *(const half8_t*)(smem + xr[0] + mt * 4096);                                            \
-        }                                                                                                    \
-        _Pragma("unroll") for (int s = 0; s < 4; ++s)                                                        \
-        {                                                                                                    \
-            if (s < 3) {                                                                                     \
-                _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                            \
-                {                                                                                            \
-                    xfn[mt] = *(const half8_t*)(smem + xr[s + 1] + mt * 4096);                               \
-                }                                                                                            \
-            }                                                                                                \
-            _Pragma("unroll") for (int t = 0; t < NT; ++t)                                                   \
-            {                                                                                                \
-                _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                            \
-                {                                                                                            \
-                    acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[t][s], xf[mt], acc[t][mt], 0, 0, 0); \
-                }                                                                                            \
-            }                                                                                                \
-            if (s < 3) {                                                                                     \
-                _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                            \
-                {                                                                                            \
-                    xf[mt] = xfn[mt];                                                                        \
-                }                                                                                            \
-            }                                                                                                \
-        }                                                                                                    \
-    }
-
-#pragma unroll
-    for (int u = 0; u < PF; ++u) {
-        TM_PP_LOAD(u, u);
-        __builtin_amdgcn_sched_barrier(0);  // pin the issue order (see gemm_kernel's prologue)
-    }
-    if (p.dbg && tid == 0) {
-        p.dbg[wgid * 8 + 1] = __builtin_amdgcn_s_memrealtime();
-        p.dbg[wgid * 8 + 5] = __builtin_amdgcn_s_memtime();
-    }
-
-    const int nsi_pad = (nsi + PF - 1) / PF * PF;
-    if (grp == 0) {
-        for (int base = 0; base < nsi_pad; base += PF) {
-#pragma unroll
-            for (int u = 0; u < PF; ++u) {
-                const int j = base + u;
-                TM_PP_PREPARE(u, j, j < nsi);
-                __syncthreads();
-                TM_PP_COMPUTE();
-                __syncthreads();
-            }
-        }
-        __syncthreads();  // pairs with group B's trailing compute slot
-    }
-    else {
-        for (int base = 0; base < nsi_pad; base += PF) {
-#pragma unroll
-            for (int u = 0; u < PF; ++u) {
-                const int j = base + u;
-                if (j > 0) {
-                    TM_PP_COMPUTE();  // k-block pair j-1
-                }
-                __syncthreads();
-                TM_PP_PREPARE(u, j, j < nsi);
-                __syncthreads();
-            }
-        }
-        TM_PP_COMPUTE();
-        __syncthreads();
-    }
-#undef TM_PP_LOAD
-#undef TM_PP_PREPARE
-#undef TM_PP_COMPUTE
-    if (p.dbg && tid == 0) {
-        p.dbg[wgid * 8 + 2] = __builtin_amdgcn_s_memrealtime();
-        p.dbg[wgid * 8 + 6] = __builtin_amdgcn_s_memtime();
-    }
-
-    // ---- group B's partial sums -> LDS -> group A (the x images are dead after the last barrier) -----------------
-    floatx4* red = (floatx4*)smem;  // [wn][t][mt][lane]
-    if (grp == 1) {
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                red[((wn * NT + t) * MT + mt) * 64 + lane] = acc[t][mt];
-            }
-        }
-    }
-    __syncthreads();
-    if (grp == 1) {
-        return;
-    }
-    // ---- epilogue: lane holds y[m = 16mt + i16][n = 16(nt_raw + t) + 4g + r], r = 0..3 ---------------------------
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        if (nt_raw + t >= ntiles) {
-            continue;
-        }
-        const int n = (nt_raw + t) * 16 + g * 4;
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            const int m = mt * 16 + i16;
-            if (m >= p.M) {
-                continue;
-            }
-            const floatx4 a = acc[t][mt] + red[((wn * NT + t) * MT + mt) * 64 + lane];
-            if (p.epilogue == 2) {
-                *(floatx4*)(p.partial + ((size_t)blockIdx.y * p.M + m) * p.N + n) = a;
-            }
-            else if (p.epilogue == 1) {
-                const float s0 = a[0] / (1.0f + __builtin_expf(-a[0]));
-                const float s1 = a[2] / (1.0f + __builtin_expf(-a[2]));
-                half2_t     o  = {(half_t)(s0 * a[1]), (half_t)(s1 * a[3])};
-                *(half2_t*)(p.y + (size_t)m * p.ldy + (n >> 1)) = o;
-            }
-            else {
-                half4_t o = {(half_t)a[0], (half_t)a[1], (half_t)a[2], (half_t)a[3]};
-                *(half4_t*)(p.y + (size_t)m * p.ldy + n) = o;
-            }
-        }
-    }
-    if (p.dbg && tid == 0) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        p.dbg[wgid * 8 + 3] = __builtin_amdgcn_s_memrealtime();
-    }
-}
-
-
-// ---------------------------------------------------------------------------------------------------------------
-// Decode kernel with LDS-DMA activation staging (u4 weights, M <= 64): like gemm_kernel<.., NT=1, WN=8, KS=1> but the
-// activations never pass through registers: every wave copies its 1 KiB pieces of the k-block image global -> LDS with
-// `buffer_load_dwordx4 ... lds` (the XOR swizzle is applied on the SOURCE address: lane L loads the chunk that belongs
-// at LDS slot L), three k-blocks ahead, into a ring of four buffers.  No x register ring (-64 VGPRs), no ds_write_b128
-// (16 x 13 LDS cycles per k-block), no x loads queued in front of the weight ring.  The DMA is issued from inline asm:
-// hipcc does not count it, so its own waits for the weight ring only become stricter (never unsafe); the completion of
-// the DMA is waited for with a counted s_waitcnt right before the barrier that publishes the buffer.
-// Fragments are register-resident per k-block and re-filled as soon as a 32-k step is done (as in gemm_decode_kernel).
-template<int MT, int PF>
-__global__ __launch_bounds__(512) void gemm_glds_kernel(GemmParams p)
-{
-    constexpr int MB   = 16 * MT;
-    constexpr int BUFB = MB * 256;       // one k-block of x
-    // four buffers: x(i) .. x(i+3) live at the same time
-    constexpr int XB   = BUFB / 1024;    // 1 KiB pieces (4 rows) per k-block image
-    constexpr int XR   = (XB + 7) / 8;   // pieces per wave
-
-    extern __shared__ __attribute__((aligned(16))) char smem[];  // 4 * BUFB
-
-    const int tid  = threadIdx.x;
-    const int wgid = blockIdx.y * gridDim.x + blockIdx.x;
-    if (p.dbg && tid == 0) {
-        p.dbg[wgid * 8 + 0] = __builtin_amdgcn_s_memrealtime();
-        p.dbg[wgid * 8 + 4] = ((uint64_t)__builtin_amdgcn_s_getreg(20 | (31 << 11)) << 32) | (uint32_t)__builtin_amdgcn_s_getreg(4 | (31 << 11));
-    }
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int i16  = lane & 15;
-    const int g    = lane >> 4;
-
-    const int ntiles = p.N / 16;
-    const int kb0    = blockIdx.y * p.kb_per_split;
-    const int nkb    = min(p.kb_per_split, p.KB - kb0);
-    const int last   = nkb - 1;
-    const int nit_pad = (nkb + PF - 1) / PF * PF;
-
-    const int  nt_raw = blockIdx.x * 8 + wave;
-    const int  nt     = min(nt_raw, ntiles - 1);
-    const auto rs_w   = __builtin_amdgcn_make_buffer_rsrc((void*)p.wq, 0, (int)((size_t)p.KB * ntiles * 1024), 0x00020000);
-    const auto rs_s   = __builtin_amdgcn_make_buffer_rsrc((void*)p.sz, 0, p.KB * ntiles * 64, 0x00020000);
-    const auto rs_x   = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)(((size_t)(p.M - 1) * p.ldx + p.K) * 2), 0x00020000);
-    const int  woff    = (nt * 64 + lane) * 16;
-    const int  soff    = (nt * 16 + i16) * 4;
-    const int  wstride = ntiles * 1024;
-    const int  sstride = ntiles * 64;
-
-    // my pieces of a k-block image: piece blk = r*8 + wave = rows 4 blk .. 4 blk + 3; lane L lands at LDS slot L of the piece
-    int       xoff[XR];
-    unsigned  xdst[XR];
-    const int my_xr = XB >= 8 ? XR : (wave < XB ? 1 : 0);  // wave-uniform number of DMA pieces per k-block
-    const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)smem);
-#pragma unroll
-    for (int r = 0; r < XR; ++r) {
-        const int blk = min(r * 8 + wave, XB - 1);
-        const int row = blk * 4 + (lane >> 4);
-        const int ci  = (lane & 15) ^ (row & 15);
-        xoff[r]       = (min(row, p.M - 1) * p.ldx + ci * 8) * 2;
-        xdst[r]       = lds0 + blk * 1024;
-    }
-#define TM_GL_DMA(j, buf)                                                                                          \
-    {                                                                                                              \
-        const int kbo_ = (kb0 + min((j), last)) * 256;                                                             \
-        _Pragma("unroll") for (int r = 0; r < XR; ++r)                                                             \
-        {                                                                                                          \
-            if (r < my_xr) {                                                                                       \
-                unsigned keep_;                                                                                    \
-                const unsigned dst_ = xdst[r] + (buf)*BUFB;                                                        \
-                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"                                  \
-                             "buffer_load_dwordx4 %1, %2, %4 offen lds\n\ts_mov_b32 m0, %0"                        \
-                             : "=&s"(keep_)                                                                        \
-                             : "v"(xoff[r]), "s"(rs_x), "s"(dst_), "s"(kbo_)                                       \
-                             : "memory");                                                                          \
-            }                                                                                                      \
-        }                                                                                                          \
-    }
-    // wait until at most `n_younger + my_xr * younger_dma_rounds` of my VMEM operations are outstanding
-#define TM_GL_WAIT(base)                                                                                           \
-    {                                                                                                              \
-        if (my_xr == 2) {                                                                                          \
-            asm volatile("s_waitcnt vmcnt(%0)" ::"i"((base) + 2) : "memory");                                      \
-        }                                                                                                          \
-        else if (my_xr == 1) {                                                                                     \
-            asm volatile("s_waitcnt vmcnt(%0)" ::"i"((base) + 1) : "memory");                                      \
-        }                                                                                                          \
-        else {                                                                                                     \
-            asm volatile("s_waitcnt vmcnt(%0)" ::"i"(base) : "memory");                                            \
-        }                                                                                                          \
-    }
-
-    floatx4 acc[MT];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-        acc[mt] = floatx4{0.f, 0.f, 0.f, 0.f};
-    }
-    u32x4    ring[PF];
-    uint32_t sring[PF];
-    uint32_t m1024 = 0x64006400u, m64 = 0x54005400u;
-    asm volatile("" : "+v"(m1024), "+v"(m64));
-
-#define TM_GW_LOAD(slot, i)                                                                              \
-    {                                                                                                    \
-        const int kb_ = kb0 + min((i), last);                                                            \
-        ring[slot]    = __builtin_amdgcn_raw_buffer_load_b128(rs_w, woff, kb_ * wstride, /*nt*/ 2);      \
-        sring[slot]   = __builtin_amdgcn_raw_buffer_load_b32(rs_s, soff, kb_ * sstride, 0);              \
-    }
-    // prologue: x(0..2) first (they are waited for first), then the weight ring
-    TM_GL_DMA(0, 0);
-    TM_GL_DMA(1, 1);
-    TM_GL_DMA(2, 2);
-#pragma unroll
-    for (int u = 0; u < PF; ++u) {
-        TM_GW_LOAD(u, u);
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    asm volatile("s_waitcnt vmcnt(%0)" ::"i"(2 * PF) : "memory");  // everything older than the ring: the three x images
-    int xr[4];
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-        xr[s] = i16 * 256 + (((s * 4 + g) ^ i16) << 4);
-    }
-    __syncthreads();
-    if (p.dbg && tid == 0) {
-        p.dbg[wgid * 8 + 1] = __builtin_amdgcn_s_memrealtime();
-        p.dbg[wgid * 8 + 5] = __builtin_amdgcn_s_memtime();
-    }
-    half8_t xf[4][MT];
-#pragma unroll
-    for (int s = 0; s < 3; ++s) {
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            xf[s][mt] = *(const half8_t*)(smem + xr[s] + mt * 4096);
-        }
-    }
-    auto dq = [&](int slot, int j, bool live) -> half8_t {
-        const half2_t pr = bit_cast<half2_t>(live ? sring[slot] : 0u);
-        return dequant8(ring[slot][j], half2_t{pr[0], pr[0]}, half2_t{pr[1], pr[1]}, m1024, m64);
-    };
-    half8_t wfn   = dq(0, 0, true);
-    int     b_cur = 0, b_nxt = BUFB, b_dma = 3 * BUFB;
-    // per-wave phase clocks (s_memtime ticks), only when tracing: barrier wait / compute incl. compiler waits / DMA wait
-    uint64_t t_bar = 0, t_cmp = 0, t_dma = 0;
-    for (int base = 0; base < nit_pad; base += PF) {
-#pragma unroll
-        for (int u = 0; u < PF; ++u) {
-            const int  i         = base + u;
-            const bool live      = i < nkb;
-            const bool live_next = i + 1 < nkb;
-            const uint64_t c0 = p.dbg ? __builtin_amdgcn_s_memtime() : 0;
-            __syncthreads();  // barrier(i): x(i+1) published, buffer of x(i-1) free
-            const uint64_t c1 = p.dbg ? __builtin_amdgcn_s_memtime() : 0;
-            {
-                const int bufi = b_dma / BUFB;
-                TM_GL_DMA(i + 3, bufi);
-            }
-            const char* cur = smem + b_cur;
-            const char* nxt = smem + b_nxt;
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                xf[3][mt] = *(const half8_t*)(cur + xr[3] + mt * 4096);
-            }
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                const half8_t wf = wfn;
-                wfn = s < 3 ? dq(u, s + 1, live) : dq((u + 1) % PF, 0, live_next);
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt) {
-                    acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf, xf[s][mt], acc[mt], 0, 0, 0);
-                }
-                if (s < 3) {
-#pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) {
-                        xf[s][mt] = *(const half8_t*)(nxt + xr[s] + mt * 4096);
-                    }
-                }
-            }
-            TM_GW_LOAD(u, i + PF);
-            // x(i+2) (DMA of iteration i-1) must have landed before the next barrier publishes it: younger operations of
-            // this wave = refill(i-1) 2 + DMA(i) my_xr + refill(i) 2
-            const uint64_t c2 = p.dbg ? __builtin_amdgcn_s_memtime() : 0;
-            TM_GL_WAIT(4);
-            if (p.dbg) {
-                const uint64_t c3 = __builtin_amdgcn_s_memtime();
-                t_bar += c1 - c0;
-                t_cmp += c2 - c1;
-                t_dma += c3 - c2;
-            }
-            b_cur = b_nxt;
-            b_nxt = b_nxt == 3 * BUFB ? 0 : b_nxt + BUFB;
-            b_dma = b_dma == 3 * BUFB ? 0 : b_dma + BUFB;
-        }
-    }
-#undef TM_GL_DMA
-#undef TM_GL_WAIT
-#undef TM_GW_LOAD
-    if (p.dbg && tid == 0) {
-        p.dbg[wgid * 8 + 2] = __builtin_amdgcn_s_memrealtime();
-        p.dbg[wgid * 8 + 6] = __builtin_amdgcn_s_memtime();
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no DMA may still be in flight when the workgroup's LDS is released
-    if (p.dbg && lane == 0 && (wave == 0 || wave == 5)) {
-        uint64_t* d2 = p.dbg + (size_t)(8192 + wgid * 2 + (wave ? 1 : 0)) * 8;
-        d2[0] = t_bar;
-        d2[1] = t_cmp;
-        d2[2] = t_dma;
-        d2[3] = (uint64_t)nit_pad;
-    }
-
-    if (nt_raw < ntiles) {
-        const int n = nt * 16 + g * 4;
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            const int m = mt * 16 + i16;
-            if (m >= p.M) {
-                continue;
-            }
-            const floatx4 a = acc[mt];
-            if (p.epilogue == 2) {
-                *(floatx4*)(p.partial + ((size_t)blockIdx.y * p.M + m) * p.N + n) = a;
-            }
-            else if (p.epilogue == 1) {
-                const float s0 = a[0] / (1.0f + __builtin_expf(-a[0]));
-                const float s1 = a[2] / (1.0f + __builtin_expf(-a[2]));
-                half2_t     o  = {(half_t)(s0 * a[1]), (half_t)(s1 * a[3])};
-                *(half2_t*)(p.y + (size_t)m * p.ldy + (n >> 1)) = o;
-            }
-            else {
-                half4_t o = {(half_t)a[0], (half_t)a[1], (half_t)a[2], (half_t)a[3]};
-                *(half4_t*)(p.y + (size_t)m * p.ldy + n) = o;
-            }
-        }
-    }
-    if (p.dbg && tid == 0) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        p.dbg[wgid * 8 + 3] = __builtin_amdgcn_s_memrealtime();
-    }
-}
-
-
 // y = h(sum_s partial[s]) (optionally through the gated-SiLU epilogue): 4 columns per thread
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(half_t* __restrict__ y,
                                                             int ldy,
@@ -1534,11 +829,13 @@ static int launch_one(const GemmParams& p, dim3 grid, hipStream_t st)
     // Requesting more than half of the 160 KB LDS makes co-residency impossible.
     static const int exclusive = env_int("TM_GEMM_EXCLUSIVE_CU", 1);
     const int lds = (exclusive && WN * WK >= 8 && lds_need < 84 * 1024 && grid.x * grid.y * grid.z <= 256) ? 84 * 1024 : lds_need;
-    static bool   attr_set = false;
-    if (!attr_set) {
+    static bool attr_set[16] = {};  // the raised dynamic-LDS limit is a per-device function attribute
+    int         dev = 0;
+    (void)hipGetDevice(&dev);
+    if (!attr_set[dev & 15]) {
         TM_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_kernel<WT, MT, NT, WN, WK, KS, PF, ABL, GRP>,
                                          hipFuncAttributeMaxDynamicSharedMemorySize, lds_need > 84 * 1024 ? lds_need : 84 * 1024));
-        attr_set = true;
+        attr_set[dev & 15] = true;
     }
     gemm_kernel<WT, MT, NT, WN, WK, KS, PF, ABL, GRP><<<grid, WN * WK * 64, lds, st>>>(p);
     TM_HIP_CHECK(hipGetLastError());
@@ -1577,72 +874,6 @@ static int launch_u4_nt1(const GemmParams& p, dim3 grid, int ks, hipStream_t st)
     static const int pf = env_int("TM_GEMM_PF", 8);  // ring depth experiment (4 | 8)
     return (p.kb_per_split / WK >= 16 && pf >= 8) ? launch_one<0, MT, 1, WN, WK, 1, 8>(p, grid, st) :
                                        launch_one<0, MT, 1, WN, WK, 1, 4>(p, grid, st);
-}
-
-template<int MT, int PF, int NPROD>
-static int launch_decode_pf(const GemmParams& p, dim3 grid, hipStream_t st)
-{
-    constexpr int lds_need = 3 * 16 * MT * 256;
-    // <= 256 workgroups must land one per CU (see launch_one): more than half of the LDS makes co-residency impossible
-    const int   lds      = grid.x * grid.y <= 256 ? 84 * 1024 : lds_need;
-    static bool attr_set = false;
-    if (!attr_set) {
-        TM_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_decode_kernel<MT, PF, NPROD>, hipFuncAttributeMaxDynamicSharedMemorySize, 84 * 1024));
-        attr_set = true;
-    }
-    gemm_decode_kernel<MT, PF, NPROD><<<grid, (8 + NPROD) * 64, lds, st>>>(p);
-    TM_HIP_CHECK(hipGetLastError());
-    return 0;
-}
-
-template<int MT>
-static int launch_decode(const GemmParams& p, dim3 grid, hipStream_t st)
-{
-    const int nprod = env_int("TM_GEMM_NPROD", 4);  // producer waves (1 | 2 | 4)
-    if constexpr (MT == 1) {
-        return nprod >= 4 ? launch_decode_pf<MT, 8, 4>(p, grid, st) : nprod == 2 ? launch_decode_pf<MT, 8, 2>(p, grid, st) : launch_decode_pf<MT, 8, 1>(p, grid, st);
-    }
-    else {
-        return nprod >= 4 ? launch_decode_pf<MT, 8, 4>(p, grid, st) : nprod == 2 ? launch_decode_pf<MT, 8, 2>(p, grid, st) : launch_decode_pf<MT, 8, 1>(p, grid, st);
-    }
-}
-
-template<int MT, int PF>
-static int launch_pingpong_pf(const GemmParams& p, dim3 grid, hipStream_t st)
-{
-    constexpr int lds_need = 2 * 16 * MT * 256;
-    const int     lds      = grid.x * grid.y <= 256 ? 84 * 1024 : lds_need;  // one workgroup per CU (see launch_one)
-    static bool   attr_set = false;
-    if (!attr_set) {
-        TM_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_pingpong_kernel<MT, PF>, hipFuncAttributeMaxDynamicSharedMemorySize, 84 * 1024));
-        attr_set = true;
-    }
-    gemm_pingpong_kernel<MT, PF><<<grid, 512, lds, st>>>(p);
-    TM_HIP_CHECK(hipGetLastError());
-    return 0;
-}
-
-template<int MT>
-static int launch_pingpong(const GemmParams& p, dim3 grid, hipStream_t st)
-{
-    const int pf = env_int("TM_GEMM_PP_PF", 3);  // ring depth in k-block pairs (registers: 3 is the most that fits)
-    return pf <= 2 ? launch_pingpong_pf<MT, 2>(p, grid, st) : launch_pingpong_pf<MT, 3>(p, grid, st);
-}
-
-template<int MT>
-static int launch_glds(const GemmParams& p, dim3 grid, hipStream_t st)
-{
-    constexpr int PF       = 8;
-    constexpr int lds_need = 4 * 16 * MT * 256;
-    const int     lds      = grid.x * grid.y <= 256 ? 84 * 1024 : lds_need;  // one workgroup per CU (see launch_one)
-    static bool   attr_set = false;
-    if (!attr_set) {
-        TM_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_glds_kernel<MT, PF>, hipFuncAttributeMaxDynamicSharedMemorySize, 84 * 1024));
-        attr_set = true;
-    }
-    gemm_glds_kernel<MT, PF><<<grid, 512, lds, st>>>(p);
-    TM_HIP_CHECK(hipGetLastError());
-    return 0;
 }
 
 template<int WT, int MT>
@@ -1807,73 +1038,6 @@ int launch_linear(const LinearWeight& w,
     splits     = (KB + p.kb_per_split - 1) / p.kb_per_split;  // no empty splits
     p.epilogue = splits > 1 ? 2 : (gated_silu ? 1 : 0);
 
-    // TM_GEMM_GLDS=1: LDS-DMA activation staging for the decode shape
-    const int gl = env_int("TM_GEMM_GLDS", 0);
-    if (gl && w.type == 0 && M <= 64 && waves == 8 && wk == 1 && nt == 1) {
-        p.kb_per_split = (KB + splits - 1) / splits;
-        splits         = (KB + p.kb_per_split - 1) / p.kb_per_split;
-        p.epilogue     = splits > 1 ? 2 : (gated_silu ? 1 : 0);
-        dim3 grid((w.N / 16 + 7) / 8, splits, 1);
-        const int rc4 = mt == 1 ? launch_glds<1>(p, grid, st) : mt == 2 ? launch_glds<2>(p, grid, st) : launch_glds<4>(p, grid, st);
-        if (rc4) {
-            return rc4;
-        }
-        if (splits > 1 && !defer_reduce) {
-            const size_t total = (size_t)M * w.N / 4;
-            splitk_reduce_kernel<<<(total + 255) / 256, 256, 0, st>>>(y, ldy, workspace, splits, M, w.N, gated_silu ? 1 : 0);
-            TM_HIP_CHECK(hipGetLastError());
-        }
-        if (slabs) {
-            *slabs = splits;
-        }
-        return 0;
-    }
-    // TM_GEMM_PP=1: ping-pong kernel for the decode shape (two wave groups in opposite phases, K split between them)
-    const int pp = env_int("TM_GEMM_PP", 0);
-    if (pp && w.type == 0 && M <= 64 && waves == 8 && KB % 2 == 0) {
-        int per        = (KB + splits - 1) / splits;
-        per            = (per + 1) / 2 * 2;
-        p.kb_per_split = per;
-        splits         = (KB + per - 1) / per;
-        p.epilogue     = splits > 1 ? 2 : (gated_silu ? 1 : 0);
-        dim3 grid((w.N / 16 + 7) / 8, splits, 1);
-        const int rc3 = mt == 1 ? launch_pingpong<1>(p, grid, st) : mt == 2 ? launch_pingpong<2>(p, grid, st) : launch_pingpong<4>(p, grid, st);
-        if (rc3) {
-            return rc3;
-        }
-        if (splits > 1 && !defer_reduce) {
-            const size_t total = (size_t)M * w.N / 4;
-            splitk_reduce_kernel<<<(total + 255) / 256, 256, 0, st>>>(y, ldy, workspace, splits, M, w.N, gated_silu ? 1 : 0);
-            TM_HIP_CHECK(hipGetLastError());
-        }
-        if (slabs) {
-            *slabs = splits;
-        }
-        return 0;
-    }
-    // TM_GEMM_V2=1: producer/consumer kernel for the decode shape.  Measured on MI355X (tools/nprod_sweep.sh): it ties
-    // the symmetric kernel (gate_up main loop 21-22 us either way, 1/2/4 producer waves alike), so it is NOT the
-    // default -- kept as the A/B arm that rules out "x staging / LDS round trips on the consumers' critical path".
-    const int v2 = env_int("TM_GEMM_V2", 0);
-    if (v2 && w.type == 0 && M <= 64 && waves == 8 && wk == 1 && nt == 1) {
-        p.kb_per_split = (KB + splits - 1) / splits;
-        splits         = (KB + p.kb_per_split - 1) / p.kb_per_split;
-        p.epilogue     = splits > 1 ? 2 : (gated_silu ? 1 : 0);
-        dim3 grid((w.N / 16 + 7) / 8, splits, 1);
-        const int rc2 = mt == 1 ? launch_decode<1>(p, grid, st) : mt == 2 ? launch_decode<2>(p, grid, st) : launch_decode<4>(p, grid, st);
-        if (rc2) {
-            return rc2;
-        }
-        if (splits > 1 && !defer_reduce) {
-            const size_t total = (size_t)M * w.N / 4;
-            splitk_reduce_kernel<<<(total + 255) / 256, 256, 0, st>>>(y, ldy, workspace, splits, M, w.N, gated_silu ? 1 : 0);
-            TM_HIP_CHECK(hipGetLastError());
-        }
-        if (slabs) {
-            *slabs = splits;
-        }
-        return 0;
-    }
     const int wn     = waves / wk;
     const int ntiles = w.N / 16;
     dim3      grid((ntiles + wn * nt - 1) / (wn * nt), splits, (M + 16 * mt - 1) / (16 * mt));

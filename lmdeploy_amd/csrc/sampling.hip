@@ -149,7 +149,8 @@ __global__ __launch_bounds__(1024) void sample_select_kernel(int* __restrict__ o
     // weight of one candidate of bin q
     auto wq = [&](int q) -> double {
         const float v = value_of_key(kBins - 1 - (tid * 64 + q));
-        return exp((double)((v - vmax) * invT));
+        const double w = exp((double)((v - vmax) * invT));
+        return w == w ? w : 0.0;  // NaN logits carry no probability
     };
     auto clip = [](long long room, long long raw) -> long long { return room <= 0 ? 0 : (room < raw ? room : raw); };
 
@@ -298,6 +299,10 @@ __global__ __launch_bounds__(1024) void sample_select_kernel(int* __restrict__ o
         }
         __syncthreads();
     }
+    // No candidate survived, or the distribution is not a distribution (NaN / inf logits: vmax not finite, Z not a positive
+    // finite number): the row still gets a DEFINED token -- the arg-max over its finite logits, lowest id on ties, token 0
+    // if there is none -- instead of silently keeping the previous step's id.
+    const bool degenerate = s_i[4] == kBins || !(Z > 0.0 && Z < 1e300) || !(__builtin_fabsf(vmax) <= 65504.f);
     const uint32_t sel_key = (uint32_t)(kBins - 1 - s_i[4]);
     const int      sel_m   = s_i[5];  // 1-based ordinal among the tokens with that logit, in id order
     if (tid == 0 && kept_out) {
@@ -313,6 +318,29 @@ __global__ __launch_bounds__(1024) void sample_select_kernel(int* __restrict__ o
     const int       per   = (V + 1023) / 1024;
     const int       begin = tid * per;
     const int       end   = min(begin + per, V);
+    if (degenerate) {
+        __shared__ unsigned long long s_best;
+        if (tid == 0) {
+            s_best = 0ull;
+        }
+        __syncthreads();
+        unsigned long long best = 0ull;
+        for (int i = begin; i < end; ++i) {
+            const uint16_t bits = row[i];
+            if ((bits & 0x7c00u) != 0x7c00u) {  // finite
+                const unsigned long long k = ((unsigned long long)(key_of(bits) + 1u) << 32) | (uint32_t)(0x7fffffff - i);
+                best                       = k > best ? k : best;
+            }
+        }
+        if (best) {
+            atomicMax(&s_best, best);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            out_ids[b] = s_best ? 0x7fffffff - (int)(uint32_t)(s_best & 0xffffffffull) : 0;
+        }
+        return;
+    }
     long long       my    = 0;
     for (int i = begin; i < end; ++i) {
         my += key_of(row[i]) == sel_key;

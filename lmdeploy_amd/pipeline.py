@@ -57,6 +57,7 @@ class Pipeline:
                 raise ValueError(f'model_format="{cfg.model_format}" but the checkpoint\'s quantization_config says {have} '
                                  f'(lmdeploy/turbomind/converter.py:174-176)')
         session_len = cfg.session_len or self.model_cfg.max_position_embeddings
+        self.session_len = int(session_len)
         devices = cfg.devices or list(range(cfg.tp))
         self.engine = Engine.from_model_config(
             self.model_cfg, weight_type={'u4': 0, 'f16': 1, 'fp8': 2}[self.model_cfg.weight_format if self.model_cfg.quantized
@@ -208,10 +209,22 @@ class Pipeline:
     def _generate_static(self, prompts: Sequence, g: GenerationConfig):
         ids = [self._encode(p) for p in prompts]
         stop = self._stop_ids(g)
-        for b0 in range(0, len(ids), self.max_batch_size):
-            chunk = ids[b0:b0 + self.max_batch_size]
+        # per-request admission on the host, as the continuous path and the reference do: a prompt that cannot fit its
+        # session is answered with INPUT_LENGTH_ERROR alone instead of failing the whole batch inside tm_engine_prefill
+        limit = self.session_len
+        order = []
+        for i, p in enumerate(ids):
+            if len(p) < 1 or len(p) + g.max_new_tokens > limit:
+                yield Response('', 0, len(p), 'error', [], index=i, error_code=ResponseType.INPUT_LENGTH_ERROR.name,
+                               error_message='empty prompt' if len(p) < 1 else
+                               f'prompt ({len(p)}) + max_new_tokens ({g.max_new_tokens}) exceeds session_len ({limit})')
+            else:
+                order.append(i)
+        for b0 in range(0, len(order), self.max_batch_size):
+            idx = order[b0:b0 + self.max_batch_size]
+            chunk = [ids[i] for i in idx]
             try:
-                self.engine.set_sampling([g.sampling_params(b0 + i) for i in range(len(chunk))] if g.sampling_params() else None)
+                self.engine.set_sampling([g.sampling_params(i) for i in idx] if g.sampling_params() else None)
                 lp = g.logits_params(sorted(stop)[:_ffi.MAX_STOP_IDS])
                 self.engine.set_logits_params([lp] * len(chunk) if lp else None)
                 self.engine.prefill(chunk, max_new_tokens=g.max_new_tokens)
@@ -228,12 +241,11 @@ class Pipeline:
             except _ffi.TmError as e:
                 self.engine.release()
                 rt = STATUS_TO_RESPONSE.get(e.status, ResponseType.INTERNAL_ENGINE_ERROR)
-                for i in range(len(chunk)):
-                    yield Response('', 0, len(chunk[i]), 'error', [], index=b0 + i, error_code=rt.name,
-                                   error_message=str(e))
+                for i, p in zip(idx, chunk):
+                    yield Response('', 0, len(p), 'error', [], index=i, error_code=rt.name, error_message=str(e))
                 continue
             self.engine.release()
-            for i, row in enumerate(toks):
+            for i, p, row in zip(idx, chunk, toks):
                 out, reason = [], 'length'
                 for tkn in row.tolist():
                     if tkn in stop:
@@ -241,4 +253,4 @@ class Pipeline:
                         break
                     out.append(tkn)
                 text = self.tokenizer.decode(out, skip_special_tokens=g.skip_special_tokens) if self.tokenizer else ''
-                yield Response(text, len(out), len(chunk[i]), reason, out, index=b0 + i)
+                yield Response(text, len(out), len(p), reason, out, index=i)

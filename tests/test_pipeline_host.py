@@ -170,6 +170,11 @@ def test_errors_become_responses_and_processors_reach_the_engine(pipe):
     assert [r.index for r in res] == [0, 1, 2]
     assert res[1].finish_reason == 'error' and res[1].error_code == 'INPUT_LENGTH_ERROR' and res[1].token_ids == []
     assert res[0].token_ids == res[2].token_ids == _expect(ok, 8)[0]
+    # the static-batch path (<= max_batch_size prompts) answers the offender alone as well: the others still run
+    res2 = pipe([too_long, ok], g)
+    assert [r.index for r in res2] == [0, 1]
+    assert res2[0].finish_reason == 'error' and res2[0].error_code == 'INPUT_LENGTH_ERROR' and res2[0].token_ids == []
+    assert res2[1].finish_reason == 'length' and res2[1].token_ids == _expect(ok, 8)[0]
     lp = g.logits_params([])
     # greedy (do_sample=False): the penalty is reset to 1.0 like the reference does (async_engine.py:424-430) ...
     assert lp == dict(repetition_penalty=pytest.approx(1.0), min_new_tokens=2, bad_ids=[5], stop_ids=[])
