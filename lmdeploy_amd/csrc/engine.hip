@@ -209,8 +209,8 @@ struct tm_engine {
     uint32_t*    p2p_state = nullptr;
     int          p2p_rows = 0;
     bool         p2p_ready = false;
-    bool         comm_overlap = true;    // TM_COMM_STREAM=0: collectives on the engine stream (round-1 behaviour)
-    bool         comm_prefetch = true;   // TM_COMM_PREFETCH=0: no weight prefetch under the collective
+    bool         comm_overlap = false;   // TM_COMM_STREAM=1: collectives on a side stream (fork / join around each)
+    bool         comm_prefetch = false;  // TM_COMM_PREFETCH=1: prefetch the next linear's weights under the collective
     bool         graph_comm_failed = false;  // capturing the RCCL calls failed once: stay eager
     bool         use_comm = false;  // collectives on the data path: tp > 1 (or TM_FORCE_COMM=1: single-rank communicator,
                                     // exercises the RCCL code path on a 1-GPU box)
@@ -838,8 +838,12 @@ int tm_engine_comm_init(tm_engine* e, const void* host_id128)
     TM_NCCL_CHECK(ncclCommInitRank(&e->comm, e->cfg.tp, id, e->cfg.rank));
     const char* cs   = getenv("TM_COMM_STREAM");
     const char* cp   = getenv("TM_COMM_PREFETCH");
-    e->comm_overlap  = !(cs && !atoi(cs));
-    e->comm_prefetch = !(cp && !atoi(cp));
+    // Measured on MI355X (per-rank emulation of Llama-3-70B TP = 8, 160 collectives per step, profiles/r02_comm_stream_arms.txt):
+    // engine stream 6.81 ms/step; side stream without the prefetch 6.81 ms (a fork/join inside a hipGraph is free, but costs
+    // ~30 us per collective on eager launches); side stream + weight prefetch 7.80 ms (the prefetch kernel costs 6 us and the
+    // next GEMM gains nothing from L2 / Infinity-Cache resident weights).  Default: engine stream; the arms stay reachable.
+    e->comm_overlap  = cs && atoi(cs);
+    e->comm_prefetch = cp && atoi(cp);
     if (e->comm_overlap && !e->comm_stream) {
         TM_HIP_CHECK(hipStreamCreateWithFlags(&e->comm_stream, hipStreamNonBlocking));
         TM_HIP_CHECK(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));

@@ -53,12 +53,13 @@ def test_engine_matches_oracle(cuda, kv_bits, use_graph):
         assert np.array_equal(toks[safe, s], ref_toks[s][safe]), f'step {s}: greedy tokens differ'
 
 
-@pytest.mark.parametrize('graph_comm', [0, 1])
-def test_engine_collective_path_single_rank(cuda, monkeypatch, graph_comm):
+@pytest.mark.parametrize('graph_comm,side_stream', [(0, 0), (1, 0), (1, 1), (0, 1)])
+def test_engine_collective_path_single_rank(cuda, monkeypatch, graph_comm, side_stream):
     """The tp > 1 data path (RCCL all-reduce after wo / w2, vocabulary-sharded lm_head + candidate all-gather), driven
     on one GPU through a 1-rank communicator (TM_FORCE_COMM=1): must reproduce the collective-free engine exactly
     (a 1-rank sum is the identity; the non-deferred split-K reduce rounds the same fp32 sums).  graph_comm=1 also
-    captures the RCCL calls into the decode hipGraph."""
+    captures the RCCL calls into the decode hipGraph; side_stream=1 is the opt-in arm with the collectives on a side stream
+    (fork / join) and the next linear's weights prefetched underneath."""
     cfg = o.ModelConfig(hidden=256, layers=2, q_heads=4, kv_heads=2, head_dim=128, inter=512, vocab=1024,
                         kv_bits=8, rope=o.RopeParam(128, 500000.0, 'llama3', 8.0, 1.0, 4.0, 8192))
     w = o.make_synthetic_weights(cfg, seed=5)
@@ -69,6 +70,8 @@ def test_engine_collective_path_single_rank(cuda, monkeypatch, graph_comm):
         if force:
             monkeypatch.setenv('TM_FORCE_COMM', '1')
             monkeypatch.setenv('TM_GRAPH_COMM', str(graph_comm))
+            monkeypatch.setenv('TM_COMM_STREAM', str(side_stream))
+            monkeypatch.setenv('TM_COMM_PREFETCH', str(side_stream))
         else:
             monkeypatch.delenv('TM_FORCE_COMM', raising=False)
         eng = Engine.from_model_config(cfg, max_batch_size=4, session_len=128, quant_policy=8, use_graph=1)
