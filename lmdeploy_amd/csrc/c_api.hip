@@ -296,7 +296,7 @@ int tm_linear_forward(const tm_linear* w, const void* x, int ldx, void* y, int l
         // 0x200 + shape: the decode kernel (gemm_decode.hip) with an explicit workgroup shape; M <= 64, u4, N % 32 == 0
         TM_REQUIRE(dec32_supported(w->w, M), "decode kernel: u4 weights, N % 32 == 0");
         cfg.d32_shape = waves & 0xff;
-        TM_REQUIRE(cfg.d32_shape <= 4 && (cfg.d32_shape == 4) == (M > 64), "decode kernel shape 0..3 (M <= 64) or 4 (M > 64)");
+        TM_REQUIRE(cfg.d32_shape <= 5 && (cfg.d32_shape >= 4) == (M > 64), "decode kernel shape 0..3 (M <= 64) or 4 / 5 (M > 64)");
         waves = 0;
     }
     if (waves > 0) {

@@ -293,7 +293,7 @@ __global__ __launch_bounds__(CG* WK * 64) void gemm_dec32_kernel(Dec32Params p)
                 D32_LOAD_W(q, phys(q / BPS) * S + wk + (q % BPS) * WK);
                 __builtin_amdgcn_sched_barrier(0);
             }
-            asm volatile("s_waitcnt vmcnt(%0)" ::"i"(3 * PF) : "memory");
+            asm volatile("s_waitcnt vmcnt(%0)" ::"i"((ABL & 0x1000) ? 0 : 3 * PF) : "memory");
         }
         else {
             D32_LOAD_X(phys(0));
@@ -333,7 +333,12 @@ __global__ __launch_bounds__(CG* WK * 64) void gemm_dec32_kernel(Dec32Params p)
                 for (int i = 0; i < BPS; ++i) {
                     asm volatile("" ::"v"(ring[u * BPS + i][0]), "v"(ring[u * BPS + i][1]), "v"(sring[u * BPS + i]));
                 }
-                D32_DMA_X(phys(t + 1), buf ^ 1);
+                // Not behind the last stage: nobody would read it, and the refills that the counted wait below relies on
+                // are dead code there (hipcc drops them in the remainder stage), so that DMA could still be landing when the
+                // epilogue lays the reduction image over the stage buffers (seen as flaky rows 96..127 of row blocks, r02).
+                if (t + 1 < nst) {  // uniform
+                    D32_DMA_X(phys(t + 1), buf ^ 1);
+                }
             }
 #pragma unroll
             for (int i = 0; i < BPS; ++i) {
@@ -455,7 +460,7 @@ __global__ __launch_bounds__(CG* WK * 64) void gemm_dec32_kernel(Dec32Params p)
             }
             if constexpr (DMA && !(ABL & 8)) {
                 // my DMA pieces of stage t+1 have landed when at most the 3 * BPS refills issued after them are in flight
-                asm volatile("s_waitcnt vmcnt(%0)" ::"i"((ABL & 16) ? 0 : 3 * BPS) : "memory");
+                asm volatile("s_waitcnt vmcnt(%0)" ::"i"((ABL & (16 | 0x2000)) ? 0 : 3 * BPS) : "memory");
             }
             __syncthreads();
         };
@@ -571,6 +576,265 @@ static int launch_dec32_one(const Dec32Params& p, dim3 grid, hipStream_t st)
     return 0;
 }
 
+// ---- prefill tile: 128 rows x 512 columns per workgroup, TWO weight fragments per activation-fragment read -----------------
+// Measured on the 128 x 256 tile above (profiles/r02_bench_gemm_prefill_ablation.txt): with loads and dequant removed the
+// loop still tops out at 62..71 % of the MFMA peak, because every v_mfma_f32_32x32x16 needs one 1 KB x fragment out of LDS
+// (4 SIMDs x 1 MFMA / 32 clk x 1 KB = 128 B/clk = the LDS peak): the LDS pipe is co-critical with the matrix pipe.  Here a
+// wave owns 64 columns (two P32 units per k-block) x 128 rows: one ds_read_b128 feeds two MFMAs, 128 accumulator registers
+// per lane, 8 waves (two per SIMD, 256 registers each).  One k-block per LDS stage (32 KB, double buffered), x staged
+// through registers (the LDS-DMA costs 30 % at this tile size), weights through a two-k-block register ring.
+// grid = (ceil(N / 512), splits, ceil(M / 128)); the epilogue stores straight from the accumulators.
+template<int ABL = 0>
+__global__ __launch_bounds__(512) void gemm_pre64_kernel(Dec32Params p)
+{
+    constexpr int MH = 4, CG = 8, NB = 2, T = 512, ROWS = 128;
+    constexpr int KBB = ROWS * 256;  // LDS bytes of one k-block of x
+    constexpr int XR  = ROWS * 16 / T;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid  = threadIdx.x;
+    const int wgid = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    if (p.dbg && tid == 0) {
+        p.dbg[wgid * 8 + 0] = __builtin_amdgcn_s_memrealtime();
+    }
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31  = lane & 31;
+    const int half = lane >> 5;
+    int       cgc[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        cgc[nb] = min((int)(blockIdx.x * NB + nb) * CG + wave, p.ncg - 1);
+    }
+    const int kb0  = blockIdx.y * p.kb_per_split;
+    const int nkb  = min(p.kb_per_split, p.KB - kb0);
+    const int m0   = blockIdx.z * ROWS;
+    const int Mloc = min(ROWS, p.M - m0);
+
+    const auto rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.wp, 0, (int)((size_t)p.KB * p.ncg * kP32Unit), 0x00020000);
+    const auto rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x + (size_t)m0 * p.ldx), 0,
+                                                        (int)(((size_t)(Mloc - 1) * p.ldx + p.K) * 2), 0x00020000);
+    const int  vw   = lane * 16;
+    const int  vs   = 2048 + l31 * 4;
+
+    floatx16 acc[NB][MH];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+#pragma unroll
+        for (int h = 0; h < MH; ++h) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                acc[nb][h][r] = 0.f;
+            }
+        }
+    }
+    u32x4    ring[2][NB][2];
+    uint32_t sring[2][NB];
+    u32x4    xr[XR];
+    // staging: thread -> (row = tid / 16 + 32 r, 16-byte chunk tid % 16); rows 32 apart share the swizzle term, so the LDS
+    // address of piece r is xlds0 + r * 8192 (an immediate) and only the global offsets need registers
+    int       xoff[XR];
+    const int xlds0 = (tid >> 4) * 256 + (((tid & 15) ^ ((tid >> 4) & 15)) << 4);
+#pragma unroll
+    for (int r = 0; r < XR; ++r) {
+        xoff[r] = (min((tid >> 4) + 32 * r, Mloc - 1) * p.ldx + (tid & 15) * 8) * 2;
+    }
+    // B fragment of 16-k step j: row (l & 31) [+ 32 h], chunk (2j + half) ^ (row & 15) = 2j ^ (half ^ (row & 15)): one
+    // v_xor with an immediate per step instead of eight address registers
+    const int frow = l31 * 256;
+    const int fsw  = (half ^ (l31 & 15)) << 4;
+    uint32_t m1024 = 0x64006400u, m64 = 0x54005400u;
+    asm volatile("" : "+v"(m1024), "+v"(m64));
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)smem);
+
+    // k-block b (relative to kb0; clamped past the slice, its scales are then zeroed) -> ring slot
+#define P64_LOAD_W(slot, b)                                                                                       \
+    _Pragma("unroll") for (int nb = 0; nb < NB; ++nb)                                                             \
+    {                                                                                                             \
+        const int uo_       = ((kb0 + min((b), nkb - 1)) * p.ncg + cgc[nb]) * kP32Unit;                           \
+        ring[slot][nb][0]   = __builtin_amdgcn_raw_buffer_load_b128(rs_w, vw, uo_, /*nt*/ 2);                     \
+        ring[slot][nb][1]   = __builtin_amdgcn_raw_buffer_load_b128(rs_w, vw + 1024, uo_, /*nt*/ 2);              \
+        sring[slot][nb]     = __builtin_amdgcn_raw_buffer_load_b32(rs_w, vs, uo_, 0);                             \
+    }
+#define P64_LOAD_X(b)                                                                                             \
+    _Pragma("unroll") for (int r = 0; r < XR; ++r)                                                                \
+    {                                                                                                             \
+        xr[r] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, xoff[r], (kb0 + min((b), nkb - 1)) * 256, 0);         \
+    }
+#define P64_STORE_X(buf)                                                                                          \
+    _Pragma("unroll") for (int r = 0; r < XR; ++r)                                                                \
+    {                                                                                                             \
+        *(u32x4*)(smem + (buf)*KBB + xlds0 + r * 8192) = xr[r];                                                   \
+    }
+
+    if (nkb > 0) {
+        // issue order = steady-state order (oldest first at the top of stage t: W(t), x(t+1), W(t+1)); see gemm_dec32_kernel
+        P64_LOAD_X(0);
+        __builtin_amdgcn_sched_barrier(0);
+        P64_LOAD_W(0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        P64_STORE_X(0);
+        __builtin_amdgcn_sched_barrier(0);
+        P64_LOAD_X(1);
+        __builtin_amdgcn_sched_barrier(0);
+        P64_LOAD_W(1, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+        if (p.dbg && tid == 0) {
+            p.dbg[wgid * 8 + 1] = __builtin_amdgcn_s_memrealtime();
+            p.dbg[wgid * 8 + 5] = __builtin_amdgcn_s_memtime();  // shader-clock counter: (d6 - d5) / loop time = the clock
+        }
+        auto stage = [&](auto U, const int t) __attribute__((always_inline)) {
+            constexpr int u    = decltype(U)::value;  // ring slot = LDS buffer = parity of t
+            const bool    live = t < nkb;
+            half2_t       s2[NB], z2[NB];
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                const half2_t pr = bit_cast<half2_t>(live ? sring[u][nb] : 0u);
+                s2[nb]           = half2_t{pr[0], pr[0]};
+                z2[nb]           = half2_t{pr[1], pr[1]};
+            }
+            half8_t        f0[MH], f1[MH];
+            const unsigned xa = lds0 + u * KBB;
+            auto           rd = [&](half8_t(&f)[MH], int j) __attribute__((always_inline)) {
+                const unsigned ad = xa + (unsigned)(frow + ((32 * j) ^ fsw));
+#pragma unroll
+                for (int h = 0; h < MH; ++h) {
+                    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(f[h]) : "v"(ad), "i"(h * 8192));
+                }
+            };
+            auto wt = [&](half8_t(&f)[MH], auto N) __attribute__((always_inline)) {
+                constexpr int n = decltype(N)::value;
+                asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]) : "i"(n));
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            rd(f0, 0);
+            // Two dequantised fragments live (a0: first column half, a1: second).  The VALU work of a dequant (14 packed
+            // ops) is interleaved INTO the MFMA stream of the same wave -- an MFMA occupies the matrix pipe for 32 cycles but
+            // the issue port for 4, so ~4 VALU ops fit behind each one: a1(j) is built behind the four MFMAs that use a0(j),
+            // a0(j+1) behind the four that use a1(j).  Back-to-back "dequant block, then MFMA block" (the first version of
+            // this kernel, and what hipcc emits on its own) measured additive: loop 102 us = 55 us of MFMA + 42 us of
+            // everything else (profiles/r02_pre64_phase_traces.txt).
+            half8_t a0 = dequant8_p32(ring[u][0][0][0], s2[0], z2[0], m1024, m64), a1;
+            static_for<8>([&](auto J) {
+                constexpr int  j  = decltype(J)::value;
+                half8_t(&cur)[MH] = (j & 1) ? f1 : f0;
+                half8_t(&nxt)[MH] = (j & 1) ? f0 : f1;
+                if constexpr (j + 1 < 8) {
+                    rd(nxt, j + 1);
+                }
+                wt(cur, std::integral_constant<int, (j + 1 < 8) ? MH : 0>{});
+                a1 = dequant8_p32(ring[u][1][j >> 2][j & 3], s2[1], z2[1], m1024, m64);
+#pragma unroll
+                for (int h = 0; h < MH; ++h) {
+                    if constexpr (ABL & 2) {
+                        asm volatile("" ::"v"(a0), "v"(cur[h]));
+                    }
+                    else {
+                        acc[0][h] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, cur[h], acc[0][h], 0, 0, 0);
+                    }
+                }
+                if constexpr (j + 1 < 8) {
+                    a0 = dequant8_p32(ring[u][0][(j + 1) >> 2][(j + 1) & 3], s2[0], z2[0], m1024, m64);
+                }
+#pragma unroll
+                for (int h = 0; h < MH; ++h) {
+                    if constexpr (ABL & 2) {
+                        asm volatile("" ::"v"(a1), "v"(cur[h]));
+                    }
+                    else {
+                        acc[1][h] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, cur[h], acc[1][h], 0, 0, 0);
+                    }
+                }
+                if constexpr (!(ABL & 4)) {
+#pragma unroll
+                    for (int g = 0; g < 2 * MH; ++g) {  // 8 x (1 MFMA, up to 4 VALU)
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            });
+            // x of k-block t+1 (loaded one stage ago) -> the other buffer, x of t+2 into the same registers, this stage's ring
+            // slot refilled for t+2; all unconditional (past the slice: the last block again, nobody consumes it)
+            P64_STORE_X(u ^ 1);
+            P64_LOAD_X(t + 2);
+            P64_LOAD_W(u, t + 2);
+            __syncthreads();
+        };
+        int t0 = 0;
+        for (; t0 + 2 <= nkb; t0 += 2) {
+            static_for<2>([&](auto U) { stage(U, t0 + decltype(U)::value); });
+        }
+        static_for<2>([&](auto U) {
+            if (t0 + decltype(U)::value < nkb) {
+                stage(U, t0 + decltype(U)::value);
+            }
+        });
+    }
+#undef P64_LOAD_W
+#undef P64_LOAD_X
+#undef P64_STORE_X
+    if (p.dbg && tid == 0) {
+        p.dbg[wgid * 8 + 2] = __builtin_amdgcn_s_memrealtime();
+        p.dbg[wgid * 8 + 6] = __builtin_amdgcn_s_memtime();
+    }
+    // ---- epilogue: straight from the accumulators (no k-phases to merge here, so no LDS round trip and no barrier: the LDS
+    // image of gemm_dec32_kernel cost 11.7 us of a 114 us workgroup).  Lane holds, per half h and register r: row
+    // m = 32h + (l & 31), column 32 cg + 8 (r >> 2) + 4 (l >> 5) + (r & 3): the two lane halves write adjacent 8-byte pieces,
+    // the 4 register groups complete a 64-byte row segment, the neighbouring wave the other half of the 128-byte line.
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        const int ncol0 = ((blockIdx.x * NB + nb) * CG + wave) * 32;
+#pragma unroll
+        for (int h = 0; h < MH; ++h) {
+            const int m = 32 * h + l31;
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int n = ncol0 + 8 * g4 + 4 * half;
+                if (m >= Mloc || n >= p.N) {
+                    continue;
+                }
+                const floatx4 a  = {acc[nb][h][4 * g4], acc[nb][h][4 * g4 + 1], acc[nb][h][4 * g4 + 2], acc[nb][h][4 * g4 + 3]};
+                const size_t  mg = (size_t)m0 + m;
+                if (p.epilogue == 2) {
+                    *(floatx4*)(p.partial + ((size_t)blockIdx.y * p.M + mg) * p.N + n) = a;
+                }
+                else if (p.epilogue == 1) {
+                    const float s0 = a[0] / (1.0f + __builtin_expf(-a[0]));
+                    const float s1 = a[2] / (1.0f + __builtin_expf(-a[2]));
+                    half2_t     o  = {(half_t)(s0 * a[1]), (half_t)(s1 * a[3])};
+                    *(half2_t*)(p.y + mg * p.ldy + (n >> 1)) = o;
+                }
+                else {
+                    half4_t o = {(half_t)a[0], (half_t)a[1], (half_t)a[2], (half_t)a[3]};
+                    *(half4_t*)(p.y + mg * p.ldy + n) = o;
+                }
+            }
+        }
+    }
+    if (p.dbg && tid == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        p.dbg[wgid * 8 + 3] = __builtin_amdgcn_s_memrealtime();
+    }
+}
+
+template<int ABL>
+static int launch_pre64_one(const Dec32Params& p, dim3 grid, hipStream_t st)
+{
+    constexpr int lds = 96 * 1024;  // two 32 KB stages; > 80 KB so that exactly one workgroup (8 waves x 256 registers) owns the CU
+    static bool   attr_set[16] = {};
+    int           dev = 0;
+    (void)hipGetDevice(&dev);
+    if (!attr_set[dev & 15]) {
+        TM_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_pre64_kernel<ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        attr_set[dev & 15] = true;
+    }
+    gemm_pre64_kernel<ABL><<<grid, 512, lds, st>>>(p);
+    TM_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
 // The default structure: LDS-DMA staging of x + the explicit fragment pipeline (measured on MI355X, tools/trace_dec32.py /
 // tools/bench_gemm.py: w1w3 main loop at M = 64 16.5 us with register staging + ds_write -> 15.3 us with the DMA -> 14.9 us
 // with the inline-asm fragment reads; M = 8192: 1.03 -> 1.09 PF/s; the LDS-read scheduling fence and s_setprio variants
@@ -585,8 +849,12 @@ static int launch_dec32_shape(const Dec32Params& p, dim3 grid, int shape, hipStr
     if constexpr (MH == 4) {
         // row blocks of 128 rows x 256 columns, 8 waves of 32 columns over the whole k slice (M > 64): every dequantised
         // weight fragment feeds 4 MFMAs, every x fragment read from LDS feeds 32 columns
+        if (shape == 5) {  // 128 x 512 tile, two weight fragments per x-fragment read (gemm_pre64_kernel)
+            if (abl == 2) return launch_pre64_one<2>(p, grid, st);  // timing: no MFMA
+            return launch_pre64_one<0>(p, grid, st);
+        }
         if (shape != 4) {
-            set_last_error("gemm_dec32: the 128-row tile is shape 4");
+            set_last_error("gemm_dec32: the 128-row tiles are shapes 4 and 5");
             return 1;
         }
         if (abl == 0) return launch_dec32_one<4, 8, 1, 2, 4, 0>(p, grid, st);
@@ -597,6 +865,10 @@ static int launch_dec32_shape(const Dec32Params& p, dim3 grid, int shape, hipStr
         if (abl == 0x10d) return launch_dec32_one<4, 8, 1, 2, 4, 0x10d>(p, grid, st);  // MFMA + weight loads only
         if (abl == 0x11d) return launch_dec32_one<4, 8, 1, 2, 4, 0x11d>(p, grid, st);  // MFMA only
         if (abl == 0x102) return launch_dec32_one<4, 8, 1, 2, 4, 0x102>(p, grid, st);  // no MFMA
+        if (abl == 0x1900) return launch_dec32_one<4, 8, 1, 2, 4, 0x1900>(p, grid, st);  // diagnosis: prologue drains vmcnt
+        if (abl == 0x2900) return launch_dec32_one<4, 8, 1, 2, 4, 0x2900>(p, grid, st);  // diagnosis: every stage drains vmcnt
+        if (abl == 0x3900) return launch_dec32_one<4, 8, 1, 2, 4, 0x3900>(p, grid, st);
+        if (abl == 0x800) return launch_dec32_one<4, 8, 1, 2, 4, 0x800>(p, grid, st);    // register staging + asm fragment pipeline
         return launch_dec32_one<4, 8, 1, 2, 4, kD32Mode>(p, grid, st);
     }
     else
@@ -636,9 +908,9 @@ static int launch_dec32_shape(const Dec32Params& p, dim3 grid, int shape, hipStr
 // shape -> (column groups, k-blocks per stage)
 static void dec32_shape_dims(int shape, int* cg, int* s)
 {
-    static const int cgs[5] = {4, 8, 4, 2, 8};
-    *cg = cgs[shape < 0 || shape > 4 ? 0 : shape];
-    *s  = shape == 4 ? 2 : 4;
+    static const int cgs[6] = {4, 8, 4, 2, 8, 16};
+    *cg = cgs[shape < 0 || shape > 5 ? 0 : shape];
+    *s  = shape == 5 ? 1 : (shape == 4 ? 2 : 4);
 }
 
 bool dec32_supported(const LinearWeight& w, int M)
@@ -659,7 +931,10 @@ void dec32_pick(const LinearWeight& w, int M, int* shape_out, int* splits_out)
         shape = 0;
     }
     if (M > 64) {
-        shape = 4;
+        // M <= 256 (batch-128 decode, small admissions): 256-column tiles keep more workgroups alive; beyond that the
+        // 512-column tile with two weight fragments per x-fragment read (TM_PRE64_MIN_M: first M that takes it)
+        static const int pre64_from = env_int2("TM_PRE64_MIN_M", 257);
+        shape = (M >= pre64_from && w.N >= 512) ? 5 : 4;
     }
     int cgn, S;
     dec32_shape_dims(shape, &cgn, &S);
@@ -687,7 +962,7 @@ int launch_linear_dec32(const LinearWeight& w, const half_t* x, int ldx, half_t*
                         int splits, float* workspace, int* slabs_out, hipStream_t st)
 {
     TM_REQUIRE(w.packed32 != nullptr && w.N % 32 == 0, "decode GEMM: P32 layout missing");
-    TM_REQUIRE(M >= 1 && (M <= 64) == (shape != 4), "decode GEMM: shapes 0..3 take M <= 64, shape 4 takes M > 64");
+    TM_REQUIRE(M >= 1 && (M <= 64) == (shape < 4), "decode GEMM: shapes 0..3 take M <= 64, shapes 4 / 5 take M > 64");
     TM_REQUIRE(ldx % 8 == 0, "x rows must be 16-byte aligned");
     int cgn, S;
     dec32_shape_dims(shape, &cgn, &S);
@@ -712,8 +987,8 @@ int launch_linear_dec32(const LinearWeight& w, const half_t* x, int ldx, half_t*
     p.epilogue     = splits > 1 ? 2 : (gated_silu ? 1 : 0);
     p.dbg          = g_gemm_dbg;
     p.rotate       = env_int2("TM_D32_ROTATE", 0);
-    dim3      grid((p.ncg + cgn - 1) / cgn, splits, shape == 4 ? (M + 127) / 128 : 1);
-    const int rc = shape == 4 ? launch_dec32_shape<4>(p, grid, shape, st) :
+    dim3      grid((p.ncg + cgn - 1) / cgn, splits, shape >= 4 ? (M + 127) / 128 : 1);
+    const int rc = shape >= 4 ? launch_dec32_shape<4>(p, grid, shape, st) :
                    M <= 32    ? launch_dec32_shape<1>(p, grid, shape, st) :
                                 launch_dec32_shape<2>(p, grid, shape, st);
     if (rc) {

@@ -307,7 +307,9 @@ __global__ __launch_bounds__(CG* WK * 64) void gemm_fp8_kernel(Fp8Params p)
             for (int i = 0; i < BPS; ++i) {
                 asm volatile("" ::"v"(ring[u * BPS + i][0]), "v"(ring[u * BPS + i][3]), "v"(swr[u * BPS + i]), "v"(sxr[u * BPS + i][MH - 1]));
             }
-            F8_DMA_X(t + 1, buf ^ 1);
+            if (t + 1 < nst) {  // uniform; see gemm_dec32_kernel: a DMA behind the last stage could land on the reduction image
+                F8_DMA_X(t + 1, buf ^ 1);
+            }
 #pragma unroll
             for (int i = 0; i < BPS; ++i) {
                 const int  slot = u * BPS + i;

@@ -89,6 +89,27 @@ def test_w4a16_linear_full_size(tm, cuda, K, N, gated, M):
         assert np.all(err <= tol), f'nt={nt} splits={splits} waves={waves:#x}: max err {err.max()} at {np.argmax(err - tol)}'
 
 
+@pytest.mark.parametrize('K,N,gated', [(4096, 28672, 1), (14336, 4096, 0), (4096, 6144, 0)])
+@pytest.mark.parametrize('waves', [0, 0x204, 0x205])
+def test_w4a16_prefill_full_size(tm, cuda, K, N, gated, waves):
+    """one 8192-token prefill chunk at the Llama-3-8B shapes through the prefill tiles (heuristic, 128 x 256, 128 x 512):
+    128 sampled rows (incl. the first and the last of the chunk and of a row block) against the fp32 oracle product"""
+    h, wd = _linear(tm, K, N)
+    M = 8192
+    g = torch.Generator(device='cuda').manual_seed(K + N)
+    x_d = torch.randn((M, K), generator=g, device='cuda').to(torch.float16)
+    ws = torch.zeros(max(1, tm.tm_linear_workspace(h, M)), dtype=torch.uint8, device='cuda')
+    y = torch.zeros((M, N // 2 if gated else N), dtype=torch.float16, device='cuda')
+    _ffi.check(tm.tm_linear_forward(h, x_d.data_ptr(), K, y.data_ptr(), y.shape[1], M, gated, 0, 0, waves, ws.data_ptr(), st()))
+    rows = np.unique(np.concatenate([[0, 127, 128, 8191, 8064], np.random.default_rng(K).integers(0, M, 123)]))
+    x = x_d[torch.from_numpy(rows).cuda()].cpu().numpy()
+    acc = x.astype(np.float32) @ wd
+    ref = (o.gated_silu_epilogue(acc) if gated else acc.astype(f16)).astype(np.float32)
+    got = y[torch.from_numpy(rows).cuda()].cpu().numpy().astype(np.float32)
+    err = np.abs(got - ref)
+    assert np.all(err <= 2e-3 + 2.0**-9 * np.abs(ref)), f'waves={waves:#x}: max err {err.max()}'
+
+
 @pytest.mark.parametrize('K,N', [(4096, 28672), (14336, 4096)])
 def test_w4a16_linearity_full_size(tm, cuda, K, N):
     """size-independent property at the headline shapes: the kernel is linear in x up to fp16 output rounding, and a

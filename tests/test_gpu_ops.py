@@ -427,8 +427,9 @@ def test_w4a16_linear(tm, cuda, K, N, M):
 @pytest.mark.parametrize('K,N,gated', [(4096, 6144, 0), (1792, 4096, 0), (1024, 512, 0), (4096, 1024, 1), (1024, 2048, 1)])
 @pytest.mark.parametrize('M', [257, 300, 512, 1000, 2500])
 def test_w4a16_linear_prefill_tiles(tm, cuda, K, N, M, gated):
-    """The prefill-shaped path (M > 256): 128-row x 256-column workgroup tiles (MT = 8), ragged last row block, the
-    automatic split-K of mid-size M (fewer than 256 workgroups otherwise) and explicit split counts, plain and gated-SiLU
+    """The prefill-shaped path (M > 256): 128-row x 512-column workgroup tiles with two weight fragments per x-fragment read
+    (0x205, the default from M = 257) and 128 x 256 tiles (0x204), the round-1 tile (explicit nt / waves), ragged last row
+    block, column counts that do not fill the last workgroup, the automatic split-K of mid-size M (fewer than 256 workgroups otherwise) and explicit split counts, plain and gated-SiLU
     epilogues -- same oracle and tolerance as the decode shapes."""
     rng = np.random.default_rng(K + N + M + 11)
     h, (q, s, z) = _make_linear(tm, rng, K, N)
@@ -436,7 +437,8 @@ def test_w4a16_linear_prefill_tiles(tm, cuda, K, N, M, gated):
     ref = (o.w4a16_linear_gated_silu(x, q, s, z) if gated else x.astype(np.float32) @ _QCACHE[(K, N)][3]).astype(np.float32)
     ws = torch.zeros(max(1, tm.tm_linear_workspace(h, M)), dtype=torch.uint8, device='cuda')
     x_d = dev(x)
-    for nt, splits, waves in ((0, 0, 0), (0, 1, 0x204), (0, 2, 0x204), (0, 3, 0x204), (2, 1, 8), (2, 2, 8), (2, 4, 8), (4, 1, 4)):
+    for nt, splits, waves in ((0, 0, 0), (0, 1, 0x204), (0, 2, 0x204), (0, 3, 0x204), (0, 1, 0x205), (0, 2, 0x205), (0, 5, 0x205),
+                              (2, 1, 8), (2, 2, 8), (2, 4, 8), (4, 1, 4)):
         if splits > K // 128:
             continue
         y = torch.zeros((M, N // 2 if gated else N), dtype=torch.float16, device='cuda')
@@ -484,6 +486,31 @@ def test_w4a16_row_block_tile_modes(tm, cuda, monkeypatch, K, N, M, gated, mode)
         _ffi.check(tm.tm_linear_forward(h, dev(x).data_ptr(), K, y.data_ptr(), y.shape[1], M, gated, 0, splits, 0x204, ws.data_ptr(), st()))
         err = np.abs(host(y).astype(np.float32) - ref)
         assert np.all(err <= 2e-3 + 2.0**-9 * np.abs(ref)), f'mode {mode:#x} splits={splits}: max err {err.max()}'
+    _ffi.check(tm.tm_linear_destroy(h))
+
+
+@pytest.mark.parametrize('K,N,M,splits,waves', [(1792, 4096, 1000, 3, 0x204), (1792, 4096, 2500, 3, 0x204), (1536, 4096, 64, 1, 0x200),
+                                                (1536, 4096, 64, 3, 0x200), (4608, 4096, 64, 1, 0x201), (1536, 2048, 32, 1, 0x203)])
+def test_w4a16_odd_stage_count_is_stable(tm, cuda, K, N, M, splits, waves):
+    """Regression (round 2): with an odd number of LDS stages per k slice the asynchronous x stage that the LDS-DMA fetched
+    behind the LAST stage could land on top of the epilogue's reduction image -- intermittently wrong rows at the end of a
+    row block.  Twelve launches of each odd-stage configuration: every one equals the oracle and the first one bit for bit."""
+    rng = np.random.default_rng(K + N + M)
+    h, (q, s, z) = _make_linear(tm, rng, K, N)
+    x = rng.standard_normal((M, K)).astype(f16)
+    ref = x.astype(np.float32) @ _QCACHE[(K, N)][3]
+    ws = torch.zeros(max(1, tm.tm_linear_workspace(h, M)), dtype=torch.uint8, device='cuda')
+    x_d = dev(x)
+    first = None
+    for rep in range(12):
+        y = torch.zeros((M, N), dtype=torch.float16, device='cuda')
+        _ffi.check(tm.tm_linear_forward(h, x_d.data_ptr(), K, y.data_ptr(), N, M, 0, 0, splits, waves, ws.data_ptr(), st()))
+        got = host(y)
+        err = np.abs(got.astype(np.float32) - ref)
+        assert np.all(err <= 2e-3 + 2.0**-9 * np.abs(ref)), f'launch {rep}: max err {err.max()}'
+        if first is None:
+            first = got
+        assert np.array_equal(got.view(np.uint16), first.view(np.uint16)), f'launch {rep} differs from launch 0'
     _ffi.check(tm.tm_linear_destroy(h))
 
 

@@ -56,6 +56,9 @@ def main():
         rows.append(t)
         ph = [('start', t[:, 0]), ('prologue', t[:, 1] - t[:, 0]), ('loop', t[:, 2] - t[:, 1]), ('reduce', t[:, 3] - t[:, 2]),
               ('store', t[:, 4] - t[:, 3]), ('end', t[:, 4])]
+        if raw[:, 5].any():      # shader-clock counter stamps around the loop (gemm_pre64_kernel)
+            mhz = (raw[:, 6] - raw[:, 5]).astype(np.float64) / np.maximum((raw[:, 2] - raw[:, 1]).astype(np.float64) / 100.0, 1e-9)
+            print(f'   shader clock inside the loop: mean {np.mean(mhz):.0f} MHz (min {np.min(mhz):.0f}, max {np.max(mhz):.0f})')
         print(f'launch {it}: {len(t)} WGs, span {np.nanmax(t[:, 4]):.2f} us | ' +
               ' | '.join(f'{n} {np.nanmean(a):.2f} (max {np.nanmax(a):.2f})' for n, a in ph) +
               f' | WGs per XCC {np.bincount(xcc.astype(int), minlength=8).tolist()}')
