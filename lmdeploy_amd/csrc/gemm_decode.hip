@@ -103,6 +103,9 @@ struct Dec32Params {
     int           rotate;    // 1: workgroup w walks its k stages starting at stage (w mod stages) -- the workgroups of a launch then
                              // read DIFFERENT parts of x (and of the weight stream) at any moment instead of hammering the same
                              // 64 KB of x from every CU at once
+    int           wt;        // bit 0: split-K slabs, bit 1: fp16 outputs leave through write-through (sc1) stores: they drain to memory
+                             // while the other workgroups still stream instead of sitting dirty in L2 until the end-of-kernel
+                             // release writes them back (the kernel boundary then waits for MBs of fp32 slabs)
     uint64_t*     dbg;       // optional [workgroups][8] s_memrealtime stamps (tm_debug_set_gemm_trace): start, loop, epilogue, end,
                              // hw id, -, -, after the k-phase reduction barrier
 };
@@ -122,6 +125,31 @@ __device__ __forceinline__ half8_t dequant8_p32(uint32_t w, half2_t s2, half2_t 
     p2                   = h2_fma(p2, s2, z2);
     p3                   = h2_fma(p3, s2, z2);
     return half8_t{p0[0], p0[1], p1[0], p1[1], p2[0], p2[1], p3[0], p3[1]};
+}
+
+__device__ __forceinline__ void store_wt(floatx4* dst, floatx4 v, int mode = 1)
+{
+    // mode (TM_D32_WT >> 4, experiment arms): 0/1 sc1, 2 sc0 sc1, 3 nt, 4 nt sc0 sc1
+    if (mode <= 1) {
+        asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(v) : "memory");
+    }
+    else if (mode == 2) {
+        asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(dst), "v"(v) : "memory");
+    }
+    else if (mode == 3) {
+        asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(dst), "v"(v) : "memory");
+    }
+    else {
+        asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt" ::"v"(dst), "v"(v) : "memory");
+    }
+}
+__device__ __forceinline__ void store_wt(half4_t* dst, half4_t v)
+{
+    asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(dst), "v"(v) : "memory");
+}
+__device__ __forceinline__ void store_wt(half2_t* dst, half2_t v)
+{
+    asm volatile("global_store_dword %0, %1, off sc1" ::"v"(dst), "v"(v) : "memory");
 }
 
 template<int N, class F, int I = 0>
@@ -531,17 +559,35 @@ __global__ __launch_bounds__(CG* WK * 64) void gemm_dec32_kernel(Dec32Params p)
             }
             const size_t mg = (size_t)m0 + m;  // row of y
             if (p.epilogue == 2) {
-                *(floatx4*)(p.partial + ((size_t)blockIdx.y * p.M + mg) * p.N + n) = a;
+                floatx4* dst = (floatx4*)(p.partial + ((size_t)blockIdx.y * p.M + mg) * p.N + n);
+                if (p.wt & 1) {
+                    store_wt(dst, a, p.wt >> 4);
+                }
+                else {
+                    *dst = a;
+                }
             }
             else if (p.epilogue == 1) {
                 const float s0 = a[0] / (1.0f + __builtin_expf(-a[0]));
                 const float s1 = a[2] / (1.0f + __builtin_expf(-a[2]));
                 half2_t     o  = {(half_t)(s0 * a[1]), (half_t)(s1 * a[3])};
-                *(half2_t*)(p.y + mg * p.ldy + (n >> 1)) = o;
+                half2_t*    dst = (half2_t*)(p.y + mg * p.ldy + (n >> 1));
+                if (p.wt & 2) {
+                    store_wt(dst, o);
+                }
+                else {
+                    *dst = o;
+                }
             }
             else {
-                half4_t o = {(half_t)a[0], (half_t)a[1], (half_t)a[2], (half_t)a[3]};
-                *(half4_t*)(p.y + mg * p.ldy + n) = o;
+                half4_t  o   = {(half_t)a[0], (half_t)a[1], (half_t)a[2], (half_t)a[3]};
+                half4_t* dst = (half4_t*)(p.y + mg * p.ldy + n);
+                if (p.wt & 2) {
+                    store_wt(dst, o);
+                }
+                else {
+                    *dst = o;
+                }
             }
         }
     }
@@ -798,7 +844,13 @@ __global__ __launch_bounds__(512) void gemm_pre64_kernel(Dec32Params p)
                 const floatx4 a  = {acc[nb][h][4 * g4], acc[nb][h][4 * g4 + 1], acc[nb][h][4 * g4 + 2], acc[nb][h][4 * g4 + 3]};
                 const size_t  mg = (size_t)m0 + m;
                 if (p.epilogue == 2) {
-                    *(floatx4*)(p.partial + ((size_t)blockIdx.y * p.M + mg) * p.N + n) = a;
+                    floatx4* dst = (floatx4*)(p.partial + ((size_t)blockIdx.y * p.M + mg) * p.N + n);
+                    if (p.wt & 1) {
+                        store_wt(dst, a, p.wt >> 4);
+                    }
+                    else {
+                        *dst = a;
+                    }
                 }
                 else if (p.epilogue == 1) {
                     const float s0 = a[0] / (1.0f + __builtin_expf(-a[0]));
@@ -987,6 +1039,7 @@ int launch_linear_dec32(const LinearWeight& w, const half_t* x, int ldx, half_t*
     p.epilogue     = splits > 1 ? 2 : (gated_silu ? 1 : 0);
     p.dbg          = g_gemm_dbg;
     p.rotate       = env_int2("TM_D32_ROTATE", 0);
+    p.wt           = env_int2("TM_D32_WT", 1);  // measured (tools/trace_boundary.py, profiles/r02_gemm_boundary_gap.txt): -0.4..-0.9 us per split-K launch
     dim3      grid((p.ncg + cgn - 1) / cgn, splits, shape >= 4 ? (M + 127) / 128 : 1);
     const int rc = shape >= 4 ? launch_dec32_shape<4>(p, grid, shape, st) :
                    M <= 32    ? launch_dec32_shape<1>(p, grid, shape, st) :
