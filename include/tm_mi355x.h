@@ -231,6 +231,10 @@ int tm_p2p_allgather(void* const* segs, int tp, int me, void* state, int rows, i
 /* debug / measurement: device buffer of [workgroups][4] uint64 that receives s_memrealtime stamps (100 MHz:
  * kernel entry, loop entry, loop exit, exit) of every GEMM workgroup launched afterwards; NULL switches it off. */
 int tm_debug_set_gemm_trace(void* dev_buf);
+/* Operator-level calls that follow treat tm_kv_cache::block_ptrs as a rectangular table: sequence b starts at b * stride
+ * (cu_block_nums must say the same); 0 = ragged (default).  The engine's own table is rectangular and always takes this
+ * path: the decode kernel then needs no dependent pointer loads (test hook for that path). */
+int tm_debug_set_block_stride(int stride);
 
 /* ----------------------------------------------------------------------------------------------
  * Engine level (static batcher around LanguageModel::Forward)

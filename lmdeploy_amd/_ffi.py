@@ -114,6 +114,7 @@ _SIGNATURES = {
     'tm_quantize_groupwise': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                                       c_void_p]),
     'tm_debug_set_gemm_trace': (c_int, [c_void_p]),
+    'tm_debug_set_block_stride': (c_int, [c_int]),
     'tm_engine_comm_native_export': (c_int, [c_void_p, c_int, c_void_p]),
     'tm_engine_comm_native_import': (c_int, [c_void_p, c_void_p, c_int]),
     'tm_p2p_segment_create': (c_int, [c_size_t, POINTER(c_void_p), c_void_p]),

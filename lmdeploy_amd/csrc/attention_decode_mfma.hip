@@ -170,6 +170,31 @@ __global__ __launch_bounds__(256, 2) void decode_attention_i8_mfma_kernel(Decode
     char* Vt = Kt + 8192;
     char* Pm = Kt + 16384;
 
+    // Block pointers.  Rectangular table (block_stride > 0): lane i fetches the pointer of block i of this sequence right
+    // here -- its address needs nothing but kernel arguments, so the load flies together with k_len[b] -- and a block's
+    // pointer is then a v_readlane away: no pointer load in front of the first cache block and none inside the block loop
+    // (it used to be a dependent hop per block: offset -> pointer -> data).  Contexts beyond 64 blocks re-fetch the window.
+    const int       bstride = p.cache.block_stride;
+    const uint64_t* blocks  = p.cache.block_ptrs + (bstride > 0 ? (size_t)b * bstride : (size_t)p.cache.cu_block_nums[b]);
+    uint64_t        bp      = 0;
+    int             bwin    = 0;
+    if (bstride > 0) {
+        bp = blocks[min(lane, bstride - 1)];
+    }
+    auto block_ptr = [&](int tile) -> const char* {  // tile: wave-uniform
+        if (bstride <= 0) {
+            return (const char*)blocks[tile];
+        }
+        const int ut = __builtin_amdgcn_readfirstlane(tile);
+        if ((ut & ~63) != bwin) {
+            bwin = ut & ~63;
+            bp   = blocks[min(bwin + lane, bstride - 1)];
+        }
+        const uint32_t lo = __builtin_amdgcn_readlane((uint32_t)bp, ut & 63);
+        const uint32_t hi = __builtin_amdgcn_readlane((uint32_t)(bp >> 32), ut & 63);
+        return (const char*)(((uint64_t)hi << 32) | lo);
+    };
+
     const int ctx        = p.k_len[b];
     const int tiles      = (ctx + 63) >> 6;
     const int per_split  = (tiles + p.splits - 1) / p.splits;
@@ -200,7 +225,6 @@ __global__ __launch_bounds__(256, 2) void decode_attention_i8_mfma_kernel(Decode
     float m = -INFINITY, lsum = 0.f, zacc = 0.f;  // per head column i16, partial over this lane's tokens
     const float sc = p.scale_log2;
 
-    const uint64_t* blocks = p.cache.block_ptrs + p.cache.cu_block_nums[b];
     const int       koff   = L.k_data(kv_head, 0);
     const int       voff   = L.v_data(kv_head, 0);
     const int       kpoff  = L.k_param(kv_head, 0);
@@ -210,7 +234,7 @@ __global__ __launch_bounds__(256, 2) void decode_attention_i8_mfma_kernel(Decode
     u32x4    kreg[NR], vreg[NR];
     uint32_t kpr = 0, vpr = 0;
     auto load_tile = [&](int tile) {
-        const char* base = (const char*)blocks[tile] + p.cache.layer_offset;
+        const char* base = block_ptr(tile) + p.cache.layer_offset;
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
             // int8: token (lane/8 + 8r), 16-byte chunk lane%8 of its 128 bytes; int4: token (lane/4 + 16r), chunk lane%4 of 64
@@ -323,8 +347,8 @@ __global__ __launch_bounds__(256, 2) void decode_attention_i8_mfma_kernel(Decode
             nq[0] = qv[0] | (qv[1] << 8) | (qv[2] << 16) | (qv[3] << 24);
             nq[1] = qv[4] | (qv[5] << 8) | (qv[6] << 16) | (qv[7] << 24);
             npar  = bit_cast<uint32_t>(half2_t{scale, zero});
+            char* blk = (char*)block_ptr((ctx - 1) >> 6) + p.cache.layer_offset;  // outside the divergent branch (v_readlane)
             if (lane < 32) {
-                char* blk = (char*)blocks[(ctx - 1) >> 6] + p.cache.layer_offset;
                 if constexpr (BITS == 8) {
                     *(u32x2*)(blk + (isv ? L.v_data(kv_head, nti) : L.k_data(kv_head, nti)) + l16 * 8) = nq;
                 }

@@ -27,11 +27,14 @@ const char* get_last_error()
     return g_last_error.c_str();
 }
 
+static int g_dbg_block_stride = 0;
+
 static KvCacheView to_view(const tm_kv_cache* c)
 {
     KvCacheView v{};
     v.block_ptrs    = c->block_ptrs;
     v.cu_block_nums = c->cu_block_nums;
+    v.block_stride  = g_dbg_block_stride;
     v.layer_offset  = c->layer_offset;
     v.layout        = KvLayout{c->kv_heads, c->head_dim, c->block_len, c->bits};
     return v;
@@ -296,7 +299,8 @@ int tm_linear_forward(const tm_linear* w, const void* x, int ldx, void* y, int l
         // 0x200 + shape: the decode kernel (gemm_decode.hip) with an explicit workgroup shape; M <= 64, u4, N % 32 == 0
         TM_REQUIRE(dec32_supported(w->w, M), "decode kernel: u4 weights, N % 32 == 0");
         cfg.d32_shape = waves & 0xff;
-        TM_REQUIRE(cfg.d32_shape <= 5 && (cfg.d32_shape >= 4) == (M > 64), "decode kernel shape 0..3 (M <= 64) or 4 / 5 (M > 64)");
+        TM_REQUIRE(cfg.d32_shape == 6 || (cfg.d32_shape <= 5 && (cfg.d32_shape >= 4) == (M > 64)),
+                   "decode kernel shape 0..3 (M <= 64), 4 / 5 (M > 64) or 6 (32-row blocks, any M)");
         waves = 0;
     }
     if (waves > 0) {
@@ -659,6 +663,13 @@ int tm_p2p_allgather(void* const* segs, int tp, int me, void* state, int rows, i
     uint32_t* flags[8];
     p2p_tables(segs, tp, data, flags);
     return launch_p2p_allgather(data, flags, tp, me, (uint32_t*)state, (size_t)rows * H, src, dst, words, (hipStream_t)st);
+}
+
+int tm_debug_set_block_stride(int stride)
+{
+    TM_REQUIRE(stride >= 0, "stride >= 0");
+    g_dbg_block_stride = stride;
+    return 0;
 }
 
 int tm_debug_set_gemm_trace(void* dev_buf)

@@ -428,6 +428,8 @@ static KvCacheView cache_view(const tm_engine* e, int layer)
     KvCacheView v{};
     v.block_ptrs    = e->d_block_ptrs;
     v.cu_block_nums = e->d_cu_block_nums;
+    static const bool rect = !getenv("TM_ATTN_RECT") || atoi(getenv("TM_ATTN_RECT")) != 0;  // A/B switch
+    v.block_stride  = rect ? e->max_blocks_per_seq : 0;  // cu_block_nums[b] = b * max_blocks_per_seq (create())
     v.layer_offset  = (int64_t)layer * e->layout.layer_size();
     v.layout        = e->layout;
     return v;

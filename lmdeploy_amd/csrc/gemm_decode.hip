@@ -259,6 +259,13 @@ __global__ __launch_bounds__(CG* WK * 64) void gemm_dec32_kernel(Dec32Params p)
     // DMA writes lane L to slot L of the piece (wave-linear), so the XOR swizzle sits on the SOURCE address: lane L
     // fetches chunk (L & 15) ^ (row & 15) of row 4 pc + (L >> 4).
     constexpr bool DMA = (ABL & 0x100) != 0;
+    // 0x4000 (needs the DMA and UNR >= 3): the ring refill moves from the END of a stage to its TOP, right behind the DMA of
+    // x(t+1), into the slots the PREVIOUS stage consumed.  vmcnt retires in issue order, so the counted wait that guards the
+    // DMA at the end of stage t forces every load issued BEFORE that DMA to have landed: a refill issued at the end of stage
+    // t-1 therefore had ONE stage to arrive whatever the ring depth (which is why PF = 4 alone bought nothing), one issued at
+    // the top of stage t -- younger than the DMA -- may stay in flight until the end of stage t+1: TWO stages.
+    constexpr bool EARLY = DMA && (ABL & 0x4000) != 0;
+    static_assert(!EARLY || UNR >= 3, "early refill needs a spare ring stage");
     constexpr int  NPC = S * ROWS / 4;
     constexpr int  DR  = NPC / WAVES;
     static_assert(!DMA || NPC % WAVES == 0, "DMA pieces per wave");
@@ -316,12 +323,13 @@ __global__ __launch_bounds__(CG* WK * 64) void gemm_dec32_kernel(Dec32Params p)
             // queue: x(0) DMA pieces, then the whole weight ring; the DMA is invisible to hipcc's waitcnt pass, so its
             // completion is waited for by hand: everything older than the 3 * PF ring loads
             D32_DMA_X(phys(0), 0);
+            constexpr int PF0 = EARLY ? PF - BPS : PF;  // EARLY: stage 0 itself fetches the slots of stage UNR - 1
 #pragma unroll
-            for (int q = 0; q < PF; ++q) {
+            for (int q = 0; q < PF0; ++q) {
                 D32_LOAD_W(q, phys(q / BPS) * S + wk + (q % BPS) * WK);
                 __builtin_amdgcn_sched_barrier(0);
             }
-            asm volatile("s_waitcnt vmcnt(%0)" ::"i"((ABL & 0x1000) ? 0 : 3 * PF) : "memory");
+            asm volatile("s_waitcnt vmcnt(%0)" ::"i"((ABL & 0x1000) ? 0 : 3 * PF0) : "memory");
         }
         else {
             D32_LOAD_X(phys(0));
@@ -350,8 +358,9 @@ __global__ __launch_bounds__(CG* WK * 64) void gemm_dec32_kernel(Dec32Params p)
         }
 
         // one stage = compute on buffer (u & 1) with ring slots u*BPS.. , then staging + refills, then the barrier
-        auto stage = [&](auto U, const int t) __attribute__((always_inline)) {
-            constexpr int u = decltype(U)::value;
+        auto stage = [&](auto U, const int t, auto REM) __attribute__((always_inline)) {
+            constexpr int  u   = decltype(U)::value;
+            constexpr bool rem = decltype(REM)::value;  // a stage of the remainder (after the last whole unrolled body)
             const int buf = u & 1;  // UNR is even: parity of t
             if constexpr (DMA && !(ABL & 8)) {
                 // First make hipcc wait for this stage's ring slots HERE (their first use), then start the DMA of stage
@@ -366,6 +375,14 @@ __global__ __launch_bounds__(CG* WK * 64) void gemm_dec32_kernel(Dec32Params p)
                 // epilogue lays the reduction image over the stage buffers (seen as flaky rows 96..127 of row blocks, r02).
                 if (t + 1 < nst) {  // uniform
                     D32_DMA_X(phys(t + 1), buf ^ 1);
+                }
+                if constexpr (EARLY && !(ABL & 16)) {
+                    constexpr int uf = (u + UNR - 1) % UNR;  // the slots stage t-1 consumed (stage 0: never loaded yet)
+#pragma unroll
+                    for (int i = 0; i < BPS; ++i) {
+                        D32_LOAD_W(uf * BPS + i, phys(t + UNR - 1) * S + wk + i * WK);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
 #pragma unroll
@@ -480,15 +497,16 @@ __global__ __launch_bounds__(CG* WK * 64) void gemm_dec32_kernel(Dec32Params p)
                 D32_STORE_X(buf ^ 1);
                 D32_LOAD_X(phys(t + 2));
             }
-            if constexpr (!(ABL & 16)) {
+            if constexpr (!(ABL & 16) && !EARLY) {
 #pragma unroll
                 for (int i = 0; i < BPS; ++i) {
                     D32_LOAD_W(u * BPS + i, phys(t + UNR) * S + wk + i * WK);
                 }
             }
             if constexpr (DMA && !(ABL & 8)) {
-                // my DMA pieces of stage t+1 have landed when at most the 3 * BPS refills issued after them are in flight
-                asm volatile("s_waitcnt vmcnt(%0)" ::"i"((ABL & (16 | 0x2000)) ? 0 : 3 * BPS) : "memory");
+                // my DMA pieces of stage t+1 have landed when at most the 3 * BPS refills issued after them are in flight.  In
+                // the remainder those refills are dead code (nobody consumes them, hipcc drops them): drain instead.
+                asm volatile("s_waitcnt vmcnt(%0)" ::"i"((rem || (ABL & (16 | 0x2000))) ? 0 : 3 * BPS) : "memory");
             }
             __syncthreads();
         };
@@ -497,11 +515,11 @@ __global__ __launch_bounds__(CG* WK * 64) void gemm_dec32_kernel(Dec32Params p)
         // moment ago, and drains vmcnt(0) at the top of every body (seen in the ISA).  The remainder runs once.
         int t0 = 0;
         for (; t0 + UNR <= nst; t0 += UNR) {
-            static_for<UNR>([&](auto U) { stage(U, t0 + decltype(U)::value); });
+            static_for<UNR>([&](auto U) { stage(U, t0 + decltype(U)::value, std::false_type{}); });
         }
         static_for<UNR>([&](auto U) {
             if (t0 + decltype(U)::value < nst) {  // uniform over the workgroup
-                stage(U, t0 + decltype(U)::value);
+                stage(U, t0 + decltype(U)::value, std::true_type{});
             }
         });
     }
@@ -937,6 +955,9 @@ static int launch_dec32_shape(const Dec32Params& p, dim3 grid, int shape, hipStr
 #undef D32_CASE
                     default: break;
                 }
+                if (env_int2("TM_D32_EARLY", 0)) {
+                    return launch_dec32_one<MH, 4, 4, 4, 4, kD32Mode | 0x4000>(p, grid, st);
+                }
                 if (env_int2("TM_D32_PF", 2) >= 4) {
                     return launch_dec32_one<MH, 4, 4, 4, 4, kD32Mode>(p, grid, st);
                 }
@@ -950,6 +971,7 @@ static int launch_dec32_shape(const Dec32Params& p, dim3 grid, int shape, hipStr
             if (abl == 0) return launch_dec32_one<MH, 4, 2, 4, 4, 0>(p, grid, st);
             return launch_dec32_one<MH, 4, 2, 4, 4, kD32Mode>(p, grid, st);
         case 3:  // 8 waves: 2 column groups x 4 k-phases (64 columns per workgroup)
+        case 6:  // the same tile on 32-row blocks (grid.z = ceil(M / 32)): see dec32_pick
             return launch_dec32_one<MH, 2, 4, 4, 2, kD32Mode>(p, grid, st);
         default: break;
     }
@@ -960,8 +982,8 @@ static int launch_dec32_shape(const Dec32Params& p, dim3 grid, int shape, hipStr
 // shape -> (column groups, k-blocks per stage)
 static void dec32_shape_dims(int shape, int* cg, int* s)
 {
-    static const int cgs[6] = {4, 8, 4, 2, 8, 16};
-    *cg = cgs[shape < 0 || shape > 5 ? 0 : shape];
+    static const int cgs[7] = {4, 8, 4, 2, 8, 16, 2};
+    *cg = cgs[shape < 0 || shape > 6 ? 0 : shape];
     *s  = shape == 5 ? 1 : (shape == 4 ? 2 : 4);
 }
 
@@ -987,6 +1009,20 @@ void dec32_pick(const LinearWeight& w, int M, int* shape_out, int* splits_out)
         // 512-column tile with two weight fragments per x-fragment read (TM_PRE64_MIN_M: first M that takes it)
         static const int pre64_from = env_int2("TM_PRE64_MIN_M", 257);
         shape = (M >= pre64_from && w.N >= 512) ? 5 : 4;
+    }
+    // Mid-width projections at a full decode batch (w_qkv of an 8B model, N = 6144): 32-row x 64-column tiles over the WHOLE
+    // k range (shape 6), >= 160 workgroups.  Split-K there costs more at the kernel boundary than it buys inside the kernel:
+    // in a back-to-back chain the launch after a split-K GEMM starts 4.1 .. 6.6 us after its last workgroup ended (MBs of
+    // dirty fp32 slabs) against 1.2 us behind a kernel that leaves fp16 outputs (profiles/r02_gemm_boundary_gap.txt).  In
+    // the model (rocprofv3, graph replays, profiles/r02_kernel_trace_by_grid_*.txt): w_qkv 12.2 -> 10.9 us and the attention
+    // kernel behind it 36.0 -> 35.6 us; wo (N = 4096, 128 such workgroups) 7.9 -> 10.0 us and stays on split-K.  The two row
+    // halves of a column tile are gridDim.x (a multiple of 8) workgroups apart: same XCD, the second reader hits L2.
+    static const int rowhalf = env_int2("TM_D32_ROWHALF", 1);
+    if (rowhalf && env_int2("TM_D32_SHAPE", -1) < 0 && M > 32 && M <= 64 && KB <= 64 && KB % 4 == 0 && ncg % 16 == 0
+        && (ncg / 2) * ((M + 31) / 32) >= 160 && ncg <= 256) {
+        *shape_out  = 6;
+        *splits_out = env_int2("TM_D32_SPLITS", 1);
+        return;
     }
     int cgn, S;
     dec32_shape_dims(shape, &cgn, &S);
@@ -1014,7 +1050,7 @@ int launch_linear_dec32(const LinearWeight& w, const half_t* x, int ldx, half_t*
                         int splits, float* workspace, int* slabs_out, hipStream_t st)
 {
     TM_REQUIRE(w.packed32 != nullptr && w.N % 32 == 0, "decode GEMM: P32 layout missing");
-    TM_REQUIRE(M >= 1 && (M <= 64) == (shape < 4), "decode GEMM: shapes 0..3 take M <= 64, shapes 4 / 5 take M > 64");
+    TM_REQUIRE(M >= 1 && (shape == 6 || (M <= 64) == (shape < 4)), "decode GEMM: shapes 0..3 take M <= 64, shapes 4 / 5 take M > 64");
     TM_REQUIRE(ldx % 8 == 0, "x rows must be 16-byte aligned");
     int cgn, S;
     dec32_shape_dims(shape, &cgn, &S);
@@ -1040,8 +1076,9 @@ int launch_linear_dec32(const LinearWeight& w, const half_t* x, int ldx, half_t*
     p.dbg          = g_gemm_dbg;
     p.rotate       = env_int2("TM_D32_ROTATE", 0);
     p.wt           = env_int2("TM_D32_WT", 1);  // measured (tools/trace_boundary.py, profiles/r02_gemm_boundary_gap.txt): -0.4..-0.9 us per split-K launch
-    dim3      grid((p.ncg + cgn - 1) / cgn, splits, shape >= 4 ? (M + 127) / 128 : 1);
-    const int rc = shape >= 4 ? launch_dec32_shape<4>(p, grid, shape, st) :
+    dim3      grid((p.ncg + cgn - 1) / cgn, splits, shape == 6 ? (M + 31) / 32 : shape >= 4 ? (M + 127) / 128 : 1);
+    const int rc = shape == 6 ? launch_dec32_shape<1>(p, grid, shape, st) :
+                   shape >= 4 ? launch_dec32_shape<4>(p, grid, shape, st) :
                    M <= 32    ? launch_dec32_shape<1>(p, grid, shape, st) :
                                 launch_dec32_shape<2>(p, grid, shape, st);
     if (rc) {

@@ -31,6 +31,10 @@ struct KvLayout {
 struct KvCacheView {
     const uint64_t* block_ptrs;     // device array of block base addresses (char**)
     const int*      cu_block_nums;  // [B+1] prefix offsets into block_ptrs
+    int             block_stride = 0;  // > 0: the table is rectangular, sequence b starts at b * block_stride (cu_block_nums[b] says the
+                                       // same): the MFMA decode kernel then fetches a sequence's block pointers with ONE load that
+                                       // depends on nothing but kernel arguments (64 pointers, one per lane) instead of two dependent
+                                       // hops (prefix offset -> pointer) in front of every cache block
     int64_t         layer_offset;   // bytes: layer * layout.layer_size()
     KvLayout        layout;
 };

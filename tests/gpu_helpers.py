@@ -44,11 +44,15 @@ class DevCache:
         self.pool = torch.zeros((num_blocks, layout.block_size), dtype=torch.uint8, device='cuda')
         self.set_tables(tables)
 
-    def set_tables(self, tables):
+    def set_tables(self, tables, stride: int = 0):
+        """stride > 0: rectangular table, every sequence owns `stride` entries (unused ones are null pointers)"""
         self.tables = [np.asarray(t, np.int64) for t in tables]
         base = self.pool.data_ptr()
-        ptrs = np.concatenate([base + t * self.layout.block_size for t in self.tables]).astype(np.uint64)
-        cu = np.concatenate([[0], np.cumsum([len(t) for t in self.tables])]).astype(np.int32)
+        rows = [base + t * self.layout.block_size for t in self.tables]
+        if stride > 0:
+            rows = [np.concatenate([r, np.zeros(stride - len(r), np.int64)]) for r in rows]
+        ptrs = np.concatenate(rows).astype(np.uint64)
+        cu = np.concatenate([[0], np.cumsum([len(r) for r in rows])]).astype(np.int32)
         self.block_ptrs = torch.from_numpy(ptrs.view(np.int64)).cuda()
         self.cu_block_nums = torch.from_numpy(cu).cuda()
 

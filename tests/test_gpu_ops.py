@@ -253,6 +253,57 @@ def test_decode_attention(tm, cuda, bits, Hq, Hkv, klen, splits):
         assert np.abs(got[b] - ref64).max() < 5e-3
 
 
+@pytest.mark.parametrize('bits', [8, 4])
+def test_decode_attention_rectangular_block_table(tm, cuda, bits):
+    """The engine's block table is rectangular (sequence b at b * stride): the MFMA decode kernel then keeps a sequence's
+    block pointers in one register (v_readlane per block) instead of loading offset -> pointer in front of every block.
+    Same bits as the ragged-table path (which the tests above pin on the oracle): plain and fused kernels, split-KV,
+    contexts of more than 64 blocks (pointer window re-fetch), cache bytes written by the fused prologue."""
+    rng = np.random.default_rng(bits)
+    Hq, Hkv = 8, 2
+    klen = [4200, 1, 64, 65, 4097, 700, 8190]
+    L = o.BlockLayout(2, Hkv, 128, 64, bits)
+    nblk = [(k + 63) // 64 for k in klen]
+    total = sum(nblk) + 1
+    perm = rng.permutation(total)
+    tables, off = [], 0
+    for nb in nblk:
+        tables.append(perm[off:off + nb])
+        off += nb
+    dc = DevCache(L, total, tables)
+    # every 2 bytes of the pool = a small positive fp16: any code bytes, finite (scale, zero) parameters
+    pool0 = (rng.random(dc.pool.numel() // 2) * 0.01 + 0.01).astype(f16)
+    B = len(klen)
+    kl = dev(np.asarray(klen, np.int32))
+    q = dev(rng.standard_normal((B, Hq * 128)).astype(f16))
+    qkv_n = (Hq + 2 * Hkv) * 128
+    qkv = dev(rng.standard_normal((B, qkv_n)).astype(f16))
+    rope = dev(rope_table(tm, 8192, o.RopeParam(128, 10000.0, 'default', 1.0, 1.0, 4.0, 8192)))
+    stride = max(nblk) + 3
+    res = {}
+    try:
+        for mode in (0, stride):
+            dc.set_tables(tables, stride=mode)
+            _ffi.check(tm.tm_debug_set_block_stride(mode))
+            for splits in (1, 3):
+                ws = torch.zeros(max(1, tm.tm_decode_attention_workspace(B, Hq, splits)), dtype=torch.uint8, device='cuda')
+                dc.pool.copy_(torch.from_numpy(pool0.view(np.uint8)).cuda().view_as(dc.pool))
+                out = torch.zeros((B, Hq * 128), dtype=torch.float16, device='cuda')
+                _ffi.check(tm.tm_decode_attention(out.data_ptr(), q.data_ptr(), Hq * 128, kl.data_ptr(), B, Hq, 0.0, splits,
+                                                  ws.data_ptr(), dc.view(1), st()))
+                outf = torch.zeros((B, Hq * 128), dtype=torch.float16, device='cuda')
+                _ffi.check(tm.tm_decode_attention_fused(outf.data_ptr(), qkv.data_ptr(), 0, qkv_n, rope.data_ptr(), 8192, kl.data_ptr(),
+                                                        B, Hq, 0.0, splits, ws.data_ptr(), dc.view(1), st()))
+                res[(mode > 0, splits)] = (host(out), host(outf), dc.download())
+    finally:
+        tm.tm_debug_set_block_stride(0)
+    for splits in (1, 3):
+        a, b = res[(False, splits)], res[(True, splits)]
+        assert np.isfinite(a[0].astype(np.float32)).all() and np.abs(a[0].astype(np.float32)).max() > 0
+        for x, y, what in zip(a, b, ('plain', 'fused', 'cache bytes')):
+            assert np.array_equal(x.view(np.uint8), y.view(np.uint8)), f'splits={splits}: {what} differ'
+
+
 @pytest.mark.parametrize('Hq,Hkv,klen,splits,qkv_splits,rope', [
     (8, 2, [1, 64, 65, 300], 1, 0, True), (8, 2, [1, 64, 65, 300], 3, 2, True), (32, 8, [1000, 37, 128, 129], 2, 4, True),
     (6, 1, [129, 5], 1, 1, False), (8, 1, [257], 4, 0, True), (12, 4, [513, 64], 16, 3, True), (64, 8, [77, 192], 2, 0, True),
@@ -470,6 +521,32 @@ def test_w4a16_decode_kernel_modes(tm, cuda, monkeypatch, K, N, M, gated, mode):
     _ffi.check(tm.tm_linear_destroy(h))
 
 
+@pytest.mark.parametrize('K,N,M,gated', [(4096, 6144, 64, 0), (1792, 4096, 33, 0), (14336, 4096, 64, 0), (4096, 1024, 64, 1), (512, 2048, 50, 1)])
+def test_w4a16_decode_kernel_early_refill(tm, cuda, monkeypatch, K, N, M, gated):
+    """TM_D32_EARLY=1: four-stage weight ring refilled at the TOP of a stage (behind the activation DMA) instead of at its
+    end -- whole unrolled bodies, remainders of 1..3 stages, one-stage slices -- three launches each, bit-identical"""
+    monkeypatch.setenv('TM_D32_EARLY', '1')
+    rng = np.random.default_rng(K + N + M + 77)
+    h, (q, s, z) = _make_linear(tm, rng, K, N)
+    x = rng.standard_normal((M, K)).astype(f16)
+    ref = (o.w4a16_linear_gated_silu(x, q, s, z) if gated else x.astype(np.float32) @ _QCACHE[(K, N)][3]).astype(np.float32)
+    ws = torch.zeros(max(1, tm.tm_linear_workspace(h, M)), dtype=torch.uint8, device='cuda')
+    x_d = dev(x)
+    for splits in (1, 2, 3, 4, 7):
+        if splits > max(1, K // 512):
+            continue
+        first = None
+        for rep in range(3):
+            y = torch.zeros((M, N // 2 if gated else N), dtype=torch.float16, device='cuda')
+            _ffi.check(tm.tm_linear_forward(h, x_d.data_ptr(), K, y.data_ptr(), y.shape[1], M, gated, 0, splits, 0x200, ws.data_ptr(), st()))
+            got = host(y)
+            err = np.abs(got.astype(np.float32) - ref)
+            assert np.all(err <= 2e-3 + 2.0**-9 * np.abs(ref)), f'splits={splits} launch {rep}: max err {err.max()}'
+            first = got if first is None else first
+            assert np.array_equal(got.view(np.uint16), first.view(np.uint16))
+    _ffi.check(tm.tm_linear_destroy(h))
+
+
 @pytest.mark.parametrize('K,N,M,gated', [(4096, 6144, 300, 0), (1792, 4096, 129, 0), (1024, 2048, 1000, 1)])
 @pytest.mark.parametrize('mode', [0, 0x100])
 def test_w4a16_row_block_tile_modes(tm, cuda, monkeypatch, K, N, M, gated, mode):
@@ -511,6 +588,27 @@ def test_w4a16_odd_stage_count_is_stable(tm, cuda, K, N, M, splits, waves):
         if first is None:
             first = got
         assert np.array_equal(got.view(np.uint16), first.view(np.uint16)), f'launch {rep} differs from launch 0'
+    _ffi.check(tm.tm_linear_destroy(h))
+
+
+@pytest.mark.parametrize('K,N,gated', [(4096, 6144, 0), (1792, 4096, 0), (1024, 512, 0), (4096, 1024, 1), (384, 64, 0)])
+@pytest.mark.parametrize('M', [1, 32, 33, 50, 64, 100, 256])
+def test_w4a16_row_half_tiles(tm, cuda, K, N, M, gated):
+    """shape 6: 32-row x 64-column workgroup tiles over the WHOLE k range (no split-K slabs: the k-phases meet on chip) --
+    the decode tiling of the narrow projections (w_qkv, wo, w2) -- plus its split-K form"""
+    rng = np.random.default_rng(K + N + M + 6)
+    h, (q, s, z) = _make_linear(tm, rng, K, N)
+    x = rng.standard_normal((M, K)).astype(f16)
+    ref = (o.w4a16_linear_gated_silu(x, q, s, z) if gated else x.astype(np.float32) @ _QCACHE[(K, N)][3]).astype(np.float32)
+    ws = torch.zeros(max(1, tm.tm_linear_workspace(h, M)), dtype=torch.uint8, device='cuda')
+    x_d = dev(x)
+    for splits in (1, 2, 3):
+        if splits > max(1, K // 512):
+            continue
+        y = torch.zeros((M, N // 2 if gated else N), dtype=torch.float16, device='cuda')
+        _ffi.check(tm.tm_linear_forward(h, x_d.data_ptr(), K, y.data_ptr(), y.shape[1], M, gated, 0, splits, 0x206, ws.data_ptr(), st()))
+        err = np.abs(host(y).astype(np.float32) - ref)
+        assert np.all(err <= 2e-3 + 2.0**-9 * np.abs(ref)), f'splits={splits}: max err {err.max()}'
     _ffi.check(tm.tm_linear_destroy(h))
 
 

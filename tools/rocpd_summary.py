@@ -6,9 +6,19 @@ import sys
 
 
 def main():
+    by_grid = '--by-grid' in sys.argv   # one line per (kernel, grid): separates the four decode linears of one template
+    if by_grid:
+        sys.argv.remove('--by-grid')
     db = sqlite3.connect(sys.argv[1])
     like = f'%{sys.argv[2]}%' if len(sys.argv) > 2 else '%'
     cur = db.cursor()
+    if by_grid:
+        rows = list(cur.execute("select name, grid_x/workgroup_x, grid_y/workgroup_y, grid_z/workgroup_z, count(*), sum(end-start), "
+                                "avg(end-start), min(end-start) from kernels where name like ? group by 1, 2, 3, 4 order by 6 desc", (like,)))
+        print(f'{"kernel":60s} {"grid":>14s} {"calls":>7s} {"total_ms":>10s} {"avg_us":>9s} {"min_us":>9s}')
+        for r in rows[:40]:
+            print(f'{r[0][:60]:60s} {int(r[1]):5d}x{int(r[2]):3d}x{int(r[3]):3d} {r[4]:7d} {r[5]/1e6:10.3f} {r[6]/1e3:9.2f} {r[7]/1e3:9.2f}')
+        return
     rows = list(cur.execute("select name, count(*), sum(end-start), avg(end-start), min(end-start), max(vgpr_count), "
                             "max(lds_size), max(grid_x*1.0/workgroup_x) from kernels where name like ? group by name "
                             "order by 3 desc", (like,)))
