@@ -323,7 +323,8 @@ int tm_engine_fetch(tm_engine* e, int* host_out, int* n_generated);
 int tm_engine_fetch_logits(tm_engine* e, void* host_out);
 /* parity tests: intermediate state of the last forward -> host.  what = 0: the residual stream, fp16 [a rows][hidden]
  * (UnifiedDecoder's residual buffer, models/llama/unified_decoder.cc:226-330); what = 1: the bytes of KV block b of
- * static-batch sequence a, all layers (block layout = kernels/attention/block.h:126-219).  `bytes` must match exactly. */
+ * static-batch sequence a, all layers (block layout = kernels/attention/block.h:126-219); what = 2: int64 count of
+ * continuous-batching steps whose decode rows shared a forward with an admission's prefill.  `bytes` must match exactly. */
 int tm_engine_debug_read(tm_engine* e, int what, int a, int b, void* host_out, int64_t bytes);
 /* Per-sequence sampling parameters (GenerationConfig: temperature, top_k, top_p, min_p, random_seed;
  * lmdeploy/messages.py:35-205).  top_k == 1 is greedy.  The uniform draw of a step is Philox(seed, context length). */

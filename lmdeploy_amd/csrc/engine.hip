@@ -275,7 +275,12 @@ struct tm_engine {
     // continuous batching (tm_engine_submit / step / poll / cancel): slot-based, every decode step runs all
     // max_batch_size slots; free slots are parked on a scratch block with k_len = 1 and never advance
     std::unique_ptr<tmk::BatchScheduler> sched;
+    int64_t          mixed_steps = 0;        // scheduler steps whose decode rows rode on a prefill forward
     int*             d_active    = nullptr;  // [max_batch] 1 = slot holds a running sequence
+    uint64_t*        d_pf_block_ptrs = nullptr;  // [max_batch][max_blocks_per_seq] the table an admission's prefill walks: a new
+                                                 // slot's row reaches the decode table (d_block_ptrs) only once it is prefilled,
+                                                 // until then its decode row stays parked on the dummy block (a mixed forward runs
+                                                 // the parked decode row and the real prefill of the same slot side by side)
     int*             d_pf_k_len  = nullptr;  // prefill-local arrays (the decode arrays stay live during an admission)
     int*             d_pf_cu_q   = nullptr;
     std::vector<int> h_active, h_step_ids;
@@ -579,11 +584,26 @@ static int linear_plain(tm_engine* e, LinearSlots& l, const half_t* x, int ldx, 
 }
 
 // One forward over M tokens.  decode: one token per sequence (cu_q = 0..B); prefill: nseq sequences.
+// Mixed forward (continuous batching, the reference's unified batch: unified_attention_layer.cc:310-311 puts the decode rows
+// first): `md` != nullptr and !decode -> rows [0, md->rows) are the decode tokens of batch slots 0 .. md->rows-1 (their KV
+// through the fused decode attention on the engine's own, UNSHIFTED block table and md->k_len), rows [md->rows, M) are the
+// prefill tokens of `nseq` sequences described by e->d_cu_q / d_k_len / d_rows (d_rows already counts from row 0 of the
+// forward).  Every linear, norm and (MoE) FFN runs ONCE over all M rows -- one weight stream serves both.
+struct MixedDecode {
+    int             rows;        // decode rows = batch slots
+    const int*      k_len;       // [rows] context lengths including this step's token
+    const uint64_t* block_ptrs;  // the unshifted block table
+};
+
 static int forward(tm_engine* e, const int* d_ids, int M, int nseq, bool decode, int max_q_len, int max_k_len,
-                   int kflat_stride, int slot0)
+                   int kflat_stride, int slot0, const MixedDecode* md = nullptr)
 {
     const tm_model_config& m = e->cfg.model;
     hipStream_t            st = e->stream;
+    const int              nd = md ? md->rows : 0;  // leading decode rows of a mixed forward
+    TM_REQUIRE(!md || (!decode && e->fuse_qkv && nd > 0 && nd < M), "internal: mixed forward");
+    half_t* const qkv_p  = e->d_qkv + (size_t)nd * e->qkv_n;            // first prefill row
+    half_t* const attn_p = e->d_attn + (size_t)nd * e->q_heads * e->D;
     TM_PROF(P_EMBED, TM_TRY(launch_embedding(e->d_resid, e->tok_embeddings, d_ids, M, e->hidden, m.vocab, st)));
     TM_PROF(P_RES_NORM, TM_TRY(launch_rmsnorm(e->d_x, e->d_resid, e->layers[0].attn_norm, m.rms_eps, M, e->hidden, st)));
     const float scale_log2 = (1.0f / std::sqrt((float)e->D)) * 1.4426950408889634f;
@@ -604,8 +624,28 @@ static int forward(tm_engine* e, const int* d_ids, int M, int nseq, bool decode,
         }
         else {
             TM_PROF(P_GEMM_QKV, TM_TRY(linear_plain(e, L.qkv, e->d_x, e->hidden, e->d_qkv, e->qkv_n, M, false)));
-            TM_PROF(P_KV_STORE, TM_TRY(launch_kv_rope_store(e->d_qkv, e->q_heads, e->d_cu_q, e->d_k_len, nseq, M, e->d_rope,
+            TM_PROF(P_KV_STORE, TM_TRY(launch_kv_rope_store(qkv_p, e->q_heads, e->d_cu_q, e->d_k_len, nseq, M - nd, e->d_rope,
                                                            e->rope_max_pos, cv, st)));
+        }
+        if (md) {  // decode rows: fused prologue (RoPE + K/V quantise-store) + attention on the fp16 projection rows
+            DecodeAttnParams p{};
+            p.qkv_f16        = e->d_qkv;
+            p.qkv_n          = e->qkv_n;
+            p.cos_sin        = e->d_rope;
+            p.max_pos        = e->rope_max_pos;
+            p.q              = e->d_qkv;
+            p.q_stride       = e->qkv_n;
+            p.out            = e->d_attn;
+            p.k_len          = md->k_len;
+            p.batch          = nd;
+            p.q_heads        = e->q_heads;
+            p.scale_log2     = scale_log2;
+            p.splits         = e->decode_splits;
+            p.partial_o      = e->d_attn_ws;
+            p.partial_ml     = e->d_attn_ws + (size_t)nd * e->q_heads * e->decode_splits * e->D;
+            p.cache          = cv;
+            p.cache.block_ptrs = md->block_ptrs;
+            TM_PROF(P_ATTN, TM_TRY(launch_decode_attention(p, st)));
         }
         if (decode) {
             DecodeAttnParams p{};
@@ -634,9 +674,9 @@ static int forward(tm_engine* e, const int* d_ids, int M, int nseq, bool decode,
             TM_PROF(P_KV_STORE, TM_TRY(launch_flatten_kv(e->d_kflat, e->d_vflat, 1, e->d_cu_koff, e->d_k_len, nseq, max_k_len,
                                                         kflat_stride, cv, st)));
             PrefillAttnParams p{};
-            p.q          = e->d_qkv;
+            p.q          = qkv_p;
             p.q_stride   = e->qkv_n;
-            p.out        = e->d_attn;
+            p.out        = attn_p;
             p.k          = e->d_kflat;
             p.vt         = e->d_vflat;
             p.k_stride   = kflat_stride;
@@ -663,63 +703,67 @@ static int forward(tm_engine* e, const int* d_ids, int M, int nseq, bool decode,
         TM_PROF(P_GEMM_GATE_UP, TM_TRY(linear_plain(e, L.w13, e->d_x, e->hidden, e->d_act, e->inter, M, true)));
         TM_TRY(linear_residual_norm(e, L.w2, e->d_act, e->inter, M, next_norm, P_GEMM_DOWN, next_lin));
     }
-    // last-token hidden states -> logits -> greedy
-    const half_t* hx = e->d_x;
-    if (!decode) {
-        TM_TRY(launch_gather_rows(e->d_last, e->d_x, e->d_rows, nseq, e->hidden, st));
-        hx = e->d_last;
-    }
-    // logits / next ids land in the batch slots [slot0, slot0 + nseq)
-    half_t* logits = e->d_logits + (size_t)slot0 * e->vocab_local;
-    int*    ids    = e->d_next_ids + slot0;
-    TM_PROF(P_LM_HEAD, TM_TRY(linear_plain(e, e->output, hx, e->hidden, logits, e->vocab_local, nseq, false)));
-    if (e->logits_on) {
-        // the tokens this forward consumed join the slots' seen masks, then penalty / bans on the (local) logits
-        uint32_t* seen = e->d_seen + (size_t)slot0 * e->seen_words;
-        TM_PROF(P_SAMPLE, TM_TRY(launch_seen_update(seen, e->seen_words, d_ids, decode ? nullptr : e->d_cu_q, nseq, M, m.vocab, st)));
-        TM_PROF(P_SAMPLE, TM_TRY(launch_logits_process(logits, nseq, e->vocab_local, e->vocab_local,
-                                                       e->vocab_local < m.vocab ? e->cfg.rank * e->vocab_local : 0, seen,
-                                                       e->seen_words, e->d_lp_rep + slot0, e->d_lp_ban + slot0 * kMaxBadIds,
-                                                       e->d_lp_end + slot0 * kMaxEndIds, e->d_k_len, e->d_lp_minlen + slot0,
-                                                       st)));
-    }
-    if (!e->use_comm && e->sampling_on) {
-        // parameters are indexed by batch slot, the counter (context length) by the row of this forward
-        TM_PROF(P_SAMPLE, TM_TRY(launch_sample_uniform(e->d_u + slot0, e->d_seed + slot0, e->d_k_len, nseq, st)));
-        TM_PROF(P_SAMPLE, TM_TRY(launch_sample(ids, nullptr, logits, nseq, e->vocab_local, e->vocab_local, e->d_temp + slot0,
-                                               e->d_topk + slot0, e->d_topp + slot0, e->d_minp + slot0, e->d_u + slot0,
-                                               e->d_sample_ws, st)));
-    }
-    else if (!e->use_comm) {
-        TM_PROF(P_SAMPLE, TM_TRY(launch_argmax(ids, nullptr, logits, nseq, e->vocab_local, e->vocab_local, 0, st)));
-    }
-    else {
-        TM_TRY(launch_argmax(ids, e->d_argmax_val, logits, nseq, e->vocab_local, e->vocab_local,
-                             e->cfg.rank * e->vocab_local, st));
-        pack_candidates_kernel<<<(nseq + 63) / 64, 64, 0, st>>>(e->d_cand, ids, e->d_argmax_val, nseq);
-        TM_HIP_CHECK(hipGetLastError());
-        if (e->p2p_ready) {
-            half_t*   data[8];
-            uint32_t* flags[8];
-            p2p_tables(e, data, flags);
-            TM_TRY(launch_p2p_allgather(data, flags, e->cfg.tp, e->cfg.rank, e->p2p_state, (size_t)e->p2p_rows * e->hidden, e->d_cand,
-                                        e->d_cand_all, nseq * 2, st));
+    // last-token hidden states -> logits -> next ids, for `n` sequences whose logits / next ids land in the batch slots
+    // [slot, slot + n): hx = their hidden rows, ids / cu_q (nullptr: one token per sequence) / ntok = the tokens this forward
+    // consumed for them, k_len = their context lengths
+    auto head = [&](const half_t* hx, int n, int slot, const int* ids_in, const int* cu_q, int ntok, const int* k_len) -> int {
+        half_t* logits = e->d_logits + (size_t)slot * e->vocab_local;
+        int*    ids    = e->d_next_ids + slot;
+        TM_PROF(P_LM_HEAD, TM_TRY(linear_plain(e, e->output, hx, e->hidden, logits, e->vocab_local, n, false)));
+        if (e->logits_on) {
+            // the tokens this forward consumed join the slots' seen masks, then penalty / bans on the (local) logits
+            uint32_t* seen = e->d_seen + (size_t)slot * e->seen_words;
+            TM_PROF(P_SAMPLE, TM_TRY(launch_seen_update(seen, e->seen_words, ids_in, cu_q, n, ntok, m.vocab, st)));
+            TM_PROF(P_SAMPLE, TM_TRY(launch_logits_process(logits, n, e->vocab_local, e->vocab_local,
+                                                           e->vocab_local < m.vocab ? e->cfg.rank * e->vocab_local : 0, seen,
+                                                           e->seen_words, e->d_lp_rep + slot, e->d_lp_ban + slot * kMaxBadIds,
+                                                           e->d_lp_end + slot * kMaxEndIds, k_len, e->d_lp_minlen + slot, st)));
         }
-        // the same communicator is only ever driven from ONE stream (the side stream when it exists)
-        else if (e->comm_overlap && e->comm_stream) {
-            TM_HIP_CHECK(hipEventRecord(e->ev_fork, st));
-            TM_HIP_CHECK(hipStreamWaitEvent(e->comm_stream, e->ev_fork, 0));
-            TM_NCCL_CHECK(ncclAllGather(e->d_cand, e->d_cand_all, (size_t)nseq * 2, ncclFloat, e->comm, e->comm_stream));
-            TM_HIP_CHECK(hipEventRecord(e->ev_join, e->comm_stream));
-            TM_HIP_CHECK(hipStreamWaitEvent(st, e->ev_join, 0));
+        if (!e->use_comm && e->sampling_on) {
+            // parameters are indexed by batch slot, the counter (context length) by the row of this forward
+            TM_PROF(P_SAMPLE, TM_TRY(launch_sample_uniform(e->d_u + slot, e->d_seed + slot, k_len, n, st)));
+            TM_PROF(P_SAMPLE, TM_TRY(launch_sample(ids, nullptr, logits, n, e->vocab_local, e->vocab_local, e->d_temp + slot,
+                                                   e->d_topk + slot, e->d_topp + slot, e->d_minp + slot, e->d_u + slot,
+                                                   e->d_sample_ws, st)));
+        }
+        else if (!e->use_comm) {
+            TM_PROF(P_SAMPLE, TM_TRY(launch_argmax(ids, nullptr, logits, n, e->vocab_local, e->vocab_local, 0, st)));
         }
         else {
-            TM_NCCL_CHECK(ncclAllGather(e->d_cand, e->d_cand_all, (size_t)nseq * 2, ncclFloat, e->comm, st));
+            TM_TRY(launch_argmax(ids, e->d_argmax_val, logits, n, e->vocab_local, e->vocab_local, e->cfg.rank * e->vocab_local, st));
+            pack_candidates_kernel<<<(n + 63) / 64, 64, 0, st>>>(e->d_cand, ids, e->d_argmax_val, n);
+            TM_HIP_CHECK(hipGetLastError());
+            if (e->p2p_ready) {
+                half_t*   data[8];
+                uint32_t* flags[8];
+                p2p_tables(e, data, flags);
+                TM_TRY(launch_p2p_allgather(data, flags, e->cfg.tp, e->cfg.rank, e->p2p_state, (size_t)e->p2p_rows * e->hidden, e->d_cand,
+                                            e->d_cand_all, n * 2, st));
+            }
+            // the same communicator is only ever driven from ONE stream (the side stream when it exists)
+            else if (e->comm_overlap && e->comm_stream) {
+                TM_HIP_CHECK(hipEventRecord(e->ev_fork, st));
+                TM_HIP_CHECK(hipStreamWaitEvent(e->comm_stream, e->ev_fork, 0));
+                TM_NCCL_CHECK(ncclAllGather(e->d_cand, e->d_cand_all, (size_t)n * 2, ncclFloat, e->comm, e->comm_stream));
+                TM_HIP_CHECK(hipEventRecord(e->ev_join, e->comm_stream));
+                TM_HIP_CHECK(hipStreamWaitEvent(st, e->ev_join, 0));
+            }
+            else {
+                TM_NCCL_CHECK(ncclAllGather(e->d_cand, e->d_cand_all, (size_t)n * 2, ncclFloat, e->comm, st));
+            }
+            pick_kernel<<<(n + 63) / 64, 64, 0, st>>>(ids, e->d_cand_all, e->cfg.tp, n);
+            TM_HIP_CHECK(hipGetLastError());
         }
-        pick_kernel<<<(nseq + 63) / 64, 64, 0, st>>>(ids, e->d_cand_all, e->cfg.tp, nseq);
-        TM_HIP_CHECK(hipGetLastError());
+        return 0;
+    };
+    if (decode) {
+        return head(e->d_x, nseq, slot0, d_ids, nullptr, M, e->d_k_len);
     }
-    return 0;
+    if (md) {  // the decode rows first: their slots are 0 .. nd-1; the prefilled slots' entries are overwritten right after
+        TM_TRY(head(e->d_x, nd, 0, d_ids, nullptr, nd, md->k_len));
+    }
+    TM_TRY(launch_gather_rows(e->d_last, e->d_x, e->d_rows, nseq, e->hidden, st));
+    return head(e->d_last, nseq, slot0, d_ids + nd, e->d_cu_q, M - nd, e->d_k_len);
 }
 
 // next ids become the current ids and are appended to generated[b][step]
@@ -1293,9 +1337,21 @@ static void setup_decode(tm_engine* e, int batch)
 // Chunked prefill of `batch` sequences into the batch slots [slot0, slot0 + batch): whole sequences,
 // <= max_prefill_token_num tokens per iteration (a sequence longer than the budget is split into history + new tokens).
 // Logits / first tokens land in d_logits / d_next_ids at slot0 + i.  Uses e->d_k_len / d_cu_q as iteration-local arrays.
-static int prefill_slots(tm_engine* e, const int* const* seq_ids, const int* host_lens, int batch, int slot0, float* ttft_ms)
+// `mix` (continuous batching): the LAST iteration also carries the decode step of all batch slots as leading rows of the
+// same forward (MixedDecode); every iteration then leaves room for those rows.  *mix->done reports that it happened.
+struct MixedStep {
+    int        rows;     // batch slots = decode rows
+    int*       k_len;    // the decode state arrays (NOT the iteration-local e->d_k_len)
+    const int* active;
+    int*       ids;      // current token of every slot
+    const uint64_t* block_ptrs;  // the decode block table
+    bool*      done;
+};
+
+static int prefill_slots(tm_engine* e, const int* const* seq_ids, const int* host_lens, int batch, int slot0, float* ttft_ms,
+                         const MixedStep* mix = nullptr)
 {
-    const int  budget  = e->max_tokens;
+    const int  budget  = e->max_tokens - (mix ? mix->rows : 0);
     const auto t_start = std::chrono::steady_clock::now();
     // Because the batch tables (block_ptrs, cu_block_nums) are indexed by the batch slot, every prefill
     // iteration covers a contiguous range of slots [b0, b1]; the block table is offset accordingly and the
@@ -1331,7 +1387,18 @@ static int prefill_slots(tm_engine* e, const int* const* seq_ids, const int* hos
         const int nseq = (int)klen.size();
         TM_REQUIRE(nseq >= 1, "internal: empty prefill iteration");
         TM_REQUIRE(koff.back() <= e->kflat_stride, "internal: flatten scratch too small");
-        TM_HIP_CHECK(hipMemcpyAsync(e->d_prefill_ids, ids.data(), ids.size() * 4, hipMemcpyHostToDevice, e->stream));
+        // the last iteration of a continuous-batching admission: decode rows of every slot in front of the prefill rows
+        const bool merge = mix && b1 == batch && !partial_last;
+        const int  nd    = merge ? mix->rows : 0;
+        if (merge) {
+            advance_active_kernel<<<(nd + 63) / 64, 64, 0, e->stream>>>(mix->k_len, mix->active, nd);
+            TM_HIP_CHECK(hipGetLastError());
+            TM_HIP_CHECK(hipMemcpyAsync(e->d_prefill_ids, mix->ids, (size_t)nd * 4, hipMemcpyDeviceToDevice, e->stream));
+            for (int& r : rows) {
+                r += nd;
+            }
+        }
+        TM_HIP_CHECK(hipMemcpyAsync(e->d_prefill_ids + nd, ids.data(), ids.size() * 4, hipMemcpyHostToDevice, e->stream));
         TM_HIP_CHECK(hipMemcpyAsync(e->d_cu_q, cu_q.data(), cu_q.size() * 4, hipMemcpyHostToDevice, e->stream));
         TM_HIP_CHECK(hipMemcpyAsync(e->d_k_len, klen.data(), klen.size() * 4, hipMemcpyHostToDevice, e->stream));
         TM_HIP_CHECK(hipMemcpyAsync(e->d_cu_koff, koff.data(), koff.size() * 4, hipMemcpyHostToDevice, e->stream));
@@ -1339,10 +1406,16 @@ static int prefill_slots(tm_engine* e, const int* const* seq_ids, const int* hos
         // shift the block tables so that slot 0 of this iteration is sequence b0
         uint64_t* saved_ptrs = e->d_block_ptrs;
         e->d_block_ptrs += (size_t)(slot0 + b0) * e->max_blocks_per_seq;
-        const int rc    = forward(e, e->d_prefill_ids, tokens, nseq, false, max_q, max_k, e->kflat_stride, slot0 + b0);
+        const MixedDecode md{nd, merge ? mix->k_len : nullptr, merge ? mix->block_ptrs : nullptr};
+        const int rc    = forward(e, e->d_prefill_ids, nd + tokens, nseq, false, max_q, max_k, e->kflat_stride, slot0 + b0,
+                                  merge ? &md : nullptr);
         e->d_block_ptrs = saved_ptrs;
         if (rc) {
             return rc;
+        }
+        if (merge) {  // as decode_step_cb: the next ids of every slot become its current token
+            TM_HIP_CHECK(hipMemcpyAsync(mix->ids, e->d_next_ids, (size_t)nd * 4, hipMemcpyDeviceToDevice, e->stream));
+            *mix->done = true;
         }
         // the host vectors above are pageable: make sure the async copies are done before they die
         TM_HIP_CHECK(hipStreamSynchronize(e->stream));
@@ -1380,6 +1453,7 @@ static int cb_enter(tm_engine* e)
         TM_TRY(dmalloc(&e->d_active, (size_t)B));
         TM_TRY(dmalloc(&e->d_pf_k_len, (size_t)B));
         TM_TRY(dmalloc(&e->d_pf_cu_q, (size_t)B + 1));
+        TM_TRY(dmalloc(&e->d_pf_block_ptrs, (size_t)B * e->max_blocks_per_seq));
     }
     e->dummy_block = (int)e->num_blocks - 1;  // parking block of the free slots; the scheduler owns the others
     e->sched.reset(new BatchScheduler(B, (int)e->num_blocks - 1, e->cfg.session_len, e->cfg.cache_block_seq_len));
@@ -1393,6 +1467,7 @@ static int cb_enter(tm_engine* e)
         cu_q[b] = b;
     }
     TM_HIP_CHECK(hipMemcpyAsync(e->d_block_ptrs, ptrs.data(), ptrs.size() * 8, hipMemcpyHostToDevice, e->stream));
+    TM_HIP_CHECK(hipMemcpyAsync(e->d_pf_block_ptrs, ptrs.data(), ptrs.size() * 8, hipMemcpyHostToDevice, e->stream));
     TM_HIP_CHECK(hipMemcpyAsync(e->d_k_len, ones.data(), B * 4, hipMemcpyHostToDevice, e->stream));
     TM_HIP_CHECK(hipMemcpyAsync(e->d_active, zeros.data(), B * 4, hipMemcpyHostToDevice, e->stream));
     TM_HIP_CHECK(hipMemcpyAsync(e->d_ids, zeros.data(), B * 4, hipMemcpyHostToDevice, e->stream));
@@ -1427,7 +1502,10 @@ static int cb_park_slot(tm_engine* e, int slot)
 }
 
 // prefill the newly admitted requests (contiguous slot runs share one chunked prefill), hand over their first tokens
-static int cb_prefill_admitted(tm_engine* e, const std::vector<SchedAdmit>& admits, std::vector<StepUpdate>* updates)
+// `merged` != nullptr: the decode step of this scheduler step may ride on the last prefill iteration (mixed forward);
+// *merged says whether it did, `fresh` receives the slots that were prefilled by that forward (they did not decode in it)
+static int cb_prefill_admitted(tm_engine* e, const std::vector<SchedAdmit>& admits, std::vector<StepUpdate>* updates,
+                               bool* merged = nullptr, std::vector<int>* fresh = nullptr)
 {
     std::vector<SchedAdmit> sorted = admits;
     std::sort(sorted.begin(), sorted.end(), [](const SchedAdmit& a, const SchedAdmit& b) { return a.slot < b.slot; });
@@ -1463,16 +1541,31 @@ static int cb_prefill_admitted(tm_engine* e, const std::vector<SchedAdmit>& admi
                 ptrs[(size_t)k * e->max_blocks_per_seq + q] = (uint64_t)(e->pool + (int64_t)r->blocks[q] * e->block_bytes);
             }
         }
-        TM_HIP_CHECK(hipMemcpyAsync(e->d_block_ptrs + (size_t)slot0 * e->max_blocks_per_seq, ptrs.data(), ptrs.size() * 8,
+        TM_HIP_CHECK(hipMemcpyAsync(e->d_pf_block_ptrs + (size_t)slot0 * e->max_blocks_per_seq, ptrs.data(), ptrs.size() * 8,
                                     hipMemcpyHostToDevice, e->stream));
-        // prefill uses iteration-local k_len / cu_q arrays: the decode arrays of the running slots stay untouched
+        // prefill uses iteration-local k_len / cu_q arrays and its own block table: the decode state of the running slots
+        // stays untouched, the new slots' decode rows stay parked until the prefill is done
+        const bool      last_run = merged && j == sorted.size();
+        bool            did      = false;
+        const MixedStep mix{e->cfg.max_batch_size, e->d_k_len, e->d_active, e->d_ids, e->d_block_ptrs, &did};
         std::swap(e->d_k_len, e->d_pf_k_len);
         std::swap(e->d_cu_q, e->d_pf_cu_q);
-        const int rc = prefill_slots(e, ids.data(), lens.data(), n, slot0, nullptr);
+        std::swap(e->d_block_ptrs, e->d_pf_block_ptrs);
+        const int rc = prefill_slots(e, ids.data(), lens.data(), n, slot0, nullptr, last_run ? &mix : nullptr);
         std::swap(e->d_k_len, e->d_pf_k_len);
         std::swap(e->d_cu_q, e->d_pf_cu_q);
+        std::swap(e->d_block_ptrs, e->d_pf_block_ptrs);
         if (rc) {
             return rc;
+        }
+        // prefilled: the rows join the decode table
+        TM_HIP_CHECK(hipMemcpyAsync(e->d_block_ptrs + (size_t)slot0 * e->max_blocks_per_seq, ptrs.data(), ptrs.size() * 8,
+                                    hipMemcpyHostToDevice, e->stream));
+        if (did) {
+            *merged = true;
+            for (int k = 0; k < n; ++k) {
+                fresh->push_back(slot0 + k);
+            }
         }
         // decode state of the new slots: context length, current token; first tokens go to the host
         std::vector<int> first(n), ones(n, 1);
@@ -1820,17 +1913,31 @@ static int step_locked(tm_engine* e, int* n_active, int* n_waiting, std::vector<
     TM_HIP_CHECK(hipSetDevice(e->cfg.device));
     const int B = e->cfg.max_batch_size;
     // 1. admission + prefill (budget = max_prefill_token_num tokens of prompts per step)
+    // Mixed steps (TM_MIXED_STEP, default on): when something is already decoding, the decode step rides on the admission's
+    // last prefill forward -- one weight stream for both (reference: the unified batch of unified_attention_layer.cc:310-311).
+    const bool        mixed_on = !getenv("TM_MIXED_STEP") || atoi(getenv("TM_MIXED_STEP")) != 0;
+    // (not with logits processors: the decode rows of the slots being prefilled are parked rows whose stale token would
+    // join the freshly cleared "seen" mask)
+    const bool        can_mix  = mixed_on && e->fuse_qkv && !e->use_comm && !e->logits_on && e->sched->n_active() > 0
+                         && e->max_tokens - B >= 16;
+    bool             merged = false;
+    std::vector<int> fresh;
     const std::vector<SchedAdmit> admits = e->sched->admit(e->max_tokens);
     if (!admits.empty()) {
-        TM_TRY(cb_prefill_admitted(e, admits, updates));
+        TM_TRY(cb_prefill_admitted(e, admits, updates, can_mix ? &merged : nullptr, &fresh));
     }
     // 2. one decode step for everything that is running
     if (e->sched->n_active() > 0) {
-        if (e->graph_cb && (e->graph_cb_sampling != e->sampling_on || e->graph_cb_logits != e->logits_on)) {
+        if (merged) {
+            ++e->mixed_steps;  // the decode rows went through the admission's forward
+        }
+        else if (e->graph_cb && (e->graph_cb_sampling != e->sampling_on || e->graph_cb_logits != e->logits_on)) {
             (void)hipGraphExecDestroy(e->graph_cb);
             e->graph_cb = nullptr;
         }
-        if (graph_enabled(e) && !e->graph_cb) {
+        if (merged) {
+        }
+        else if (graph_enabled(e) && !e->graph_cb) {
             TM_TRY(decode_step_cb(e));  // one eager step first (lazy module loading must not happen inside a capture)
             TM_HIP_CHECK(hipStreamSynchronize(e->stream));
             TM_TRY(capture_step(e, decode_step_cb, &e->graph_cb));
@@ -1847,8 +1954,8 @@ static int step_locked(tm_engine* e, int* n_active, int* n_waiting, std::vector<
         TM_HIP_CHECK(hipStreamSynchronize(e->stream));
         for (int b = 0; b < B; ++b) {
             const int64_t id = e->sched->slot_request(b);
-            if (!e->h_active[b] || id < 0) {
-                continue;
+            if (!e->h_active[b] || id < 0 || std::find(fresh.begin(), fresh.end(), b) != fresh.end()) {
+                continue;  // free, or prefilled by this step's mixed forward: its first token was handed over above
             }
             const bool finished = e->sched->on_token(b, e->h_step_ids[b]);
             if (updates) {
@@ -2137,6 +2244,11 @@ int tm_engine_debug_read(tm_engine* e, int what, int a, int b, void* host_out, i
         TM_HIP_CHECK(hipMemcpy(host_out, e->pool + (int64_t)e->h_blocks[a][b] * e->block_bytes, (size_t)bytes, hipMemcpyDeviceToHost));
         return 0;
     }
+    if (what == 2) {  // int64: scheduler steps whose decode rows rode on a prefill forward (mixed steps)
+        TM_REQUIRE(bytes == 8, "byte count must be 8");
+        *(int64_t*)host_out = e->mixed_steps;
+        return 0;
+    }
     set_last_error("tm_engine_debug_read: unknown selector");
     return 1;
 }
@@ -2186,7 +2298,7 @@ int tm_engine_destroy(tm_engine* e)
     if (e->graph_cb) {
         (void)hipGraphExecDestroy(e->graph_cb);
     }
-    for (void* q : {(void*)e->d_active, (void*)e->d_pf_k_len, (void*)e->d_pf_cu_q, (void*)e->d_temp, (void*)e->d_topp, (void*)e->d_minp,
+    for (void* q : {(void*)e->d_active, (void*)e->d_pf_k_len, (void*)e->d_pf_cu_q, (void*)e->d_pf_block_ptrs, (void*)e->d_temp, (void*)e->d_topp, (void*)e->d_minp,
                     (void*)e->d_u, (void*)e->d_topk, (void*)e->d_seed, e->d_sample_ws, (void*)e->d_seen, (void*)e->d_lp_rep,
                     (void*)e->d_lp_minlen, (void*)e->d_lp_ban, (void*)e->d_lp_end}) {
         if (q) {

@@ -156,6 +156,12 @@ class Engine:
         _ffi.check(self._lib.tm_engine_debug_read(self._h, 1, seq, block, out.ctypes.data, out.nbytes))
         return out
 
+    def mixed_steps(self) -> int:
+        """continuous batching: scheduler steps whose decode rows shared ONE forward with an admission's prefill"""
+        out = np.zeros(1, np.int64)
+        _ffi.check(self._lib.tm_engine_debug_read(self._h, 2, 0, 0, out.ctypes.data, 8))
+        return int(out[0])
+
     # ---- continuous batching (tm_engine_submit / step / poll / cancel) -----------------------------
     def submit(self, prompt: Sequence[int], max_new_tokens: int, eos_id: int = -1, sampling=None, logits=None) -> int:
         """Queue one request; returns its id.  eos_id < 0 = ignore_eos.  sampling = (temperature, top_k, top_p, min_p,

@@ -176,9 +176,13 @@ def test_continuous_batching_matches_static(cuda, slots):
     eng.close()
 
 
+@pytest.mark.parametrize('mixed', [1, 0])
 @pytest.mark.parametrize('kv_bits', [8, 4])
-def test_continuous_batching_matches_oracle(cuda, kv_bits):
-    """The scheduler path against the ORACLE (not against the engine's own static path): 8 requests of different prompt and
+def test_continuous_batching_matches_oracle(cuda, monkeypatch, kv_bits, mixed):
+    """mixed = 1 (default): an admission that arrives while other requests decode runs as ONE forward -- decode rows of
+    every slot first, then the prompt tokens (the reference's unified batch, unified_attention_layer.cc:310-311) -- and the
+    test insists that this happened; mixed = 0: prefill forwards and decode steps alternate.
+    The scheduler path against the ORACLE (not against the engine's own static path): 8 requests of different prompt and
     generation lengths through 3 batch slots (admissions join a running batch, slots and KV blocks are reused, one prompt
     is chunked); every request's token stream is replayed through the oracle model alone (batch 1, teacher-forced with
     the engine's tokens) and every engine token must be the arg-max of the oracle's logits wherever the oracle's top-2
@@ -191,6 +195,7 @@ def test_continuous_batching_matches_oracle(cuda, kv_bits):
     lens = [70, 5, 64, 33, 150, 9, 1, 40]
     news = [6, 12, 3, 9, 5, 14, 8, 2]
     prompts = [rng.integers(0, cfg.vocab, n).astype(np.int32) for n in lens]
+    monkeypatch.setenv('TM_MIXED_STEP', str(mixed))
     eng = Engine.from_model_config(cfg, max_batch_size=3, session_len=256, quant_policy=kv_bits, max_prefill_token_num=96)
     eng.load_weights(export_weights(cfg, w))
     eng.start()
@@ -205,7 +210,9 @@ def test_continuous_batching_matches_oracle(cuda, kv_bits):
                 st, toks = eng.poll(rid)
                 if st != 0:
                     done[i] = (st, toks.copy())
+    n_mixed = eng.mixed_steps()
     eng.close()
+    assert (n_mixed >= 3) if mixed else (n_mixed == 0), f'{n_mixed} mixed steps'
     checked = 0
     for i, (st, toks) in done.items():
         assert st == 7 and len(toks) == news[i], f'request {i}: status {st}, {len(toks)} tokens'

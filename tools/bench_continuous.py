@@ -57,7 +57,8 @@ def main():
                       'value': round(got / dt, 1), 'unit': 'tokens/s', 'requests': args.requests, 'requests_per_s': round(args.requests / dt, 2),
                       'batch_slots': args.batch, 'prompt_len': [p0, p1], 'output_len': [o0, o1], 'prompt_tokens': int(plen.sum()),
                       'output_tokens': got, 'wall_s': round(dt, 3), 'scheduler_steps': steps,
-                      'mean_active_slots': round(occ / steps, 1), 'total_tokens_per_s': round((got + int(plen.sum())) / dt, 1)}))
+                      'mean_active_slots': round(occ / steps, 1), 'total_tokens_per_s': round((got + int(plen.sum())) / dt, 1),
+                      'mixed_steps': eng.mixed_steps(), 'TM_MIXED_STEP': os.environ.get('TM_MIXED_STEP', '1')}))
     eng.close()
 
 
