@@ -27,6 +27,7 @@
 // transpose-read simply addresses those rows.
 #include "tm_common.h"
 #include "tm_kernels.h"
+#include <type_traits>
 
 namespace tmk {
 
@@ -231,14 +232,20 @@ __global__ __launch_bounds__(256, 2) void decode_attention_i8_mfma_kernel(Decode
     const int       vpoff  = L.v_param(kv_head, 0);
 
     constexpr int NR = BITS == 8 ? 8 : 4;  // 16-byte loads per lane per K (V) block
-    u32x4    kreg[NR], vreg[NR];
+    u32x4    kreg[NR] = {}, vreg[NR] = {};
     uint32_t kpr = 0, vpr = 0;
-    auto load_tile = [&](int tile) {
+    // FIRST: the first block a wave touches -- the only one that can be the (partial) newest block of the sequence.  Rows past
+    // the context are masked to exactly nothing below whatever the registers hold, so those lanes re-read the last valid row
+    // instead (same cache lines: no HBM traffic, no branches) -- on average half a block of HBM reads per (sequence, kv head)
+    // and launch, all of it on the critical path of the wave that owns one block more than the others.
+    auto load_tile = [&](int tile, auto FIRST) {
         const char* base = block_ptr(tile) + p.cache.layer_offset;
+        const int   last = decltype(FIRST)::value ? min(63, ctx - tile * 64 - 1) : 63;
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
             // int8: token (lane/8 + 8r), 16-byte chunk lane%8 of its 128 bytes; int4: token (lane/4 + 16r), chunk lane%4 of 64
-            const int off = BITS == 8 ? ((lane >> 3) + 8 * r) * 128 + (lane & 7) * 16 : ((lane >> 2) + 16 * r) * 64 + (lane & 3) * 16;
+            const int row = BITS == 8 ? (lane >> 3) + 8 * r : (lane >> 2) + 16 * r;
+            const int off = BITS == 8 ? min(row, last) * 128 + (lane & 7) * 16 : min(row, last) * 64 + (lane & 3) * 16;
             kreg[r]       = *(const u32x4*)(base + koff + off);
             vreg[r]       = *(const u32x4*)(base + voff + off);
         }
@@ -301,7 +308,7 @@ __global__ __launch_bounds__(256, 2) void decode_attention_i8_mfma_kernel(Decode
             }
         }
         if (tile >= tile_begin) {
-            load_tile(tile);
+            load_tile(tile, std::true_type{});
         }
         half8_t t = qkv_finish(p, b, qcol, rq);
         if (p.cos_sin) {
@@ -370,7 +377,7 @@ __global__ __launch_bounds__(256, 2) void decode_attention_i8_mfma_kernel(Decode
     }
     else {
         if (tile >= tile_begin) {
-            load_tile(tile);
+            load_tile(tile, std::true_type{});
         }
     }
 #pragma unroll
@@ -401,7 +408,7 @@ __global__ __launch_bounds__(256, 2) void decode_attention_i8_mfma_kernel(Decode
         }
         const int ntok = min(64, ctx - tile * 64);
         if (tile - 4 >= tile_begin) {
-            load_tile(tile - 4);  // next block streams in while this one is contracted
+            load_tile(tile - 4, std::false_type{});  // next block streams in while this one is contracted
         }
 
         // ---- S^T = K q^T on raw codes -----------------------------------------------------------------------
