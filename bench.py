@@ -146,6 +146,8 @@ def main():
     ap.add_argument('--layers', type=int, default=0, help='debug only: override the layer count (result is then INVALID)')
     ap.add_argument('--model', default='llama3_8b', choices=['llama3_8b', 'internlm2_20b', 'llama3_70b', 'mixtral_8x7b'],
                     help='shapes to time; the headline metric is llama3_8b (anything else changes metric/config in the output)')
+    ap.add_argument('--tune', type=int, default=1, help='1 (default): TM_GEMM_TUNE=1 -- the engine measures its decode GEMM tilings at '
+                    'start-up, outside the timed region (the reference\'s warm-up tuning); 0: heuristics only')
     ap.add_argument('--no-traffic', action='store_true', help='skip the rocprofv3 --pmc FETCH_SIZE child run (roofline.traffic = null)')
     ap.add_argument('--no-full-run', action='store_true', help='skip the continuation to 1024 generated tokens (value_full_run)')
     ap.add_argument('--traffic-child', action='store_true', help=argparse.SUPPRESS)
@@ -204,6 +206,9 @@ def main():
         eng.comm_init(Engine.comm_unique_id())
     eng.init_synthetic(seed=0)          # same seed on every rank: shards are generated per rank-local shape
     eng.start()
+    tuned = bool(args.tune) and world == 1 and emu <= 1 and B <= 64 and not child
+    if tuned:                           # start-up work like the reference's TM_GEMM_TUNE warm-up: not in any timed region
+        eng.tune_gemm(B)
 
     gen = torch.Generator().manual_seed(0)
     prompts = torch.randint(0, model['vocab'], (B, S), generator=gen, dtype=torch.int32).numpy()
@@ -276,7 +281,8 @@ def main():
             'config': {'workload': f'Llama-3-8B shapes, W4A16 AWQ g128 random weights, quant_policy={args.quant_policy} '
                                    f'KV, batch {B}, {S}-token random prompts, greedy decode, TP={world}',
                        'batch': B, 'prompt_len': S, 'ctx_first_timed_step': ctx_first, 'ctx_mean': ctx_mean,
-                       'parallelism': f'tp{world}', 'rccl_ranks': world if world > 1 else 0, 'decode_splits': stats['decode_splits'], 'hipgraph': not args.no_graph},
+                       'parallelism': f'tp{world}', 'rccl_ranks': world if world > 1 else 0, 'decode_splits': stats['decode_splits'], 'hipgraph': not args.no_graph,
+                       'gemm_dispatch': 'measured at start-up (tm_engine_tune_gemm)' if tuned else 'heuristic'},
             'ttft_p50_ms': round(float(np.median(ttft)), 2), 'prefill_total_s': round(prefill_s, 3),
             'prefill_tokens_per_s': round(B * S / prefill_s, 1),
             'step_roofline': {'bound': 'hbm', 'algorithmic_bytes_per_step': int(step_bytes),

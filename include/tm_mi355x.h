@@ -356,6 +356,15 @@ int tm_engine_set_logits_params(tm_engine* e, const tm_logits_param* host_params
 
 /* release the batch (blocks return to the pool); also ends a continuous-batching session */
 int tm_engine_release(tm_engine* e);
+/* Measured GEMM dispatch (the reference's warm-up tuning, turbomind.cc:363-487 / kernels/gemm/gemm.cu:92-224): time every
+ * (workgroup shape, split-K) candidate of the decode kernel for the model's w_qkv / wo / w1w3 / w2 at M (<= 64) rows -- as a
+ * hipGraph over the engine's own layer weights, each GEMM followed by the kernel that consumes it -- and remember the winner
+ * per (K, N, M).  After tm_engine_start, before the first batch.  export_path (may be NULL): write the table as text lines
+ * "K N M shape splits".  Environment equivalents read by tm_engine_start: TM_GEMM_TUNE=1 (M = max_batch_size),
+ * TM_GEMM_EXPORT=<file>, TM_GEMM_IMPORT=<file>; TM_GEMM_TUNE_VERBOSE=1 prints every measurement to stderr. */
+int tm_engine_tune_gemm(tm_engine* e, int M, const char* export_path);
+int tm_gemm_import(const char* path);
+
 
 /* ----------------------------------------------------------------------------------------------
  * Continuous batching.  Replaces ModelRequest.forward / cancel + the engine thread's

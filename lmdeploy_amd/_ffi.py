@@ -114,6 +114,8 @@ _SIGNATURES = {
     'tm_quantize_groupwise': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                                       c_void_p]),
     'tm_debug_set_gemm_trace': (c_int, [c_void_p]),
+    'tm_engine_tune_gemm': (c_int, [c_void_p, c_int, c_char_p]),
+    'tm_gemm_import': (c_int, [c_char_p]),
     'tm_debug_set_block_stride': (c_int, [c_int]),
     'tm_engine_comm_native_export': (c_int, [c_void_p, c_int, c_void_p]),
     'tm_engine_comm_native_import': (c_int, [c_void_p, c_void_p, c_int]),

@@ -1112,6 +1112,178 @@ int tm_engine_process_weights(tm_engine* e)
     return 0;
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Measured GEMM dispatch (reference: the warm-up tuning of turbomind.cc:363-487 -> gemm::Gemm::Run's DispatchCache,
+// kernels/gemm/gemm.cu:92-224; TM_GEMM_TUNE / TM_GEMM_EXPORT / TM_GEMM_IMPORT).  For the decode batch M <= 64 every
+// dense linear role of the model (w_qkv, wo, w1w3, w2) is timed with every (workgroup shape, split-K) candidate of the
+// decode kernel as ONE hipGraph over the model's own layers -- distinct weights per node, more bytes than the Infinity
+// Cache holds, as in a decode step -- and each node is followed by the kernel that consumes its result (the fused split-K
+// reduce + residual + RMSNorm for wo / w2, the slab reduce standing in for the attention prologue for w_qkv): a split-K
+// GEMM looks cheap in isolation and pays at the kernel boundary (profiles/r02_gemm_boundary_gap.txt).  The winner enters
+// the (K, N, M) table that dec32_pick consults first; it replaces the heuristic only when it is >= 3 % faster.
+// ------------------------------------------------------------------------------------------------------------------
+static int tune_decode_gemms(tm_engine* e, int M, bool verbose)
+{
+    TM_REQUIRE(M >= 1 && M <= 64 && M <= e->cfg.max_batch_size, "tuning covers the decode kernel: 1 <= M <= min(64, max_batch_size)");
+    hipStream_t st = e->stream;
+    struct Role {
+        const char*   name;
+        int           which;  // 0 qkv, 1 wo, 2 w13, 3 w2
+        const half_t* x;
+        int           ldx;
+        half_t*       y;
+        int           ldy;
+        bool          gated;
+    };
+    const Role roles[4] = {{"w_qkv", 0, e->d_x, e->hidden, e->d_qkv, e->qkv_n, false},
+                           {"wo", 1, e->d_attn, e->q_heads * e->D, e->d_tmp, e->hidden, false},
+                           {"w1w3", 2, e->d_x, e->hidden, e->d_act, e->inter, true},
+                           {"w2", 3, e->d_act, e->inter, e->d_tmp, e->hidden, false}};
+    hipEvent_t e0, e1;
+    TM_HIP_CHECK(hipEventCreate(&e0));
+    TM_HIP_CHECK(hipEventCreate(&e1));
+    // finite inputs (the buffers are scratch before the first forward): zeros
+    TM_HIP_CHECK(hipMemsetAsync(e->d_x, 0, (size_t)M * e->hidden * 2, st));
+    TM_HIP_CHECK(hipMemsetAsync(e->d_attn, 0, (size_t)M * e->q_heads * e->D * 2, st));
+    TM_HIP_CHECK(hipMemsetAsync(e->d_act, 0, (size_t)M * e->inter * 2, st));
+    TM_HIP_CHECK(hipMemsetAsync(e->d_resid, 0, (size_t)M * e->hidden * 2, st));
+    int rc = 0;
+    for (const Role& r : roles) {
+        std::vector<const LinearWeight*> ws;
+        for (Layer& L : e->layers) {
+            if (r.which >= 2 && L.is_moe) {
+                continue;
+            }
+            const LinearWeight* w = r.which == 0 ? &L.qkv.w : r.which == 1 ? &L.wo.w : r.which == 2 ? &L.w13.w : &L.w2.w;
+            if (w->packed && dec32_supported(*w, M)) {
+                ws.push_back(w);
+            }
+        }
+        if (ws.size() < 2) {
+            continue;
+        }
+        const LinearWeight& w0 = *ws[0];
+        int                 hs, hp;
+        if (dec32_table_get(w0.K, w0.N, M, &hs, &hp)) {
+            continue;  // imported / tuned already
+        }
+        dec32_pick_ex(w0, M, &hs, &hp, false);
+        int       cand[96][2];
+        int       nc = dec32_candidates(w0, M, cand, 95);
+        bool      has = false;
+        for (int i = 0; i < nc; ++i) {
+            has = has || (cand[i][0] == hs && cand[i][1] == hp);
+        }
+        if (!has) {
+            cand[nc][0] = hs;
+            cand[nc][1] = hp;
+            ++nc;
+        }
+        float best = 1e30f, heur = 1e30f;
+        int   bs = hs, bp = hp;
+        for (int i = 0; i < nc && !rc; ++i) {
+            GemmConfig cfg{};
+            cfg.nt        = 2;
+            cfg.waves     = 16;
+            cfg.kphases   = 1;
+            cfg.d32_shape = cand[i][0];
+            cfg.splits    = cand[i][1];
+            if (gemm_workspace_bytes(M, w0.N, cfg.splits) > e->gemm_ws_bytes) {
+                continue;
+            }
+            const bool norm_consumer = (r.which == 1 || r.which == 3) && !e->use_comm;
+            auto chain = [&]() -> int {
+                for (const LinearWeight* w : ws) {
+                    int slabs = 1;
+                    TM_TRY(launch_linear(*w, r.x, r.ldx, r.y, r.ldy, M, r.gated, cfg, e->d_gemm_ws, norm_consumer && cfg.splits > 1, &slabs, st));
+                    if (norm_consumer) {
+                        TM_TRY(launch_residual_rmsnorm(e->d_last, e->d_resid, slabs > 1 ? nullptr : e->d_tmp, slabs > 1 ? e->d_gemm_ws : nullptr,
+                                                       slabs, nullptr, e->final_norm, e->cfg.model.rms_eps, M, e->hidden, st));
+                    }
+                }
+                return 0;
+            };
+            if ((rc = chain())) {  // eager once: lazy module loading, function attributes
+                break;
+            }
+            TM_HIP_CHECK(hipStreamSynchronize(st));
+            hipGraph_t     g  = nullptr;
+            hipGraphExec_t ge = nullptr;
+            TM_HIP_CHECK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+            const int crc = chain();
+            TM_HIP_CHECK(hipStreamEndCapture(st, &g));
+            if (crc) {
+                rc = crc;
+                (void)hipGraphDestroy(g);
+                break;
+            }
+            TM_HIP_CHECK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+            float us = 1e30f;
+            for (int rep = 0; rep < 4; ++rep) {
+                TM_HIP_CHECK(hipEventRecord(e0, st));
+                TM_HIP_CHECK(hipGraphLaunch(ge, st));
+                TM_HIP_CHECK(hipEventRecord(e1, st));
+                TM_HIP_CHECK(hipEventSynchronize(e1));
+                float ms = 0.f;
+                TM_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+                if (rep > 0) {
+                    us = std::min(us, ms * 1000.f / (float)ws.size());
+                }
+            }
+            (void)hipGraphExecDestroy(ge);
+            (void)hipGraphDestroy(g);
+            if (cand[i][0] == hs && cand[i][1] == hp) {
+                heur = us;
+            }
+            if (us < best) {
+                best = us;
+                bs   = cand[i][0];
+                bp   = cand[i][1];
+            }
+            if (verbose) {
+                fprintf(stderr, "[tm tune] %-5s K=%d N=%d M=%d shape %d splits %2d: %7.2f us / layer%s\n", r.name, w0.K, w0.N, M, cand[i][0],
+                        cand[i][1], us, (cand[i][0] == hs && cand[i][1] == hp) ? "  <- heuristic" : "");
+            }
+        }
+        if (rc) {
+            break;
+        }
+        if (!(best < 0.97f * heur)) {  // keep the heuristic unless the measurement clearly beats it
+            bs = hs;
+            bp = hp;
+        }
+        dec32_table_set(w0.K, w0.N, M, bs, bp);
+        if (verbose) {
+            fprintf(stderr, "[tm tune] %-5s K=%d N=%d M=%d -> shape %d splits %d (%.2f us; heuristic shape %d splits %d %.2f us)\n", r.name, w0.K,
+                    w0.N, M, bs, bp, best, hs, hp, heur);
+        }
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    TM_HIP_CHECK(hipMemsetAsync(e->d_resid, 0, (size_t)M * e->hidden * 2, st));
+    TM_HIP_CHECK(hipStreamSynchronize(st));
+    return rc;
+}
+
+int tm_engine_tune_gemm(tm_engine* e, int M, const char* export_path)
+{
+    TM_REQUIRE(e && e->started, "engine not started");
+    TM_REQUIRE(e->batch == 0 && !e->sched, "tune before the first batch is admitted");
+    TM_HIP_CHECK(hipSetDevice(e->cfg.device));
+    const char* v = getenv("TM_GEMM_TUNE_VERBOSE");
+    TM_TRY(tune_decode_gemms(e, M, v && atoi(v)));
+    if (export_path && *export_path) {
+        return dec32_table_export(export_path);
+    }
+    return 0;
+}
+
+int tm_gemm_import(const char* path)
+{
+    TM_REQUIRE(path && *path, "path");
+    return dec32_table_import(path);
+}
+
 int tm_engine_start(tm_engine* e)
 {
     TM_REQUIRE(e, "null pointer");
@@ -1207,6 +1379,21 @@ int tm_engine_start(tm_engine* e)
     }
     TM_HIP_CHECK(hipStreamSynchronize(e->stream));
     e->started = true;
+    // the reference's switches: TM_GEMM_IMPORT=<file> loads a dispatch table, TM_GEMM_TUNE=1 measures the decode batch
+    // (max_batch_size rows) now, TM_GEMM_EXPORT=<file> writes the table
+    if (const char* imp = getenv("TM_GEMM_IMPORT")) {
+        if (dec32_table_import(imp)) {
+            fprintf(stderr, "[tm] TM_GEMM_IMPORT: nothing read from %s\n", imp);
+        }
+    }
+    const char* tune = getenv("TM_GEMM_TUNE");
+    if (tune && atoi(tune) && B <= 64) {
+        const char* v = getenv("TM_GEMM_TUNE_VERBOSE");
+        TM_TRY(tune_decode_gemms(e, B, v && atoi(v)));
+    }
+    if (const char* exp = getenv("TM_GEMM_EXPORT")) {
+        TM_TRY(dec32_table_export(exp));
+    }
     return 0;
 }
 

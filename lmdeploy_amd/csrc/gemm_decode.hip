@@ -32,6 +32,10 @@
 #include "tm_kernels.h"
 #include <stdlib.h>
 #include <type_traits>
+#include <map>
+#include <string>
+#include <tuple>
+#include <stdio.h>
 
 namespace tmk {
 
@@ -971,7 +975,6 @@ static int launch_dec32_shape(const Dec32Params& p, dim3 grid, int shape, hipStr
             if (abl == 0) return launch_dec32_one<MH, 4, 2, 4, 4, 0>(p, grid, st);
             return launch_dec32_one<MH, 4, 2, 4, 4, kD32Mode>(p, grid, st);
         case 3:  // 8 waves: 2 column groups x 4 k-phases (64 columns per workgroup)
-        case 6:  // the same tile on 32-row blocks (grid.z = ceil(M / 32)): see dec32_pick
             return launch_dec32_one<MH, 2, 4, 4, 2, kD32Mode>(p, grid, st);
         default: break;
     }
@@ -979,11 +982,23 @@ static int launch_dec32_shape(const Dec32Params& p, dim3 grid, int shape, hipStr
     return 1;
 }
 
+// Shapes 6 .. 9 are the decode shapes 3, 0, 2, 1 on 32-ROW blocks (grid.z = ceil(M / 32), the MH = 1 instantiations): twice the
+// workgroups of half the LDS footprint (64 KB: two per CU), every weight unit read by the two row halves of its column tile
+// (the second reader hits L2: the halves are gridDim.x * gridDim.y workgroups apart, the same XCD whenever that product is a
+// multiple of 8).  They trade dequantisation work (one MFMA per fragment instead of two) for parallelism without split-K
+// slabs -- which side wins is measured (tune_decode_gemms), not guessed.
+static int dec32_base_shape(int shape)
+{
+    static const int base[4] = {3, 0, 2, 1};
+    return shape >= 6 && shape <= 9 ? base[shape - 6] : shape;
+}
+
 // shape -> (column groups, k-blocks per stage)
 static void dec32_shape_dims(int shape, int* cg, int* s)
 {
-    static const int cgs[7] = {4, 8, 4, 2, 8, 16, 2};
-    *cg = cgs[shape < 0 || shape > 6 ? 0 : shape];
+    static const int cgs[6] = {4, 8, 4, 2, 8, 16};
+    shape = dec32_base_shape(shape);
+    *cg = cgs[shape < 0 || shape > 5 ? 0 : shape];
     *s  = shape == 5 ? 1 : (shape == 4 ? 2 : 4);
 }
 
@@ -994,12 +1009,115 @@ bool dec32_supported(const LinearWeight& w, int M)
     return on && (M <= 64 || on_big) && w.type == 0 && w.packed32 != nullptr && M >= 1 && w.N % 32 == 0 && w.K % 128 == 0;
 }
 
+// ---- measured dispatch (reference: gemm::Gemm::Run's DispatchCache, kernels/gemm/gemm.cu:92-224, filled by the warm-up
+// tuning of turbomind.cc:363-487 under TM_GEMM_TUNE and carried between runs by TM_GEMM_EXPORT / TM_GEMM_IMPORT).  Here the
+// key is (K, N, M) of a decode-batch linear, the value its workgroup shape and split-K count; the engine's tuner
+// (engine.hip: tune_decode_gemms) fills it by timing every candidate as a hipGraph over the model's own layer weights
+// TOGETHER with the kernel that consumes the result (a split-K GEMM pays at the boundary, not inside the kernel).
+static std::map<std::tuple<int, int, int>, std::pair<int, int>> g_d32_table;
+
+void dec32_table_set(int K, int N, int M, int shape, int splits)
+{
+    g_d32_table[std::make_tuple(K, N, M)] = std::make_pair(shape, splits);
+}
+
+bool dec32_table_get(int K, int N, int M, int* shape, int* splits)
+{
+    auto it = g_d32_table.find(std::make_tuple(K, N, M));
+    if (it == g_d32_table.end()) {
+        return false;
+    }
+    *shape  = it->second.first;
+    *splits = it->second.second;
+    return true;
+}
+
+void dec32_table_clear()
+{
+    g_d32_table.clear();
+}
+
+// text, one line per entry: K N M shape splits
+int dec32_table_export(const char* path)
+{
+    FILE* f = fopen(path, "w");
+    if (!f) {
+        set_last_error(std::string("cannot write ") + path);
+        return 1;
+    }
+    for (const auto& kv : g_d32_table) {
+        fprintf(f, "%d %d %d %d %d\n", std::get<0>(kv.first), std::get<1>(kv.first), std::get<2>(kv.first), kv.second.first,
+                kv.second.second);
+    }
+    fclose(f);
+    return 0;
+}
+
+int dec32_table_import(const char* path)
+{
+    FILE* f = fopen(path, "r");
+    if (!f) {
+        set_last_error(std::string("cannot read ") + path);
+        return 1;
+    }
+    int K, N, M, shape, splits, n = 0;
+    while (fscanf(f, "%d %d %d %d %d", &K, &N, &M, &shape, &splits) == 5) {
+        if (K > 0 && N > 0 && M > 0 && M <= 64 && shape >= 0 && shape <= 9 && shape != 4 && shape != 5 && splits >= 1 && splits <= 16) {
+            dec32_table_set(K, N, M, shape, splits);
+            ++n;
+        }
+    }
+    fclose(f);
+    return n > 0 ? 0 : 1;
+}
+
+// every (shape, splits) the decode kernel can run this linear with at M <= 64 rows: whole stages per slice, <= 512 workgroups
+int dec32_candidates(const LinearWeight& w, int M, int (*out)[2], int cap)
+{
+    const int ncg = w.N / 32, KB = w.K / 128;
+    int       n   = 0;
+    static const int shapes[8] = {0, 1, 2, 3, 6, 7, 8, 9};
+    for (int si = 0; si < 8 && M <= 64; ++si) {
+        const int shape = shapes[si];
+        if (shape >= 6 && M <= 32) {
+            continue;  // one row block: identical to the base shape
+        }
+        int       cgn, S;
+        dec32_shape_dims(shape, &cgn, &S);
+        const int tiles = (ncg + cgn - 1) / cgn * (shape >= 6 ? (M + 31) / 32 : 1);
+        for (int s = 1; s <= 16; ++s) {
+            int per = (KB + s - 1) / s;
+            per     = (per + S - 1) / S * S;
+            if ((KB + per - 1) / per != s) {
+                continue;  // not a distinct slicing
+            }
+            if ((s > 1 && tiles * s > (shape >= 6 ? 512 : 320)) || tiles * s < 32) {
+                continue;  // split-K beyond one (32-row shapes: two) workgroup(s) per CU / a handful of workgroups
+            }
+            if (n < cap) {
+                out[n][0] = shape;
+                out[n][1] = s;
+                ++n;
+            }
+        }
+    }
+    return n;
+}
+
 // Tiling for the decode GEMM: `shape` (see launch_dec32_shape) and the split-K count.  One workgroup per CU (128 KB of
 // LDS): take the widest split that keeps <= 256 workgroups and >= one stage (4 k-blocks) per slice.
 void dec32_pick(const LinearWeight& w, int M, int* shape_out, int* splits_out)
 {
+    dec32_pick_ex(w, M, shape_out, splits_out, true);
+}
+
+void dec32_pick_ex(const LinearWeight& w, int M, int* shape_out, int* splits_out, bool use_table)
+{
     const int ncg = w.N / 32;
     const int KB  = w.K / 128;
+    if (use_table && M <= 64 && dec32_table_get(w.K, w.N, M, shape_out, splits_out)) {
+        return;  // measured on this machine for exactly this problem
+    }
     int       shape = env_int2("TM_D32_SHAPE", -1);
     if (shape < 0 || shape > 3) {
         shape = 0;
@@ -1050,7 +1168,8 @@ int launch_linear_dec32(const LinearWeight& w, const half_t* x, int ldx, half_t*
                         int splits, float* workspace, int* slabs_out, hipStream_t st)
 {
     TM_REQUIRE(w.packed32 != nullptr && w.N % 32 == 0, "decode GEMM: P32 layout missing");
-    TM_REQUIRE(M >= 1 && (shape == 6 || (M <= 64) == (shape < 4)), "decode GEMM: shapes 0..3 take M <= 64, shapes 4 / 5 take M > 64");
+    TM_REQUIRE(M >= 1 && shape >= 0 && shape <= 9 && (shape >= 6 || (M <= 64) == (shape < 4)),
+               "decode GEMM: shapes 0..3 take M <= 64, shapes 4 / 5 take M > 64, shapes 6..9 any M");
     TM_REQUIRE(ldx % 8 == 0, "x rows must be 16-byte aligned");
     int cgn, S;
     dec32_shape_dims(shape, &cgn, &S);
@@ -1076,8 +1195,8 @@ int launch_linear_dec32(const LinearWeight& w, const half_t* x, int ldx, half_t*
     p.dbg          = g_gemm_dbg;
     p.rotate       = env_int2("TM_D32_ROTATE", 0);
     p.wt           = env_int2("TM_D32_WT", 1);  // measured (tools/trace_boundary.py, profiles/r02_gemm_boundary_gap.txt): -0.4..-0.9 us per split-K launch
-    dim3      grid((p.ncg + cgn - 1) / cgn, splits, shape == 6 ? (M + 31) / 32 : shape >= 4 ? (M + 127) / 128 : 1);
-    const int rc = shape == 6 ? launch_dec32_shape<1>(p, grid, shape, st) :
+    dim3      grid((p.ncg + cgn - 1) / cgn, splits, shape >= 6 ? (M + 31) / 32 : shape >= 4 ? (M + 127) / 128 : 1);
+    const int rc = shape >= 6 ? launch_dec32_shape<1>(p, grid, dec32_base_shape(shape), st) :
                    shape >= 4 ? launch_dec32_shape<4>(p, grid, shape, st) :
                    M <= 32    ? launch_dec32_shape<1>(p, grid, shape, st) :
                                 launch_dec32_shape<2>(p, grid, shape, st);

@@ -146,7 +146,15 @@ int launch_linear(const LinearWeight& w, const half_t* x, int ldx, half_t* y, in
 size_t p32_bytes(int K, int N);
 int    launch_repack_p32(void* out, const int32_t* qweight, const half_t* scales, const half_t* zeros, int K, int N, hipStream_t st);
 bool   dec32_supported(const LinearWeight& w, int M);
-void   dec32_pick(const LinearWeight& w, int M, int* shape_out, int* splits_out);
+void   dec32_pick(const LinearWeight& w, int M, int* shape_out, int* splits_out);  // measured table first, then the heuristic
+void   dec32_pick_ex(const LinearWeight& w, int M, int* shape_out, int* splits_out, bool use_table);
+// measured dispatch table of the decode linears: key (K, N, M <= 64) -> (shape, splits)
+void   dec32_table_set(int K, int N, int M, int shape, int splits);
+bool   dec32_table_get(int K, int N, int M, int* shape, int* splits);
+void   dec32_table_clear();
+int    dec32_table_export(const char* path);
+int    dec32_table_import(const char* path);
+int    dec32_candidates(const LinearWeight& w, int M, int (*out)[2], int cap);
 int    launch_linear_dec32(const LinearWeight& w, const half_t* x, int ldx, half_t* y, int ldy, int M, bool gated_silu, int shape,
                            int splits, float* workspace, int* slabs_out, hipStream_t st);
 

@@ -85,6 +85,13 @@ class Engine:
     def start(self):
         _ffi.check(self._lib.tm_engine_start(self._h))
 
+    def tune_gemm(self, M: int = 0, export_path: str = ''):
+        """Measured GEMM dispatch for the decode batch (the reference's TM_GEMM_TUNE warm-up): times every candidate tiling
+        of the decode linears at M rows (default: max_batch_size) on this engine's weights and keeps the winners; optional
+        text export (`tm_gemm_import` / TM_GEMM_IMPORT loads it in a later process)."""
+        M = M or int(self.cfg.max_batch_size)
+        _ffi.check(self._lib.tm_engine_tune_gemm(self._h, int(M), export_path.encode() if export_path else None))
+
     # ---- static batch ----------------------------------------------------------------------------
     def set_sampling(self, params):
         """Static batch: per-sequence (temperature, top_k, top_p, min_p, seed) tuples for the NEXT prefill; None = greedy."""

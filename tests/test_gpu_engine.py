@@ -91,6 +91,37 @@ def test_engine_collective_path_single_rank(cuda, monkeypatch, graph_comm, side_
     assert np.abs(l0.astype(np.float32) - l1.astype(np.float32)).max() <= 2e-3
 
 
+def test_engine_gemm_tuning_roundtrip(cuda, tmp_path):
+    """Measured GEMM dispatch (the reference's TM_GEMM_TUNE / EXPORT / IMPORT): the tuner times the candidate tilings of the
+    four decode linears on the engine's own weights, the table can be exported and imported, and whatever it picked the
+    engine still reproduces the oracle (every candidate is a parity-tested tiling of the same arithmetic)."""
+    cfg = o.ModelConfig(hidden=512, layers=3, q_heads=4, kv_heads=2, head_dim=128, inter=1024, vocab=1024, kv_bits=8,
+                        rope=o.RopeParam(128, 500000.0, 'llama3', 8.0, 1.0, 4.0, 8192))
+    w = o.make_synthetic_weights(cfg, seed=5)
+    rng = np.random.default_rng(9)
+    prompts = [rng.integers(0, cfg.vocab, n).astype(np.int32) for n in (40, 7, 65, 12)]
+    path = str(tmp_path / 'gemm_dispatch.txt')
+    eng = Engine.from_model_config(cfg, max_batch_size=4, session_len=128, quant_policy=8, max_prefill_token_num=128)
+    eng.load_weights(export_weights(cfg, w))
+    eng.start()
+    eng.tune_gemm(4, path)
+    rows = [tuple(int(v) for v in ln.split()) for ln in open(path).read().splitlines()]
+    assert len(rows) == 4 and all(r[2] == 4 and r[4] >= 1 for r in rows), rows        # w_qkv, wo, w1w3, w2 at M = 4
+    assert {(r[0], r[1]) for r in rows} == {(512, 1024), (512, 512), (512, 2048), (1024, 512)}
+    eng.prefill(prompts, max_new_tokens=5)
+    eng.decode(4)
+    toks = eng.fetch()
+    lg = eng.fetch_logits()
+    eng.close()
+    _ffi.check(_ffi.load().tm_gemm_import(path.encode()))
+    om = o.OracleModel(cfg, w, batch=4, max_ctx=128)
+    _, ref = om.forward(prompts)
+    for s in range(4):
+        _, ref = om.forward([[int(t)] for t in toks[:, s]])
+    err = np.abs(lg.astype(np.float32) - ref.astype(np.float32))
+    assert err.max() <= 4e-2, err.max()
+
+
 @pytest.mark.parametrize('slots', [1, 3])
 def test_continuous_batching_matches_static(cuda, slots):
     """the engine scheduler (submit / step / poll / cancel).  9 requests through 1 or 3 batch slots,

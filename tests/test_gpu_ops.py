@@ -593,9 +593,10 @@ def test_w4a16_odd_stage_count_is_stable(tm, cuda, K, N, M, splits, waves):
 
 @pytest.mark.parametrize('K,N,gated', [(4096, 6144, 0), (1792, 4096, 0), (1024, 512, 0), (4096, 1024, 1), (384, 64, 0)])
 @pytest.mark.parametrize('M', [1, 32, 33, 50, 64, 100, 256])
-def test_w4a16_row_half_tiles(tm, cuda, K, N, M, gated):
-    """shape 6: 32-row x 64-column workgroup tiles over the WHOLE k range (no split-K slabs: the k-phases meet on chip) --
-    the decode tiling of the narrow projections (w_qkv, wo, w2) -- plus its split-K form"""
+@pytest.mark.parametrize('shape', [6, 7, 8, 9])
+def test_w4a16_row_half_tiles(tm, cuda, K, N, M, gated, shape):
+    """shapes 6 .. 9: the decode tilings on 32-row blocks (6: 64-column tiles over the WHOLE k range, no split-K slabs: the
+    k-phases meet on chip -- the measured choice for the narrow projections) plus their split-K forms"""
     rng = np.random.default_rng(K + N + M + 6)
     h, (q, s, z) = _make_linear(tm, rng, K, N)
     x = rng.standard_normal((M, K)).astype(f16)
@@ -606,9 +607,9 @@ def test_w4a16_row_half_tiles(tm, cuda, K, N, M, gated):
         if splits > max(1, K // 512):
             continue
         y = torch.zeros((M, N // 2 if gated else N), dtype=torch.float16, device='cuda')
-        _ffi.check(tm.tm_linear_forward(h, x_d.data_ptr(), K, y.data_ptr(), y.shape[1], M, gated, 0, splits, 0x206, ws.data_ptr(), st()))
+        _ffi.check(tm.tm_linear_forward(h, x_d.data_ptr(), K, y.data_ptr(), y.shape[1], M, gated, 0, splits, 0x200 | shape, ws.data_ptr(), st()))
         err = np.abs(host(y).astype(np.float32) - ref)
-        assert np.all(err <= 2e-3 + 2.0**-9 * np.abs(ref)), f'splits={splits}: max err {err.max()}'
+        assert np.all(err <= 2e-3 + 2.0**-9 * np.abs(ref)), f'shape {shape} splits={splits}: max err {err.max()}'
     _ffi.check(tm.tm_linear_destroy(h))
 
 
