@@ -1128,18 +1128,30 @@ void dec32_pick_ex(const LinearWeight& w, int M, int* shape_out, int* splits_out
         static const int pre64_from = env_int2("TM_PRE64_MIN_M", 257);
         shape = (M >= pre64_from && w.N >= 512) ? 5 : 4;
     }
-    // Mid-width projections at a full decode batch (w_qkv of an 8B model, N = 6144): 32-row x 64-column tiles over the WHOLE
-    // k range (shape 6), >= 160 workgroups.  Split-K there costs more at the kernel boundary than it buys inside the kernel:
-    // in a back-to-back chain the launch after a split-K GEMM starts 4.1 .. 6.6 us after its last workgroup ended (MBs of
-    // dirty fp32 slabs) against 1.2 us behind a kernel that leaves fp16 outputs (profiles/r02_gemm_boundary_gap.txt).  In
-    // the model (rocprofv3, graph replays, profiles/r02_kernel_trace_by_grid_*.txt): w_qkv 12.2 -> 10.9 us and the attention
-    // kernel behind it 36.0 -> 35.6 us; wo (N = 4096, 128 such workgroups) 7.9 -> 10.0 us and stays on split-K.  The two row
-    // halves of a column tile are gridDim.x (a multiple of 8) workgroups apart: same XCD, the second reader hits L2.
+    // Narrow projections at a full decode batch (33 .. 64 rows, N <= 8192: w_qkv, wo, w2 of an 8B model): 64-column tiles
+    // with as little split-K as still gives ~256 workgroups.  Split-K costs more at the kernel boundary than it buys inside
+    // the kernel -- in a back-to-back chain the launch after a split-K GEMM starts 4.1 .. 6.6 us after its last workgroup
+    // ended (MBs of dirty fp32 slabs) against 1.2 us behind a kernel that leaves fp16 outputs
+    // (profiles/r02_gemm_boundary_gap.txt) -- so the k range stays on chip as far as the workgroup count allows:
+    //   K <= 8192: shape 6 (32-row x 64-column tiles, two row blocks), splits = 256 / tiles  (w_qkv: 192 tiles x 1, wo: 128 x 2)
+    //   K >  8192: shape 3 (64-row x 64-column tiles),                  splits = 256 / tiles  (w2: 64 tiles x 4)
+    // These are the winners of the measured dispatch on the Llama-3-8B shapes (tune_decode_gemms, GEMM + consumer per layer:
+    // wo 14.3 -> 10.5 us, w2 18.6 -> 17.1 us, w_qkv 12.2 -> 9.8 us; profiles/r02_gemm_tune_llama3_8b.txt); with
+    // TM_GEMM_TUNE=1 the engine measures instead of trusting this rule.  The two row halves of a shape-6 column tile are
+    // gridDim.x * gridDim.y workgroups apart -- the same XCD when that is a multiple of 8: the second reader hits L2.
     static const int rowhalf = env_int2("TM_D32_ROWHALF", 1);
-    if (rowhalf && env_int2("TM_D32_SHAPE", -1) < 0 && M > 32 && M <= 64 && KB <= 64 && KB % 4 == 0 && ncg % 16 == 0
-        && (ncg / 2) * ((M + 31) / 32) >= 160 && ncg <= 256) {
-        *shape_out  = 6;
-        *splits_out = env_int2("TM_D32_SPLITS", 1);
+    if (rowhalf && env_int2("TM_D32_SHAPE", -1) < 0 && M > 32 && M <= 64 && KB % 4 == 0 && ncg % 16 == 0 && ncg >= 64 && ncg <= 256) {
+        const int nshape = KB <= 64 ? 6 : 3;
+        const int tiles  = (ncg / 2) * (nshape == 6 ? 2 : 1);
+        int       sp     = 1;
+        for (int s2 = 2; s2 <= 16 && tiles * s2 <= 256; ++s2) {
+            const int per = ((KB + s2 - 1) / s2 + 3) / 4 * 4;
+            if ((KB + per - 1) / per == s2 && per >= 8) {
+                sp = s2;
+            }
+        }
+        *shape_out  = nshape;
+        *splits_out = env_int2("TM_D32_SPLITS", sp);
         return;
     }
     int cgn, S;
