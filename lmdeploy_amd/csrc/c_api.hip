@@ -299,8 +299,9 @@ int tm_linear_forward(const tm_linear* w, const void* x, int ldx, void* y, int l
         // 0x200 + shape: the decode kernel (gemm_decode.hip) with an explicit workgroup shape; M <= 64, u4, N % 32 == 0
         TM_REQUIRE(dec32_supported(w->w, M), "decode kernel: u4 weights, N % 32 == 0");
         cfg.d32_shape = waves & 0xff;
-        TM_REQUIRE((cfg.d32_shape >= 6 && cfg.d32_shape <= 9) || (cfg.d32_shape <= 5 && (cfg.d32_shape >= 4) == (M > 64)),
-                   "decode kernel shape 0..3 (M <= 64), 4 / 5 (M > 64) or 6..9 (32-row blocks, any M)");
+        TM_REQUIRE((cfg.d32_shape >= 6 && cfg.d32_shape <= 11 && (cfg.d32_shape != 10 || M <= 64))
+                       || (cfg.d32_shape <= 5 && (cfg.d32_shape >= 4) == (M > 64)),
+                   "decode kernel shape 0..3, 10 (M <= 64), 4 / 5 (M > 64) or 6..9, 11 (32-row blocks, any M)");
         waves = 0;
     }
     if (waves > 0) {

@@ -644,6 +644,307 @@ static int launch_dec32_one(const Dec32Params& p, dim3 grid, hipStream_t st)
     return 0;
 }
 
+// ---- decode tile with TWO weight fragments per activation-fragment read (shapes 10 / 11) --------------------------------------
+// At M = 64 the loop of gemm_dec32_kernel is co-limited on the CU: per 2176-byte weight unit 128 clk of matrix pipe, 128 clk of
+// LDS (16 x 1 KB fragment reads at 128 B/clk) and 112 clk of VALU issue against ~205 clk of HBM at the fair share (DESIGN.md
+// 3.1).  Here a wave owns TWO adjacent 32-column groups of its k-phase: one ds_read_b128 feeds two MFMAs per row half, the LDS
+// term halves.  The accumulators double (2 x MH x 16 registers), so a workgroup is 8 waves (two per SIMD, 256 registers
+// each): CG column PAIRS x WK k-phases; the dequantisation of one fragment is interleaved into the MFMAs of the other
+// (sched_group_barrier, as gemm_pre64_kernel) because two waves per SIMD no longer hide it for free.  Structure otherwise
+// as gemm_dec32_kernel in its default mode: LDS-DMA staging of x in stages of S k-blocks, register ring for the weights,
+// inline-asm fragment pipeline, on-chip k-phase reduction, same epilogues, same arithmetic.
+template<int MH, int CG, int WK, int S, int PF>
+__global__ __launch_bounds__(CG* WK * 64) void gemm_dec64_kernel(Dec32Params p)
+{
+    constexpr int NB    = 2;
+    constexpr int WAVES = CG * WK;
+    constexpr int T     = WAVES * 64;
+    constexpr int ROWS  = 32 * MH;
+    constexpr int KBB   = ROWS * 256;
+    constexpr int STG   = S * KBB;
+    constexpr int BPS   = S / WK;
+    constexpr int UNR   = PF / BPS;
+    static_assert(S % WK == 0 && PF % BPS == 0 && UNR == 2, "tile parameters");
+    constexpr int LPB = 3 * NB;  // loads per ring slot
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid  = threadIdx.x;
+    const int wgid = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    if (p.dbg && tid == 0) {
+        p.dbg[wgid * 8 + 0] = __builtin_amdgcn_s_memrealtime();
+    }
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int cgl  = wave % CG;
+    const int wk   = wave / CG;
+    const int l31  = lane & 31;
+    const int half = lane >> 5;
+    int       cgc[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        cgc[nb] = min((int)(blockIdx.x * CG + cgl) * NB + nb, p.ncg - 1);
+    }
+    const int kb0  = blockIdx.y * p.kb_per_split;
+    const int nkb  = min(p.kb_per_split, p.KB - kb0);
+    const int nst  = (nkb + S - 1) / S;
+    const int m0   = blockIdx.z * ROWS;
+    const int Mloc = min(ROWS, p.M - m0);
+
+    const auto rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.wp, 0, (int)((size_t)p.KB * p.ncg * kP32Unit), 0x00020000);
+    const auto rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x + (size_t)m0 * p.ldx), 0,
+                                                        (int)(((size_t)(Mloc - 1) * p.ldx + p.K) * 2), 0x00020000);
+    const int  vw   = lane * 16;
+    const int  vs   = 2048 + l31 * 4;
+
+    floatx16 acc[NB][MH];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+#pragma unroll
+        for (int h = 0; h < MH; ++h) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                acc[nb][h][r] = 0.f;
+            }
+        }
+    }
+    u32x4    ring[PF][NB][2];
+    uint32_t sring[PF][NB];
+    int      coff[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        coff[j] = l31 * 256 + (((2 * j + half) ^ (l31 & 15)) << 4);
+    }
+    uint32_t m1024 = 0x64006400u, m64 = 0x54005400u;
+    asm volatile("" : "+v"(m1024), "+v"(m64));
+
+    // LDS-DMA pieces (see gemm_dec32_kernel): 1 KiB = 4 rows x 256 B, piece pc = r * WAVES + wave, swizzle on the source address
+    constexpr int NPC = S * ROWS / 4;
+    constexpr int DR  = NPC / WAVES;
+    static_assert(NPC % WAVES == 0, "DMA pieces per wave");
+    int            doff[DR];
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)smem);
+#pragma unroll
+    for (int r = 0; r < DR; ++r) {
+        const int pc  = r * WAVES + wave;
+        const int kbi = pc / (ROWS / 4);
+        const int row = (pc % (ROWS / 4)) * 4 + (lane >> 4);
+        const int ch  = (lane & 15) ^ (row & 15);
+        doff[r]       = (min(row, Mloc - 1) * p.ldx + ch * 8) * 2 + kbi * 256;
+    }
+#define D64_DMA_X(t, buf)                                                                                         \
+    _Pragma("unroll") for (int r = 0; r < DR; ++r)                                                                \
+    {                                                                                                             \
+        unsigned       keep_;                                                                                     \
+        const unsigned dst_ = lds0 + (buf)*STG + (r * WAVES + wave) * 1024;                                       \
+        const int      so_  = (kb0 + (t)*S) * 256;                                                                \
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"                                       \
+                     "buffer_load_dwordx4 %1, %2, %4 offen lds\n\ts_mov_b32 m0, %0"                               \
+                     : "=&s"(keep_)                                                                               \
+                     : "v"(doff[r]), "s"(rs_x), "s"(dst_), "s"(so_)                                               \
+                     : "memory");                                                                                 \
+    }
+#define D64_LOAD_W(slot, b)                                                                                       \
+    _Pragma("unroll") for (int nb = 0; nb < NB; ++nb)                                                             \
+    {                                                                                                             \
+        const int uo_       = ((kb0 + min((b), nkb - 1)) * p.ncg + cgc[nb]) * kP32Unit;                           \
+        ring[slot][nb][0]   = __builtin_amdgcn_raw_buffer_load_b128(rs_w, vw, uo_, /*nt*/ 2);                     \
+        ring[slot][nb][1]   = __builtin_amdgcn_raw_buffer_load_b128(rs_w, vw + 1024, uo_, /*nt*/ 2);              \
+        sring[slot][nb]     = __builtin_amdgcn_raw_buffer_load_b32(rs_w, vs, uo_, 0);                             \
+    }
+
+    if (nst > 0) {
+        D64_DMA_X(0, 0);
+#pragma unroll
+        for (int q = 0; q < PF; ++q) {
+            D64_LOAD_W(q, min(q / BPS, nst - 1) * S + wk + (q % BPS) * WK);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        asm volatile("s_waitcnt vmcnt(%0)" ::"i"(LPB * PF) : "memory");  // everything older than the ring: x(0)
+        __syncthreads();
+        if (p.dbg && tid == 0) {
+            p.dbg[wgid * 8 + 1] = __builtin_amdgcn_s_memrealtime();
+        }
+        auto stage = [&](auto U, const int t, auto REM) __attribute__((always_inline)) {
+            constexpr int  u   = decltype(U)::value;
+            constexpr bool rem = decltype(REM)::value;
+            const int      buf = u & 1;
+#pragma unroll
+            for (int i = 0; i < BPS; ++i) {  // hipcc's wait for this stage's ring slots goes HERE, before the invisible DMA
+                asm volatile("" ::"v"(ring[u * BPS + i][0][0]), "v"(ring[u * BPS + i][NB - 1][1]), "v"(sring[u * BPS + i][NB - 1]));
+            }
+            if (t + 1 < nst) {  // uniform; never behind the last stage (the epilogue reuses the buffers)
+                D64_DMA_X(t + 1, buf ^ 1);
+            }
+#pragma unroll
+            for (int i = 0; i < BPS; ++i) {
+                const int  slot = u * BPS + i;
+                const int  kbi  = wk + i * WK;
+                const bool live = t * S + kbi < nkb;
+                half2_t    s2[NB], z2[NB];
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) {
+                    const half2_t pr = bit_cast<half2_t>(live ? sring[slot][nb] : 0u);
+                    s2[nb]           = half2_t{pr[0], pr[0]};
+                    z2[nb]           = half2_t{pr[1], pr[1]};
+                }
+                half8_t        f0[MH], f1[MH];
+                const unsigned xa = lds0 + buf * STG + kbi * KBB;
+                auto           rd = [&](half8_t(&f)[MH], int j) __attribute__((always_inline)) {
+                    const unsigned ad = xa + (unsigned)coff[j];
+#pragma unroll
+                    for (int h = 0; h < MH; ++h) {
+                        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(f[h]) : "v"(ad), "i"(h * 8192));
+                    }
+                };
+                auto wt = [&](half8_t(&f)[MH], auto N) __attribute__((always_inline)) {
+                    constexpr int n = decltype(N)::value;
+                    if constexpr (MH == 1) {
+                        asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(f[0]) : "i"(n));
+                    }
+                    else {
+                        asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(f[0]), "+v"(f[1]) : "i"(n));
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                };
+                rd(f0, 0);
+                half8_t a0 = dequant8_p32(ring[slot][0][0][0], s2[0], z2[0], m1024, m64), a1;
+                static_for<8>([&](auto J) {
+                    constexpr int  j  = decltype(J)::value;
+                    half8_t(&cur)[MH] = (j & 1) ? f1 : f0;
+                    half8_t(&nxt)[MH] = (j & 1) ? f0 : f1;
+                    if constexpr (j + 1 < 8) {
+                        rd(nxt, j + 1);
+                    }
+                    wt(cur, std::integral_constant<int, (j + 1 < 8) ? MH : 0>{});
+                    a1 = dequant8_p32(ring[slot][1][j >> 2][j & 3], s2[1], z2[1], m1024, m64);
+#pragma unroll
+                    for (int h = 0; h < MH; ++h) {
+                        acc[0][h] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, cur[h], acc[0][h], 0, 0, 0);
+                    }
+                    if constexpr (j + 1 < 8) {
+                        a0 = dequant8_p32(ring[slot][0][(j + 1) >> 2][(j + 1) & 3], s2[0], z2[0], m1024, m64);
+                    }
+#pragma unroll
+                    for (int h = 0; h < MH; ++h) {
+                        acc[1][h] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, cur[h], acc[1][h], 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int g = 0; g < NB * MH; ++g) {  // (1 MFMA, the VALU work that fits behind it)
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x002, MH == 2 ? 7 : 14, 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                });
+            }
+#pragma unroll
+            for (int i = 0; i < BPS; ++i) {
+                D64_LOAD_W(u * BPS + i, min(t + UNR, nst - 1) * S + wk + i * WK);
+            }
+            // my DMA pieces of stage t+1 have landed when at most the refills issued after them are in flight (remainder
+            // stages: the refills are dead code there, drain)
+            asm volatile("s_waitcnt vmcnt(%0)" ::"i"(rem ? 0 : LPB * BPS) : "memory");
+            __syncthreads();
+        };
+        int t0 = 0;
+        for (; t0 + UNR <= nst; t0 += UNR) {
+            static_for<UNR>([&](auto U) { stage(U, t0 + decltype(U)::value, std::false_type{}); });
+        }
+        static_for<UNR>([&](auto U) {
+            if (t0 + decltype(U)::value < nst) {
+                stage(U, t0 + decltype(U)::value, std::true_type{});
+            }
+        });
+    }
+#undef D64_DMA_X
+#undef D64_LOAD_W
+    if (p.dbg && tid == 0) {
+        p.dbg[wgid * 8 + 2] = __builtin_amdgcn_s_memrealtime();
+    }
+    // ---- the WK k-phase partial tiles meet in LDS: red[wk][row][c4 ^ (row & 7)] (floatx4 units, CG * NB * 8 per row) ----------
+    {
+        constexpr int C4  = CG * NB * 8;
+        floatx4*      red = (floatx4*)smem;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+#pragma unroll
+            for (int h = 0; h < MH; ++h) {
+                const int m = 32 * h + l31;
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const int c4 = (cgl * NB + nb) * 8 + 2 * g4 + half;
+                    red[(wk * ROWS + m) * C4 + (c4 ^ (m & 7))] =
+                        floatx4{acc[nb][h][4 * g4], acc[nb][h][4 * g4 + 1], acc[nb][h][4 * g4 + 2], acc[nb][h][4 * g4 + 3]};
+                }
+            }
+        }
+        __syncthreads();
+        if (p.dbg && tid == 0) {
+            p.dbg[wgid * 8 + 7] = __builtin_amdgcn_s_memrealtime();
+        }
+        constexpr int NE    = ROWS * C4;
+        const int     ncol0 = blockIdx.x * CG * NB * 32;
+        static_assert(NE % T == 0, "output tile / threads");
+#pragma unroll
+        for (int e0 = 0; e0 < NE; e0 += T) {
+            const int e  = e0 + tid;
+            const int m  = e / C4;
+            const int c4 = e % C4;
+            floatx4   a  = red[m * C4 + (c4 ^ (m & 7))];
+#pragma unroll
+            for (int k = 1; k < WK; ++k) {  // fixed order: deterministic
+                a += red[(k * ROWS + m) * C4 + (c4 ^ (m & 7))];
+            }
+            const int n = ncol0 + c4 * 4;
+            if (m >= Mloc || n >= p.N) {
+                continue;
+            }
+            const size_t mg = (size_t)m0 + m;
+            if (p.epilogue == 2) {
+                floatx4* dst = (floatx4*)(p.partial + ((size_t)blockIdx.y * p.M + mg) * p.N + n);
+                if (p.wt & 1) {
+                    store_wt(dst, a, p.wt >> 4);
+                }
+                else {
+                    *dst = a;
+                }
+            }
+            else if (p.epilogue == 1) {
+                const float s0 = a[0] / (1.0f + __builtin_expf(-a[0]));
+                const float s1 = a[2] / (1.0f + __builtin_expf(-a[2]));
+                half2_t     o  = {(half_t)(s0 * a[1]), (half_t)(s1 * a[3])};
+                *(half2_t*)(p.y + mg * p.ldy + (n >> 1)) = o;
+            }
+            else {
+                half4_t o = {(half_t)a[0], (half_t)a[1], (half_t)a[2], (half_t)a[3]};
+                *(half4_t*)(p.y + mg * p.ldy + n) = o;
+            }
+        }
+    }
+    if (p.dbg && tid == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        p.dbg[wgid * 8 + 3] = __builtin_amdgcn_s_memrealtime();
+    }
+}
+
+template<int MH, int CG, int WK, int S, int PF>
+static int launch_dec64_one(const Dec32Params& p, dim3 grid, hipStream_t st)
+{
+    constexpr int stage = 2 * S * 32 * MH * 256;
+    constexpr int red   = WK * 32 * MH * CG * 2 * 128;
+    constexpr int lds   = stage > red ? stage : red;
+    static bool   attr_set[16] = {};
+    int           dev = 0;
+    (void)hipGetDevice(&dev);
+    if (!attr_set[dev & 15]) {
+        TM_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_dec64_kernel<MH, CG, WK, S, PF>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        attr_set[dev & 15] = true;
+    }
+    gemm_dec64_kernel<MH, CG, WK, S, PF><<<grid, CG * WK * 64, lds, st>>>(p);
+    TM_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
 // ---- prefill tile: 128 rows x 512 columns per workgroup, TWO weight fragments per activation-fragment read -----------------
 // Measured on the 128 x 256 tile above (profiles/r02_bench_gemm_prefill_ablation.txt): with loads and dequant removed the
 // loop still tops out at 62..71 % of the MFMA peak, because every v_mfma_f32_32x32x16 needs one 1 KB x fragment out of LDS
@@ -997,6 +1298,11 @@ static int dec32_base_shape(int shape)
 static void dec32_shape_dims(int shape, int* cg, int* s)
 {
     static const int cgs[6] = {4, 8, 4, 2, 8, 16};
+    if (shape == 10 || shape == 11) {  // gemm_dec64_kernel: 2 column pairs x 4 k-phases (10: 64-row, 11: 32-row blocks)
+        *cg = 4;
+        *s  = 4;
+        return;
+    }
     shape = dec32_base_shape(shape);
     *cg = cgs[shape < 0 || shape > 5 ? 0 : shape];
     *s  = shape == 5 ? 1 : (shape == 4 ? 2 : 4);
@@ -1062,7 +1368,7 @@ int dec32_table_import(const char* path)
     }
     int K, N, M, shape, splits, n = 0;
     while (fscanf(f, "%d %d %d %d %d", &K, &N, &M, &shape, &splits) == 5) {
-        if (K > 0 && N > 0 && M > 0 && M <= 64 && shape >= 0 && shape <= 9 && shape != 4 && shape != 5 && splits >= 1 && splits <= 16) {
+        if (K > 0 && N > 0 && M > 0 && M <= 64 && shape >= 0 && shape <= 11 && shape != 4 && shape != 5 && splits >= 1 && splits <= 16) {
             dec32_table_set(K, N, M, shape, splits);
             ++n;
         }
@@ -1076,22 +1382,22 @@ int dec32_candidates(const LinearWeight& w, int M, int (*out)[2], int cap)
 {
     const int ncg = w.N / 32, KB = w.K / 128;
     int       n   = 0;
-    static const int shapes[8] = {0, 1, 2, 3, 6, 7, 8, 9};
-    for (int si = 0; si < 8 && M <= 64; ++si) {
+    static const int shapes[10] = {0, 1, 2, 3, 6, 7, 8, 9, 10, 11};
+    for (int si = 0; si < 10 && M <= 64; ++si) {
         const int shape = shapes[si];
-        if (shape >= 6 && M <= 32) {
+        if (shape >= 6 && shape != 10 && M <= 32) {
             continue;  // one row block: identical to the base shape
         }
         int       cgn, S;
         dec32_shape_dims(shape, &cgn, &S);
-        const int tiles = (ncg + cgn - 1) / cgn * (shape >= 6 ? (M + 31) / 32 : 1);
+        const int tiles = (ncg + cgn - 1) / cgn * (shape >= 6 && shape != 10 ? (M + 31) / 32 : 1);
         for (int s = 1; s <= 16; ++s) {
             int per = (KB + s - 1) / s;
             per     = (per + S - 1) / S * S;
             if ((KB + per - 1) / per != s) {
                 continue;  // not a distinct slicing
             }
-            if ((s > 1 && tiles * s > (shape >= 6 ? 512 : 320)) || tiles * s < 32) {
+            if ((s > 1 && tiles * s > (shape >= 6 && shape != 10 ? 512 : 320)) || tiles * s < 32) {
                 continue;  // split-K beyond one (32-row shapes: two) workgroup(s) per CU / a handful of workgroups
             }
             if (n < cap) {
@@ -1180,8 +1486,8 @@ int launch_linear_dec32(const LinearWeight& w, const half_t* x, int ldx, half_t*
                         int splits, float* workspace, int* slabs_out, hipStream_t st)
 {
     TM_REQUIRE(w.packed32 != nullptr && w.N % 32 == 0, "decode GEMM: P32 layout missing");
-    TM_REQUIRE(M >= 1 && shape >= 0 && shape <= 9 && (shape >= 6 || (M <= 64) == (shape < 4)),
-               "decode GEMM: shapes 0..3 take M <= 64, shapes 4 / 5 take M > 64, shapes 6..9 any M");
+    TM_REQUIRE(M >= 1 && shape >= 0 && shape <= 11 && (shape == 10 ? M <= 64 : (shape >= 6 || (M <= 64) == (shape < 4))),
+               "decode GEMM: shapes 0..3 and 10 take M <= 64, shapes 4 / 5 take M > 64, shapes 6..9 and 11 any M");
     TM_REQUIRE(ldx % 8 == 0, "x rows must be 16-byte aligned");
     int cgn, S;
     dec32_shape_dims(shape, &cgn, &S);
@@ -1207,8 +1513,10 @@ int launch_linear_dec32(const LinearWeight& w, const half_t* x, int ldx, half_t*
     p.dbg          = g_gemm_dbg;
     p.rotate       = env_int2("TM_D32_ROTATE", 0);
     p.wt           = env_int2("TM_D32_WT", 1);  // measured (tools/trace_boundary.py, profiles/r02_gemm_boundary_gap.txt): -0.4..-0.9 us per split-K launch
-    dim3      grid((p.ncg + cgn - 1) / cgn, splits, shape >= 6 ? (M + 31) / 32 : shape >= 4 ? (M + 127) / 128 : 1);
-    const int rc = shape >= 6 ? launch_dec32_shape<1>(p, grid, dec32_base_shape(shape), st) :
+    dim3      grid((p.ncg + cgn - 1) / cgn, splits, shape == 10 ? 1 : shape >= 6 ? (M + 31) / 32 : shape >= 4 ? (M + 127) / 128 : 1);
+    const int rc = shape >= 10 ? ((shape == 11 || M <= 32) ? launch_dec64_one<1, 2, 4, 4, 2>(p, grid, st) :
+                                                            launch_dec64_one<2, 2, 4, 4, 2>(p, grid, st)) :
+                   shape >= 6 ? launch_dec32_shape<1>(p, grid, dec32_base_shape(shape), st) :
                    shape >= 4 ? launch_dec32_shape<4>(p, grid, shape, st) :
                    M <= 32    ? launch_dec32_shape<1>(p, grid, shape, st) :
                                 launch_dec32_shape<2>(p, grid, shape, st);

@@ -593,10 +593,12 @@ def test_w4a16_odd_stage_count_is_stable(tm, cuda, K, N, M, splits, waves):
 
 @pytest.mark.parametrize('K,N,gated', [(4096, 6144, 0), (1792, 4096, 0), (1024, 512, 0), (4096, 1024, 1), (384, 64, 0)])
 @pytest.mark.parametrize('M', [1, 32, 33, 50, 64, 100, 256])
-@pytest.mark.parametrize('shape', [6, 7, 8, 9])
+@pytest.mark.parametrize('shape', [6, 7, 8, 9, 10, 11])
 def test_w4a16_row_half_tiles(tm, cuda, K, N, M, gated, shape):
     """shapes 6 .. 9: the decode tilings on 32-row blocks (6: 64-column tiles over the WHOLE k range, no split-K slabs: the
     k-phases meet on chip -- the measured choice for the narrow projections) plus their split-K forms"""
+    if shape == 10 and M > 64:
+        pytest.skip('shape 10 = one 64-row block')
     rng = np.random.default_rng(K + N + M + 6)
     h, (q, s, z) = _make_linear(tm, rng, K, N)
     x = rng.standard_normal((M, K)).astype(f16)
