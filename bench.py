@@ -206,7 +206,7 @@ def main():
         eng.comm_init(Engine.comm_unique_id())
     eng.init_synthetic(seed=0)          # same seed on every rank: shards are generated per rank-local shape
     eng.start()
-    tuned = bool(args.tune) and world == 1 and emu <= 1 and B <= 64 and not child
+    tuned = bool(args.tune) and world == 1 and emu <= 1 and B <= 256 and not child
     if tuned:                           # start-up work like the reference's TM_GEMM_TUNE warm-up: not in any timed region
         eng.tune_gemm(B)
 

@@ -357,7 +357,7 @@ int tm_engine_set_logits_params(tm_engine* e, const tm_logits_param* host_params
 /* release the batch (blocks return to the pool); also ends a continuous-batching session */
 int tm_engine_release(tm_engine* e);
 /* Measured GEMM dispatch (the reference's warm-up tuning, turbomind.cc:363-487 / kernels/gemm/gemm.cu:92-224): time every
- * (workgroup shape, split-K) candidate of the decode kernel for the model's w_qkv / wo / w1w3 / w2 at M (<= 64) rows -- as a
+ * (workgroup shape, split-K) candidate of the decode kernels for the model's w_qkv / wo / w1w3 / w2 at M (<= 256) rows -- as a
  * hipGraph over the engine's own layer weights, each GEMM followed by the kernel that consumes it -- and remember the winner
  * per (K, N, M).  After tm_engine_start, before the first batch.  export_path (may be NULL): write the table as text lines
  * "K N M shape splits".  Environment equivalents read by tm_engine_start: TM_GEMM_TUNE=1 (M = max_batch_size),

@@ -1114,7 +1114,7 @@ int tm_engine_process_weights(tm_engine* e)
 
 // ------------------------------------------------------------------------------------------------------------------
 // Measured GEMM dispatch (reference: the warm-up tuning of turbomind.cc:363-487 -> gemm::Gemm::Run's DispatchCache,
-// kernels/gemm/gemm.cu:92-224; TM_GEMM_TUNE / TM_GEMM_EXPORT / TM_GEMM_IMPORT).  For the decode batch M <= 64 every
+// kernels/gemm/gemm.cu:92-224; TM_GEMM_TUNE / TM_GEMM_EXPORT / TM_GEMM_IMPORT).  For the decode batch M <= 256 every
 // dense linear role of the model (w_qkv, wo, w1w3, w2) is timed with every (workgroup shape, split-K) candidate of the
 // decode kernel as ONE hipGraph over the model's own layers -- distinct weights per node, more bytes than the Infinity
 // Cache holds, as in a decode step -- and each node is followed by the kernel that consumes its result (the fused split-K
@@ -1124,7 +1124,7 @@ int tm_engine_process_weights(tm_engine* e)
 // ------------------------------------------------------------------------------------------------------------------
 static int tune_decode_gemms(tm_engine* e, int M, bool verbose)
 {
-    TM_REQUIRE(M >= 1 && M <= 64 && M <= e->cfg.max_batch_size, "tuning covers the decode kernel: 1 <= M <= min(64, max_batch_size)");
+    TM_REQUIRE(M >= 1 && M <= 256 && M <= e->cfg.max_batch_size, "tuning covers the decode kernels: 1 <= M <= min(256, max_batch_size)");
     hipStream_t st = e->stream;
     struct Role {
         const char*   name;
@@ -1387,7 +1387,7 @@ int tm_engine_start(tm_engine* e)
         }
     }
     const char* tune = getenv("TM_GEMM_TUNE");
-    if (tune && atoi(tune) && B <= 64) {
+    if (tune && atoi(tune) && B <= 256) {
         const char* v = getenv("TM_GEMM_TUNE_VERBOSE");
         TM_TRY(tune_decode_gemms(e, B, v && atoi(v)));
     }

@@ -1368,7 +1368,9 @@ int dec32_table_import(const char* path)
     }
     int K, N, M, shape, splits, n = 0;
     while (fscanf(f, "%d %d %d %d %d", &K, &N, &M, &shape, &splits) == 5) {
-        if (K > 0 && N > 0 && M > 0 && M <= 64 && shape >= 0 && shape <= 11 && shape != 4 && shape != 5 && splits >= 1 && splits <= 16) {
+        const bool big = M > 64;
+        if (K > 0 && N > 0 && M > 0 && M <= 256 && shape >= 0 && shape <= 11 && splits >= 1 && splits <= 16
+            && (big ? (shape >= 4 && shape != 10) : (shape != 4 && shape != 5))) {
             dec32_table_set(K, N, M, shape, splits);
             ++n;
         }
@@ -1377,27 +1379,31 @@ int dec32_table_import(const char* path)
     return n > 0 ? 0 : 1;
 }
 
-// every (shape, splits) the decode kernel can run this linear with at M <= 64 rows: whole stages per slice, <= 512 workgroups
+// every (shape, splits) the decode kernels can run this linear with at M <= 256 rows: whole stages per slice, <= 512 workgroups
 int dec32_candidates(const LinearWeight& w, int M, int (*out)[2], int cap)
 {
     const int ncg = w.N / 32, KB = w.K / 128;
     int       n   = 0;
-    static const int shapes[10] = {0, 1, 2, 3, 6, 7, 8, 9, 10, 11};
-    for (int si = 0; si < 10 && M <= 64; ++si) {
-        const int shape = shapes[si];
-        if (shape >= 6 && shape != 10 && M <= 32) {
-            continue;  // one row block: identical to the base shape
+    static const int shapes[12] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11};
+    for (int si = 0; si < 12 && M <= 256; ++si) {
+        const int  shape  = shapes[si];
+        const bool rows32 = shape >= 6 && shape != 10;  // 32-row blocks on grid.z: any M
+        if (rows32 ? M <= 32 : ((shape == 4 || shape == 5) != (M > 64))) {
+            continue;  // one row block: identical to the base shape / 64-row shapes take M <= 64, 128-row tiles M > 64
+        }
+        if (shape == 5 && w.N < 512) {
+            continue;
         }
         int       cgn, S;
         dec32_shape_dims(shape, &cgn, &S);
-        const int tiles = (ncg + cgn - 1) / cgn * (shape >= 6 && shape != 10 ? (M + 31) / 32 : 1);
+        const int tiles = (ncg + cgn - 1) / cgn * (rows32 ? (M + 31) / 32 : (shape == 4 || shape == 5) ? (M + 127) / 128 : 1);
         for (int s = 1; s <= 16; ++s) {
             int per = (KB + s - 1) / s;
             per     = (per + S - 1) / S * S;
             if ((KB + per - 1) / per != s) {
                 continue;  // not a distinct slicing
             }
-            if ((s > 1 && tiles * s > (shape >= 6 && shape != 10 ? 512 : 320)) || tiles * s < 32) {
+            if ((s > 1 && tiles * s > (rows32 ? 512 : 320)) || tiles * s < 32) {
                 continue;  // split-K beyond one (32-row shapes: two) workgroup(s) per CU / a handful of workgroups
             }
             if (n < cap) {
@@ -1421,7 +1427,7 @@ void dec32_pick_ex(const LinearWeight& w, int M, int* shape_out, int* splits_out
 {
     const int ncg = w.N / 32;
     const int KB  = w.K / 128;
-    if (use_table && M <= 64 && dec32_table_get(w.K, w.N, M, shape_out, splits_out)) {
+    if (use_table && M <= 256 && dec32_table_get(w.K, w.N, M, shape_out, splits_out)) {
         return;  // measured on this machine for exactly this problem
     }
     int       shape = env_int2("TM_D32_SHAPE", -1);
@@ -1442,7 +1448,7 @@ void dec32_pick_ex(const LinearWeight& w, int M, int* shape_out, int* splits_out
     //   K <= 8192: shape 6 (32-row x 64-column tiles, two row blocks), splits = 256 / tiles  (w_qkv: 192 tiles x 1, wo: 128 x 2)
     //   K >  8192: shape 3 (64-row x 64-column tiles),                  splits = 256 / tiles  (w2: 64 tiles x 4)
     // These are the winners of the measured dispatch on the Llama-3-8B shapes (tune_decode_gemms, GEMM + consumer per layer:
-    // wo 14.3 -> 10.5 us, w2 18.6 -> 17.1 us, w_qkv 12.2 -> 9.8 us; profiles/r02_gemm_tune_llama3_8b.txt); with
+    // wo 14.3 -> 10.5 us, w2 18.6 -> 17.1 us, w_qkv 12.2 -> 9.8 us; profiles/r02_gemm_tune_measurements.txt); with
     // TM_GEMM_TUNE=1 the engine measures instead of trusting this rule.  The two row halves of a shape-6 column tile are
     // gridDim.x * gridDim.y workgroups apart -- the same XCD when that is a multiple of 8: the second reader hits L2.
     static const int rowhalf = env_int2("TM_D32_ROWHALF", 1);

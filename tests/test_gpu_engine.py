@@ -91,7 +91,8 @@ def test_engine_collective_path_single_rank(cuda, monkeypatch, graph_comm, side_
     assert np.abs(l0.astype(np.float32) - l1.astype(np.float32)).max() <= 2e-3
 
 
-def test_engine_gemm_tuning_roundtrip(cuda, tmp_path):
+@pytest.mark.parametrize('B', [4, 80])
+def test_engine_gemm_tuning_roundtrip(cuda, tmp_path, B):
     """Measured GEMM dispatch (the reference's TM_GEMM_TUNE / EXPORT / IMPORT): the tuner times the candidate tilings of the
     four decode linears on the engine's own weights, the table can be exported and imported, and whatever it picked the
     engine still reproduces the oracle (every candidate is a parity-tested tiling of the same arithmetic)."""
@@ -101,23 +102,26 @@ def test_engine_gemm_tuning_roundtrip(cuda, tmp_path):
     rng = np.random.default_rng(9)
     prompts = [rng.integers(0, cfg.vocab, n).astype(np.int32) for n in (40, 7, 65, 12)]
     path = str(tmp_path / 'gemm_dispatch.txt')
-    eng = Engine.from_model_config(cfg, max_batch_size=4, session_len=128, quant_policy=8, max_prefill_token_num=128)
+    eng = Engine.from_model_config(cfg, max_batch_size=B, session_len=128, quant_policy=8, max_prefill_token_num=128)
     eng.load_weights(export_weights(cfg, w))
     eng.start()
-    eng.tune_gemm(4, path)
-    rows = [tuple(int(v) for v in ln.split()) for ln in open(path).read().splitlines()]
-    assert len(rows) == 4 and all(r[2] == 4 and r[4] >= 1 for r in rows), rows        # w_qkv, wo, w1w3, w2 at M = 4
+    eng.tune_gemm(B, path)     # B = 80: the 64 < M <= 256 decode path (128-row tiles vs the 32-row-block shapes)
+    rows = [tuple(int(v) for v in ln.split()) for ln in open(path).read().splitlines() if int(ln.split()[2]) == B]
+    assert len(rows) == 4 and all(r[4] >= 1 for r in rows), rows        # w_qkv, wo, w1w3, w2 at M = B
     assert {(r[0], r[1]) for r in rows} == {(512, 1024), (512, 512), (512, 2048), (1024, 512)}
+    prompts = (prompts * ((B + 3) // 4))[:B]
     eng.prefill(prompts, max_new_tokens=5)
     eng.decode(4)
     toks = eng.fetch()
     lg = eng.fetch_logits()
     eng.close()
     _ffi.check(_ffi.load().tm_gemm_import(path.encode()))
-    om = o.OracleModel(cfg, w, batch=4, max_ctx=128)
-    _, ref = om.forward(prompts)
+    om = o.OracleModel(cfg, w, batch=4, max_ctx=128)      # the batch repeats four prompts: the oracle runs them once
+    _, ref = om.forward(prompts[:4])
     for s in range(4):
-        _, ref = om.forward([[int(t)] for t in toks[:, s]])
+        _, ref = om.forward([[int(t)] for t in toks[:4, s]])
+    assert all(np.array_equal(toks[b], toks[b % 4]) for b in range(B))
+    lg = lg[:4]
     err = np.abs(lg.astype(np.float32) - ref.astype(np.float32))
     assert err.max() <= 4e-2, err.max()
 
