@@ -31,6 +31,20 @@ def test_library_exports_every_declared_symbol():
     assert lib.tm_kv_layer_size(1, 128, 64, 4) == 8704             # 70B / TP8 per rank
 
 
+def test_gemm_dispatch_table_import(tmp_path):
+    """tm_gemm_import (the reference's TM_GEMM_IMPORT): text lines `K N M shape splits`; lines that name a tiling the kernels
+    cannot run (unknown shape, 64-row shapes at M > 64, 128-row tiles at M <= 64, splits out of range) are ignored, a file
+    without a single valid line is an error -- host-side parsing, no GPU involved"""
+    lib = _ffi.load()
+    good = tmp_path / 'good.txt'
+    good.write_text('4096 4096 64 6 2\n14336 4096 64 3 4\n6144 8192 128 7 1\n4096 28672 64 0 1\n')
+    assert lib.tm_gemm_import(str(good).encode()) == 0
+    bad = tmp_path / 'bad.txt'
+    bad.write_text('4096 4096 64 4 2\n4096 4096 128 0 2\n4096 4096 64 12 1\n4096 4096 64 6 17\n4096 4096 300 6 1\n')
+    assert lib.tm_gemm_import(str(bad).encode()) == 1
+    assert lib.tm_gemm_import(str(tmp_path / 'missing.txt').encode()) == 1 and 'cannot read' in _ffi.last_error()
+
+
 def test_errors_are_status_codes_not_exceptions():
     lib = _ffi.load()
     rc = lib.tm_rmsnorm(None, None, None, 1e-5, 1, 8, None)
