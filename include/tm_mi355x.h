@@ -336,7 +336,9 @@ typedef struct tm_sampling {
     uint64_t seed;
 } tm_sampling;
 /* Static batch: sampling parameters of the NEXT tm_engine_prefill (host array [batch], copied); NULL / never called =
- * greedy arg-max.  Cleared by tm_engine_release.  TP > 1 supports greedy only in this round (TM_INVALID). */
+ * greedy arg-max.  Cleared by tm_engine_release.  TP > 1 (RCCL communicator): the vocabulary shards of the logits
+ * are all-gathered and every rank draws the same token from the full row (models/language_model.cc:304-333 gathers the
+ * logits as well); with the native P2P communicator alone sampling is TM_INVALID. */
 int tm_engine_set_sampling(tm_engine* e, const tm_sampling* host_params, int batch);
 /* Per-sequence logits processors (GenerationConfig: repetition_penalty, min_new_tokens, bad_token_ids,
  * stop_token_ids; applied in the reference's order, see tm_logits_process).  stop ids end a sequence of the

@@ -154,6 +154,18 @@ __global__ void pick_kernel(int* out_ids, const float* cand /*[tp][B][2]*/, int 
     out_ids[b] = bi;
 }
 
+// all-gathered vocabulary shards [tp][n][vl] -> full rows [n][tp * vl] (16-byte vectors; vl % 8 == 0)
+__global__ void gather_vocab_kernel(half_t* __restrict__ full, const half_t* __restrict__ shards, int n, int vl, int tp)
+{
+    const size_t nvec = (size_t)n * tp * (vl / 8);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (size_t)gridDim.x * blockDim.x) {
+        const int    v = (int)(i % (vl / 8));
+        const int    r = (int)((i / (vl / 8)) % tp);
+        const size_t b = i / ((size_t)(vl / 8) * tp);
+        *(u32x4*)(full + (b * tp + r) * vl + (size_t)v * 8) = *(const u32x4*)(shards + ((size_t)r * n + b) * vl + (size_t)v * 8);
+    }
+}
+
 __global__ void pack_candidates_kernel(float* cand, const int* ids, const half_t* vals, int batch)
 {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
@@ -293,6 +305,8 @@ struct tm_engine {
     int*      d_topk = nullptr;
     uint64_t* d_seed = nullptr;
     void*     d_sample_ws = nullptr;
+    half_t*   d_logits_gather = nullptr;  // tp > 1 + sampling: [tp][max_batch][vocab / tp] all-gathered shards ...
+    half_t*   d_logits_full   = nullptr;  // ... and the full rows [max_batch][vocab] every rank samples from
     void*     d_moe_ws    = nullptr;  // routing tables + expert activations of one forward (moe_workspace_bytes)
     std::vector<tm_sampling>       h_sampling;      // static batch: parameters of the next prefill
     std::map<int64_t, tm_sampling> cb_sampling;     // continuous batching: per request
@@ -719,12 +733,34 @@ static int forward(tm_engine* e, const int* d_ids, int M, int nseq, bool decode,
                                                            e->seen_words, e->d_lp_rep + slot, e->d_lp_ban + slot * kMaxBadIds,
                                                            e->d_lp_end + slot * kMaxEndIds, k_len, e->d_lp_minlen + slot, st)));
         }
-        if (!e->use_comm && e->sampling_on) {
+        if (e->sampling_on && (!e->use_comm || (e->comm && e->d_logits_full))) {
             // parameters are indexed by batch slot, the counter (context length) by the row of this forward
+            const half_t* lg = logits;
+            int           V  = e->vocab_local;
+            if (e->use_comm) {
+                // tp > 1: the vocabulary shards are all-gathered into full rows (the reference gathers the logits too,
+                // models/language_model.cc:304-333) and EVERY rank draws from the same distribution with the same Philox
+                // number -> the same token everywhere, no further exchange
+                const size_t cnt = (size_t)n * e->vocab_local;
+                if (e->comm_overlap && e->comm_stream) {
+                    TM_HIP_CHECK(hipEventRecord(e->ev_fork, st));
+                    TM_HIP_CHECK(hipStreamWaitEvent(e->comm_stream, e->ev_fork, 0));
+                    TM_NCCL_CHECK(ncclAllGather(logits, e->d_logits_gather, cnt, ncclHalf, e->comm, e->comm_stream));
+                    TM_HIP_CHECK(hipEventRecord(e->ev_join, e->comm_stream));
+                    TM_HIP_CHECK(hipStreamWaitEvent(st, e->ev_join, 0));
+                }
+                else {
+                    TM_NCCL_CHECK(ncclAllGather(logits, e->d_logits_gather, cnt, ncclHalf, e->comm, st));
+                }
+                V = e->vocab_local * e->cfg.tp;
+                gather_vocab_kernel<<<std::min<size_t>(1024, (cnt * e->cfg.tp / 8 + 255) / 256), 256, 0, st>>>(
+                    e->d_logits_full, e->d_logits_gather, n, e->vocab_local, e->cfg.tp);
+                TM_HIP_CHECK(hipGetLastError());
+                lg = e->d_logits_full;
+            }
             TM_PROF(P_SAMPLE, TM_TRY(launch_sample_uniform(e->d_u + slot, e->d_seed + slot, k_len, n, st)));
-            TM_PROF(P_SAMPLE, TM_TRY(launch_sample(ids, nullptr, logits, n, e->vocab_local, e->vocab_local, e->d_temp + slot,
-                                                   e->d_topk + slot, e->d_topp + slot, e->d_minp + slot, e->d_u + slot,
-                                                   e->d_sample_ws, st)));
+            TM_PROF(P_SAMPLE, TM_TRY(launch_sample(ids, nullptr, lg, n, V, V, e->d_temp + slot, e->d_topk + slot, e->d_topp + slot,
+                                                   e->d_minp + slot, e->d_u + slot, e->d_sample_ws, st)));
         }
         else if (!e->use_comm) {
             TM_PROF(P_SAMPLE, TM_TRY(launch_argmax(ids, nullptr, logits, n, e->vocab_local, e->vocab_local, 0, st)));
@@ -1411,6 +1447,10 @@ static int sampling_upload(tm_engine* e, const tm_sampling* p, int slot0, int n)
         TM_TRY(dmalloc(&e->d_seed, (size_t)B));
         TM_HIP_CHECK(hipMalloc(&e->d_sample_ws, sample_workspace_bytes(B)));
         TM_HIP_CHECK(hipMemsetAsync(e->d_sample_ws, 0, sample_workspace_bytes(B), e->stream));
+        if (e->use_comm) {
+            TM_TRY(dmalloc(&e->d_logits_gather, (size_t)B * e->vocab_local * e->cfg.tp));
+            TM_TRY(dmalloc(&e->d_logits_full, (size_t)B * e->vocab_local * e->cfg.tp));
+        }
         std::vector<float>    one(B, 1.f), zero(B, 0.f);
         std::vector<int>      k1(B, 1);
         std::vector<uint64_t> s0(B, 0);
@@ -2001,7 +2041,7 @@ int tm_engine_set_sampling(tm_engine* e, const tm_sampling* host_params, int bat
     if (!host_params) {
         return 0;
     }
-    TM_REQUIRE(!e->use_comm, "stochastic sampling with tp > 1 is not supported in this round (greedy only)");
+    TM_REQUIRE(!e->use_comm || e->comm, "stochastic sampling with tp > 1 gathers the logits over RCCL: tm_engine_comm_init first");
     TM_REQUIRE(batch >= 1 && batch <= e->cfg.max_batch_size, "1 <= batch <= max_batch_size");
     for (int i = 0; i < batch; ++i) {
         TM_REQUIRE(host_params[i].temperature > 0.f, "sampling: temperature must be > 0");
@@ -2056,7 +2096,7 @@ int tm_engine_submit_gen(tm_engine* e, const int* host_ids, int n, int max_new_t
         TM_TRY(logits_param_check(*logits_param));
     }
     if (sampling) {
-        TM_REQUIRE(!e->use_comm, "stochastic sampling with tp > 1 is not supported in this round (greedy only)");
+        TM_REQUIRE(!e->use_comm || e->comm, "stochastic sampling with tp > 1 gathers the logits over RCCL: tm_engine_comm_init first");
         TM_REQUIRE(sampling->temperature > 0.f, "sampling: temperature must be > 0");
     }
     {
@@ -2486,7 +2526,8 @@ int tm_engine_destroy(tm_engine* e)
         (void)hipGraphExecDestroy(e->graph_cb);
     }
     for (void* q : {(void*)e->d_active, (void*)e->d_pf_k_len, (void*)e->d_pf_cu_q, (void*)e->d_pf_block_ptrs, (void*)e->d_temp, (void*)e->d_topp, (void*)e->d_minp,
-                    (void*)e->d_u, (void*)e->d_topk, (void*)e->d_seed, e->d_sample_ws, (void*)e->d_seen, (void*)e->d_lp_rep,
+                    (void*)e->d_u, (void*)e->d_topk, (void*)e->d_seed, e->d_sample_ws, (void*)e->d_logits_gather, (void*)e->d_logits_full,
+                    (void*)e->d_seen, (void*)e->d_lp_rep,
                     (void*)e->d_lp_minlen, (void*)e->d_lp_ban, (void*)e->d_lp_end}) {
         if (q) {
             (void)hipFree(q);

@@ -486,6 +486,46 @@ def test_pipeline_continuous_generation(cuda):
     pipe.close()
 
 
+def test_engine_sampling_on_the_collective_path(cuda, monkeypatch):
+    """Stochastic sampling at tp > 1: the vocabulary shards of the logits are all-gathered (RCCL) into full rows and every
+    rank samples from them.  Driven on one GPU through a 1-rank communicator (TM_FORCE_COMM=1): same seeds -> the tokens of
+    the collective-free engine, static and continuous."""
+    cfg = o.ModelConfig(hidden=256, layers=2, q_heads=4, kv_heads=2, head_dim=128, inter=512, vocab=1024,
+                        kv_bits=8, rope=o.RopeParam(128, 500000.0, 'llama3', 8.0, 1.0, 4.0, 8192))
+    w = o.make_synthetic_weights(cfg, seed=23)
+    rng = np.random.default_rng(3)
+    prompts = [rng.integers(0, cfg.vocab, n).astype(np.int32) for n in (12, 40, 7)]
+    params = [(0.9, 30, 0.95, 0.0, 111), None, (1.4, 0, 0.8, 0.02, 222)]
+
+    def run(force):
+        if force:
+            monkeypatch.setenv('TM_FORCE_COMM', '1')
+        else:
+            monkeypatch.delenv('TM_FORCE_COMM', raising=False)
+        eng = Engine.from_model_config(cfg, max_batch_size=3, session_len=128, quant_policy=8)
+        if force:
+            eng.comm_init(Engine.comm_unique_id())
+        eng.load_weights(export_weights(cfg, w))
+        eng.start()
+        eng.set_sampling(params)
+        eng.prefill(prompts, max_new_tokens=6)
+        eng.decode(5)
+        toks = eng.fetch().copy()
+        eng.release()
+        ids = [eng.submit(p_, 6, -1, sp) for p_, sp in zip(prompts, params)]
+        while eng.step() != (0, 0):
+            pass
+        cont = [eng.poll(r)[1].copy() for r in ids]
+        eng.close()
+        return toks, cont
+
+    t0, c0 = run(False)
+    t1, c1 = run(True)
+    assert np.array_equal(t0, t1)
+    assert all(np.array_equal(a, b) for a, b in zip(c0, c1))
+    assert not np.array_equal(t0[0], t0[1])
+
+
 def test_engine_sampling_static_and_continuous(cuda):
     """Stochastic sampling inside the engine: every generated token must be the oracle's draw (sample_filter +
     sample_draw with the Philox number of (seed, context length)) from the engine's own logits of that step; the same
