@@ -139,3 +139,46 @@ def test_tp2_moe_fp8_block_matches_unsharded():
     assert tuple(ret['w13_shape']) == (256, 256)                    # [hidden, 2 * inter / tp]
     got = ret['out'].astype(np.float32)
     assert np.all(np.abs(got - ref) <= 1e-2 * np.abs(ref) + 2e-3), np.abs(got - ref).max()
+
+
+def _sampling_worker(rank, world, port, logits, params, ctx, ret):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    B, V = logits.shape
+    vl = V // world
+    shard = torch.from_numpy(np.ascontiguousarray(logits[:, rank * vl:(rank + 1) * vl]).view(np.uint8))      # this rank's lm_head output (bytes)
+    gathered = [torch.empty_like(shard) for _ in range(world)]
+    dist.all_gather(gathered, shard)                                   # engine: ncclAllGather(ncclHalf) -> [tp][B][vl]
+    stacked = np.stack([g.numpy().view(f16).reshape(B, vl) for g in gathered])        # [tp][B][vl]
+    full = np.ascontiguousarray(stacked.transpose(1, 0, 2)).reshape(B, V)      # gather_vocab_kernel: [B][tp * vl]
+    toks = []
+    for b, p in enumerate(params):
+        ids, pr = o.sample_filter(full[b], p[0], p[1], p[2], p[3])
+        toks.append(o.sample_draw(ids, pr, o.philox_uniform(p[4], ctx[b])))
+    ret[rank] = (toks, full)
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_tp2_sampling_gathers_logits_and_draws_identically():
+    """Stochastic sampling at tp = 2 (engine.hip head(): all-gather of the vocabulary shards, gather_vocab_kernel, the same
+    Philox number on every rank): both ranks rebuild exactly the unsharded logits row and draw exactly the token the
+    unsharded oracle draws -- no exchange after the gather."""
+    rng = np.random.default_rng(17)
+    B, V = 3, 512
+    logits = rng.standard_normal((B, V)).astype(f16)
+    params = [(0.9, 30, 0.95, 0.0, 111), (1.0, 1, 1.0, 0.0, 5), (1.4, 0, 0.8, 0.02, 222)]
+    ctx = [13, 40, 8]
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_sampling_worker, args=(2, _free_port(), logits, params, ctx, ret), nprocs=2, join=True)
+    want = []
+    for b, p in enumerate(params):
+        ids, pr = o.sample_filter(logits[b], p[0], p[1], p[2], p[3])
+        want.append(o.sample_draw(ids, pr, o.philox_uniform(p[4], ctx[b])))
+    for rank in (0, 1):
+        toks, full = ret[rank]
+        assert np.array_equal(full.view(np.uint16), logits.view(np.uint16))
+        assert toks == want
+    assert want[1] == int(np.argmax(logits[1].astype(np.float32)))      # top_k = 1 row = greedy
