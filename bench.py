@@ -208,7 +208,11 @@ def main():
     eng.start()
     tuned = bool(args.tune) and world == 1 and emu <= 1 and B <= 256 and not child
     if tuned:                           # start-up work like the reference's TM_GEMM_TUNE warm-up: not in any timed region
-        eng.tune_gemm(B)
+        try:
+            eng.tune_gemm(B)
+        except Exception as exc:        # noqa: BLE001 -- the heuristics are the measured winners on these shapes anyway
+            print(f'[bench] GEMM tuning skipped: {exc}', file=sys.stderr)
+            tuned = False
 
     gen = torch.Generator().manual_seed(0)
     prompts = torch.randint(0, model['vocab'], (B, S), generator=gen, dtype=torch.int32).numpy()
