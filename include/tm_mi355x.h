@@ -231,6 +231,11 @@ int tm_p2p_allgather(void* const* segs, int tp, int me, void* state, int rows, i
 /* debug / measurement: device buffer of [workgroups][4] uint64 that receives s_memrealtime stamps (100 MHz:
  * kernel entry, loop entry, loop exit, exit) of every GEMM workgroup launched afterwards; NULL switches it off. */
 int tm_debug_set_gemm_trace(void* dev_buf);
+/* Host-only: the (workgroup shape, split-K) the decode GEMM dispatch picks for a W4A16 linear of K x N at M rows --
+ * use_table != 0: the measured table first (tm_engine_tune_gemm / tm_gemm_import), then the heuristic; 0: heuristic only.
+ * Shapes: 0..3 decode tiles (M <= 64), 4 / 5 the 128-row tiles (M > 64), 6..9 shapes 3, 0, 2, 1 on 32-row blocks, 10 / 11
+ * the two-fragment tile (gemm_decode.hip). */
+int tm_debug_pick_tiling(int K, int N, int M, int use_table, int* shape, int* splits);
 /* Operator-level calls that follow treat tm_kv_cache::block_ptrs as a rectangular table: sequence b starts at b * stride
  * (cu_block_nums must say the same); 0 = ragged (default).  The engine's own table is rectangular and always takes this
  * path: the decode kernel then needs no dependent pointer loads (test hook for that path). */

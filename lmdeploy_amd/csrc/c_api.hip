@@ -666,6 +666,17 @@ int tm_p2p_allgather(void* const* segs, int tp, int me, void* state, int rows, i
     return launch_p2p_allgather(data, flags, tp, me, (uint32_t*)state, (size_t)rows * H, src, dst, words, (hipStream_t)st);
 }
 
+int tm_debug_pick_tiling(int K, int N, int M, int use_table, int* shape, int* splits)
+{
+    TM_REQUIRE(shape && splits && K > 0 && N > 0 && M > 0, "arguments");
+    TM_REQUIRE(K % 128 == 0 && N % 32 == 0, "the decode kernels take K % 128 == 0, N % 32 == 0");
+    LinearWeight w{};
+    w.K = K;
+    w.N = N;
+    dec32_pick_ex(w, M, shape, splits, use_table != 0);
+    return 0;
+}
+
 int tm_debug_set_block_stride(int stride)
 {
     TM_REQUIRE(stride >= 0, "stride >= 0");

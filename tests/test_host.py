@@ -31,6 +31,37 @@ def test_library_exports_every_declared_symbol():
     assert lib.tm_kv_layer_size(1, 128, 64, 4) == 8704             # 70B / TP8 per rank
 
 
+def _pick(lib, K, N, M, table=0):
+    sh, sp = _ffi.C.c_int(-1), _ffi.C.c_int(-1)
+    _ffi.check(lib.tm_debug_pick_tiling(K, N, M, table, _ffi.C.byref(sh), _ffi.C.byref(sp)))
+    return sh.value, sp.value
+
+
+def test_decode_gemm_heuristic_equals_the_measured_winners(tmp_path):
+    """dec32_pick (host code): on the Llama-3-8B decode shapes the heuristic picks what the start-up tuner measured as
+    fastest on MI355X (profiles/r02_gemm_tune_measurements.txt); wide / tiny linears and other batch sizes keep the older
+    rules; an imported table entry wins over the heuristic for exactly its (K, N, M)."""
+    lib = _ffi.load()
+    assert _pick(lib, 4096, 6144, 64) == (6, 1)       # w_qkv: 32-row x 64-column tiles over the whole k range, no slabs
+    assert _pick(lib, 4096, 4096, 64) == (6, 2)       # wo
+    assert _pick(lib, 14336, 4096, 64) == (3, 4)      # w2: 64-column tiles x 4 slabs
+    assert _pick(lib, 4096, 28672, 64) == (0, 1)      # w1w3: 128-column tiles, 224 workgroups
+    assert _pick(lib, 4096, 6144, 33) == (6, 1) and _pick(lib, 4096, 6144, 32)[0] == 0     # one row block: the older rule
+    assert _pick(lib, 8192, 1280, 64)[0] == 0         # a 70B / TP8 rank's narrow projection
+    assert _pick(lib, 4096, 6144, 128)[0] == 4 and _pick(lib, 4096, 6144, 8192)[0] == 5    # 128-row tiles beyond 64 rows
+    for K, N in ((4096, 3072), (2048, 4096), (7168, 4096), (6144, 8192), (16384, 6144)):   # tp shards / 20B shapes: valid slicing
+        sh, sp = _pick(lib, K, N, 64)
+        S = 4
+        per = -(-(K // 128) // sp)
+        per = -(-per // S) * S
+        assert sh in (3, 6) and 1 <= sp <= 16 and -(-(K // 128) // per) == sp, (K, N, sh, sp)
+    f = tmp_path / 't.txt'
+    f.write_text('5120 5120 64 2 3\n')
+    assert lib.tm_gemm_import(str(f).encode()) == 0
+    assert _pick(lib, 5120, 5120, 64, table=1) == (2, 3) and _pick(lib, 5120, 5120, 64, table=0) != (2, 3)
+    assert _pick(lib, 5120, 5120, 48, table=1) == _pick(lib, 5120, 5120, 48, table=0)
+
+
 def test_gemm_dispatch_table_import(tmp_path):
     """tm_gemm_import (the reference's TM_GEMM_IMPORT): text lines `K N M shape splits`; lines that name a tiling the kernels
     cannot run (unknown shape, 64-row shapes at M > 64, 128-row tiles at M <= 64, splits out of range) are ignored, a file
