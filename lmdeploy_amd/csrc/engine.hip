@@ -1578,6 +1578,18 @@ struct MixedStep {
 static int prefill_slots(tm_engine* e, const int* const* seq_ids, const int* host_lens, int batch, int slot0, float* ttft_ms,
                          const MixedStep* mix = nullptr)
 {
+    // A mixed forward only when the WHOLE admission fits one iteration next to the decode rows: the decode head of a merged
+    // iteration writes the next-id entry of every batch slot, so first tokens that an EARLIER iteration of the same admission
+    // left in d_next_ids (sequences still parked) would be overwritten.  Larger admissions and chunked prompts prefill alone.
+    if (mix) {
+        int64_t total = 0;
+        for (int i = 0; i < batch; ++i) {
+            total += host_lens[i];
+        }
+        if (total > (int64_t)e->max_tokens - mix->rows) {
+            mix = nullptr;
+        }
+    }
     const int  budget  = e->max_tokens - (mix ? mix->rows : 0);
     const auto t_start = std::chrono::steady_clock::now();
     // Because the batch tables (block_ptrs, cu_block_nums) are indexed by the batch slot, every prefill

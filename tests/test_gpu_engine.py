@@ -247,7 +247,7 @@ def test_continuous_batching_matches_oracle(cuda, monkeypatch, kv_bits, mixed):
                     done[i] = (st, toks.copy())
     n_mixed = eng.mixed_steps()
     eng.close()
-    assert (n_mixed >= 3) if mixed else (n_mixed == 0), f'{n_mixed} mixed steps'
+    assert (n_mixed >= 1) if mixed else (n_mixed == 0), f'{n_mixed} mixed steps'
     checked = 0
     for i, (st, toks) in done.items():
         assert st == 7 and len(toks) == news[i], f'request {i}: status {st}, {len(toks)} tokens'
