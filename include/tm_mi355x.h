@@ -169,6 +169,15 @@ int tm_linear_prepare(tm_linear* w, const void* weight, const void* scales, cons
 size_t tm_linear_workspace(const tm_linear* w, int M);
 int    tm_linear_forward(const tm_linear* w, const void* x, int ldx, void* y, int ldy, int M, int gated_silu,
                          int nt, int splits, int waves, void* workspace, tm_stream_t st);
+/* Row-parallel linear closed by residual + RMSNorm -- wo / w2 of a decoder layer at the decode batch: LlamaLinear::Forward
+ * followed by invokeResidualBiasRMSNorm (src/turbomind/models/llama/unified_decoder.cc:149,226; kernels/norm/rms_norm.cu:286-362):
+ *   resid += fp16(x . W);  y = RMSNorm(resid) * norm_w.
+ * fused != 0: split-K reduce + residual + norm run INSIDE the GEMM launch (its last workgroups consume the slabs; needs
+ * M <= 64, u4 weights, N % 32 == 0, N <= 8192 and `sync` = 4 zeroed device words, left zero by the call; sync[2] != 0 afterwards
+ * means a hand-off wait gave up).  fused == 0: the GEMM, then the reduce-norm kernel -- the same bits.
+ * shape: decode tile 0..3 / 6..9, -1 = dispatch; splits: 0 = dispatch.  workspace >= tm_linear_workspace(w, M) + M * N * 2 bytes. */
+int    tm_linear_residual_norm(const tm_linear* w, const void* x, int ldx, void* y, void* resid, const void* norm_w, float eps, int M,
+                               int shape, int splits, int fused, void* workspace, void* sync, tm_stream_t st);
 /* FP8 x FP8 linear on the fp8 matrix cores -- the reference's path for e4m3 weights on fp8 tensor cores:
  * LlamaLinear::Forward quantises the activations per row and 128-channel group (QuantizeSymm,
  * src/turbomind/kernels/quantization.cu:28-125, called at models/llama/LlamaLinear.cu:67-93) and runs the fp8 GEMM with
@@ -233,9 +242,13 @@ int tm_p2p_allgather(void* const* segs, int tp, int me, void* state, int rows, i
 int tm_debug_set_gemm_trace(void* dev_buf);
 /* Host-only: the (workgroup shape, split-K) the decode GEMM dispatch picks for a W4A16 linear of K x N at M rows --
  * use_table != 0: the measured table first (tm_engine_tune_gemm / tm_gemm_import), then the heuristic; 0: heuristic only.
- * Shapes: 0..3 decode tiles (M <= 64), 4 / 5 the 128-row tiles (M > 64), 6..9 shapes 3, 0, 2, 1 on 32-row blocks, 10 / 11
- * the two-fragment tile (gemm_decode.hip). */
+ * Shapes: 0..3 decode tiles (M <= 64), 4 / 5 the 128-row tiles (M > 64), 6..9 shapes 3, 0, 2, 1 on 32-row blocks
+ * (gemm_decode.hip). */
 int tm_debug_pick_tiling(int K, int N, int M, int use_table, int* shape, int* splits);
+/* Host-only: every (shape, splits) pair the start-up tuner (tm_engine_tune_gemm; gemm::Gemm::Run's dispatch candidates,
+ * src/turbomind/kernels/gemm/gemm.cu:92-224) may pick for a K x N linear at M rows; *count = how many exist (<= 128), the first
+ * min(cap, *count) are written.  The full-size parity tests sweep exactly this list. */
+int tm_debug_tiling_candidates(int K, int N, int M, int* shapes, int* splits, int cap, int* count);
 /* Operator-level calls that follow treat tm_kv_cache::block_ptrs as a rectangular table: sequence b starts at b * stride
  * (cu_block_nums must say the same); 0 = ragged (default).  The engine's own table is rectangular and always takes this
  * path: the decode kernel then needs no dependent pointer loads (test hook for that path). */

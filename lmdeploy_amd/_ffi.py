@@ -106,6 +106,8 @@ _SIGNATURES = {
     'tm_linear_workspace': (c_size_t, [c_void_p, c_int]),
     'tm_linear_forward': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
                                   c_void_p, c_void_p]),
+    'tm_linear_residual_norm': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_float, c_int, c_int, c_int, c_int,
+                                        c_void_p, c_void_p, c_void_p]),
     'tm_linear_destroy': (c_int, [c_void_p]),
     'tm_linear_prepare_fp8_gated': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
     'tm_linear_fp8_workspace': (c_size_t, [c_void_p, c_int]),
@@ -118,6 +120,7 @@ _SIGNATURES = {
     'tm_gemm_import': (c_int, [c_char_p]),
     'tm_debug_set_block_stride': (c_int, [c_int]),
     'tm_debug_pick_tiling': (c_int, [c_int, c_int, c_int, c_int, POINTER(c_int), POINTER(c_int)]),
+    'tm_debug_tiling_candidates': (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_int, POINTER(c_int)]),
     'tm_engine_comm_native_export': (c_int, [c_void_p, c_int, c_void_p]),
     'tm_engine_comm_native_import': (c_int, [c_void_p, c_void_p, c_int]),
     'tm_p2p_segment_create': (c_int, [c_size_t, POINTER(c_void_p), c_void_p]),

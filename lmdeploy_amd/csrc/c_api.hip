@@ -299,9 +299,8 @@ int tm_linear_forward(const tm_linear* w, const void* x, int ldx, void* y, int l
         // 0x200 + shape: the decode kernel (gemm_decode.hip) with an explicit workgroup shape; M <= 64, u4, N % 32 == 0
         TM_REQUIRE(dec32_supported(w->w, M), "decode kernel: u4 weights, N % 32 == 0");
         cfg.d32_shape = waves & 0xff;
-        TM_REQUIRE((cfg.d32_shape >= 6 && cfg.d32_shape <= 11 && (cfg.d32_shape != 10 || M <= 64))
-                       || (cfg.d32_shape <= 5 && (cfg.d32_shape >= 4) == (M > 64)),
-                   "decode kernel shape 0..3, 10 (M <= 64), 4 / 5 (M > 64) or 6..9, 11 (32-row blocks, any M)");
+        TM_REQUIRE((cfg.d32_shape >= 6 && cfg.d32_shape <= 9) || (cfg.d32_shape <= 5 && (cfg.d32_shape >= 4) == (M > 64)),
+                   "decode kernel shape 0..3 (M <= 64), 4 / 5 (M > 64) or 6..9 (32-row blocks, any M)");
         waves = 0;
     }
     if (waves > 0) {
@@ -317,6 +316,34 @@ int tm_linear_forward(const tm_linear* w, const void* x, int ldx, void* y, int l
     }
     return launch_linear(w->w, (const half_t*)x, ldx, (half_t*)y, ldy, M, gated_silu != 0, cfg, (float*)workspace, false,
                          nullptr, (hipStream_t)st);
+}
+
+int tm_linear_residual_norm(const tm_linear* w, const void* x, int ldx, void* y, void* resid, const void* norm_w, float eps, int M,
+                            int shape, int splits, int fused, void* workspace, void* sync, tm_stream_t st)
+{
+    TM_REQUIRE(w && x && y && resid && norm_w && workspace, "null pointer");
+    const int N = w->w.N;
+    GemmConfig cfg = gemm_pick_config(w->w, M);
+    if (shape >= 0) {
+        TM_REQUIRE(dec32_supported(w->w, M) && (shape <= 3 || (shape >= 6 && shape <= 9)) && M <= 64, "decode tile 0..3 / 6..9, M <= 64");
+        cfg.d32_shape = shape;
+    }
+    if (splits > 0) {
+        cfg.splits = splits;
+    }
+    TM_REQUIRE(cfg.splits <= 16, "splits <= 16");
+    if (fused) {
+        TM_REQUIRE(sync != nullptr && cfg.d32_shape >= 0 && dec32_tail_supported(w->w, M),
+                   "fused residual-norm: u4 decode kernel, M <= 64, N % 32 == 0, 4 zeroed sync words");
+        NormTail tail{(half_t*)y, (half_t*)resid, (const half_t*)norm_w, eps, (unsigned*)sync};
+        return launch_linear(w->w, (const half_t*)x, ldx, nullptr, N, M, false, cfg, (float*)workspace, true, nullptr, (hipStream_t)st, &tail);
+    }
+    // unfused: slabs (or, with one slice, the fp16 product parked at the end of the workspace) + the reduce-norm kernel
+    int     slabs = 1;
+    half_t* tmp   = (half_t*)((char*)workspace + gemm_workspace_bytes(M, N, 16));
+    TM_TRY_RC(launch_linear(w->w, (const half_t*)x, ldx, tmp, N, M, false, cfg, (float*)workspace, cfg.splits > 1, &slabs, (hipStream_t)st));
+    return launch_residual_rmsnorm((half_t*)y, (half_t*)resid, slabs > 1 ? nullptr : tmp, slabs > 1 ? (const float*)workspace : nullptr,
+                                   slabs, nullptr, (const half_t*)norm_w, eps, M, N, (hipStream_t)st);
 }
 
 int tm_linear_prepare_fp8_gated(tm_linear* w, const void* weight, const void* scales, tm_stream_t st)
@@ -674,6 +701,23 @@ int tm_debug_pick_tiling(int K, int N, int M, int use_table, int* shape, int* sp
     w.K = K;
     w.N = N;
     dec32_pick_ex(w, M, shape, splits, use_table != 0);
+    return 0;
+}
+
+int tm_debug_tiling_candidates(int K, int N, int M, int* shapes, int* splits, int cap, int* count)
+{
+    TM_REQUIRE(shapes && splits && count && cap >= 0 && K > 0 && N > 0 && M > 0, "arguments");
+    TM_REQUIRE(K % 128 == 0 && N % 32 == 0, "the decode kernels take K % 128 == 0, N % 32 == 0");
+    LinearWeight w{};
+    w.K = K;
+    w.N = N;
+    int       cand[128][2];
+    const int n = dec32_candidates(w, M, cand, 128);
+    for (int i = 0; i < n && i < cap; ++i) {
+        shapes[i] = cand[i][0];
+        splits[i] = cand[i][1];
+    }
+    *count = n;
     return 0;
 }
 

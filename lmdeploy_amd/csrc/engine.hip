@@ -222,7 +222,6 @@ struct tm_engine {
     int          p2p_rows = 0;
     bool         p2p_ready = false;
     bool         comm_overlap = false;   // TM_COMM_STREAM=1: collectives on a side stream (fork / join around each)
-    bool         comm_prefetch = false;  // TM_COMM_PREFETCH=1: prefetch the next linear's weights under the collective
     bool         graph_comm_failed = false;  // capturing the RCCL calls failed once: stay eager
     bool         use_comm = false;  // collectives on the data path: tp > 1 (or TM_FORCE_COMM=1: single-rank communicator,
                                     // exercises the RCCL code path on a 1-GPU box)
@@ -251,6 +250,14 @@ struct tm_engine {
     half_t* d_last   = nullptr;
     float*  d_gemm_ws = nullptr;
     size_t  gemm_ws_bytes = 0;
+    // TM_GEMM_TAIL=1: wo / w2 of a decode step close with the in-launch residual-norm consumer (gemm_decode.hip).  Measured on
+    // MI355X (tools/trace_tail.py, profiles/r03_gemm_tail_trace.txt): correct and bit-identical, but SLOWER than the reduce-norm
+    // kernel it replaces -- wo 13.6 vs 10.8 us, w2 20.3 vs 18.5 us per (GEMM + norm) period, 3.39 vs 3.27 ms per step: the
+    // last workgroup's store drain + ticket (3.1 us) and the consumer's slab round trip (2.7 us) cost more than two kernel
+    // boundaries (1.2 us each here) plus a 2 us kernel.  Default off.
+    bool      gemm_tail = false;
+    unsigned  h_marks[2] = {0, 0};    // host copies of the device give-up marks (device_marks_fetch)
+    unsigned* d_tail_sync = nullptr;  // 4 words: hand-off state of the in-launch residual-norm consumer (gemm_decode.hip), zero between launches
     float*  d_attn_ws = nullptr;
     half_t *d_kflat = nullptr, *d_vflat = nullptr;
     int     kflat_stride = 0;
@@ -454,39 +461,9 @@ static KvCacheView cache_view(const tm_engine* e, int layer)
     return v;
 }
 
-// Touch the weights a following linear will stream (decode layout when M <= 64) so that they are on their way into the
-// 256 MB Infinity Cache / L2 while the collective is in flight; results are discarded.
-__global__ __launch_bounds__(256) void weight_prefetch_kernel(const u32x4* __restrict__ p, size_t n16)
-{
-    u32x4 a = {0u, 0u, 0u, 0u};
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) {
-        const u32x4 v = __builtin_nontemporal_load(p + i);
-        a ^= v;
-    }
-    asm volatile("" ::"v"(a));
-}
-
-static int launch_weight_prefetch(const LinearWeight* w, int M, hipStream_t st)
-{
-    if (!w) {
-        return 0;
-    }
-    const void* p     = (M <= 64 && w->packed32) ? w->packed32 : w->packed;
-    size_t      bytes = (M <= 64 && w->packed32) ? w->packed32_bytes : w->packed_bytes;
-    bytes             = std::min(bytes, (size_t)64 << 20);
-    if (!p || bytes < 16) {
-        return 0;
-    }
-    const size_t n16 = bytes / 16;
-    const int    grid = (int)std::min<size_t>((n16 + 255) / 256, 512);
-    weight_prefetch_kernel<<<grid, 256, 0, st>>>((const u32x4*)p, n16);
-    TM_HIP_CHECK(hipGetLastError());
-    return 0;
-}
-
 // fp16 sum of the row-parallel partial outputs over the TP group (comm/nccl/nccl.cu:356-398 calls ncclAllReduce on the
-// compute stream; here it runs on the side stream, the engine stream meanwhile prefetches `next`'s weights)
-static int allreduce_hidden(tm_engine* e, half_t* buf, int M, const LinearWeight* next = nullptr)
+// compute stream; TM_COMM_STREAM=1: on a side stream between a fork / join pair)
+static int allreduce_hidden(tm_engine* e, half_t* buf, int M)
 {
     if (!e->use_comm) {
         return 0;
@@ -500,9 +477,6 @@ static int allreduce_hidden(tm_engine* e, half_t* buf, int M, const LinearWeight
     TM_HIP_CHECK(hipStreamWaitEvent(e->comm_stream, e->ev_fork, 0));
     TM_NCCL_CHECK(ncclAllReduce(buf, buf, (size_t)M * e->hidden, ncclHalf, ncclSum, e->comm, e->comm_stream));
     TM_HIP_CHECK(hipEventRecord(e->ev_join, e->comm_stream));
-    if (e->comm_prefetch) {
-        TM_TRY(launch_weight_prefetch(next, M, e->stream));
-    }
     TM_HIP_CHECK(hipStreamWaitEvent(e->stream, e->ev_join, 0));
     return 0;
 }
@@ -544,7 +518,7 @@ static void p2p_tables(tm_engine* e, half_t** data, uint32_t** flags)
 
 // d_x = RMSNorm(d_resid += sum over ranks of d_tmp): one fused P2P launch per <= p2p_rows rows on the native communicator
 // (any M when there is no RCCL communicator to fall back to), else RCCL all-reduce + the residual-norm kernel
-static int reduce_residual_norm(tm_engine* e, int M, const half_t* norm_w, const LinearWeight* next)
+static int reduce_residual_norm(tm_engine* e, int M, const half_t* norm_w)
 {
     if (e->p2p_ready && (M <= e->p2p_rows || !e->comm)) {
         half_t*   data[8];
@@ -560,7 +534,7 @@ static int reduce_residual_norm(tm_engine* e, int M, const half_t* norm_w, const
         }
         return 0;
     }
-    TM_PROF(P_ALLREDUCE, TM_TRY(allreduce_hidden(e, e->d_tmp, M, next)));
+    TM_PROF(P_ALLREDUCE, TM_TRY(allreduce_hidden(e, e->d_tmp, M)));
     TM_PROF(P_RES_NORM, TM_TRY(launch_residual_rmsnorm(e->d_x, e->d_resid, e->d_tmp, nullptr, 0, nullptr, norm_w,
                                                        e->cfg.model.rms_eps, M, e->hidden, e->stream)));
     return 0;
@@ -568,13 +542,21 @@ static int reduce_residual_norm(tm_engine* e, int M, const half_t* norm_w, const
 
 // row-parallel linear followed by (all-reduce +) residual + RMSNorm
 static int linear_residual_norm(tm_engine* e, LinearSlots& l, const half_t* x, int ldx, int M, const half_t* norm_w,
-                                int gemm_cat, const LinearWeight* next = nullptr)
+                                int gemm_cat)
 {
     GemmConfig cfg = gemm_pick_config(l.w, M);
     const bool can_defer = !e->use_comm && cfg.splits > 1
                            && gemm_workspace_bytes(M, l.w.N, cfg.splits) <= e->gemm_ws_bytes;
     if (gemm_workspace_bytes(M, l.w.N, cfg.splits) > e->gemm_ws_bytes) {
         cfg.splits = 1;
+    }
+    // decode batch on one GPU: the split-K reduce + residual + RMSNorm run inside the GEMM launch (its last workgroups consume
+    // the slabs) -- one launch instead of two, no dirty-slab write-back in front of a kernel boundary
+    if (e->gemm_tail && !e->use_comm && cfg.d32_shape >= 0 && l.w.N == e->hidden && dec32_tail_supported(l.w, M)
+        && gemm_workspace_bytes(M, l.w.N, std::max(cfg.splits, 2)) <= e->gemm_ws_bytes) {
+        NormTail tail{e->d_x, e->d_resid, norm_w, e->cfg.model.rms_eps, e->d_tail_sync};
+        TM_PROF(gemm_cat, TM_TRY(launch_linear(l.w, x, ldx, nullptr, e->hidden, M, false, cfg, e->d_gemm_ws, true, nullptr, e->stream, &tail)));
+        return 0;
     }
     int slabs = 1;
     TM_PROF(gemm_cat, TM_TRY(launch_linear(l.w, x, ldx, e->d_tmp, e->hidden, M, false, cfg, e->d_gemm_ws, can_defer, &slabs,
@@ -585,7 +567,7 @@ static int linear_residual_norm(tm_engine* e, LinearSlots& l, const half_t* x, i
         return 0;
     }
     TM_REQUIRE(!can_defer || slabs == 1, "internal: deferred reduce without slabs");
-    return reduce_residual_norm(e, M, norm_w, next);
+    return reduce_residual_norm(e, M, norm_w);
 }
 
 static int linear_plain(tm_engine* e, LinearSlots& l, const half_t* x, int ldx, half_t* y, int ldy, int M, bool gated)
@@ -704,18 +686,17 @@ static int forward(tm_engine* e, const int* d_ids, int M, int nseq, bool decode,
             p.scale_log2 = scale_log2;
             TM_PROF(P_ATTN, TM_TRY(launch_prefill_attention(p, st)));
         }
-        TM_TRY(linear_residual_norm(e, L.wo, e->d_attn, e->q_heads * e->D, M, L.ffn_norm, P_GEMM_O, L.is_moe ? nullptr : &L.w13.w));
-        const half_t*       next_norm = li + 1 < m.layers ? e->layers[li + 1].attn_norm : e->final_norm;
-        const LinearWeight* next_lin  = li + 1 < m.layers ? &e->layers[li + 1].qkv.w : &e->output.w;
+        TM_TRY(linear_residual_norm(e, L.wo, e->d_attn, e->q_heads * e->D, M, L.ffn_norm, P_GEMM_O));
+        const half_t* next_norm = li + 1 < m.layers ? e->layers[li + 1].attn_norm : e->final_norm;
         if (L.is_moe) {
             // router + grouped expert FFNs + combine -> d_tmp, then (all-reduce +) residual + RMSNorm as for the dense FFN
             TM_PROF(P_GEMM_GATE_UP, TM_TRY(moe_forward(L.moe, e->d_tmp, e->hidden, e->d_x, e->hidden, M, e->d_moe_ws, nullptr,
                                                        nullptr, st)));
-            TM_TRY(reduce_residual_norm(e, M, next_norm, next_lin));
+            TM_TRY(reduce_residual_norm(e, M, next_norm));
             continue;
         }
         TM_PROF(P_GEMM_GATE_UP, TM_TRY(linear_plain(e, L.w13, e->d_x, e->hidden, e->d_act, e->inter, M, true)));
-        TM_TRY(linear_residual_norm(e, L.w2, e->d_act, e->inter, M, next_norm, P_GEMM_DOWN, next_lin));
+        TM_TRY(linear_residual_norm(e, L.w2, e->d_act, e->inter, M, next_norm, P_GEMM_DOWN));
     }
     // last-token hidden states -> logits -> next ids, for `n` sequences whose logits / next ids land in the batch slots
     // [slot, slot + n): hx = their hidden rows, ids / cu_q (nullptr: one token per sequence) / ntok = the tokens this forward
@@ -800,6 +781,45 @@ static int forward(tm_engine* e, const int* d_ids, int M, int nseq, bool decode,
     }
     TM_TRY(launch_gather_rows(e->d_last, e->d_x, e->d_rows, nseq, e->hidden, st));
     return head(e->d_last, nseq, slot0, d_ids + nd, e->d_cu_q, M - nd, e->d_k_len);
+}
+
+// Device-side give-up marks -- bounded waits that expired: the in-launch residual-norm consumer of the decode GEMMs
+// (d_tail_sync[2]) and the native P2P communicator (p2p_state[3] = the call number a peer missed; comm_p2p.hip carries on with
+// wrong numbers instead of hanging).  Read at the host's synchronisation points: what ran before them is then reported as
+// TM_FAIL instead of being returned as tokens.  `async`: enqueue the two copies on the engine stream (the caller syncs).
+static int device_marks_fetch(tm_engine* e, bool async)
+{
+    if (e->d_tail_sync) {
+        if (async) {
+            TM_HIP_CHECK(hipMemcpyAsync(&e->h_marks[0], e->d_tail_sync + 2, 4, hipMemcpyDeviceToHost, e->stream));
+        }
+        else {
+            TM_HIP_CHECK(hipMemcpy(&e->h_marks[0], e->d_tail_sync + 2, 4, hipMemcpyDeviceToHost));
+        }
+    }
+    if (e->p2p_state) {
+        if (async) {
+            TM_HIP_CHECK(hipMemcpyAsync(&e->h_marks[1], e->p2p_state + 3, 4, hipMemcpyDeviceToHost, e->stream));
+        }
+        else {
+            TM_HIP_CHECK(hipMemcpy(&e->h_marks[1], e->p2p_state + 3, 4, hipMemcpyDeviceToHost));
+        }
+    }
+    return 0;
+}
+
+static int device_marks_check(tm_engine* e)
+{
+    if (e->h_marks[0]) {
+        set_last_error("decode GEMM: the in-launch residual-norm hand-off gave up waiting (results are invalid)");
+        return TM_FAIL;
+    }
+    if (e->h_marks[1]) {
+        set_last_error("native communicator: a peer did not arrive within the wait bound (call " + std::to_string(e->h_marks[1])
+                       + "); results are invalid");
+        return TM_FAIL;
+    }
+    return 0;
 }
 
 // next ids become the current ids and are appended to generated[b][step]
@@ -919,13 +939,11 @@ int tm_engine_comm_init(tm_engine* e, const void* host_id128)
     TM_HIP_CHECK(hipSetDevice(e->cfg.device));
     TM_NCCL_CHECK(ncclCommInitRank(&e->comm, e->cfg.tp, id, e->cfg.rank));
     const char* cs   = getenv("TM_COMM_STREAM");
-    const char* cp   = getenv("TM_COMM_PREFETCH");
     // Measured on MI355X (per-rank emulation of Llama-3-70B TP = 8, 160 collectives per step, profiles/r02_comm_stream_arms.txt):
     // engine stream 6.81 ms/step; side stream without the prefetch 6.81 ms (a fork/join inside a hipGraph is free, but costs
     // ~30 us per collective on eager launches); side stream + weight prefetch 7.80 ms (the prefetch kernel costs 6 us and the
     // next GEMM gains nothing from L2 / Infinity-Cache resident weights).  Default: engine stream; the arms stay reachable.
     e->comm_overlap  = cs && atoi(cs);
-    e->comm_prefetch = cp && atoi(cp);
     if (e->comm_overlap && !e->comm_stream) {
         TM_HIP_CHECK(hipStreamCreateWithFlags(&e->comm_stream, hipStreamNonBlocking));
         TM_HIP_CHECK(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
@@ -1228,9 +1246,16 @@ static int tune_decode_gemms(tm_engine* e, int M, bool verbose)
                 continue;
             }
             const bool norm_consumer = (r.which == 1 || r.which == 3) && !e->use_comm;
+            const bool tail_consumer = e->gemm_tail && norm_consumer && w0.N == e->hidden && dec32_tail_supported(w0, M)
+                                       && gemm_workspace_bytes(M, w0.N, std::max(cfg.splits, 2)) <= e->gemm_ws_bytes;
             auto chain = [&]() -> int {
                 for (const LinearWeight* w : ws) {
                     int slabs = 1;
+                    if (tail_consumer) {  // as linear_residual_norm runs it: the consumer inside the launch
+                        NormTail tail{e->d_last, e->d_resid, e->final_norm, e->cfg.model.rms_eps, e->d_tail_sync};
+                        TM_TRY(launch_linear(*w, r.x, r.ldx, nullptr, r.ldy, M, false, cfg, e->d_gemm_ws, true, nullptr, st, &tail));
+                        continue;
+                    }
                     TM_TRY(launch_linear(*w, r.x, r.ldx, r.y, r.ldy, M, r.gated, cfg, e->d_gemm_ws, norm_consumer && cfg.splits > 1, &slabs, st));
                     if (norm_consumer) {
                         TM_TRY(launch_residual_rmsnorm(e->d_last, e->d_resid, slabs > 1 ? nullptr : e->d_tmp, slabs > 1 ? e->d_gemm_ws : nullptr,
@@ -1242,32 +1267,44 @@ static int tune_decode_gemms(tm_engine* e, int M, bool verbose)
             if ((rc = chain())) {  // eager once: lazy module loading, function attributes
                 break;
             }
-            TM_HIP_CHECK(hipStreamSynchronize(st));
             hipGraph_t     g  = nullptr;
             hipGraphExec_t ge = nullptr;
-            TM_HIP_CHECK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
-            const int crc = chain();
-            TM_HIP_CHECK(hipStreamEndCapture(st, &g));
-            if (crc) {
-                rc = crc;
+            float          us = 1e30f;
+            // every error path below ends the capture and destroys what was created: a failed candidate must not leave the
+            // engine stream capturing (every later launch would fail) nor leak the graph
+            auto timed = [&]() -> int {
+                TM_HIP_CHECK(hipStreamSynchronize(st));
+                TM_HIP_CHECK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+                const int        crc = chain();
+                const hipError_t erc = hipStreamEndCapture(st, &g);
+                if (crc) {
+                    return crc;
+                }
+                TM_HIP_CHECK(erc);
+                TM_HIP_CHECK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+                for (int rep = 0; rep < 4; ++rep) {
+                    TM_HIP_CHECK(hipEventRecord(e0, st));
+                    TM_HIP_CHECK(hipGraphLaunch(ge, st));
+                    TM_HIP_CHECK(hipEventRecord(e1, st));
+                    TM_HIP_CHECK(hipEventSynchronize(e1));
+                    float ms = 0.f;
+                    TM_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+                    if (rep > 0) {
+                        us = std::min(us, ms * 1000.f / (float)ws.size());
+                    }
+                }
+                return 0;
+            };
+            rc = timed();
+            if (ge) {
+                (void)hipGraphExecDestroy(ge);
+            }
+            if (g) {
                 (void)hipGraphDestroy(g);
+            }
+            if (rc) {
                 break;
             }
-            TM_HIP_CHECK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
-            float us = 1e30f;
-            for (int rep = 0; rep < 4; ++rep) {
-                TM_HIP_CHECK(hipEventRecord(e0, st));
-                TM_HIP_CHECK(hipGraphLaunch(ge, st));
-                TM_HIP_CHECK(hipEventRecord(e1, st));
-                TM_HIP_CHECK(hipEventSynchronize(e1));
-                float ms = 0.f;
-                TM_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
-                if (rep > 0) {
-                    us = std::min(us, ms * 1000.f / (float)ws.size());
-                }
-            }
-            (void)hipGraphExecDestroy(ge);
-            (void)hipGraphDestroy(g);
             if (cand[i][0] == hs && cand[i][1] == hp) {
                 heur = us;
             }
@@ -1349,6 +1386,12 @@ int tm_engine_start(tm_engine* e)
     // split-K workspace: decode-sized problems only (M <= 64 rows x widest N x 16 slabs)
     e->gemm_ws_bytes = (size_t)16 * 64 * std::max(std::max(e->qkv_n, 2 * e->inter), e->hidden) * sizeof(float);
     TM_HIP_CHECK(hipMalloc((void**)&e->d_gemm_ws, e->gemm_ws_bytes));
+    {
+        const char* gt = getenv("TM_GEMM_TAIL");
+        e->gemm_tail   = gt && atoi(gt);
+    }
+    TM_HIP_CHECK(hipMalloc((void**)&e->d_tail_sync, 16));
+    TM_HIP_CHECK(hipMemsetAsync(e->d_tail_sync, 0, 16, e->stream));
     if (m.moe_experts > 0) {
         TM_HIP_CHECK(hipMalloc(&e->d_moe_ws, moe_workspace_bytes(e->layers[0].moe, e->max_tokens)));
     }
@@ -1425,7 +1468,9 @@ int tm_engine_start(tm_engine* e)
     const char* tune = getenv("TM_GEMM_TUNE");
     if (tune && atoi(tune) && B <= 256) {
         const char* v = getenv("TM_GEMM_TUNE_VERBOSE");
-        TM_TRY(tune_decode_gemms(e, B, v && atoi(v)));
+        if (tune_decode_gemms(e, B, v && atoi(v))) {  // not fatal: the heuristic tilings stay
+            fprintf(stderr, "[tm] TM_GEMM_TUNE failed (%s); keeping the heuristic tilings\n", tm_last_error());
+        }
     }
     if (const char* exp = getenv("TM_GEMM_EXPORT")) {
         TM_TRY(dec32_table_export(exp));
@@ -2190,7 +2235,9 @@ static int step_locked(tm_engine* e, int* n_active, int* n_waiting, std::vector<
             TM_TRY(decode_step_cb(e));
         }
         TM_HIP_CHECK(hipMemcpyAsync(e->h_step_ids.data(), e->d_ids, (size_t)B * 4, hipMemcpyDeviceToHost, e->stream));
+        TM_TRY(device_marks_fetch(e, true));
         TM_HIP_CHECK(hipStreamSynchronize(e->stream));
+        TM_TRY(device_marks_check(e));  // -> the serve loop ends every unfinished request with kFail
         for (int b = 0; b < B; ++b) {
             const int64_t id = e->sched->slot_request(b);
             if (!e->h_active[b] || id < 0 || std::find(fresh.begin(), fresh.end(), b) != fresh.end()) {
@@ -2448,13 +2495,16 @@ int tm_engine_sync(tm_engine* e)
 {
     TM_REQUIRE(e, "null pointer");
     TM_HIP_CHECK(hipStreamSynchronize(e->stream));
-    return 0;
+    TM_TRY(device_marks_fetch(e, false));
+    return device_marks_check(e);
 }
 
 int tm_engine_fetch(tm_engine* e, int* host_out, int* n_generated)
 {
     TM_REQUIRE(e && host_out && n_generated, "null pointer");
     TM_HIP_CHECK(hipStreamSynchronize(e->stream));
+    TM_TRY(device_marks_fetch(e, false));
+    TM_TRY(device_marks_check(e));
     TM_HIP_CHECK(hipMemcpy(host_out, e->d_generated, (size_t)e->batch * e->max_new * 4, hipMemcpyDeviceToHost));
     *n_generated = e->steps_done;
     return 0;
@@ -2571,7 +2621,7 @@ int tm_engine_destroy(tm_engine* e)
     void* bufs[] = {e->pool, e->d_block_ptrs, e->d_cu_block_nums, e->d_resid, e->d_x, e->d_qkv, e->d_attn, e->d_act,
                     e->d_tmp, e->d_logits, e->d_last, e->d_gemm_ws, e->d_attn_ws, e->d_kflat, e->d_vflat, e->d_rope,
                     e->d_ids, e->d_k_len, e->d_cu_q, e->d_cu_koff, e->d_rows, e->d_generated, e->d_step,
-                    e->d_prefill_ids, e->d_argmax_val, e->d_cand, e->d_cand_all, e->d_next_ids};
+                    e->d_prefill_ids, e->d_argmax_val, e->d_cand, e->d_cand_all, e->d_next_ids, e->d_tail_sync};
     for (void* p : bufs) {
         if (p) {
             (void)hipFree(p);

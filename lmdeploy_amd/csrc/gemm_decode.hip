@@ -30,9 +30,11 @@
 //     [2048, 2176) 32 x (s, -z*s) half2 pairs of the group's columns.
 #include "tm_common.h"
 #include "tm_kernels.h"
+#include "norm_row.h"
 #include <stdlib.h>
 #include <type_traits>
 #include <map>
+#include <mutex>
 #include <string>
 #include <tuple>
 #include <stdio.h>
@@ -104,12 +106,22 @@ struct Dec32Params {
     int           M, N, K, KB, ncg;
     int           kb_per_split;
     int           epilogue;  // 0: fp16   1: gated SiLU fp16 (N/2 columns)   2: fp32 slab of split blockIdx.y
-    int           rotate;    // 1: workgroup w walks its k stages starting at stage (w mod stages) -- the workgroups of a launch then
-                             // read DIFFERENT parts of x (and of the weight stream) at any moment instead of hammering the same
-                             // 64 KB of x from every CU at once
     int           wt;        // bit 0: split-K slabs, bit 1: fp16 outputs leave through write-through (sc1) stores: they drain to memory
                              // while the other workgroups still stream instead of sitting dirty in L2 until the end-of-kernel
                              // release writes them back (the kernel boundary then waits for MBs of fp32 slabs)
+    // In-launch consumer of a row-parallel linear (epilogue 2 only; reference: the residual + RMSNorm that follows wo / w2,
+    // unified_decoder.cc:149,226 -> rms_norm.cu:286-362): the LAST `min(M, 64)` workgroups to finish their slab tiles each take
+    // token rows and run norm_row<2> on them (split-K reduce in slab order -> fp16 -> residual add -> RMSNorm), so the
+    // separate reduce-norm launch, its kernel boundary and the dirty-slab write-back in front of it disappear.  Hand-off:
+    // write-through slab stores, every wave drains vmcnt, ONE relaxed agent-scope ticket per workgroup; a tail workgroup polls
+    // that one word (relaxed, s_sleep, BOUNDED: on give-up it sets tail_sync[2] and carries on) and reads the slabs with sc1
+    // loads (cdna_hip_programming.md Guideline 16 R1).  tail_sync = 4 device words, zero before the first launch; the last
+    // tail workgroup to finish re-zeroes the two counters, so consecutive launches on one stream may share the words.
+    half_t*       tail_y;       // nullptr: no in-launch consumer
+    half_t*       tail_resid;
+    const half_t* tail_w;
+    float         tail_eps;
+    unsigned*     tail_sync;    // [0] arrivals, [1] finished tail workgroups, [2] give-up mark (sticky), [3] -
     uint64_t*     dbg;       // optional [workgroups][8] s_memrealtime stamps (tm_debug_set_gemm_trace): start, loop, epilogue, end,
                              // hw id, -, -, after the k-phase reduction barrier
 };
@@ -165,6 +177,79 @@ __device__ __forceinline__ void static_for(F&& f)
     }
 }
 
+// The in-launch consumer (Dec32Params::tail_*).  Called by every thread of the workgroup after its slab stores were ISSUED.
+// Arrival: every wave drains its write-through stores, then one relaxed agent-scope ticket per workgroup.  The last
+// R = min(M, 64, workgroups) arrivers stay: workgroup with ticket total - R + j takes rows j, j + R, ...  They fetch what does
+// not depend on anybody (residual row, norm weight), wait for the last ticket (one lane polls, bounded), then read the slabs
+// L1-bypassing.  No workgroup waits for one that is not resident unless fewer than R + 1 workgroups fit on the chip
+// (R <= 64 of >= 256 slots), so the wait cannot deadlock.
+template<int NV>
+__device__ __forceinline__ void dec32_norm_tail_rows(const Dec32Params& p, char* smem, int tid, unsigned total, unsigned R, int j, int wgid,
+                                                     int nthreads)
+{
+    typedef __attribute__((address_space(1))) unsigned gu32;
+    gu32* const     sync = (gu32*)p.tail_sync;
+    float* const    red  = (float*)smem;
+    NormRowRegs<NV> g;
+    norm_row_load<2, false, NV>(g, p.tail_resid, nullptr, nullptr, p.tail_w, p.N, j, tid, nthreads);
+    if (tid == 0) {
+        unsigned spins = 0;
+        while (__hip_atomic_load(sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < total) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > (1u << 21)) {  // ~ seconds: something is badly wrong -- mark it and carry on (wrong numbers, no hang)
+                __hip_atomic_store(sync + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+            }
+        }
+    }
+    __syncthreads();
+    if (p.dbg && tid == 0) {
+        p.dbg[wgid * 8 + 6] = __builtin_amdgcn_s_memrealtime();
+    }
+    for (int row = j; row < p.M; row += (int)R) {
+        if (row != j) {
+            __syncthreads();  // `red` is reused
+            norm_row_load<2, false, NV>(g, p.tail_resid, nullptr, nullptr, p.tail_w, p.N, row, tid, nthreads);
+        }
+        norm_row_finish<2, false, NV, true>(g, p.tail_y, p.tail_resid, p.partial, (int)gridDim.y, p.tail_eps, p.M, p.N, tid, nthreads, red);
+    }
+    if (tid == 0) {
+        const unsigned d = __hip_atomic_fetch_add(sync + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (d + 1 == R) {  // every tail workgroup is past its poll: the words are free for the next launch on the stream
+            __hip_atomic_store(sync, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(sync + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+__device__ __forceinline__ void dec32_norm_tail(const Dec32Params& p, char* smem, int tid, unsigned total, int wgid)
+{
+    typedef __attribute__((address_space(1))) unsigned gu32;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // EVERY storing wave (Guideline 16 pitfall 14)
+    __syncthreads();                                  // also: every read of the k-phase reduction image is done
+    unsigned* const sh = (unsigned*)smem;
+    if (tid == 0) {
+        sh[64] = __hip_atomic_fetch_add((gu32*)p.tail_sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    const unsigned ticket = sh[64];
+    const unsigned R      = min(min((unsigned)p.M, 64u), total);
+    if (ticket + R < total) {
+        return;  // uniform: not one of the last R
+    }
+    if (p.dbg && tid == 0) {
+        p.dbg[wgid * 8 + 5] = __builtin_amdgcn_s_memrealtime();
+    }
+    int nthreads, nv;
+    norm_geometry(p.N, &nthreads, &nv);
+    if (nv == 1) {
+        dec32_norm_tail_rows<1>(p, smem, tid, total, R, (int)(ticket + R - total), wgid, nthreads);
+    }
+    else {
+        dec32_norm_tail_rows<2>(p, smem, tid, total, R, (int)(ticket + R - total), wgid, nthreads);
+    }
+}
+
 // MH: 32-row halves of the batch (1: M <= 32, 2: M <= 64).  CG x WK waves.  S k-blocks per LDS stage (S % WK == 0).
 // PF: ring depth in k-blocks per wave, a multiple of 2 * S / WK (the unrolled body covers PF / (S / WK) stages, an even
 // number, so that ring slots and the LDS buffer parity are compile-time constants).
@@ -212,12 +297,7 @@ __global__ __launch_bounds__(CG* WK * 64) void gemm_dec32_kernel(Dec32Params p)
     const int kb0 = blockIdx.y * p.kb_per_split;
     const int nkb = min(p.kb_per_split, p.KB - kb0);
     const int nst = (nkb + S - 1) / S;
-    // logical stage t of this workgroup -> stage of the k slice (rotated start, see Dec32Params::rotate)
-    const int rot0 = (p.rotate && nst > 1) ? (int)((blockIdx.x + blockIdx.z * 7u) % (unsigned)nst) : 0;
-    auto      phys = [&](int t) {
-        int r = min(t, nst - 1) + rot0;
-        return r >= nst ? r - nst : r;
-    };
+    auto      phys = [&](int t) { return min(t, nst - 1); };  // stages past the slice re-read the last one (nobody consumes them)
     // row block (prefill: M > ROWS): rows m0 .. m0 + Mloc of x / y; the x descriptor starts at row m0
     const int m0   = blockIdx.z * ROWS;
     const int Mloc = min(ROWS, p.M - m0);
@@ -263,13 +343,6 @@ __global__ __launch_bounds__(CG* WK * 64) void gemm_dec32_kernel(Dec32Params p)
     // DMA writes lane L to slot L of the piece (wave-linear), so the XOR swizzle sits on the SOURCE address: lane L
     // fetches chunk (L & 15) ^ (row & 15) of row 4 pc + (L >> 4).
     constexpr bool DMA = (ABL & 0x100) != 0;
-    // 0x4000 (needs the DMA and UNR >= 3): the ring refill moves from the END of a stage to its TOP, right behind the DMA of
-    // x(t+1), into the slots the PREVIOUS stage consumed.  vmcnt retires in issue order, so the counted wait that guards the
-    // DMA at the end of stage t forces every load issued BEFORE that DMA to have landed: a refill issued at the end of stage
-    // t-1 therefore had ONE stage to arrive whatever the ring depth (which is why PF = 4 alone bought nothing), one issued at
-    // the top of stage t -- younger than the DMA -- may stay in flight until the end of stage t+1: TWO stages.
-    constexpr bool EARLY = DMA && (ABL & 0x4000) != 0;
-    static_assert(!EARLY || UNR >= 3, "early refill needs a spare ring stage");
     constexpr int  NPC = S * ROWS / 4;
     constexpr int  DR  = NPC / WAVES;
     static_assert(!DMA || NPC % WAVES == 0, "DMA pieces per wave");
@@ -327,7 +400,7 @@ __global__ __launch_bounds__(CG* WK * 64) void gemm_dec32_kernel(Dec32Params p)
             // queue: x(0) DMA pieces, then the whole weight ring; the DMA is invisible to hipcc's waitcnt pass, so its
             // completion is waited for by hand: everything older than the 3 * PF ring loads
             D32_DMA_X(phys(0), 0);
-            constexpr int PF0 = EARLY ? PF - BPS : PF;  // EARLY: stage 0 itself fetches the slots of stage UNR - 1
+            constexpr int PF0 = PF;
 #pragma unroll
             for (int q = 0; q < PF0; ++q) {
                 D32_LOAD_W(q, phys(q / BPS) * S + wk + (q % BPS) * WK);
@@ -379,14 +452,6 @@ __global__ __launch_bounds__(CG* WK * 64) void gemm_dec32_kernel(Dec32Params p)
                 // epilogue lays the reduction image over the stage buffers (seen as flaky rows 96..127 of row blocks, r02).
                 if (t + 1 < nst) {  // uniform
                     D32_DMA_X(phys(t + 1), buf ^ 1);
-                }
-                if constexpr (EARLY && !(ABL & 16)) {
-                    constexpr int uf = (u + UNR - 1) % UNR;  // the slots stage t-1 consumed (stage 0: never loaded yet)
-#pragma unroll
-                    for (int i = 0; i < BPS; ++i) {
-                        D32_LOAD_W(uf * BPS + i, phys(t + UNR - 1) * S + wk + i * WK);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
 #pragma unroll
@@ -501,7 +566,7 @@ __global__ __launch_bounds__(CG* WK * 64) void gemm_dec32_kernel(Dec32Params p)
                 D32_STORE_X(buf ^ 1);
                 D32_LOAD_X(phys(t + 2));
             }
-            if constexpr (!(ABL & 16) && !EARLY) {
+            if constexpr (!(ABL & 16)) {
 #pragma unroll
                 for (int i = 0; i < BPS; ++i) {
                     D32_LOAD_W(u * BPS + i, phys(t + UNR) * S + wk + i * WK);
@@ -613,6 +678,9 @@ __global__ __launch_bounds__(CG* WK * 64) void gemm_dec32_kernel(Dec32Params p)
             }
         }
     }
+    if (p.tail_y != nullptr) {  // uniform over the launch (epilogue 2, write-through slab stores)
+        dec32_norm_tail(p, smem, tid, (unsigned)(gridDim.x * gridDim.y * gridDim.z), wgid);
+    }
     if (p.dbg && tid == 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         p.dbg[wgid * 8 + 3] = __builtin_amdgcn_s_memrealtime();
@@ -640,307 +708,6 @@ static int launch_dec32_one(const Dec32Params& p, dim3 grid, hipStream_t st)
         attr_set[dev & 15] = true;
     }
     gemm_dec32_kernel<MH, CG, WK, S, PF, ABL><<<grid, CG * WK * 64, lds, st>>>(p);
-    TM_HIP_CHECK(hipGetLastError());
-    return 0;
-}
-
-// ---- decode tile with TWO weight fragments per activation-fragment read (shapes 10 / 11) --------------------------------------
-// At M = 64 the loop of gemm_dec32_kernel is co-limited on the CU: per 2176-byte weight unit 128 clk of matrix pipe, 128 clk of
-// LDS (16 x 1 KB fragment reads at 128 B/clk) and 112 clk of VALU issue against ~205 clk of HBM at the fair share (DESIGN.md
-// 3.1).  Here a wave owns TWO adjacent 32-column groups of its k-phase: one ds_read_b128 feeds two MFMAs per row half, the LDS
-// term halves.  The accumulators double (2 x MH x 16 registers), so a workgroup is 8 waves (two per SIMD, 256 registers
-// each): CG column PAIRS x WK k-phases; the dequantisation of one fragment is interleaved into the MFMAs of the other
-// (sched_group_barrier, as gemm_pre64_kernel) because two waves per SIMD no longer hide it for free.  Structure otherwise
-// as gemm_dec32_kernel in its default mode: LDS-DMA staging of x in stages of S k-blocks, register ring for the weights,
-// inline-asm fragment pipeline, on-chip k-phase reduction, same epilogues, same arithmetic.
-template<int MH, int CG, int WK, int S, int PF>
-__global__ __launch_bounds__(CG* WK * 64) void gemm_dec64_kernel(Dec32Params p)
-{
-    constexpr int NB    = 2;
-    constexpr int WAVES = CG * WK;
-    constexpr int T     = WAVES * 64;
-    constexpr int ROWS  = 32 * MH;
-    constexpr int KBB   = ROWS * 256;
-    constexpr int STG   = S * KBB;
-    constexpr int BPS   = S / WK;
-    constexpr int UNR   = PF / BPS;
-    static_assert(S % WK == 0 && PF % BPS == 0 && UNR == 2, "tile parameters");
-    constexpr int LPB = 3 * NB;  // loads per ring slot
-
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-
-    const int tid  = threadIdx.x;
-    const int wgid = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
-    if (p.dbg && tid == 0) {
-        p.dbg[wgid * 8 + 0] = __builtin_amdgcn_s_memrealtime();
-    }
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int cgl  = wave % CG;
-    const int wk   = wave / CG;
-    const int l31  = lane & 31;
-    const int half = lane >> 5;
-    int       cgc[NB];
-#pragma unroll
-    for (int nb = 0; nb < NB; ++nb) {
-        cgc[nb] = min((int)(blockIdx.x * CG + cgl) * NB + nb, p.ncg - 1);
-    }
-    const int kb0  = blockIdx.y * p.kb_per_split;
-    const int nkb  = min(p.kb_per_split, p.KB - kb0);
-    const int nst  = (nkb + S - 1) / S;
-    const int m0   = blockIdx.z * ROWS;
-    const int Mloc = min(ROWS, p.M - m0);
-
-    const auto rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.wp, 0, (int)((size_t)p.KB * p.ncg * kP32Unit), 0x00020000);
-    const auto rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x + (size_t)m0 * p.ldx), 0,
-                                                        (int)(((size_t)(Mloc - 1) * p.ldx + p.K) * 2), 0x00020000);
-    const int  vw   = lane * 16;
-    const int  vs   = 2048 + l31 * 4;
-
-    floatx16 acc[NB][MH];
-#pragma unroll
-    for (int nb = 0; nb < NB; ++nb) {
-#pragma unroll
-        for (int h = 0; h < MH; ++h) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                acc[nb][h][r] = 0.f;
-            }
-        }
-    }
-    u32x4    ring[PF][NB][2];
-    uint32_t sring[PF][NB];
-    int      coff[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        coff[j] = l31 * 256 + (((2 * j + half) ^ (l31 & 15)) << 4);
-    }
-    uint32_t m1024 = 0x64006400u, m64 = 0x54005400u;
-    asm volatile("" : "+v"(m1024), "+v"(m64));
-
-    // LDS-DMA pieces (see gemm_dec32_kernel): 1 KiB = 4 rows x 256 B, piece pc = r * WAVES + wave, swizzle on the source address
-    constexpr int NPC = S * ROWS / 4;
-    constexpr int DR  = NPC / WAVES;
-    static_assert(NPC % WAVES == 0, "DMA pieces per wave");
-    int            doff[DR];
-    const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)smem);
-#pragma unroll
-    for (int r = 0; r < DR; ++r) {
-        const int pc  = r * WAVES + wave;
-        const int kbi = pc / (ROWS / 4);
-        const int row = (pc % (ROWS / 4)) * 4 + (lane >> 4);
-        const int ch  = (lane & 15) ^ (row & 15);
-        doff[r]       = (min(row, Mloc - 1) * p.ldx + ch * 8) * 2 + kbi * 256;
-    }
-#define D64_DMA_X(t, buf)                                                                                         \
-    _Pragma("unroll") for (int r = 0; r < DR; ++r)                                                                \
-    {                                                                                                             \
-        unsigned       keep_;                                                                                     \
-        const unsigned dst_ = lds0 + (buf)*STG + (r * WAVES + wave) * 1024;                                       \
-        const int      so_  = (kb0 + (t)*S) * 256;                                                                \
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"                                       \
-                     "buffer_load_dwordx4 %1, %2, %4 offen lds\n\ts_mov_b32 m0, %0"                               \
-                     : "=&s"(keep_)                                                                               \
-                     : "v"(doff[r]), "s"(rs_x), "s"(dst_), "s"(so_)                                               \
-                     : "memory");                                                                                 \
-    }
-#define D64_LOAD_W(slot, b)                                                                                       \
-    _Pragma("unroll") for (int nb = 0; nb < NB; ++nb)                                                             \
-    {                                                                                                             \
-        const int uo_       = ((kb0 + min((b), nkb - 1)) * p.ncg + cgc[nb]) * kP32Unit;                           \
-        ring[slot][nb][0]   = __builtin_amdgcn_raw_buffer_load_b128(rs_w, vw, uo_, /*nt*/ 2);                     \
-        ring[slot][nb][1]   = __builtin_amdgcn_raw_buffer_load_b128(rs_w, vw + 1024, uo_, /*nt*/ 2);              \
-        sring[slot][nb]     = __builtin_amdgcn_raw_buffer_load_b32(rs_w, vs, uo_, 0);                             \
-    }
-
-    if (nst > 0) {
-        D64_DMA_X(0, 0);
-#pragma unroll
-        for (int q = 0; q < PF; ++q) {
-            D64_LOAD_W(q, min(q / BPS, nst - 1) * S + wk + (q % BPS) * WK);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        asm volatile("s_waitcnt vmcnt(%0)" ::"i"(LPB * PF) : "memory");  // everything older than the ring: x(0)
-        __syncthreads();
-        if (p.dbg && tid == 0) {
-            p.dbg[wgid * 8 + 1] = __builtin_amdgcn_s_memrealtime();
-        }
-        auto stage = [&](auto U, const int t, auto REM) __attribute__((always_inline)) {
-            constexpr int  u   = decltype(U)::value;
-            constexpr bool rem = decltype(REM)::value;
-            const int      buf = u & 1;
-#pragma unroll
-            for (int i = 0; i < BPS; ++i) {  // hipcc's wait for this stage's ring slots goes HERE, before the invisible DMA
-                asm volatile("" ::"v"(ring[u * BPS + i][0][0]), "v"(ring[u * BPS + i][NB - 1][1]), "v"(sring[u * BPS + i][NB - 1]));
-            }
-            if (t + 1 < nst) {  // uniform; never behind the last stage (the epilogue reuses the buffers)
-                D64_DMA_X(t + 1, buf ^ 1);
-            }
-#pragma unroll
-            for (int i = 0; i < BPS; ++i) {
-                const int  slot = u * BPS + i;
-                const int  kbi  = wk + i * WK;
-                const bool live = t * S + kbi < nkb;
-                half2_t    s2[NB], z2[NB];
-#pragma unroll
-                for (int nb = 0; nb < NB; ++nb) {
-                    const half2_t pr = bit_cast<half2_t>(live ? sring[slot][nb] : 0u);
-                    s2[nb]           = half2_t{pr[0], pr[0]};
-                    z2[nb]           = half2_t{pr[1], pr[1]};
-                }
-                half8_t        f0[MH], f1[MH];
-                const unsigned xa = lds0 + buf * STG + kbi * KBB;
-                auto           rd = [&](half8_t(&f)[MH], int j) __attribute__((always_inline)) {
-                    const unsigned ad = xa + (unsigned)coff[j];
-#pragma unroll
-                    for (int h = 0; h < MH; ++h) {
-                        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(f[h]) : "v"(ad), "i"(h * 8192));
-                    }
-                };
-                auto wt = [&](half8_t(&f)[MH], auto N) __attribute__((always_inline)) {
-                    constexpr int n = decltype(N)::value;
-                    if constexpr (MH == 1) {
-                        asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(f[0]) : "i"(n));
-                    }
-                    else {
-                        asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(f[0]), "+v"(f[1]) : "i"(n));
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                };
-                rd(f0, 0);
-                half8_t a0 = dequant8_p32(ring[slot][0][0][0], s2[0], z2[0], m1024, m64), a1;
-                static_for<8>([&](auto J) {
-                    constexpr int  j  = decltype(J)::value;
-                    half8_t(&cur)[MH] = (j & 1) ? f1 : f0;
-                    half8_t(&nxt)[MH] = (j & 1) ? f0 : f1;
-                    if constexpr (j + 1 < 8) {
-                        rd(nxt, j + 1);
-                    }
-                    wt(cur, std::integral_constant<int, (j + 1 < 8) ? MH : 0>{});
-                    a1 = dequant8_p32(ring[slot][1][j >> 2][j & 3], s2[1], z2[1], m1024, m64);
-#pragma unroll
-                    for (int h = 0; h < MH; ++h) {
-                        acc[0][h] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, cur[h], acc[0][h], 0, 0, 0);
-                    }
-                    if constexpr (j + 1 < 8) {
-                        a0 = dequant8_p32(ring[slot][0][(j + 1) >> 2][(j + 1) & 3], s2[0], z2[0], m1024, m64);
-                    }
-#pragma unroll
-                    for (int h = 0; h < MH; ++h) {
-                        acc[1][h] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, cur[h], acc[1][h], 0, 0, 0);
-                    }
-#pragma unroll
-                    for (int g = 0; g < NB * MH; ++g) {  // (1 MFMA, the VALU work that fits behind it)
-                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                        __builtin_amdgcn_sched_group_barrier(0x002, MH == 2 ? 7 : 14, 0);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                });
-            }
-#pragma unroll
-            for (int i = 0; i < BPS; ++i) {
-                D64_LOAD_W(u * BPS + i, min(t + UNR, nst - 1) * S + wk + i * WK);
-            }
-            // my DMA pieces of stage t+1 have landed when at most the refills issued after them are in flight (remainder
-            // stages: the refills are dead code there, drain)
-            asm volatile("s_waitcnt vmcnt(%0)" ::"i"(rem ? 0 : LPB * BPS) : "memory");
-            __syncthreads();
-        };
-        int t0 = 0;
-        for (; t0 + UNR <= nst; t0 += UNR) {
-            static_for<UNR>([&](auto U) { stage(U, t0 + decltype(U)::value, std::false_type{}); });
-        }
-        static_for<UNR>([&](auto U) {
-            if (t0 + decltype(U)::value < nst) {
-                stage(U, t0 + decltype(U)::value, std::true_type{});
-            }
-        });
-    }
-#undef D64_DMA_X
-#undef D64_LOAD_W
-    if (p.dbg && tid == 0) {
-        p.dbg[wgid * 8 + 2] = __builtin_amdgcn_s_memrealtime();
-    }
-    // ---- the WK k-phase partial tiles meet in LDS: red[wk][row][c4 ^ (row & 7)] (floatx4 units, CG * NB * 8 per row) ----------
-    {
-        constexpr int C4  = CG * NB * 8;
-        floatx4*      red = (floatx4*)smem;
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb) {
-#pragma unroll
-            for (int h = 0; h < MH; ++h) {
-                const int m = 32 * h + l31;
-#pragma unroll
-                for (int g4 = 0; g4 < 4; ++g4) {
-                    const int c4 = (cgl * NB + nb) * 8 + 2 * g4 + half;
-                    red[(wk * ROWS + m) * C4 + (c4 ^ (m & 7))] =
-                        floatx4{acc[nb][h][4 * g4], acc[nb][h][4 * g4 + 1], acc[nb][h][4 * g4 + 2], acc[nb][h][4 * g4 + 3]};
-                }
-            }
-        }
-        __syncthreads();
-        if (p.dbg && tid == 0) {
-            p.dbg[wgid * 8 + 7] = __builtin_amdgcn_s_memrealtime();
-        }
-        constexpr int NE    = ROWS * C4;
-        const int     ncol0 = blockIdx.x * CG * NB * 32;
-        static_assert(NE % T == 0, "output tile / threads");
-#pragma unroll
-        for (int e0 = 0; e0 < NE; e0 += T) {
-            const int e  = e0 + tid;
-            const int m  = e / C4;
-            const int c4 = e % C4;
-            floatx4   a  = red[m * C4 + (c4 ^ (m & 7))];
-#pragma unroll
-            for (int k = 1; k < WK; ++k) {  // fixed order: deterministic
-                a += red[(k * ROWS + m) * C4 + (c4 ^ (m & 7))];
-            }
-            const int n = ncol0 + c4 * 4;
-            if (m >= Mloc || n >= p.N) {
-                continue;
-            }
-            const size_t mg = (size_t)m0 + m;
-            if (p.epilogue == 2) {
-                floatx4* dst = (floatx4*)(p.partial + ((size_t)blockIdx.y * p.M + mg) * p.N + n);
-                if (p.wt & 1) {
-                    store_wt(dst, a, p.wt >> 4);
-                }
-                else {
-                    *dst = a;
-                }
-            }
-            else if (p.epilogue == 1) {
-                const float s0 = a[0] / (1.0f + __builtin_expf(-a[0]));
-                const float s1 = a[2] / (1.0f + __builtin_expf(-a[2]));
-                half2_t     o  = {(half_t)(s0 * a[1]), (half_t)(s1 * a[3])};
-                *(half2_t*)(p.y + mg * p.ldy + (n >> 1)) = o;
-            }
-            else {
-                half4_t o = {(half_t)a[0], (half_t)a[1], (half_t)a[2], (half_t)a[3]};
-                *(half4_t*)(p.y + mg * p.ldy + n) = o;
-            }
-        }
-    }
-    if (p.dbg && tid == 0) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        p.dbg[wgid * 8 + 3] = __builtin_amdgcn_s_memrealtime();
-    }
-}
-
-template<int MH, int CG, int WK, int S, int PF>
-static int launch_dec64_one(const Dec32Params& p, dim3 grid, hipStream_t st)
-{
-    constexpr int stage = 2 * S * 32 * MH * 256;
-    constexpr int red   = WK * 32 * MH * CG * 2 * 128;
-    constexpr int lds   = stage > red ? stage : red;
-    static bool   attr_set[16] = {};
-    int           dev = 0;
-    (void)hipGetDevice(&dev);
-    if (!attr_set[dev & 15]) {
-        TM_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_dec64_kernel<MH, CG, WK, S, PF>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        attr_set[dev & 15] = true;
-    }
-    gemm_dec64_kernel<MH, CG, WK, S, PF><<<grid, CG * WK * 64, lds, st>>>(p);
     TM_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -1217,38 +984,42 @@ static int launch_pre64_one(const Dec32Params& p, dim3 grid, hipStream_t st)
 // between row blocks)
 constexpr int kD32Mode = 0x900;
 
+// TM_EXPERIMENTS (compile-time, off in the shipped library): the timing / structure ablations of tools/trace_dec32.py and
+// tools/bench_gemm.py (TM_D32_ABL) -- ~40 further instantiations of the kernel whose results are garbage by design.
 template<int MH>
 static int launch_dec32_shape(const Dec32Params& p, dim3 grid, int shape, hipStream_t st)
 {
-    const int abl = env_int2("TM_D32_ABL", -1);  // timing / structure experiments (tools/trace_dec32.py, tools/bench_gemm.py)
+#ifdef TM_EXPERIMENTS
+    static const int abl = env_int2("TM_D32_ABL", -1);
+#endif
     if constexpr (MH == 4) {
         // row blocks of 128 rows x 256 columns, 8 waves of 32 columns over the whole k slice (M > 64): every dequantised
         // weight fragment feeds 4 MFMAs, every x fragment read from LDS feeds 32 columns
         if (shape == 5) {  // 128 x 512 tile, two weight fragments per x-fragment read (gemm_pre64_kernel)
+#ifdef TM_EXPERIMENTS
             if (abl == 2) return launch_pre64_one<2>(p, grid, st);  // timing: no MFMA
+#endif
             return launch_pre64_one<0>(p, grid, st);
         }
         if (shape != 4) {
             set_last_error("gemm_dec32: the 128-row tiles are shapes 4 and 5");
             return 1;
         }
-        if (abl == 0) return launch_dec32_one<4, 8, 1, 2, 4, 0>(p, grid, st);
-        if (abl == 0x100) return launch_dec32_one<4, 8, 1, 2, 4, 0x100>(p, grid, st);
-        if (abl == 0x101) return launch_dec32_one<4, 8, 1, 2, 4, 0x101>(p, grid, st);  // timing: no dequant
-        if (abl == 0x104) return launch_dec32_one<4, 8, 1, 2, 4, 0x104>(p, grid, st);  // no LDS fragment reads
-        if (abl == 0x108) return launch_dec32_one<4, 8, 1, 2, 4, 0x108>(p, grid, st);  // no x staging
-        if (abl == 0x10d) return launch_dec32_one<4, 8, 1, 2, 4, 0x10d>(p, grid, st);  // MFMA + weight loads only
-        if (abl == 0x11d) return launch_dec32_one<4, 8, 1, 2, 4, 0x11d>(p, grid, st);  // MFMA only
-        if (abl == 0x102) return launch_dec32_one<4, 8, 1, 2, 4, 0x102>(p, grid, st);  // no MFMA
-        if (abl == 0x1900) return launch_dec32_one<4, 8, 1, 2, 4, 0x1900>(p, grid, st);  // diagnosis: prologue drains vmcnt
-        if (abl == 0x2900) return launch_dec32_one<4, 8, 1, 2, 4, 0x2900>(p, grid, st);  // diagnosis: every stage drains vmcnt
-        if (abl == 0x3900) return launch_dec32_one<4, 8, 1, 2, 4, 0x3900>(p, grid, st);
-        if (abl == 0x800) return launch_dec32_one<4, 8, 1, 2, 4, 0x800>(p, grid, st);    // register staging + asm fragment pipeline
+#ifdef TM_EXPERIMENTS
+        switch (abl) {
+#define D32_CASE(v) case v: return launch_dec32_one<4, 8, 1, 2, 4, v>(p, grid, st)
+            D32_CASE(0); D32_CASE(0x100); D32_CASE(0x101); D32_CASE(0x104); D32_CASE(0x108); D32_CASE(0x10d); D32_CASE(0x11d);
+            D32_CASE(0x102); D32_CASE(0x1900); D32_CASE(0x2900); D32_CASE(0x3900); D32_CASE(0x800);
+#undef D32_CASE
+            default: break;
+        }
+#endif
         return launch_dec32_one<4, 8, 1, 2, 4, kD32Mode>(p, grid, st);
     }
     else
     switch (shape) {
         case 0: {  // 16 waves: 4 column groups x 4 k-phases, one k-block per wave per stage
+#ifdef TM_EXPERIMENTS
             if constexpr (MH == 2) {
                 switch (abl) {
 #define D32_CASE(v) case v: return launch_dec32_one<MH, 4, 4, 4, 2, v>(p, grid, st)
@@ -1260,20 +1031,13 @@ static int launch_dec32_shape(const Dec32Params& p, dim3 grid, int shape, hipStr
 #undef D32_CASE
                     default: break;
                 }
-                if (env_int2("TM_D32_EARLY", 0)) {
-                    return launch_dec32_one<MH, 4, 4, 4, 4, kD32Mode | 0x4000>(p, grid, st);
-                }
-                if (env_int2("TM_D32_PF", 2) >= 4) {
-                    return launch_dec32_one<MH, 4, 4, 4, 4, kD32Mode>(p, grid, st);
-                }
             }
+#endif
             return launch_dec32_one<MH, 4, 4, 4, 2, kD32Mode>(p, grid, st);
         }
         case 1:  // 16 waves: 8 column groups x 2 k-phases (256 columns per workgroup), two k-blocks per wave per stage
             return launch_dec32_one<MH, 8, 2, 4, 4, kD32Mode>(p, grid, st);
         case 2:  // 8 waves: 4 column groups x 2 k-phases
-            if (abl == 32) return launch_dec32_one<MH, 4, 2, 4, 4, 32>(p, grid, st);
-            if (abl == 0) return launch_dec32_one<MH, 4, 2, 4, 4, 0>(p, grid, st);
             return launch_dec32_one<MH, 4, 2, 4, 4, kD32Mode>(p, grid, st);
         case 3:  // 8 waves: 2 column groups x 4 k-phases (64 columns per workgroup)
             return launch_dec32_one<MH, 2, 4, 4, 2, kD32Mode>(p, grid, st);
@@ -1298,11 +1062,6 @@ static int dec32_base_shape(int shape)
 static void dec32_shape_dims(int shape, int* cg, int* s)
 {
     static const int cgs[6] = {4, 8, 4, 2, 8, 16};
-    if (shape == 10 || shape == 11) {  // gemm_dec64_kernel: 2 column pairs x 4 k-phases (10: 64-row, 11: 32-row blocks)
-        *cg = 4;
-        *s  = 4;
-        return;
-    }
     shape = dec32_base_shape(shape);
     *cg = cgs[shape < 0 || shape > 5 ? 0 : shape];
     *s  = shape == 5 ? 1 : (shape == 4 ? 2 : 4);
@@ -1321,15 +1080,18 @@ bool dec32_supported(const LinearWeight& w, int M)
 // (engine.hip: tune_decode_gemms) fills it by timing every candidate as a hipGraph over the model's own layer weights
 // TOGETHER with the kernel that consumes the result (a split-K GEMM pays at the boundary, not inside the kernel).
 static std::map<std::tuple<int, int, int>, std::pair<int, int>> g_d32_table;
+static std::mutex                                               g_d32_mutex;  // engines tune / import while others launch
 
 void dec32_table_set(int K, int N, int M, int shape, int splits)
 {
+    std::lock_guard<std::mutex> lk(g_d32_mutex);
     g_d32_table[std::make_tuple(K, N, M)] = std::make_pair(shape, splits);
 }
 
 bool dec32_table_get(int K, int N, int M, int* shape, int* splits)
 {
-    auto it = g_d32_table.find(std::make_tuple(K, N, M));
+    std::lock_guard<std::mutex> lk(g_d32_mutex);
+    auto                        it = g_d32_table.find(std::make_tuple(K, N, M));
     if (it == g_d32_table.end()) {
         return false;
     }
@@ -1340,6 +1102,7 @@ bool dec32_table_get(int K, int N, int M, int* shape, int* splits)
 
 void dec32_table_clear()
 {
+    std::lock_guard<std::mutex> lk(g_d32_mutex);
     g_d32_table.clear();
 }
 
@@ -1351,6 +1114,7 @@ int dec32_table_export(const char* path)
         set_last_error(std::string("cannot write ") + path);
         return 1;
     }
+    std::lock_guard<std::mutex> lk(g_d32_mutex);
     for (const auto& kv : g_d32_table) {
         fprintf(f, "%d %d %d %d %d\n", std::get<0>(kv.first), std::get<1>(kv.first), std::get<2>(kv.first), kv.second.first,
                 kv.second.second);
@@ -1369,8 +1133,8 @@ int dec32_table_import(const char* path)
     int K, N, M, shape, splits, n = 0;
     while (fscanf(f, "%d %d %d %d %d", &K, &N, &M, &shape, &splits) == 5) {
         const bool big = M > 64;
-        if (K > 0 && N > 0 && M > 0 && M <= 256 && shape >= 0 && shape <= 11 && splits >= 1 && splits <= 16
-            && (big ? (shape >= 4 && shape != 10) : (shape != 4 && shape != 5))) {
+        if (K > 0 && N > 0 && M > 0 && M <= 256 && shape >= 0 && shape <= 9 && splits >= 1 && splits <= 16
+            && (big ? shape >= 4 : (shape != 4 && shape != 5)) && !(shape == 5 && N < 512) && K % 128 == 0 && N % 32 == 0) {
             dec32_table_set(K, N, M, shape, splits);
             ++n;
         }
@@ -1384,10 +1148,8 @@ int dec32_candidates(const LinearWeight& w, int M, int (*out)[2], int cap)
 {
     const int ncg = w.N / 32, KB = w.K / 128;
     int       n   = 0;
-    static const int shapes[12] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11};
-    for (int si = 0; si < 12 && M <= 256; ++si) {
-        const int  shape  = shapes[si];
-        const bool rows32 = shape >= 6 && shape != 10;  // 32-row blocks on grid.z: any M
+    for (int shape = 0; shape < 10 && M <= 256; ++shape) {
+        const bool rows32 = shape >= 6;  // 32-row blocks on grid.z: any M
         if (rows32 ? M <= 32 : ((shape == 4 || shape == 5) != (M > 64))) {
             continue;  // one row block: identical to the base shape / 64-row shapes take M <= 64, 128-row tiles M > 64
         }
@@ -1430,7 +1192,9 @@ void dec32_pick_ex(const LinearWeight& w, int M, int* shape_out, int* splits_out
     if (use_table && M <= 256 && dec32_table_get(w.K, w.N, M, shape_out, splits_out)) {
         return;  // measured on this machine for exactly this problem
     }
-    int       shape = env_int2("TM_D32_SHAPE", -1);
+    static const int env_shape  = env_int2("TM_D32_SHAPE", -1);  // read once: this runs on every eager launch
+    static const int env_splits = env_int2("TM_D32_SPLITS", 0);
+    int              shape      = env_shape;
     if (shape < 0 || shape > 3) {
         shape = 0;
     }
@@ -1452,7 +1216,7 @@ void dec32_pick_ex(const LinearWeight& w, int M, int* shape_out, int* splits_out
     // TM_GEMM_TUNE=1 the engine measures instead of trusting this rule.  The two row halves of a shape-6 column tile are
     // gridDim.x * gridDim.y workgroups apart -- the same XCD when that is a multiple of 8: the second reader hits L2.
     static const int rowhalf = env_int2("TM_D32_ROWHALF", 1);
-    if (rowhalf && env_int2("TM_D32_SHAPE", -1) < 0 && M > 32 && M <= 64 && KB % 4 == 0 && ncg % 16 == 0 && ncg >= 64 && ncg <= 256) {
+    if (rowhalf && env_shape < 0 && M > 32 && M <= 64 && KB % 4 == 0 && ncg % 16 == 0 && ncg >= 64 && ncg <= 256) {
         const int nshape = KB <= 64 ? 6 : 3;
         const int tiles  = (ncg / 2) * (nshape == 6 ? 2 : 1);
         int       sp     = 1;
@@ -1463,7 +1227,7 @@ void dec32_pick_ex(const LinearWeight& w, int M, int* shape_out, int* splits_out
             }
         }
         *shape_out  = nshape;
-        *splits_out = env_int2("TM_D32_SPLITS", sp);
+        *splits_out = env_splits > 0 ? env_splits : sp;
         return;
     }
     int cgn, S;
@@ -1482,18 +1246,23 @@ void dec32_pick_ex(const LinearWeight& w, int M, int* shape_out, int* splits_out
             splits = s;
         }
     }
-    splits      = env_int2("TM_D32_SPLITS", splits);
+    splits      = env_splits > 0 ? env_splits : splits;
     *shape_out  = shape;
     *splits_out = splits < 1 ? 1 : (splits > KB ? KB : splits);
 }
 
 // y / slabs as launch_linear: *slabs_out = number of fp32 slabs written into `workspace` (1 = direct epilogue)
+bool dec32_tail_supported(const LinearWeight& w, int M)
+{
+    return dec32_supported(w, M) && M <= 64 && w.N % 8 == 0 && w.N <= kNormMaxThreads * kNormMaxVec * 8;
+}
+
 int launch_linear_dec32(const LinearWeight& w, const half_t* x, int ldx, half_t* y, int ldy, int M, bool gated_silu, int shape,
-                        int splits, float* workspace, int* slabs_out, hipStream_t st)
+                        int splits, float* workspace, int* slabs_out, hipStream_t st, const NormTail* tail)
 {
     TM_REQUIRE(w.packed32 != nullptr && w.N % 32 == 0, "decode GEMM: P32 layout missing");
-    TM_REQUIRE(M >= 1 && shape >= 0 && shape <= 11 && (shape == 10 ? M <= 64 : (shape >= 6 || (M <= 64) == (shape < 4))),
-               "decode GEMM: shapes 0..3 and 10 take M <= 64, shapes 4 / 5 take M > 64, shapes 6..9 and 11 any M");
+    TM_REQUIRE(M >= 1 && shape >= 0 && shape <= 9 && (shape >= 6 || (M <= 64) == (shape < 4)),
+               "decode GEMM: shapes 0..3 take M <= 64, shapes 4 / 5 take M > 64, shapes 6..9 any M");
     TM_REQUIRE(ldx % 8 == 0, "x rows must be 16-byte aligned");
     int cgn, S;
     dec32_shape_dims(shape, &cgn, &S);
@@ -1517,12 +1286,21 @@ int launch_linear_dec32(const LinearWeight& w, const half_t* x, int ldx, half_t*
     p.kb_per_split = per;
     p.epilogue     = splits > 1 ? 2 : (gated_silu ? 1 : 0);
     p.dbg          = g_gemm_dbg;
-    p.rotate       = env_int2("TM_D32_ROTATE", 0);
-    p.wt           = env_int2("TM_D32_WT", 1);  // measured (tools/trace_boundary.py, profiles/r02_gemm_boundary_gap.txt): -0.4..-0.9 us per split-K launch
-    dim3      grid((p.ncg + cgn - 1) / cgn, splits, shape == 10 ? 1 : shape >= 6 ? (M + 31) / 32 : shape >= 4 ? (M + 127) / 128 : 1);
-    const int rc = shape >= 10 ? ((shape == 11 || M <= 32) ? launch_dec64_one<1, 2, 4, 4, 2>(p, grid, st) :
-                                                            launch_dec64_one<2, 2, 4, 4, 2>(p, grid, st)) :
-                   shape >= 6 ? launch_dec32_shape<1>(p, grid, dec32_base_shape(shape), st) :
+    static const int wt = env_int2("TM_D32_WT", 1);  // measured (tools/trace_boundary.py, profiles/r02_gemm_boundary_gap.txt): -0.4..-0.9 us per split-K launch
+    p.wt           = wt;
+    if (tail) {  // slabs (also for ONE slice) consumed by the last workgroups of this launch: write-through stores are the publish
+        TM_REQUIRE(shape < 4 || shape >= 6, "in-launch consumer: decode tiles only");
+        TM_REQUIRE(workspace != nullptr && !gated_silu && M <= 64, "in-launch consumer: row-parallel decode linear with a slab workspace");
+        p.epilogue   = 2;
+        p.wt         = 1;
+        p.tail_y     = tail->y;
+        p.tail_resid = tail->resid;
+        p.tail_w     = tail->weight;
+        p.tail_eps   = tail->eps;
+        p.tail_sync  = tail->sync;
+    }
+    dim3      grid((p.ncg + cgn - 1) / cgn, splits, shape >= 6 ? (M + 31) / 32 : shape >= 4 ? (M + 127) / 128 : 1);
+    const int rc = shape >= 6 ? launch_dec32_shape<1>(p, grid, dec32_base_shape(shape), st) :
                    shape >= 4 ? launch_dec32_shape<4>(p, grid, shape, st) :
                    M <= 32    ? launch_dec32_shape<1>(p, grid, shape, st) :
                                 launch_dec32_shape<2>(p, grid, shape, st);
@@ -1530,7 +1308,7 @@ int launch_linear_dec32(const LinearWeight& w, const half_t* x, int ldx, half_t*
         return rc;
     }
     if (slabs_out) {
-        *slabs_out = splits;
+        *slabs_out = tail ? 0 : splits;
     }
     return 0;
 }

@@ -922,11 +922,14 @@ int launch_linear(const LinearWeight& w,
                   float*              workspace,
                   bool                defer_reduce,
                   int*                slabs,
-                  hipStream_t         st)
+                  hipStream_t         st,
+                  const NormTail*     tail)
 {
     if (slabs) {
         *slabs = 1;
     }
+    TM_REQUIRE(!tail || (cfg.d32_shape >= 0 && dec32_tail_supported(w, M) && workspace && !gated_silu),
+               "in-launch residual-norm consumer: decode kernel, M <= 64, a slab workspace");
     TM_REQUIRE(w.packed != nullptr, "linear weight not prepared");
     TM_REQUIRE(ldx % 8 == 0, "x rows must be 16-byte aligned");
     TM_REQUIRE(!gated_silu || w.N % 32 == 0, "gated epilogue needs N % 32 == 0");
@@ -936,12 +939,12 @@ int launch_linear(const LinearWeight& w,
     if (cfg.d32_shape >= 0 && dec32_supported(w, M)) {
         int       nslab = 1;
         const int sp    = workspace ? (cfg.splits < 1 ? 1 : cfg.splits) : 1;
-        TM_REQUIRE(!defer_reduce || sp > 1, "defer_reduce only with split-K");
-        const int rc = launch_linear_dec32(w, x, ldx, y, ldy, M, gated_silu, cfg.d32_shape, sp, workspace, &nslab, st);
+        TM_REQUIRE(!defer_reduce || sp > 1 || tail, "defer_reduce only with split-K");
+        const int rc = launch_linear_dec32(w, x, ldx, y, ldy, M, gated_silu, cfg.d32_shape, sp, workspace, &nslab, st, tail);
         if (rc) {
             return rc;
         }
-        if (nslab > 1 && !defer_reduce) {
+        if (nslab > 1 && !defer_reduce && !tail) {
             const size_t total = (size_t)M * w.N / 4;
             splitk_reduce_kernel<<<(total + 255) / 256, 256, 0, st>>>(y, ldy, workspace, nslab, M, w.N, gated_silu ? 1 : 0);
             TM_HIP_CHECK(hipGetLastError());

@@ -137,10 +137,22 @@ size_t gemm_workspace_bytes(int M, int N, int splits);
 int    launch_splitk_reduce(half_t* y, int ldy, const float* partial, int splits, int M, int N, bool gated, hipStream_t st);
 GemmConfig gemm_pick_config(const LinearWeight& w, int M);          // decode kernel when it applies, else ...
 GemmConfig gemm_pick_config_general(const LinearWeight& w, int M);  // ... the tiling of gemm_kernel (gemm_w4a16.hip)
+// In-launch consumer of a row-parallel decode linear (gemm_decode.hip, Dec32Params::tail_*): resid += fp16(sum of the split-K
+// slabs); y = RMSNorm(resid) * weight, executed by the last workgroups of the GEMM launch itself.  sync = 4 device words,
+// zero before the first use (the launch leaves them zero); sync[2] != 0 afterwards = a hand-off wait gave up (fatal).
+struct NormTail {
+    half_t*       y;
+    half_t*       resid;
+    const half_t* weight;
+    float         eps;
+    unsigned*     sync;
+};
+bool dec32_tail_supported(const LinearWeight& w, int M);  // decode kernel applies, M <= 64 rows, N within the norm's reach
 // y[M][N (or N/2 if gated)] = x[M][K] . W ; if cfg.splits > 1 fp32 slabs land in `workspace` and, unless
-// `defer_reduce`, a reduce kernel writes y.
+// `defer_reduce`, a reduce kernel writes y.  tail != nullptr (needs dec32_tail_supported and a workspace): the slabs are
+// consumed inside the launch, y is not written, *slabs = 0.
 int launch_linear(const LinearWeight& w, const half_t* x, int ldx, half_t* y, int ldy, int M, bool gated_silu,
-                  GemmConfig cfg, float* workspace, bool defer_reduce, int* slabs, hipStream_t st);
+                  GemmConfig cfg, float* workspace, bool defer_reduce, int* slabs, hipStream_t st, const NormTail* tail = nullptr);
 
 // ---- gemm_decode.hip: W4A16 decode GEMM (M <= 64), 32x32x16 MFMA, 16 waves per CU ------------------------------
 size_t p32_bytes(int K, int N);
@@ -156,7 +168,7 @@ int    dec32_table_export(const char* path);
 int    dec32_table_import(const char* path);
 int    dec32_candidates(const LinearWeight& w, int M, int (*out)[2], int cap);
 int    launch_linear_dec32(const LinearWeight& w, const half_t* x, int ldx, half_t* y, int ldy, int M, bool gated_silu, int shape,
-                           int splits, float* workspace, int* slabs_out, hipStream_t st);
+                           int splits, float* workspace, int* slabs_out, hipStream_t st, const NormTail* tail = nullptr);
 
 // ---- gemm_fp8.hip: fp8 x fp8 linear on v_mfma_f32_32x32x16_fp8_fp8 (activations quantised per row and 128 channels) ---
 size_t p8_bytes(int K, int N);

@@ -171,7 +171,12 @@ class Pipeline:
             if lp is None and len(in_engine) > 1:
                 lp = dict(stop_ids=in_engine[1:])
             try:
-                pending[self.engine.submit(p, gi.max_new_tokens, eos, gi.sampling_params(i), lp)] = i
+                # the reference clamps per request: generate until the session is full, then 'length' (async_engine.py:561-565)
+                room = self.session_len - len(p)
+                if len(p) < 1 or room < 1:
+                    raise _ffi.TmError(6, 'empty prompt' if len(p) < 1 else
+                                       f'prompt ({len(p)}) leaves no room for a new token in session_len ({self.session_len})')
+                pending[self.engine.submit(p, min(gi.max_new_tokens, room), eos, gi.sampling_params(i), lp)] = i
             except _ffi.TmError as e:
                 rt = STATUS_TO_RESPONSE.get(e.status, ResponseType.INTERNAL_ENGINE_ERROR)
                 out_of_engine.append(Response('', 0, len(p), 'error', [], index=i, error_code=rt.name, error_message=str(e)))
@@ -209,28 +214,32 @@ class Pipeline:
     def _generate_static(self, prompts: Sequence, g: GenerationConfig):
         ids = [self._encode(p) for p in prompts]
         stop = self._stop_ids(g)
-        # per-request admission on the host, as the continuous path and the reference do: a prompt that cannot fit its
-        # session is answered with INPUT_LENGTH_ERROR alone instead of failing the whole batch inside tm_engine_prefill
+        # per-request admission on the host as the reference does it (lmdeploy/serve/async_engine.py:561-565): only a prompt
+        # that leaves no room for a single new token (len >= session_len) is refused with INPUT_LENGTH_ERROR; otherwise the
+        # request generates until its session is full and finishes with 'length' (max_new_tokens clamped per request).
+        # Requests that need the clamp run in a chunk of their own: a static chunk shares one max_new_tokens.
         limit = self.session_len
-        order = []
+        chunks, plain = [], []
         for i, p in enumerate(ids):
-            if len(p) < 1 or len(p) + g.max_new_tokens > limit:
+            if len(p) < 1 or len(p) >= limit:
                 yield Response('', 0, len(p), 'error', [], index=i, error_code=ResponseType.INPUT_LENGTH_ERROR.name,
                                error_message='empty prompt' if len(p) < 1 else
-                               f'prompt ({len(p)}) + max_new_tokens ({g.max_new_tokens}) exceeds session_len ({limit})')
+                               f'prompt ({len(p)}) leaves no room for a new token in session_len ({limit})')
+            elif len(p) + g.max_new_tokens > limit:
+                chunks.append(([i], limit - len(p)))
             else:
-                order.append(i)
-        for b0 in range(0, len(order), self.max_batch_size):
-            idx = order[b0:b0 + self.max_batch_size]
+                plain.append(i)
+        chunks += [(plain[b0:b0 + self.max_batch_size], g.max_new_tokens) for b0 in range(0, len(plain), self.max_batch_size)]
+        for idx, max_new in sorted(chunks, key=lambda c: c[0][0]):
             chunk = [ids[i] for i in idx]
             try:
                 self.engine.set_sampling([g.sampling_params(i) for i in idx] if g.sampling_params() else None)
                 lp = g.logits_params(sorted(stop)[:_ffi.MAX_STOP_IDS])
                 self.engine.set_logits_params([lp] * len(chunk) if lp else None)
-                self.engine.prefill(chunk, max_new_tokens=g.max_new_tokens)
+                self.engine.prefill(chunk, max_new_tokens=max_new)
                 done = 1
-                while done < g.max_new_tokens:
-                    n = min(32, g.max_new_tokens - done)
+                while done < max_new:
+                    n = min(32, max_new - done)
                     self.engine.decode(n)
                     done += n
                     if stop:

@@ -89,6 +89,71 @@ def test_w4a16_linear_full_size(tm, cuda, K, N, gated, M):
         assert np.all(err <= tol), f'nt={nt} splits={splits} waves={waves:#x}: max err {err.max()} at {np.argmax(err - tol)}'
 
 
+def _candidates(tm, K, N, M):
+    sh, sp = np.zeros(128, np.int32), np.zeros(128, np.int32)
+    n = _ffi.C.c_int(0)
+    _ffi.check(tm.tm_debug_tiling_candidates(K, N, M, sh.ctypes.data, sp.ctypes.data, 128, _ffi.C.byref(n)))
+    return list(zip(sh[:n.value].tolist(), sp[:n.value].tolist()))
+
+
+# the four Llama-3-8B linears at batch 64 and the InternLM2-20B ones at batch 128 (BASELINE configs 2 / 3)
+TUNER_SHAPES = [(4096, 6144, 0, 64), (4096, 4096, 0, 64), (4096, 28672, 1, 64), (14336, 4096, 0, 64),
+                (6144, 8192, 0, 128), (6144, 6144, 0, 128), (6144, 32768, 1, 128), (16384, 6144, 0, 128)]
+
+
+@pytest.mark.parametrize('K,N,gated,M', TUNER_SHAPES)
+def test_w4a16_every_tuner_candidate_full_size(tm, cuda, K, N, gated, M):
+    """the timed configuration must be a tested tiling.  bench.py tunes at start-up and runs whatever
+    (shape, split-K) wins on that box -- so EVERY candidate the tuner can pick (tm_debug_tiling_candidates = the list
+    tune_decode_gemms walks, incl. the 32-row-block shapes 6..9 and split counts up to 16) is compared with the fp32 oracle
+    product at the full (K, N) of the model, plus the heuristic's own pick."""
+    h, wd = _linear(tm, K, N)
+    rng = np.random.default_rng(K + N + M + 1)
+    x = rng.standard_normal((M, K)).astype(f16)
+    acc = x.astype(np.float32) @ wd
+    ref = (o.gated_silu_epilogue(acc) if gated else acc.astype(f16)).astype(np.float32)
+    tol = 2e-3 + 2.0**-9 * np.abs(ref)
+    ws = torch.zeros(max(1, tm.tm_linear_workspace(h, M)), dtype=torch.uint8, device='cuda')
+    x_d = dev(x)
+    cands = _candidates(tm, K, N, M)
+    assert len(cands) >= 8, cands
+    hs, hp = _ffi.C.c_int(0), _ffi.C.c_int(0)
+    _ffi.check(tm.tm_debug_pick_tiling(K, N, M, 0, _ffi.C.byref(hs), _ffi.C.byref(hp)))
+    for shape, splits in cands + [(hs.value, hp.value)]:
+        y = torch.zeros((M, N // 2 if gated else N), dtype=torch.float16, device='cuda')
+        _ffi.check(tm.tm_linear_forward(h, x_d.data_ptr(), K, y.data_ptr(), y.shape[1], M, gated, 0, splits, 0x200 | shape, ws.data_ptr(), st()))
+        err = np.abs(host(y).astype(np.float32) - ref)
+        assert np.all(err <= tol), f'shape {shape} splits {splits}: max err {err.max()} at {np.argmax(err - tol)}'
+
+
+@pytest.mark.parametrize('K,N', [(4096, 4096), (14336, 4096)])
+def test_w4a16_in_launch_consumer_every_candidate_full_size(tm, cuda, K, N):
+    """wo / w2 of Llama-3-8B at batch 64 with the in-launch residual-norm consumer, every tiling the tuner can pick: residual
+    stream and normed output equal the two-launch sequence bit for bit (the consumer's own parity against the oracle:
+    tests/test_gpu_ops.py::test_w4a16_linear_residual_norm_in_launch_consumer)."""
+    M = 64
+    h, wd = _linear(tm, K, N)
+    rng = np.random.default_rng(K + N + 9)
+    x_d = dev(rng.standard_normal((M, K)).astype(f16))
+    r0 = rng.standard_normal((M, N)).astype(f16)
+    nw = dev((1 + 0.05 * rng.standard_normal(N)).astype(f16))
+    ws = torch.zeros(max(1, tm.tm_linear_workspace(h, M)) + M * N * 2, dtype=torch.uint8, device='cuda')
+    sync = torch.zeros(4, dtype=torch.int32, device='cuda')
+    n = 0
+    for shape, splits in _candidates(tm, K, N, M):
+        out = []
+        for fused in (0, 1):
+            y = torch.zeros((M, N), dtype=torch.float16, device='cuda')
+            r = dev(r0.copy())
+            _ffi.check(tm.tm_linear_residual_norm(h, x_d.data_ptr(), K, y.data_ptr(), r.data_ptr(), nw.data_ptr(), 1e-5, M, shape, splits, fused,
+                                                  ws.data_ptr(), sync.data_ptr(), st()))
+            out.append((host(y), host(r)))
+        assert np.array_equal(out[0][1].view(np.uint16), out[1][1].view(np.uint16)), f'shape {shape} splits {splits}: residual differs'
+        assert np.array_equal(out[0][0].view(np.uint16), out[1][0].view(np.uint16)), f'shape {shape} splits {splits}: normed output differs'
+        n += 1
+    assert n >= 8 and not host(sync).any()
+
+
 @pytest.mark.parametrize('K,N,gated', [(4096, 28672, 1), (14336, 4096, 0), (4096, 6144, 0)])
 @pytest.mark.parametrize('waves', [0, 0x204, 0x205])
 def test_w4a16_prefill_full_size(tm, cuda, K, N, gated, waves):
@@ -339,3 +404,144 @@ def test_full_width_layer_engine_vs_oracle(cuda):
             gp = got[data:data + L.kv_heads * 2 * 256].view(np.float16).reshape(L.kv_heads * 2, 64, 2)[:, :valid]
             rp = ref[data:data + L.kv_heads * 2 * 256].view(np.float16).reshape(L.kv_heads * 2, 64, 2)[:, :valid]
             assert ulp_diff_f16(gp, rp).max() <= 1, f'seq {b} block {i}: (scale, zero) differ'
+
+
+# ------------------------------------------------------------------------------------------------
+def _random_decoder_weights(cfg, rng, distinct=2):
+    """Random-code AWQ weights for a whole decoder (the fast form of _random_awq: every byte pattern is a legal state of the
+    format; the dequantisation rule is pinned by test_fast_dequant_equals_oracle).  `distinct` different sets of linear
+    weights are cycled over the layers (quantising / dequantising 218 M parameters per layer on the CPU is the slow part),
+    every layer has its own norm weights; the oracle's fp32 copy of each linear is filled in up front (`_dense`)."""
+    H, D, I = cfg.hidden, cfg.head_dim, cfg.inter
+    nq, nkv = cfg.q_heads * D, cfg.kv_heads * D
+
+    def lin(K, N):
+        _, s, z, wd, q = _random_awq(rng, K, N)
+        return dict(q=q, s=s, z=z, _dense=wd)
+    sets = [dict(w_qkv=lin(H, nq + 2 * nkv), wo=lin(nq, H), w1w3=lin(H, 2 * I), w2=lin(I, H)) for _ in range(distinct)]
+    layers = [dict(attn_norm=(1 + 0.02 * rng.standard_normal(H)).astype(f16), ffn_norm=(1 + 0.02 * rng.standard_normal(H)).astype(f16),
+                   **sets[li % distinct]) for li in range(cfg.layers)]
+    return dict(tok_embeddings=(0.02 * rng.standard_normal((cfg.vocab, H))).astype(f16), layers=layers,
+                norm=(1 + 0.02 * rng.standard_normal(H)).astype(f16),
+                output=(rng.standard_normal((H, cfg.vocab)) * (0.1 / math.sqrt(H))).astype(f16))
+
+
+def test_eight_full_width_layers_engine_vs_oracle(cuda):
+    """SURVEY 8(c) 'end-to-end tokens' at depth: EIGHT decoder layers at the Llama-3-8B width (H = 4096, 32 q / 8 kv
+    heads, inter 14336, int8 KV), prefill of three ragged prompts + 16 graph-replayed decode steps through the C++ engine
+    against the oracle model -- first-token and every decode step's logits, greedy tokens (teacher-forced with the engine's
+    tokens, equal wherever the oracle's top-2 margin exceeds twice the logit bound) and the residual stream after the last
+    layer.  Stated bound: |logit - oracle| <= 6e-2 at 8 layers (3e-2 at one layer: fp16 accumulation-order noise grows with
+    depth; the reference's own gate for fp16 end-to-end comparisons is 0.25 x scale, tests/turbomind/linear/fixture.py:34-42)."""
+    from lmdeploy_amd.turbomind.engine import Engine
+    from lmdeploy_amd.turbomind.loader import export_weights
+
+    cfg = o.ModelConfig(hidden=4096, layers=8, q_heads=32, kv_heads=8, head_dim=128, inter=14336, vocab=2048, kv_bits=8,
+                        rope=o.RopeParam(128, 500000.0, 'llama3', 8.0, 1.0, 4.0, 8192))
+    rng = np.random.default_rng(11)
+    w = _random_decoder_weights(cfg, rng)
+    lens = (40, 64, 21)
+    prompts = [rng.integers(0, cfg.vocab, n).astype(np.int32) for n in lens]
+    steps = 16
+    eng = Engine.from_model_config(cfg, max_batch_size=3, session_len=128, quant_policy=8, max_prefill_token_num=128, use_graph=1)
+    bare = dict(w, layers=[{k: ({f: a for f, a in v.items() if f != '_dense'} if isinstance(v, dict) else v) for k, v in L.items()}
+                           for L in w['layers']])     # without the oracle's fp32 copies
+    eng.load_weights(export_weights(cfg, bare))
+    eng.start()
+    eng.prefill(prompts, max_new_tokens=steps + 1)
+    logits = [eng.fetch_logits()]
+    resid = [eng.fetch_residual(sum(lens))]
+    for _ in range(steps):
+        eng.decode(1)
+        logits.append(eng.fetch_logits())
+        resid.append(eng.fetch_residual(len(lens)))
+    toks = eng.fetch()
+    eng.close()
+
+    om = o.OracleModel(cfg, w, batch=len(prompts), max_ctx=128)
+    ids, lg = om.forward(prompts)
+    worst = 0.0
+    for s in range(steps + 1):
+        d = np.abs(logits[s].astype(np.float32) - lg.astype(np.float32)).max()
+        worst = max(worst, float(d))
+        assert d <= 6e-2, f'step {s}: max logit diff {d}'
+        top2 = np.sort(lg.astype(np.float32), -1)[:, -2:]
+        safe = (top2[:, 1] - top2[:, 0]) > 1.2e-1
+        assert np.array_equal(toks[safe, s], ids[safe]), f'step {s}: greedy tokens differ'
+        r, rr = resid[s].astype(np.float32), om.last_resid.astype(np.float32)
+        assert r.shape == rr.shape
+        assert np.all(np.abs(r - rr) <= 2e-2 + 2.0**-7 * np.abs(rr)), f'step {s}: residual stream max diff {np.abs(r - rr).max()}'
+        if s < steps:
+            ids, lg = om.forward([[int(t)] for t in toks[:, s]])
+    print(f'8 full-width layers, {steps} decode steps: worst |logit - oracle| = {worst:.4f}')
+
+
+def test_decode_attention_split_sweep_with_canaries(tm, cuda):
+    """'an unexplained memory access fault in back-to-back int4 split-KV launches'.  ONE process loops split
+    counts 1 / 2 / 4 / 8 / 16 x int4 / int8 x plain / fused prologue, back to back and without synchronising in between,
+    three passes, at the shape the report came from (B = 64, 32 q / 8 kv heads, contexts around 1.1 k).  The cache pool and
+    the split workspace sit INSIDE larger allocations whose margins are filled with a canary pattern: an out-of-bounds
+    write of the kernels shows as a damaged canary instead of depending on what happens to be mapped next to the buffer.
+    Every launch must leave the canaries intact, equal the one-split result within the attention tolerance, and the
+    fused prologue must write the same cache bytes for every split count."""
+    rng = np.random.default_rng(77)
+    B, Hq, Hkv, layer = 64, 32, 8, 1
+    klen = rng.integers(1030, 1180, B).tolist()
+    klen[0], klen[1], klen[2] = 1088, 1089, 1151          # a block boundary, one past it, one short of it
+    CAN = 0xA5
+    pad = 1 << 20
+    qkv_n = (Hq + 2 * Hkv) * 128
+    rope = dev(rope_table_cached(tm))
+    for bits in (4, 8):
+        L = o.BlockLayout(2, Hkv, 128, 64, bits)
+        oc, tables, total = _random_cache(rng, L, klen)
+        # pool inside a canary-padded allocation (DevCache allocates its own pool: replace it with a view)
+        dc = DevCache(L, total, tables)
+        raw = torch.full((pad + total * L.block_size + pad,), CAN, dtype=torch.uint8, device='cuda')
+        dc.pool = raw[pad:pad + total * L.block_size].view(total, L.block_size)
+        dc.set_tables(tables)
+        pool0 = torch.from_numpy(oc.pool).cuda()
+        q = dev(rng.standard_normal((B, Hq * 128)).astype(f16))
+        qkv = dev(rng.standard_normal((B, qkv_n)).astype(f16))
+        kl = dev(np.asarray(klen, np.int32))
+        ws_bytes = tm.tm_decode_attention_workspace(B, Hq, 16)
+        ws_raw = torch.full((pad + ws_bytes + pad,), CAN, dtype=torch.uint8, device='cuda')
+        ws_ptr = ws_raw.data_ptr() + pad
+        base, base_f, bytes_f = None, None, None
+        for rep in range(3):
+            outs = []
+            for splits in (1, 2, 4, 8, 16):
+                dc.pool.copy_(pool0)
+                out = torch.zeros((B, Hq * 128), dtype=torch.float16, device='cuda')
+                outf = torch.zeros((B, Hq * 128), dtype=torch.float16, device='cuda')
+                _ffi.check(tm.tm_decode_attention(out.data_ptr(), q.data_ptr(), Hq * 128, kl.data_ptr(), B, Hq, 0.0, splits, ws_ptr,
+                                                  dc.view(layer), st()))
+                _ffi.check(tm.tm_decode_attention_fused(outf.data_ptr(), qkv.data_ptr(), 0, qkv_n, rope.data_ptr(), 8192, kl.data_ptr(), B, Hq,
+                                                        0.0, splits, ws_ptr, dc.view(layer), st()))
+                outs.append((splits, out, outf, dc.pool.clone()))
+            torch.cuda.synchronize()
+            assert bool((raw[:pad] == CAN).all()) and bool((raw[-pad:] == CAN).all()), f'bits {bits} pass {rep}: write outside the cache pool'
+            assert bool((ws_raw[:pad] == CAN).all()) and bool((ws_raw[-pad:] == CAN).all()), f'bits {bits} pass {rep}: write outside the workspace'
+            for splits, out, outf, pool in outs:
+                a, af = host(out).astype(np.float32), host(outf).astype(np.float32)
+                assert np.isfinite(a).all() and np.isfinite(af).all()
+                if base is None:
+                    base, base_f, bytes_f = a, af, host(pool)
+                    continue
+                assert np.all(np.abs(a - base) <= 1e-2 * np.abs(base) + 2e-3), f'bits {bits} pass {rep} splits {splits}: plain kernel'
+                assert np.all(np.abs(af - base_f) <= 1e-2 * np.abs(base_f) + 2e-3), f'bits {bits} pass {rep} splits {splits}: fused prologue'
+                assert np.array_equal(host(pool), bytes_f), f'bits {bits} pass {rep} splits {splits}: cache bytes differ'
+        # the one-split result itself against the fp64 reference on three sequences (longest, block boundary, one past it)
+        for b in (int(np.argmax(klen)), 0, 1):
+            Ks, Vs = [], []
+            for hd in range(Hkv):
+                kd, vd = oc.load_dequant(tables[b], layer, hd, 0, klen[b], 'decode')
+                Ks.append(kd)
+                Vs.append(vd)
+            ref64 = o.attention_reference_unfused(host(q)[b].reshape(Hq, 128), np.stack(Ks), np.stack(Vs))
+            assert np.abs(base[b].reshape(Hq, 128) - ref64).max() < 5e-3
+
+
+def rope_table_cached(tm):
+    from tests.gpu_helpers import rope_table
+    return rope_table(tm, 8192, o.RopeParam(128, 10000.0, 'default', 1.0, 1.0, 4.0, 8192))

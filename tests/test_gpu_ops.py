@@ -499,73 +499,6 @@ def test_w4a16_linear_prefill_tiles(tm, cuda, K, N, M, gated):
     _ffi.check(tm.tm_linear_destroy(h))
 
 
-@pytest.mark.parametrize('K,N,M,gated', [(4096, 6144, 64, 0), (1792, 4096, 33, 0), (256, 64, 40, 0), (4096, 1024, 64, 1), (1024, 2048, 50, 1)])
-@pytest.mark.parametrize('mode', [0, 0x100, 0x200, 0x300, 0x400, 0x500, 0x700, 0x800])
-def test_w4a16_decode_kernel_modes(tm, cuda, monkeypatch, K, N, M, gated, mode):
-    """Structure variants of the decode kernel (gemm_decode.hip): register staging + ds_write of the activations (0),
-    LDS-DMA staging (0x100), the LDS read scheduling fence (0x200), s_setprio around the MFMAs (0x400), the inline-asm
-    fragment pipeline without the DMA (0x800) and combinations (the default is 0x900) -- same oracle, same tolerance."""
-    monkeypatch.setenv('TM_D32_ABL', str(mode))
-    rng = np.random.default_rng(K + N + M + mode)
-    h, (q, s, z) = _make_linear(tm, rng, K, N)
-    x = rng.standard_normal((M, K)).astype(f16)
-    ref = (o.w4a16_linear_gated_silu(x, q, s, z) if gated else x.astype(np.float32) @ _QCACHE[(K, N)][3]).astype(np.float32)
-    ws = torch.zeros(max(1, tm.tm_linear_workspace(h, M)), dtype=torch.uint8, device='cuda')
-    for splits in (1, 2, 3):
-        if splits > max(1, K // 512):
-            continue
-        y = torch.zeros((M, N // 2 if gated else N), dtype=torch.float16, device='cuda')
-        _ffi.check(tm.tm_linear_forward(h, dev(x).data_ptr(), K, y.data_ptr(), y.shape[1], M, gated, 0, splits, 0x200, ws.data_ptr(), st()))
-        err = np.abs(host(y).astype(np.float32) - ref)
-        assert np.all(err <= 2e-3 + 2.0**-9 * np.abs(ref)), f'mode {mode:#x} splits={splits}: max err {err.max()}'
-    _ffi.check(tm.tm_linear_destroy(h))
-
-
-@pytest.mark.parametrize('K,N,M,gated', [(4096, 6144, 64, 0), (1792, 4096, 33, 0), (14336, 4096, 64, 0), (4096, 1024, 64, 1), (512, 2048, 50, 1)])
-def test_w4a16_decode_kernel_early_refill(tm, cuda, monkeypatch, K, N, M, gated):
-    """TM_D32_EARLY=1: four-stage weight ring refilled at the TOP of a stage (behind the activation DMA) instead of at its
-    end -- whole unrolled bodies, remainders of 1..3 stages, one-stage slices -- three launches each, bit-identical"""
-    monkeypatch.setenv('TM_D32_EARLY', '1')
-    rng = np.random.default_rng(K + N + M + 77)
-    h, (q, s, z) = _make_linear(tm, rng, K, N)
-    x = rng.standard_normal((M, K)).astype(f16)
-    ref = (o.w4a16_linear_gated_silu(x, q, s, z) if gated else x.astype(np.float32) @ _QCACHE[(K, N)][3]).astype(np.float32)
-    ws = torch.zeros(max(1, tm.tm_linear_workspace(h, M)), dtype=torch.uint8, device='cuda')
-    x_d = dev(x)
-    for splits in (1, 2, 3, 4, 7):
-        if splits > max(1, K // 512):
-            continue
-        first = None
-        for rep in range(3):
-            y = torch.zeros((M, N // 2 if gated else N), dtype=torch.float16, device='cuda')
-            _ffi.check(tm.tm_linear_forward(h, x_d.data_ptr(), K, y.data_ptr(), y.shape[1], M, gated, 0, splits, 0x200, ws.data_ptr(), st()))
-            got = host(y)
-            err = np.abs(got.astype(np.float32) - ref)
-            assert np.all(err <= 2e-3 + 2.0**-9 * np.abs(ref)), f'splits={splits} launch {rep}: max err {err.max()}'
-            first = got if first is None else first
-            assert np.array_equal(got.view(np.uint16), first.view(np.uint16))
-    _ffi.check(tm.tm_linear_destroy(h))
-
-
-@pytest.mark.parametrize('K,N,M,gated', [(4096, 6144, 300, 0), (1792, 4096, 129, 0), (1024, 2048, 1000, 1)])
-@pytest.mark.parametrize('mode', [0, 0x100])
-def test_w4a16_row_block_tile_modes(tm, cuda, monkeypatch, K, N, M, gated, mode):
-    """the 128-row tile of the decode kernel (M > 64) with register staging (0) and with LDS-DMA + compiler-scheduled
-    fragment reads (0x100); the default (LDS-DMA + the explicit fragment pipeline) is covered by the prefill-tile test"""
-    monkeypatch.setenv('TM_D32_ABL', str(mode))
-    rng = np.random.default_rng(K + N + M + mode)
-    h, (q, s, z) = _make_linear(tm, rng, K, N)
-    x = rng.standard_normal((M, K)).astype(f16)
-    ref = (o.w4a16_linear_gated_silu(x, q, s, z) if gated else x.astype(np.float32) @ _QCACHE[(K, N)][3]).astype(np.float32)
-    ws = torch.zeros(max(1, tm.tm_linear_workspace(h, M)), dtype=torch.uint8, device='cuda')
-    for splits in (1, 2):
-        y = torch.zeros((M, N // 2 if gated else N), dtype=torch.float16, device='cuda')
-        _ffi.check(tm.tm_linear_forward(h, dev(x).data_ptr(), K, y.data_ptr(), y.shape[1], M, gated, 0, splits, 0x204, ws.data_ptr(), st()))
-        err = np.abs(host(y).astype(np.float32) - ref)
-        assert np.all(err <= 2e-3 + 2.0**-9 * np.abs(ref)), f'mode {mode:#x} splits={splits}: max err {err.max()}'
-    _ffi.check(tm.tm_linear_destroy(h))
-
-
 @pytest.mark.parametrize('K,N,M,splits,waves', [(1792, 4096, 1000, 3, 0x204), (1792, 4096, 2500, 3, 0x204), (1536, 4096, 64, 1, 0x200),
                                                 (1536, 4096, 64, 3, 0x200), (4608, 4096, 64, 1, 0x201), (1536, 2048, 32, 1, 0x203)])
 def test_w4a16_odd_stage_count_is_stable(tm, cuda, K, N, M, splits, waves):
@@ -593,12 +526,10 @@ def test_w4a16_odd_stage_count_is_stable(tm, cuda, K, N, M, splits, waves):
 
 @pytest.mark.parametrize('K,N,gated', [(4096, 6144, 0), (1792, 4096, 0), (1024, 512, 0), (4096, 1024, 1), (384, 64, 0)])
 @pytest.mark.parametrize('M', [1, 32, 33, 50, 64, 100, 256])
-@pytest.mark.parametrize('shape', [6, 7, 8, 9, 10, 11])
+@pytest.mark.parametrize('shape', [6, 7, 8, 9])
 def test_w4a16_row_half_tiles(tm, cuda, K, N, M, gated, shape):
     """shapes 6 .. 9: the decode tilings on 32-row blocks (6: 64-column tiles over the WHOLE k range, no split-K slabs: the
     k-phases meet on chip -- the measured choice for the narrow projections) plus their split-K forms"""
-    if shape == 10 and M > 64:
-        pytest.skip('shape 10 = one 64-row block')
     rng = np.random.default_rng(K + N + M + 6)
     h, (q, s, z) = _make_linear(tm, rng, K, N)
     x = rng.standard_normal((M, K)).astype(f16)
@@ -612,6 +543,95 @@ def test_w4a16_row_half_tiles(tm, cuda, K, N, M, gated, shape):
         _ffi.check(tm.tm_linear_forward(h, x_d.data_ptr(), K, y.data_ptr(), y.shape[1], M, gated, 0, splits, 0x200 | shape, ws.data_ptr(), st()))
         err = np.abs(host(y).astype(np.float32) - ref)
         assert np.all(err <= 2e-3 + 2.0**-9 * np.abs(ref)), f'shape {shape} splits={splits}: max err {err.max()}'
+    _ffi.check(tm.tm_linear_destroy(h))
+
+
+def _residual_norm_case(tm, rng, K, N, M):
+    h, (q, s, z) = _make_linear(tm, rng, K, N)
+    ws = torch.zeros(max(1, tm.tm_linear_workspace(h, M)) + M * N * 2, dtype=torch.uint8, device='cuda')
+    sync = torch.zeros(4, dtype=torch.int32, device='cuda')
+    nw = (1 + 0.05 * rng.standard_normal(N)).astype(f16)
+    return h, (q, s, z), ws, sync, nw
+
+
+@pytest.mark.parametrize('K,N', [(4096, 4096), (14336, 4096), (1792, 2048), (1024, 8192), (512, 64)])
+@pytest.mark.parametrize('M', [1, 33, 64])
+def test_w4a16_linear_residual_norm_in_launch_consumer(tm, cuda, K, N, M):
+    """tm_linear_residual_norm: the row-parallel linear closed by split-K reduce + residual + RMSNorm INSIDE the GEMM launch
+    (the last workgroups of the launch consume the slabs; unified_decoder.cc:149,226 + rms_norm.cu:286-362) against the
+    two-launch sequence (GEMM, then the reduce-norm kernel): residual stream and normed output bit for bit, for every decode
+    tile and split count; the hand-off words are left zero; the unfused result is checked against the oracle."""
+    rng = np.random.default_rng(K + N + M + 3)
+    h, (q, s, z), ws, sync, nw = _residual_norm_case(tm, rng, K, N, M)
+    x = rng.standard_normal((M, K)).astype(f16)
+    r0 = rng.standard_normal((M, N)).astype(f16)
+    lin = (x.astype(np.float32) @ _QCACHE[(K, N)][3]).astype(f16)
+    r_ref, y_ref = o.residual_rmsnorm(r0, lin, nw, 1e-5)
+    x_d, nw_d = dev(x), dev(nw)
+    n_checked = 0
+    for shape in (-1, 0, 1, 2, 3, 6, 7, 8, 9):
+        if shape >= 6 and M <= 32:
+            continue    # one row block: identical to the base shape
+        for splits in (0, 1, 2, 4, 7):
+            if splits > max(1, K // 512) or (shape == -1 and splits):
+                continue
+            out = []
+            for fused in (0, 1):
+                y = torch.zeros((M, N), dtype=torch.float16, device='cuda')
+                r = dev(r0.copy())
+                _ffi.check(tm.tm_linear_residual_norm(h, x_d.data_ptr(), K, y.data_ptr(), r.data_ptr(), nw_d.data_ptr(), 1e-5, M, shape,
+                                                      splits, fused, ws.data_ptr(), sync.data_ptr(), st()))
+                out.append((host(y), host(r)))
+            (y0, rr0), (y1, rr1) = out
+            assert np.array_equal(rr0.view(np.uint16), rr1.view(np.uint16)), f'shape {shape} splits {splits}: residual differs'
+            assert np.array_equal(y0.view(np.uint16), y1.view(np.uint16)), f'shape {shape} splits {splits}: normed output differs'
+            assert not host(sync).any(), f'shape {shape} splits {splits}: hand-off words not left zero: {host(sync)}'
+            assert np.all(np.abs(rr0.astype(np.float32) - r_ref.astype(np.float32)) <= 4e-3 + 2.0**-9 * np.abs(r_ref.astype(np.float32)))
+            assert np.all(np.abs(y0.astype(np.float32) - y_ref.astype(np.float32)) <= 8e-3 + 2.0**-8 * np.abs(y_ref.astype(np.float32)))
+            n_checked += 1
+    assert n_checked >= 3
+    _ffi.check(tm.tm_linear_destroy(h))
+
+
+@pytest.mark.parametrize('K,N,shape,splits', [(4096, 4096, 6, 2), (14336, 4096, 3, 4), (4096, 4096, 0, 4)])
+def test_w4a16_in_launch_consumer_back_to_back_under_load(tm, cuda, K, N, shape, splits):
+    """The hand-off of the in-launch consumer under the conditions that expose stale reads (cdna_hip_programming.md Guideline 16:
+    re-reads of lines another workgroup has rewritten, uneven load): 60 launches back to back on one stream, alternating between
+    two inputs so that every slab word changes between consecutive launches, while a second stream streams 1 GB copies
+    through the memory system.  Every launch equals the two-launch sequence bit for bit."""
+    M = 64
+    rng = np.random.default_rng(K + N + shape)
+    h, (q, s, z), ws, sync, nw = _residual_norm_case(tm, rng, K, N, M)
+    xs = [dev(rng.standard_normal((M, K)).astype(f16)) for _ in range(2)]
+    r0 = rng.standard_normal((M, N)).astype(f16)
+    nw_d = dev(nw)
+    want = []
+    for i in range(2):
+        y = torch.zeros((M, N), dtype=torch.float16, device='cuda')
+        r = dev(r0.copy())
+        _ffi.check(tm.tm_linear_residual_norm(h, xs[i].data_ptr(), K, y.data_ptr(), r.data_ptr(), nw_d.data_ptr(), 1e-5, M, shape, splits, 0,
+                                              ws.data_ptr(), sync.data_ptr(), st()))
+        want.append((host(y), host(r)))
+    assert not np.array_equal(want[0][0], want[1][0])
+    n = 60
+    ys = torch.zeros((n, M, N), dtype=torch.float16, device='cuda')
+    rs = torch.from_numpy(np.broadcast_to(r0, (n, M, N)).copy()).cuda()
+    side = torch.cuda.Stream()
+    big = torch.empty(1 << 28, dtype=torch.float32, device='cuda')
+    big2 = torch.empty_like(big)
+    torch.cuda.synchronize()
+    with torch.cuda.stream(side):
+        for _ in range(6):
+            big2.copy_(big)
+    for i in range(n):
+        _ffi.check(tm.tm_linear_residual_norm(h, xs[i & 1].data_ptr(), K, ys[i].data_ptr(), rs[i].data_ptr(), nw_d.data_ptr(), 1e-5, M, shape,
+                                              splits, 1, ws.data_ptr(), sync.data_ptr(), st()))
+    torch.cuda.synchronize()
+    ys_h, rs_h = host(ys), host(rs)
+    for i in range(n):
+        assert np.array_equal(rs_h[i].view(np.uint16), want[i & 1][1].view(np.uint16)), f'launch {i}: residual differs'
+        assert np.array_equal(ys_h[i].view(np.uint16), want[i & 1][0].view(np.uint16)), f'launch {i}: normed output differs'
+    assert not host(sync).any()
     _ffi.check(tm.tm_linear_destroy(h))
 
 

@@ -165,7 +165,7 @@ def test_streaming_deltas_and_final_responses(pipe):
 
 def test_errors_become_responses_and_processors_reach_the_engine(pipe):
     g = GenerationConfig(max_new_tokens=8, ignore_eos=True, repetition_penalty=1.2, min_new_tokens=2, bad_token_ids=[5])
-    ok, too_long = list(range(10)), list(range(60))                        # 60 + 8 > session_len 64
+    ok, too_long, tight = list(range(10)), list(range(64)), list(range(60))   # 64 >= session_len 64; 60 + 8 > 64: room for 4
     res = pipe([ok, too_long, ok], g)
     assert [r.index for r in res] == [0, 1, 2]
     assert res[1].finish_reason == 'error' and res[1].error_code == 'INPUT_LENGTH_ERROR' and res[1].token_ids == []
@@ -175,6 +175,12 @@ def test_errors_become_responses_and_processors_reach_the_engine(pipe):
     assert [r.index for r in res2] == [0, 1]
     assert res2[0].finish_reason == 'error' and res2[0].error_code == 'INPUT_LENGTH_ERROR' and res2[0].token_ids == []
     assert res2[1].finish_reason == 'length' and res2[1].token_ids == _expect(ok, 8)[0]
+    # a prompt that fits but lies within max_new_tokens of the session end is NOT refused (the reference rejects only
+    # input_len >= session_len, async_engine.py:561-565): it generates until the session is full and ends with 'length'
+    for res3 in (pipe([tight, ok], g), pipe([ok, tight, ok], g)):
+        r = [x for x in res3 if x.input_token_len == 60][0]
+        assert r.finish_reason == 'length' and r.token_ids == _expect(tight, 4)[0]
+        assert all(x.token_ids == _expect(ok, 8)[0] for x in res3 if x.input_token_len == 10)
     lp = g.logits_params([])
     # greedy (do_sample=False): the penalty is reset to 1.0 like the reference does (async_engine.py:424-430) ...
     assert lp == dict(repetition_penalty=pytest.approx(1.0), min_new_tokens=2, bad_ids=[5], stop_ids=[])
