@@ -129,6 +129,34 @@ def measure_attention_traffic(args, ctx_prof):
         shutil.rmtree(tmp, ignore_errors=True)
 
 
+class Watchdog:
+    """Multi-GPU runs only: a rank that makes no progress (a collective that never completes, a peer that died before its
+    first step) would otherwise hang until the launcher's own limit.  Every phase of the run re-arms the timer; when it
+    fires the rank says which phase stalled and exits with code 3 -- the record then shows a cause instead of a timeout."""
+
+    def __init__(self, enabled, rank):
+        import threading
+        self.enabled, self.rank, self.phase, self.deadline = enabled, rank, 'start', None
+        self._lock = threading.Lock()
+        if enabled:
+            threading.Thread(target=self._run, daemon=True).start()
+
+    def arm(self, phase, seconds):
+        with self._lock:
+            self.phase, self.deadline = phase, time.monotonic() + seconds
+
+    def _run(self):
+        while True:
+            time.sleep(1.0)
+            with self._lock:
+                late = self.deadline is not None and time.monotonic() > self.deadline
+                phase = self.phase
+            if late:
+                print(f'bench.py: rank {self.rank} made no progress in phase "{phase}" within its time limit -- giving up '
+                      f'(exit 3); TM_COMM=native / TM_GRAPH_COMM=0 select the other collective paths', file=sys.stderr, flush=True)
+                os._exit(3)
+
+
 def main():
     # multi-process GPU work on this pool needs dmabuf IPC (RCCL's P2P setup fails with the legacy mode:
     # "hipIpcGetMemHandle: invalid argument"); already exported on the driver's boxes, kept here for hand launches
@@ -192,27 +220,62 @@ def main():
     eng = Engine.from_model_config(_Cfg(model), weight_type=weight_type, tp=world, rank=rank, device=local_rank, max_batch_size=B,
                                    session_len=S + max_new + 1, quant_policy=args.quant_policy,
                                    max_prefill_token_num=8192, use_graph=0 if args.no_graph else 1)
+    dog = Watchdog(world > 1, rank)
+    comm_note = ''
     if world > 1:
+        dog.arm('communicator set-up', 300)
+
+        def gather(h):
+            out = [None] * world
+            dist.all_gather_object(out, h)
+            return out
+        want_native = os.environ.get('TM_COMM', 'rccl') == 'native'
         uid = [Engine.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(uid, src=0)
-        eng.comm_init(uid[0])
-        if os.environ.get('TM_COMM', 'rccl') == 'native':     # fused P2P all-reduce + norm for the decode steps (opt-in)
-            def gather(h):
-                out = [None] * world
-                dist.all_gather_object(out, h)
-                return out
+        rccl_ok = True
+        try:
+            eng.comm_init(uid[0])
+        except Exception as exc:        # noqa: BLE001 -- RCCL could not be brought up on this node: the native communicator remains
+            rccl_ok = False
+            print(f'[bench] rank {rank}: RCCL communicator failed ({exc}); trying the native P2P communicator', file=sys.stderr)
+        oks = gather(rccl_ok)
+        if not all(oks):                # a collective path needs EVERY rank: fall back together
+            comm_note = f'RCCL init failed on ranks {[r for r, ok in enumerate(oks) if not ok]} -> native P2P communicator'
+            want_native = True
+            eng.comm_drop_rccl()
+        if want_native:                 # fused P2P all-reduce + residual + RMSNorm for the decode steps
             eng.comm_native_setup(gather, rows=max(B, 1))
     elif emu > 1:
         eng.comm_init(Engine.comm_unique_id())
+    dog.arm('weights + engine start', 600)
     eng.init_synthetic(seed=0)          # same seed on every rank: shards are generated per rank-local shape
     eng.start()
-    tuned = bool(args.tune) and world == 1 and emu <= 1 and B <= 256 and not child
-    if tuned:                           # start-up work like the reference's TM_GEMM_TUNE warm-up: not in any timed region
-        try:
-            eng.tune_gemm(B)
-        except Exception as exc:        # noqa: BLE001 -- the heuristics are the measured winners on these shapes anyway
-            print(f'[bench] GEMM tuning skipped: {exc}', file=sys.stderr)
-            tuned = False
+    # measured GEMM dispatch (start-up work like the reference's TM_GEMM_TUNE warm-up: not in any timed region).  tp > 1: rank 0
+    # times the candidates on ITS shard shapes (all ranks hold the same shapes) and the table is broadcast, so that every rank
+    # runs identical tilings (a rank-local winner could differ by noise and desynchronise the ranks' step times)
+    tuned = bool(args.tune) and emu <= 1 and B <= 256 and not child
+    if tuned:
+        dog.arm('GEMM tuning', 600)
+        import tempfile
+        table = None
+        if rank == 0:
+            try:
+                with tempfile.TemporaryDirectory() as td:
+                    path = os.path.join(td, 'gemm_table.txt')
+                    eng.tune_gemm(B, path)
+                    table = open(path).read()
+            except Exception as exc:    # noqa: BLE001 -- the heuristics are the measured winners on these shapes anyway
+                print(f'[bench] GEMM tuning skipped: {exc}', file=sys.stderr)
+        if world > 1:
+            box = [table]
+            dist.broadcast_object_list(box, src=0)
+            table = box[0]
+            if table and rank != 0:
+                with tempfile.TemporaryDirectory() as td:
+                    path = os.path.join(td, 'gemm_table.txt')
+                    open(path, 'w').write(table)
+                    eng.import_gemm_table(path)
+        tuned = bool(table)
 
     gen = torch.Generator().manual_seed(0)
     prompts = torch.randint(0, model['vocab'], (B, S), generator=gen, dtype=torch.int32).numpy()
@@ -223,6 +286,7 @@ def main():
         if world > 1:
             dist.barrier()
 
+    dog.arm('prefill', 600)
     barrier()
     t0 = time.perf_counter()
     eng.prefill(list(prompts), max_new_tokens=max_new)
@@ -230,12 +294,15 @@ def main():
     prefill_s = time.perf_counter() - t0
     ttft = eng.prefill_times_ms()
 
+    dog.arm('decode warm-up (graph capture)', 600)
     eng.decode(W)                       # untimed warm-up (includes the graph capture)
     barrier()
+    dog.arm('timed decode steps', 300 + K)
     t0 = time.perf_counter()
     eng.decode(K)                       # exactly K steps
     barrier()
     dt = time.perf_counter() - t0
+    dog.arm('after the timed region', 1800)
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -269,6 +336,14 @@ def main():
                     ms_per_step=round((dt + dt_r) / (K + R) * 1e3, 4))
     toks = eng.fetch()
     stats = eng.stats()
+    cinfo = eng.comm_info()
+    # the tilings the timed steps ran (measured table first, then the heuristic): per decode linear (shape, split-K) at M = B
+    hq_l, hkv_l = model['q_heads'] // world, max(1, model['kv_heads'] // world)
+    D_, H_, I_l = model['head_dim'], model['hidden'], model['inter'] // world
+    tilings = {}
+    if weight_type == 0 and not model.get('moe_experts') and B <= 256:
+        for name, (kk, nn) in dict(w_qkv=(H_, (hq_l + 2 * hkv_l) * D_), wo=(hq_l * D_, H_), w1w3=(H_, 2 * I_l), w2=(I_l, H_)).items():
+            tilings[name] = dict(zip(('shape', 'splits'), Engine.pick_tiling(kk, nn, B)))
     if weight_type != 0 or model.get('moe_experts'):
         # formats other than AWQ u4 / MoE: the weight bytes are what the engine actually streams (packed weights + scales +
         # lm_head); with batch 64 and top-2 of 8 every expert is hit every step
@@ -285,14 +360,23 @@ def main():
             'config': {'workload': f'Llama-3-8B shapes, W4A16 AWQ g128 random weights, quant_policy={args.quant_policy} '
                                    f'KV, batch {B}, {S}-token random prompts, greedy decode, TP={world}',
                        'batch': B, 'prompt_len': S, 'ctx_first_timed_step': ctx_first, 'ctx_mean': ctx_mean,
-                       'parallelism': f'tp{world}', 'rccl_ranks': world if world > 1 else 0, 'decode_splits': stats['decode_splits'], 'hipgraph': not args.no_graph,
-                       'gemm_dispatch': 'measured at start-up (tm_engine_tune_gemm)' if tuned else 'heuristic'},
+                       'parallelism': f'tp{world}', 'collectives': cinfo['backend'], 'rccl_ranks': cinfo['ranks'] if world > 1 else 0,
+                       'decode_splits': stats['decode_splits'], 'hipgraph': cinfo['hipgraph'],
+                       'gemm_dispatch': ('measured at start-up (tm_engine_tune_gemm' + (', rank 0\'s table broadcast' if world > 1 else '') + ')')
+                                        if tuned else 'heuristic',
+                       'gemm_tilings': tilings},
             'ttft_p50_ms': round(float(np.median(ttft)), 2), 'prefill_total_s': round(prefill_s, 3),
             'prefill_tokens_per_s': round(B * S / prefill_s, 1),
             'step_roofline': {'bound': 'hbm', 'algorithmic_bytes_per_step': int(step_bytes),
                               'achieved': round(step_bytes / (dt / K) / 1e9, 1), 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
                               'frac': round(step_bytes / (dt / K) / 1e9 / HBM_PEAK_GBPS, 4)},
         }
+        if comm_note:
+            out['config']['collectives_note'] = comm_note
+        if world > 1 or emu > 1:
+            out['scaling_note'] = ('no 1 -> 8 GPU scaling curve of this engine has been measured on hardware before this run: the tensor-parallel '
+                                   'path was validated on one device only (two processes on one GPU over the native communicator, 1-rank RCCL, '
+                                   'gloo world-size-2 CPU tests)')
         if args.model != 'llama3_8b':
             out['metric'] = f'decode tokens/sec, {args.model} W4A16 quant_policy={args.quant_policy} batch {B} (NOT the headline config)'
             out['config']['workload'] = out['config']['workload'].replace('Llama-3-8B', args.model)
@@ -309,7 +393,9 @@ def main():
             traffic, traffic_src = None, 'skipped'
             if not args.no_traffic and not child and world == 1:
                 traffic, traffic_src = measure_attention_traffic(args, ctx_prof)
-            out['roofline'] = {'bound': 'hbm', 'kernel': 'decode_attention_i8_mfma_kernel' if args.quant_policy == 8 else 'decode_attention_kernel',
+            attn_kernel = {8: 'decode_attention_i8_mfma_kernel<fused, 8>', 4: 'decode_attention_i8_mfma_kernel<fused, 4> (int4 codes expanded to '
+                           'bytes on the way into LDS)'}.get(args.quant_policy, 'decode_attention_kernel<16> (fp16 KV, VALU)')
+            out['roofline'] = {'bound': 'hbm', 'kernel': attn_kernel,
                                'achieved': round(ach, 1), 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
                                'frac': round(ach / HBM_PEAK_GBPS, 4), 'traffic': traffic, 'traffic_source': traffic_src,
                                'bytes_per_launch': int(per_launch_bytes), 'us_per_launch': round(per_launch_s * 1e6, 2),

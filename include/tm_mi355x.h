@@ -237,8 +237,9 @@ int tm_p2p_allreduce_norm(void* const* segs, int tp, int me, void* state, int ro
 int tm_p2p_allgather(void* const* segs, int tp, int me, void* state, int rows, int H, const void* src, void* dst, int words,
                      tm_stream_t st);
 
-/* debug / measurement: device buffer of [workgroups][4] uint64 that receives s_memrealtime stamps (100 MHz:
- * kernel entry, loop entry, loop exit, exit) of every GEMM workgroup launched afterwards; NULL switches it off. */
+/* debug / measurement: device buffer of 8192 x 8 uint64 (512 KB) that receives s_memrealtime stamps (100 MHz: kernel
+ * entry, loop entry, loop exit, exit, ...) of every GEMM / decode-attention workgroup launched afterwards; launches of more
+ * than 8192 workgroups are not traced; NULL switches it off. */
 int tm_debug_set_gemm_trace(void* dev_buf);
 /* Host-only: the (workgroup shape, split-K) the decode GEMM dispatch picks for a W4A16 linear of K x N at M rows --
  * use_table != 0: the measured table first (tm_engine_tune_gemm / tm_gemm_import), then the heuristic; 0: heuristic only.
@@ -298,6 +299,7 @@ int tm_comm_unique_id(void* host_out128);
 int tm_engine_comm_init(tm_engine* e, const void* host_id128);
 /* native communicator (opt-in; see tm_p2p_* below): export = allocate this rank's segment, return its IPC handle; import =
  * map the tp ranks' handles (rank order) and route the row-parallel all-reduces of forwards with <= rows tokens through it */
+int tm_engine_comm_drop_rccl(tm_engine* e);   /* continue on the native communicator alone (every rank must call it) */
 int tm_engine_comm_native_export(tm_engine* e, int rows, void* handle64);              /* after tm_engine_comm_init */
 int tm_engine_comm_native_import(tm_engine* e, const void* handles, int count);        /* count = tp handles, rank order */
 
@@ -452,6 +454,12 @@ int tm_sched_forget(tm_sched* s, int64_t req_id);
 /* the engine's stream (hipStream_t) so callers can bracket it with their own events */
 tm_stream_t tm_engine_stream(tm_engine* e);
 /* introspection for benchmarks: bytes of quantised weights + scales + lm_head, KV bytes per token, #blocks */
+/* What the tensor-parallel data path of this engine actually runs on (for benchmark records; any pointer may be NULL):
+ * backend: 0 = no collectives (tp = 1), bit 0 = RCCL communicator up (comm/nccl/nccl.cu:356-398), bit 1 = native P2P communicator
+ * imported (comm/cuda_ipc role); ranks = the communicator's own rank count (ncclCommCount), not the launcher's world size;
+ * graph_captured: 1 = decode steps replay a hipGraph (collectives captured inside), 0 = eager launches (never captured yet,
+ * use_graph = 0, or the capture with collectives failed and the engine fell back). */
+int tm_engine_comm_info(tm_engine* e, int* backend, int* ranks, int* graph_captured);
 int tm_engine_stats(tm_engine* e, int64_t* weight_bytes, int64_t* kv_bytes_per_token, int64_t* num_blocks,
                     int* decode_splits);
 

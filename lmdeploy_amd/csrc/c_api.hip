@@ -620,9 +620,14 @@ int tm_p2p_segment_create(size_t bytes, void** dev_ptr, void* handle64)
     TM_REQUIRE(dev_ptr && handle64 && bytes > 0, "null pointer");
     static_assert(sizeof(hipIpcMemHandle_t) == 64, "IPC handle size");
     void* p = nullptr;
-    // flags are polled mid-kernel by other devices: fine-grained (uncached across devices) memory when the runtime offers it
+    // Flags and tiles are written and polled MID-KERNEL by other devices: that needs fine-grained (device-coherent) memory.
+    // On coarse-grained hipMalloc memory a flag another device wrote is not guaranteed to become visible before the kernel
+    // ends, so there is no silent fall-back: the caller stays on RCCL instead (TM_P2P_COARSE_OK=1 overrides, for experiments).
     if (hipExtMallocWithFlags(&p, bytes, hipDeviceMallocFinegrained) != hipSuccess) {
         (void)hipGetLastError();
+        const char* ok = getenv("TM_P2P_COARSE_OK");
+        TM_REQUIRE(ok && atoi(ok), "native communicator: fine-grained device memory is unavailable (hipExtMallocWithFlags failed)");
+        fprintf(stderr, "[tm] native communicator on COARSE-grained memory (TM_P2P_COARSE_OK=1): cross-device visibility is not guaranteed\n");
         TM_HIP_CHECK(hipMalloc(&p, bytes));
     }
     TM_HIP_CHECK(hipMemset(p, 0, bytes));

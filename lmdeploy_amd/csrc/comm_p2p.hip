@@ -24,7 +24,8 @@
 // buffer (c & 1) -- by the time this rank overwrites that buffer (step 0 of call c+2) nobody reads it any more.
 // p2p_allgather_kernel runs the same steps 0-2 and 4 around a copy of every rank's n bytes (the lm_head's (value, index)
 // candidates); every rank issues the same sequence of calls, so both kernels share the epoch counter.
-// Every spin is bounded: on a timeout the kernel records the epoch in state[3] and carries on (wrong numbers, no hang).
+// Every spin is bounded: on a timeout the kernel records the epoch in state[3] and carries on (wrong numbers, no hang); the
+// engine reads state[3] at its host synchronisation points and fails the step (engine.hip: device_marks_check).
 //
 // Status: protocol and arithmetic run on ONE GPU only in this round -- tests/test_gpu_p2p.py (tp ranks = tp streams, and tp
 // PROCESSES that map each other's segments through IPC handles) and tests/test_gpu_tp.py (a tp = 2 engine as two processes
@@ -212,6 +213,23 @@ __global__ __launch_bounds__(256) void p2p_allgather_kernel(P2pParams p)
     p2p_exit(p, epoch);
 }
 
+// token rows one launch may carry = workgroups of `threads` threads that are resident at once on the current device
+int p2p_allreduce_capacity(int threads, bool one_vec)
+{
+    int dev = 0, cus = 0, per_cu = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    const void* k = one_vec ? (const void*)p2p_allreduce_norm_kernel<1> : (const void*)p2p_allreduce_norm_kernel<2>;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k, threads, 0) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    per_cu = per_cu > 1 ? per_cu - 1 : per_cu;
+    return per_cu * cus;
+}
+
 // data[r]: the two-tile region (2 * tile elements) of rank r's segment, flags[r]: its flag array, both as mapped by THIS rank
 // (index me = local pointers); state: 4 zero-initialised local words; partial: this rank's [M][H] sums, M <= tile / H rows
 int launch_p2p_allreduce_norm(half_t* const* data, uint32_t* const* flags, int tp, int me, uint32_t* state, size_t tile,
@@ -234,7 +252,12 @@ int launch_p2p_allreduce_norm(half_t* const* data, uint32_t* const* flags, int t
     const int nvec = H / 8;
     int       t    = (nvec + 63) / 64 * 64;
     t              = t > 512 ? 512 : t;
-    if ((nvec + t - 1) / t == 1) {
+    const bool one = (nvec + t - 1) / t == 1;
+    // Every workgroup of the launch waits for the LAST local ticket before the epoch is published, so all M of them must be
+    // resident at once: M is capped by what the occupancy query says fits on the chip (one below it per CU when more than one
+    // fits: the query is one block per CU high for some SGPR counts, MI355X_MICROARCH.md "Residency and cooperative launch")
+    TM_REQUIRE(M <= p2p_allreduce_capacity(t, one), "p2p all-reduce: more token rows than workgroups that are resident at once");
+    if (one) {
         p2p_allreduce_norm_kernel<1><<<M, t, 0, st>>>(p);
     }
     else {

@@ -420,7 +420,10 @@ static int prepare_linear(tm_engine* e, LinearSlots& l)
     if (l.w.type == TM_WEIGHT_U4) {
         Slot &q = e->slots[l.prefix + ".qweight"], &s = e->slots[l.prefix + ".scales"], &z = e->slots[l.prefix + ".zeros"];
         TM_REQUIRE(q.filled && s.filled && z.filled, "weight not loaded: " + l.prefix);
-        TM_TRY(linear_weight_prepare_u4(l.w, (const int32_t*)q.dev, (const half_t*)s.dev, (const half_t*)z.dev, e->stream));
+        // dense linears whose every M goes to gemm_decode.hip keep ONE HBM image (P32); MoE experts run the grouped mode of
+        // gemm_kernel and keep the 16-column image as well
+        const bool p32_only = l.prefix.find(".experts.") == std::string::npos && dec32_serves_every_m(l.w.K, l.w.N);
+        TM_TRY(linear_weight_prepare_u4(l.w, (const int32_t*)q.dev, (const half_t*)s.dev, (const half_t*)z.dev, e->stream, p32_only));
         TM_HIP_CHECK(hipStreamSynchronize(e->stream));
         for (Slot* p : {&q, &s, &z}) {
             TM_HIP_CHECK(hipFree(p->dev));
@@ -952,6 +955,18 @@ int tm_engine_comm_init(tm_engine* e, const void* host_id128)
     return 0;
 }
 
+// Forget the RCCL communicator (a tensor-parallel job whose ranks could not ALL bring RCCL up continues on the native P2P
+// communicator alone: a rank that kept its communicator would call ncclAllReduce for large forwards while its peers do not)
+int tm_engine_comm_drop_rccl(tm_engine* e)
+{
+    TM_REQUIRE(e, "null pointer");
+    if (e->comm) {
+        (void)ncclCommDestroy(e->comm);
+        e->comm = nullptr;
+    }
+    return 0;
+}
+
 // Native communicator set-up, two calls around one host-side exchange (any transport: the caller's torch.distributed /
 // MPI / files): export allocates this rank's segment and returns its 64-byte IPC handle; import takes the tp handles in rank
 // order, maps the peers' segments and switches the row-parallel all-reduces with M <= rows (every M when tm_engine_comm_init
@@ -964,6 +979,13 @@ int tm_engine_comm_native_export(tm_engine* e, int rows, void* handle64)
     TM_REQUIRE(!e->p2p_seg, "native communicator: already exported");
     TM_REQUIRE(rows >= 1 && rows <= 1024, "native communicator: 1 <= rows <= 1024 (one-shot exchange; larger batches stay on RCCL)");
     TM_HIP_CHECK(hipSetDevice(e->cfg.device));
+    {   // one workgroup per token row, all resident at once (comm_p2p.hip): clamp to what this device holds
+        const int nvec = e->hidden / 8;
+        const int t    = std::min(512, (nvec + 63) / 64 * 64);
+        const int cap  = p2p_allreduce_capacity(t, (nvec + t - 1) / t == 1);
+        TM_REQUIRE(cap >= 1, "native communicator: occupancy query failed");
+        rows = std::min(rows, cap);
+    }
     TM_TRY(tm_p2p_segment_create(tm_p2p_segment_bytes(rows, e->hidden), &e->p2p_seg, handle64));
     TM_HIP_CHECK(hipMalloc((void**)&e->p2p_state, 4 * sizeof(uint32_t)));
     TM_HIP_CHECK(hipMemset(e->p2p_state, 0, 4 * sizeof(uint32_t)));
@@ -1117,7 +1139,7 @@ int tm_engine_process_weights(tm_engine* e)
         const std::string p = "layers." + std::to_string(i);
         Layer&            L = e->layers[i];
         for (LinearSlots* l : {&L.qkv, &L.wo}) {
-            if (!l->w.packed) {
+            if (!l->w.packed && !l->w.packed32) {
                 TM_TRY(prepare_linear(e, *l));
             }
         }
@@ -1132,7 +1154,7 @@ int tm_engine_process_weights(tm_engine* e)
             L.moe.w2.resize(m.moe_experts);
             for (int x = 0; x < m.moe_experts; ++x) {
                 for (LinearSlots* l : {&L.ex13[x], &L.ex2[x]}) {
-                    if (!l->w.packed) {
+                    if (!l->w.packed && !l->w.packed32) {
                         TM_TRY(prepare_linear(e, *l));
                     }
                 }
@@ -1149,7 +1171,7 @@ int tm_engine_process_weights(tm_engine* e)
         }
         else {
             for (LinearSlots* l : {&L.w13, &L.w2}) {
-                if (!l->w.packed) {
+                if (!l->w.packed && !l->w.packed32) {
                     TM_TRY(prepare_linear(e, *l));
                 }
             }
@@ -1209,7 +1231,7 @@ static int tune_decode_gemms(tm_engine* e, int M, bool verbose)
                 continue;
             }
             const LinearWeight* w = r.which == 0 ? &L.qkv.w : r.which == 1 ? &L.wo.w : r.which == 2 ? &L.w13.w : &L.w2.w;
-            if (w->packed && dec32_supported(*w, M)) {
+            if (dec32_supported(*w, M)) {
                 ws.push_back(w);
             }
         }
@@ -2568,6 +2590,26 @@ int tm_engine_stats(tm_engine* e, int64_t* weight_bytes, int64_t* kv_bytes_per_t
     if (kv_bytes_per_token) *kv_bytes_per_token = e->started ? e->block_bytes / 64 : 0;
     if (num_blocks) *num_blocks = e->num_blocks;
     if (decode_splits) *decode_splits = e->decode_splits;
+    return 0;
+}
+
+int tm_engine_comm_info(tm_engine* e, int* backend, int* ranks, int* graph_captured)
+{
+    TM_REQUIRE(e, "null pointer");
+    int b = 0, n = 1;
+    if (e->use_comm) {
+        if (e->comm) {
+            b = 1;
+            TM_NCCL_CHECK(ncclCommCount(e->comm, &n));
+        }
+        if (e->p2p_ready) {
+            b |= 2;
+            n = e->cfg.tp;
+        }
+    }
+    if (backend) *backend = b;
+    if (ranks) *ranks = n;
+    if (graph_captured) *graph_captured = (e->graph || e->graph_cb) ? 1 : 0;
     return 0;
 }
 

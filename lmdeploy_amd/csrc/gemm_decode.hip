@@ -1067,11 +1067,21 @@ static void dec32_shape_dims(int shape, int* cg, int* s)
     *s  = shape == 5 ? 1 : (shape == 4 ? 2 : 4);
 }
 
-bool dec32_supported(const LinearWeight& w, int M)
+static bool dec32_on(bool big)
 {
     static const int on     = env_int2("TM_GEMM_D32", 1);
-    static const int on_big = env_int2("TM_GEMM_D32_PREFILL", 1);  // M > 64: the 128-row tile of the same kernel
-    return on && (M <= 64 || on_big) && w.type == 0 && w.packed32 != nullptr && M >= 1 && w.N % 32 == 0 && w.K % 128 == 0;
+    static const int on_big = env_int2("TM_GEMM_D32_PREFILL", 1);  // M > 64: the 128-row tiles of the same kernel family
+    return on && (!big || on_big);
+}
+
+bool dec32_supported(const LinearWeight& w, int M)
+{
+    return dec32_on(M > 64) && w.type == 0 && w.packed32 != nullptr && M >= 1 && w.N % 32 == 0 && w.K % 128 == 0;
+}
+
+bool dec32_serves_every_m(int K, int N)
+{
+    return dec32_on(true) && N % 32 == 0 && K % 128 == 0;
 }
 
 // ---- measured dispatch (reference: gemm::Gemm::Run's DispatchCache, kernels/gemm/gemm.cu:92-224, filled by the warm-up
@@ -1285,7 +1295,6 @@ int launch_linear_dec32(const LinearWeight& w, const half_t* x, int ldx, half_t*
     TM_REQUIRE(splits == 1 || workspace != nullptr, "split-K needs a workspace");
     p.kb_per_split = per;
     p.epilogue     = splits > 1 ? 2 : (gated_silu ? 1 : 0);
-    p.dbg          = g_gemm_dbg;
     static const int wt = env_int2("TM_D32_WT", 1);  // measured (tools/trace_boundary.py, profiles/r02_gemm_boundary_gap.txt): -0.4..-0.9 us per split-K launch
     p.wt           = wt;
     if (tail) {  // slabs (also for ONE slice) consumed by the last workgroups of this launch: write-through stores are the publish
@@ -1300,6 +1309,7 @@ int launch_linear_dec32(const LinearWeight& w, const half_t* x, int ldx, half_t*
         p.tail_sync  = tail->sync;
     }
     dim3      grid((p.ncg + cgn - 1) / cgn, splits, shape >= 6 ? (M + 31) / 32 : shape >= 4 ? (M + 127) / 128 : 1);
+    p.dbg        = gemm_trace_for((size_t)grid.x * grid.y * grid.z);
     const int rc = shape >= 6 ? launch_dec32_shape<1>(p, grid, dec32_base_shape(shape), st) :
                    shape >= 4 ? launch_dec32_shape<4>(p, grid, shape, st) :
                    M <= 32    ? launch_dec32_shape<1>(p, grid, shape, st) :

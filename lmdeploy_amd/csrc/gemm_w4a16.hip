@@ -178,23 +178,26 @@ void linear_weight_free(LinearWeight& w)
 }
 
 int linear_weight_prepare_u4(LinearWeight& w, const int32_t* qweight, const half_t* scales, const half_t* zeros,
-                             hipStream_t st)
+                             hipStream_t st, bool p32_only)
 {
     TM_REQUIRE(w.group == 128, "AWQ group size must be 128 (lmdeploy/turbomind/converter.py:86-92)");
     TM_REQUIRE(w.K % 128 == 0 && w.N % 16 == 0, "K % 128 == 0 and N % 16 == 0");
+    TM_REQUIRE(!p32_only || dec32_serves_every_m(w.K, w.N), "p32_only: the decode kernels must serve every M of this linear");
     w.type         = 0;
-    w.packed_bytes = (size_t)w.K * w.N / 2;
+    w.packed_bytes = (size_t)w.K * w.N / 2;  // algorithmic size of the codes / (s, -z*s) pairs, whichever image holds them
     w.sz_bytes     = (size_t)(w.K / 128) * w.N * 4;
-    if (!w.packed) {
-        TM_HIP_CHECK(hipMalloc(&w.packed, w.packed_bytes));
-        TM_HIP_CHECK(hipMalloc((void**)&w.sz, w.sz_bytes));
+    if (!p32_only) {
+        if (!w.packed) {
+            TM_HIP_CHECK(hipMalloc(&w.packed, w.packed_bytes));
+            TM_HIP_CHECK(hipMalloc((void**)&w.sz, w.sz_bytes));
+        }
+        const size_t nd = (size_t)w.K * w.N / 8;
+        repack_u4_kernel<<<(nd + 255) / 256, 256, 0, st>>>((uint32_t*)w.packed, qweight, w.K, w.N);
+        TM_HIP_CHECK(hipGetLastError());
+        const size_t ns = (size_t)(w.K / 128) * w.N;
+        repack_sz_kernel<<<(ns + 255) / 256, 256, 0, st>>>(w.sz, scales, zeros, w.K / 128, w.N);
+        TM_HIP_CHECK(hipGetLastError());
     }
-    const size_t nd = (size_t)w.K * w.N / 8;
-    repack_u4_kernel<<<(nd + 255) / 256, 256, 0, st>>>((uint32_t*)w.packed, qweight, w.K, w.N);
-    TM_HIP_CHECK(hipGetLastError());
-    const size_t ns = (size_t)(w.K / 128) * w.N;
-    repack_sz_kernel<<<(ns + 255) / 256, 256, 0, st>>>(w.sz, scales, zeros, w.K / 128, w.N);
-    TM_HIP_CHECK(hipGetLastError());
     if (w.N % 32 == 0) {  // the decode kernel's layout (gemm_decode.hip)
         w.packed32_bytes = p32_bytes(w.K, w.N);
         if (!w.packed32) {
@@ -930,7 +933,7 @@ int launch_linear(const LinearWeight& w,
     }
     TM_REQUIRE(!tail || (cfg.d32_shape >= 0 && dec32_tail_supported(w, M) && workspace && !gated_silu),
                "in-launch residual-norm consumer: decode kernel, M <= 64, a slab workspace");
-    TM_REQUIRE(w.packed != nullptr, "linear weight not prepared");
+    TM_REQUIRE(w.packed != nullptr || w.packed32 != nullptr, "linear weight not prepared");
     TM_REQUIRE(ldx % 8 == 0, "x rows must be 16-byte aligned");
     TM_REQUIRE(!gated_silu || w.N % 32 == 0, "gated epilogue needs N % 32 == 0");
     if (M == 0) {
@@ -954,6 +957,7 @@ int launch_linear(const LinearWeight& w,
         }
         return 0;
     }
+    TM_REQUIRE(w.packed != nullptr, "this linear holds only the decode kernels' image (prepared p32_only)");
     int nt    = cfg.nt;
     int waves = cfg.waves == 16 ? 16 : (cfg.waves == 8 ? 8 : 4);
     int wk    = cfg.kphases == 2 || waves == 16 ? 2 : 1;
@@ -1012,7 +1016,7 @@ int launch_linear(const LinearWeight& w,
     p.K        = w.K;
     p.KB       = KB;
     p.rotate_k = 0;
-    p.dbg      = g_gemm_dbg;
+    p.dbg      = nullptr;  // set below, once the grid is known
     // k-blocks per grid.y slice: whole iterations of ks*wk k-blocks, for every slice including the last one.
     // ks (k-blocks per barrier) = the largest of {4, 2, 1} (capped by cfg.kstage) that divides the slice.
     // measured (tools/ablate_gemm.sh): more k-blocks per barrier does NOT pay (the loop is issue-bound, not
@@ -1044,6 +1048,7 @@ int launch_linear(const LinearWeight& w,
     const int wn     = waves / wk;
     const int ntiles = w.N / 16;
     dim3      grid((ntiles + wn * nt - 1) / (wn * nt), splits, (M + 16 * mt - 1) / (16 * mt));
+    p.dbg        = gemm_trace_for((size_t)grid.x * grid.y * grid.z);
     int       rc = 0;
     if (w.type == 0 && mt == 8) {
         static const int xpin = env_int("TM_GEMM_XPIN", 1);  // pinned next-iteration dequant (see the main loop): +2..6 % at M = 8192

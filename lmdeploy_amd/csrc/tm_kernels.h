@@ -106,7 +106,7 @@ int launch_prefill_attention(const PrefillAttnParams& p, hipStream_t st);
 struct LinearWeight {
     int       K = 0, N = 0, group = 128;
     int       type = 0;          // 0 = u4 (AWQ), 1 = f16 dense, 2 = fp8 e4m3 with 128x128 block scales
-    void*     packed = nullptr;  // fragment-ordered weights
+    void*     packed = nullptr;  // fragment-ordered weights (nullptr for a u4 linear prepared p32_only)
     uint32_t* sz     = nullptr;  // fragment-ordered (s, -z*s) half2 pairs (u4), (s, 0) (fp8)
     size_t    packed_bytes = 0, sz_bytes = 0;
     // u4 only, N % 32 == 0: the decode kernel's layout (gemm_decode.hip, "P32": 2176-byte units of 32 columns x 128 k
@@ -127,8 +127,11 @@ struct GemmConfig {
     int d32_shape = -1;  // >= 0: the decode kernel of gemm_decode.hip with this workgroup shape (M <= 64, u4, N % 32 == 0)
 };
 // Load-time repack (reference: LinearWeight::prepare, models/linear_weight.cc:101-324)
+// p32_only: build ONLY the P32 image (gemm_decode.hip) -- for linears that every M dispatches to those kernels
+// (dec32_serves_every_m): the 16-column image of gemm_kernel would never be read.
 int    linear_weight_prepare_u4(LinearWeight& w, const int32_t* qweight /*[K][N/8]*/, const half_t* scales,
-                                const half_t* zeros, hipStream_t st);
+                                const half_t* zeros, hipStream_t st, bool p32_only = false);
+bool   dec32_serves_every_m(int K, int N);  // dense u4 linear, N % 32 == 0, K % 128 == 0, TM_GEMM_D32 / _PREFILL on
 int    linear_weight_prepare_f16(LinearWeight& w, const half_t* weight /*[K][N]*/, hipStream_t st);
 int    linear_weight_prepare_fp8(LinearWeight& w, const uint8_t* weight /*[K][N] e4m3*/, const float* block_scales /*[K/128][ceil(N/128)]*/,
                                  bool gated_scales /* w1w3: scale row = [w1 blocks | w3 blocks] for interleaved columns */, hipStream_t st);
@@ -186,6 +189,7 @@ int    launch_linear_fp8_grouped(const LinearWeight& proto, const void* d_groups
 int launch_p2p_allreduce_norm(half_t* const* data, uint32_t* const* flags, int tp, int me, uint32_t* state, size_t tile,
                               const half_t* partial, half_t* y, half_t* resid, const half_t* weight, float eps, int M, int H,
                               hipStream_t st);
+int p2p_allreduce_capacity(int threads, bool one_vec);  // token rows per launch: workgroups resident at once on this device
 int launch_p2p_allgather(half_t* const* data, uint32_t* const* flags, int tp, int me, uint32_t* state, size_t tile, const void* src,
                          void* dst, int words, hipStream_t st);
 
@@ -233,6 +237,14 @@ int launch_moe_combine(half_t* out, int ldo, const half_t* y, int ldy, const flo
                        hipStream_t st);
 
 extern uint64_t* g_gemm_dbg;  // gemm_w4a16.hip: optional per-workgroup timing stamps (tm_debug_set_gemm_trace)
+// The trace buffer holds kTraceMaxWorkgroups x 8 stamps; a launch with more workgroups is not traced.  (The only unbounded
+// device write the library had: a trace buffer sized for one kernel left set while a larger grid ran -- the probable origin of
+// the one-off "memory access fault" of a round-2 diagnostic script; tests/test_gpu_fullsize.py::..._with_canaries is clean.)
+constexpr size_t kTraceMaxWorkgroups = 8192;
+inline uint64_t* gemm_trace_for(size_t workgroups)
+{
+    return workgroups <= kTraceMaxWorkgroups ? g_gemm_dbg : nullptr;
+}
 
 // ---- misc.hip ---------------------------------------------------------------------------
 int launch_embedding(half_t* out, const half_t* table, const int* ids, int T, int H, int vocab, hipStream_t st);

@@ -66,6 +66,9 @@ class Engine:
         buf = C.create_string_buffer(unique_id, 128)
         _ffi.check(self._lib.tm_engine_comm_init(self._h, buf))
 
+    def comm_drop_rccl(self):
+        _ffi.check(self._lib.tm_engine_comm_drop_rccl(self._h))
+
     def comm_native_setup(self, all_gather, rows: int = 256):
         """TM_COMM=native: switch the row-parallel all-reduces of forwards with <= `rows` tokens to the fused P2P kernel.
         `all_gather(bytes) -> list[bytes]` (rank order) is the caller's host-side exchange, e.g. torch.distributed's
@@ -91,6 +94,17 @@ class Engine:
         text export (`tm_gemm_import` / TM_GEMM_IMPORT loads it in a later process)."""
         M = M or int(self.cfg.max_batch_size)
         _ffi.check(self._lib.tm_engine_tune_gemm(self._h, int(M), export_path.encode() if export_path else None))
+
+    def import_gemm_table(self, path: str):
+        """load a `K N M shape splits` dispatch table written by tune_gemm (the reference's TM_GEMM_IMPORT)"""
+        _ffi.check(self._lib.tm_gemm_import(path.encode()))
+
+    @staticmethod
+    def pick_tiling(K: int, N: int, M: int, use_table: bool = True):
+        """(shape, split-K) the decode GEMM dispatch runs a K x N W4A16 linear with at M rows (measured table first)"""
+        sh, sp = C.c_int(), C.c_int()
+        _ffi.check(_ffi.load().tm_debug_pick_tiling(K, N, M, 1 if use_table else 0, C.byref(sh), C.byref(sp)))
+        return sh.value, sp.value
 
     # ---- static batch ----------------------------------------------------------------------------
     def set_sampling(self, params):
@@ -241,6 +255,13 @@ class Engine:
         wb, kv, nb, sp = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int()
         _ffi.check(self._lib.tm_engine_stats(self._h, C.byref(wb), C.byref(kv), C.byref(nb), C.byref(sp)))
         return dict(weight_bytes=wb.value, kv_bytes_per_token=kv.value, num_blocks=nb.value, decode_splits=sp.value)
+
+    def comm_info(self) -> dict:
+        """which communicator the tensor-parallel data path runs on, its own rank count, graph replay or eager"""
+        b, n, g = C.c_int(), C.c_int(), C.c_int()
+        _ffi.check(self._lib.tm_engine_comm_info(self._h, C.byref(b), C.byref(n), C.byref(g)))
+        name = {0: 'none', 1: 'rccl', 2: 'native-p2p', 3: 'native-p2p (decode) + rccl (large forwards)'}[b.value]
+        return dict(backend=name, ranks=n.value, hipgraph=bool(g.value))
 
     def close(self):
         if self._h:

@@ -46,9 +46,27 @@ def _rope(x, cos, sin):
     return torch.cat([x1 * cos - x2 * sin, x2 * cos + x1 * sin], -1)
 
 
+def physical_cores() -> int:
+    """distinct (package, core) pairs of /proc/cpuinfo; SMT siblings count once.  Falls back to the logical count."""
+    try:
+        pairs, pkg = set(), None
+        for line in open('/proc/cpuinfo'):
+            if line.startswith('physical id'):
+                pkg = line.split(':')[1].strip()
+            elif line.startswith('core id'):
+                pairs.add((pkg, line.split(':')[1].strip()))
+        if pairs:
+            return len(pairs)
+    except OSError:
+        pass
+    return os.cpu_count() or 1
+
+
 def run(model: dict, batch: int, ctx: int, sample_layers: int = 2, seed: int = 0, threads: int | None = None,
         passes: int = 3, budget_s: float = 25.0) -> dict:
-    threads = threads or os.cpu_count() or 1
+    # one thread per PHYSICAL core: the contraction is fp32 FMA-bound, SMT siblings only add contention (round 2 ran
+    # os.cpu_count() = 256 logical CPUs of a 128-core host and measured the oversubscribed rate)
+    threads = threads or physical_cores()
     torch.set_num_threads(threads)
     g = torch.Generator().manual_seed(seed)
     H, D = model['hidden'], model['head_dim']
@@ -115,7 +133,10 @@ def run(model: dict, batch: int, ctx: int, sample_layers: int = 2, seed: int = 0
     t_layer = sorted(per_layer)[len(per_layer) // 2]
     t_head = sorted(per_head)[len(per_head) // 2]
     step_s = t_layer * model['layers'] + t_head
-    return dict(value=batch / step_s, unit='tokens/s', cores=threads, kind='port',
+    return dict(value=batch / step_s, unit='tokens/s', cores=threads, logical_cpus=os.cpu_count(), kind='port',
+                pinned_by='tests/test_oracle.py::test_cpu_baseline_port_matches_reference_golden_vectors (golden vectors generated by '
+                          'importing the reference\'s pytorch/backends/default functions; /root/reference does not exist on the GPU box, '
+                          'so the reference functions themselves cannot be the timed baseline)',
                 sample=(f'{sample_layers} of {model["layers"]} decoder layers + lm_head, one decode step, batch {batch}, '
                         f'ctx {ctx}, int8 KV; 1 warm-up + {len(per_layer)} timed passes (median {t_layer:.2f} s / layer, '
                         f'{t_head:.2f} s head); fp32 contraction on CPU; extrapolated to {model["layers"]} layers'))

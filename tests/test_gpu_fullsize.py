@@ -431,8 +431,9 @@ def test_eight_full_width_layers_engine_vs_oracle(cuda):
     heads, inter 14336, int8 KV), prefill of three ragged prompts + 16 graph-replayed decode steps through the C++ engine
     against the oracle model -- first-token and every decode step's logits, greedy tokens (teacher-forced with the engine's
     tokens, equal wherever the oracle's top-2 margin exceeds twice the logit bound) and the residual stream after the last
-    layer.  Stated bound: |logit - oracle| <= 6e-2 at 8 layers (3e-2 at one layer: fp16 accumulation-order noise grows with
-    depth; the reference's own gate for fp16 end-to-end comparisons is 0.25 x scale, tests/turbomind/linear/fixture.py:34-42)."""
+    layer.  Stated bound: |logit - oracle| <= 5e-3 on logits of standard deviation ~0.1 (measured on MI355X: 1.0e-3 worst over
+    the 17 forwards; the reference's own gate for fp16 end-to-end comparisons is 0.25 x scale,
+    tests/turbomind/linear/fixture.py:34-42), residual stream <= 2e-2 + 2^-7 |r|."""
     from lmdeploy_amd.turbomind.engine import Engine
     from lmdeploy_amd.turbomind.loader import export_weights
 
@@ -464,9 +465,9 @@ def test_eight_full_width_layers_engine_vs_oracle(cuda):
     for s in range(steps + 1):
         d = np.abs(logits[s].astype(np.float32) - lg.astype(np.float32)).max()
         worst = max(worst, float(d))
-        assert d <= 6e-2, f'step {s}: max logit diff {d}'
+        assert d <= 5e-3, f'step {s}: max logit diff {d}'
         top2 = np.sort(lg.astype(np.float32), -1)[:, -2:]
-        safe = (top2[:, 1] - top2[:, 0]) > 1.2e-1
+        safe = (top2[:, 1] - top2[:, 0]) > 1e-2
         assert np.array_equal(toks[safe, s], ids[safe]), f'step {s}: greedy tokens differ'
         r, rr = resid[s].astype(np.float32), om.last_resid.astype(np.float32)
         assert r.shape == rr.shape

@@ -33,7 +33,7 @@ def main():
     y = torch.empty((M, N), device='cuda').half()
     ws = torch.empty(max(1, tm.tm_linear_workspace(hs[0], M)), dtype=torch.uint8, device='cuda')
     flush = torch.empty(512 << 20, dtype=torch.uint8, device='cuda')
-    dbg = torch.zeros((L, 4096, 8), dtype=torch.int64, device='cuda')
+    dbg = torch.zeros((L, 8192, 8), dtype=torch.int64, device='cuda')
     gaps, spans = [], []
     for it in range(6):
         flush.fill_(it)

@@ -34,7 +34,7 @@ def main():
     y = torch.empty((M, N), device='cuda').half()
     ws = torch.empty(max(1, tm.tm_linear_workspace(hs[0], M)), dtype=torch.uint8, device='cuda')
     flush = torch.empty(512 << 20, dtype=torch.uint8, device='cuda')
-    dbg = torch.zeros((4096, 8), dtype=torch.int64, device='cuda')
+    dbg = torch.zeros((8192, 8), dtype=torch.int64, device='cuda')
     rows = []
     for it in range(8):
         flush.fill_(it)

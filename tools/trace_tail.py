@@ -36,7 +36,7 @@ def main():
     ws = torch.empty(max(1, tm.tm_linear_workspace(hs[0], M)) + M * N * 2, dtype=torch.uint8, device='cuda')
     sync = torch.zeros(4, dtype=torch.int32, device='cuda')
     flush = torch.empty(512 << 20, dtype=torch.uint8, device='cuda')
-    dbg = torch.zeros((L, 4096, 8), dtype=torch.int64, device='cuda')
+    dbg = torch.zeros((L, 8192, 8), dtype=torch.int64, device='cuda')
     for fused in (1, 0):
         acc = []
         for it in range(6):
