@@ -358,7 +358,7 @@ typedef struct tm_sampling {
 /* Static batch: sampling parameters of the NEXT tm_engine_prefill (host array [batch], copied); NULL / never called =
  * greedy arg-max.  Cleared by tm_engine_release.  TP > 1 (RCCL communicator): the vocabulary shards of the logits
  * are all-gathered and every rank draws the same token from the full row (models/language_model.cc:304-333 gathers the
- * logits as well); with the native P2P communicator alone sampling is TM_INVALID. */
+ * logits as well) -- over RCCL, or through the native P2P segments when no RCCL communicator exists. */
 int tm_engine_set_sampling(tm_engine* e, const tm_sampling* host_params, int batch);
 /* Per-sequence logits processors (GenerationConfig: repetition_penalty, min_new_tokens, bad_token_ids,
  * stop_token_ids; applied in the reference's order, see tm_logits_process).  stop ids end a sequence of the

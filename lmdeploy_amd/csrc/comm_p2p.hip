@@ -49,8 +49,9 @@ struct P2pParams {
     float         eps;
     int           M, H;
     const uint32_t* src;    // all-gather: n words of this rank
-    uint32_t*       dst;    // all-gather: [tp][n] words
+    uint32_t*       dst;    // all-gather: rank q's n words land at dst + q * dst_stride
     int             n;
+    size_t          dst_stride;
 };
 
 constexpr uint32_t kSpinLimit = 1u << 20;  // ~1 s of polling
@@ -207,7 +208,7 @@ __global__ __launch_bounds__(256) void p2p_allgather_kernel(P2pParams p)
     for (int q = 0; q < p.tp; ++q) {
         const uint32_t* theirs = (const uint32_t*)(p.data[q] + boff);
         for (int i = tid; i < p.n; i += blockDim.x) {
-            p.dst[(size_t)q * p.n + i] = __builtin_nontemporal_load(theirs + i);
+            p.dst[(size_t)q * p.dst_stride + i] = __builtin_nontemporal_load(theirs + i);
         }
     }
     p2p_exit(p, epoch);
@@ -268,7 +269,7 @@ int launch_p2p_allreduce_norm(half_t* const* data, uint32_t* const* flags, int t
 }
 
 int launch_p2p_allgather(half_t* const* data, uint32_t* const* flags, int tp, int me, uint32_t* state, size_t tile, const void* src,
-                         void* dst, int words, hipStream_t st)
+                         void* dst, int words, hipStream_t st, size_t dst_stride_words)
 {
     TM_REQUIRE(tp >= 1 && tp <= 8 && me >= 0 && me < tp, "p2p all-gather: 1 <= tp <= 8");
     TM_REQUIRE((size_t)words * 2 <= tile, "p2p all-gather: message larger than the segment buffer");
@@ -281,6 +282,7 @@ int launch_p2p_allgather(half_t* const* data, uint32_t* const* flags, int tp, in
         p.flags[r] = flags[r];
     }
     p.tp = tp, p.me = me, p.state = state, p.tile = tile, p.src = (const uint32_t*)src, p.dst = (uint32_t*)dst, p.n = words;
+    p.dst_stride = dst_stride_words ? dst_stride_words : (size_t)words;
     p2p_allgather_kernel<<<1, 256, 0, st>>>(p);
     TM_HIP_CHECK(hipGetLastError());
     return 0;

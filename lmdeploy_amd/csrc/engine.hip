@@ -214,6 +214,11 @@ struct tm_engine {
     // stream pulls the NEXT linear's weights towards the Infinity Cache (weight_prefetch_kernel)
     hipStream_t  comm_stream = nullptr;
     hipEvent_t   ev_fork = nullptr, ev_join = nullptr;
+    // mixed forwards: the decode rows' attention runs on this stream beside the prefill rows' K/V store -> flatten -> attention
+    // on the engine stream (reference: aux_stream_ + event fork / join, unified_attention_layer.cc:613-651)
+    hipStream_t  aux_stream = nullptr;
+    hipEvent_t   ev_aux_fork = nullptr, ev_aux_join = nullptr;
+    bool         mixed_two_streams = true;  // TM_MIXED_2STREAM=0: back to back on the engine stream
     // native communicator (TM_COMM=native, comm_p2p.hip): this rank's symmetric segment [flags 256 B | tile 0 | tile 1] and the
     // peers' mappings of theirs; serves the row-parallel all-reduces of forwards with M <= p2p_rows, RCCL the rest
     void*        p2p_seg = nullptr;
@@ -302,6 +307,7 @@ struct tm_engine {
                                                  // the parked decode row and the real prefill of the same slot side by side)
     int*             d_pf_k_len  = nullptr;  // prefill-local arrays (the decode arrays stay live during an admission)
     int*             d_pf_cu_q   = nullptr;
+    int*             d_first_ids = nullptr;  // [max_batch] first tokens of an admission's earlier prefill iterations (mixed steps)
     std::vector<int> h_active, h_step_ids;
     int              dummy_block = -1;
     hipGraphExec_t   graph_cb    = nullptr;
@@ -592,6 +598,8 @@ struct MixedDecode {
     int             rows;        // decode rows = batch slots
     const int*      k_len;       // [rows] context lengths including this step's token
     const uint64_t* block_ptrs;  // the unshifted block table
+    const int*      cu_q;        // [rows + 1] = 0 .. rows (one token per decode row; kv_rope_store of the fp16-KV path)
+    const int*      active;      // [rows] 1 = the slot holds a running sequence (logits processors skip the others)
 };
 
 static int forward(tm_engine* e, const int* d_ids, int M, int nseq, bool decode, int max_q_len, int max_k_len,
@@ -600,7 +608,7 @@ static int forward(tm_engine* e, const int* d_ids, int M, int nseq, bool decode,
     const tm_model_config& m = e->cfg.model;
     hipStream_t            st = e->stream;
     const int              nd = md ? md->rows : 0;  // leading decode rows of a mixed forward
-    TM_REQUIRE(!md || (!decode && e->fuse_qkv && nd > 0 && nd < M), "internal: mixed forward");
+    TM_REQUIRE(!md || (!decode && nd > 0 && nd < M), "internal: mixed forward");
     half_t* const qkv_p  = e->d_qkv + (size_t)nd * e->qkv_n;            // first prefill row
     half_t* const attn_p = e->d_attn + (size_t)nd * e->q_heads * e->D;
     TM_PROF(P_EMBED, TM_TRY(launch_embedding(e->d_resid, e->tok_embeddings, d_ids, M, e->hidden, m.vocab, st)));
@@ -626,12 +634,29 @@ static int forward(tm_engine* e, const int* d_ids, int M, int nseq, bool decode,
             TM_PROF(P_KV_STORE, TM_TRY(launch_kv_rope_store(qkv_p, e->q_heads, e->d_cu_q, e->d_k_len, nseq, M - nd, e->d_rope,
                                                            e->rope_max_pos, cv, st)));
         }
-        if (md) {  // decode rows: fused prologue (RoPE + K/V quantise-store) + attention on the fp16 projection rows
+        if (md) {
+            // decode rows: (fused prologue: RoPE + K/V quantise-store) + attention on the fp16 projection rows; they share
+            // nothing with the prefill rows' path below, so they run beside it on the aux stream (fork here, join behind the
+            // prefill attention) -- the reference's decode / prefill split of a unified batch
+            hipStream_t dst = st;
+            if (e->mixed_two_streams && e->aux_stream) {
+                TM_HIP_CHECK(hipEventRecord(e->ev_aux_fork, st));
+                TM_HIP_CHECK(hipStreamWaitEvent(e->aux_stream, e->ev_aux_fork, 0));
+                dst = e->aux_stream;
+            }
+            KvCacheView cvd = cv;
+            cvd.block_ptrs  = md->block_ptrs;
             DecodeAttnParams p{};
-            p.qkv_f16        = e->d_qkv;
-            p.qkv_n          = e->qkv_n;
-            p.cos_sin        = e->d_rope;
-            p.max_pos        = e->rope_max_pos;
+            if (e->fuse_qkv) {
+                p.qkv_f16 = e->d_qkv;
+                p.qkv_n   = e->qkv_n;
+                p.cos_sin = e->d_rope;
+                p.max_pos = e->rope_max_pos;
+            }
+            else {  // fp16 KV (no fused prologue): RoPE + store of the decode rows' K/V first
+                TM_PROF(P_KV_STORE, TM_TRY(launch_kv_rope_store(e->d_qkv, e->q_heads, md->cu_q, md->k_len, nd, nd, e->d_rope,
+                                                               e->rope_max_pos, cvd, dst)));
+            }
             p.q              = e->d_qkv;
             p.q_stride       = e->qkv_n;
             p.out            = e->d_attn;
@@ -642,9 +667,11 @@ static int forward(tm_engine* e, const int* d_ids, int M, int nseq, bool decode,
             p.splits         = e->decode_splits;
             p.partial_o      = e->d_attn_ws;
             p.partial_ml     = e->d_attn_ws + (size_t)nd * e->q_heads * e->decode_splits * e->D;
-            p.cache          = cv;
-            p.cache.block_ptrs = md->block_ptrs;
-            TM_PROF(P_ATTN, TM_TRY(launch_decode_attention(p, st)));
+            p.cache          = cvd;
+            TM_PROF(P_ATTN, TM_TRY(launch_decode_attention(p, dst)));
+            if (dst != st) {
+                TM_HIP_CHECK(hipEventRecord(e->ev_aux_join, dst));
+            }
         }
         if (decode) {
             DecodeAttnParams p{};
@@ -688,6 +715,9 @@ static int forward(tm_engine* e, const int* d_ids, int M, int nseq, bool decode,
             p.kv_heads   = e->kv_heads;
             p.scale_log2 = scale_log2;
             TM_PROF(P_ATTN, TM_TRY(launch_prefill_attention(p, st)));
+            if (md && e->mixed_two_streams && e->aux_stream) {
+                TM_HIP_CHECK(hipStreamWaitEvent(st, e->ev_aux_join, 0));  // join: wo reads the decode rows' attention output too
+            }
         }
         TM_TRY(linear_residual_norm(e, L.wo, e->d_attn, e->q_heads * e->D, M, L.ffn_norm, P_GEMM_O));
         const half_t* next_norm = li + 1 < m.layers ? e->layers[li + 1].attn_norm : e->final_norm;
@@ -704,20 +734,21 @@ static int forward(tm_engine* e, const int* d_ids, int M, int nseq, bool decode,
     // last-token hidden states -> logits -> next ids, for `n` sequences whose logits / next ids land in the batch slots
     // [slot, slot + n): hx = their hidden rows, ids / cu_q (nullptr: one token per sequence) / ntok = the tokens this forward
     // consumed for them, k_len = their context lengths
-    auto head = [&](const half_t* hx, int n, int slot, const int* ids_in, const int* cu_q, int ntok, const int* k_len) -> int {
+    auto head = [&](const half_t* hx, int n, int slot, const int* ids_in, const int* cu_q, int ntok, const int* k_len,
+                    const int* active = nullptr) -> int {
         half_t* logits = e->d_logits + (size_t)slot * e->vocab_local;
         int*    ids    = e->d_next_ids + slot;
         TM_PROF(P_LM_HEAD, TM_TRY(linear_plain(e, e->output, hx, e->hidden, logits, e->vocab_local, n, false)));
         if (e->logits_on) {
             // the tokens this forward consumed join the slots' seen masks, then penalty / bans on the (local) logits
             uint32_t* seen = e->d_seen + (size_t)slot * e->seen_words;
-            TM_PROF(P_SAMPLE, TM_TRY(launch_seen_update(seen, e->seen_words, ids_in, cu_q, n, ntok, m.vocab, st)));
+            TM_PROF(P_SAMPLE, TM_TRY(launch_seen_update(seen, e->seen_words, ids_in, cu_q, n, ntok, m.vocab, st, active)));
             TM_PROF(P_SAMPLE, TM_TRY(launch_logits_process(logits, n, e->vocab_local, e->vocab_local,
                                                            e->vocab_local < m.vocab ? e->cfg.rank * e->vocab_local : 0, seen,
                                                            e->seen_words, e->d_lp_rep + slot, e->d_lp_ban + slot * kMaxBadIds,
                                                            e->d_lp_end + slot * kMaxEndIds, k_len, e->d_lp_minlen + slot, st)));
         }
-        if (e->sampling_on && (!e->use_comm || (e->comm && e->d_logits_full))) {
+        if (e->sampling_on && (!e->use_comm || ((e->comm || e->p2p_ready) && e->d_logits_full))) {
             // parameters are indexed by batch slot, the counter (context length) by the row of this forward
             const half_t* lg = logits;
             int           V  = e->vocab_local;
@@ -726,7 +757,23 @@ static int forward(tm_engine* e, const int* d_ids, int M, int nseq, bool decode,
                 // models/language_model.cc:304-333) and EVERY rank draws from the same distribution with the same Philox
                 // number -> the same token everywhere, no further exchange
                 const size_t cnt = (size_t)n * e->vocab_local;
-                if (e->comm_overlap && e->comm_stream) {
+                if (!e->comm) {
+                    // native communicator alone: the shards travel through the P2P segments, as many whole rows per exchange as
+                    // one segment buffer holds; rank q's rows land in its [n][vocab / tp] plane of d_logits_gather
+                    half_t*   data[8];
+                    uint32_t* flags[8];
+                    p2p_tables(e, data, flags);
+                    const size_t tile = (size_t)e->p2p_rows * e->hidden;  // fp16 elements of one segment buffer
+                    const int    per  = (int)std::min<size_t>(n, tile / e->vocab_local);
+                    TM_REQUIRE(per >= 1, "native communicator: one logits row does not fit a segment buffer (export more rows)");
+                    for (int r0 = 0; r0 < n; r0 += per) {
+                        const int rows = std::min(per, n - r0);
+                        TM_TRY(launch_p2p_allgather(data, flags, e->cfg.tp, e->cfg.rank, e->p2p_state, tile, logits + (size_t)r0 * e->vocab_local,
+                                                    e->d_logits_gather + (size_t)r0 * e->vocab_local, rows * e->vocab_local / 2, st,
+                                                    cnt / 2));
+                    }
+                }
+                else if (e->comm_overlap && e->comm_stream) {
                     TM_HIP_CHECK(hipEventRecord(e->ev_fork, st));
                     TM_HIP_CHECK(hipStreamWaitEvent(e->comm_stream, e->ev_fork, 0));
                     TM_NCCL_CHECK(ncclAllGather(logits, e->d_logits_gather, cnt, ncclHalf, e->comm, e->comm_stream));
@@ -780,7 +827,7 @@ static int forward(tm_engine* e, const int* d_ids, int M, int nseq, bool decode,
         return head(e->d_x, nseq, slot0, d_ids, nullptr, M, e->d_k_len);
     }
     if (md) {  // the decode rows first: their slots are 0 .. nd-1; the prefilled slots' entries are overwritten right after
-        TM_TRY(head(e->d_x, nd, 0, d_ids, nullptr, nd, md->k_len));
+        TM_TRY(head(e->d_x, nd, 0, d_ids, nullptr, nd, md->k_len, md->active));
     }
     TM_TRY(launch_gather_rows(e->d_last, e->d_x, e->d_rows, nseq, e->hidden, st));
     return head(e->d_last, nseq, slot0, d_ids + nd, e->d_cu_q, M - nd, e->d_k_len);
@@ -1639,24 +1686,17 @@ struct MixedStep {
     const int* active;
     int*       ids;      // current token of every slot
     const uint64_t* block_ptrs;  // the decode block table
+    const int* cu_q;     // 0 .. rows (the decode step's own array)
     bool*      done;
 };
 
 static int prefill_slots(tm_engine* e, const int* const* seq_ids, const int* host_lens, int batch, int slot0, float* ttft_ms,
                          const MixedStep* mix = nullptr)
 {
-    // A mixed forward only when the WHOLE admission fits one iteration next to the decode rows: the decode head of a merged
-    // iteration writes the next-id entry of every batch slot, so first tokens that an EARLIER iteration of the same admission
-    // left in d_next_ids (sequences still parked) would be overwritten.  Larger admissions and chunked prompts prefill alone.
-    if (mix) {
-        int64_t total = 0;
-        for (int i = 0; i < batch; ++i) {
-            total += host_lens[i];
-        }
-        if (total > (int64_t)e->max_tokens - mix->rows) {
-            mix = nullptr;
-        }
-    }
+    // The decode rows ride on the LAST iteration of the admission (any number of iterations, chunked prompts included -- the
+    // reference mixes unconditionally, unified_attention_layer.cc:310-311).  The decode head of that iteration writes the
+    // next-id entry of every batch slot, so the first tokens that EARLIER iterations left in d_next_ids are moved to
+    // d_first_ids right after each iteration and handed back when the admission is done.
     const int  budget  = e->max_tokens - (mix ? mix->rows : 0);
     const auto t_start = std::chrono::steady_clock::now();
     // Because the batch tables (block_ptrs, cu_block_nums) are indexed by the batch slot, every prefill
@@ -1712,15 +1752,29 @@ static int prefill_slots(tm_engine* e, const int* const* seq_ids, const int* hos
         // shift the block tables so that slot 0 of this iteration is sequence b0
         uint64_t* saved_ptrs = e->d_block_ptrs;
         e->d_block_ptrs += (size_t)(slot0 + b0) * e->max_blocks_per_seq;
-        const MixedDecode md{nd, merge ? mix->k_len : nullptr, merge ? mix->block_ptrs : nullptr};
+        const MixedDecode md{nd, merge ? mix->k_len : nullptr, merge ? mix->block_ptrs : nullptr, merge ? mix->cu_q : nullptr,
+                             merge ? mix->active : nullptr};
         const int rc    = forward(e, e->d_prefill_ids, nd + tokens, nseq, false, max_q, max_k, e->kflat_stride, slot0 + b0,
                                   merge ? &md : nullptr);
         e->d_block_ptrs = saved_ptrs;
         if (rc) {
             return rc;
         }
-        if (merge) {  // as decode_step_cb: the next ids of every slot become its current token
+        if (mix) {
+            const int n_done = b1 - b0;  // sequences b0 .. b1-1 got their first token in this iteration
+            if (n_done > 0 && !merge) {
+                TM_HIP_CHECK(hipMemcpyAsync(e->d_first_ids + slot0 + b0, e->d_next_ids + slot0 + b0, (size_t)n_done * 4,
+                                            hipMemcpyDeviceToDevice, e->stream));
+            }
+        }
+        if (merge) {  // as decode_step_cb: the next ids of every slot become its current token ...
             TM_HIP_CHECK(hipMemcpyAsync(mix->ids, e->d_next_ids, (size_t)nd * 4, hipMemcpyDeviceToDevice, e->stream));
+            // ... and the first tokens of the admission's earlier iterations return to their d_next_ids entries (the caller
+            // reads first tokens from there); the sequences of THIS iteration wrote theirs after the decode head
+            if (b0 > 0) {
+                TM_HIP_CHECK(hipMemcpyAsync(e->d_next_ids + slot0, e->d_first_ids + slot0, (size_t)b0 * 4, hipMemcpyDeviceToDevice,
+                                            e->stream));
+            }
             *mix->done = true;
         }
         // the host vectors above are pageable: make sure the async copies are done before they die
@@ -1760,6 +1814,14 @@ static int cb_enter(tm_engine* e)
         TM_TRY(dmalloc(&e->d_pf_k_len, (size_t)B));
         TM_TRY(dmalloc(&e->d_pf_cu_q, (size_t)B + 1));
         TM_TRY(dmalloc(&e->d_pf_block_ptrs, (size_t)B * e->max_blocks_per_seq));
+        TM_TRY(dmalloc(&e->d_first_ids, (size_t)B));
+    }
+    if (!e->aux_stream) {
+        const char* ts       = getenv("TM_MIXED_2STREAM");
+        e->mixed_two_streams = !(ts && !atoi(ts));
+        TM_HIP_CHECK(hipStreamCreateWithFlags(&e->aux_stream, hipStreamNonBlocking));
+        TM_HIP_CHECK(hipEventCreateWithFlags(&e->ev_aux_fork, hipEventDisableTiming));
+        TM_HIP_CHECK(hipEventCreateWithFlags(&e->ev_aux_join, hipEventDisableTiming));
     }
     e->dummy_block = (int)e->num_blocks - 1;  // parking block of the free slots; the scheduler owns the others
     e->sched.reset(new BatchScheduler(B, (int)e->num_blocks - 1, e->cfg.session_len, e->cfg.cache_block_seq_len));
@@ -1853,7 +1915,7 @@ static int cb_prefill_admitted(tm_engine* e, const std::vector<SchedAdmit>& admi
         // stays untouched, the new slots' decode rows stay parked until the prefill is done
         const bool      last_run = merged && j == sorted.size();
         bool            did      = false;
-        const MixedStep mix{e->cfg.max_batch_size, e->d_k_len, e->d_active, e->d_ids, e->d_block_ptrs, &did};
+        const MixedStep mix{e->cfg.max_batch_size, e->d_k_len, e->d_active, e->d_ids, e->d_block_ptrs, e->d_cu_q, &did};
         std::swap(e->d_k_len, e->d_pf_k_len);
         std::swap(e->d_cu_q, e->d_pf_cu_q);
         std::swap(e->d_block_ptrs, e->d_pf_block_ptrs);
@@ -2120,7 +2182,8 @@ int tm_engine_set_sampling(tm_engine* e, const tm_sampling* host_params, int bat
     if (!host_params) {
         return 0;
     }
-    TM_REQUIRE(!e->use_comm || e->comm, "stochastic sampling with tp > 1 gathers the logits over RCCL: tm_engine_comm_init first");
+    TM_REQUIRE(!e->use_comm || e->comm || e->p2p_ready,
+               "stochastic sampling with tp > 1 gathers the logits: tm_engine_comm_init or the native communicator first");
     TM_REQUIRE(batch >= 1 && batch <= e->cfg.max_batch_size, "1 <= batch <= max_batch_size");
     for (int i = 0; i < batch; ++i) {
         TM_REQUIRE(host_params[i].temperature > 0.f, "sampling: temperature must be > 0");
@@ -2175,7 +2238,8 @@ int tm_engine_submit_gen(tm_engine* e, const int* host_ids, int n, int max_new_t
         TM_TRY(logits_param_check(*logits_param));
     }
     if (sampling) {
-        TM_REQUIRE(!e->use_comm || e->comm, "stochastic sampling with tp > 1 gathers the logits over RCCL: tm_engine_comm_init first");
+        TM_REQUIRE(!e->use_comm || e->comm || e->p2p_ready,
+               "stochastic sampling with tp > 1 gathers the logits: tm_engine_comm_init or the native communicator first");
         TM_REQUIRE(sampling->temperature > 0.f, "sampling: temperature must be > 0");
     }
     {
@@ -2222,10 +2286,10 @@ static int step_locked(tm_engine* e, int* n_active, int* n_waiting, std::vector<
     // Mixed steps (TM_MIXED_STEP, default on): when something is already decoding, the decode step rides on the admission's
     // last prefill forward -- one weight stream for both (reference: the unified batch of unified_attention_layer.cc:310-311).
     const bool        mixed_on = !getenv("TM_MIXED_STEP") || atoi(getenv("TM_MIXED_STEP")) != 0;
-    // (not with logits processors: the decode rows of the slots being prefilled are parked rows whose stale token would
-    // join the freshly cleared "seen" mask)
-    const bool        can_mix  = mixed_on && e->fuse_qkv && !e->use_comm && !e->logits_on && e->sched->n_active() > 0
-                         && e->max_tokens - B >= 16;
+    // Every configuration mixes: tp > 1 (the row-parallel reductions of the merged forward take the large-message path),
+    // logits processors (the seen-mask update skips decode rows whose slot holds no running sequence), fp16 KV (the decode
+    // rows' K/V go through kv_rope_store instead of the fused prologue), admissions of any size (see prefill_slots).
+    const bool        can_mix  = mixed_on && e->sched->n_active() > 0 && e->max_tokens - B >= 16;
     bool             merged = false;
     std::vector<int> fresh;
     const std::vector<SchedAdmit> admits = e->sched->admit(e->max_tokens);
@@ -2629,7 +2693,12 @@ int tm_engine_destroy(tm_engine* e)
     if (e->graph_cb) {
         (void)hipGraphExecDestroy(e->graph_cb);
     }
-    for (void* q : {(void*)e->d_active, (void*)e->d_pf_k_len, (void*)e->d_pf_cu_q, (void*)e->d_pf_block_ptrs, (void*)e->d_temp, (void*)e->d_topp, (void*)e->d_minp,
+    if (e->aux_stream) {
+        (void)hipStreamDestroy(e->aux_stream);
+        (void)hipEventDestroy(e->ev_aux_fork);
+        (void)hipEventDestroy(e->ev_aux_join);
+    }
+    for (void* q : {(void*)e->d_active, (void*)e->d_pf_k_len, (void*)e->d_pf_cu_q, (void*)e->d_pf_block_ptrs, (void*)e->d_first_ids, (void*)e->d_temp, (void*)e->d_topp, (void*)e->d_minp,
                     (void*)e->d_u, (void*)e->d_topk, (void*)e->d_seed, e->d_sample_ws, (void*)e->d_logits_gather, (void*)e->d_logits_full,
                     (void*)e->d_seen, (void*)e->d_lp_rep,
                     (void*)e->d_lp_minlen, (void*)e->d_lp_ban, (void*)e->d_lp_end}) {

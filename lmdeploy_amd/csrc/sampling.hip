@@ -440,11 +440,14 @@ float philox_uniform_host(uint64_t seed, uint32_t ctr)
 // and arg-max consume fp16): penalised values differ from the reference's by at most half an fp16 ulp.
 // ------------------------------------------------------------------------------------------------------------------
 __global__ void seen_update_kernel(uint32_t* __restrict__ seen, int words, const int* __restrict__ ids,
-                                   const int* __restrict__ cu_q, int nseq, int n_tokens, int vocab)
+                                   const int* __restrict__ cu_q, int nseq, int n_tokens, int vocab, const int* __restrict__ active)
 {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n_tokens) {
         return;
+    }
+    if (active && !cu_q && !active[t]) {
+        return;  // decode row of a slot that holds no sequence (parked, or being prefilled by this very forward): its token is stale
     }
     int row = t;
     if (cu_q) {  // packed prefill rows: sequence of token t = last r with cu_q[r] <= t
@@ -529,12 +532,12 @@ __global__ __launch_bounds__(256) void logits_process_kernel(half_t* __restrict_
 }
 
 int launch_seen_update(uint32_t* seen, int words, const int* ids, const int* cu_q, int nseq, int n_tokens, int vocab,
-                       hipStream_t st)
+                       hipStream_t st, const int* active)
 {
     if (n_tokens <= 0) {
         return 0;
     }
-    seen_update_kernel<<<(n_tokens + 255) / 256, 256, 0, st>>>(seen, words, ids, cu_q, nseq, n_tokens, vocab);
+    seen_update_kernel<<<(n_tokens + 255) / 256, 256, 0, st>>>(seen, words, ids, cu_q, nseq, n_tokens, vocab, active);
     TM_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -190,8 +190,9 @@ int launch_p2p_allreduce_norm(half_t* const* data, uint32_t* const* flags, int t
                               const half_t* partial, half_t* y, half_t* resid, const half_t* weight, float eps, int M, int H,
                               hipStream_t st);
 int p2p_allreduce_capacity(int threads, bool one_vec);  // token rows per launch: workgroups resident at once on this device
+// dst_stride_words: 32-bit words between the destinations of consecutive ranks (0 = words: dst is [tp][words])
 int launch_p2p_allgather(half_t* const* data, uint32_t* const* flags, int tp, int me, uint32_t* state, size_t tile, const void* src,
-                         void* dst, int words, hipStream_t st);
+                         void* dst, int words, hipStream_t st, size_t dst_stride_words = 0);
 
 // sampling.hip: temperature / top-k / top-p / min-p sampling without a sort (see the file header)
 size_t sample_workspace_bytes(int batch);
@@ -205,8 +206,9 @@ float  philox_uniform_host(uint64_t seed, uint32_t ctr);
 // min-length ban of the end ids.  ban = [batch][kMaxBadIds], end = [batch][kMaxEndIds], padded with -1.
 constexpr int kMaxBadIds = 32;  // = TM_MAX_BAD_IDS
 constexpr int kMaxEndIds = 9;   // eos id + TM_MAX_STOP_IDS
+// active (decode rows only, cu_q == nullptr): rows with active[row] == 0 are skipped
 int launch_seen_update(uint32_t* seen, int words, const int* ids, const int* cu_q, int nseq, int n_tokens, int vocab,
-                       hipStream_t st);
+                       hipStream_t st, const int* active = nullptr);
 int launch_logits_process(half_t* logits, int batch, int V, int ld, int vocab_offset, const uint32_t* seen, int words,
                           const float* rep, const int* ban, const int* end, const int* k_len, const int* min_len,
                           hipStream_t st);

@@ -212,17 +212,19 @@ def test_continuous_batching_matches_static(cuda, slots):
 
 
 @pytest.mark.parametrize('mixed', [1, 0])
-@pytest.mark.parametrize('kv_bits', [8, 4])
-def test_continuous_batching_matches_oracle(cuda, monkeypatch, kv_bits, mixed):
-    """mixed = 1 (default): an admission that arrives while other requests decode runs as ONE forward -- decode rows of
-    every slot first, then the prompt tokens (the reference's unified batch, unified_attention_layer.cc:310-311) -- and the
-    test insists that this happened; mixed = 0: prefill forwards and decode steps alternate.
+@pytest.mark.parametrize('kv_bits,banned', [(8, 0), (4, 0), (16, 0), (8, 1)])
+def test_continuous_batching_matches_oracle(cuda, monkeypatch, kv_bits, banned, mixed):
+    """mixed = 1 (default): an admission that arrives while other requests decode runs its LAST prefill forward together with
+    the decode rows of every slot (the reference's unified batch, unified_attention_layer.cc:310-311) -- int8 / int4 KV through
+    the fused decode prologue, fp16 KV through kv_rope_store, chunked and multi-iteration admissions included, with logits
+    processors on (banned = 1: every request carries 24 banned token ids, so the seen-mask / processor kernels run in the
+    merged forward) -- and the test insists that this happened; mixed = 0: prefill forwards and decode steps alternate.
     The scheduler path against the ORACLE (not against the engine's own static path): 8 requests of different prompt and
     generation lengths through 3 batch slots (admissions join a running batch, slots and KV blocks are reused, one prompt
     is chunked); every request's token stream is replayed through the oracle model alone (batch 1, teacher-forced with
-    the engine's tokens) and every engine token must be the arg-max of the oracle's logits wherever the oracle's top-2
-    margin exceeds 1.5e-2 -- the synthetic model's logits have sigma = 0.1, the engine's measured logit error is a few
-    1e-3 -- and within 1e-2 of the oracle's best logit everywhere else (near ties)."""
+    the engine's tokens; banned ids masked in the oracle's row) and every engine token must be the arg-max of the oracle's
+    logits wherever the oracle's top-2 margin exceeds 1.5e-2 -- the synthetic model's logits have sigma = 0.1, the engine's
+    measured logit error is a few 1e-3 -- and within 1e-2 of the oracle's best logit everywhere else (near ties)."""
     cfg = o.ModelConfig(hidden=256, layers=2, q_heads=4, kv_heads=2, head_dim=128, inter=512, vocab=1024,
                         kv_bits=kv_bits, rope=o.RopeParam(128, 500000.0, 'llama3', 8.0, 1.0, 4.0, 8192))
     w = o.make_synthetic_weights(cfg, seed=13)
@@ -230,11 +232,13 @@ def test_continuous_batching_matches_oracle(cuda, monkeypatch, kv_bits, mixed):
     lens = [70, 5, 64, 33, 150, 9, 1, 40]
     news = [6, 12, 3, 9, 5, 14, 8, 2]
     prompts = [rng.integers(0, cfg.vocab, n).astype(np.int32) for n in lens]
+    bans = [sorted(rng.choice(np.arange(1, cfg.vocab), 24, replace=False).tolist()) for _ in lens] if banned else [None] * len(lens)
     monkeypatch.setenv('TM_MIXED_STEP', str(mixed))
-    eng = Engine.from_model_config(cfg, max_batch_size=3, session_len=256, quant_policy=kv_bits, max_prefill_token_num=96)
+    eng = Engine.from_model_config(cfg, max_batch_size=3, session_len=256, quant_policy=0 if kv_bits == 16 else kv_bits,
+                                   max_prefill_token_num=96)
     eng.load_weights(export_weights(cfg, w))
     eng.start()
-    ids = [eng.submit(p, n, -1) for p, n in zip(prompts, news)]
+    ids = [eng.submit(p, n, -1, None, dict(bad_ids=b) if b else None) for p, n, b in zip(prompts, news, bans)]
     done, steps = {}, 0
     while len(done) < len(ids):
         eng.step()
@@ -247,7 +251,8 @@ def test_continuous_batching_matches_oracle(cuda, monkeypatch, kv_bits, mixed):
                     done[i] = (st, toks.copy())
     n_mixed = eng.mixed_steps()
     eng.close()
-    assert (n_mixed >= 1) if mixed else (n_mixed == 0), f'{n_mixed} mixed steps'
+    # 5 admissions join a running batch (the first three start together); the 150-token prompt is chunked (96 + 54): all merge
+    assert (n_mixed >= 4) if mixed else (n_mixed == 0), f'{n_mixed} mixed steps'
     checked = 0
     for i, (st, toks) in done.items():
         assert st == 7 and len(toks) == news[i], f'request {i}: status {st}, {len(toks)} tokens'
@@ -256,6 +261,9 @@ def test_continuous_batching_matches_oracle(cuda, monkeypatch, kv_bits, mixed):
         for k in range(news[i]):
             _, lg = om.forward(feed)
             row = lg[0].astype(np.float32)
+            if bans[i]:
+                assert int(toks[k]) not in bans[i], f'request {i} token {k}: banned id {toks[k]} generated'
+                row[bans[i]] = -np.inf
             top2 = np.sort(row)[-2:]
             if top2[1] - top2[0] > 1.5e-2:
                 assert int(toks[k]) == int(np.argmax(row)), f'request {i} token {k}: engine {toks[k]} oracle {np.argmax(row)}'

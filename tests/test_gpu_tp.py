@@ -53,3 +53,38 @@ def test_tp2_engine_two_processes_one_gpu(cuda, moe, kv_bits):
     assert res['max_logit_diff'] <= 4e-2, res
     assert res['resid_diff'] <= 2e-2, res
     assert res['token_mismatch'] == 0, res
+
+
+@pytest.mark.timeout(600)
+def test_tp2_sampling_and_mixed_steps_on_the_native_communicator(cuda):
+    """tp = 2 as two processes on cuda:0 over the native communicator, decode collectives captured in the hipGraph
+    (TM_GRAPH_COMM=1): (a) stochastic sampling -- the vocabulary shards of the logits are gathered through the P2P segments
+    (no RCCL communicator exists), every token is the oracle's draw from the re-assembled logits and both ranks draw the same
+    token; (b) a continuous-batching session whose admissions join the running batch as mixed forwards (asserted), one
+    prompt chunked, token streams teacher-forced through the unsharded oracle and identical on both ranks."""
+    env = dict(os.environ)
+    env['GPU_MAX_HW_QUEUES'] = '8'
+    env['HSA_ENABLE_IPC_MODE_LEGACY'] = '0'
+    env['TM_GRAPH_COMM'] = '1'
+    port = _free_port()
+    procs = [subprocess.Popen([sys.executable, WORKER, str(r), '2', str(port), '0', '8', '1'], env=env,
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = []
+    try:
+        for pr in procs:
+            outs.append(pr.communicate(timeout=480)[0])
+    finally:
+        for pr in procs:
+            if pr.poll() is None:
+                pr.kill()
+    res = None
+    for line in reversed(outs[0].strip().splitlines()):
+        if line.startswith('{'):
+            res = json.loads(line)
+            break
+    assert res is not None, outs[0][-3000:] + '\n----\n' + outs[1][-3000:]
+    assert res['ok'], (res, outs[1][-2000:])
+    assert res['same_resid'] and res['same_tokens'] and res['token_mismatch'] == 0, res
+    assert res['sampling_mismatch'] == 0 and res['sampling_same_tokens'], res
+    assert res['cb_finished'] and res['cb_same_tokens'], res
+    assert res['cb_mixed_steps'] >= 2 and res['cb_token_mismatch'] == 0 and res['cb_checked'] >= 4, res
