@@ -219,6 +219,8 @@ struct tm_engine {
     hipStream_t  aux_stream = nullptr;
     hipEvent_t   ev_aux_fork = nullptr, ev_aux_join = nullptr;
     bool         mixed_two_streams = true;  // TM_MIXED_2STREAM=0: back to back on the engine stream
+    bool         mixed_steps_on    = true;  // TM_MIXED_STEP=0: prefill forwards and decode steps alternate
+    bool         graph_comm        = true;  // TM_GRAPH_COMM=0: tensor-parallel decode steps stay eager (collectives not captured)
     // native communicator (TM_COMM=native, comm_p2p.hip): this rank's symmetric segment [flags 256 B | tile 0 | tile 1] and the
     // peers' mappings of theirs; serves the row-parallel all-reduces of forwards with M <= p2p_rows, RCCL the rest
     void*        p2p_seg = nullptr;
@@ -928,6 +930,10 @@ int tm_engine_create(tm_engine** out, const tm_engine_config* c)
     {
         const char* fc = getenv("TM_FORCE_COMM");
         e->use_comm    = c->tp > 1 || (fc && atoi(fc));
+        const char* ms    = getenv("TM_MIXED_STEP");
+        const char* gc    = getenv("TM_GRAPH_COMM");
+        e->mixed_steps_on = !(ms && !atoi(ms));
+        e->graph_comm     = !(gc && !atoi(gc));
     }
     e->qkv_n       = (e->q_heads + 2 * e->kv_heads) * e->D;
     TM_REQUIRE((e->inter * 1) % 128 == 0 && (e->q_heads * e->D) % 128 == 0 && m.hidden % 128 == 0,
@@ -2097,8 +2103,7 @@ static bool graph_enabled(const tm_engine* e)
     if (!e->use_comm) {
         return true;
     }
-    const char* gc = getenv("TM_GRAPH_COMM");  // default on; TM_GRAPH_COMM=0 keeps collectives out of graphs
-    return !(gc && !atoi(gc)) && !e->graph_comm_failed;
+    return e->graph_comm && !e->graph_comm_failed;  // TM_GRAPH_COMM=0 (read at create) keeps collectives out of graphs
 }
 
 static int capture_step(tm_engine* e, int (*step)(tm_engine*), hipGraphExec_t* exec)
@@ -2285,7 +2290,7 @@ static int step_locked(tm_engine* e, int* n_active, int* n_waiting, std::vector<
     // 1. admission + prefill (budget = max_prefill_token_num tokens of prompts per step)
     // Mixed steps (TM_MIXED_STEP, default on): when something is already decoding, the decode step rides on the admission's
     // last prefill forward -- one weight stream for both (reference: the unified batch of unified_attention_layer.cc:310-311).
-    const bool        mixed_on = !getenv("TM_MIXED_STEP") || atoi(getenv("TM_MIXED_STEP")) != 0;
+    const bool        mixed_on = e->mixed_steps_on;  // TM_MIXED_STEP, read when the engine was created
     // Every configuration mixes: tp > 1 (the row-parallel reductions of the merged forward take the large-message path),
     // logits processors (the seen-mask update skips decode rows whose slot holds no running sequence), fp16 KV (the decode
     // rows' K/V go through kv_rope_store instead of the fused prologue), admissions of any size (see prefill_slots).

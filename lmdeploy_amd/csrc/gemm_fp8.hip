@@ -467,7 +467,8 @@ static int fp8_splits(int col_wgs, int KB, int want)
 int launch_linear_fp8(const LinearWeight& w, const uint8_t* xq, const float* sx, int ldsx, half_t* y, int ldy, int M, bool gated_silu,
                       int splits, float* workspace, int* slabs_out, hipStream_t st)
 {
-    TM_REQUIRE(fp8_mfma_supported(w), "fp8 MFMA linear: e4m3 weights in P8 layout, N % 32 == 0");
+    // (the TM_FP8_MFMA switch is evaluated where the path is CHOSEN -- fp8_mfma_supported at load / dispatch time --, not per launch)
+    TM_REQUIRE(w.type == 2 && w.packed8 != nullptr && w.N % 32 == 0 && w.K % 128 == 0, "fp8 MFMA linear: e4m3 weights in P8 layout, N % 32 == 0");
     if (slabs_out) {
         *slabs_out = 1;
     }
