@@ -161,6 +161,8 @@ __global__ __launch_bounds__(256, 2) void decode_attention_i8_mfma_kernel(Decode
     const int wgid = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
     if (p.dbg && threadIdx.x == 0) {
         p.dbg[wgid * 8 + 0] = __builtin_amdgcn_s_memrealtime();
+        // XCC_ID (hwreg 20) in the high word, HW_ID (hwreg 4: wave / SIMD / CU / SE) in the low word
+        p.dbg[wgid * 8 + 4] = ((uint64_t)__builtin_amdgcn_s_getreg(20 | (31 << 11)) << 32) | (uint32_t)__builtin_amdgcn_s_getreg(4 | (31 << 11));
     }
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -602,19 +604,13 @@ int launch_decode_attention_i8_mfma(const DecodeAttnParams& p, hipStream_t st)
     // 4 wave-private images (+ 4 KB q exchange for the fused prologue); the merge buffers overlay the images
     static_assert(4 * kWaveLds + 4096 > 4 * 16 * 128 * 4 + 4 * 16 * 2 * 4, "merge buffers must fit");
     const int lds = 4 * kWaveLds + 4096;
-    static bool attr_set[16] = {};  // the raised dynamic-LDS limit is a per-device function attribute
-    int         dev = 0;
-    (void)hipGetDevice(&dev);
-    if (!attr_set[dev & 15]) {
-        TM_HIP_CHECK(hipFuncSetAttribute((const void*)decode_attention_i8_mfma_kernel<false, 8>,
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        TM_HIP_CHECK(hipFuncSetAttribute((const void*)decode_attention_i8_mfma_kernel<true, 8>,
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        TM_HIP_CHECK(hipFuncSetAttribute((const void*)decode_attention_i8_mfma_kernel<false, 4>,
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        TM_HIP_CHECK(hipFuncSetAttribute((const void*)decode_attention_i8_mfma_kernel<true, 4>,
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        attr_set[dev & 15] = true;
+    const void* const k = (p.qkv_slabs || p.qkv_f16) ?
+                              (p.cache.layout.bits == 4 ? (const void*)decode_attention_i8_mfma_kernel<true, 4> :
+                                                          (const void*)decode_attention_i8_mfma_kernel<true, 8>) :
+                              (p.cache.layout.bits == 4 ? (const void*)decode_attention_i8_mfma_kernel<false, 4> :
+                                                          (const void*)decode_attention_i8_mfma_kernel<false, 8>);
+    if (const int rc = ensure_dynamic_lds(k, lds)) {
+        return rc;
     }
     if (p.qkv_slabs || p.qkv_f16) {
         TM_REQUIRE(p.qkv_n % 8 == 0 && (p.qkv_splits == 0) == (p.qkv_slabs == nullptr), "fused qkv input");

@@ -699,13 +699,8 @@ static int launch_dec32_one(const Dec32Params& p, dim3 grid, hipStream_t st)
     constexpr int stage = 2 * S * 32 * MH * 256;
     constexpr int red   = WK * 32 * MH * CG * 128;
     constexpr int lds   = stage > red ? stage : red;
-    static bool   attr_set[16] = {};
-    int           dev = 0;
-    (void)hipGetDevice(&dev);
-    if (!attr_set[dev & 15]) {
-        TM_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_dec32_kernel<MH, CG, WK, S, PF, ABL>,
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        attr_set[dev & 15] = true;
+    if (const int rc = ensure_dynamic_lds((const void*)gemm_dec32_kernel<MH, CG, WK, S, PF, ABL>, lds)) {
+        return rc;
     }
     gemm_dec32_kernel<MH, CG, WK, S, PF, ABL><<<grid, CG * WK * 64, lds, st>>>(p);
     TM_HIP_CHECK(hipGetLastError());
@@ -965,12 +960,8 @@ template<int ABL>
 static int launch_pre64_one(const Dec32Params& p, dim3 grid, hipStream_t st)
 {
     constexpr int lds = 96 * 1024;  // two 32 KB stages; > 80 KB so that exactly one workgroup (8 waves x 256 registers) owns the CU
-    static bool   attr_set[16] = {};
-    int           dev = 0;
-    (void)hipGetDevice(&dev);
-    if (!attr_set[dev & 15]) {
-        TM_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_pre64_kernel<ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        attr_set[dev & 15] = true;
+    if (const int rc = ensure_dynamic_lds((const void*)gemm_pre64_kernel<ABL>, lds)) {
+        return rc;
     }
     gemm_pre64_kernel<ABL><<<grid, 512, lds, st>>>(p);
     TM_HIP_CHECK(hipGetLastError());

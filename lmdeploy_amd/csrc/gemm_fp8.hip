@@ -422,12 +422,8 @@ static int launch_fp8_one(const Fp8Params& p, dim3 grid, hipStream_t st)
     constexpr int stage = 2 * S * 32 * MH * 128;
     constexpr int red   = WK * 32 * MH * CG * 128;
     constexpr int lds   = stage > red ? stage : red;
-    static bool   attr_set[16] = {};
-    int           dev = 0;
-    (void)hipGetDevice(&dev);
-    if (!attr_set[dev & 15]) {
-        TM_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_fp8_kernel<MH, CG, WK, S, GRP>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        attr_set[dev & 15] = true;
+    if (const int rc = ensure_dynamic_lds((const void*)gemm_fp8_kernel<MH, CG, WK, S, GRP>, lds)) {
+        return rc;
     }
     gemm_fp8_kernel<MH, CG, WK, S, GRP><<<grid, CG * WK * 64, lds, st>>>(p);
     TM_HIP_CHECK(hipGetLastError());

@@ -832,13 +832,9 @@ static int launch_one(const GemmParams& p, dim3 grid, hipStream_t st)
     // Requesting more than half of the 160 KB LDS makes co-residency impossible.
     static const int exclusive = env_int("TM_GEMM_EXCLUSIVE_CU", 1);
     const int lds = (exclusive && WN * WK >= 8 && lds_need < 84 * 1024 && grid.x * grid.y * grid.z <= 256) ? 84 * 1024 : lds_need;
-    static bool attr_set[16] = {};  // the raised dynamic-LDS limit is a per-device function attribute
-    int         dev = 0;
-    (void)hipGetDevice(&dev);
-    if (!attr_set[dev & 15]) {
-        TM_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_kernel<WT, MT, NT, WN, WK, KS, PF, ABL, GRP>,
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, lds_need > 84 * 1024 ? lds_need : 84 * 1024));
-        attr_set[dev & 15] = true;
+    if (const int rc = ensure_dynamic_lds((const void*)gemm_kernel<WT, MT, NT, WN, WK, KS, PF, ABL, GRP>,
+                                          lds_need > 84 * 1024 ? lds_need : 84 * 1024)) {
+        return rc;
     }
     gemm_kernel<WT, MT, NT, WN, WK, KS, PF, ABL, GRP><<<grid, WN * WK * 64, lds, st>>>(p);
     TM_HIP_CHECK(hipGetLastError());

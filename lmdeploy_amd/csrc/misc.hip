@@ -7,6 +7,8 @@
 //           QuantizeGroupwise / IntegralQuantizer (kernels/quantization.cu:384-440,515-676).
 #include "tm_common.h"
 #include "tm_kernels.h"
+#include <map>
+#include <mutex>
 
 namespace tmk {
 
@@ -240,6 +242,22 @@ int launch_quantize_groupwise_u4(int32_t* qweight, half_t* scales, half_t* zeros
     }
     quantize_groupwise_u4_kernel<<<(total + 255) / 256, 256, 0, st>>>(qweight, scales, zeros, dequant, w, K, N, group);
     TM_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int ensure_dynamic_lds(const void* kernel, int bytes)
+{
+    static std::mutex                               mu;
+    static std::map<std::pair<const void*, int>, int> done;  // (kernel, device) -> bytes granted
+    int dev = 0;
+    TM_HIP_CHECK(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lk(mu);
+    auto                        it = done.find({kernel, dev});
+    if (it != done.end() && it->second >= bytes) {
+        return 0;
+    }
+    TM_HIP_CHECK(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    done[{kernel, dev}] = bytes;
     return 0;
 }
 

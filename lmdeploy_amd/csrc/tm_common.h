@@ -20,6 +20,9 @@ constexpr int kWave = 64;
 // ---- error plumbing (C-ABI never throws) -----------------------------------------------
 void        set_last_error(const std::string& msg);
 const char* get_last_error();
+// Raise a kernel's dynamic-LDS limit on the CURRENT device, once per (kernel, device): hipFuncAttributeMaxDynamicSharedMemorySize
+// is a per-device function attribute.  Thread-safe (engines of several devices / threads launch concurrently).
+int         ensure_dynamic_lds(const void* kernel, int bytes);
 
 #define TM_HIP_CHECK(expr)                                                                         \
     do {                                                                                           \

@@ -75,6 +75,25 @@ def main():
             for name, v in (('start skew', t[:, 0] - t0), ('prologue', t[:, 1] - t[:, 0]), ('wave0 loop', t[:, 2] - t[:, 1]),
                             ('wait waves', t[:, 5] - t[:, 2]), ('merge+store', t[:, 3] - t[:, 5]), ('end time', t[:, 3] - t0)):
                 print(f'  {name:11s} min {v.min():6.2f}  mean {v.mean():6.2f}  p90 {np.percentile(v, 90):6.2f}  max {v.max():6.2f} us')
+            # where do the late workgroups sit?  end time by XCD, by CU, by (sequence, kv head)
+            live = raw[raw[:, 0] > 0]
+            end = live[:, 3].astype(np.float64) / 100.0 - t0
+            xcc = ((live[:, 4] >> 32) & 0xf).astype(int)
+            hw = (live[:, 4] & 0xffffffff).astype(np.int64)
+            cuid = ((hw >> 8) & 0xf) | (((hw >> 13) & 0x7) << 4) | (xcc << 7)      # CU_ID | SE_ID << 4 | XCC << 7
+            start = live[:, 0].astype(np.float64) / 100.0 - t0
+            print('  end time by XCD: ' + '  '.join(f'{x}: {end[xcc == x].mean():5.1f} (n {int((xcc == x).sum())})' for x in range(8)))
+            print('  start    by XCD: ' + '  '.join(f'{x}: {start[xcc == x].mean():5.2f}' for x in range(8)))
+            print('  max end  by XCD: ' + '  '.join(f'{x}: {end[xcc == x].max():5.1f}' for x in range(8)))
+            per_cu = {}
+            for c, e_ in zip(cuid, end):
+                per_cu.setdefault(int(c), []).append(e_)
+            occ = np.bincount([len(v) for v in per_cu.values()])
+            print(f'  CUs used {len(per_cu)}; workgroups per CU histogram {occ.tolist()}; mean end of CUs with 1 / 2 / 3+ WGs: ' +
+                  ' / '.join(f"{np.mean([np.max(v) for v in per_cu.values() if (len(v) if len(v) < 3 else 3) == k]) if any((len(v) if len(v) < 3 else 3) == k for v in per_cu.values()) else float('nan'):.1f}" for k in (1, 2, 3)))
+            order = np.argsort(live[:, 0])
+            q = len(order) // 4
+            print('  end time by launch-order quartile: ' + '  '.join(f'{end[order[i * q:(i + 1) * q]].mean():5.1f}' for i in range(4)))
         return
     for splits in [int(s) for s in a.splits.split(',')]:
         ws = torch.empty(max(1, tm.tm_decode_attention_workspace(B, Hq, splits)), dtype=torch.uint8, device='cuda')
