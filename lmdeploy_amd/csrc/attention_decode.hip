@@ -170,11 +170,11 @@ __global__ __launch_bounds__(256, 2) void decode_attention_kernel(DecodeAttnPara
         for (int r = 0; r < IPT; ++r) {
             const char* ptr = kdata + (size_t)(r * TPI + tg) * TOKB + c * Tr::LOAD_BYTES;
             if constexpr (LW == 4) {
-                const u32x4 t = *(const u32x4*)ptr;
+                const u32x4 t = __builtin_nontemporal_load((const u32x4*)ptr);  // read once per launch: streaming policy
                 kraw[r][0] = t[0], kraw[r][1] = t[1], kraw[r][2] = t[2], kraw[r][3] = t[3];
             }
             else {
-                const u32x2 t = *(const u32x2*)ptr;
+                const u32x2 t = __builtin_nontemporal_load((const u32x2*)ptr);
                 kraw[r][0] = t[0], kraw[r][1] = t[1];
             }
         }
@@ -209,11 +209,11 @@ __global__ __launch_bounds__(256, 2) void decode_attention_kernel(DecodeAttnPara
         for (int r = 0; r < IPT; ++r) {
             const char* ptr = vdata + (size_t)(r * TPI + tg) * TOKB + c * Tr::LOAD_BYTES;
             if constexpr (LW == 4) {
-                const u32x4 t = *(const u32x4*)ptr;
+                const u32x4 t = __builtin_nontemporal_load((const u32x4*)ptr);  // read once per launch: streaming policy
                 vraw[r][0] = t[0], vraw[r][1] = t[1], vraw[r][2] = t[2], vraw[r][3] = t[3];
             }
             else {
-                const u32x2 t = *(const u32x2*)ptr;
+                const u32x2 t = __builtin_nontemporal_load((const u32x2*)ptr);
                 vraw[r][0] = t[0], vraw[r][1] = t[1];
             }
         }
