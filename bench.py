@@ -197,7 +197,10 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if world != args.gpus:
         sys.exit(f'bench.py: --gpus {args.gpus} but the launcher set WORLD_SIZE={world}')
-    torch.cuda.set_device(local_rank)
+    # one GPU per rank; on a box with fewer GPUs than ranks (the 1-GPU test box: `--gpus 2` exercises the launcher, the RCCL
+    # bring-up failure -> native communicator fall-back and the tuning-table broadcast) ranks share devices
+    local_dev = local_rank % max(1, torch.cuda.device_count())
+    torch.cuda.set_device(local_dev)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group('gloo', rank=rank, world_size=world)   # control plane only; data plane = RCCL in C++
@@ -217,7 +220,7 @@ def main():
     full_run = (not args.no_full_run) and not child and 1 + W + K < 1024     # continue to 1024 generated tokens after the timed region
     max_new = max(1 + W + K + P + 2, (1024 + P + 2) if full_run else 0)
     weight_type = int(model.pop('weight_type', 0))
-    eng = Engine.from_model_config(_Cfg(model), weight_type=weight_type, tp=world, rank=rank, device=local_rank, max_batch_size=B,
+    eng = Engine.from_model_config(_Cfg(model), weight_type=weight_type, tp=world, rank=rank, device=local_dev, max_batch_size=B,
                                    session_len=S + max_new + 1, quant_policy=args.quant_policy,
                                    max_prefill_token_num=8192, use_graph=0 if args.no_graph else 1)
     dog = Watchdog(world > 1, rank)

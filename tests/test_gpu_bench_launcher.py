@@ -1,0 +1,35 @@
+"""bench.py's multi-rank path on the ONE-GPU test box: `--gpus 2` starts two ranks that share cuda:0.  RCCL refuses two ranks on
+one device, which is exactly the failure the launcher must survive: every rank reports it, ALL ranks drop RCCL and continue on
+the native P2P communicator (comm_p2p.hip), rank 0's measured GEMM dispatch table is broadcast, the decode step (collectives
+included) is captured in a hipGraph, and the JSON line says what actually ran (`tm_engine_comm_info`), not what was intended.
+(the first multi-GPU run must be survivable.  Reference: one process per rank + NCCL id exchange,
+lmdeploy/turbomind/turbomind.py:187-217, src/turbomind/comm/nccl/nccl.cu:505-518.)"""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.timeout(600)
+def test_bench_two_ranks_on_one_gpu_falls_back_to_the_native_communicator(cuda):
+    env = dict(os.environ, GPU_MAX_HW_QUEUES='8', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    env.pop('WORLD_SIZE', None)
+    pr = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '6', '--warmup', '3', '--layers', '2',
+                         '--batch', '8', '--prompt-len', '96', '--no-traffic', '--no-cpu-baseline', '--no-full-run', '--profile-steps', '0'],
+                        env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=480)
+    assert pr.returncode == 0, pr.stderr[-3000:]
+    line = [ln for ln in pr.stdout.strip().splitlines() if ln.startswith('{')][-1]
+    d = json.loads(line)
+    cfg = d['config']
+    assert d['n_gpus'] == 2 and d['value'] > 0 and cfg['parallelism'] == 'tp2'
+    assert cfg['collectives'] == 'native-p2p' and cfg['rccl_ranks'] == 2, cfg
+    assert 'RCCL init failed' in cfg['collectives_note']
+    assert cfg['hipgraph'] is True
+    assert set(cfg['gemm_tilings']) == {'w_qkv', 'wo', 'w1w3', 'w2'} and 'broadcast' in cfg['gemm_dispatch']
+    assert 'scaling_note' in d
+    assert 'RCCL communicator failed' in pr.stderr
