@@ -266,6 +266,8 @@ def main():
                 with tempfile.TemporaryDirectory() as td:
                     path = os.path.join(td, 'gemm_table.txt')
                     eng.tune_gemm(B, path)
+                    if B * S >= 8192:          # the prefill forwards of this run are 8192-token chunks: their size class as well
+                        eng.tune_gemm(8192, path)
                     table = open(path).read()
             except Exception as exc:    # noqa: BLE001 -- the heuristics are the measured winners on these shapes anyway
                 print(f'[bench] GEMM tuning skipped: {exc}', file=sys.stderr)

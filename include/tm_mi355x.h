@@ -379,9 +379,10 @@ int tm_engine_set_logits_params(tm_engine* e, const tm_logits_param* host_params
 /* release the batch (blocks return to the pool); also ends a continuous-batching session */
 int tm_engine_release(tm_engine* e);
 /* Measured GEMM dispatch (the reference's warm-up tuning, turbomind.cc:363-487 / kernels/gemm/gemm.cu:92-224): time every
- * (workgroup shape, split-K) candidate of the decode kernels for the model's w_qkv / wo / w1w3 / w2 at M (<= 256) rows -- as a
- * hipGraph over the engine's own layer weights, each GEMM followed by the kernel that consumes it -- and remember the winner
- * per (K, N, M).  After tm_engine_start, before the first batch.  export_path (may be NULL): write the table as text lines
+ * (workgroup shape, split-K) candidate of the W4A16 kernels for the model's w_qkv / wo / w1w3 / w2 at M rows -- M <= 256: a decode
+ * batch, keyed by the exact M; M = 512, 1024, 2048, 4096, 8192 (<= max_prefill_token_num): the size class of prefill forwards
+ * with up to M tokens -- as a hipGraph over the engine's own layer weights, each GEMM followed by the kernel that consumes it,
+ * and remember the winner per (K, N, M).  After tm_engine_start, before the first batch.  export_path (may be NULL): write the table as text lines
  * "K N M shape splits".  Environment equivalents read by tm_engine_start: TM_GEMM_TUNE=1 (M = max_batch_size),
  * TM_GEMM_EXPORT=<file>, TM_GEMM_IMPORT=<file>; TM_GEMM_TUNE_VERBOSE=1 prints every measurement to stderr. */
 int tm_engine_tune_gemm(tm_engine* e, int M, const char* export_path);

@@ -1253,7 +1253,9 @@ int tm_engine_process_weights(tm_engine* e)
 // ------------------------------------------------------------------------------------------------------------------
 static int tune_decode_gemms(tm_engine* e, int M, bool verbose)
 {
-    TM_REQUIRE(M >= 1 && M <= 256 && M <= e->cfg.max_batch_size, "tuning covers the decode kernels: 1 <= M <= min(256, max_batch_size)");
+    TM_REQUIRE(M >= 1 && M <= e->max_tokens && M == dec32_m_bucket(M),
+               "tuning: 1 <= M <= 256 (a decode batch) or a prefill size class 512, 1024, ... 8192, within max_prefill_token_num");
+    half_t* const norm_out = M <= e->cfg.max_batch_size ? e->d_last : e->d_x;  // (d_x is the INPUT of w_qkv / w1w3 only)
     hipStream_t st = e->stream;
     struct Role {
         const char*   name;
@@ -1327,13 +1329,13 @@ static int tune_decode_gemms(tm_engine* e, int M, bool verbose)
                 for (const LinearWeight* w : ws) {
                     int slabs = 1;
                     if (tail_consumer) {  // as linear_residual_norm runs it: the consumer inside the launch
-                        NormTail tail{e->d_last, e->d_resid, e->final_norm, e->cfg.model.rms_eps, e->d_tail_sync};
+                        NormTail tail{norm_out, e->d_resid, e->final_norm, e->cfg.model.rms_eps, e->d_tail_sync};
                         TM_TRY(launch_linear(*w, r.x, r.ldx, nullptr, r.ldy, M, false, cfg, e->d_gemm_ws, true, nullptr, st, &tail));
                         continue;
                     }
                     TM_TRY(launch_linear(*w, r.x, r.ldx, r.y, r.ldy, M, r.gated, cfg, e->d_gemm_ws, norm_consumer && cfg.splits > 1, &slabs, st));
                     if (norm_consumer) {
-                        TM_TRY(launch_residual_rmsnorm(e->d_last, e->d_resid, slabs > 1 ? nullptr : e->d_tmp, slabs > 1 ? e->d_gemm_ws : nullptr,
+                        TM_TRY(launch_residual_rmsnorm(norm_out, e->d_resid, slabs > 1 ? nullptr : e->d_tmp, slabs > 1 ? e->d_gemm_ws : nullptr,
                                                        slabs, nullptr, e->final_norm, e->cfg.model.rms_eps, M, e->hidden, st));
                     }
                 }

@@ -1134,7 +1134,7 @@ int dec32_table_import(const char* path)
     int K, N, M, shape, splits, n = 0;
     while (fscanf(f, "%d %d %d %d %d", &K, &N, &M, &shape, &splits) == 5) {
         const bool big = M > 64;
-        if (K > 0 && N > 0 && M > 0 && M <= 256 && shape >= 0 && shape <= 9 && splits >= 1 && splits <= 16
+        if (K > 0 && N > 0 && M > 0 && M == dec32_m_bucket(M) && shape >= 0 && shape <= 9 && splits >= 1 && splits <= 16
             && (big ? shape >= 4 : (shape != 4 && shape != 5)) && !(shape == 5 && N < 512) && K % 128 == 0 && N % 32 == 0) {
             dec32_table_set(K, N, M, shape, splits);
             ++n;
@@ -1145,14 +1145,29 @@ int dec32_table_import(const char* path)
 }
 
 // every (shape, splits) the decode kernels can run this linear with at M <= 256 rows: whole stages per slice, <= 512 workgroups
+// The dispatch table is keyed by the exact row count up to 256 (decode batches) and by power-of-two buckets above (prefill
+// forwards of an admission have arbitrary token counts: 512, 1024, ... 8192 stand for everything up to them)
+int dec32_m_bucket(int M)
+{
+    if (M <= 256) {
+        return M;
+    }
+    int b = 512;
+    while (b < M && b < 8192) {
+        b <<= 1;
+    }
+    return b;
+}
+
 int dec32_candidates(const LinearWeight& w, int M, int (*out)[2], int cap)
 {
     const int ncg = w.N / 32, KB = w.K / 128;
     int       n   = 0;
-    for (int shape = 0; shape < 10 && M <= 256; ++shape) {
+    for (int shape = 0; shape < 10 && M <= 8192; ++shape) {
         const bool rows32 = shape >= 6;  // 32-row blocks on grid.z: any M
-        if (rows32 ? M <= 32 : ((shape == 4 || shape == 5) != (M > 64))) {
-            continue;  // one row block: identical to the base shape / 64-row shapes take M <= 64, 128-row tiles M > 64
+        if (rows32 ? (M <= 32 || M > 1024) : ((shape == 4 || shape == 5) != (M > 64))) {
+            continue;  // one row block: identical to the base shape / 64-row shapes take M <= 64, 128-row tiles M > 64; beyond
+                       // 1024 rows a 32-row block re-reads every weight unit > 32 times: never competitive
         }
         if (shape == 5 && w.N < 512) {
             continue;
@@ -1166,8 +1181,8 @@ int dec32_candidates(const LinearWeight& w, int M, int (*out)[2], int cap)
             if ((KB + per - 1) / per != s) {
                 continue;  // not a distinct slicing
             }
-            if ((s > 1 && tiles * s > (rows32 ? 512 : 320)) || tiles * s < 32) {
-                continue;  // split-K beyond one (32-row shapes: two) workgroup(s) per CU / a handful of workgroups
+            if ((s > 1 && tiles * s > (rows32 ? 512 : 320)) || tiles * s < 32 || (M > 256 && s > 4)) {
+                continue;  // split-K beyond one (32-row shapes: two) workgroup(s) per CU / a handful of workgroups / slabs of MBs per slice
             }
             if (n < cap) {
                 out[n][0] = shape;
@@ -1190,8 +1205,8 @@ void dec32_pick_ex(const LinearWeight& w, int M, int* shape_out, int* splits_out
 {
     const int ncg = w.N / 32;
     const int KB  = w.K / 128;
-    if (use_table && M <= 256 && dec32_table_get(w.K, w.N, M, shape_out, splits_out)) {
-        return;  // measured on this machine for exactly this problem
+    if (use_table && dec32_table_get(w.K, w.N, dec32_m_bucket(M), shape_out, splits_out)) {
+        return;  // measured on this machine for exactly this problem (M <= 256) / for this size class of forwards (above)
     }
     static const int env_shape  = env_int2("TM_D32_SHAPE", -1);  // read once: this runs on every eager launch
     static const int env_splits = env_int2("TM_D32_SPLITS", 0);
@@ -1203,7 +1218,12 @@ void dec32_pick_ex(const LinearWeight& w, int M, int* shape_out, int* splits_out
         // M <= 256 (batch-128 decode, small admissions): 256-column tiles keep more workgroups alive; beyond that the
         // 512-column tile with two weight fragments per x-fragment read (TM_PRE64_MIN_M: first M that takes it)
         static const int pre64_from = env_int2("TM_PRE64_MIN_M", 257);
-        shape = (M >= pre64_from && w.N >= 512) ? 5 : 4;
+        // The 128 x 512 tile only when it alone puts ~one workgroup on most CUs; otherwise the 128 x 256 tile with at most 4
+        // split-K slices (round 3, measured by the tuner at the Llama-3-8B shapes, us per layer incl. the consumer --
+        // M = 512: w_qkv 49.3 -> 36.5, wo 44.9 -> 28.5, w2 74.2 -> 54.2; M = 1024: 66.8 -> 48.1, 61.4 -> 41.5, 105.5 -> 92.6;
+        // M = 2048: wo 81.6 -> 61.2; from M = 4096 the wide tile wins everywhere: profiles/r03_gemm_tune_prefill_classes.txt)
+        const int wgs5 = (ncg + 15) / 16 * ((M + 127) / 128);
+        shape          = (M >= pre64_from && w.N >= 512 && wgs5 >= 192) ? 5 : 4;
     }
     // Narrow projections at a full decode batch (33 .. 64 rows, N <= 8192: w_qkv, wo, w2 of an 8B model): 64-column tiles
     // with as little split-K as still gives ~256 workgroups.  Split-K costs more at the kernel boundary than it buys inside
@@ -1243,8 +1263,8 @@ void dec32_pick_ex(const LinearWeight& w, int M, int* shape_out, int* splits_out
         if (eff != s) {
             continue;
         }
-        if (col_wgs * s <= 256 && per >= (M > 64 ? 8 : min_kb)) {
-            splits = s;
+        if (col_wgs * s <= 256 && per >= (M > 64 ? 8 : min_kb) && (M <= 256 || s <= 4)) {
+            splits = s;  // (prefill-sized forwards: slabs of MBs per slice -- never more than 4)
         }
     }
     splits      = env_splits > 0 ? env_splits : splits;

@@ -170,6 +170,7 @@ void   dec32_table_clear();
 int    dec32_table_export(const char* path);
 int    dec32_table_import(const char* path);
 int    dec32_candidates(const LinearWeight& w, int M, int (*out)[2], int cap);
+int    dec32_m_bucket(int M);  // table key of a forward with M rows: M itself up to 256, then 512, 1024, ... 8192
 int    launch_linear_dec32(const LinearWeight& w, const half_t* x, int ldx, half_t* y, int ldy, int M, bool gated_silu, int shape,
                            int splits, float* workspace, int* slabs_out, hipStream_t st, const NormTail* tail = nullptr);
 

@@ -97,8 +97,11 @@ def _candidates(tm, K, N, M):
 
 
 # the four Llama-3-8B linears at batch 64 and the InternLM2-20B ones at batch 128 (BASELINE configs 2 / 3)
+# ... and prefill-sized forwards of a continuous-batching admission (size classes 512 / 1024 of the dispatch table; 600 = a ragged
+# last row block)
 TUNER_SHAPES = [(4096, 6144, 0, 64), (4096, 4096, 0, 64), (4096, 28672, 1, 64), (14336, 4096, 0, 64),
-                (6144, 8192, 0, 128), (6144, 6144, 0, 128), (6144, 32768, 1, 128), (16384, 6144, 0, 128)]
+                (6144, 8192, 0, 128), (6144, 6144, 0, 128), (6144, 32768, 1, 128), (16384, 6144, 0, 128),
+                (4096, 4096, 0, 512), (14336, 4096, 0, 600), (4096, 28672, 1, 1024), (4096, 6144, 0, 2048)]
 
 
 @pytest.mark.parametrize('K,N,gated,M', TUNER_SHAPES)
@@ -116,7 +119,7 @@ def test_w4a16_every_tuner_candidate_full_size(tm, cuda, K, N, gated, M):
     ws = torch.zeros(max(1, tm.tm_linear_workspace(h, M)), dtype=torch.uint8, device='cuda')
     x_d = dev(x)
     cands = _candidates(tm, K, N, M)
-    assert len(cands) >= 8, cands
+    assert len(cands) >= (8 if M <= 256 else 2), cands
     hs, hp = _ffi.C.c_int(0), _ffi.C.c_int(0)
     _ffi.check(tm.tm_debug_pick_tiling(K, N, M, 0, _ffi.C.byref(hs), _ffi.C.byref(hp)))
     for shape, splits in cands + [(hs.value, hp.value)]:

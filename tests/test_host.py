@@ -60,6 +60,17 @@ def test_decode_gemm_heuristic_equals_the_measured_winners(tmp_path):
     assert lib.tm_gemm_import(str(f).encode()) == 0
     assert _pick(lib, 5120, 5120, 64, table=1) == (2, 3) and _pick(lib, 5120, 5120, 64, table=0) != (2, 3)
     assert _pick(lib, 5120, 5120, 48, table=1) == _pick(lib, 5120, 5120, 48, table=0)
+    # prefill-sized forwards (round 3, profiles/r03_gemm_tune_prefill_classes.txt): the 128 x 256 tile with <= 4 slices unless the
+    # 128 x 512 tile alone fills the chip -- the tuner's winners at the Llama-3-8B shapes
+    assert [_pick(lib, 4096, 6144, m) for m in (512, 1024, 2048, 8192)] == [(4, 2), (4, 1), (5, 1), (5, 1)]
+    assert [_pick(lib, 4096, 4096, m) for m in (512, 1024, 2048, 8192)] == [(4, 4), (4, 2), (4, 1), (5, 1)]
+    assert [_pick(lib, 14336, 4096, m) for m in (512, 1024, 2048, 8192)] == [(4, 4), (4, 2), (4, 1), (5, 1)]
+    assert [_pick(lib, 4096, 28672, m) for m in (512, 1024, 8192)] == [(5, 1), (5, 1), (5, 1)]
+    # above 256 rows the table is keyed by size class: an entry measured at 512 serves every forward of 257 .. 512 rows
+    f.write_text('5120 5120 512 4 3\n5120 5120 300 4 2\n')      # the second line is not a class key: ignored
+    assert lib.tm_gemm_import(str(f).encode()) == 0
+    assert _pick(lib, 5120, 5120, 400, table=1) == (4, 3) and _pick(lib, 5120, 5120, 512, table=1) == (4, 3)
+    assert _pick(lib, 5120, 5120, 600, table=1) == _pick(lib, 5120, 5120, 600, table=0)
 
 
 def test_gemm_dispatch_table_import(tmp_path):

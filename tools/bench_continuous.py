@@ -22,6 +22,7 @@ def main():
     ap.add_argument('--batch', type=int, default=64)
     ap.add_argument('--prompt', default='64,1024')
     ap.add_argument('--out', default='32,256')
+    ap.add_argument('--tune', type=int, default=1)
     args = ap.parse_args()
     from lmdeploy_amd.turbomind.engine import Engine
     p0, p1 = map(int, args.prompt.split(','))
@@ -33,6 +34,9 @@ def main():
                                    max_prefill_token_num=8192)
     eng.init_synthetic(seed=0)
     eng.start()
+    if args.tune:   # measured GEMM dispatch: the decode batch and every prefill size class an admission can produce
+        for m in (args.batch, 512, 1024, 2048, 4096, 8192):
+            eng.tune_gemm(m)
     prompts = [rng.integers(0, LLAMA3_8B['vocab'], n).astype(np.int32) for n in plen]
     # warm-up: one short session (graph capture, lazy module loads)
     for p in prompts[:2]:
@@ -58,7 +62,8 @@ def main():
                       'batch_slots': args.batch, 'prompt_len': [p0, p1], 'output_len': [o0, o1], 'prompt_tokens': int(plen.sum()),
                       'output_tokens': got, 'wall_s': round(dt, 3), 'scheduler_steps': steps,
                       'mean_active_slots': round(occ / steps, 1), 'total_tokens_per_s': round((got + int(plen.sum())) / dt, 1),
-                      'mixed_steps': eng.mixed_steps(), 'TM_MIXED_STEP': os.environ.get('TM_MIXED_STEP', '1')}))
+                      'mixed_steps': eng.mixed_steps(), 'TM_MIXED_STEP': os.environ.get('TM_MIXED_STEP', '1'),
+                      'gemm_dispatch': 'measured (decode batch + prefill size classes 512 .. 8192)' if args.tune else 'heuristic'}))
     eng.close()
 
 
