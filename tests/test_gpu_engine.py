@@ -15,8 +15,12 @@ from oracle import tm_oracle as o
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize('kv_bits,use_graph', [(8, 1), (4, 0), (16, 1)])
-def test_engine_matches_oracle(cuda, kv_bits, use_graph):
+@pytest.mark.parametrize('kv_bits,use_graph,tail', [(8, 1, 0), (4, 0, 0), (16, 1, 0), (8, 1, 1), (4, 0, 1)])
+def test_engine_matches_oracle(cuda, monkeypatch, kv_bits, use_graph, tail):
+    """prefill + 6 decode steps of a ragged batch against the oracle model: logits of every step, greedy tokens.  tail = 1:
+    wo / w2 of the decode steps close with the in-launch residual-norm consumer (TM_GEMM_TAIL=1, gemm_decode.hip), eager and
+    graph-replayed."""
+    monkeypatch.setenv('TM_GEMM_TAIL', str(tail))
     cfg = o.ModelConfig(hidden=256, layers=2, q_heads=4, kv_heads=2, head_dim=128, inter=512, vocab=1024,
                         kv_bits=kv_bits, rope=o.RopeParam(128, 500000.0, 'llama3', 8.0, 1.0, 4.0, 8192))
     w = o.make_synthetic_weights(cfg, seed=3)
@@ -59,7 +63,7 @@ def test_engine_collective_path_single_rank(cuda, monkeypatch, graph_comm, side_
     on one GPU through a 1-rank communicator (TM_FORCE_COMM=1): must reproduce the collective-free engine exactly
     (a 1-rank sum is the identity; the non-deferred split-K reduce rounds the same fp32 sums).  graph_comm=1 also
     captures the RCCL calls into the decode hipGraph; side_stream=1 is the opt-in arm with the collectives on a side stream
-    (fork / join) and the next linear's weights prefetched underneath."""
+    (fork / join)."""
     cfg = o.ModelConfig(hidden=256, layers=2, q_heads=4, kv_heads=2, head_dim=128, inter=512, vocab=1024,
                         kv_bits=8, rope=o.RopeParam(128, 500000.0, 'llama3', 8.0, 1.0, 4.0, 8192))
     w = o.make_synthetic_weights(cfg, seed=5)
@@ -71,7 +75,6 @@ def test_engine_collective_path_single_rank(cuda, monkeypatch, graph_comm, side_
             monkeypatch.setenv('TM_FORCE_COMM', '1')
             monkeypatch.setenv('TM_GRAPH_COMM', str(graph_comm))
             monkeypatch.setenv('TM_COMM_STREAM', str(side_stream))
-            monkeypatch.setenv('TM_COMM_PREFETCH', str(side_stream))
         else:
             monkeypatch.delenv('TM_FORCE_COMM', raising=False)
         eng = Engine.from_model_config(cfg, max_batch_size=4, session_len=128, quant_policy=8, use_graph=1)
