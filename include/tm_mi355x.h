@@ -236,6 +236,17 @@ int tm_p2p_allreduce_norm(void* const* segs, int tp, int me, void* state, int ro
                           const void* weight, float eps, int M, int H, tm_stream_t st);
 int tm_p2p_allgather(void* const* segs, int tp, int me, void* state, int rows, int H, const void* src, void* dst, int words,
                      tm_stream_t st);
+/* Two-shot form for large messages -- AllreduceResidualBiasRMSnorm_Simple_Push / _Pull and the two-shot all-reduce of the reference
+ * (src/turbomind/comm/cuda_ipc/fused_allreduce.cu:25-405, allreduce.cu:22-248): reduce-scatter (rank r sums rows
+ * [r * slice, (r + 1) * slice), slice = ceil(M / tp), of all ranks' partials in rank order), residual + RMSNorm on the owned slice,
+ * all-gather of the normed rows by pushing them into every peer's segment: (tp - 1) / tp of one message read and written per rank
+ * instead of (tp - 1) messages read.  y: all M normed rows (the bits of the one-shot form); resid: updated for the rank's OWN
+ * slice only (the reference shards the residual stream the same way).  Segments of tm_p2p_segment_bytes2(rows, rows2, H) bytes =
+ * [256 B flags | one-shot tile 0 | tile 1 (rows x H each) | in2 | out2 (rows2 x H each)], M <= rows2; shares `state` and the call
+ * sequence with the one-shot calls (it advances the epoch by two). */
+size_t tm_p2p_segment_bytes2(int rows, int rows2, int H);
+int tm_p2p_allreduce_norm_2shot(void* const* segs, int tp, int me, void* state, int rows, int rows2, const void* partial, void* y,
+                                void* resid, const void* weight, float eps, int M, int H, tm_stream_t st);
 
 /* debug / measurement: device buffer of 8192 x 8 uint64 (512 KB) that receives s_memrealtime stamps (100 MHz: kernel
  * entry, loop entry, loop exit, exit, ...) of every GEMM / decode-attention workgroup launched afterwards; launches of more

@@ -131,6 +131,9 @@ _SIGNATURES = {
     'tm_p2p_segment_bytes': (c_size_t, [c_int, c_int]),
     'tm_p2p_allreduce_norm': (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int,
                                c_int, c_void_p]),
+    'tm_p2p_segment_bytes2': (c_size_t, [c_int, c_int, c_int]),
+    'tm_p2p_allreduce_norm_2shot': (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_float,
+                                            c_int, c_int, c_void_p]),
     'tm_p2p_allgather': (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p]),
     'tm_engine_create': (c_int, [POINTER(c_void_p), POINTER(EngineConfig)]),
     'tm_engine_destroy': (c_int, [c_void_p]),

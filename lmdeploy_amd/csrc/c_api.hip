@@ -687,6 +687,28 @@ int tm_p2p_allreduce_norm(void* const* segs, int tp, int me, void* state, int ro
                                      (half_t*)resid, (const half_t*)weight, eps, M, H, (hipStream_t)st);
 }
 
+size_t tm_p2p_segment_bytes2(int rows, int rows2, int H)
+{
+    return 256 + 2 * ((size_t)rows + (size_t)rows2) * (size_t)H * sizeof(half_t);
+}
+
+int tm_p2p_allreduce_norm_2shot(void* const* segs, int tp, int me, void* state, int rows, int rows2, const void* partial, void* y,
+                                void* resid, const void* weight, float eps, int M, int H, tm_stream_t st)
+{
+    TM_REQUIRE(segs && state && partial && y && resid && weight, "null pointer");
+    TM_REQUIRE(tp >= 1 && tp <= 8 && rows >= 0 && rows2 >= 1, "p2p: 1 <= tp <= 8, rows2 >= 1");
+    half_t*   data[8];
+    uint32_t* flags[8];
+    half_t *  in2[8], *out2[8];
+    p2p_tables(segs, tp, data, flags);
+    for (int r = 0; r < tp; ++r) {  // [flags | tile 0 | tile 1 | in2 | out2]
+        in2[r]  = data[r] + 2 * (size_t)rows * H;
+        out2[r] = in2[r] + (size_t)rows2 * H;
+    }
+    return launch_p2p_allreduce_norm_2shot(in2, out2, flags, tp, me, (uint32_t*)state, (size_t)rows2 * H, (const half_t*)partial, (half_t*)y,
+                                           (half_t*)resid, (const half_t*)weight, eps, M, H, (hipStream_t)st);
+}
+
 int tm_p2p_allgather(void* const* segs, int tp, int me, void* state, int rows, int H, const void* src, void* dst, int words,
                      tm_stream_t st)
 {

@@ -33,6 +33,8 @@
 // between devices) has not run on multi-GPU hardware: RCCL stays the default, TM_COMM=native opts in.
 #include "tm_common.h"
 #include "tm_kernels.h"
+#include <algorithm>
+#include <stdlib.h>
 
 namespace tmk {
 
@@ -48,6 +50,11 @@ struct P2pParams {
     const half_t* weight;
     float         eps;
     int           M, H;
+    // two-shot form (p2p_allreduce_norm_2shot_kernel): per rank an input region (every rank's partial rows) and an output region
+    // (the normed rows the slice owners push), both [rows2][H] fp16, behind the one-shot tiles of the same segment
+    half_t*       in2[8];
+    half_t*       out2[8];
+    int           slice;    // rows per rank: rank r owns rows [r * slice, min(M, (r + 1) * slice))
     const uint32_t* src;    // all-gather: n words of this rank
     uint32_t*       dst;    // all-gather: rank q's n words land at dst + q * dst_stride
     int             n;
@@ -60,6 +67,10 @@ constexpr uint32_t kSpinLimit = 1u << 20;  // ~1 s of polling
 __device__ __forceinline__ void p2p_publish_and_wait(const P2pParams& p, uint32_t epoch)
 {
     const int tid = threadIdx.x;
+    // every storing wave drains its own stores before the one release below can cover them (cdna_hip_programming.md Guideline
+    // 16 pitfall 14: "only lane 0 drained" is stale under load)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
     if (tid == 0) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");  // system scope: this XCD's dirty lines of the tile leave the L2
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -186,6 +197,171 @@ __global__ __launch_bounds__(512) void p2p_allreduce_norm_kernel(P2pParams p)
         }
     }
     p2p_exit(p, epoch);
+}
+
+// ---- two-shot form for large messages ---------------------------------------------------------------------------------------
+// Replaces: AllreduceResidualBiasRMSnorm_Simple_Push / _Pull (src/turbomind/comm/cuda_ipc/fused_allreduce.cu:25-405) and the
+// two-shot all-reduce of comm/cuda_ipc/allreduce.cu:22-248: reduce-scatter, residual + RMSNorm on the owned slice, all-gather.
+// A prefill forward's [M][H] partial sums are MBs: the one-shot exchange above reads (tp - 1) x M x H x 2 bytes per rank, this
+// form reads (tp - 1) / tp of one message and writes as much:
+//   0. every rank copies its partial rows into its `in2` region;                                   sync A (epoch e)
+//   1. rank r reduces rows [r * slice, (r + 1) * slice) over all ranks' `in2` (rank order, fp32 -- the one-shot kernel's
+//      association, so the two forms give the same bits), adds ITS slice of the residual stream, normalises, stores the
+//      normed rows locally and PUSHES them into every peer's `out2` region;                         sync B (epoch e + 1)
+//   2. every rank copies the other slices' normed rows from its own `out2` into y.
+// As in the reference the residual stream is sharded by row slice from here on: a rank keeps only its own rows current
+// (nothing else reads them: the next reduction of the same forward owns the same slice; a new forward starts from the embedding).
+// The two syncs per call make the regions reusable without the parity alternation the one-shot form needs; the calls share the
+// epoch counter and flags with it (two epochs per call), so any interleaving of the two forms keeps its ordering argument.
+// Persistent grid: workgroups loop over rows (all of them must be resident: they wait for each other's tickets).
+template<int NV>
+__global__ __launch_bounds__(512) void p2p_allreduce_norm_2shot_kernel(P2pParams p)
+{
+    __shared__ float    red[8];
+    __shared__ uint32_t s_epoch;
+    const int tid = threadIdx.x;
+    if (tid == 0) {
+        s_epoch = __hip_atomic_load(p.state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
+    }
+    __syncthreads();
+    const uint32_t epoch = s_epoch;
+    const int      nvec  = p.H / 8;
+    const int      nthr  = blockDim.x;
+    // ---- 0. own partial rows -> own in2 ----------------------------------------------------------------------------------------
+    for (int row = blockIdx.x; row < p.M; row += gridDim.x) {
+        for (int vi = tid; vi < nvec; vi += nthr) {
+            const size_t o = (size_t)row * p.H + (size_t)vi * 8;
+            *(half8_t*)(p.in2[p.me] + o) = *(const half8_t*)(p.partial + o);
+        }
+    }
+    p2p_publish_and_wait(p, epoch);
+    // ---- 1. reduce + residual + RMSNorm of the owned slice; push the normed rows ---------------------------------------------------
+    const int r0 = p.me * p.slice, r1 = min(p.M, r0 + p.slice);
+    for (int row = r0 + (int)blockIdx.x; row < r1; row += gridDim.x) {
+        half8_t wv[NV], r[NV];
+        size_t  off[NV];
+        bool    ok[NV];
+        float   ss = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int vi = tid + i * nthr;
+            ok[i]        = vi < nvec;
+            const int vc = ok[i] ? vi : nvec - 1;
+            off[i]       = (size_t)row * p.H + (size_t)vc * 8;
+            wv[i]        = *(const half8_t*)(p.weight + (size_t)vc * 8);
+            r[i]         = *(const half8_t*)(p.resid + off[i]);
+            float acc[8] = {};
+            for (int q = 0; q < p.tp; ++q) {  // rank order: the same association on every rank and in the one-shot form
+                const u32x4   raw = __builtin_nontemporal_load((const u32x4*)(p.in2[q] + off[i]));
+                const half8_t v   = bit_cast<half8_t>(raw);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    acc[e] += (float)v[e];
+                }
+            }
+            half8_t h;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                h[e] = (half_t)acc[e];
+            }
+            r[i] = r[i] + h;
+            if (ok[i]) {
+                *(half8_t*)(p.resid + off[i]) = r[i];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float f = (float)r[i][e];
+                    ss            = __builtin_fmaf(f, f, ss);
+                }
+            }
+        }
+        ss = group_sum<64>(ss);
+        __syncthreads();  // `red` of the previous row has been read by everybody
+        if ((tid & 63) == 0) {
+            red[tid >> 6] = ss;
+        }
+        __syncthreads();
+        float tot = 0.f;
+        for (int w = 0; w < (nthr >> 6); ++w) {
+            tot += red[w];
+        }
+        const float inv = 1.0f / __builtin_sqrtf(tot / (float)p.H + p.eps);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            if (ok[i]) {
+                half8_t o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const half_t n = (half_t)((float)r[i][e] * inv);
+                    o[e]           = n * wv[i][e];
+                }
+                *(half8_t*)(p.y + off[i]) = o;
+                for (int q = 1; q < p.tp; ++q) {  // start with the next rank: the pushes of the tp ranks fan out over the links
+                    const int dst = p.me + q < p.tp ? p.me + q : p.me + q - p.tp;
+                    *(half8_t*)(p.out2[dst] + off[i]) = o;
+                }
+            }
+        }
+    }
+    p2p_publish_and_wait(p, epoch + 1);
+    // ---- 2. the other slices' normed rows: own out2 -> y --------------------------------------------------------------------------------
+    for (int row = blockIdx.x; row < p.M; row += gridDim.x) {
+        if (row >= r0 && row < r1) {
+            continue;
+        }
+        for (int vi = tid; vi < nvec; vi += nthr) {
+            const size_t o = (size_t)row * p.H + (size_t)vi * 8;
+            const u32x4  v = __builtin_nontemporal_load((const u32x4*)(p.out2[p.me] + o));
+            *(u32x4*)(p.y + o) = v;
+        }
+    }
+    p2p_exit(p, epoch + 1);
+}
+
+// in2[r] / out2[r]: rank r's two-shot regions ([rows2][H] fp16 each) as mapped by THIS rank; M <= rows2
+int launch_p2p_allreduce_norm_2shot(half_t* const* in2, half_t* const* out2, uint32_t* const* flags, int tp, int me, uint32_t* state,
+                                    size_t region, const half_t* partial, half_t* y, half_t* resid, const half_t* weight, float eps, int M,
+                                    int H, hipStream_t st)
+{
+    TM_REQUIRE(tp >= 1 && tp <= 8 && me >= 0 && me < tp, "p2p all-reduce: 1 <= tp <= 8");
+    TM_REQUIRE(H % 8 == 0 && H <= 8192, "p2p all-reduce: H % 8 == 0, H <= 8192");
+    TM_REQUIRE((size_t)M * H <= region, "p2p two-shot all-reduce: the message does not fit the segment region");
+    if (M == 0) {
+        return 0;
+    }
+    P2pParams p{};
+    for (int r = 0; r < tp; ++r) {
+        p.in2[r]   = in2[r];
+        p.out2[r]  = out2[r];
+        p.flags[r] = flags[r];
+    }
+    p.tp = tp, p.me = me, p.state = state, p.partial = partial, p.y = y, p.resid = resid, p.weight = weight;
+    p.eps = eps, p.M = M, p.H = H;
+    p.slice        = (M + tp - 1) / tp;
+    const int nvec = H / 8;
+    int       t    = (nvec + 63) / 64 * 64;
+    t              = t > 512 ? 512 : t;
+    const bool one = (nvec + t - 1) / t == 1;
+    int dev = 0, cus = 0, per_cu = 0;
+    TM_HIP_CHECK(hipGetDevice(&dev));
+    TM_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    const void* k = one ? (const void*)p2p_allreduce_norm_2shot_kernel<1> : (const void*)p2p_allreduce_norm_2shot_kernel<2>;
+    TM_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k, t, 0));
+    per_cu         = per_cu > 1 ? per_cu - 1 : per_cu;  // (see p2p_allreduce_capacity)
+    // every workgroup of a rank must be resident at once; ranks that SHARE a device (the one-GPU tests: tp streams / processes on
+    // cuda:0) must fit together, so the grid can be capped from outside
+    static const int cap_env = getenv("TM_P2P_2SHOT_GRID") ? atoi(getenv("TM_P2P_2SHOT_GRID")) : 0;
+    int              grid    = std::max(1, std::min(M, std::min(per_cu, 2) * cus));
+    if (cap_env > 0) {
+        grid = std::min(grid, cap_env);
+    }
+    if (one) {
+        p2p_allreduce_norm_2shot_kernel<1><<<grid, t, 0, st>>>(p);
+    }
+    else {
+        p2p_allreduce_norm_2shot_kernel<2><<<grid, t, 0, st>>>(p);
+    }
+    TM_HIP_CHECK(hipGetLastError());
+    return 0;
 }
 
 // all-gather of n 32-bit words per rank through the same segments (one workgroup)

@@ -227,6 +227,7 @@ struct tm_engine {
     void*        p2p_peer[8] = {};
     uint32_t*    p2p_state = nullptr;
     int          p2p_rows = 0;
+    int          p2p_rows2 = 0;  // rows of the segment's two-shot regions (in2 / out2): forwards larger than p2p_rows (prefill) without RCCL
     bool         p2p_ready = false;
     bool         comm_overlap = false;   // TM_COMM_STREAM=1: collectives on a side stream (fork / join around each)
     bool         graph_comm_failed = false;  // capturing the RCCL calls failed once: stay eager
@@ -535,6 +536,19 @@ static int reduce_residual_norm(tm_engine* e, int M, const half_t* norm_w)
         half_t*   data[8];
         uint32_t* flags[8];
         p2p_tables(e, data, flags);
+        if (M > e->p2p_rows && M <= e->p2p_rows2) {
+            // a prefill-sized forward on the native communicator alone: ONE two-shot launch (reduce-scatter, norm on the owned row
+            // slice, all-gather) instead of a chain of one-shot launches over row chunks, each reading tp x its bytes
+            half_t *in2[8], *out2[8];
+            for (int r = 0; r < e->cfg.tp; ++r) {
+                in2[r]  = data[r] + 2 * (size_t)e->p2p_rows * e->hidden;
+                out2[r] = in2[r] + (size_t)e->p2p_rows2 * e->hidden;
+            }
+            TM_PROF(P_ALLREDUCE, TM_TRY(launch_p2p_allreduce_norm_2shot(in2, out2, flags, e->cfg.tp, e->cfg.rank, e->p2p_state,
+                                                                        (size_t)e->p2p_rows2 * e->hidden, e->d_tmp, e->d_x, e->d_resid, norm_w,
+                                                                        e->cfg.model.rms_eps, M, e->hidden, e->stream)));
+            return 0;
+        }
         const size_t tile = (size_t)e->p2p_rows * e->hidden;
         for (int m0 = 0; m0 < M; m0 += e->p2p_rows) {
             const int    rows = std::min(e->p2p_rows, M - m0);
@@ -1039,7 +1053,11 @@ int tm_engine_comm_native_export(tm_engine* e, int rows, void* handle64)
         TM_REQUIRE(cap >= 1, "native communicator: occupancy query failed");
         rows = std::min(rows, cap);
     }
-    TM_TRY(tm_p2p_segment_create(tm_p2p_segment_bytes(rows, e->hidden), &e->p2p_seg, handle64));
+    // two-shot regions for everything a forward can carry (TM_P2P_2SHOT=0: one-shot row chunks only)
+    const char* ts = getenv("TM_P2P_2SHOT");
+    const int   rows2 = (ts && !atoi(ts)) ? 0 : std::max(e->cfg.max_prefill_token_num, e->cfg.max_batch_size);
+    TM_TRY(tm_p2p_segment_create(tm_p2p_segment_bytes2(rows, rows2, e->hidden), &e->p2p_seg, handle64));
+    e->p2p_rows2 = rows2;
     TM_HIP_CHECK(hipMalloc((void**)&e->p2p_state, 4 * sizeof(uint32_t)));
     TM_HIP_CHECK(hipMemset(e->p2p_state, 0, 4 * sizeof(uint32_t)));
     e->p2p_rows = rows;

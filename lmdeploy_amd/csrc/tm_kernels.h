@@ -190,6 +190,11 @@ int    launch_linear_fp8_grouped(const LinearWeight& proto, const void* d_groups
 int launch_p2p_allreduce_norm(half_t* const* data, uint32_t* const* flags, int tp, int me, uint32_t* state, size_t tile,
                               const half_t* partial, half_t* y, half_t* resid, const half_t* weight, float eps, int M, int H,
                               hipStream_t st);
+// two-shot form (reduce-scatter, norm on the owned row slice, all-gather by push) for messages of MBs; region = fp16 elements of
+// one in2 / out2 region; the residual stream is updated for the rank's own slice only
+int launch_p2p_allreduce_norm_2shot(half_t* const* in2, half_t* const* out2, uint32_t* const* flags, int tp, int me, uint32_t* state,
+                                    size_t region, const half_t* partial, half_t* y, half_t* resid, const half_t* weight, float eps, int M,
+                                    int H, hipStream_t st);
 int p2p_allreduce_capacity(int threads, bool one_vec);  // token rows per launch: workgroups resident at once on this device
 // dst_stride_words: 32-bit words between the destinations of consecutive ranks (0 = words: dst is [tp][words])
 int launch_p2p_allgather(half_t* const* data, uint32_t* const* flags, int tp, int me, uint32_t* state, size_t tile, const void* src,

@@ -1,6 +1,8 @@
 """Driver of the native P2P all-reduce + residual + RMSNorm parity runs (not a test module: tests/test_gpu_p2p.py starts it
 in a subprocess with a hard timeout, because a protocol bug shows up as ranks waiting for each other).
 
+  (append `2` to either form: the TWO-SHOT all-reduce for large messages -- reduce-scatter, norm on the owned row slice,
+   all-gather by push -- instead of the one-shot exchange; the residual is then checked on every rank's own slice)
   streams <tp> <M> <H> <calls>      one process: tp "ranks" = tp segments on cuda:0, one stream each, peers addressed through
                                     the same pointer tables a multi-GPU run uses (needs GPU_MAX_HW_QUEUES >= tp so that the tp
                                     kernels really run concurrently)
@@ -34,13 +36,15 @@ def _tables(ptrs):
     return (ctypes.c_void_p * len(ptrs))(*ptrs)
 
 
-def _check(tag, c, state, resid, y, r_ref, y_ref, gathered, g_ref):
+def _check(tag, c, state, resid, y, r_ref, y_ref, gathered, g_ref, rows=None):
+    """rows: (lo, hi) of the residual rows this rank keeps current (two-shot form), None = all; the two-shot call takes two epochs"""
     st = state.cpu().numpy()
     if st[3] != 0:
         return f'{tag} timed out waiting in call {st[3]}'
-    if st[0] != 2 * (c + 1) or st[1] != 0 or st[2] != 0:
+    if st[0] != (3 if rows else 2) * (c + 1) or st[1] != 0 or st[2] != 0:
         return f'{tag} state after call {c}: {st.tolist()}'
-    if not np.array_equal(resid.cpu().numpy().view(np.uint16), r_ref.view(np.uint16)):
+    lo, hi = rows or (0, r_ref.shape[0])
+    if not np.array_equal(resid.cpu().numpy()[lo:hi].view(np.uint16), r_ref[lo:hi].view(np.uint16)):
         return f'{tag} residual differs from the oracle in call {c}'
     # y = h(h(r * inv) * w): the kernel's fp32 sum of squares associates differently from numpy's, so n = h(r * inv) may sit
     # one fp16 ulp off on a rounding boundary, and one ulp of n is up to two ulps of y when n * w drops a binade
@@ -56,15 +60,21 @@ def _gather_src(tp, words, c):
     return [np.random.default_rng(77 * c + r).integers(0, 2**31, words).astype(np.int32) for r in range(tp)]
 
 
-def run_streams(tp, M, H, calls):
+def _slice(tp, M, r):
+    sl = (M + tp - 1) // tp
+    return (min(M, r * sl), min(M, (r + 1) * sl))
+
+
+def run_streams(tp, M, H, calls, two=0):
     tm = _ffi.load()
     rng = np.random.default_rng(5)
     w = (1 + 0.02 * rng.standard_normal(H)).astype(f16)
     resid0 = rng.standard_normal((M, H)).astype(f16)
     w_d = torch.from_numpy(w).cuda()
-    rows = M + 3                              # segment capacity need not equal M
-    words = 2 * M
-    seg = [torch.zeros(tm.tm_p2p_segment_bytes(rows, H), dtype=torch.uint8, device='cuda') for _ in range(tp)]
+    rows = (M + 3) if not two else 8          # segment capacity need not equal M; two-shot: small one-shot tiles, big regions
+    rows2 = M + 5
+    words = 2 * M if not two else 2 * rows
+    seg = [torch.zeros(tm.tm_p2p_segment_bytes2(rows, rows2 if two else 0, H), dtype=torch.uint8, device='cuda') for _ in range(tp)]
     state = [torch.zeros(4, dtype=torch.int32, device='cuda') for _ in range(tp)]
     resid = [torch.from_numpy(resid0).cuda() for _ in range(tp)]
     y = [torch.empty((M, H), dtype=torch.float16, device='cuda') for _ in range(tp)]
@@ -80,14 +90,18 @@ def run_streams(tp, M, H, calls):
         gsrc_d = [torch.from_numpy(g).cuda() for g in gsrc]
         torch.cuda.synchronize()
         for r in range(tp):                   # every rank: fused all-reduce + norm, then the all-gather, back to back
-            _ffi.check(tm.tm_p2p_allreduce_norm(segs, tp, r, state[r].data_ptr(), rows, part_d[r].data_ptr(), y[r].data_ptr(),
-                                               resid[r].data_ptr(), w_d.data_ptr(), 1e-5, M, H, streams[r].cuda_stream))
+            if two:
+                _ffi.check(tm.tm_p2p_allreduce_norm_2shot(segs, tp, r, state[r].data_ptr(), rows, rows2, part_d[r].data_ptr(), y[r].data_ptr(),
+                                                         resid[r].data_ptr(), w_d.data_ptr(), 1e-5, M, H, streams[r].cuda_stream))
+            else:
+                _ffi.check(tm.tm_p2p_allreduce_norm(segs, tp, r, state[r].data_ptr(), rows, part_d[r].data_ptr(), y[r].data_ptr(),
+                                                   resid[r].data_ptr(), w_d.data_ptr(), 1e-5, M, H, streams[r].cuda_stream))
             _ffi.check(tm.tm_p2p_allgather(segs, tp, r, state[r].data_ptr(), rows, H, gsrc_d[r].data_ptr(), gathered[r].data_ptr(),
                                           words, streams[r].cuda_stream))
         torch.cuda.synchronize()
         r_ref, y_ref = o.p2p_allreduce_norm(parts, r_ref, w, 1e-5)
         for r in range(tp):
-            why = _check(f'rank {r}', c, state[r], resid[r], y[r], r_ref, y_ref, gathered[r], np.stack(gsrc))
+            why = _check(f'rank {r}', c, state[r], resid[r], y[r], r_ref, y_ref, gathered[r], np.stack(gsrc), _slice(tp, M, r) if two else None)
             if why:
                 return {'ok': False, 'why': why}
             if not torch.equal(y[r], y[0]):
@@ -110,17 +124,18 @@ def _barrier(d, rank, tp, tag):
         _wait_file(os.path.join(d, f'{tag}.{r}'))
 
 
-def run_ipc(d, rank, tp, M, H, calls):
+def run_ipc(d, rank, tp, M, H, calls, two=0):
     tm = _ffi.load()
     torch.cuda.init()
     torch.zeros(1, device='cuda')
     rng = np.random.default_rng(5)
     w = (1 + 0.02 * rng.standard_normal(H)).astype(f16)
     resid0 = rng.standard_normal((M, H)).astype(f16)
-    rows, words = M, 2 * M
+    rows, words = (M, 2 * M) if not two else (8, 16)
+    rows2 = M
     mine = ctypes.c_void_p()
     handle = ctypes.create_string_buffer(64)
-    _ffi.check(tm.tm_p2p_segment_create(tm.tm_p2p_segment_bytes(rows, H), ctypes.byref(mine), handle))
+    _ffi.check(tm.tm_p2p_segment_create(tm.tm_p2p_segment_bytes2(rows, rows2 if two else 0, H), ctypes.byref(mine), handle))
     with open(os.path.join(d, f'handle.{rank}.tmp'), 'wb') as f:
         f.write(handle.raw)
     os.rename(os.path.join(d, f'handle.{rank}.tmp'), os.path.join(d, f'handle.{rank}'))
@@ -148,13 +163,17 @@ def run_ipc(d, rank, tp, M, H, calls):
         gsrc = _gather_src(tp, words, c)
         part_d = torch.from_numpy(parts[rank]).cuda()
         gsrc_d = torch.from_numpy(gsrc[rank]).cuda()
-        _ffi.check(tm.tm_p2p_allreduce_norm(segs, tp, rank, state.data_ptr(), rows, part_d.data_ptr(), y.data_ptr(), resid.data_ptr(),
-                                           w_d.data_ptr(), 1e-5, M, H, stream))
+        if two:
+            _ffi.check(tm.tm_p2p_allreduce_norm_2shot(segs, tp, rank, state.data_ptr(), rows, rows2, part_d.data_ptr(), y.data_ptr(),
+                                                     resid.data_ptr(), w_d.data_ptr(), 1e-5, M, H, stream))
+        else:
+            _ffi.check(tm.tm_p2p_allreduce_norm(segs, tp, rank, state.data_ptr(), rows, part_d.data_ptr(), y.data_ptr(), resid.data_ptr(),
+                                               w_d.data_ptr(), 1e-5, M, H, stream))
         _ffi.check(tm.tm_p2p_allgather(segs, tp, rank, state.data_ptr(), rows, H, gsrc_d.data_ptr(), gathered.data_ptr(), words,
                                       stream))
         torch.cuda.synchronize()
         r_ref, y_ref = o.p2p_allreduce_norm(parts, r_ref, w, 1e-5)
-        why = _check(f'rank {rank}', c, state, resid, y, r_ref, y_ref, gathered, np.stack(gsrc))
+        why = _check(f'rank {rank}', c, state, resid, y, r_ref, y_ref, gathered, np.stack(gsrc), _slice(tp, M, rank) if two else None)
         if why:
             out = {'ok': False, 'why': why}
             break
@@ -170,9 +189,9 @@ def run_ipc(d, rank, tp, M, H, calls):
 if __name__ == '__main__':
     try:
         if sys.argv[1] == 'streams':
-            res = run_streams(*[int(a) for a in sys.argv[2:6]])
+            res = run_streams(*[int(a) for a in sys.argv[2:7]])
         else:
-            res = run_ipc(sys.argv[2], *[int(a) for a in sys.argv[3:8]])
+            res = run_ipc(sys.argv[2], *[int(a) for a in sys.argv[3:9]])
     except Exception as e:      # noqa: BLE001
         res = {'ok': False, 'why': f'{type(e).__name__}: {e}'}
     print(json.dumps(res), flush=True)

@@ -17,7 +17,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 @pytest.mark.timeout(600)
 def test_bench_two_ranks_on_one_gpu_falls_back_to_the_native_communicator(cuda):
-    env = dict(os.environ, GPU_MAX_HW_QUEUES='8', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    env = dict(os.environ, GPU_MAX_HW_QUEUES='8', HSA_ENABLE_IPC_MODE_LEGACY='0', TM_P2P_2SHOT_GRID='96')
     env.pop('WORLD_SIZE', None)
     pr = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '6', '--warmup', '3', '--layers', '2',
                          '--batch', '8', '--prompt-len', '96', '--no-traffic', '--no-cpu-baseline', '--no-full-run', '--profile-steps', '0'],

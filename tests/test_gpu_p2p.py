@@ -23,6 +23,7 @@ def _env():
     env = dict(os.environ)
     env['GPU_MAX_HW_QUEUES'] = '8'            # tp concurrent kernels need tp hardware queues
     env['HSA_ENABLE_IPC_MODE_LEGACY'] = '0'
+    env['TM_P2P_2SHOT_GRID'] = '48'           # the tp ranks share ONE device here: their persistent grids must fit together
     return env
 
 
@@ -47,6 +48,37 @@ def test_p2p_allreduce_norm_streams(cuda, tp, M, H):
 def test_p2p_allreduce_norm_ipc_processes(cuda, tp, M, H):
     with tempfile.TemporaryDirectory() as d:
         procs = [subprocess.Popen([sys.executable, WORKER, 'ipc', d, str(r), str(tp), str(M), str(H), '5'], env=_env(),
+                                  stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(tp)]
+        outs = []
+        try:
+            for pr in procs:
+                outs.append(pr.communicate(timeout=300)[0])
+        finally:
+            for pr in procs:
+                if pr.poll() is None:
+                    pr.kill()
+        for r, text in enumerate(outs):
+            res = _last_json(text)
+            assert res['ok'], (r, res)
+
+
+@pytest.mark.timeout(400)
+@pytest.mark.parametrize('tp,M,H', [(2, 300, 4096), (4, 1000, 4096), (3, 130, 8192), (2, 1, 2048), (4, 3, 5120)])
+def test_p2p_allreduce_norm_two_shot_streams(cuda, tp, M, H):
+    """the two-shot form (reduce-scatter, norm on the owned row slice, all-gather by push; reference
+    comm/cuda_ipc/fused_allreduce.cu:25-405): all M normed rows on every rank equal the oracle and each other, the residual
+    stream is current on every rank's own slice; ragged last slice, slices of zero rows (M < tp), two vectors per thread"""
+    p = subprocess.run([sys.executable, WORKER, 'streams', str(tp), str(M), str(H), '5', '2'], env=_env(), capture_output=True,
+                       text=True, timeout=300)
+    res = _last_json(p.stdout + '\n' + p.stderr)
+    assert res['ok'], res
+
+
+@pytest.mark.timeout(400)
+@pytest.mark.parametrize('tp,M,H', [(2, 520, 4096), (8, 260, 4096)])
+def test_p2p_allreduce_norm_two_shot_ipc_processes(cuda, tp, M, H):
+    with tempfile.TemporaryDirectory() as d:
+        procs = [subprocess.Popen([sys.executable, WORKER, 'ipc', d, str(r), str(tp), str(M), str(H), '4', '2'], env=_env(),
                                   stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(tp)]
         outs = []
         try:

@@ -31,6 +31,7 @@ def test_tp2_engine_two_processes_one_gpu(cuda, moe, kv_bits):
     env = dict(os.environ)
     env['GPU_MAX_HW_QUEUES'] = '8'
     env['HSA_ENABLE_IPC_MODE_LEGACY'] = '0'
+    env['TM_P2P_2SHOT_GRID'] = '96'           # both ranks share cuda:0: their persistent two-shot grids must fit together
     port = _free_port()
     procs = [subprocess.Popen([sys.executable, WORKER, str(r), '2', str(port), str(moe), str(kv_bits)], env=env,
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
@@ -65,6 +66,7 @@ def test_tp2_sampling_and_mixed_steps_on_the_native_communicator(cuda):
     env = dict(os.environ)
     env['GPU_MAX_HW_QUEUES'] = '8'
     env['HSA_ENABLE_IPC_MODE_LEGACY'] = '0'
+    env['TM_P2P_2SHOT_GRID'] = '96'           # both ranks share cuda:0: their persistent two-shot grids must fit together
     env['TM_GRAPH_COMM'] = '1'
     port = _free_port()
     procs = [subprocess.Popen([sys.executable, WORKER, str(r), '2', str(port), '0', '8', '1'], env=env,
