@@ -94,24 +94,30 @@ def test_engine_collective_path_single_rank(cuda, monkeypatch, graph_comm, side_
     assert np.abs(l0.astype(np.float32) - l1.astype(np.float32)).max() <= 2e-3
 
 
-@pytest.mark.parametrize('B', [4, 80])
-def test_engine_gemm_tuning_roundtrip(cuda, tmp_path, B):
+@pytest.mark.parametrize('B,pf_class', [(4, 0), (80, 0), (4, 512)])
+def test_engine_gemm_tuning_roundtrip(cuda, tmp_path, B, pf_class):
     """Measured GEMM dispatch (the reference's TM_GEMM_TUNE / EXPORT / IMPORT): the tuner times the candidate tilings of the
     four decode linears on the engine's own weights, the table can be exported and imported, and whatever it picked the
-    engine still reproduces the oracle (every candidate is a parity-tested tiling of the same arithmetic)."""
+    engine still reproduces the oracle (every candidate is a parity-tested tiling of the same arithmetic).  pf_class = 512:
+    additionally the prefill size class of forwards with 257 .. 512 tokens is tuned (table key M = 512) and the prompts are long
+    enough that the prefill forward falls into it."""
     cfg = o.ModelConfig(hidden=512, layers=3, q_heads=4, kv_heads=2, head_dim=128, inter=1024, vocab=1024, kv_bits=8,
                         rope=o.RopeParam(128, 500000.0, 'llama3', 8.0, 1.0, 4.0, 8192))
     w = o.make_synthetic_weights(cfg, seed=5)
     rng = np.random.default_rng(9)
-    prompts = [rng.integers(0, cfg.vocab, n).astype(np.int32) for n in (40, 7, 65, 12)]
+    prompts = [rng.integers(0, cfg.vocab, n).astype(np.int32) for n in ((40, 7, 65, 12) if not pf_class else (100, 90, 110, 85))]
     path = str(tmp_path / 'gemm_dispatch.txt')
-    eng = Engine.from_model_config(cfg, max_batch_size=B, session_len=128, quant_policy=8, max_prefill_token_num=128)
+    eng = Engine.from_model_config(cfg, max_batch_size=B, session_len=128, quant_policy=8, max_prefill_token_num=pf_class or 128)
     eng.load_weights(export_weights(cfg, w))
     eng.start()
     eng.tune_gemm(B, path)     # B = 80: the 64 < M <= 256 decode path (128-row tiles vs the 32-row-block shapes)
     rows = [tuple(int(v) for v in ln.split()) for ln in open(path).read().splitlines() if int(ln.split()[2]) == B]
     assert len(rows) == 4 and all(r[4] >= 1 for r in rows), rows        # w_qkv, wo, w1w3, w2 at M = B
     assert {(r[0], r[1]) for r in rows} == {(512, 1024), (512, 512), (512, 2048), (1024, 512)}
+    if pf_class:               # one 385-token prefill forward: size class 512
+        eng.tune_gemm(pf_class, path)
+        rows = [tuple(int(v) for v in ln.split()) for ln in open(path).read().splitlines() if int(ln.split()[2]) == pf_class]
+        assert len(rows) == 4 and all(r[3] >= 4 for r in rows), rows     # 128-row tiles or 32-row-block shapes
     prompts = (prompts * ((B + 3) // 4))[:B]
     eng.prefill(prompts, max_new_tokens=5)
     eng.decode(4)
