@@ -345,10 +345,13 @@ def main():
     # the tilings the timed steps ran (measured table first, then the heuristic): per decode linear (shape, split-K) at M = B
     hq_l, hkv_l = model['q_heads'] // world, max(1, model['kv_heads'] // world)
     D_, H_, I_l = model['head_dim'], model['hidden'], model['inter'] // world
-    tilings = {}
+    tilings, prefill_tilings = {}, {}
+    pf_rows = min(B * S, 8192)     # rows of a prefill forward of this run (max_prefill_token_num chunks)
     if weight_type == 0 and not model.get('moe_experts') and B <= 256:
         for name, (kk, nn) in dict(w_qkv=(H_, (hq_l + 2 * hkv_l) * D_), wo=(hq_l * D_, H_), w1w3=(H_, 2 * I_l), w2=(I_l, H_)).items():
             tilings[name] = dict(zip(('shape', 'splits'), Engine.pick_tiling(kk, nn, B)))
+            # shape 10 = dequantise + hipBLASLt fp16 GEMM (gemm_f16_library.hip), 4 / 5 = the fused 128-row W4A16 tiles
+            prefill_tilings[name] = dict(zip(('shape', 'splits'), Engine.pick_tiling(kk, nn, pf_rows)))
     if weight_type != 0 or model.get('moe_experts'):
         # formats other than AWQ u4 / MoE: the weight bytes are what the engine actually streams (packed weights + scales +
         # lm_head); with batch 64 and top-2 of 8 every expert is hit every step
@@ -369,7 +372,7 @@ def main():
                        'decode_splits': stats['decode_splits'], 'hipgraph': cinfo['hipgraph'],
                        'gemm_dispatch': ('measured at start-up (tm_engine_tune_gemm' + (', rank 0\'s table broadcast' if world > 1 else '') + ')')
                                         if tuned else 'heuristic',
-                       'gemm_tilings': tilings},
+                       'gemm_tilings': tilings, 'prefill_rows': pf_rows, 'prefill_gemm_tilings': prefill_tilings},
             'ttft_p50_ms': round(float(np.median(ttft)), 2), 'prefill_total_s': round(prefill_s, 3),
             'prefill_tokens_per_s': round(B * S / prefill_s, 1),
             'step_roofline': {'bound': 'hbm', 'algorithmic_bytes_per_step': int(step_bytes),

@@ -275,14 +275,39 @@ int tm_linear_prepare(tm_linear* w, const void* weight, const void* scales, cons
 
 size_t tm_linear_workspace(const tm_linear* w, int M)
 {
-    return w ? gemm_workspace_bytes(M, w->w.N, 16) : 0;
+    if (!w) {
+        return 0;
+    }
+    size_t b = gemm_workspace_bytes(M, w->w.N, 16);
+    if (M >= kF16LibraryMinM && dec32_supported(w->w, M) && f16_library_available()) {  // either gated or not, either image
+        b = std::max(b, f16_library_workspace_bytes(w->w.K, w->w.N, M, true, false));
+    }
+    return b;
+}
+
+int tm_f16_library_available(void)
+{
+    return f16_library_available() ? 1 : 0;
+}
+
+int tm_linear_dequant_f16(const tm_linear* w, void* out_nk, tm_stream_t st)
+{
+    TM_REQUIRE(w && out_nk, "null pointer");
+    return launch_dequant_p32_f16((half_t*)out_nk, w->w, (hipStream_t)st);
+}
+
+int tm_linear_build_f16_image(tm_linear* w, tm_stream_t st)
+{
+    TM_REQUIRE(w, "null pointer");
+    TM_REQUIRE(w->w.type == 0 && w->w.packed32 != nullptr, "fp16 image: a prepared u4 linear with N % 32 == 0");
+    return linear_weight_build_f16_image(w->w, (hipStream_t)st);
 }
 
 int tm_linear_forward(const tm_linear* w, const void* x, int ldx, void* y, int ldy, int M, int gated_silu, int nt,
                       int splits, int waves, void* workspace, tm_stream_t st)
 {
     TM_REQUIRE(w && x && y, "null pointer");
-    GemmConfig cfg = gemm_pick_config(w->w, M);
+    GemmConfig cfg = gemm_pick_config(w->w, M, workspace != nullptr);  // (workspace: tm_linear_workspace(w, M) bytes)
     if (nt > 0) {
         cfg.nt = nt;
     }
@@ -299,9 +324,15 @@ int tm_linear_forward(const tm_linear* w, const void* x, int ldx, void* y, int l
         // 0x200 + shape: the decode kernel (gemm_decode.hip) with an explicit workgroup shape; M <= 64, u4, N % 32 == 0
         TM_REQUIRE(dec32_supported(w->w, M), "decode kernel: u4 weights, N % 32 == 0");
         cfg.d32_shape = waves & 0xff;
-        TM_REQUIRE((cfg.d32_shape >= 6 && cfg.d32_shape <= 9) || (cfg.d32_shape <= 5 && (cfg.d32_shape >= 4) == (M > 64)),
-                   "decode kernel shape 0..3 (M <= 64), 4 / 5 (M > 64) or 6..9 (32-row blocks, any M)");
+        TM_REQUIRE((cfg.d32_shape >= 6 && cfg.d32_shape <= 9) || (cfg.d32_shape <= 5 && (cfg.d32_shape >= 4) == (M > 64))
+                       || (cfg.d32_shape == kShapeF16Library && M >= kF16LibraryMinM && workspace),
+                   "decode kernel shape 0..3 (M <= 64), 4 / 5 (M > 64), 6..9 (32-row blocks, any M) or 10 (library GEMM, M >= 512)");
         waves = 0;
+    }
+    if (cfg.d32_shape == kShapeF16Library) {
+        cfg.splits       = 1;
+        cfg.lib_ws       = workspace;
+        cfg.lib_ws_bytes = tm_linear_workspace(w, M);
     }
     if (waves > 0) {
         // waves per workgroup (4 | 8); + 0x100 = split K two ways INSIDE the workgroup (8 waves only)
@@ -727,7 +758,7 @@ int tm_debug_pick_tiling(int K, int N, int M, int use_table, int* shape, int* sp
     LinearWeight w{};
     w.K = K;
     w.N = N;
-    dec32_pick_ex(w, M, shape, splits, use_table != 0);
+    dec32_pick_ex(w, M, shape, splits, (use_table & 1) != 0, (use_table & 2) == 0);
     return 0;
 }
 

@@ -264,6 +264,14 @@ struct tm_engine {
     // last workgroup's store drain + ticket (3.1 us) and the consumer's slab round trip (2.7 us) cost more than two kernel
     // boundaries (1.2 us each here) plus a 2 us kernel.  Default off.
     bool      gemm_tail = false;
+    // Prefill-sized forwards of the dense u4 linears through dequantise + the vendor library's fp16 GEMM
+    // (gemm_f16_library.hip): its scratch (library workspace | fp16 image of one linear | gated intermediate), nullptr when the
+    // library is not loadable / switched off.  f16_resident (TM_PREFILL_F16_RESIDENT=1): every dense u4 linear also keeps its
+    // fp16 [N][K] image in HBM (2 bytes per weight next to the 0.53 of the u4 image) and the per-call dequant pass disappears.
+    void*     d_lib_ws     = nullptr;
+    size_t    lib_ws_bytes = 0;
+    bool      f16_resident = false;
+    bool      f16_resident_auto = false;  // env unset: resident when the images take <= 8 % of the device's memory
     unsigned  h_marks[2] = {0, 0};    // host copies of the device give-up marks (device_marks_fetch)
     unsigned* d_tail_sync = nullptr;  // 4 words: hand-off state of the in-launch residual-norm consumer (gemm_decode.hip), zero between launches
     float*  d_attn_ws = nullptr;
@@ -433,6 +441,9 @@ static int prepare_linear(tm_engine* e, LinearSlots& l)
         // gemm_kernel and keep the 16-column image as well
         const bool p32_only = l.prefix.find(".experts.") == std::string::npos && dec32_serves_every_m(l.w.K, l.w.N);
         TM_TRY(linear_weight_prepare_u4(l.w, (const int32_t*)q.dev, (const half_t*)s.dev, (const half_t*)z.dev, e->stream, p32_only));
+        if (p32_only && e->f16_resident && e->cfg.max_prefill_token_num >= kF16LibraryMinM && f16_library_available()) {
+            TM_TRY(linear_weight_build_f16_image(l.w, e->stream));
+        }
         TM_HIP_CHECK(hipStreamSynchronize(e->stream));
         for (Slot* p : {&q, &s, &z}) {
             TM_HIP_CHECK(hipFree(p->dev));
@@ -565,11 +576,28 @@ static int reduce_residual_norm(tm_engine* e, int M, const half_t* norm_w)
     return 0;
 }
 
+// gemm_pick_config + the engine's scratch for the library path (prefill-sized forwards); without scratch of the needed size
+// the fused tiles
+static GemmConfig pick_config(tm_engine* e, const LinearWeight& w, int M, bool gated)
+{
+    GemmConfig cfg = gemm_pick_config(w, M, e->d_lib_ws != nullptr);
+    if (cfg.d32_shape == kShapeF16Library) {
+        if (f16_library_workspace_bytes(w.K, w.N, M, gated, w.f16_nk != nullptr) <= e->lib_ws_bytes) {
+            cfg.lib_ws       = e->d_lib_ws;
+            cfg.lib_ws_bytes = e->lib_ws_bytes;
+        }
+        else {
+            cfg = gemm_pick_config(w, M, false);
+        }
+    }
+    return cfg;
+}
+
 // row-parallel linear followed by (all-reduce +) residual + RMSNorm
 static int linear_residual_norm(tm_engine* e, LinearSlots& l, const half_t* x, int ldx, int M, const half_t* norm_w,
                                 int gemm_cat)
 {
-    GemmConfig cfg = gemm_pick_config(l.w, M);
+    GemmConfig cfg = pick_config(e, l.w, M, false);
     const bool can_defer = !e->use_comm && cfg.splits > 1
                            && gemm_workspace_bytes(M, l.w.N, cfg.splits) <= e->gemm_ws_bytes;
     if (gemm_workspace_bytes(M, l.w.N, cfg.splits) > e->gemm_ws_bytes) {
@@ -597,7 +625,7 @@ static int linear_residual_norm(tm_engine* e, LinearSlots& l, const half_t* x, i
 
 static int linear_plain(tm_engine* e, LinearSlots& l, const half_t* x, int ldx, half_t* y, int ldy, int M, bool gated)
 {
-    GemmConfig cfg = gemm_pick_config(l.w, M);
+    GemmConfig cfg = pick_config(e, l.w, M, gated);
     if (gemm_workspace_bytes(M, l.w.N, cfg.splits) > e->gemm_ws_bytes) {
         cfg.splits = 1;
     }
@@ -947,6 +975,9 @@ int tm_engine_create(tm_engine** out, const tm_engine_config* c)
         const char* ms    = getenv("TM_MIXED_STEP");
         const char* gc    = getenv("TM_GRAPH_COMM");
         e->mixed_steps_on = !(ms && !atoi(ms));
+        const char* fr    = getenv("TM_PREFILL_F16_RESIDENT");
+        e->f16_resident   = fr && atoi(fr);
+        e->f16_resident_auto = !fr;
         e->graph_comm     = !(gc && !atoi(gc));
     }
     e->qkv_n       = (e->q_heads + 2 * e->kv_heads) * e->D;
@@ -956,6 +987,16 @@ int tm_engine_create(tm_engine** out, const tm_engine_config* c)
                                       && m.weight_type != TM_WEIGHT_F16),
                "moe: 1 <= top_k <= experts <= 64, top_k <= 8, u4 or fp8 expert weights");
     TM_HIP_CHECK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+    if (e->f16_resident_auto && m.weight_type == TM_WEIGHT_U4 && c->max_prefill_token_num >= kF16LibraryMinM) {
+        // 2 bytes per dense weight next to the 0.53 of the u4 image: Llama-3-8B 14 GB of 288 (kept), InternLM2-20B 37 GB (not kept:
+        // the per-call dequantisation pass costs ~3 % of a prefill GEMM, the KV cache is worth more)
+        const double attn = (double)m.hidden * e->qkv_n + (double)e->q_heads * e->D * m.hidden;
+        const double ffn  = m.moe_experts > 0 ? 0.0 : 3.0 * m.hidden * e->inter;
+        size_t       free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+            e->f16_resident = 2.0 * m.layers * (attn + ffn) <= 0.08 * (double)total_b;
+        }
+    }
 
     e->layers.resize(m.layers);
     for (int i = 0; i < m.layers; ++i) {
@@ -1291,10 +1332,12 @@ static int tune_decode_gemms(tm_engine* e, int M, bool verbose)
     hipEvent_t e0, e1;
     TM_HIP_CHECK(hipEventCreate(&e0));
     TM_HIP_CHECK(hipEventCreate(&e1));
-    // finite inputs (the buffers are scratch before the first forward): zeros
-    TM_HIP_CHECK(hipMemsetAsync(e->d_x, 0, (size_t)M * e->hidden * 2, st));
-    TM_HIP_CHECK(hipMemsetAsync(e->d_attn, 0, (size_t)M * e->q_heads * e->D * 2, st));
-    TM_HIP_CHECK(hipMemsetAsync(e->d_act, 0, (size_t)M * e->inter * 2, st));
+    // stand-in activations (the buffers are scratch before the first forward): pseudo-random values of the magnitude a
+    // normed hidden state / an attention output / a gated activation has -- NOT zeros, which let the power-limited matrix pipe
+    // run ~45 % faster than on real data and mis-rank the compute-bound candidates (launch_fill_uniform_f16)
+    TM_TRY(launch_fill_uniform_f16(e->d_x, (size_t)M * e->hidden, 1.7f, 1u, st));
+    TM_TRY(launch_fill_uniform_f16(e->d_attn, (size_t)M * e->q_heads * e->D, 0.5f, 2u, st));
+    TM_TRY(launch_fill_uniform_f16(e->d_act, (size_t)M * e->inter, 0.5f, 3u, st));
     TM_HIP_CHECK(hipMemsetAsync(e->d_resid, 0, (size_t)M * e->hidden * 2, st));
     int rc = 0;
     for (const Role& r : roles) {
@@ -1316,7 +1359,9 @@ static int tune_decode_gemms(tm_engine* e, int M, bool verbose)
         if (dec32_table_get(w0.K, w0.N, M, &hs, &hp)) {
             continue;  // imported / tuned already
         }
-        dec32_pick_ex(w0, M, &hs, &hp, false);
+        const bool lib_ok = e->d_lib_ws != nullptr
+                            && f16_library_workspace_bytes(w0.K, w0.N, M, r.gated, w0.f16_nk != nullptr) <= e->lib_ws_bytes;
+        dec32_pick_ex(w0, M, &hs, &hp, false, lib_ok);
         int       cand[96][2];
         int       nc = dec32_candidates(w0, M, cand, 95);
         bool      has = false;
@@ -1340,6 +1385,14 @@ static int tune_decode_gemms(tm_engine* e, int M, bool verbose)
             if (gemm_workspace_bytes(M, w0.N, cfg.splits) > e->gemm_ws_bytes) {
                 continue;
             }
+            const bool lib = cfg.d32_shape == kShapeF16Library;
+            if (lib && !lib_ok) {
+                continue;
+            }
+            if (lib) {
+                cfg.lib_ws       = e->d_lib_ws;
+                cfg.lib_ws_bytes = e->lib_ws_bytes;
+            }
             const bool norm_consumer = (r.which == 1 || r.which == 3) && !e->use_comm;
             const bool tail_consumer = e->gemm_tail && norm_consumer && w0.N == e->hidden && dec32_tail_supported(w0, M)
                                        && gemm_workspace_bytes(M, w0.N, std::max(cfg.splits, 2)) <= e->gemm_ws_bytes;
@@ -1359,7 +1412,15 @@ static int tune_decode_gemms(tm_engine* e, int M, bool verbose)
                 }
                 return 0;
             };
+            if (norm_consumer) {  // the chain accumulates into the residual stream: every candidate starts from zero
+                TM_HIP_CHECK(hipMemsetAsync(e->d_resid, 0, (size_t)M * e->hidden * 2, st));
+            }
             if ((rc = chain())) {  // eager once: lazy module loading, function attributes
+                if (lib) {         // the library refused (no algorithm, version skew): not a candidate here, not an error
+                    rc = 0;
+                    (void)hipGetLastError();
+                    continue;
+                }
                 break;
             }
             hipGraph_t     g  = nullptr;
@@ -1396,6 +1457,11 @@ static int tune_decode_gemms(tm_engine* e, int M, bool verbose)
             }
             if (g) {
                 (void)hipGraphDestroy(g);
+            }
+            if (rc && lib) {  // e.g. the library's launch is not capturable: the eager engine could still use it, but unmeasured = not chosen
+                rc = 0;
+                (void)hipGetLastError();
+                continue;
             }
             if (rc) {
                 break;
@@ -1484,6 +1550,25 @@ int tm_engine_start(tm_engine* e)
     {
         const char* gt = getenv("TM_GEMM_TAIL");
         e->gemm_tail   = gt && atoi(gt);
+    }
+    if (f16_library_available() && e->max_tokens >= kF16LibraryMinM) {
+        size_t need = 0;
+        for (Layer& L : e->layers) {
+            const LinearWeight* ws[4]    = {&L.qkv.w, &L.wo.w, L.is_moe ? nullptr : &L.w13.w, L.is_moe ? nullptr : &L.w2.w};
+            const bool          gated[4] = {false, false, true, false};
+            for (int i = 0; i < 4; ++i) {
+                if (ws[i] && dec32_supported(*ws[i], e->max_tokens)) {
+                    need = std::max(need, f16_library_workspace_bytes(ws[i]->K, ws[i]->N, e->max_tokens, gated[i], ws[i]->f16_nk != nullptr));
+                }
+            }
+        }
+        if (need > 0 && hipMalloc(&e->d_lib_ws, need) == hipSuccess) {
+            e->lib_ws_bytes = need;
+        }
+        else {
+            (void)hipGetLastError();  // no scratch: the fused kernels serve every M
+            e->d_lib_ws = nullptr;
+        }
     }
     TM_HIP_CHECK(hipMalloc((void**)&e->d_tail_sync, 16));
     TM_HIP_CHECK(hipMemsetAsync(e->d_tail_sync, 0, 16, e->stream));
@@ -2757,7 +2842,7 @@ int tm_engine_destroy(tm_engine* e)
     void* bufs[] = {e->pool, e->d_block_ptrs, e->d_cu_block_nums, e->d_resid, e->d_x, e->d_qkv, e->d_attn, e->d_act,
                     e->d_tmp, e->d_logits, e->d_last, e->d_gemm_ws, e->d_attn_ws, e->d_kflat, e->d_vflat, e->d_rope,
                     e->d_ids, e->d_k_len, e->d_cu_q, e->d_cu_koff, e->d_rows, e->d_generated, e->d_step,
-                    e->d_prefill_ids, e->d_argmax_val, e->d_cand, e->d_cand_all, e->d_next_ids, e->d_tail_sync};
+                    e->d_prefill_ids, e->d_argmax_val, e->d_cand, e->d_cand_all, e->d_next_ids, e->d_tail_sync, e->d_lib_ws};
     for (void* p : bufs) {
         if (p) {
             (void)hipFree(p);

@@ -31,7 +31,9 @@
 #include "tm_common.h"
 #include "tm_kernels.h"
 #include "norm_row.h"
+#include "p32_layout.h"
 #include <stdlib.h>
+#include <algorithm>
 #include <type_traits>
 #include <map>
 #include <mutex>
@@ -42,8 +44,6 @@
 namespace tmk {
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
-
-constexpr int kP32Unit = 2176;
 
 __global__ void repack_p32_kernel(uint32_t* __restrict__ out, const int32_t* __restrict__ qw, const half_t* __restrict__ scales,
                                   const half_t* __restrict__ zeros, int K, int N)
@@ -125,23 +125,6 @@ struct Dec32Params {
     uint64_t*     dbg;       // optional [workgroups][8] s_memrealtime stamps (tm_debug_set_gemm_trace): start, loop, epilogue, end,
                              // hw id, -, -, after the k-phase reduction barrier
 };
-
-__device__ __forceinline__ half8_t dequant8_p32(uint32_t w, half2_t s2, half2_t z2, uint32_t m1024, uint32_t m64)
-{
-    // same arithmetic as dequant8 of gemm_w4a16.hip (quantization.h:503-524 magic numbers, exact subtract, one fma)
-    const half2_t  k1024 = {(half_t)1024.0f, (half_t)1024.0f};
-    const half2_t  k64   = {(half_t)64.0f, (half_t)64.0f};
-    const uint32_t hi    = w >> 8;
-    half2_t        p0    = bit_cast<half2_t>((w & 0x000f000fu) | m1024) - k1024;
-    half2_t        p1    = bit_cast<half2_t>((w & 0x00f000f0u) | m64) - k64;
-    half2_t        p2    = bit_cast<half2_t>((hi & 0x000f000fu) | m1024) - k1024;
-    half2_t        p3    = bit_cast<half2_t>((hi & 0x00f000f0u) | m64) - k64;
-    p0                   = h2_fma(p0, s2, z2);
-    p1                   = h2_fma(p1, s2, z2);
-    p2                   = h2_fma(p2, s2, z2);
-    p3                   = h2_fma(p3, s2, z2);
-    return half8_t{p0[0], p0[1], p1[0], p1[1], p2[0], p2[1], p3[0], p3[1]};
-}
 
 __device__ __forceinline__ void store_wt(floatx4* dst, floatx4 v, int mode = 1)
 {
@@ -1134,7 +1117,8 @@ int dec32_table_import(const char* path)
     int K, N, M, shape, splits, n = 0;
     while (fscanf(f, "%d %d %d %d %d", &K, &N, &M, &shape, &splits) == 5) {
         const bool big = M > 64;
-        if (K > 0 && N > 0 && M > 0 && M == dec32_m_bucket(M) && shape >= 0 && shape <= 9 && splits >= 1 && splits <= 16
+        const bool lib = shape == kShapeF16Library && M >= kF16LibraryMinM && splits == 1;  // (falls back at pick time without the library)
+        if (K > 0 && N > 0 && M > 0 && M == dec32_m_bucket(M) && shape >= 0 && (shape <= 9 || lib) && splits >= 1 && splits <= 16
             && (big ? shape >= 4 : (shape != 4 && shape != 5)) && !(shape == 5 && N < 512) && K % 128 == 0 && N % 32 == 0) {
             dec32_table_set(K, N, M, shape, splits);
             ++n;
@@ -1191,6 +1175,11 @@ int dec32_candidates(const LinearWeight& w, int M, int (*out)[2], int cap)
             }
         }
     }
+    if (M >= kF16LibraryMinM && M <= 8192 && f16_library_available() && n < cap) {  // dequantise + vendor fp16 GEMM (gemm_f16_library.hip)
+        out[n][0] = kShapeF16Library;
+        out[n][1] = 1;
+        ++n;
+    }
     return n;
 }
 
@@ -1201,12 +1190,24 @@ void dec32_pick(const LinearWeight& w, int M, int* shape_out, int* splits_out)
     dec32_pick_ex(w, M, shape_out, splits_out, true);
 }
 
-void dec32_pick_ex(const LinearWeight& w, int M, int* shape_out, int* splits_out, bool use_table)
+void dec32_pick_ex(const LinearWeight& w, int M, int* shape_out, int* splits_out, bool use_table, bool allow_library)
 {
     const int ncg = w.N / 32;
     const int KB  = w.K / 128;
-    if (use_table && dec32_table_get(w.K, w.N, dec32_m_bucket(M), shape_out, splits_out)) {
+    allow_library = allow_library && f16_library_available();
+    if (use_table && dec32_table_get(w.K, w.N, dec32_m_bucket(M), shape_out, splits_out)
+        && (*shape_out != kShapeF16Library || (allow_library && M >= kF16LibraryMinM))) {
         return;  // measured on this machine for exactly this problem (M <= 256) / for this size class of forwards (above)
+    }
+    // Compute-bound forwards: dequantise + the vendor library's fp16 GEMM (gemm_f16_library.hip).  Measured against the fused
+    // 128 x 512 tile on the Llama-3-8B shapes (profiles/r03_prefill_gemm_vs_library.txt, us incl. the dequant pass / the SiLU
+    // pass of w1w3): M = 4096: w_qkv 186 vs 240, wo 106 vs 126, w1w3 ~765 vs 848, w2 348 vs 396; M = 1024: 66 vs 57, 48 vs 47,
+    // ~255 vs 236, 147 vs 118 -- the crossover sits near 2048 rows; with a resident fp16 image (no dequant pass) near 1024.
+    static const int lib_from = env_int2("TM_F16_LIBRARY_MIN_M", 2048);
+    if (allow_library && M >= (w.f16_nk ? std::min(lib_from, 1024) : lib_from)) {
+        *shape_out  = kShapeF16Library;
+        *splits_out = 1;
+        return;
     }
     static const int env_shape  = env_int2("TM_D32_SHAPE", -1);  // read once: this runs on every eager launch
     static const int env_splits = env_int2("TM_D32_SPLITS", 0);

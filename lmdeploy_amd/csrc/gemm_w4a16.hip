@@ -171,6 +171,10 @@ void linear_weight_free(LinearWeight& w)
     if (w.packed8) {
         (void)hipFree(w.packed8);
     }
+    if (w.f16_nk) {
+        (void)hipFree(w.f16_nk);
+    }
+    w.f16_nk  = nullptr;
     w.packed8 = nullptr;
     w.packed   = nullptr;
     w.sz       = nullptr;
@@ -726,11 +730,11 @@ static int env_int(const char* name, int dflt)
     return v ? atoi(v) : dflt;
 }
 
-GemmConfig gemm_pick_config(const LinearWeight& w, int M)
+GemmConfig gemm_pick_config(const LinearWeight& w, int M, bool allow_library)
 {
     if (dec32_supported(w, M)) {  // decode batch: the weight-streaming kernel of gemm_decode.hip
         GemmConfig cfg{};
-        dec32_pick(w, M, &cfg.d32_shape, &cfg.splits);
+        dec32_pick_ex(w, M, &cfg.d32_shape, &cfg.splits, true, allow_library);
         cfg.nt      = 2;
         cfg.waves   = 16;
         cfg.kphases = 1;
@@ -934,6 +938,11 @@ int launch_linear(const LinearWeight& w,
     TM_REQUIRE(!gated_silu || w.N % 32 == 0, "gated epilogue needs N % 32 == 0");
     if (M == 0) {
         return 0;
+    }
+    if (cfg.d32_shape == kShapeF16Library) {
+        TM_REQUIRE(!tail && !defer_reduce && dec32_supported(w, M) && M >= kF16LibraryMinM,
+                   "library GEMM: a prefill-sized forward of a dense u4 linear, no slab consumers");
+        return launch_linear_f16_library(w, x, ldx, y, ldy, M, gated_silu, cfg.lib_ws, cfg.lib_ws_bytes, st);
     }
     if (cfg.d32_shape >= 0 && dec32_supported(w, M)) {
         int       nslab = 1;

@@ -132,6 +132,35 @@ int launch_argmax(int* out_ids, half_t* out_val, const half_t* logits, int B, in
 }
 
 // unfused activation on a [M][2*inter] buffer laid out [gate | up]
+// Pseudo-random fp16 values in (-amp, amp) -- stand-in activations for the start-up GEMM tuner.  Not zeros: the matrix pipe
+// of MI355X is power-limited, and a GEMM over all-zero activations runs at the full 2.4 GHz instead of the ~1.6 GHz it sustains
+// on real data (measured: the fused w1w3 prefill tile 1152 us on zeros, 1697 us on N(0,1) rows) -- timings on zeros rank
+// compute-bound candidates wrongly.
+__global__ __launch_bounds__(256) void fill_uniform_f16_kernel(half_t* __restrict__ out, size_t n, float amp, uint32_t seed)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) {
+        return;
+    }
+    uint32_t h = (uint32_t)i * 0x9E3779B1u + (uint32_t)(i >> 32) + seed;  // one round of a 32-bit integer hash
+    h ^= h >> 16;
+    h *= 0x7feb352du;
+    h ^= h >> 15;
+    h *= 0x846ca68bu;
+    h ^= h >> 16;
+    out[i] = (half_t)(((float)(h >> 8) * (1.0f / 8388608.0f) - 1.0f) * amp);
+}
+
+int launch_fill_uniform_f16(half_t* out, size_t n, float amp, uint32_t seed, hipStream_t st)
+{
+    if (n == 0) {
+        return 0;
+    }
+    fill_uniform_f16_kernel<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(out, n, amp, seed);
+    TM_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
 __global__ __launch_bounds__(256) void silu_mul_kernel(half_t* __restrict__ out,
                                                        const half_t* __restrict__ gate_up,
                                                        int M,

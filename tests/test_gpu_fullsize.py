@@ -129,6 +129,41 @@ def test_w4a16_every_tuner_candidate_full_size(tm, cuda, K, N, gated, M):
         assert np.all(err <= tol), f'shape {shape} splits {splits}: max err {err.max()} at {np.argmax(err - tol)}'
 
 
+@pytest.mark.parametrize('K,N,gated,M', [(4096, 6144, 0, 2048), (4096, 28672, 1, 5000), (14336, 4096, 0, 512)])
+def test_w4a16_f16_library_path_full_size(tm, cuda, K, N, gated, M):
+    """Prefill-sized forwards as "dequantise + the vendor library's fp16 GEMM" (gemm_f16_library.hip, candidate shape 10 of the
+    measured dispatch): (1) the fp16 [N][K] image equals the oracle's dequantised weights bit for bit; (2) the product through
+    the per-call image and through the resident image (tm_linear_build_f16_image) are the same bits and within the u4 linear's
+    tolerance of the fp32 oracle product; gated case: 5000 rows = two row chunks (2560 + 2440) of the SiLU pass."""
+    assert tm.tm_f16_library_available(), 'hipBLASLt must be loadable on the GPU box (the library path would silently never run)'
+    rng = np.random.default_rng(K + 3 * N + M)
+    packed, s, z, wd, _ = _random_awq(rng, K, N)
+    h = _ffi.C.c_void_p()
+    _ffi.check(tm.tm_linear_create(_ffi.C.byref(h), K, N, 0, 128))
+    _ffi.check(tm.tm_linear_prepare(h, dev(packed).data_ptr(), dev(s).data_ptr(), dev(z).data_ptr(), st()))
+    img = torch.zeros((N, K), dtype=torch.float16, device='cuda')
+    _ffi.check(tm.tm_linear_dequant_f16(h, img.data_ptr(), st()))
+    assert np.array_equal(host(img).view(np.uint16), np.ascontiguousarray(wd.T).astype(f16).view(np.uint16)), 'fp16 image must be bit exact'
+    del img
+    x = rng.standard_normal((M, K)).astype(f16)
+    acc = x.astype(np.float32) @ wd
+    ref = (o.gated_silu_epilogue(acc) if gated else acc.astype(f16)).astype(np.float32)
+    tol = 2e-3 + 2.0**-9 * np.abs(ref)
+    ws = torch.zeros(tm.tm_linear_workspace(h, M), dtype=torch.uint8, device='cuda')
+    x_d = dev(x)
+    outs = []
+    for resident in (False, True):
+        if resident:
+            _ffi.check(tm.tm_linear_build_f16_image(h, st()))
+        y = torch.zeros((M, N // 2 if gated else N), dtype=torch.float16, device='cuda')
+        _ffi.check(tm.tm_linear_forward(h, x_d.data_ptr(), K, y.data_ptr(), y.shape[1], M, gated, 0, 1, 0x200 | 10, ws.data_ptr(), st()))
+        outs.append(host(y))
+        err = np.abs(outs[-1].astype(np.float32) - ref)
+        assert np.all(err <= tol), f'resident={resident}: max err {err.max()} at {np.argmax(err - tol)}'
+    assert np.array_equal(outs[0].view(np.uint16), outs[1].view(np.uint16))
+    tm.tm_linear_destroy(h)
+
+
 @pytest.mark.parametrize('K,N', [(4096, 4096), (14336, 4096)])
 def test_w4a16_in_launch_consumer_every_candidate_full_size(tm, cuda, K, N):
     """wo / w2 of Llama-3-8B at batch 64 with the in-launch residual-norm consumer, every tiling the tuner can pick: residual

@@ -406,7 +406,8 @@ def test_decode_attention_block_table_permutation_invariance(tm, cuda):
 
 
 @pytest.mark.parametrize('Hq,Hkv,qlens,hist', [(4, 2, [70, 5, 129], [0, 0, 0]), (8, 8, [33], [95]), (6, 2, [1, 64], [0, 64]),
-                                               (8, 2, [200, 37], [0, 10]), (32, 8, [130], [62]), (16, 2, [64, 96], [0, 32])])
+                                               (8, 2, [200, 37], [0, 10]), (32, 8, [130], [62]), (16, 2, [64, 96], [0, 32]),
+                                               (32, 8, [1024, 700], [0, 324]), (8, 4, [300], [1000])])
 def test_prefill_attention(tm, cuda, Hq, Hkv, qlens, hist):
     rng = np.random.default_rng(Hq + sum(qlens))
     B = len(qlens)

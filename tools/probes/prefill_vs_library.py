@@ -38,11 +38,14 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--ms', default='2048,4096,8192')
     ap.add_argument('--iters', type=int, default=10)
+    ap.add_argument('--only', default='')
     args = ap.parse_args()
     tm = _ffi.load()
     C = _ffi.C
     g = torch.Generator(device='cuda').manual_seed(1)
     for name, (K, N, gated) in SHAPES.items():
+        if args.only and name not in args.only.split(','):
+            continue
         qw = torch.randint(-2**31, 2**31 - 1, (K, N // 8), generator=g, device='cuda', dtype=torch.int32)
         s = (torch.rand((K // 128, N), generator=g, device='cuda') * 0.002 + 0.001).to(torch.float16)
         z = torch.randint(4, 12, (K // 128, N), generator=g, device='cuda').to(torch.float16)
@@ -59,16 +62,26 @@ def main():
             ws = torch.zeros(max(1, tm.tm_linear_workspace(h, M)), dtype=torch.uint8, device='cuda')
             st = torch.cuda.current_stream().cuda_stream
 
+            sh, sp = C.c_int(), C.c_int()
+            _ffi.check(tm.tm_debug_pick_tiling(K, N, M, 2, C.byref(sh), C.byref(sp)))     # the fused kernels' own heuristic
+
             def ours():
-                _ffi.check(tm.tm_linear_forward(h, x.data_ptr(), K, y.data_ptr(), y.shape[1], M, gated, 0, 0, 0, ws.data_ptr(), st))
+                _ffi.check(tm.tm_linear_forward(h, x.data_ptr(), K, y.data_ptr(), y.shape[1], M, gated, 0, sp.value, 0x200 | sh.value,
+                                                ws.data_ptr(), st))
             out = torch.empty((M, N), dtype=torch.float16, device='cuda')
             t_ours = timed(ours, args.iters)
+            ws_l = torch.zeros(tm.tm_linear_workspace(h, M), dtype=torch.uint8, device='cuda')
+
+            def ours_lib():
+                _ffi.check(tm.tm_linear_forward(h, x.data_ptr(), K, y.data_ptr(), y.shape[1], M, gated, 0, 1, 0x200 | 10, ws_l.data_ptr(), st))
+            t_lib = timed(ours_lib, args.iters) if tm.tm_f16_library_available() and M >= 512 else float('nan')
             t_nn = timed(lambda: torch.matmul(x, w_kn, out=out), args.iters)
             t_nt = timed(lambda: torch.matmul(x, w_nk.t(), out=out), args.iters)
             fl = 2.0 * M * K * N
             print(f'{name:8s} M={M:5d} K={K:6d} N={N:6d}  fused W4A16 {t_ours:8.1f} us {fl / t_ours / 1e6:7.1f} TF/s | '
+                  f'dequant + library{" + SiLU pass" if gated else ""} (shape 10) {t_lib:8.1f} us {fl / t_lib / 1e6:7.1f} TF/s | '
                   f'library fp16 NN {t_nn:8.1f} us {fl / t_nn / 1e6:7.1f} TF/s | NT {t_nt:8.1f} us {fl / t_nt / 1e6:7.1f} TF/s', flush=True)
-            del x, y, ws, out
+            del x, y, ws, out, ws_l
         tm.tm_linear_destroy(h)
         del w_kn, w_nk
         torch.cuda.empty_cache()
