@@ -47,10 +47,13 @@ __global__ __launch_bounds__(256, 2) void prefill_attention_kernel(PrefillAttnPa
     const int qlen  = p.cu_q_len[b + 1] - q_beg;
     const int klen  = p.k_len[b];
     const int hist  = klen - qlen;
-    if ((int)blockIdx.x * 64 >= qlen) {
+    // causal: query block bx walks bx + 1 stages (+ history).  The dispatcher hands out workgroups in blockIdx order, so the
+    // LONGEST blocks of every (head group, sequence) go first and the short ones fill the tail (longest-processing-time order)
+    const int bx = (int)gridDim.x - 1 - (int)blockIdx.x;
+    if (bx * 64 >= qlen) {
         return;  // workgroup-uniform
     }
-    const int  q0     = blockIdx.x * 64 + wave * 16;
+    const int  q0     = bx * 64 + wave * 16;
     const bool active = q0 < qlen;  // wave-uniform; an inactive wave still stages tiles and meets the barriers
     const int  group  = p.q_heads / p.kv_heads;
     const int  kvh    = hq0 / group;
@@ -114,7 +117,7 @@ __global__ __launch_bounds__(256, 2) void prefill_attention_kernel(PrefillAttnPa
     const float sc      = p.scale_log2;
     const int   qpos    = hist + q0 + i16;                              // absolute position of this lane's query row
     const int   kend_w  = active ? min(klen, hist + q0 + 16) : 0;       // keys visible to the last row of this wave
-    const int   kend_wg = min(klen, hist + (int)blockIdx.x * 64 + 64);  // ... of this workgroup
+    const int   kend_wg = min(klen, hist + bx * 64 + 64);               // ... of this workgroup
     const int   krow    = 8 * (i16 >> 2) + (i16 & 3);                   // key (within the 32-key step) of score-tile-A row i16; tile B: +4
 
     stage_in(0, 0);
