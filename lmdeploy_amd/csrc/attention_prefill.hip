@@ -247,7 +247,8 @@ int launch_prefill_attention(const PrefillAttnParams& p, hipStream_t st)
         return 0;
     }
     const int group = p.q_heads / p.kv_heads;
-    const int G     = group % 4 == 0 ? 4 : (group % 2 == 0 ? 2 : 1);  // query heads per wave (share one kv head)
+    const int G     = group % 4 == 0 ? 4 : (group % 2 == 0 ? 2 : 1);  // query heads per wave (share one kv head); G = 4 spills ~25
+                                                                       // registers at two workgroups per CU -- measured equal to G = 2
     dim3      grid((p.max_q_len + 63) / 64, p.q_heads / G, p.batch);
     constexpr int lds = 2 * 2 * 64 * 128 * 2;  // two stages of (K tile + V^T tile)
     const void* const k = G == 4 ? (const void*)prefill_attention_kernel<4> :

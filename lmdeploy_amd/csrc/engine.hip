@@ -1655,6 +1655,41 @@ int tm_engine_start(tm_engine* e)
     if (const char* exp = getenv("TM_GEMM_EXPORT")) {
         TM_TRY(dec32_table_export(exp));
     }
+    // The library path's first use loads the library's code objects, creates its handle and searches its kernel list: ~150 ms
+    // (measured: TTFT p50 581 ms on a cold process against 415 ms after the tuner had been through it).  Start-up work, like
+    // the reference's warm-up (turbomind.cc:363-487): one full-chunk forward of every distinct dense linear, results discarded.
+    if (e->d_lib_ws) {
+        const int M = e->max_tokens;
+        Layer&    L = e->layers[0];
+        struct Warm {
+            LinearSlots*  l;
+            const half_t* x;
+            int           ldx;
+            half_t*       y;
+            int           ldy;
+            bool          gated;
+        };
+        const Warm ws[4] = {{&L.qkv, e->d_x, e->hidden, e->d_qkv, e->qkv_n, false},
+                            {&L.wo, e->d_attn, e->q_heads * e->D, e->d_tmp, e->hidden, false},
+                            {L.is_moe ? nullptr : &L.w13, e->d_x, e->hidden, e->d_act, e->inter, true},
+                            {L.is_moe ? nullptr : &L.w2, e->d_act, e->inter, e->d_tmp, e->hidden, false}};
+        for (const Warm& w : ws) {
+            if (!w.l || !dec32_supported(w.l->w, M)) {
+                continue;
+            }
+            const GemmConfig cfg = pick_config(e, w.l->w, M, w.gated);
+            if (cfg.d32_shape == kShapeF16Library
+                && launch_linear(w.l->w, w.x, w.ldx, w.y, w.ldy, M, w.gated, cfg, e->d_gemm_ws, false, nullptr, e->stream)) {
+                fprintf(stderr, "[tm] library GEMM warm-up failed (%s); the fused kernels serve prefill\n", tm_last_error());
+                (void)hipGetLastError();
+                (void)hipFree(e->d_lib_ws);
+                e->d_lib_ws     = nullptr;
+                e->lib_ws_bytes = 0;
+                break;
+            }
+        }
+        TM_HIP_CHECK(hipStreamSynchronize(e->stream));
+    }
     return 0;
 }
 
