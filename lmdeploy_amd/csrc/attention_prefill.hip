@@ -19,7 +19,8 @@
 // (K 16 KB + V^T 16 KB) is brought in ONCE per workgroup by LDS-DMA (buffer_load ... lds: no staging registers -- accumulators
 // and Q fragments already take ~200), double buffered, one barrier per stage; the XOR swizzle that makes the 16-byte fragment
 // reads bank-conflict free sits on the DMA's source addresses (the DMA writes lane L to slot L of its 1 KB piece).
-// Measured (8 x 1024 prompt tokens of Llama-3-8B per launch, rocprofv3 kernel trace): 282 -> 252 us, 0.27 PFLOP/s.  What
+// Measured (8 x 1024 prompt tokens of Llama-3-8B per launch, rocprofv3 kernel trace): 282 -> 252 us; 235 us = 0.29 PFLOP/s with
+// the conflict-free swizzle (ksw) and the leaner softmax below (profiles/r03_pmc_prefill_attention.txt).  What
 // bounds it now is the softmax's VALU issue, not memory: per 32-key step and wave 64 MFMAs (1024 matrix-pipe cycles) stand
 // against ~500 VALU slots (32 v_exp_f32 at quarter rate alone are 512 cycles), and the two waves of a SIMD share one VALU.
 // Prefill attention is 8 % of a prefill chunk (the GEMMs are 82 %), so this is where the kernel was left.
