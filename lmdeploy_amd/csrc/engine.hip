@@ -1308,7 +1308,7 @@ int tm_engine_process_weights(tm_engine* e)
 // Cache holds, as in a decode step -- and each node is followed by the kernel that consumes its result (the fused split-K
 // reduce + residual + RMSNorm for wo / w2, the slab reduce standing in for the attention prologue for w_qkv): a split-K
 // GEMM looks cheap in isolation and pays at the kernel boundary (profiles/r02_gemm_boundary_gap.txt).  The winner enters
-// the (K, N, M) table that dec32_pick consults first; it replaces the heuristic only when it is >= 3 % faster.
+// the (K, N, M) table that dec32_pick consults first; it replaces the heuristic only when it is >= 7 % faster.
 // ------------------------------------------------------------------------------------------------------------------
 static int tune_decode_gemms(tm_engine* e, int M, bool verbose)
 {
@@ -1438,7 +1438,7 @@ static int tune_decode_gemms(tm_engine* e, int M, bool verbose)
                 }
                 TM_HIP_CHECK(erc);
                 TM_HIP_CHECK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
-                for (int rep = 0; rep < 4; ++rep) {
+                for (int rep = 0; rep < 6; ++rep) {
                     TM_HIP_CHECK(hipEventRecord(e0, st));
                     TM_HIP_CHECK(hipGraphLaunch(ge, st));
                     TM_HIP_CHECK(hipEventRecord(e1, st));
@@ -1482,7 +1482,11 @@ static int tune_decode_gemms(tm_engine* e, int M, bool verbose)
         if (rc) {
             break;
         }
-        if (!(best < 0.97f * heur)) {  // keep the heuristic unless the measurement clearly beats it
+        // keep the heuristic unless the measurement clearly beats it.  7 %: run-to-run spread of a candidate is +-3 % (the same tiling
+        // measured 18.35 / 18.72 / 19.13 us in three starts on one box), and the chain here is not the model (the same kernel back
+        // to back, its activations hot in L2): with a 3 % bar w2 of Llama-3-8B once flipped from (3, 4) to (6, 2) -- 12 % slower in
+        // the model (gpurun_out/profile_r03c: 0.61 vs 0.54 ms per step)
+        if (!(best < 0.93f * heur)) {
             bs = hs;
             bp = hp;
         }
