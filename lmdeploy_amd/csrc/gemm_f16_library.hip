@@ -131,30 +131,52 @@ int lt_plan(int N, int M, int K, int ldx, int ldy, hipblasLtHandle_t* handle, Lt
         return 0;
     }
     LtPlan p;
-    TM_LT_CHECK(api.desc_create(&p.desc, HIPBLAS_COMPUTE_32F, HIP_R_32F));
-    const int32_t opt = HIPBLAS_OP_T, opn = HIPBLAS_OP_N;
-    TM_LT_CHECK(api.desc_set(p.desc, HIPBLASLT_MATMUL_DESC_TRANSA, &opt, sizeof(opt)));
-    TM_LT_CHECK(api.desc_set(p.desc, HIPBLASLT_MATMUL_DESC_TRANSB, &opn, sizeof(opn)));
-    TM_LT_CHECK(api.layout_create(&p.a, HIP_R_16F, (uint64_t)K, (uint64_t)N, (int64_t)K));
-    TM_LT_CHECK(api.layout_create(&p.b, HIP_R_16F, (uint64_t)K, (uint64_t)M, (int64_t)ldx));
-    TM_LT_CHECK(api.layout_create(&p.d, HIP_R_16F, (uint64_t)N, (uint64_t)M, (int64_t)ldy));
+    // (a failure below returns with the descriptors created so far destroyed)
+    auto build = [&]() -> int {
+        TM_LT_CHECK(api.desc_create(&p.desc, HIPBLAS_COMPUTE_32F, HIP_R_32F));
+        const int32_t opt = HIPBLAS_OP_T, opn = HIPBLAS_OP_N;
+        TM_LT_CHECK(api.desc_set(p.desc, HIPBLASLT_MATMUL_DESC_TRANSA, &opt, sizeof(opt)));
+        TM_LT_CHECK(api.desc_set(p.desc, HIPBLASLT_MATMUL_DESC_TRANSB, &opn, sizeof(opn)));
+        TM_LT_CHECK(api.layout_create(&p.a, HIP_R_16F, (uint64_t)K, (uint64_t)N, (int64_t)K));
+        TM_LT_CHECK(api.layout_create(&p.b, HIP_R_16F, (uint64_t)K, (uint64_t)M, (int64_t)ldx));
+        TM_LT_CHECK(api.layout_create(&p.d, HIP_R_16F, (uint64_t)N, (uint64_t)M, (int64_t)ldy));
+        return 0;
+    };
+    auto drop = [&]() {
+        if (p.desc) {
+            (void)api.desc_destroy(p.desc);
+        }
+        for (hipblasLtMatrixLayout_t l : {p.a, p.b, p.d}) {
+            if (l) {
+                (void)api.layout_destroy(l);
+            }
+        }
+    };
+    if (const int rc = build()) {
+        drop();
+        return rc;
+    }
     hipblasLtMatmulPreference_t pref = nullptr;
-    TM_LT_CHECK(api.pref_create(&pref));
+    if (api.pref_create(&pref) != HIPBLAS_STATUS_SUCCESS) {
+        drop();
+        ::tmk::set_last_error("hipBLASLt: hipblasLtMatmulPreferenceCreate failed");
+        return 2;
+    }
     const uint64_t max_ws = kLtWorkspace;
-    TM_LT_CHECK(api.pref_set(pref, HIPBLASLT_MATMUL_PREF_MAX_WORKSPACE_BYTES, &max_ws, sizeof(max_ws)));
+    (void)api.pref_set(pref, HIPBLASLT_MATMUL_PREF_MAX_WORKSPACE_BYTES, &max_ws, sizeof(max_ws));
     hipblasLtMatmulHeuristicResult_t res[8];
     int                              found = 0;
     const hipblasStatus_t            hs    = api.heuristic(*handle, p.desc, p.a, p.b, p.d, p.d, pref, 8, res, &found);
     (void)api.pref_destroy(pref);
-    TM_LT_CHECK(hs);
     int pick = -1;
-    for (int i = 0; i < found && pick < 0; ++i) {
+    for (int i = 0; hs == HIPBLAS_STATUS_SUCCESS && i < found && pick < 0; ++i) {
         if (res[i].state == HIPBLAS_STATUS_SUCCESS && res[i].workspaceSize <= kLtWorkspace) {
             pick = i;
         }
     }
     if (pick < 0) {
-        ::tmk::set_last_error("hipBLASLt: no fp16 GEMM algorithm for this problem");
+        drop();
+        ::tmk::set_last_error("hipBLASLt: no fp16 GEMM algorithm for this problem (status " + std::to_string((int)hs) + ")");
         return 2;
     }
     p.algo = res[pick].algo;
