@@ -325,8 +325,9 @@ int tm_linear_forward(const tm_linear* w, const void* x, int ldx, void* y, int l
         TM_REQUIRE(dec32_supported(w->w, M), "decode kernel: u4 weights, N % 32 == 0");
         cfg.d32_shape = waves & 0xff;
         TM_REQUIRE((cfg.d32_shape >= 6 && cfg.d32_shape <= 9) || (cfg.d32_shape <= 5 && (cfg.d32_shape >= 4) == (M > 64))
+                       || (cfg.d32_shape == kShapeLC && M <= 64)
                        || (cfg.d32_shape == kShapeF16Library && M >= kF16LibraryMinM && workspace),
-                   "decode kernel shape 0..3 (M <= 64), 4 / 5 (M > 64), 6..9 (32-row blocks, any M) or 10 (library GEMM, M >= 512)");
+                   "decode kernel shape 0..3 / 11 (M <= 64), 4 / 5 (M > 64), 6..9 (32-row blocks, any M) or 10 (library GEMM, M >= 512)");
         waves = 0;
     }
     if (cfg.d32_shape == kShapeF16Library) {

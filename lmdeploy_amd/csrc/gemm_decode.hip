@@ -32,6 +32,7 @@
 #include "tm_kernels.h"
 #include "norm_row.h"
 #include "p32_layout.h"
+#include "gemm_decode_common.h"
 #include <stdlib.h>
 #include <algorithm>
 #include <type_traits>
@@ -42,8 +43,6 @@
 #include <stdio.h>
 
 namespace tmk {
-
-typedef float floatx16 __attribute__((ext_vector_type(16)));
 
 __global__ void repack_p32_kernel(uint32_t* __restrict__ out, const int32_t* __restrict__ qw, const half_t* __restrict__ scales,
                                   const half_t* __restrict__ zeros, int K, int N)
@@ -94,70 +93,6 @@ int launch_repack_p32(void* out, const int32_t* qweight, const half_t* scales, c
     repack_p32_kernel<<<(unsigned)((total + 255) / 256), 256, 0, st>>>((uint32_t*)out, qweight, scales, zeros, K, N);
     TM_HIP_CHECK(hipGetLastError());
     return 0;
-}
-
-struct Dec32Params {
-    const half_t* x;
-    int           ldx;
-    const void*   wp;  // P32 units
-    half_t*       y;
-    int           ldy;
-    float*        partial;  // [splits][M][N] fp32 slabs (epilogue 2)
-    int           M, N, K, KB, ncg;
-    int           kb_per_split;
-    int           epilogue;  // 0: fp16   1: gated SiLU fp16 (N/2 columns)   2: fp32 slab of split blockIdx.y
-    int           wt;        // bit 0: split-K slabs, bit 1: fp16 outputs leave through write-through (sc1) stores: they drain to memory
-                             // while the other workgroups still stream instead of sitting dirty in L2 until the end-of-kernel
-                             // release writes them back (the kernel boundary then waits for MBs of fp32 slabs)
-    // In-launch consumer of a row-parallel linear (epilogue 2 only; reference: the residual + RMSNorm that follows wo / w2,
-    // unified_decoder.cc:149,226 -> rms_norm.cu:286-362): the LAST `min(M, 64)` workgroups to finish their slab tiles each take
-    // token rows and run norm_row<2> on them (split-K reduce in slab order -> fp16 -> residual add -> RMSNorm), so the
-    // separate reduce-norm launch, its kernel boundary and the dirty-slab write-back in front of it disappear.  Hand-off:
-    // write-through slab stores, every wave drains vmcnt, ONE relaxed agent-scope ticket per workgroup; a tail workgroup polls
-    // that one word (relaxed, s_sleep, BOUNDED: on give-up it sets tail_sync[2] and carries on) and reads the slabs with sc1
-    // loads (cdna_hip_programming.md Guideline 16 R1).  tail_sync = 4 device words, zero before the first launch; the last
-    // tail workgroup to finish re-zeroes the two counters, so consecutive launches on one stream may share the words.
-    half_t*       tail_y;       // nullptr: no in-launch consumer
-    half_t*       tail_resid;
-    const half_t* tail_w;
-    float         tail_eps;
-    unsigned*     tail_sync;    // [0] arrivals, [1] finished tail workgroups, [2] give-up mark (sticky), [3] -
-    uint64_t*     dbg;       // optional [workgroups][8] s_memrealtime stamps (tm_debug_set_gemm_trace): start, loop, epilogue, end,
-                             // hw id, -, -, after the k-phase reduction barrier
-};
-
-__device__ __forceinline__ void store_wt(floatx4* dst, floatx4 v, int mode = 1)
-{
-    // mode (TM_D32_WT >> 4, experiment arms): 0/1 sc1, 2 sc0 sc1, 3 nt, 4 nt sc0 sc1
-    if (mode <= 1) {
-        asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(v) : "memory");
-    }
-    else if (mode == 2) {
-        asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(dst), "v"(v) : "memory");
-    }
-    else if (mode == 3) {
-        asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(dst), "v"(v) : "memory");
-    }
-    else {
-        asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt" ::"v"(dst), "v"(v) : "memory");
-    }
-}
-__device__ __forceinline__ void store_wt(half4_t* dst, half4_t v)
-{
-    asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(dst), "v"(v) : "memory");
-}
-__device__ __forceinline__ void store_wt(half2_t* dst, half2_t v)
-{
-    asm volatile("global_store_dword %0, %1, off sc1" ::"v"(dst), "v"(v) : "memory");
-}
-
-template<int N, class F, int I = 0>
-__device__ __forceinline__ void static_for(F&& f)
-{
-    if constexpr (I < N) {
-        f(std::integral_constant<int, I>{});
-        static_for<N, F, I + 1>(static_cast<F&&>(f));
-    }
 }
 
 // The in-launch consumer (Dec32Params::tail_*).  Called by every thread of the workgroup after its slab stores were ISSUED.
@@ -1036,6 +971,11 @@ static int dec32_base_shape(int shape)
 static void dec32_shape_dims(int shape, int* cg, int* s)
 {
     static const int cgs[6] = {4, 8, 4, 2, 8, 16};
+    if (shape == kShapeLC) {
+        *cg = 4;
+        *s  = 4;
+        return;
+    }
     shape = dec32_base_shape(shape);
     *cg = cgs[shape < 0 || shape > 5 ? 0 : shape];
     *s  = shape == 5 ? 1 : (shape == 4 ? 2 : 4);
@@ -1118,7 +1058,8 @@ int dec32_table_import(const char* path)
     while (fscanf(f, "%d %d %d %d %d", &K, &N, &M, &shape, &splits) == 5) {
         const bool big = M > 64;
         const bool lib = shape == kShapeF16Library && M >= kF16LibraryMinM && splits == 1;  // (falls back at pick time without the library)
-        if (K > 0 && N > 0 && M > 0 && M == dec32_m_bucket(M) && shape >= 0 && (shape <= 9 || lib) && splits >= 1 && splits <= 16
+        const bool lc  = shape == kShapeLC && M <= 64;
+        if (K > 0 && N > 0 && M > 0 && M == dec32_m_bucket(M) && shape >= 0 && (shape <= 9 || lib || lc) && splits >= 1 && splits <= 16
             && (big ? shape >= 4 : (shape != 4 && shape != 5)) && !(shape == 5 && N < 512) && K % 128 == 0 && N % 32 == 0) {
             dec32_table_set(K, N, M, shape, splits);
             ++n;
@@ -1170,6 +1111,21 @@ int dec32_candidates(const LinearWeight& w, int M, int (*out)[2], int cap)
             }
             if (n < cap) {
                 out[n][0] = shape;
+                out[n][1] = s;
+                ++n;
+            }
+        }
+    }
+    if (M <= 64) {  // the loader / consumer kernel (gemm_decode_lc.hip): 128-column tiles, whole stages of 4 k-blocks per slice
+        const int tiles = (ncg + 3) / 4;
+        for (int s = 1; s <= 16; ++s) {
+            int per = (KB + s - 1) / s;
+            per     = (per + 3) / 4 * 4;
+            if ((KB + per - 1) / per != s || (s > 1 && tiles * s > 320) || tiles * s < 32) {
+                continue;
+            }
+            if (n < cap) {
+                out[n][0] = kShapeLC;
                 out[n][1] = s;
                 ++n;
             }
@@ -1283,8 +1239,9 @@ int launch_linear_dec32(const LinearWeight& w, const half_t* x, int ldx, half_t*
                         int splits, float* workspace, int* slabs_out, hipStream_t st, const NormTail* tail)
 {
     TM_REQUIRE(w.packed32 != nullptr && w.N % 32 == 0, "decode GEMM: P32 layout missing");
-    TM_REQUIRE(M >= 1 && shape >= 0 && shape <= 9 && (shape >= 6 || (M <= 64) == (shape < 4)),
-               "decode GEMM: shapes 0..3 take M <= 64, shapes 4 / 5 take M > 64, shapes 6..9 any M");
+    TM_REQUIRE(M >= 1 && shape >= 0 && (shape <= 9 || shape == kShapeLC) && (shape >= 6 || (M <= 64) == (shape < 4))
+                   && (shape != kShapeLC || M <= 64),
+               "decode GEMM: shapes 0..3 and 11 take M <= 64, shapes 4 / 5 take M > 64, shapes 6..9 any M");
     TM_REQUIRE(ldx % 8 == 0, "x rows must be 16-byte aligned");
     int cgn, S;
     dec32_shape_dims(shape, &cgn, &S);
@@ -1310,7 +1267,7 @@ int launch_linear_dec32(const LinearWeight& w, const half_t* x, int ldx, half_t*
     static const int wt = env_int2("TM_D32_WT", 1);  // measured (tools/trace_boundary.py, profiles/r02_gemm_boundary_gap.txt): -0.4..-0.9 us per split-K launch
     p.wt           = wt;
     if (tail) {  // slabs (also for ONE slice) consumed by the last workgroups of this launch: write-through stores are the publish
-        TM_REQUIRE(shape < 4 || shape >= 6, "in-launch consumer: decode tiles only");
+        TM_REQUIRE(shape < 4 || (shape >= 6 && shape <= 9), "in-launch consumer: the 16-wave decode tiles only");
         TM_REQUIRE(workspace != nullptr && !gated_silu && M <= 64, "in-launch consumer: row-parallel decode linear with a slab workspace");
         p.epilogue   = 2;
         p.wt         = 1;
@@ -1320,9 +1277,10 @@ int launch_linear_dec32(const LinearWeight& w, const half_t* x, int ldx, half_t*
         p.tail_eps   = tail->eps;
         p.tail_sync  = tail->sync;
     }
-    dim3      grid((p.ncg + cgn - 1) / cgn, splits, shape >= 6 ? (M + 31) / 32 : shape >= 4 ? (M + 127) / 128 : 1);
+    dim3      grid((p.ncg + cgn - 1) / cgn, splits, shape == kShapeLC ? 1 : shape >= 6 ? (M + 31) / 32 : shape >= 4 ? (M + 127) / 128 : 1);
     p.dbg        = gemm_trace_for((size_t)grid.x * grid.y * grid.z);
-    const int rc = shape >= 6 ? launch_dec32_shape<1>(p, grid, dec32_base_shape(shape), st) :
+    const int rc = shape == kShapeLC ? launch_dec_lc(p, grid, st) :
+                   shape >= 6 ? launch_dec32_shape<1>(p, grid, dec32_base_shape(shape), st) :
                    shape >= 4 ? launch_dec32_shape<4>(p, grid, shape, st) :
                    M <= 32    ? launch_dec32_shape<1>(p, grid, shape, st) :
                                 launch_dec32_shape<2>(p, grid, shape, st);

@@ -133,6 +133,7 @@ struct GemmConfig {
     size_t lib_ws_bytes = 0;
 };
 constexpr int kShapeF16Library = 10;
+constexpr int kShapeLC         = 11;   // gemm_decode_lc.hip: 8 consumer + 4 loader waves, 128 columns x M <= 64 rows per workgroup
 constexpr int kF16LibraryMinM  = 512;  // candidate of the measured dispatch from this size class on
 // Load-time repack (reference: LinearWeight::prepare, models/linear_weight.cc:101-324)
 // p32_only: build ONLY the P32 image (gemm_decode.hip) -- for linears that every M dispatches to those kernels

@@ -547,6 +547,50 @@ def test_w4a16_row_half_tiles(tm, cuda, K, N, M, gated, shape):
     _ffi.check(tm.tm_linear_destroy(h))
 
 
+@pytest.mark.parametrize('K,N,gated', [(4096, 6144, 0), (1792, 4096, 0), (1024, 512, 0), (4096, 1024, 1), (384, 64, 0), (14336, 256, 0)])
+@pytest.mark.parametrize('M', [1, 32, 33, 50, 64])
+def test_w4a16_loader_consumer_tiles(tm, cuda, K, N, M, gated):
+    """shape 11 (gemm_decode_lc.hip): 4 loader waves stage the activations, 8 consumer waves (2 column halves x 4 k-phases)
+    stream the weights through a 3-stage register ring.  K slices that are not whole stages (14 and 3 k-blocks), column tiles
+    that do not fill the workgroup (N = 64), both row-half instantiations, plain / gated / split-K epilogues; the same oracle
+    and tolerance as the other decode tiles, and every launch bit-identical to the first."""
+    rng = np.random.default_rng(K + N + M + 11)
+    h, (q, s, z) = _make_linear(tm, rng, K, N)
+    x = rng.standard_normal((M, K)).astype(f16)
+    ref = (o.w4a16_linear_gated_silu(x, q, s, z) if gated else x.astype(np.float32) @ _QCACHE[(K, N)][3]).astype(np.float32)
+    ws = torch.zeros(max(1, tm.tm_linear_workspace(h, M)), dtype=torch.uint8, device='cuda')
+    x_d = dev(x)
+    for splits in (1, 2, 3, 7):
+        if splits > max(1, K // 512):
+            continue
+        first = None
+        for rep in range(3):
+            y = torch.zeros((M, N // 2 if gated else N), dtype=torch.float16, device='cuda')
+            _ffi.check(tm.tm_linear_forward(h, x_d.data_ptr(), K, y.data_ptr(), y.shape[1], M, gated, 0, splits, 0x200 | 11, ws.data_ptr(), st()))
+            got = host(y)
+            err = np.abs(got.astype(np.float32) - ref)
+            assert np.all(err <= 2e-3 + 2.0**-9 * np.abs(ref)), f'splits={splits} launch {rep}: max err {err.max()}'
+            if first is None:
+                first = got
+            assert np.array_equal(got.view(np.uint16), first.view(np.uint16)), f'splits={splits}: launch {rep} differs from launch 0'
+    _ffi.check(tm.tm_linear_destroy(h))
+
+
+def test_w4a16_loader_consumer_identity(tm, cuda):
+    """x = rows of the identity through shape 11: the dequantised weights come back bit for bit (operand = the reference's)."""
+    rng = np.random.default_rng(5)
+    K, N = 512, 160
+    h, (q, s, z) = _make_linear(tm, rng, K, N)
+    w = o.w4a16_dequant(q, s, z)
+    x = np.zeros((64, K), f16)
+    rows = rng.permutation(K)[:64]
+    x[np.arange(64), rows] = 1
+    y = torch.zeros((64, N), dtype=torch.float16, device='cuda')
+    _ffi.check(tm.tm_linear_forward(h, dev(x).data_ptr(), K, y.data_ptr(), N, 64, 0, 0, 1, 0x200 | 11, None, st()))
+    assert np.array_equal(host(y).view(np.uint16), w[rows].view(np.uint16)), 'dequantised weights must be bit exact'
+    _ffi.check(tm.tm_linear_destroy(h))
+
+
 def _residual_norm_case(tm, rng, K, N, M):
     h, (q, s, z) = _make_linear(tm, rng, K, N)
     ws = torch.zeros(max(1, tm.tm_linear_workspace(h, M)) + M * N * 2, dtype=torch.uint8, device='cuda')

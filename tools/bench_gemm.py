@@ -63,6 +63,10 @@ def main():
                 nt, waves = 1, 0x108           # round-1 default: 4 column groups x 2 k-phases, 8 waves
             elif variant == 'oldp':
                 nt, waves = 2, 8               # round-1 prefill tile: 8 waves x 2 tiles, 128-row blocks
+            elif variant == 'auto':
+                nt, waves = 0, 0               # the library's own pick (measured table, then the heuristic)
+            elif variant == 'lc':
+                waves = 0x200 | 11             # loader / consumer kernel (gemm_decode_lc.hip)
             elif variant.startswith('d'):
                 shape = int(variant[1])
                 waves = 0x200 | shape
@@ -100,7 +104,7 @@ def main():
             return float(np.median(ts)), float(ts.min())
 
         for variant in args.variants.split(','):
-            sp_list = [int(v) for v in args.splits.split(',')] if variant.startswith('d') else [0]
+            sp_list = [int(v) for v in args.splits.split(',')] if (variant.startswith('d') or variant == 'lc') else [0]
             for sp in sp_list:
                 try:
                     med, mn = run(variant, sp)
