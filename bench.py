@@ -95,7 +95,8 @@ def measure_attention_traffic(args, ctx_prof):
     `rocprofv3 --pmc FETCH_SIZE` (its own pass, no tracing domains) with the same batch / KV format, two layers, eager
     launches, and a prompt length that puts the mean context of its decode steps at `ctx_prof`.  FETCH_SIZE is corrected
     as /opt/skills/guides/MI355X_MICROARCH.md (HBM section) prescribes for gfx950: KiB -> bytes, x 2 for wide coalesced
-    streaming reads.  Returns (bytes_per_launch | None, description)."""
+    streaming reads.  Returns (attention bytes_per_launch | None, description, {bytes_per_layer, launches} of the four decode GEMMs
+    of the same pass | None)."""
     import glob
     import shutil
     import sqlite3
@@ -103,7 +104,7 @@ def measure_attention_traffic(args, ctx_prof):
     import tempfile
     prof = shutil.which('rocprofv3') or ('/opt/rocm/bin/rocprofv3' if os.path.exists('/opt/rocm/bin/rocprofv3') else None)
     if prof is None:
-        return None, 'rocprofv3 not found'
+        return None, 'rocprofv3 not found', None
     steps, warm = 6, 1
     s_child = max(64, int(round(ctx_prof - 1 - (warm + steps - 1) / 2.0)))
     tmp = tempfile.mkdtemp(prefix='tm_pmc_', dir='/tmp')
@@ -119,12 +120,22 @@ def measure_attention_traffic(args, ctx_prof):
                                       "'%decode_attention%' and counter_name = 'FETCH_SIZE'"))[0]
         db.close()
         if not n:
-            return None, 'no decode_attention dispatches in the PMC pass'
+            return None, 'no decode_attention dispatches in the PMC pass', None
         ctx_child = s_child + 1 + (warm + steps - 1) / 2.0
+        # the decode linears of the same pass: every launch of the M <= 64 GEMM kernels (the row-block templates <1, ..> / <2, ..> of
+        # gemm_dec32_kernel and the loader / consumer kernel; the prefill forwards run the <4, ..> / pre64 tiles), four per layer
+        gdb = sqlite3.connect(dbs[0])
+        gsum, gn = list(gdb.execute("select sum(value), count(*) from counters_collection where counter_name = 'FETCH_SIZE' and "
+                                    "(kernel_name like '%gemm_dec32_kernel<1,%' or kernel_name like '%gemm_dec32_kernel<2,%' "
+                                    "or kernel_name like '%gemm_dec_lc_kernel%')"))[0]
+        gdb.close()
+        gemm = None
+        if gn and gn % 4 == 0:
+            gemm = dict(bytes_per_layer=int(gsum * 1024.0 * 2.0 / (gn / 4)), launches=int(gn))
         return int(mean_kib * 1024.0 * 2.0), (f'rocprofv3 --pmc FETCH_SIZE child run of this bench ({n} launches, 2 layers, eager, mean ctx '
-                                              f'{ctx_child}): mean FETCH_SIZE {mean_kib:.0f} KiB x 1024 x 2 (gfx950 correction)')
+                                              f'{ctx_child}): mean FETCH_SIZE {mean_kib:.0f} KiB x 1024 x 2 (gfx950 correction)'), gemm
     except Exception as e:   # noqa: BLE001 -- a failed profiler pass must not take the bench line down
-        return None, f'PMC pass failed: {type(e).__name__}'
+        return None, f'PMC pass failed: {type(e).__name__}', None
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
 
@@ -157,6 +168,29 @@ class Watchdog:
                 os._exit(3)
 
 
+_JSON_FD = None
+
+
+def claim_stdout():
+    """Rank 0's stdout must carry the JSON line and nothing else, but native libraries (RCCL's version banner, rocprofv3
+    children) write to file descriptor 1 behind Python's back.  Keep a private duplicate of the real stdout for the result and
+    point fd 1 at stderr for everybody else."""
+    global _JSON_FD
+    if _JSON_FD is None:
+        sys.stdout.flush()
+        _JSON_FD = os.dup(1)
+        os.dup2(2, 1)
+
+
+def emit_json(obj):
+    data = (json.dumps(obj) + '\n').encode()
+    if _JSON_FD is None:
+        sys.stdout.write(data.decode())
+        sys.stdout.flush()
+    else:
+        os.write(_JSON_FD, data)
+
+
 def main():
     # multi-process GPU work on this pool needs dmabuf IPC (RCCL's P2P setup fails with the legacy mode:
     # "hipIpcGetMemHandle: invalid argument"); already exported on the driver's boxes, kept here for hand launches
@@ -179,6 +213,9 @@ def main():
     ap.add_argument('--no-traffic', action='store_true', help='skip the rocprofv3 --pmc FETCH_SIZE child run (roofline.traffic = null)')
     ap.add_argument('--no-full-run', action='store_true', help='skip the continuation to 1024 generated tokens (value_full_run)')
     ap.add_argument('--traffic-child', action='store_true', help=argparse.SUPPRESS)
+    ap.add_argument('--allow-shared-devices', action='store_true',
+                    help='let several ranks share one GPU when the box has fewer GPUs than --gpus (launcher / bring-up tests only: the '
+                         'record then says so and is not a scaling result)')
     ap.add_argument('--emulate-tp', type=int, default=0,
                     help='SURVEY 8(e) on a 1-GPU box: run ONE rank\'s shard of a TP=N job (heads / inter / vocab divided by N, '
                          'collectives through a 1-rank RCCL communicator): per-rank kernel time only, labelled as such')
@@ -188,6 +225,7 @@ def main():
         # reference starts all ranks of a node from one call too: lmdeploy/turbomind/turbomind.py:191-217)
         sys.exit(self_launch(args.gpus))
 
+    claim_stdout()
     import torch
     import torch.distributed as dist
     from lmdeploy_amd.turbomind.engine import Engine
@@ -199,7 +237,15 @@ def main():
         sys.exit(f'bench.py: --gpus {args.gpus} but the launcher set WORLD_SIZE={world}')
     # one GPU per rank; on a box with fewer GPUs than ranks (the 1-GPU test box: `--gpus 2` exercises the launcher, the RCCL
     # bring-up failure -> native communicator fall-back and the tuning-table broadcast) ranks share devices
-    local_dev = local_rank % max(1, torch.cuda.device_count())
+    ndev = max(1, torch.cuda.device_count())
+    ranks_per_device = (world + ndev - 1) // ndev
+    if ranks_per_device > 1:
+        if not args.allow_shared_devices:
+            sys.exit(f'bench.py: --gpus {world} on a box with {ndev} GPU(s): ranks would share devices, which is not a scaling measurement; '
+                     f'pass --allow-shared-devices for a launcher / bring-up test')
+        # co-located ranks: the two-shot all-reduce's persistent grids must fit on the device TOGETHER
+        os.environ.setdefault('TM_P2P_2SHOT_GRID', str(max(8, 256 // ranks_per_device // 2)))
+    local_dev = local_rank % ndev
     torch.cuda.set_device(local_dev)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
@@ -350,7 +396,7 @@ def main():
     if weight_type == 0 and not model.get('moe_experts') and B <= 256:
         for name, (kk, nn) in dict(w_qkv=(H_, (hq_l + 2 * hkv_l) * D_), wo=(hq_l * D_, H_), w1w3=(H_, 2 * I_l), w2=(I_l, H_)).items():
             tilings[name] = dict(zip(('shape', 'splits'), Engine.pick_tiling(kk, nn, B)))
-            # shape 10 = dequantise + hipBLASLt fp16 GEMM (gemm_f16_library.hip), 4 / 5 = the fused 128-row W4A16 tiles
+            # 4 / 5 = the fused 128-row W4A16 tiles, 12 = the 256 x 256 tile with the dequant through LDS (gemm_prefill.hip)
             prefill_tilings[name] = dict(zip(('shape', 'splits'), Engine.pick_tiling(kk, nn, pf_rows)))
     if weight_type != 0 or model.get('moe_experts'):
         # formats other than AWQ u4 / MoE: the weight bytes are what the engine actually streams (packed weights + scales +
@@ -360,8 +406,11 @@ def main():
     if rank == 0:
         ms_step = dt / K * 1e3
         value = B * K / dt
+        kv_name = {0: 'fp16-KV', 4: 'int4-KV', 8: 'int8-KV'}.get(args.quant_policy, f'quant_policy={args.quant_policy}')
+        headline = args.model == 'llama3_8b' and args.quant_policy == 8 and B == 64 and S == 1024 and not args.layers
         out = {
-            'metric': 'decode tokens/sec, Llama-3-8B W4A16 int8-KV batch 64 (1k-in/1k-out synthetic)',
+            'metric': f'decode tokens/sec, Llama-3-8B W4A16 {kv_name} batch {B} ({S}-in/1k-out synthetic)'
+                      + ('' if headline else ' (NOT the headline config)'),
             'value': round(value, 1), 'unit': 'tokens/s', 'n_gpus': world, 'steps': K, 'warmup': W,
             'ms_per_step': round(ms_step, 4), 'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None,
             'dtype': 'f16', 'data': 'synthetic',
@@ -381,12 +430,16 @@ def main():
         }
         if comm_note:
             out['config']['collectives_note'] = comm_note
+        if ranks_per_device > 1:
+            out['config']['devices_shared'] = True
+            out['config']['ranks_per_device'] = ranks_per_device
+            out['metric'] += ' -- RANKS SHARE A DEVICE: launcher / bring-up test, not a multi-GPU result'
         if world > 1 or emu > 1:
             out['scaling_note'] = ('no 1 -> 8 GPU scaling curve of this engine has been measured on hardware before this run: the tensor-parallel '
                                    'path was validated on one device only (two processes on one GPU over the native communicator, 1-rank RCCL, '
                                    'gloo world-size-2 CPU tests)')
         if args.model != 'llama3_8b':
-            out['metric'] = f'decode tokens/sec, {args.model} W4A16 quant_policy={args.quant_policy} batch {B} (NOT the headline config)'
+            out['metric'] = f'decode tokens/sec, {args.model} W4A16 {kv_name} batch {B} (NOT the headline config)'
             out['config']['workload'] = out['config']['workload'].replace('Llama-3-8B', args.model)
         if emu > 1:
             out['metric'] = (f'PER-RANK EMULATION of TP={emu} on one GPU (one rank\'s shard, 1-rank collectives): '
@@ -398,9 +451,9 @@ def main():
             per_launch_s = attn_ms / 1e3 / max(model['layers'], 1)          # attention (+ split-K merge) of one layer
             ach = per_launch_bytes / per_launch_s / 1e9
             # HBM bytes per launch: measured in THIS run by a rocprofv3 --pmc FETCH_SIZE child pass (null if unavailable)
-            traffic, traffic_src = None, 'skipped'
+            traffic, traffic_src, gemm_traffic = None, 'skipped', None
             if not args.no_traffic and not child and world == 1:
-                traffic, traffic_src = measure_attention_traffic(args, ctx_prof)
+                traffic, traffic_src, gemm_traffic = measure_attention_traffic(args, ctx_prof)
             attn_kernel = {8: 'decode_attention_i8_mfma_kernel<fused, 8>', 4: 'decode_attention_i8_mfma_kernel<fused, 4> (int4 codes expanded to '
                            'bytes on the way into LDS)'}.get(args.quant_policy, 'decode_attention_kernel<16> (fp16 KV, VALU)')
             out['roofline'] = {'bound': 'hbm', 'kernel': attn_kernel,
@@ -415,7 +468,15 @@ def main():
                                     'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
                                     'frac': round(wbytes / (gemm_ms / 1e3) / 1e9 / HBM_PEAK_GBPS, 4),
                                     'bytes_per_step': int(wbytes)}
+            if gemm_traffic:
+                # HBM-side bytes of the four decode GEMM launches of one layer (same child PMC pass as roofline.traffic) against the
+                # algorithmic weight bytes of a layer: > 1 would mean weights fetched more than once
+                alg = wbytes / model['layers']
+                out['roofline_gemm_traffic'] = {'bytes_per_layer': gemm_traffic['bytes_per_layer'], 'algorithmic_bytes_per_layer': int(alg),
+                                                'ratio': round(gemm_traffic['bytes_per_layer'] / alg, 4), 'launches': gemm_traffic['launches'],
+                                                'source': 'FETCH_SIZE x 1024 x 2 of the M <= 64 GEMM dispatches in the child PMC pass'}
         if full is not None:
+            out['value_1k_out'] = full['value']      # the metric-faithful rate: all 1024 generated tokens of the batch
             out['value_full_run'] = full
             out['value_full_run']['step_roofline_frac'] = round(
                 algorithmic_bytes(model, B, (full['ctx_first'] + full['ctx_last']) / 2.0, kv_bits, world)[0] / (full['ms_per_step'] / 1e3) / 1e9
@@ -424,11 +485,9 @@ def main():
             from oracle import cpu_baseline
             out['cpu_baseline'] = cpu_baseline.run(model, B, S, sample_layers=2)
         out['sample_tokens'] = toks[0, :4].tolist()
-        # RCCL prints a version banner through C stdio (fully buffered on a pipe): push it out first so that the JSON
-        # line is the LAST line of stdout
         import ctypes
-        ctypes.CDLL(None).fflush(None)
-        print(json.dumps(out), flush=True)
+        ctypes.CDLL(None).fflush(None)     # whatever C stdio still buffers goes to stderr (claim_stdout), the JSON line alone to stdout
+        emit_json(out)
     eng.close()
     if world > 1:
         dist.destroy_process_group()

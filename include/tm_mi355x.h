@@ -169,23 +169,18 @@ int tm_linear_prepare(tm_linear* w, const void* weight, const void* scales, cons
 size_t tm_linear_workspace(const tm_linear* w, int M);
 int    tm_linear_forward(const tm_linear* w, const void* x, int ldx, void* y, int ldy, int M, int gated_silu,
                          int nt, int splits, int waves, void* workspace, tm_stream_t st);
-/* Prefill-sized forwards (M >= 512) of a dense u4 linear as "dequantise + the vendor library's fp16 GEMM" -- the large-batch
- * end of gemm::Gemm::Run (src/turbomind/kernels/gemm/gemm.cu:257-344).  tm_linear_forward takes it as waves = 0x200 + 10, or
- * by dispatch (measured table, else from 2048 rows -- 1024 with a resident image) when a workspace of tm_linear_workspace()
- * bytes is passed and tm_f16_library_available() (hipBLASLt loadable in this process, TM_GEMM_F16_LIBRARY != 0).
- * tm_linear_dequant_f16: the fp16 image [N][K] of the weights, bit for bit the operand the fused kernels build in registers
- * (w = h(fma(h(q), s, h(-z*s))), kernels/gemm/transform.h:34-74).  tm_linear_build_f16_image keeps that image in HBM next to
- * the u4 image, so that the per-call dequantisation pass disappears (2 bytes per weight: MI355X has the memory). */
-int    tm_f16_library_available(void);
+/* tm_linear_dequant_f16: the fp16 image [N][K] of the weights, bit for bit the operand the W4A16 kernels build on chip
+ * (w = h(fma(h(q), s, h(-z*s))), kernels/gemm/transform.h:34-74) -- what the reference's own tests call quant_vs_dequant
+ * (tests/turbomind/linear/fixture.py:404-507).  (Round 3 also exported tm_f16_library_available / tm_linear_build_f16_image:
+ * prefill-sized forwards through a vendor fp16 GEMM on that image -- removed in round 4, every GEMM of this library is its own.) */
 int    tm_linear_dequant_f16(const tm_linear* w, void* out_nk, tm_stream_t st);
-int    tm_linear_build_f16_image(tm_linear* w, tm_stream_t st);
 /* Row-parallel linear closed by residual + RMSNorm -- wo / w2 of a decoder layer at the decode batch: LlamaLinear::Forward
  * followed by invokeResidualBiasRMSNorm (src/turbomind/models/llama/unified_decoder.cc:149,226; kernels/norm/rms_norm.cu:286-362):
  *   resid += fp16(x . W);  y = RMSNorm(resid) * norm_w.
- * fused != 0: split-K reduce + residual + norm run INSIDE the GEMM launch (its last workgroups consume the slabs; needs
- * M <= 64, u4 weights, N % 32 == 0, N <= 8192 and `sync` = 4 zeroed device words, left zero by the call; sync[2] != 0 afterwards
- * means a hand-off wait gave up).  fused == 0: the GEMM, then the reduce-norm kernel -- the same bits.
- * shape: decode tile 0..3 / 6..9, -1 = dispatch; splits: 0 = dispatch.  workspace >= tm_linear_workspace(w, M) + M * N * 2 bytes. */
+ * The GEMM (fp32 split-K slabs when it splits), then the reduce-norm kernel.  `fused` must be 0 and `sync` is ignored: round 3's
+ * in-launch consumer (the GEMM's last workgroups ran the norm) was bit-identical but slower than the kernel boundary it replaced
+ * and was removed in round 4 (TM_INVALID for fused != 0).
+ * shape: decode tile 0..3 / 6..9 / 11, -1 = dispatch; splits: 0 = dispatch.  workspace >= tm_linear_workspace(w, M) + M * N * 2 bytes. */
 int    tm_linear_residual_norm(const tm_linear* w, const void* x, int ldx, void* y, void* resid, const void* norm_w, float eps, int M,
                                int shape, int splits, int fused, void* workspace, void* sync, tm_stream_t st);
 /* FP8 x FP8 linear on the fp8 matrix cores -- the reference's path for e4m3 weights on fp8 tensor cores:
@@ -264,9 +259,9 @@ int tm_p2p_allreduce_norm_2shot(void* const* segs, int tp, int me, void* state, 
 int tm_debug_set_gemm_trace(void* dev_buf);
 /* Host-only: the (workgroup shape, split-K) the decode GEMM dispatch picks for a W4A16 linear of K x N at M rows --
  * use_table bit 0: the measured table first (tm_engine_tune_gemm / tm_gemm_import), then the heuristic; clear: heuristic only.
- * Bit 1: leave the library path out (what a caller without its workspace gets).
  * Shapes: 0..3 decode tiles (M <= 64), 4 / 5 the 128-row tiles (M > 64), 6..9 shapes 3, 0, 2, 1 on 32-row blocks
- * (gemm_decode.hip), 10 dequantise + the vendor library's fp16 GEMM (gemm_f16_library.hip; prefill-sized forwards). */
+ * (gemm_decode.hip), 11 the loader / consumer decode kernel (gemm_decode_lc.hip, M <= 64), 12 the 256 x 256 prefill tile with
+ * the weights dequantised once per workgroup tile through LDS (gemm_prefill.hip, M > 64).  (10 was a vendor-library path: gone.) */
 int tm_debug_pick_tiling(int K, int N, int M, int use_table, int* shape, int* splits);
 /* Host-only: every (shape, splits) pair the start-up tuner (tm_engine_tune_gemm; gemm::Gemm::Run's dispatch candidates,
  * src/turbomind/kernels/gemm/gemm.cu:92-224) may pick for a K x N linear at M rows; *count = how many exist (<= 128), the first

@@ -106,9 +106,7 @@ _SIGNATURES = {
     'tm_linear_workspace': (c_size_t, [c_void_p, c_int]),
     'tm_linear_forward': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
                                   c_void_p, c_void_p]),
-    'tm_f16_library_available': (c_int, []),
     'tm_linear_dequant_f16': (c_int, [c_void_p, c_void_p, c_void_p]),
-    'tm_linear_build_f16_image': (c_int, [c_void_p, c_void_p]),
     'tm_linear_residual_norm': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_float, c_int, c_int, c_int, c_int,
                                         c_void_p, c_void_p, c_void_p]),
     'tm_linear_destroy': (c_int, [c_void_p]),

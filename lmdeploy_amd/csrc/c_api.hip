@@ -278,16 +278,7 @@ size_t tm_linear_workspace(const tm_linear* w, int M)
     if (!w) {
         return 0;
     }
-    size_t b = gemm_workspace_bytes(M, w->w.N, 16);
-    if (M >= kF16LibraryMinM && dec32_supported(w->w, M) && f16_library_available()) {  // either gated or not, either image
-        b = std::max(b, f16_library_workspace_bytes(w->w.K, w->w.N, M, true, false));
-    }
-    return b;
-}
-
-int tm_f16_library_available(void)
-{
-    return f16_library_available() ? 1 : 0;
+    return gemm_workspace_bytes(M, w->w.N, 16);
 }
 
 int tm_linear_dequant_f16(const tm_linear* w, void* out_nk, tm_stream_t st)
@@ -296,18 +287,12 @@ int tm_linear_dequant_f16(const tm_linear* w, void* out_nk, tm_stream_t st)
     return launch_dequant_p32_f16((half_t*)out_nk, w->w, (hipStream_t)st);
 }
 
-int tm_linear_build_f16_image(tm_linear* w, tm_stream_t st)
-{
-    TM_REQUIRE(w, "null pointer");
-    TM_REQUIRE(w->w.type == 0 && w->w.packed32 != nullptr, "fp16 image: a prepared u4 linear with N % 32 == 0");
-    return linear_weight_build_f16_image(w->w, (hipStream_t)st);
-}
 
 int tm_linear_forward(const tm_linear* w, const void* x, int ldx, void* y, int ldy, int M, int gated_silu, int nt,
                       int splits, int waves, void* workspace, tm_stream_t st)
 {
     TM_REQUIRE(w && x && y, "null pointer");
-    GemmConfig cfg = gemm_pick_config(w->w, M, workspace != nullptr);  // (workspace: tm_linear_workspace(w, M) bytes)
+    GemmConfig cfg = gemm_pick_config(w->w, M);  // (workspace: tm_linear_workspace(w, M) bytes)
     if (nt > 0) {
         cfg.nt = nt;
     }
@@ -325,15 +310,9 @@ int tm_linear_forward(const tm_linear* w, const void* x, int ldx, void* y, int l
         TM_REQUIRE(dec32_supported(w->w, M), "decode kernel: u4 weights, N % 32 == 0");
         cfg.d32_shape = waves & 0xff;
         TM_REQUIRE((cfg.d32_shape >= 6 && cfg.d32_shape <= 9) || (cfg.d32_shape <= 5 && (cfg.d32_shape >= 4) == (M > 64))
-                       || (cfg.d32_shape == kShapeLC && M <= 64)
-                       || (cfg.d32_shape == kShapeF16Library && M >= kF16LibraryMinM && workspace),
-                   "decode kernel shape 0..3 / 11 (M <= 64), 4 / 5 (M > 64), 6..9 (32-row blocks, any M) or 10 (library GEMM, M >= 512)");
+                       || (cfg.d32_shape == kShapeLC && M <= 64) || (cfg.d32_shape == kShapePre256 && M > 64),
+                   "P32 kernel shape 0..3 / 11 (M <= 64), 4 / 5 / 12 (M > 64) or 6..9 (32-row blocks, any M)");
         waves = 0;
-    }
-    if (cfg.d32_shape == kShapeF16Library) {
-        cfg.splits       = 1;
-        cfg.lib_ws       = workspace;
-        cfg.lib_ws_bytes = tm_linear_workspace(w, M);
     }
     if (waves > 0) {
         // waves per workgroup (4 | 8); + 0x100 = split K two ways INSIDE the workgroup (8 waves only)
@@ -357,19 +336,18 @@ int tm_linear_residual_norm(const tm_linear* w, const void* x, int ldx, void* y,
     const int N = w->w.N;
     GemmConfig cfg = gemm_pick_config(w->w, M);
     if (shape >= 0) {
-        TM_REQUIRE(dec32_supported(w->w, M) && (shape <= 3 || (shape >= 6 && shape <= 9)) && M <= 64, "decode tile 0..3 / 6..9, M <= 64");
+        TM_REQUIRE(dec32_supported(w->w, M) && (shape <= 3 || (shape >= 6 && shape <= 9) || shape == kShapeLC) && M <= 64,
+                   "decode tile 0..3 / 6..9 / 11, M <= 64");
         cfg.d32_shape = shape;
     }
     if (splits > 0) {
         cfg.splits = splits;
     }
     TM_REQUIRE(cfg.splits <= 16, "splits <= 16");
-    if (fused) {
-        TM_REQUIRE(sync != nullptr && cfg.d32_shape >= 0 && dec32_tail_supported(w->w, M),
-                   "fused residual-norm: u4 decode kernel, M <= 64, N % 32 == 0, 4 zeroed sync words");
-        NormTail tail{(half_t*)y, (half_t*)resid, (const half_t*)norm_w, eps, (unsigned*)sync};
-        return launch_linear(w->w, (const half_t*)x, ldx, nullptr, N, M, false, cfg, (float*)workspace, true, nullptr, (hipStream_t)st, &tail);
-    }
+    // fused != 0 was the in-launch consumer of round 3 (the GEMM's last workgroups ran the norm): parity-green but 2.8 us SLOWER per
+    // instance than the kernel boundary it replaced (profiles/r03_gemm_tail_trace.txt) -- removed in round 4
+    TM_REQUIRE(!fused, "the in-launch residual-norm consumer was removed (round 4): pass fused = 0");
+    (void)sync;
     // unfused: slabs (or, with one slice, the fp16 product parked at the end of the workspace) + the reduce-norm kernel
     int     slabs = 1;
     half_t* tmp   = (half_t*)((char*)workspace + gemm_workspace_bytes(M, N, 16));
@@ -759,7 +737,7 @@ int tm_debug_pick_tiling(int K, int N, int M, int use_table, int* shape, int* sp
     LinearWeight w{};
     w.K = K;
     w.N = N;
-    dec32_pick_ex(w, M, shape, splits, (use_table & 1) != 0, (use_table & 2) == 0);
+    dec32_pick_ex(w, M, shape, splits, (use_table & 1) != 0);
     return 0;
 }
 

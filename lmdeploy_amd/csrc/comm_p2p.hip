@@ -24,8 +24,9 @@
 // buffer (c & 1) -- by the time this rank overwrites that buffer (step 0 of call c+2) nobody reads it any more.
 // p2p_allgather_kernel runs the same steps 0-2 and 4 around a copy of every rank's n bytes (the lm_head's (value, index)
 // candidates); every rank issues the same sequence of calls, so both kernels share the epoch counter.
-// Every spin is bounded: on a timeout the kernel records the epoch in state[3] and carries on (wrong numbers, no hang); the
-// engine reads state[3] at its host synchronisation points and fails the step (engine.hip: device_marks_check).
+// Every spin is bounded (TM_P2P_TIMEOUT_MS, default 30 s): on a timeout the kernel records the epoch in state[3] and carries on
+// (wrong numbers, no hang); the engine reads state[3] at its host synchronisation points, fails the step and refuses further
+// work until it is recreated (engine.hip: device_marks_check).
 //
 // Status: protocol and arithmetic run on ONE GPU only in this round -- tests/test_gpu_p2p.py (tp ranks = tp streams, and tp
 // PROCESSES that map each other's segments through IPC handles) and tests/test_gpu_tp.py (a tp = 2 engine as two processes
@@ -59,12 +60,28 @@ struct P2pParams {
     uint32_t*       dst;    // all-gather: rank q's n words land at dst + q * dst_stride
     int             n;
     size_t          dst_stride;
+    uint64_t        timeout;  // bound of a peer wait in 100 MHz ticks (p2p_timeout_ticks)
 };
 
-constexpr uint32_t kSpinLimit = 1u << 20;  // ~1 s of polling
+// Wait bound of a peer flag, in ticks of the 100 MHz realtime counter.  TM_P2P_TIMEOUT_MS, default 30 s (read once): RCCL has no
+// bound at all, and ranks are host-driven one by one -- graph capture, a first-use code load or a descheduled host thread on ONE
+// rank must not end the job (the former bound was ~1 s of polling).  On expiry: state[3] = the epoch, the engine
+// fails the step and refuses further work (engine.hip: device_marks_check).
+static uint64_t p2p_timeout_ticks()
+{
+    static const uint64_t t = [] {
+        const char* v  = getenv("TM_P2P_TIMEOUT_MS");
+        const long  ms = v ? atol(v) : 30000;
+        return (uint64_t)(ms < 1 ? 1 : ms) * 100000ull;
+    }();
+    return t;
+}
 
-// steps 1 + 2; the caller's writes into its own segment buffer precede (a __syncthreads in between)
-__device__ __forceinline__ void p2p_publish_and_wait(const P2pParams& p, uint32_t epoch)
+// steps 1 + 2; the caller's writes into its own segment buffer precede (a __syncthreads in between).  `phase` = how many syncs of
+// THIS launch came before: the entry tickets (state[1]) run monotonically through a launch -- sync k publishes at ticket
+// (k + 1) * gridDim.x - 1 -- and are reset by p2p_exit only, when every workgroup is past its last sync (a reset
+// between two syncs of one launch could wipe an early ticket of the second).
+__device__ __forceinline__ void p2p_publish_and_wait(const P2pParams& p, uint32_t epoch, uint32_t phase = 0)
 {
     const int tid = threadIdx.x;
     // every storing wave drains its own stores before the one release below can cover them (cdna_hip_programming.md Guideline
@@ -75,20 +92,20 @@ __device__ __forceinline__ void p2p_publish_and_wait(const P2pParams& p, uint32_
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");  // system scope: this XCD's dirty lines of the tile leave the L2
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const uint32_t t = __hip_atomic_fetch_add(p.state + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (t == gridDim.x - 1) {  // every workgroup (hence every XCD that ran one) has written back
-            __hip_atomic_store(p.state + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (t == (phase + 1) * gridDim.x - 1) {  // every workgroup (hence every XCD that ran one) has written back
             for (int r = 0; r < p.tp; ++r) {
                 __hip_atomic_store(p.flags[r] + p.me, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             }
         }
     }
     if (tid < p.tp) {
-        uint32_t spins = 0;
+        const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
+        uint32_t       spins = 0;
         // ">= epoch" (wrap-safe), not "== epoch": a peer that has already left this call may have published the NEXT epoch
         // before this workgroup got to look (it can be one call ahead, never two: see the reuse argument in the header)
         while ((int32_t)(__hip_atomic_load(p.flags[p.me] + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - epoch) < 0) {
             __builtin_amdgcn_s_sleep(2);
-            if (++spins > kSpinLimit) {
+            if ((++spins & 63u) == 0 && __builtin_amdgcn_s_memrealtime() - t0 > p.timeout) {
                 __hip_atomic_store(p.state + 3, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 break;
             }
@@ -104,6 +121,7 @@ __device__ __forceinline__ void p2p_exit(const P2pParams& p, uint32_t epoch)
     if (threadIdx.x == 0) {
         const uint32_t t = __hip_atomic_fetch_add(p.state + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (t == gridDim.x - 1) {
+            __hip_atomic_store(p.state + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // entry tickets of this launch's syncs
             __hip_atomic_store(p.state + 2, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(p.state, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
@@ -302,7 +320,7 @@ __global__ __launch_bounds__(512) void p2p_allreduce_norm_2shot_kernel(P2pParams
             }
         }
     }
-    p2p_publish_and_wait(p, epoch + 1);
+    p2p_publish_and_wait(p, epoch + 1, 1);
     // ---- 2. the other slices' normed rows: own out2 -> y --------------------------------------------------------------------------------
     for (int row = blockIdx.x; row < p.M; row += gridDim.x) {
         if (row >= r0 && row < r1) {
@@ -335,6 +353,7 @@ int launch_p2p_allreduce_norm_2shot(half_t* const* in2, half_t* const* out2, uin
         p.flags[r] = flags[r];
     }
     p.tp = tp, p.me = me, p.state = state, p.partial = partial, p.y = y, p.resid = resid, p.weight = weight;
+    p.timeout = p2p_timeout_ticks();
     p.eps = eps, p.M = M, p.H = H;
     p.slice        = (M + tp - 1) / tp;
     const int nvec = H / 8;
@@ -425,6 +444,7 @@ int launch_p2p_allreduce_norm(half_t* const* data, uint32_t* const* flags, int t
         p.flags[r] = flags[r];
     }
     p.tp = tp, p.me = me, p.state = state, p.tile = tile, p.partial = partial, p.y = y, p.resid = resid, p.weight = weight;
+    p.timeout = p2p_timeout_ticks();
     p.eps = eps, p.M = M, p.H = H;
     const int nvec = H / 8;
     int       t    = (nvec + 63) / 64 * 64;
@@ -458,6 +478,7 @@ int launch_p2p_allgather(half_t* const* data, uint32_t* const* flags, int tp, in
         p.flags[r] = flags[r];
     }
     p.tp = tp, p.me = me, p.state = state, p.tile = tile, p.src = (const uint32_t*)src, p.dst = (uint32_t*)dst, p.n = words;
+    p.timeout = p2p_timeout_ticks();
     p.dst_stride = dst_stride_words ? dst_stride_words : (size_t)words;
     p2p_allgather_kernel<<<1, 256, 0, st>>>(p);
     TM_HIP_CHECK(hipGetLastError());

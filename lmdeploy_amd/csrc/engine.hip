@@ -258,22 +258,8 @@ struct tm_engine {
     half_t* d_last   = nullptr;
     float*  d_gemm_ws = nullptr;
     size_t  gemm_ws_bytes = 0;
-    // TM_GEMM_TAIL=1: wo / w2 of a decode step close with the in-launch residual-norm consumer (gemm_decode.hip).  Measured on
-    // MI355X (tools/trace_tail.py, profiles/r03_gemm_tail_trace.txt): correct and bit-identical, but SLOWER than the reduce-norm
-    // kernel it replaces -- wo 13.6 vs 10.8 us, w2 20.3 vs 18.5 us per (GEMM + norm) period, 3.39 vs 3.27 ms per step: the
-    // last workgroup's store drain + ticket (3.1 us) and the consumer's slab round trip (2.7 us) cost more than two kernel
-    // boundaries (1.2 us each here) plus a 2 us kernel.  Default off.
-    bool      gemm_tail = false;
-    // Prefill-sized forwards of the dense u4 linears through dequantise + the vendor library's fp16 GEMM
-    // (gemm_f16_library.hip): its scratch (library workspace | fp16 image of one linear | gated intermediate), nullptr when the
-    // library is not loadable / switched off.  f16_resident (TM_PREFILL_F16_RESIDENT=1): every dense u4 linear also keeps its
-    // fp16 [N][K] image in HBM (2 bytes per weight next to the 0.53 of the u4 image) and the per-call dequant pass disappears.
-    void*     d_lib_ws     = nullptr;
-    size_t    lib_ws_bytes = 0;
-    bool      f16_resident = false;
-    bool      f16_resident_auto = false;  // env unset: resident when the images take <= 8 % of the device's memory
-    unsigned  h_marks[2] = {0, 0};    // host copies of the device give-up marks (device_marks_fetch)
-    unsigned* d_tail_sync = nullptr;  // 4 words: hand-off state of the in-launch residual-norm consumer (gemm_decode.hip), zero between launches
+    unsigned  h_mark = 0;             // host copy of the native communicator's give-up mark (device_marks_fetch)
+    bool      comm_failed = false;    // a give-up mark was seen: the ranks' call sequences may have diverged (sticky, see device_marks_check)
     float*  d_attn_ws = nullptr;
     half_t *d_kflat = nullptr, *d_vflat = nullptr;
     int     kflat_stride = 0;
@@ -441,9 +427,6 @@ static int prepare_linear(tm_engine* e, LinearSlots& l)
         // gemm_kernel and keep the 16-column image as well
         const bool p32_only = l.prefix.find(".experts.") == std::string::npos && dec32_serves_every_m(l.w.K, l.w.N);
         TM_TRY(linear_weight_prepare_u4(l.w, (const int32_t*)q.dev, (const half_t*)s.dev, (const half_t*)z.dev, e->stream, p32_only));
-        if (p32_only && e->f16_resident && e->cfg.max_prefill_token_num >= kF16LibraryMinM && f16_library_available()) {
-            TM_TRY(linear_weight_build_f16_image(l.w, e->stream));
-        }
         TM_HIP_CHECK(hipStreamSynchronize(e->stream));
         for (Slot* p : {&q, &s, &z}) {
             TM_HIP_CHECK(hipFree(p->dev));
@@ -576,21 +559,9 @@ static int reduce_residual_norm(tm_engine* e, int M, const half_t* norm_w)
     return 0;
 }
 
-// gemm_pick_config + the engine's scratch for the library path (prefill-sized forwards); without scratch of the needed size
-// the fused tiles
-static GemmConfig pick_config(tm_engine* e, const LinearWeight& w, int M, bool gated)
+static GemmConfig pick_config(tm_engine*, const LinearWeight& w, int M, bool)
 {
-    GemmConfig cfg = gemm_pick_config(w, M, e->d_lib_ws != nullptr);
-    if (cfg.d32_shape == kShapeF16Library) {
-        if (f16_library_workspace_bytes(w.K, w.N, M, gated, w.f16_nk != nullptr) <= e->lib_ws_bytes) {
-            cfg.lib_ws       = e->d_lib_ws;
-            cfg.lib_ws_bytes = e->lib_ws_bytes;
-        }
-        else {
-            cfg = gemm_pick_config(w, M, false);
-        }
-    }
-    return cfg;
+    return gemm_pick_config(w, M);
 }
 
 // row-parallel linear followed by (all-reduce +) residual + RMSNorm
@@ -602,14 +573,6 @@ static int linear_residual_norm(tm_engine* e, LinearSlots& l, const half_t* x, i
                            && gemm_workspace_bytes(M, l.w.N, cfg.splits) <= e->gemm_ws_bytes;
     if (gemm_workspace_bytes(M, l.w.N, cfg.splits) > e->gemm_ws_bytes) {
         cfg.splits = 1;
-    }
-    // decode batch on one GPU: the split-K reduce + residual + RMSNorm run inside the GEMM launch (its last workgroups consume
-    // the slabs) -- one launch instead of two, no dirty-slab write-back in front of a kernel boundary
-    if (e->gemm_tail && !e->use_comm && cfg.d32_shape >= 0 && l.w.N == e->hidden && dec32_tail_supported(l.w, M)
-        && gemm_workspace_bytes(M, l.w.N, std::max(cfg.splits, 2)) <= e->gemm_ws_bytes) {
-        NormTail tail{e->d_x, e->d_resid, norm_w, e->cfg.model.rms_eps, e->d_tail_sync};
-        TM_PROF(gemm_cat, TM_TRY(launch_linear(l.w, x, ldx, nullptr, e->hidden, M, false, cfg, e->d_gemm_ws, true, nullptr, e->stream, &tail)));
-        return 0;
     }
     int slabs = 1;
     TM_PROF(gemm_cat, TM_TRY(launch_linear(l.w, x, ldx, e->d_tmp, e->hidden, M, false, cfg, e->d_gemm_ws, can_defer, &slabs,
@@ -877,40 +840,37 @@ static int forward(tm_engine* e, const int* d_ids, int M, int nseq, bool decode,
     return head(e->d_last, nseq, slot0, d_ids + nd, e->d_cu_q, M - nd, e->d_k_len);
 }
 
-// Device-side give-up marks -- bounded waits that expired: the in-launch residual-norm consumer of the decode GEMMs
-// (d_tail_sync[2]) and the native P2P communicator (p2p_state[3] = the call number a peer missed; comm_p2p.hip carries on with
-// wrong numbers instead of hanging).  Read at the host's synchronisation points: what ran before them is then reported as
-// TM_FAIL instead of being returned as tokens.  `async`: enqueue the two copies on the engine stream (the caller syncs).
+// Device-side give-up mark of the native P2P communicator: a bounded wait for a peer expired (p2p_state[3] = the call number a
+// peer missed; comm_p2p.hip carries on with wrong numbers instead of hanging).  Read at the host's synchronisation points.
+// `async`: enqueue the copy on the engine stream (the caller syncs).
 static int device_marks_fetch(tm_engine* e, bool async)
 {
-    if (e->d_tail_sync) {
-        if (async) {
-            TM_HIP_CHECK(hipMemcpyAsync(&e->h_marks[0], e->d_tail_sync + 2, 4, hipMemcpyDeviceToHost, e->stream));
-        }
-        else {
-            TM_HIP_CHECK(hipMemcpy(&e->h_marks[0], e->d_tail_sync + 2, 4, hipMemcpyDeviceToHost));
-        }
-    }
     if (e->p2p_state) {
         if (async) {
-            TM_HIP_CHECK(hipMemcpyAsync(&e->h_marks[1], e->p2p_state + 3, 4, hipMemcpyDeviceToHost, e->stream));
+            TM_HIP_CHECK(hipMemcpyAsync(&e->h_mark, e->p2p_state + 3, 4, hipMemcpyDeviceToHost, e->stream));
         }
         else {
-            TM_HIP_CHECK(hipMemcpy(&e->h_marks[1], e->p2p_state + 3, 4, hipMemcpyDeviceToHost));
+            TM_HIP_CHECK(hipMemcpy(&e->h_mark, e->p2p_state + 3, 4, hipMemcpyDeviceToHost));
         }
     }
     return 0;
 }
 
+// A mark means: this rank stopped waiting for a peer in collective call `h_mark` and continued with whatever the peer's buffer
+// held.  What was computed from that call on is invalid on THIS rank, and the ranks may no longer agree on the call sequence
+// (a late peer is still inside the call this rank left), so the condition is terminal for the communicator: the step fails with
+// TM_FAIL, the serve loop ends the requests in flight with kFail, and every later step / submit fails with the same status until the engine is
+// recreated (tm_engine_destroy + tm_engine_create on every rank).  Tokens fetched BEFORE the failing step stay readable
+// (tm_engine_fetch does not check the mark).  The wait bound is TM_P2P_TIMEOUT_MS (default 30 s: RCCL has no bound at all; a
+// one-sided stall -- graph capture, a first-use library load, a descheduled host thread -- must not kill the job).
 static int device_marks_check(tm_engine* e)
 {
-    if (e->h_marks[0]) {
-        set_last_error("decode GEMM: the in-launch residual-norm hand-off gave up waiting (results are invalid)");
-        return TM_FAIL;
+    if (e->h_mark) {
+        e->comm_failed = true;
     }
-    if (e->h_marks[1]) {
-        set_last_error("native communicator: a peer did not arrive within the wait bound (call " + std::to_string(e->h_marks[1])
-                       + "); results are invalid");
+    if (e->comm_failed) {
+        set_last_error("native communicator: a peer did not arrive within TM_P2P_TIMEOUT_MS (call " + std::to_string(e->h_mark)
+                       + "); results from that call on are invalid and the ranks may have diverged: recreate the engine on every rank");
         return TM_FAIL;
     }
     return 0;
@@ -975,9 +935,6 @@ int tm_engine_create(tm_engine** out, const tm_engine_config* c)
         const char* ms    = getenv("TM_MIXED_STEP");
         const char* gc    = getenv("TM_GRAPH_COMM");
         e->mixed_steps_on = !(ms && !atoi(ms));
-        const char* fr    = getenv("TM_PREFILL_F16_RESIDENT");
-        e->f16_resident   = fr && atoi(fr);
-        e->f16_resident_auto = !fr;
         e->graph_comm     = !(gc && !atoi(gc));
     }
     e->qkv_n       = (e->q_heads + 2 * e->kv_heads) * e->D;
@@ -987,16 +944,6 @@ int tm_engine_create(tm_engine** out, const tm_engine_config* c)
                                       && m.weight_type != TM_WEIGHT_F16),
                "moe: 1 <= top_k <= experts <= 64, top_k <= 8, u4 or fp8 expert weights");
     TM_HIP_CHECK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
-    if (e->f16_resident_auto && m.weight_type == TM_WEIGHT_U4 && c->max_prefill_token_num >= kF16LibraryMinM) {
-        // 2 bytes per dense weight next to the 0.53 of the u4 image: Llama-3-8B 14 GB of 288 (kept), InternLM2-20B 37 GB (not kept:
-        // the per-call dequantisation pass costs ~3 % of a prefill GEMM, the KV cache is worth more)
-        const double attn = (double)m.hidden * e->qkv_n + (double)e->q_heads * e->D * m.hidden;
-        const double ffn  = m.moe_experts > 0 ? 0.0 : 3.0 * m.hidden * e->inter;
-        size_t       free_b = 0, total_b = 0;
-        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
-            e->f16_resident = 2.0 * m.layers * (attn + ffn) <= 0.08 * (double)total_b;
-        }
-    }
 
     e->layers.resize(m.layers);
     for (int i = 0; i < m.layers; ++i) {
@@ -1359,9 +1306,7 @@ static int tune_decode_gemms(tm_engine* e, int M, bool verbose)
         if (dec32_table_get(w0.K, w0.N, M, &hs, &hp)) {
             continue;  // imported / tuned already
         }
-        const bool lib_ok = e->d_lib_ws != nullptr
-                            && f16_library_workspace_bytes(w0.K, w0.N, M, r.gated, w0.f16_nk != nullptr) <= e->lib_ws_bytes;
-        dec32_pick_ex(w0, M, &hs, &hp, false, lib_ok);
+        dec32_pick_ex(w0, M, &hs, &hp, false);
         int       cand[96][2];
         int       nc = dec32_candidates(w0, M, cand, 95);
         bool      has = false;
@@ -1385,25 +1330,10 @@ static int tune_decode_gemms(tm_engine* e, int M, bool verbose)
             if (gemm_workspace_bytes(M, w0.N, cfg.splits) > e->gemm_ws_bytes) {
                 continue;
             }
-            const bool lib = cfg.d32_shape == kShapeF16Library;
-            if (lib && !lib_ok) {
-                continue;
-            }
-            if (lib) {
-                cfg.lib_ws       = e->d_lib_ws;
-                cfg.lib_ws_bytes = e->lib_ws_bytes;
-            }
             const bool norm_consumer = (r.which == 1 || r.which == 3) && !e->use_comm;
-            const bool tail_consumer = e->gemm_tail && norm_consumer && w0.N == e->hidden && dec32_tail_supported(w0, M)
-                                       && gemm_workspace_bytes(M, w0.N, std::max(cfg.splits, 2)) <= e->gemm_ws_bytes;
             auto chain = [&]() -> int {
                 for (const LinearWeight* w : ws) {
                     int slabs = 1;
-                    if (tail_consumer) {  // as linear_residual_norm runs it: the consumer inside the launch
-                        NormTail tail{norm_out, e->d_resid, e->final_norm, e->cfg.model.rms_eps, e->d_tail_sync};
-                        TM_TRY(launch_linear(*w, r.x, r.ldx, nullptr, r.ldy, M, false, cfg, e->d_gemm_ws, true, nullptr, st, &tail));
-                        continue;
-                    }
                     TM_TRY(launch_linear(*w, r.x, r.ldx, r.y, r.ldy, M, r.gated, cfg, e->d_gemm_ws, norm_consumer && cfg.splits > 1, &slabs, st));
                     if (norm_consumer) {
                         TM_TRY(launch_residual_rmsnorm(norm_out, e->d_resid, slabs > 1 ? nullptr : e->d_tmp, slabs > 1 ? e->d_gemm_ws : nullptr,
@@ -1416,11 +1346,6 @@ static int tune_decode_gemms(tm_engine* e, int M, bool verbose)
                 TM_HIP_CHECK(hipMemsetAsync(e->d_resid, 0, (size_t)M * e->hidden * 2, st));
             }
             if ((rc = chain())) {  // eager once: lazy module loading, function attributes
-                if (lib) {         // the library refused (no algorithm, version skew): not a candidate here, not an error
-                    rc = 0;
-                    (void)hipGetLastError();
-                    continue;
-                }
                 break;
             }
             hipGraph_t     g  = nullptr;
@@ -1457,11 +1382,6 @@ static int tune_decode_gemms(tm_engine* e, int M, bool verbose)
             }
             if (g) {
                 (void)hipGraphDestroy(g);
-            }
-            if (rc && lib) {  // e.g. the library's launch is not capturable: the eager engine could still use it, but unmeasured = not chosen
-                rc = 0;
-                (void)hipGetLastError();
-                continue;
             }
             if (rc) {
                 break;
@@ -1551,31 +1471,6 @@ int tm_engine_start(tm_engine* e)
     // split-K workspace: decode-sized problems only (M <= 64 rows x widest N x 16 slabs)
     e->gemm_ws_bytes = (size_t)16 * 64 * std::max(std::max(e->qkv_n, 2 * e->inter), e->hidden) * sizeof(float);
     TM_HIP_CHECK(hipMalloc((void**)&e->d_gemm_ws, e->gemm_ws_bytes));
-    {
-        const char* gt = getenv("TM_GEMM_TAIL");
-        e->gemm_tail   = gt && atoi(gt);
-    }
-    if (f16_library_available() && e->max_tokens >= kF16LibraryMinM) {
-        size_t need = 0;
-        for (Layer& L : e->layers) {
-            const LinearWeight* ws[4]    = {&L.qkv.w, &L.wo.w, L.is_moe ? nullptr : &L.w13.w, L.is_moe ? nullptr : &L.w2.w};
-            const bool          gated[4] = {false, false, true, false};
-            for (int i = 0; i < 4; ++i) {
-                if (ws[i] && dec32_supported(*ws[i], e->max_tokens)) {
-                    need = std::max(need, f16_library_workspace_bytes(ws[i]->K, ws[i]->N, e->max_tokens, gated[i], ws[i]->f16_nk != nullptr));
-                }
-            }
-        }
-        if (need > 0 && hipMalloc(&e->d_lib_ws, need) == hipSuccess) {
-            e->lib_ws_bytes = need;
-        }
-        else {
-            (void)hipGetLastError();  // no scratch: the fused kernels serve every M
-            e->d_lib_ws = nullptr;
-        }
-    }
-    TM_HIP_CHECK(hipMalloc((void**)&e->d_tail_sync, 16));
-    TM_HIP_CHECK(hipMemsetAsync(e->d_tail_sync, 0, 16, e->stream));
     if (m.moe_experts > 0) {
         TM_HIP_CHECK(hipMalloc(&e->d_moe_ws, moe_workspace_bytes(e->layers[0].moe, e->max_tokens)));
     }
@@ -1658,41 +1553,6 @@ int tm_engine_start(tm_engine* e)
     }
     if (const char* exp = getenv("TM_GEMM_EXPORT")) {
         TM_TRY(dec32_table_export(exp));
-    }
-    // The library path's first use loads the library's code objects, creates its handle and searches its kernel list: ~150 ms
-    // (measured: TTFT p50 581 ms on a cold process against 415 ms after the tuner had been through it).  Start-up work, like
-    // the reference's warm-up (turbomind.cc:363-487): one full-chunk forward of every distinct dense linear, results discarded.
-    if (e->d_lib_ws) {
-        const int M = e->max_tokens;
-        Layer&    L = e->layers[0];
-        struct Warm {
-            LinearSlots*  l;
-            const half_t* x;
-            int           ldx;
-            half_t*       y;
-            int           ldy;
-            bool          gated;
-        };
-        const Warm ws[4] = {{&L.qkv, e->d_x, e->hidden, e->d_qkv, e->qkv_n, false},
-                            {&L.wo, e->d_attn, e->q_heads * e->D, e->d_tmp, e->hidden, false},
-                            {L.is_moe ? nullptr : &L.w13, e->d_x, e->hidden, e->d_act, e->inter, true},
-                            {L.is_moe ? nullptr : &L.w2, e->d_act, e->inter, e->d_tmp, e->hidden, false}};
-        for (const Warm& w : ws) {
-            if (!w.l || !dec32_supported(w.l->w, M)) {
-                continue;
-            }
-            const GemmConfig cfg = pick_config(e, w.l->w, M, w.gated);
-            if (cfg.d32_shape == kShapeF16Library
-                && launch_linear(w.l->w, w.x, w.ldx, w.y, w.ldy, M, w.gated, cfg, e->d_gemm_ws, false, nullptr, e->stream)) {
-                fprintf(stderr, "[tm] library GEMM warm-up failed (%s); the fused kernels serve prefill\n", tm_last_error());
-                (void)hipGetLastError();
-                (void)hipFree(e->d_lib_ws);
-                e->d_lib_ws     = nullptr;
-                e->lib_ws_bytes = 0;
-                break;
-            }
-        }
-        TM_HIP_CHECK(hipStreamSynchronize(e->stream));
     }
     return 0;
 }
@@ -2359,6 +2219,9 @@ int tm_engine_set_logits_params(tm_engine* e, const tm_logits_param* host_params
 
 static int submit_locked(tm_engine* e, const int* host_ids, int n, int max_new_tokens, int eos_id, int64_t* req_id)
 {
+    if (e->comm_failed) {  // terminal for the communicator (device_marks_check): no new work on this engine
+        return device_marks_check(e);
+    }
     TM_TRY(cb_enter(e));
     const int rc = e->sched->submit(host_ids, n, max_new_tokens, eos_id, req_id);
     if (rc == TM_TOO_LONG) {
@@ -2739,10 +2602,11 @@ int tm_engine_fetch(tm_engine* e, int* host_out, int* n_generated)
     TM_REQUIRE(e && host_out && n_generated, "null pointer");
     TM_HIP_CHECK(hipStreamSynchronize(e->stream));
     TM_TRY(device_marks_fetch(e, false));
-    TM_TRY(device_marks_check(e));
+    // the tokens are handed over in any case (those of the steps before a communicator give-up are valid); the status says
+    // whether every step behind them was
     TM_HIP_CHECK(hipMemcpy(host_out, e->d_generated, (size_t)e->batch * e->max_new * 4, hipMemcpyDeviceToHost));
     *n_generated = e->steps_done;
-    return 0;
+    return device_marks_check(e);
 }
 
 int tm_engine_fetch_logits(tm_engine* e, void* host_out)
@@ -2881,7 +2745,7 @@ int tm_engine_destroy(tm_engine* e)
     void* bufs[] = {e->pool, e->d_block_ptrs, e->d_cu_block_nums, e->d_resid, e->d_x, e->d_qkv, e->d_attn, e->d_act,
                     e->d_tmp, e->d_logits, e->d_last, e->d_gemm_ws, e->d_attn_ws, e->d_kflat, e->d_vflat, e->d_rope,
                     e->d_ids, e->d_k_len, e->d_cu_q, e->d_cu_koff, e->d_rows, e->d_generated, e->d_step,
-                    e->d_prefill_ids, e->d_argmax_val, e->d_cand, e->d_cand_all, e->d_next_ids, e->d_tail_sync, e->d_lib_ws};
+                    e->d_prefill_ids, e->d_argmax_val, e->d_cand, e->d_cand_all, e->d_next_ids};
     for (void* p : bufs) {
         if (p) {
             (void)hipFree(p);

@@ -30,7 +30,6 @@
 //     [2048, 2176) 32 x (s, -z*s) half2 pairs of the group's columns.
 #include "tm_common.h"
 #include "tm_kernels.h"
-#include "norm_row.h"
 #include "p32_layout.h"
 #include "gemm_decode_common.h"
 #include <stdlib.h>
@@ -82,6 +81,54 @@ __global__ void repack_p32_kernel(uint32_t* __restrict__ out, const int32_t* __r
     out[idx] = w;
 }
 
+// The fp16 [N][K] image of a P32 linear (operator level, tm_linear_dequant_f16): bit for bit the operand the GEMM kernels build.
+// One wave per P32 unit (32 columns x 128 k): the lane dequantises its two 16-byte pieces exactly as the GEMM's fragment
+// pipeline does (8 x dequant8_p32 -> row l & 31, k = 16 j + 8 (l >> 5) + e), the 32 x 128 fp16 tile is transposed through a
+// wave-private LDS image and leaves as whole 256-byte row segments of the [N][K] image.
+__global__ __launch_bounds__(256) void dequant_p32_f16_kernel(half_t* __restrict__ out, const char* __restrict__ wp, int KB, int ncg)
+{
+    constexpr int kRow = 256 + 16;  // bytes per image row (+16: rows 4 banks apart -> the 16-byte column writes do not collide)
+    __shared__ __attribute__((aligned(16))) char smem[4 * 32 * kRow];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int cg   = blockIdx.x * 4 + wave;
+    const int kb   = blockIdx.y;
+    if (cg >= ncg) {
+        return;
+    }
+    const char*    unit = wp + ((size_t)kb * ncg + cg) * kP32Unit;
+    const u32x4    w0   = *(const u32x4*)(unit + lane * 16);
+    const u32x4    w1   = *(const u32x4*)(unit + 1024 + lane * 16);
+    const half2_t  pr   = *(const half2_t*)(unit + 2048 + (lane & 31) * 4);
+    const half2_t  s2   = {pr[0], pr[0]};
+    const half2_t  z2   = {pr[1], pr[1]};
+    const uint32_t m1024 = 0x64006400u, m64 = 0x54005400u;
+    char*          img   = smem + wave * 32 * kRow;
+    char*          mine  = img + (lane & 31) * kRow + (lane >> 5) * 16;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        *(half8_t*)(mine + j * 32) = dequant8_p32(j < 4 ? w0[j & 3] : w1[j & 3], s2, z2, m1024, m64);
+    }
+    __builtin_amdgcn_wave_barrier();  // wave-private image, in-order LDS pipe: no workgroup barrier
+    const size_t K = (size_t)KB * 128;
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+        const int idx = it * 64 + lane;
+        const int row = idx >> 4, chunk = idx & 15;
+        const u32x4 v = *(const u32x4*)(img + row * kRow + chunk * 16);
+        __builtin_nontemporal_store(v, (u32x4*)(out + ((size_t)cg * 32 + row) * K + (size_t)kb * 128 + chunk * 8));
+    }
+}
+
+int launch_dequant_p32_f16(half_t* out_nk, const LinearWeight& w, hipStream_t st)
+{
+    TM_REQUIRE(w.type == 0 && w.packed32 != nullptr && w.N % 32 == 0 && w.K % 128 == 0, "fp16 image: a u4 linear with its P32 image");
+    const int ncg = w.N / 32, KB = w.K / 128;
+    dequant_p32_f16_kernel<<<dim3((ncg + 3) / 4, KB), 256, 0, st>>>(out_nk, (const char*)w.packed32, KB, ncg);
+    TM_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
 size_t p32_bytes(int K, int N)
 {
     return (size_t)(K / 128) * (N / 32) * kP32Unit;
@@ -93,79 +140,6 @@ int launch_repack_p32(void* out, const int32_t* qweight, const half_t* scales, c
     repack_p32_kernel<<<(unsigned)((total + 255) / 256), 256, 0, st>>>((uint32_t*)out, qweight, scales, zeros, K, N);
     TM_HIP_CHECK(hipGetLastError());
     return 0;
-}
-
-// The in-launch consumer (Dec32Params::tail_*).  Called by every thread of the workgroup after its slab stores were ISSUED.
-// Arrival: every wave drains its write-through stores, then one relaxed agent-scope ticket per workgroup.  The last
-// R = min(M, 64, workgroups) arrivers stay: workgroup with ticket total - R + j takes rows j, j + R, ...  They fetch what does
-// not depend on anybody (residual row, norm weight), wait for the last ticket (one lane polls, bounded), then read the slabs
-// L1-bypassing.  No workgroup waits for one that is not resident unless fewer than R + 1 workgroups fit on the chip
-// (R <= 64 of >= 256 slots), so the wait cannot deadlock.
-template<int NV>
-__device__ __forceinline__ void dec32_norm_tail_rows(const Dec32Params& p, char* smem, int tid, unsigned total, unsigned R, int j, int wgid,
-                                                     int nthreads)
-{
-    typedef __attribute__((address_space(1))) unsigned gu32;
-    gu32* const     sync = (gu32*)p.tail_sync;
-    float* const    red  = (float*)smem;
-    NormRowRegs<NV> g;
-    norm_row_load<2, false, NV>(g, p.tail_resid, nullptr, nullptr, p.tail_w, p.N, j, tid, nthreads);
-    if (tid == 0) {
-        unsigned spins = 0;
-        while (__hip_atomic_load(sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < total) {
-            __builtin_amdgcn_s_sleep(1);
-            if (++spins > (1u << 21)) {  // ~ seconds: something is badly wrong -- mark it and carry on (wrong numbers, no hang)
-                __hip_atomic_store(sync + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                break;
-            }
-        }
-    }
-    __syncthreads();
-    if (p.dbg && tid == 0) {
-        p.dbg[wgid * 8 + 6] = __builtin_amdgcn_s_memrealtime();
-    }
-    for (int row = j; row < p.M; row += (int)R) {
-        if (row != j) {
-            __syncthreads();  // `red` is reused
-            norm_row_load<2, false, NV>(g, p.tail_resid, nullptr, nullptr, p.tail_w, p.N, row, tid, nthreads);
-        }
-        norm_row_finish<2, false, NV, true>(g, p.tail_y, p.tail_resid, p.partial, (int)gridDim.y, p.tail_eps, p.M, p.N, tid, nthreads, red);
-    }
-    if (tid == 0) {
-        const unsigned d = __hip_atomic_fetch_add(sync + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (d + 1 == R) {  // every tail workgroup is past its poll: the words are free for the next launch on the stream
-            __hip_atomic_store(sync, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(sync + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
-}
-
-__device__ __forceinline__ void dec32_norm_tail(const Dec32Params& p, char* smem, int tid, unsigned total, int wgid)
-{
-    typedef __attribute__((address_space(1))) unsigned gu32;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // EVERY storing wave (Guideline 16 pitfall 14)
-    __syncthreads();                                  // also: every read of the k-phase reduction image is done
-    unsigned* const sh = (unsigned*)smem;
-    if (tid == 0) {
-        sh[64] = __hip_atomic_fetch_add((gu32*)p.tail_sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    __syncthreads();
-    const unsigned ticket = sh[64];
-    const unsigned R      = min(min((unsigned)p.M, 64u), total);
-    if (ticket + R < total) {
-        return;  // uniform: not one of the last R
-    }
-    if (p.dbg && tid == 0) {
-        p.dbg[wgid * 8 + 5] = __builtin_amdgcn_s_memrealtime();
-    }
-    int nthreads, nv;
-    norm_geometry(p.N, &nthreads, &nv);
-    if (nv == 1) {
-        dec32_norm_tail_rows<1>(p, smem, tid, total, R, (int)(ticket + R - total), wgid, nthreads);
-    }
-    else {
-        dec32_norm_tail_rows<2>(p, smem, tid, total, R, (int)(ticket + R - total), wgid, nthreads);
-    }
 }
 
 // MH: 32-row halves of the batch (1: M <= 32, 2: M <= 64).  CG x WK waves.  S k-blocks per LDS stage (S % WK == 0).
@@ -596,9 +570,6 @@ __global__ __launch_bounds__(CG* WK * 64) void gemm_dec32_kernel(Dec32Params p)
             }
         }
     }
-    if (p.tail_y != nullptr) {  // uniform over the launch (epilogue 2, write-through slab stores)
-        dec32_norm_tail(p, smem, tid, (unsigned)(gridDim.x * gridDim.y * gridDim.z), wgid);
-    }
     if (p.dbg && tid == 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         p.dbg[wgid * 8 + 3] = __builtin_amdgcn_s_memrealtime();
@@ -976,6 +947,11 @@ static void dec32_shape_dims(int shape, int* cg, int* s)
         *s  = 4;
         return;
     }
+    if (shape == kShapePre256) {
+        *cg = 8;
+        *s  = 1;
+        return;
+    }
     shape = dec32_base_shape(shape);
     *cg = cgs[shape < 0 || shape > 5 ? 0 : shape];
     *s  = shape == 5 ? 1 : (shape == 4 ? 2 : 4);
@@ -1057,9 +1033,9 @@ int dec32_table_import(const char* path)
     int K, N, M, shape, splits, n = 0;
     while (fscanf(f, "%d %d %d %d %d", &K, &N, &M, &shape, &splits) == 5) {
         const bool big = M > 64;
-        const bool lib = shape == kShapeF16Library && M >= kF16LibraryMinM && splits == 1;  // (falls back at pick time without the library)
         const bool lc  = shape == kShapeLC && M <= 64;
-        if (K > 0 && N > 0 && M > 0 && M == dec32_m_bucket(M) && shape >= 0 && (shape <= 9 || lib || lc) && splits >= 1 && splits <= 16
+        const bool p256 = shape == kShapePre256 && M >= 256 && N >= 256 && splits <= 4;
+        if (K > 0 && N > 0 && M > 0 && M == dec32_m_bucket(M) && shape >= 0 && (shape <= 9 || lc || p256) && splits >= 1 && splits <= 16
             && (big ? shape >= 4 : (shape != 4 && shape != 5)) && !(shape == 5 && N < 512) && K % 128 == 0 && N % 32 == 0) {
             dec32_table_set(K, N, M, shape, splits);
             ++n;
@@ -1131,10 +1107,19 @@ int dec32_candidates(const LinearWeight& w, int M, int (*out)[2], int cap)
             }
         }
     }
-    if (M >= kF16LibraryMinM && M <= 8192 && f16_library_available() && n < cap) {  // dequantise + vendor fp16 GEMM (gemm_f16_library.hip)
-        out[n][0] = kShapeF16Library;
-        out[n][1] = 1;
-        ++n;
+    if (M >= 256 && M <= 8192 && w.N >= 256) {  // gemm_prefill.hip: 256 x 256 tiles (<= 4 slices: slabs of MBs each)
+        const int tiles = (ncg + 7) / 8 * ((M + 255) / 256);
+        for (int s = 1; s <= 4; ++s) {
+            const int per = (KB + s - 1) / s;
+            if ((KB + per - 1) / per != s || (s > 1 && tiles * s > 512) || per < 8) {
+                continue;
+            }
+            if (n < cap) {
+                out[n][0] = kShapePre256;
+                out[n][1] = s;
+                ++n;
+            }
+        }
     }
     return n;
 }
@@ -1146,24 +1131,12 @@ void dec32_pick(const LinearWeight& w, int M, int* shape_out, int* splits_out)
     dec32_pick_ex(w, M, shape_out, splits_out, true);
 }
 
-void dec32_pick_ex(const LinearWeight& w, int M, int* shape_out, int* splits_out, bool use_table, bool allow_library)
+void dec32_pick_ex(const LinearWeight& w, int M, int* shape_out, int* splits_out, bool use_table)
 {
     const int ncg = w.N / 32;
     const int KB  = w.K / 128;
-    allow_library = allow_library && f16_library_available();
-    if (use_table && dec32_table_get(w.K, w.N, dec32_m_bucket(M), shape_out, splits_out)
-        && (*shape_out != kShapeF16Library || (allow_library && M >= kF16LibraryMinM))) {
+    if (use_table && dec32_table_get(w.K, w.N, dec32_m_bucket(M), shape_out, splits_out)) {
         return;  // measured on this machine for exactly this problem (M <= 256) / for this size class of forwards (above)
-    }
-    // Compute-bound forwards: dequantise + the vendor library's fp16 GEMM (gemm_f16_library.hip).  Measured against the fused
-    // 128 x 512 tile on the Llama-3-8B shapes (profiles/r03_prefill_gemm_vs_library.txt, us incl. the dequant pass / the SiLU
-    // pass of w1w3): M = 4096: w_qkv 186 vs 240, wo 106 vs 126, w1w3 ~765 vs 848, w2 348 vs 396; M = 1024: 66 vs 57, 48 vs 47,
-    // ~255 vs 236, 147 vs 118 -- the crossover sits near 2048 rows; with a resident fp16 image (no dequant pass) near 1024.
-    static const int lib_from = env_int2("TM_F16_LIBRARY_MIN_M", 2048);
-    if (allow_library && M >= (w.f16_nk ? std::min(lib_from, 1024) : lib_from)) {
-        *shape_out  = kShapeF16Library;
-        *splits_out = 1;
-        return;
     }
     static const int env_shape  = env_int2("TM_D32_SHAPE", -1);  // read once: this runs on every eager launch
     static const int env_splits = env_int2("TM_D32_SPLITS", 0);
@@ -1230,18 +1203,13 @@ void dec32_pick_ex(const LinearWeight& w, int M, int* shape_out, int* splits_out
 }
 
 // y / slabs as launch_linear: *slabs_out = number of fp32 slabs written into `workspace` (1 = direct epilogue)
-bool dec32_tail_supported(const LinearWeight& w, int M)
-{
-    return dec32_supported(w, M) && M <= 64 && w.N % 8 == 0 && w.N <= kNormMaxThreads * kNormMaxVec * 8;
-}
-
 int launch_linear_dec32(const LinearWeight& w, const half_t* x, int ldx, half_t* y, int ldy, int M, bool gated_silu, int shape,
-                        int splits, float* workspace, int* slabs_out, hipStream_t st, const NormTail* tail)
+                        int splits, float* workspace, int* slabs_out, hipStream_t st)
 {
     TM_REQUIRE(w.packed32 != nullptr && w.N % 32 == 0, "decode GEMM: P32 layout missing");
-    TM_REQUIRE(M >= 1 && shape >= 0 && (shape <= 9 || shape == kShapeLC) && (shape >= 6 || (M <= 64) == (shape < 4))
-                   && (shape != kShapeLC || M <= 64),
-               "decode GEMM: shapes 0..3 and 11 take M <= 64, shapes 4 / 5 take M > 64, shapes 6..9 any M");
+    TM_REQUIRE(M >= 1 && shape >= 0 && (shape <= 9 || shape == kShapeLC || shape == kShapePre256)
+                   && (shape >= 6 || (M <= 64) == (shape < 4)) && (shape != kShapeLC || M <= 64) && (shape != kShapePre256 || M > 64),
+               "decode GEMM: shapes 0..3 and 11 take M <= 64, shapes 4 / 5 / 12 take M > 64, shapes 6..9 any M");
     TM_REQUIRE(ldx % 8 == 0, "x rows must be 16-byte aligned");
     int cgn, S;
     dec32_shape_dims(shape, &cgn, &S);
@@ -1266,20 +1234,11 @@ int launch_linear_dec32(const LinearWeight& w, const half_t* x, int ldx, half_t*
     p.epilogue     = splits > 1 ? 2 : (gated_silu ? 1 : 0);
     static const int wt = env_int2("TM_D32_WT", 1);  // measured (tools/trace_boundary.py, profiles/r02_gemm_boundary_gap.txt): -0.4..-0.9 us per split-K launch
     p.wt           = wt;
-    if (tail) {  // slabs (also for ONE slice) consumed by the last workgroups of this launch: write-through stores are the publish
-        TM_REQUIRE(shape < 4 || (shape >= 6 && shape <= 9), "in-launch consumer: the 16-wave decode tiles only");
-        TM_REQUIRE(workspace != nullptr && !gated_silu && M <= 64, "in-launch consumer: row-parallel decode linear with a slab workspace");
-        p.epilogue   = 2;
-        p.wt         = 1;
-        p.tail_y     = tail->y;
-        p.tail_resid = tail->resid;
-        p.tail_w     = tail->weight;
-        p.tail_eps   = tail->eps;
-        p.tail_sync  = tail->sync;
-    }
-    dim3      grid((p.ncg + cgn - 1) / cgn, splits, shape == kShapeLC ? 1 : shape >= 6 ? (M + 31) / 32 : shape >= 4 ? (M + 127) / 128 : 1);
+    dim3      grid((p.ncg + cgn - 1) / cgn, splits,
+                   shape == kShapePre256 ? (M + 255) / 256 : shape == kShapeLC ? 1 : shape >= 6 ? (M + 31) / 32 : shape >= 4 ? (M + 127) / 128 : 1);
     p.dbg        = gemm_trace_for((size_t)grid.x * grid.y * grid.z);
-    const int rc = shape == kShapeLC ? launch_dec_lc(p, grid, st) :
+    const int rc = shape == kShapePre256 ? launch_pre256(p, grid, st) :
+                   shape == kShapeLC ? launch_dec_lc(p, grid, st) :
                    shape >= 6 ? launch_dec32_shape<1>(p, grid, dec32_base_shape(shape), st) :
                    shape >= 4 ? launch_dec32_shape<4>(p, grid, shape, st) :
                    M <= 32    ? launch_dec32_shape<1>(p, grid, shape, st) :
@@ -1288,7 +1247,7 @@ int launch_linear_dec32(const LinearWeight& w, const half_t* x, int ldx, half_t*
         return rc;
     }
     if (slabs_out) {
-        *slabs_out = tail ? 0 : splits;
+        *slabs_out = splits;
     }
     return 0;
 }

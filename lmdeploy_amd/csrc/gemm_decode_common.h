@@ -23,19 +23,6 @@ struct Dec32Params {
     int           wt;        // bit 0: split-K slabs, bit 1: fp16 outputs leave through write-through (sc1) stores: they drain to memory
                              // while the other workgroups still stream instead of sitting dirty in L2 until the end-of-kernel
                              // release writes them back (the kernel boundary then waits for MBs of fp32 slabs)
-    // In-launch consumer of a row-parallel linear (epilogue 2 only; reference: the residual + RMSNorm that follows wo / w2,
-    // unified_decoder.cc:149,226 -> rms_norm.cu:286-362): the LAST `min(M, 64)` workgroups to finish their slab tiles each take
-    // token rows and run norm_row<2> on them (split-K reduce in slab order -> fp16 -> residual add -> RMSNorm), so the
-    // separate reduce-norm launch, its kernel boundary and the dirty-slab write-back in front of it disappear.  Hand-off:
-    // write-through slab stores, every wave drains vmcnt, ONE relaxed agent-scope ticket per workgroup; a tail workgroup polls
-    // that one word (relaxed, s_sleep, BOUNDED: on give-up it sets tail_sync[2] and carries on) and reads the slabs with sc1
-    // loads (cdna_hip_programming.md Guideline 16 R1).  tail_sync = 4 device words, zero before the first launch; the last
-    // tail workgroup to finish re-zeroes the two counters, so consecutive launches on one stream may share the words.
-    half_t*       tail_y;       // nullptr: no in-launch consumer
-    half_t*       tail_resid;
-    const half_t* tail_w;
-    float         tail_eps;
-    unsigned*     tail_sync;    // [0] arrivals, [1] finished tail workgroups, [2] give-up mark (sticky), [3] -
     uint64_t*     dbg;       // optional [workgroups][8] s_memrealtime stamps (tm_debug_set_gemm_trace): start, loop, epilogue, end,
                              // hw id, -, -, after the k-phase reduction barrier
 };
@@ -76,5 +63,8 @@ __device__ __forceinline__ void static_for(F&& f)
 
 // gemm_decode_lc.hip: the loader / consumer decode kernel (shape kShapeLC), grid = (ceil(ncg / 4), splits)
 int launch_dec_lc(const Dec32Params& p, dim3 grid, hipStream_t st);
+// gemm_prefill.hip: 256 x 256 prefill tiles, weights dequantised once per workgroup tile through LDS (shape kShapePre256),
+// grid = (ceil(ncg / 8), splits, ceil(M / 256))
+int launch_pre256(const Dec32Params& p, dim3 grid, hipStream_t st);
 
 }  // namespace tmk

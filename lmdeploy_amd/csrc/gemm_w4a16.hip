@@ -171,10 +171,6 @@ void linear_weight_free(LinearWeight& w)
     if (w.packed8) {
         (void)hipFree(w.packed8);
     }
-    if (w.f16_nk) {
-        (void)hipFree(w.f16_nk);
-    }
-    w.f16_nk  = nullptr;
     w.packed8 = nullptr;
     w.packed   = nullptr;
     w.sz       = nullptr;
@@ -730,11 +726,11 @@ static int env_int(const char* name, int dflt)
     return v ? atoi(v) : dflt;
 }
 
-GemmConfig gemm_pick_config(const LinearWeight& w, int M, bool allow_library)
+GemmConfig gemm_pick_config(const LinearWeight& w, int M)
 {
     if (dec32_supported(w, M)) {  // decode batch: the weight-streaming kernel of gemm_decode.hip
         GemmConfig cfg{};
-        dec32_pick_ex(w, M, &cfg.d32_shape, &cfg.splits, true, allow_library);
+        dec32_pick_ex(w, M, &cfg.d32_shape, &cfg.splits, true);
         cfg.nt      = 2;
         cfg.waves   = 16;
         cfg.kphases = 1;
@@ -925,34 +921,26 @@ int launch_linear(const LinearWeight& w,
                   float*              workspace,
                   bool                defer_reduce,
                   int*                slabs,
-                  hipStream_t         st,
-                  const NormTail*     tail)
+                  hipStream_t         st)
 {
     if (slabs) {
         *slabs = 1;
     }
-    TM_REQUIRE(!tail || (cfg.d32_shape >= 0 && dec32_tail_supported(w, M) && workspace && !gated_silu),
-               "in-launch residual-norm consumer: decode kernel, M <= 64, a slab workspace");
     TM_REQUIRE(w.packed != nullptr || w.packed32 != nullptr, "linear weight not prepared");
     TM_REQUIRE(ldx % 8 == 0, "x rows must be 16-byte aligned");
     TM_REQUIRE(!gated_silu || w.N % 32 == 0, "gated epilogue needs N % 32 == 0");
     if (M == 0) {
         return 0;
     }
-    if (cfg.d32_shape == kShapeF16Library) {
-        TM_REQUIRE(!tail && !defer_reduce && dec32_supported(w, M) && M >= kF16LibraryMinM,
-                   "library GEMM: a prefill-sized forward of a dense u4 linear, no slab consumers");
-        return launch_linear_f16_library(w, x, ldx, y, ldy, M, gated_silu, cfg.lib_ws, cfg.lib_ws_bytes, st);
-    }
     if (cfg.d32_shape >= 0 && dec32_supported(w, M)) {
         int       nslab = 1;
         const int sp    = workspace ? (cfg.splits < 1 ? 1 : cfg.splits) : 1;
-        TM_REQUIRE(!defer_reduce || sp > 1 || tail, "defer_reduce only with split-K");
-        const int rc = launch_linear_dec32(w, x, ldx, y, ldy, M, gated_silu, cfg.d32_shape, sp, workspace, &nslab, st, tail);
+        TM_REQUIRE(!defer_reduce || sp > 1, "defer_reduce only with split-K");
+        const int rc = launch_linear_dec32(w, x, ldx, y, ldy, M, gated_silu, cfg.d32_shape, sp, workspace, &nslab, st);
         if (rc) {
             return rc;
         }
-        if (nslab > 1 && !defer_reduce && !tail) {
+        if (nslab > 1 && !defer_reduce) {
             const size_t total = (size_t)M * w.N / 4;
             splitk_reduce_kernel<<<(total + 255) / 256, 256, 0, st>>>(y, ldy, workspace, nslab, M, w.N, gated_silu ? 1 : 0);
             TM_HIP_CHECK(hipGetLastError());

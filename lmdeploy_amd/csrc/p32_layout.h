@@ -1,5 +1,5 @@
 // Layout "P32" of a dense u4 (AWQ) linear, shared by the kernels that read it (gemm_decode.hip: the W4A16 GEMMs;
-// gemm_f16_library.hip: the fp16 image for the vendor library's GEMM).  Built once by repack_p32_kernel at load
+// gemm_decode_lc.hip, gemm_prefill.hip; tm_linear_dequant_f16: the operand as an fp16 image).  Built once by repack_p32_kernel at load
 // (LinearWeight::prepare's role, models/linear_weight.cc:101-324):
 //   unit (kb, cg) at byte ((kb * N/32) + cg) * 2176:
 //     [0, 2048)    dword d = (p*64 + lane)*4 + jj  (p = 0..1, jj = 0..3): j = 4p + jj is the 16-k step of the k-block,

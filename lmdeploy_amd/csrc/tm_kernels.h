@@ -117,9 +117,6 @@ struct LinearWeight {
     // their even / odd column block scales)
     void*     packed8 = nullptr;
     size_t    packed8_bytes = 0;
-    // u4 only, optional: the dequantised fp16 image in [N][K] order for the vendor library's GEMM on prefill-sized forwards
-    // (gemm_f16_library.hip).  nullptr: that path dequantises into its workspace on every call.
-    half_t*   f16_nk = nullptr;
 };
 struct GemmConfig {
     int nt;      // n-tiles (16 cols) per wave: 1,2,4
@@ -127,14 +124,11 @@ struct GemmConfig {
     int waves;   // waves per workgroup: 4 or 8
     int kphases; // split-K inside the workgroup: 1 or 2 (8 waves only)
     int kstage;  // max k-blocks per barrier (0 = auto: 4)
-    int d32_shape = -1;  // >= 0: the decode kernel of gemm_decode.hip with this workgroup shape (M <= 64, u4, N % 32 == 0);
-                         // kShapeF16Library: dequantised weights x the vendor library's fp16 GEMM (gemm_f16_library.hip)
-    void*  lib_ws       = nullptr;  // kShapeF16Library only: f16_library_workspace_bytes() of device memory, 256-byte aligned
-    size_t lib_ws_bytes = 0;
+    int d32_shape = -1;  // >= 0: a P32 kernel (gemm_decode.hip / gemm_decode_lc.hip / gemm_prefill.hip) with this workgroup shape
 };
-constexpr int kShapeF16Library = 10;
+// (shape 10 was "dequantise + the vendor library's fp16 GEMM" in round 3: removed -- no vendor GEMM on any path of this library)
+constexpr int kShapePre256     = 12;   // gemm_prefill.hip: 256 x 256 tiles, weights dequantised once per workgroup tile through LDS (M > 64)
 constexpr int kShapeLC         = 11;   // gemm_decode_lc.hip: 8 consumer + 4 loader waves, 128 columns x M <= 64 rows per workgroup
-constexpr int kF16LibraryMinM  = 512;  // candidate of the measured dispatch from this size class on
 // Load-time repack (reference: LinearWeight::prepare, models/linear_weight.cc:101-324)
 // p32_only: build ONLY the P32 image (gemm_decode.hip) -- for linears that every M dispatches to those kernels
 // (dec32_serves_every_m): the 16-column image of gemm_kernel would never be read.
@@ -145,42 +139,22 @@ int    linear_weight_prepare_f16(LinearWeight& w, const half_t* weight /*[K][N]*
 int    linear_weight_prepare_fp8(LinearWeight& w, const uint8_t* weight /*[K][N] e4m3*/, const float* block_scales /*[K/128][ceil(N/128)]*/,
                                  bool gated_scales /* w1w3: scale row = [w1 blocks | w3 blocks] for interleaved columns */, hipStream_t st);
 void   linear_weight_free(LinearWeight& w);
-// gemm_f16_library.hip: prefill-sized forwards of a dense u4 linear as dequantise + library GEMM
-bool   f16_library_available();  // hipBLASLt loadable here and TM_GEMM_F16_LIBRARY != 0
-size_t f16_image_bytes(int K, int N);
-size_t f16_library_workspace_bytes(int K, int N, int M, bool gated, bool resident);
-int    launch_dequant_p32_f16(half_t* out_nk /*[N][K]*/, const LinearWeight& w, hipStream_t st);
-int    linear_weight_build_f16_image(LinearWeight& w, hipStream_t st);  // resident image (LinearWeight::f16_nk)
-int    launch_linear_f16_library(const LinearWeight& w, const half_t* x, int ldx, half_t* y, int ldy, int M, bool gated_silu, void* ws,
-                                 size_t ws_bytes, hipStream_t st);
+int    launch_dequant_p32_f16(half_t* out_nk /*[N][K]*/, const LinearWeight& w, hipStream_t st);  // gemm_decode.hip: the operand as an fp16 image
 size_t gemm_workspace_bytes(int M, int N, int splits);
 int    launch_splitk_reduce(half_t* y, int ldy, const float* partial, int splits, int M, int N, bool gated, hipStream_t st);
-GemmConfig gemm_pick_config(const LinearWeight& w, int M, bool allow_library = false);  // decode kernel when it applies, else ...
-                                                                   // (allow_library: the caller fills lib_ws when kShapeF16Library comes back)
+GemmConfig gemm_pick_config(const LinearWeight& w, int M);  // a P32 kernel when it applies, else ...
 GemmConfig gemm_pick_config_general(const LinearWeight& w, int M);  // ... the tiling of gemm_kernel (gemm_w4a16.hip)
-// In-launch consumer of a row-parallel decode linear (gemm_decode.hip, Dec32Params::tail_*): resid += fp16(sum of the split-K
-// slabs); y = RMSNorm(resid) * weight, executed by the last workgroups of the GEMM launch itself.  sync = 4 device words,
-// zero before the first use (the launch leaves them zero); sync[2] != 0 afterwards = a hand-off wait gave up (fatal).
-struct NormTail {
-    half_t*       y;
-    half_t*       resid;
-    const half_t* weight;
-    float         eps;
-    unsigned*     sync;
-};
-bool dec32_tail_supported(const LinearWeight& w, int M);  // decode kernel applies, M <= 64 rows, N within the norm's reach
 // y[M][N (or N/2 if gated)] = x[M][K] . W ; if cfg.splits > 1 fp32 slabs land in `workspace` and, unless
-// `defer_reduce`, a reduce kernel writes y.  tail != nullptr (needs dec32_tail_supported and a workspace): the slabs are
-// consumed inside the launch, y is not written, *slabs = 0.
+// `defer_reduce`, a reduce kernel writes y.
 int launch_linear(const LinearWeight& w, const half_t* x, int ldx, half_t* y, int ldy, int M, bool gated_silu,
-                  GemmConfig cfg, float* workspace, bool defer_reduce, int* slabs, hipStream_t st, const NormTail* tail = nullptr);
+                  GemmConfig cfg, float* workspace, bool defer_reduce, int* slabs, hipStream_t st);
 
 // ---- gemm_decode.hip: W4A16 decode GEMM (M <= 64), 32x32x16 MFMA, 16 waves per CU ------------------------------
 size_t p32_bytes(int K, int N);
 int    launch_repack_p32(void* out, const int32_t* qweight, const half_t* scales, const half_t* zeros, int K, int N, hipStream_t st);
 bool   dec32_supported(const LinearWeight& w, int M);
 void   dec32_pick(const LinearWeight& w, int M, int* shape_out, int* splits_out);  // measured table first, then the heuristic
-void   dec32_pick_ex(const LinearWeight& w, int M, int* shape_out, int* splits_out, bool use_table, bool allow_library = true);
+void   dec32_pick_ex(const LinearWeight& w, int M, int* shape_out, int* splits_out, bool use_table);
 // measured dispatch table of the decode linears: key (K, N, M <= 64) -> (shape, splits)
 void   dec32_table_set(int K, int N, int M, int shape, int splits);
 bool   dec32_table_get(int K, int N, int M, int* shape, int* splits);
@@ -190,7 +164,7 @@ int    dec32_table_import(const char* path);
 int    dec32_candidates(const LinearWeight& w, int M, int (*out)[2], int cap);
 int    dec32_m_bucket(int M);  // table key of a forward with M rows: M itself up to 256, then 512, 1024, ... 8192
 int    launch_linear_dec32(const LinearWeight& w, const half_t* x, int ldx, half_t* y, int ldy, int M, bool gated_silu, int shape,
-                           int splits, float* workspace, int* slabs_out, hipStream_t st, const NormTail* tail = nullptr);
+                           int splits, float* workspace, int* slabs_out, hipStream_t st);
 
 // ---- gemm_fp8.hip: fp8 x fp8 linear on v_mfma_f32_32x32x16_fp8_fp8 (activations quantised per row and 128 channels) ---
 size_t p8_bytes(int K, int N);

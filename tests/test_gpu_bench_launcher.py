@@ -20,12 +20,15 @@ def test_bench_two_ranks_on_one_gpu_falls_back_to_the_native_communicator(cuda):
     env = dict(os.environ, GPU_MAX_HW_QUEUES='8', HSA_ENABLE_IPC_MODE_LEGACY='0', TM_P2P_2SHOT_GRID='96')
     env.pop('WORLD_SIZE', None)
     pr = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '6', '--warmup', '3', '--layers', '2',
-                         '--batch', '8', '--prompt-len', '96', '--no-traffic', '--no-cpu-baseline', '--no-full-run', '--profile-steps', '0'],
+                         '--batch', '8', '--prompt-len', '96', '--no-traffic', '--no-cpu-baseline', '--no-full-run', '--profile-steps', '0',
+                         '--allow-shared-devices'],
                         env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=480)
     assert pr.returncode == 0, pr.stderr[-3000:]
-    line = [ln for ln in pr.stdout.strip().splitlines() if ln.startswith('{')][-1]
-    d = json.loads(line)
+    lines = pr.stdout.strip().splitlines()
+    assert len(lines) == 1 and lines[0].startswith('{'), f'stdout must be the JSON line alone (native banners go to stderr): {lines[:3]}'
+    d = json.loads(lines[0])
     cfg = d['config']
+    assert cfg['devices_shared'] is True and cfg['ranks_per_device'] == 2 and 'RANKS SHARE A DEVICE' in d['metric']
     assert d['n_gpus'] == 2 and d['value'] > 0 and cfg['parallelism'] == 'tp2'
     assert cfg['collectives'] == 'native-p2p' and cfg['rccl_ranks'] == 2, cfg
     assert 'RCCL init failed' in cfg['collectives_note']
@@ -33,3 +36,34 @@ def test_bench_two_ranks_on_one_gpu_falls_back_to_the_native_communicator(cuda):
     assert set(cfg['gemm_tilings']) == {'w_qkv', 'wo', 'w1w3', 'w2'} and 'broadcast' in cfg['gemm_dispatch']
     assert 'scaling_note' in d
     assert 'RCCL communicator failed' in pr.stderr
+
+
+@pytest.mark.timeout(900)
+def test_bench_refuses_shared_devices_unless_asked(cuda):
+    """`--gpus 2` on a one-GPU box silently put both ranks on cuda:0 and reported tp2 as if it were a scaling run."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    env.pop('WORLD_SIZE', None)
+    pr = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1', '--layers', '1',
+                         '--batch', '4', '--prompt-len', '64', '--no-traffic', '--no-cpu-baseline', '--no-full-run', '--profile-steps', '0'],
+                        env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert pr.returncode != 0 and 'ranks would share devices' in pr.stderr and pr.stdout.strip() == ''
+
+
+@pytest.mark.timeout(1200)
+def test_bench_eight_ranks_on_one_gpu_bring_up(cuda):
+    """the first real 8-GPU run must not die in bring-up.  All eight ranks of the TP = 8 job (one kv head and
+    four q heads per rank, vocabulary / inter sharded eight ways) as eight processes on the one GPU: launcher, RCCL refusal ->
+    native communicator on every rank, table broadcast, graph capture with the collectives inside, greedy tokens out."""
+    env = dict(os.environ, GPU_MAX_HW_QUEUES='8', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    env.pop('WORLD_SIZE', None)
+    pr = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '8', '--steps', '4', '--warmup', '2', '--layers', '2',
+                         '--batch', '8', '--prompt-len', '96', '--no-traffic', '--no-cpu-baseline', '--no-full-run', '--profile-steps', '0',
+                         '--allow-shared-devices', '--tune', '0'],
+                        env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=1100)
+    assert pr.returncode == 0, pr.stderr[-3000:]
+    lines = pr.stdout.strip().splitlines()
+    assert len(lines) == 1, lines[:3]
+    d = json.loads(lines[0])
+    cfg = d['config']
+    assert d['n_gpus'] == 8 and d['value'] > 0 and cfg['parallelism'] == 'tp8' and cfg['ranks_per_device'] == 8
+    assert cfg['collectives'] == 'native-p2p' and cfg['rccl_ranks'] == 8, cfg

@@ -31,10 +31,10 @@ def test_library_exports_every_declared_symbol():
     assert lib.tm_kv_layer_size(1, 128, 64, 4) == 8704             # 70B / TP8 per rank
 
 
-def _pick(lib, K, N, M, table=0, library=False):
-    """the fused kernels' dispatch unless library=True (then: as a caller with the library path's workspace sees it)"""
+def _pick(lib, K, N, M, table=0):
+    """the dispatch of the P32 kernels: (shape, splits)"""
     sh, sp = _ffi.C.c_int(-1), _ffi.C.c_int(-1)
-    _ffi.check(lib.tm_debug_pick_tiling(K, N, M, table | (0 if library else 2), _ffi.C.byref(sh), _ffi.C.byref(sp)))
+    _ffi.check(lib.tm_debug_pick_tiling(K, N, M, table, _ffi.C.byref(sh), _ffi.C.byref(sp)))
     return sh.value, sp.value
 
 
@@ -72,15 +72,13 @@ def test_decode_gemm_heuristic_equals_the_measured_winners(tmp_path):
     assert lib.tm_gemm_import(str(f).encode()) == 0
     assert _pick(lib, 5120, 5120, 400, table=1) == (4, 3) and _pick(lib, 5120, 5120, 512, table=1) == (4, 3)
     assert _pick(lib, 5120, 5120, 600, table=1) == _pick(lib, 5120, 5120, 600, table=0)
-    # compute-bound forwards: dequantise + the vendor library's fp16 GEMM from 2048 rows on when it is loadable
-    # (profiles/r03_prefill_gemm_vs_library.txt); a table entry naming it needs the library as well
-    if lib.tm_f16_library_available():
-        assert [_pick(lib, 4096, 28672, m, library=True) for m in (1024, 2048, 8192)] == [(5, 1), (10, 1), (10, 1)]
-        f.write_text('5120 5120 1024 10 1\n5120 5120 256 10 1\n')     # second line: not a prefill size class, ignored
-        assert lib.tm_gemm_import(str(f).encode()) == 0
-        assert _pick(lib, 5120, 5120, 700, table=1, library=True) == (10, 1)
-        assert _pick(lib, 5120, 5120, 700, table=1) == _pick(lib, 5120, 5120, 700, table=0)
-        assert _pick(lib, 5120, 5120, 256, table=1, library=True)[0] != 10
+    # round 4: shapes 11 (loader / consumer decode kernel) and 12 (256 x 256 prefill tile) are importable for their row ranges;
+    # shape 10 (round 3's vendor-library path) no longer exists and is ignored
+    f.write_text('5120 5120 64 11 2\n5120 5120 1024 12 1\n5120 5120 2048 10 1\n5120 5120 128 11 1\n5120 5120 64 12 1\n')
+    assert lib.tm_gemm_import(str(f).encode()) == 0
+    assert _pick(lib, 5120, 5120, 64, table=1) == (11, 2) and _pick(lib, 5120, 5120, 1000, table=1) == (12, 1)
+    assert _pick(lib, 5120, 5120, 2048, table=1) == _pick(lib, 5120, 5120, 2048, table=0)
+    assert _pick(lib, 5120, 5120, 128, table=1) == _pick(lib, 5120, 5120, 128, table=0)
 
 
 def test_gemm_dispatch_table_import(tmp_path):

@@ -65,6 +65,10 @@ def main():
                 nt, waves = 2, 8               # round-1 prefill tile: 8 waves x 2 tiles, 128-row blocks
             elif variant == 'auto':
                 nt, waves = 0, 0               # the library's own pick (measured table, then the heuristic)
+            elif variant == 'p256':
+                waves = 0x200 | 12             # 256 x 256 prefill tiles, dequant through LDS (gemm_prefill.hip)
+            elif variant == 'lib':
+                waves = 0x200 | 10             # dequantise + vendor fp16 GEMM (probe only)
             elif variant == 'lc':
                 waves = 0x200 | 11             # loader / consumer kernel (gemm_decode_lc.hip)
             elif variant.startswith('d'):
@@ -104,7 +108,7 @@ def main():
             return float(np.median(ts)), float(ts.min())
 
         for variant in args.variants.split(','):
-            sp_list = [int(v) for v in args.splits.split(',')] if (variant.startswith('d') or variant == 'lc') else [0]
+            sp_list = [int(v) for v in args.splits.split(',')] if (variant.startswith('d') or variant in ('lc', 'p256')) else [0]
             for sp in sp_list:
                 try:
                     med, mn = run(variant, sp)

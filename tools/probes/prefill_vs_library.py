@@ -63,25 +63,24 @@ def main():
             st = torch.cuda.current_stream().cuda_stream
 
             sh, sp = C.c_int(), C.c_int()
-            _ffi.check(tm.tm_debug_pick_tiling(K, N, M, 2, C.byref(sh), C.byref(sp)))     # the fused kernels' own heuristic
+            _ffi.check(tm.tm_debug_pick_tiling(K, N, M, 0, C.byref(sh), C.byref(sp)))     # the library's own heuristic
 
             def ours():
                 _ffi.check(tm.tm_linear_forward(h, x.data_ptr(), K, y.data_ptr(), y.shape[1], M, gated, 0, sp.value, 0x200 | sh.value,
                                                 ws.data_ptr(), st))
             out = torch.empty((M, N), dtype=torch.float16, device='cuda')
             t_ours = timed(ours, args.iters)
-            ws_l = torch.zeros(tm.tm_linear_workspace(h, M), dtype=torch.uint8, device='cuda')
 
-            def ours_lib():
-                _ffi.check(tm.tm_linear_forward(h, x.data_ptr(), K, y.data_ptr(), y.shape[1], M, gated, 0, 1, 0x200 | 10, ws_l.data_ptr(), st))
-            t_lib = timed(ours_lib, args.iters) if tm.tm_f16_library_available() and M >= 512 else float('nan')
+            def ours_p256():
+                _ffi.check(tm.tm_linear_forward(h, x.data_ptr(), K, y.data_ptr(), y.shape[1], M, gated, 0, 1, 0x200 | 12, ws.data_ptr(), st))
+            t_lib = timed(ours_p256, args.iters) if M >= 256 and N >= 256 else float('nan')
             t_nn = timed(lambda: torch.matmul(x, w_kn, out=out), args.iters)
             t_nt = timed(lambda: torch.matmul(x, w_nk.t(), out=out), args.iters)
             fl = 2.0 * M * K * N
             print(f'{name:8s} M={M:5d} K={K:6d} N={N:6d}  fused W4A16 {t_ours:8.1f} us {fl / t_ours / 1e6:7.1f} TF/s | '
-                  f'dequant + library{" + SiLU pass" if gated else ""} (shape 10) {t_lib:8.1f} us {fl / t_lib / 1e6:7.1f} TF/s | '
+                  f'256 x 256 tile (shape 12) {t_lib:8.1f} us {fl / t_lib / 1e6:7.1f} TF/s | '
                   f'library fp16 NN {t_nn:8.1f} us {fl / t_nn / 1e6:7.1f} TF/s | NT {t_nt:8.1f} us {fl / t_nt / 1e6:7.1f} TF/s', flush=True)
-            del x, y, ws, out, ws_l
+            del x, y, ws, out
         tm.tm_linear_destroy(h)
         del w_kn, w_nk
         torch.cuda.empty_cache()
