@@ -1,0 +1,8 @@
+#!/bin/bash
+# round 4, call 10: 256 x 256 prefill tile with 4 waves of 128 x 128 (one per SIMD, AGPR accumulators) vs 8 waves of 128 x 64
+TM_PRE256_WAVES=4 timeout 600 python -m pytest tests/test_gpu_ops.py tests/test_gpu_fullsize.py -q -m gpu -x -k "prefill_tiles or odd_stage or prefill_full_size" 2>&1 | tail -3
+for nw in 8 4; do
+  echo "== TM_PRE256_WAVES=$nw"
+  TM_PRE256_WAVES=$nw timeout 300 python tools/bench_gemm.py --m 8192 --variants d5,p256 --splits 1 --reps 10 2>&1 | grep -v "^$\|amdgpu.ids"
+done
+TM_PRE256_WAVES=4 timeout 200 python tools/trace_dec32.py 14336 4096 8192 0 12 1 2>&1 | tail -2 | cut -c1-200
