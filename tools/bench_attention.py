@@ -92,8 +92,8 @@ def main():
             print(f'  CUs used {len(per_cu)}; workgroups per CU histogram {occ.tolist()}; mean end of CUs with 1 / 2 / 3+ WGs: ' +
                   ' / '.join(f"{np.mean([np.max(v) for v in per_cu.values() if (len(v) if len(v) < 3 else 3) == k]) if any((len(v) if len(v) < 3 else 3) == k for v in per_cu.values()) else float('nan'):.1f}" for k in (1, 2, 3)))
             order = np.argsort(live[:, 0])
-            q = len(order) // 4
-            print('  end time by launch-order quartile: ' + '  '.join(f'{end[order[i * q:(i + 1) * q]].mean():5.1f}' for i in range(4)))
+            nq4 = len(order) // 4
+            print('  end time by launch-order quartile: ' + '  '.join(f'{end[order[i * nq4:(i + 1) * nq4]].mean():5.1f}' for i in range(4)))
         return
     for splits in [int(s) for s in a.splits.split(',')]:
         ws = torch.empty(max(1, tm.tm_decode_attention_workspace(B, Hq, splits)), dtype=torch.uint8, device='cuda')

@@ -35,6 +35,22 @@ def main():
         print('\ncounters (mean per dispatch):')
         for r in crow:
             print(f'{r[0][:72]:72s} {r[1]:28s} {r[2]:16.1f} n={r[3]}')
+    # the same per (kernel, workgroups): separates the launches of one template (the four decode linears, tuner candidates) --
+    # VERDICT r03 item 1a.  The counters view carries the dispatch's total grid / workgroup sizes under version-dependent names.
+    try:
+        cols = [r[1] for r in cur.execute("pragma table_info(counters_collection)")]
+    except sqlite3.Error:
+        cols = []
+    gcol = next((c for c in ('grid_size', 'grid_size_x', 'grid_x') if c in cols), None)
+    wcol = next((c for c in ('workgroup_size', 'workgroup_size_x', 'workgroup_x') if c in cols), None)
+    if crow and gcol and wcol:
+        rows = list(cur.execute(f"select kernel_name, cast({gcol} / {wcol} as int), counter_name, avg(value), count(*) from counters_collection "
+                                f"where kernel_name like ? group by 1, 2, 3 order by 1, 2, 3", (like,)))
+        print(f'\ncounters by (kernel, workgroups = {gcol} / {wcol}) (mean per dispatch):')
+        for r in rows:
+            print(f'{r[0][:60]:60s} wgs={r[1]:<6d} {r[2]:28s} {r[3]:16.1f} n={r[4]}')
+    elif crow:
+        print('\n(no grid columns in counters_collection; columns: ' + ', '.join(cols) + ')')
 
 
 if __name__ == '__main__':
