@@ -143,9 +143,7 @@ __device__ __forceinline__ void expand_u4x32(u32x4 w, u32x4& a, u32x4& b)
 // BITS = 8: the cache bytes are the codes.  BITS = 4: the block is half as large in HBM; the nibbles are expanded to
 // one byte per code when the block is written to the wave's LDS image, everything after that is the int8 path
 // (scales / zeros are per token either way, quantization.h:316-366).
-// POL (cache policy of the KV stream; TM_ATTN_POL, experiment): 0 = global loads, non-temporal (the measured default);
-// 1..5 = the same bytes through a buffer descriptor with aux = nt / sc1 / sc0 sc1 / sc1 nt / none.
-template<bool FUSED, int BITS, int POL = 0>
+template<bool FUSED, int BITS>
 __global__ __launch_bounds__(256, 2) void decode_attention_i8_mfma_kernel(DecodeAttnParams p, int head_chunks, int hpw)
 {
     static_assert(BITS == 8 || BITS == 4, "int8 / int4 KV");
@@ -252,19 +250,8 @@ __global__ __launch_bounds__(256, 2) void decode_attention_i8_mfma_kernel(Decode
             const int off = BITS == 8 ? min(row, last) * 128 + (lane & 7) * 16 : min(row, last) * 64 + (lane & 3) * 16;
             // non-temporal: every cache byte is read ONCE per launch by ONE workgroup -- measured (tools/r03_calls/call8.sh,
             // profiles/r03_attention_nontemporal_loads.txt) 32.4 -> 30.3 us at ctx 1040, 43.3 -> 39.5 us at ctx 1536
-            if constexpr (POL == 0) {
-                kreg[r] = __builtin_nontemporal_load((const u32x4*)(base + koff + off));
-                vreg[r] = __builtin_nontemporal_load((const u32x4*)(base + voff + off));
-            }
-            else {
-                constexpr int  aux = POL == 1 ? 2 : POL == 2 ? 16 : POL == 3 ? 17 : POL == 4 ? 18 : 0;
-                const uint64_t ub  = (uint64_t)base;
-                const uint64_t sb  = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(ub >> 32)) << 32)
-                                    | (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)ub);
-                const auto     rs  = __builtin_amdgcn_make_buffer_rsrc((void*)sb, 0, 0x7fffffff, 0x00020000);
-                kreg[r]            = __builtin_amdgcn_raw_buffer_load_b128(rs, koff + off, 0, aux);
-                vreg[r]            = __builtin_amdgcn_raw_buffer_load_b128(rs, voff + off, 0, aux);
-            }
+            kreg[r]       = __builtin_nontemporal_load((const u32x4*)(base + koff + off));
+            vreg[r]       = __builtin_nontemporal_load((const u32x4*)(base + voff + off));
         }
         kpr = *(const uint32_t*)(base + kpoff + lane * 4);
         vpr = *(const uint32_t*)(base + vpoff + lane * 4);
@@ -615,10 +602,6 @@ int launch_decode_attention_i8_mfma(const DecodeAttnParams& p, hipStream_t st)
         hpw /= d;
     }
     const int chunks = group / hpw;
-    static const int pol = [] {
-        const char* v = getenv("TM_ATTN_POL");
-        return v ? atoi(v) : 0;
-    }();
     dim3      grid(p.cache.layout.kv_heads * chunks, p.batch, p.splits);
     // 4 wave-private images (+ 4 KB q exchange for the fused prologue); the merge buffers overlay the images
     static_assert(4 * kWaveLds + 4096 > 4 * 16 * 128 * 4 + 4 * 16 * 2 * 4, "merge buffers must fit");
@@ -637,13 +620,7 @@ int launch_decode_attention_i8_mfma(const DecodeAttnParams& p, hipStream_t st)
             decode_attention_i8_mfma_kernel<true, 4><<<grid, 256, lds, st>>>(p, chunks, hpw);
         }
         else {
-            switch (pol) {
-#define ATTN_POL(v) case v: if (const int rc_ = ensure_dynamic_lds((const void*)decode_attention_i8_mfma_kernel<true, 8, v>, lds)) return rc_; \
-                            decode_attention_i8_mfma_kernel<true, 8, v><<<grid, 256, lds, st>>>(p, chunks, hpw); break
-                ATTN_POL(1); ATTN_POL(2); ATTN_POL(3); ATTN_POL(4); ATTN_POL(5);
-#undef ATTN_POL
-                default: decode_attention_i8_mfma_kernel<true, 8><<<grid, 256, lds, st>>>(p, chunks, hpw);
-            }
+            decode_attention_i8_mfma_kernel<true, 8><<<grid, 256, lds, st>>>(p, chunks, hpw);
         }
     }
     else {
@@ -651,13 +628,7 @@ int launch_decode_attention_i8_mfma(const DecodeAttnParams& p, hipStream_t st)
             decode_attention_i8_mfma_kernel<false, 4><<<grid, 256, lds, st>>>(p, chunks, hpw);
         }
         else {
-            switch (pol) {
-#define ATTN_POL(v) case v: if (const int rc_ = ensure_dynamic_lds((const void*)decode_attention_i8_mfma_kernel<false, 8, v>, lds)) return rc_; \
-                            decode_attention_i8_mfma_kernel<false, 8, v><<<grid, 256, lds, st>>>(p, chunks, hpw); break
-                ATTN_POL(1); ATTN_POL(2); ATTN_POL(3); ATTN_POL(4); ATTN_POL(5);
-#undef ATTN_POL
-                default: decode_attention_i8_mfma_kernel<false, 8><<<grid, 256, lds, st>>>(p, chunks, hpw);
-            }
+            decode_attention_i8_mfma_kernel<false, 8><<<grid, 256, lds, st>>>(p, chunks, hpw);
         }
     }
     TM_HIP_CHECK(hipGetLastError());
