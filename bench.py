@@ -439,7 +439,8 @@ def main():
                                    'path was validated on one device only (two processes on one GPU over the native communicator, 1-rank RCCL, '
                                    'gloo world-size-2 CPU tests)')
         if args.model != 'llama3_8b':
-            out['metric'] = f'decode tokens/sec, {args.model} W4A16 {kv_name} batch {B} (NOT the headline config)'
+            out['metric'] = (f'decode tokens/sec, {args.model} {"FP8 block-scaled weights" if weight_type == 2 else "W4A16"} {kv_name} '
+                             f'batch {B} (NOT the headline config)')
             out['config']['workload'] = out['config']['workload'].replace('Llama-3-8B', args.model)
         if emu > 1:
             out['metric'] = (f'PER-RANK EMULATION of TP={emu} on one GPU (one rank\'s shard, 1-rank collectives): '
@@ -468,6 +469,17 @@ def main():
                                     'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
                                     'frac': round(wbytes / (gemm_ms / 1e3) / 1e9 / HBM_PEAK_GBPS, 4),
                                     'bytes_per_step': int(wbytes)}
+            # matrix-pipe view of the same four GEMMs (north_star: "MFMA utilisation for the dequant-GEMM against gfx950 peak"):
+            # 2 * B * (quantised linear parameters) flop per step over their time, against the dense fp16 peak of 2.5 PFLOP/s
+            lin_params = model['layers'] * (H_ * (hq_l + 2 * hkv_l) * D_ + hq_l * D_ * H_ + 3 * H_ * I_l) if not model.get('moe_experts') else 0
+            if lin_params:
+                tf = 2.0 * B * lin_params / (gemm_ms / 1e3) / 1e12
+                out['gemm_roofline']['mfma_tflops'] = round(tf, 1)
+                out['gemm_roofline']['mfma_util'] = round(tf / 2500.0, 4)
+                # prefill: all linear flops of the prompt tokens over the WHOLE prefill time (attention, norms, KV stores included):
+                # a lower bound of the prefill GEMMs' matrix-pipe utilisation
+                tfp = 2.0 * B * S * lin_params / prefill_s / 1e12
+                out['prefill_mfma_util'] = {'linear_tflops_over_whole_prefill': round(tfp, 1), 'frac_of_2500': round(tfp / 2500.0, 4)}
             if gemm_traffic:
                 # HBM-side bytes of the four decode GEMM launches of one layer (same child PMC pass as roofline.traffic) against the
                 # algorithmic weight bytes of a layer: > 1 would mean weights fetched more than once
