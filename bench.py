@@ -216,6 +216,7 @@ def main():
     ap.add_argument('--allow-shared-devices', action='store_true',
                     help='let several ranks share one GPU when the box has fewer GPUs than --gpus (launcher / bring-up tests only: the '
                          'record then says so and is not a scaling result)')
+    ap.add_argument('--decode-splits', type=int, default=0, help='split-KV count of the decode attention (0: the engine\'s heuristic)')
     ap.add_argument('--emulate-tp', type=int, default=0,
                     help='SURVEY 8(e) on a 1-GPU box: run ONE rank\'s shard of a TP=N job (heads / inter / vocab divided by N, '
                          'collectives through a 1-rank RCCL communicator): per-rank kernel time only, labelled as such')
@@ -268,7 +269,7 @@ def main():
     weight_type = int(model.pop('weight_type', 0))
     eng = Engine.from_model_config(_Cfg(model), weight_type=weight_type, tp=world, rank=rank, device=local_dev, max_batch_size=B,
                                    session_len=S + max_new + 1, quant_policy=args.quant_policy,
-                                   max_prefill_token_num=8192, use_graph=0 if args.no_graph else 1)
+                                   max_prefill_token_num=8192, use_graph=0 if args.no_graph else 1, decode_splits=args.decode_splits)
     dog = Watchdog(world > 1, rank)
     comm_note = ''
     if world > 1:
@@ -302,7 +303,7 @@ def main():
     # measured GEMM dispatch (start-up work like the reference's TM_GEMM_TUNE warm-up: not in any timed region).  tp > 1: rank 0
     # times the candidates on ITS shard shapes (all ranks hold the same shapes) and the table is broadcast, so that every rank
     # runs identical tilings (a rank-local winner could differ by noise and desynchronise the ranks' step times)
-    tuned = bool(args.tune) and emu <= 1 and B <= 256 and not child
+    tuned = bool(args.tune) and B <= 256 and not child
     if tuned:
         dog.arm('GEMM tuning', 600)
         import tempfile

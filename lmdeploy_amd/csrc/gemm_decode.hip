@@ -735,7 +735,36 @@ __global__ __launch_bounds__(512) void gemm_pre64_kernel(Dec32Params p)
             // a0(j+1) behind the four that use a1(j).  Back-to-back "dequant block, then MFMA block" (the first version of
             // this kernel, and what hipcc emits on its own) measured additive: loop 102 us = 55 us of MFMA + 42 us of
             // everything else (profiles/r02_pre64_phase_traces.txt).
-            half8_t a0 = dequant8_p32(ring[u][0][0][0], s2[0], z2[0], m1024, m64), a1;
+            // experiments (TM_D32_ABL, results are garbage; profiles/r04_gemm_experiments_session2.txt): 8 = the raw codes as fp16
+            // subnormals on the matrix pipe instead of the dequantised operand, 16 = the accumulators rescaled once per k-block
+            // (what a per-group scale applied on the accumulator side would cost)
+            auto dq = [&](uint32_t w, int nb) __attribute__((always_inline)) {
+                if constexpr (ABL & 8) {
+                    const uint32_t m = 0x000f000fu;
+                    return bit_cast<half8_t>(u32x4{w & m, (w >> 4) & m, (w >> 8) & m, (w >> 12) & m});
+                }
+                else {
+                    return dequant8_p32(w, s2[nb], z2[nb], m1024, m64);
+                }
+            };
+            if constexpr (ABL & 16) {
+                typedef float floatx2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) {
+                    const float   rt = 1.0f + (float)s2[nb][0];
+                    const floatx2 rr = {rt, rt};
+#pragma unroll
+                    for (int h = 0; h < MH; ++h) {
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) {
+                            floatx2 v         = {acc[nb][h][2 * r], acc[nb][h][2 * r + 1]};
+                            v                 = v * rr;
+                            acc[nb][h][2 * r] = v[0], acc[nb][h][2 * r + 1] = v[1];
+                        }
+                    }
+                }
+            }
+            half8_t a0 = dq(ring[u][0][0][0], 0), a1;
             static_for<8>([&](auto J) {
                 constexpr int  j  = decltype(J)::value;
                 half8_t(&cur)[MH] = (j & 1) ? f1 : f0;
@@ -744,7 +773,7 @@ __global__ __launch_bounds__(512) void gemm_pre64_kernel(Dec32Params p)
                     rd(nxt, j + 1);
                 }
                 wt(cur, std::integral_constant<int, (j + 1 < 8) ? MH : 0>{});
-                a1 = dequant8_p32(ring[u][1][j >> 2][j & 3], s2[1], z2[1], m1024, m64);
+                a1 = dq(ring[u][1][j >> 2][j & 3], 1);
 #pragma unroll
                 for (int h = 0; h < MH; ++h) {
                     if constexpr (ABL & 2) {
@@ -755,7 +784,7 @@ __global__ __launch_bounds__(512) void gemm_pre64_kernel(Dec32Params p)
                     }
                 }
                 if constexpr (j + 1 < 8) {
-                    a0 = dequant8_p32(ring[u][0][(j + 1) >> 2][(j + 1) & 3], s2[0], z2[0], m1024, m64);
+                    a0 = dq(ring[u][0][(j + 1) >> 2][(j + 1) & 3], 0);
                 }
 #pragma unroll
                 for (int h = 0; h < MH; ++h) {
@@ -878,6 +907,8 @@ static int launch_dec32_shape(const Dec32Params& p, dim3 grid, int shape, hipStr
         if (shape == 5) {  // 128 x 512 tile, two weight fragments per x-fragment read (gemm_pre64_kernel)
 #ifdef TM_EXPERIMENTS
             if (abl == 2) return launch_pre64_one<2>(p, grid, st);  // timing: no MFMA
+            if (abl == 8) return launch_pre64_one<8>(p, grid, st);  // timing: raw codes on the matrix pipe
+            if (abl == 24) return launch_pre64_one<24>(p, grid, st);  // + accumulators rescaled per k-block
 #endif
             return launch_pre64_one<0>(p, grid, st);
         }
@@ -1166,14 +1197,18 @@ void dec32_pick_ex(const LinearWeight& w, int M, int* shape_out, int* splits_out
     // wo 14.3 -> 10.5 us, w2 18.6 -> 17.1 us, w_qkv 12.2 -> 9.8 us; profiles/r02_gemm_tune_measurements.txt); with
     // TM_GEMM_TUNE=1 the engine measures instead of trusting this rule.  The two row halves of a shape-6 column tile are
     // gridDim.x * gridDim.y workgroups apart -- the same XCD when that is a multiple of 8: the second reader hits L2.
+    // Round 4: the same rule holds for the TP-shard shapes (one rank of TP = 2 / 8 of Llama-3-8B / -70B: N = 768 .. 8192, K = 512 ..
+    // 8192, ragged k-block counts) -- the tuner picks shape 6 for every one of them (profiles/r04_gemm_experiments_session2.txt,
+    // call23: w2 1792 x 4096 6.2 us against 10.6 for the old fall-back, w_qkv 4096 x 768 7.7 against 10.8) -- with slices of at
+    // least 16 k-blocks: below that a slab boundary costs more than the workgroups it adds.
     static const int rowhalf = env_int2("TM_D32_ROWHALF", 1);
-    if (rowhalf && env_shape < 0 && M > 32 && M <= 64 && KB % 4 == 0 && ncg % 16 == 0 && ncg >= 64 && ncg <= 256) {
+    if (rowhalf && env_shape < 0 && M > 32 && M <= 64 && ncg >= 8 && ncg <= 256) {
         const int nshape = KB <= 64 ? 6 : 3;
-        const int tiles  = (ncg / 2) * (nshape == 6 ? 2 : 1);
+        const int tiles  = ((ncg + 1) / 2) * (nshape == 6 ? 2 : 1);
         int       sp     = 1;
         for (int s2 = 2; s2 <= 16 && tiles * s2 <= 256; ++s2) {
             const int per = ((KB + s2 - 1) / s2 + 3) / 4 * 4;
-            if ((KB + per - 1) / per == s2 && per >= 8) {
+            if ((KB + per - 1) / per == s2 && per >= 16) {
                 sp = s2;
             }
         }

@@ -29,6 +29,15 @@
 
 namespace tmk {
 
+typedef float floatx2 __attribute__((ext_vector_type(2)));
+
+// experiment (TM_D32_ABL 0x40): the raw codes as fp16 subnormals q * 2^-24, no scale / zero point in the operand
+__device__ __forceinline__ half8_t raw8_p32(uint32_t w)
+{
+    const uint32_t m = 0x000f000fu;
+    return bit_cast<half8_t>(u32x4{w & m, (w >> 4) & m, (w >> 8) & m, (w >> 12) & m});
+}
+
 template<int MH, int PFS, int ABL = 0>
 __global__ __launch_bounds__(768) void gemm_dec_lc_kernel(Dec32Params p)
 {
@@ -97,7 +106,8 @@ __global__ __launch_bounds__(768) void gemm_dec_lc_kernel(Dec32Params p)
             const int kbi = pc / (ROWS / 4);
             const int row = (pc % (ROWS / 4)) * 4 + (lane >> 4);
             const int ch  = (lane & 15) ^ (row & 15);
-            doff[r]       = (min(row, Mloc - 1) * p.ldx + ch * 8) * 2 + kbi * 256;
+            doff[r]       = (ABL & 0x20) ? (kbi * ROWS + row) * 256 + ch * 16  // experiment: x k-block major ([kb][row][128])
+                                          : (min(row, Mloc - 1) * p.ldx + ch * 8) * 2 + kbi * 256;
         }
         // one DMA instruction per piece; M0 = LDS byte address of the piece (saved / restored: the compiler owns M0)
 #define LC_DMA_X(t, buf)                                                                                          \
@@ -105,7 +115,7 @@ __global__ __launch_bounds__(768) void gemm_dec_lc_kernel(Dec32Params p)
     {                                                                                                             \
         unsigned       keep_;                                                                                     \
         const unsigned dst_ = lds0 + (buf)*STG + (r * NLOAD + lw) * 1024;                                         \
-        const int      so_  = (kb0 + (t)*S) * 256;                                                                \
+        const int      so_  = (kb0 + (t)*S) * ((ABL & 0x20) ? ROWS * 256 : 256);                                  \
         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"                                       \
                      "buffer_load_dwordx4 %1, %2, %4 offen lds\n\ts_mov_b32 m0, %0"                               \
                      : "=&s"(keep_)                                                                               \
@@ -207,7 +217,23 @@ __global__ __launch_bounds__(768) void gemm_dec_lc_kernel(Dec32Params p)
                 // Two dequantised fragments live (a0: first unit, a1: second).  a1(j) is built behind the MFMAs that use
                 // a0(j), a0(j+1) behind those that use a1(j): an MFMA occupies the matrix pipe for 32 cycles but the issue
                 // port for 4, so ~6 VALU ops fit behind each one.
-                half8_t a0 = dequant8_p32(ring[u][0][0][0], s2[0], z2[0], m1024, m64), a1;
+                half8_t a0 = (ABL & 0x40) ? raw8_p32(ring[u][0][0][0]) : dequant8_p32(ring[u][0][0][0], s2[0], z2[0], m1024, m64), a1;
+                if constexpr (ABL & 0x80) {  // experiment: the accumulators move to this group's scale (one packed multiply per pair)
+#pragma unroll
+                    for (int c = 0; c < NCW; ++c) {
+                        const float   rt = 1.0f + (float)s2[c][0];
+                        const floatx2 rr = {rt, rt};
+#pragma unroll
+                        for (int h = 0; h < MH; ++h) {
+#pragma unroll
+                            for (int r = 0; r < 8; ++r) {
+                                floatx2 v        = {acc[c][h][2 * r], acc[c][h][2 * r + 1]};
+                                v                = v * rr;
+                                acc[c][h][2 * r] = v[0], acc[c][h][2 * r + 1] = v[1];
+                            }
+                        }
+                    }
+                }
                 static_for<8>([&](auto J) {
                     constexpr int  j  = decltype(J)::value;
                     half8_t(&cur)[MH] = (j & 1) ? f1 : f0;
@@ -227,6 +253,9 @@ __global__ __launch_bounds__(768) void gemm_dec_lc_kernel(Dec32Params p)
                     if constexpr (ABL & 1) {
                         a1 = bit_cast<half8_t>(ring[u][1][j >> 2]);
                     }
+                    else if constexpr (ABL & 0x40) {
+                        a1 = raw8_p32(ring[u][1][j >> 2][j & 3]);
+                    }
                     else {
                         a1 = dequant8_p32(ring[u][1][j >> 2][j & 3], s2[1], z2[1], m1024, m64);
                     }
@@ -242,6 +271,9 @@ __global__ __launch_bounds__(768) void gemm_dec_lc_kernel(Dec32Params p)
                     if constexpr (j + 1 < 8) {
                         if constexpr (ABL & 1) {
                             a0 = bit_cast<half8_t>(ring[u][0][(j + 1) >> 2]);
+                        }
+                        else if constexpr (ABL & 0x40) {
+                            a0 = raw8_p32(ring[u][0][(j + 1) >> 2][(j + 1) & 3]);
                         }
                         else {
                             a0 = dequant8_p32(ring[u][0][(j + 1) >> 2][(j + 1) & 3], s2[0], z2[0], m1024, m64);
@@ -400,7 +432,7 @@ int launch_dec_lc(const Dec32Params& p, dim3 grid, hipStream_t st)
     if (p.M > 32) {
         switch (abl) {
 #define LC_CASE(v) case v: return launch_lc_one<2, 3, v>(p, grid, st)
-            LC_CASE(1); LC_CASE(2); LC_CASE(4); LC_CASE(8); LC_CASE(16); LC_CASE(7); LC_CASE(15); LC_CASE(24); LC_CASE(31);
+            LC_CASE(0x20); LC_CASE(0x40); LC_CASE(0xc0); LC_CASE(0xe0); LC_CASE(1); LC_CASE(2); LC_CASE(4); LC_CASE(8); LC_CASE(16); LC_CASE(7); LC_CASE(15); LC_CASE(24); LC_CASE(31);
 #undef LC_CASE
             default: break;
         }

@@ -48,7 +48,11 @@ def test_decode_gemm_heuristic_equals_the_measured_winners(tmp_path):
     assert _pick(lib, 14336, 4096, 64) == (3, 4)      # w2: 64-column tiles x 4 slabs
     assert _pick(lib, 4096, 28672, 64) == (0, 1)      # w1w3: 128-column tiles, 224 workgroups
     assert _pick(lib, 4096, 6144, 33) == (6, 1) and _pick(lib, 4096, 6144, 32)[0] == 0     # one row block: the older rule
-    assert _pick(lib, 8192, 1280, 64)[0] == 0         # a 70B / TP8 rank's narrow projection
+    # round 4 (profiles/r04_gemm_experiments_session2.txt, call23): one rank's shard shapes of TP = 8 -- the tuner's winners
+    assert _pick(lib, 8192, 1280, 64) == (6, 4)       # Llama-3-70B w_qkv shard (was shape 0 x 16: 14.3 -> 9.5 us)
+    assert _pick(lib, 1792, 4096, 64) == (6, 1)       # Llama-3-8B w2 shard, 14 k-blocks (was shape 0 x 4: 10.6 -> 6.2 us)
+    assert _pick(lib, 512, 4096, 64) == (6, 1) and _pick(lib, 3584, 8192, 64) == (6, 1)     # wo (8B), w2 (70B) shards
+    assert _pick(lib, 4096, 768, 64)[0] == 6 and _pick(lib, 4096, 3584, 64)[0] == 6         # w_qkv, w1w3 (8B) shards
     assert _pick(lib, 4096, 6144, 128)[0] == 4 and _pick(lib, 4096, 6144, 8192)[0] == 5    # 128-row tiles beyond 64 rows
     for K, N in ((4096, 3072), (2048, 4096), (7168, 4096), (6144, 8192), (16384, 6144)):   # tp shards / 20B shapes: valid slicing
         sh, sp = _pick(lib, K, N, 64)

@@ -72,7 +72,8 @@ def main():
             elif variant == 'lc':
                 waves = 0x200 | 11             # loader / consumer kernel (gemm_decode_lc.hip)
             elif variant.startswith('d'):
-                shape = int(variant[1])
+                digits = ''.join(c for c in variant[1:3] if c.isdigit())   # d0 .. d9, d11 .. d17
+                shape = int(digits)
                 waves = 0x200 | shape
                 if 'pf4' in variant:
                     env['TM_D32_PF'] = '4'
