@@ -1666,16 +1666,35 @@ static void setup_decode(tm_engine* e, int batch)
     const tm_engine_config& c = e->cfg;
     int splits = c.decode_splits;
     if (splits <= 0) {
-        int group = e->q_heads / e->kv_heads, hpw = 1;
-        for (int cand = 4; cand >= 1; --cand) {
-            if (group % cand == 0) {
-                hpw = cand;
-                break;
+        // int8 / int4 KV run the MFMA kernel: up to 16 query heads of a kv head per workgroup (launch_decode_attention_i8_mfma),
+        // four waves = four cache blocks in flight per workgroup -- one workgroup per CU is enough: measured at one rank's head
+        // count of TP = 8 (profiles/r04_gemm_experiments_session2.txt, call25): 64 x 4 workgroups 1.485 ms per step against
+        // 1.547 .. 1.587 with 64 x 8 (Llama-3-8B shard), 5.06 against 5.26 (Llama-3-70B shard).  fp16 KV (VALU kernel, <= 4
+        // heads per workgroup): two workgroups per CU as before.
+        const bool mfma  = e->cfg.quant_policy == 8 || e->cfg.quant_policy == 4;
+        const int  group = e->q_heads / e->kv_heads;
+        int        hpw   = 1;
+        if (mfma) {
+            hpw = group;
+            while (hpw > 16) {
+                int d = 2;
+                while (hpw % d) {
+                    ++d;
+                }
+                hpw /= d;
+            }
+        }
+        else {
+            for (int cand = 4; cand >= 1; --cand) {
+                if (group % cand == 0) {
+                    hpw = cand;
+                    break;
+                }
             }
         }
         const int wgs = e->kv_heads * (group / hpw) * batch;
         splits        = 1;
-        while (wgs * splits < 512 && splits < 16) {
+        while (wgs * splits < (mfma ? 256 : 512) && splits < 16) {
             splits *= 2;
         }
     }
