@@ -395,10 +395,11 @@ def main():
     tilings, prefill_tilings = {}, {}
     pf_rows = min(B * S, 8192)     # rows of a prefill forward of this run (max_prefill_token_num chunks)
     if weight_type == 0 and not model.get('moe_experts') and B <= 256:
-        for name, (kk, nn) in dict(w_qkv=(H_, (hq_l + 2 * hkv_l) * D_), wo=(hq_l * D_, H_), w1w3=(H_, 2 * I_l), w2=(I_l, H_)).items():
-            tilings[name] = dict(zip(('shape', 'splits'), Engine.pick_tiling(kk, nn, B)))
+        for role, (name, (kk, nn)) in enumerate(dict(w_qkv=(H_, (hq_l + 2 * hkv_l) * D_), wo=(hq_l * D_, H_), w1w3=(H_, 2 * I_l),
+                                                      w2=(I_l, H_)).items(), start=1):
+            tilings[name] = dict(zip(('shape', 'splits'), Engine.pick_tiling(kk, nn, B, role=role)))
             # 4 / 5 = the fused 128-row W4A16 tiles, 12 = the 256 x 256 tile with the dequant through LDS (gemm_prefill.hip)
-            prefill_tilings[name] = dict(zip(('shape', 'splits'), Engine.pick_tiling(kk, nn, pf_rows)))
+            prefill_tilings[name] = dict(zip(('shape', 'splits'), Engine.pick_tiling(kk, nn, pf_rows, role=role)))
     if weight_type != 0 or model.get('moe_experts'):
         # formats other than AWQ u4 / MoE: the weight bytes are what the engine actually streams (packed weights + scales +
         # lm_head); with batch 64 and top-2 of 8 every expert is hit every step

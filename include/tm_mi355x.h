@@ -258,7 +258,9 @@ int tm_p2p_allreduce_norm_2shot(void* const* segs, int tp, int me, void* state, 
  * than 8192 workgroups are not traced; NULL switches it off. */
 int tm_debug_set_gemm_trace(void* dev_buf);
 /* Host-only: the (workgroup shape, split-K) the decode GEMM dispatch picks for a W4A16 linear of K x N at M rows --
- * use_table bit 0: the measured table first (tm_engine_tune_gemm / tm_gemm_import), then the heuristic; clear: heuristic only.
+ * use_table bit 0: the measured table first (tm_engine_tune_gemm / tm_gemm_import), then the heuristic; clear: heuristic only;
+ * bits 8 .. 11: the linear's role -- 0 any, 1 w_qkv, 2 wo, 3 w1w3, 4 w2 (the table is keyed (role, K, N, M): the tuner times each
+ * role with its own consumer kernel; an entry of role 0, e.g. an imported line without a role column, serves every role).
  * Shapes: 0..3 decode tiles (M <= 64), 4 / 5 the 128-row tiles (M > 64), 6..9 shapes 3, 0, 2, 1 on 32-row blocks
  * (gemm_decode.hip), 11 the loader / consumer decode kernel (gemm_decode_lc.hip, M <= 64), 12 the 256 x 256 prefill tile with
  * the weights dequantised once per workgroup tile through LDS (gemm_prefill.hip, M > 64).  (10 was a vendor-library path: gone.) */

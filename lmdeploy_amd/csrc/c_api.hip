@@ -735,8 +735,10 @@ int tm_debug_pick_tiling(int K, int N, int M, int use_table, int* shape, int* sp
     TM_REQUIRE(shape && splits && K > 0 && N > 0 && M > 0, "arguments");
     TM_REQUIRE(K % 128 == 0 && N % 32 == 0, "the decode kernels take K % 128 == 0, N % 32 == 0");
     LinearWeight w{};
-    w.K = K;
-    w.N = N;
+    w.K    = K;
+    w.N    = N;
+    w.role = (use_table >> 8) & 0xf;  // 0 any, 1 w_qkv, 2 wo, 3 w1w3, 4 w2: the measured table is keyed (role, K, N, M)
+    TM_REQUIRE(w.role <= 4, "role 0 .. 4 in bits 8 .. 11 of use_table");
     dec32_pick_ex(w, M, shape, splits, (use_table & 1) != 0);
     return 0;
 }

@@ -377,9 +377,10 @@ static int64_t slot_bytes_linear(const tm_engine* e, int K, int N, const char* p
     return 0;
 }
 
-static void add_linear(tm_engine* e, LinearSlots& l, const std::string& prefix, int K, int N, int type)
+static void add_linear(tm_engine* e, LinearSlots& l, const std::string& prefix, int K, int N, int type, int role = 0)
 {
     l.prefix  = prefix;
+    l.w.role  = role;  // dispatch-table key next to (K, N, M): the tuner times each role with its own consumer
     l.w.K     = K;
     l.w.N     = N;
     l.w.group = e->cfg.model.group_size;
@@ -949,8 +950,8 @@ int tm_engine_create(tm_engine** out, const tm_engine_config* c)
     for (int i = 0; i < m.layers; ++i) {
         const std::string p = "layers." + std::to_string(i);
         Layer&            L = e->layers[i];
-        add_linear(e, L.qkv, p + ".attention.w_qkv", m.hidden, e->qkv_n, m.weight_type);
-        add_linear(e, L.wo, p + ".attention.wo", e->q_heads * e->D, m.hidden, m.weight_type);
+        add_linear(e, L.qkv, p + ".attention.w_qkv", m.hidden, e->qkv_n, m.weight_type, 1);
+        add_linear(e, L.wo, p + ".attention.wo", e->q_heads * e->D, m.hidden, m.weight_type, 2);
         if (m.moe_experts > 0) {
             L.is_moe = true;
             L.ex13.resize(m.moe_experts);
@@ -963,8 +964,8 @@ int tm_engine_create(tm_engine** out, const tm_engine_config* c)
             }
         }
         else {
-            add_linear(e, L.w13, p + ".feed_forward.w1w3", m.hidden, 2 * e->inter, m.weight_type);
-            add_linear(e, L.w2, p + ".feed_forward.w2", e->inter, m.hidden, m.weight_type);
+            add_linear(e, L.w13, p + ".feed_forward.w1w3", m.hidden, 2 * e->inter, m.weight_type, 3);
+            add_linear(e, L.w2, p + ".feed_forward.w2", e->inter, m.hidden, m.weight_type, 4);
         }
         e->slots[p + ".attention_norm.weight"].bytes = (int64_t)m.hidden * 2;
         e->slots[p + ".ffn_norm.weight"].bytes       = (int64_t)m.hidden * 2;
@@ -1303,7 +1304,7 @@ static int tune_decode_gemms(tm_engine* e, int M, bool verbose)
         }
         const LinearWeight& w0 = *ws[0];
         int                 hs, hp;
-        if (dec32_table_get(w0.K, w0.N, M, &hs, &hp)) {
+        if (dec32_table_get(w0.K, w0.N, M, &hs, &hp, r.which + 1)) {
             continue;  // imported / tuned already
         }
         dec32_pick_ex(w0, M, &hs, &hp, false);
@@ -1410,7 +1411,7 @@ static int tune_decode_gemms(tm_engine* e, int M, bool verbose)
             bs = hs;
             bp = hp;
         }
-        dec32_table_set(w0.K, w0.N, M, bs, bp);
+        dec32_table_set(w0.K, w0.N, M, bs, bp, r.which + 1);
         if (verbose) {
             fprintf(stderr, "[tm tune] %-5s K=%d N=%d M=%d -> shape %d splits %d (%.2f us; heuristic shape %d splits %d %.2f us)\n", r.name, w0.K,
                     w0.N, M, bs, bp, best, hs, hp, heur);

@@ -1010,19 +1010,22 @@ bool dec32_serves_every_m(int K, int N)
 // key is (K, N, M) of a decode-batch linear, the value its workgroup shape and split-K count; the engine's tuner
 // (engine.hip: tune_decode_gemms) fills it by timing every candidate as a hipGraph over the model's own layer weights
 // TOGETHER with the kernel that consumes the result (a split-K GEMM pays at the boundary, not inside the kernel).
-static std::map<std::tuple<int, int, int>, std::pair<int, int>> g_d32_table;
+static std::map<std::tuple<int, int, int, int>, std::pair<int, int>> g_d32_table;  // (role, K, N, M) -> (shape, splits)
 static std::mutex                                               g_d32_mutex;  // engines tune / import while others launch
 
-void dec32_table_set(int K, int N, int M, int shape, int splits)
+void dec32_table_set(int K, int N, int M, int shape, int splits, int role)
 {
     std::lock_guard<std::mutex> lk(g_d32_mutex);
-    g_d32_table[std::make_tuple(K, N, M)] = std::make_pair(shape, splits);
+    g_d32_table[std::make_tuple(role, K, N, M)] = std::make_pair(shape, splits);
 }
 
-bool dec32_table_get(int K, int N, int M, int* shape, int* splits)
+bool dec32_table_get(int K, int N, int M, int* shape, int* splits, int role)
 {
     std::lock_guard<std::mutex> lk(g_d32_mutex);
-    auto                        it = g_d32_table.find(std::make_tuple(K, N, M));
+    auto                        it = g_d32_table.find(std::make_tuple(role, K, N, M));
+    if (it == g_d32_table.end() && role != 0) {
+        it = g_d32_table.find(std::make_tuple(0, K, N, M));  // an entry without a role serves every role
+    }
     if (it == g_d32_table.end()) {
         return false;
     }
@@ -1037,7 +1040,7 @@ void dec32_table_clear()
     g_d32_table.clear();
 }
 
-// text, one line per entry: K N M shape splits
+// text, one line per entry: K N M shape splits [role]   (role 0 / absent: any linear of that shape)
 int dec32_table_export(const char* path)
 {
     FILE* f = fopen(path, "w");
@@ -1047,8 +1050,8 @@ int dec32_table_export(const char* path)
     }
     std::lock_guard<std::mutex> lk(g_d32_mutex);
     for (const auto& kv : g_d32_table) {
-        fprintf(f, "%d %d %d %d %d\n", std::get<0>(kv.first), std::get<1>(kv.first), std::get<2>(kv.first), kv.second.first,
-                kv.second.second);
+        fprintf(f, "%d %d %d %d %d %d\n", std::get<1>(kv.first), std::get<2>(kv.first), std::get<3>(kv.first), kv.second.first,
+                kv.second.second, std::get<0>(kv.first));
     }
     fclose(f);
     return 0;
@@ -1061,14 +1064,20 @@ int dec32_table_import(const char* path)
         set_last_error(std::string("cannot read ") + path);
         return 1;
     }
-    int K, N, M, shape, splits, n = 0;
-    while (fscanf(f, "%d %d %d %d %d", &K, &N, &M, &shape, &splits) == 5) {
+    int  K, N, M, shape, splits, n = 0;
+    char line[160];
+    while (fgets(line, sizeof line, f)) {
+        int       role = 0;
+        const int got  = sscanf(line, "%d %d %d %d %d %d", &K, &N, &M, &shape, &splits, &role);
+        if (got < 5 || role < 0 || role > 4) {
+            continue;
+        }
         const bool big = M > 64;
         const bool lc  = shape == kShapeLC && M <= 64;
         const bool p256 = shape == kShapePre256 && M >= 256 && N >= 256 && splits <= 4;
         if (K > 0 && N > 0 && M > 0 && M == dec32_m_bucket(M) && shape >= 0 && (shape <= 9 || lc || p256) && splits >= 1 && splits <= 16
             && (big ? shape >= 4 : (shape != 4 && shape != 5)) && !(shape == 5 && N < 512) && K % 128 == 0 && N % 32 == 0) {
-            dec32_table_set(K, N, M, shape, splits);
+            dec32_table_set(K, N, M, shape, splits, role);
             ++n;
         }
     }
@@ -1166,7 +1175,7 @@ void dec32_pick_ex(const LinearWeight& w, int M, int* shape_out, int* splits_out
 {
     const int ncg = w.N / 32;
     const int KB  = w.K / 128;
-    if (use_table && dec32_table_get(w.K, w.N, dec32_m_bucket(M), shape_out, splits_out)) {
+    if (use_table && dec32_table_get(w.K, w.N, dec32_m_bucket(M), shape_out, splits_out, w.role)) {
         return;  // measured on this machine for exactly this problem (M <= 256) / for this size class of forwards (above)
     }
     static const int env_shape  = env_int2("TM_D32_SHAPE", -1);  // read once: this runs on every eager launch

@@ -106,6 +106,9 @@ int launch_prefill_attention(const PrefillAttnParams& p, hipStream_t st);
 struct LinearWeight {
     int       K = 0, N = 0, group = 128;
     int       type = 0;          // 0 = u4 (AWQ), 1 = f16 dense, 2 = fp8 e4m3 with 128x128 block scales
+    int       role = 0;          // key of the measured dispatch table next to (K, N, M): 0 = any (operator-level handles, imported
+                                 // tables without a role column), 1 w_qkv, 2 wo, 3 w1w3, 4 w2 -- two roles of equal (K, N) are timed
+                                 // with DIFFERENT consumers by the tuner and keep separate winners
     void*     packed = nullptr;  // fragment-ordered weights (nullptr for a u4 linear prepared p32_only)
     uint32_t* sz     = nullptr;  // fragment-ordered (s, -z*s) half2 pairs (u4), (s, 0) (fp8)
     size_t    packed_bytes = 0, sz_bytes = 0;
@@ -156,8 +159,8 @@ bool   dec32_supported(const LinearWeight& w, int M);
 void   dec32_pick(const LinearWeight& w, int M, int* shape_out, int* splits_out);  // measured table first, then the heuristic
 void   dec32_pick_ex(const LinearWeight& w, int M, int* shape_out, int* splits_out, bool use_table);
 // measured dispatch table of the decode linears: key (K, N, M <= 64) -> (shape, splits)
-void   dec32_table_set(int K, int N, int M, int shape, int splits);
-bool   dec32_table_get(int K, int N, int M, int* shape, int* splits);
+void   dec32_table_set(int K, int N, int M, int shape, int splits, int role = 0);
+bool   dec32_table_get(int K, int N, int M, int* shape, int* splits, int role = 0);  // the role's entry, else the role-0 entry
 void   dec32_table_clear();
 int    dec32_table_export(const char* path);
 int    dec32_table_import(const char* path);

@@ -100,10 +100,11 @@ class Engine:
         _ffi.check(self._lib.tm_gemm_import(path.encode()))
 
     @staticmethod
-    def pick_tiling(K: int, N: int, M: int, use_table: bool = True):
-        """(shape, split-K) the decode GEMM dispatch runs a K x N W4A16 linear with at M rows (measured table first)"""
+    def pick_tiling(K: int, N: int, M: int, use_table: bool = True, role: int = 0):
+        """(shape, split-K) the decode GEMM dispatch runs a K x N W4A16 linear with at M rows (measured table first); role: 0 any,
+        1 w_qkv, 2 wo, 3 w1w3, 4 w2 -- the measured table is keyed (role, K, N, M)"""
         sh, sp = C.c_int(), C.c_int()
-        _ffi.check(_ffi.load().tm_debug_pick_tiling(K, N, M, 1 if use_table else 0, C.byref(sh), C.byref(sp)))
+        _ffi.check(_ffi.load().tm_debug_pick_tiling(K, N, M, (1 if use_table else 0) | (role << 8), C.byref(sh), C.byref(sp)))
         return sh.value, sp.value
 
     # ---- static batch ----------------------------------------------------------------------------

@@ -112,6 +112,7 @@ def test_engine_gemm_tuning_roundtrip(cuda, tmp_path, B, pf_class):
     rows = [tuple(int(v) for v in ln.split()) for ln in open(path).read().splitlines() if int(ln.split()[2]) == B]
     assert len(rows) == 4 and all(r[4] >= 1 for r in rows), rows        # w_qkv, wo, w1w3, w2 at M = B
     assert {(r[0], r[1]) for r in rows} == {(512, 1024), (512, 512), (512, 2048), (1024, 512)}
+    assert {(r[0], r[1], r[5]) for r in rows} == {(512, 1024, 1), (512, 512, 2), (512, 2048, 3), (1024, 512, 4)}    # keyed by role
     if pf_class:               # one 385-token prefill forward: size class 512
         eng.tune_gemm(pf_class, path)
         rows = [tuple(int(v) for v in ln.split()) for ln in open(path).read().splitlines() if int(ln.split()[2]) == pf_class]

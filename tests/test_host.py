@@ -31,11 +31,34 @@ def test_library_exports_every_declared_symbol():
     assert lib.tm_kv_layer_size(1, 128, 64, 4) == 8704             # 70B / TP8 per rank
 
 
-def _pick(lib, K, N, M, table=0):
+def _pick(lib, K, N, M, table=0, role=0):
     """the dispatch of the P32 kernels: (shape, splits)"""
     sh, sp = _ffi.C.c_int(-1), _ffi.C.c_int(-1)
-    _ffi.check(lib.tm_debug_pick_tiling(K, N, M, table, _ffi.C.byref(sh), _ffi.C.byref(sp)))
+    _ffi.check(lib.tm_debug_pick_tiling(K, N, M, table | (role << 8), _ffi.C.byref(sh), _ffi.C.byref(sp)))
     return sh.value, sp.value
+
+
+def test_dispatch_table_is_keyed_by_role(tmp_path):
+    """The measured dispatch table is keyed (role, K, N, M) (round 4; gemm::Gemm::Run's DispatchCache keys the whole problem
+    description, kernels/gemm/gemm.cu:92-224): two linears of equal shape but different roles -- timed by the tuner with different
+    consumer kernels -- keep separate winners; a line without a role column (tables exported by earlier rounds) serves every role;
+    the export writes the role and re-imports to the same picks."""
+    lib = _ffi.load()
+    K, N, M = 6144, 6144, 64
+    heur = _pick(lib, K, N, M, table=0)
+    f = tmp_path / 't.txt'
+    f.write_text(f'{K} {N} {M} 2 3 1\n{K} {N} {M} 3 2 2\n')          # w_qkv and wo of equal shape, different winners
+    assert lib.tm_gemm_import(str(f).encode()) == 0
+    assert _pick(lib, K, N, M, table=1, role=1) == (2, 3) and _pick(lib, K, N, M, table=1, role=2) == (3, 2)
+    assert _pick(lib, K, N, M, table=1, role=3) == heur and _pick(lib, K, N, M, table=1, role=0) == heur   # no entry for these
+    f.write_text(f'{K} {N} {M} 1 2\n')                                # no role column: any role without its own entry
+    assert lib.tm_gemm_import(str(f).encode()) == 0
+    assert _pick(lib, K, N, M, table=1, role=3) == (1, 2) and _pick(lib, K, N, M, table=1, role=0) == (1, 2)
+    assert _pick(lib, K, N, M, table=1, role=1) == (2, 3)             # the role's own entry still wins
+    f.write_text(f'{K} {N} {M} 1 2 9\n')                              # an unknown role is ignored, not mis-filed
+    assert lib.tm_gemm_import(str(f).encode()) != 0
+    with pytest.raises(RuntimeError):
+        _pick(lib, K, N, M, table=1, role=5)
 
 
 def test_decode_gemm_heuristic_equals_the_measured_winners(tmp_path):
