@@ -462,6 +462,9 @@ int tm_sched_destroy(tm_sched* s);
 int tm_sched_submit(tm_sched* s, const int* ids, int n, int max_new_tokens, int eos_id, int64_t* req_id);
 /* admit waiting requests for one step: writes up to cap (request id, slot) pairs */
 int tm_sched_admit(tm_sched* s, int token_budget, int64_t* req_ids, int* slots, int cap, int* n_admitted);
+/* *ready = 1 if tm_sched_admit would admit at least one request right now (no side effects): the engine asks before it keeps a
+ * decode step in flight across scheduler steps (two-phase schedule / forward overlap, turbomind.cc:171) */
+int tm_sched_admit_ready(tm_sched* s, int* ready);
 int tm_sched_on_token(tm_sched* s, int slot, int token, int* finished);
 int tm_sched_cancel(tm_sched* s, int64_t req_id, int* released_slot);
 /* status (Request::k*), slot (-1 unless running), tokens generated, blocks held; TM_INVALID for unknown ids */

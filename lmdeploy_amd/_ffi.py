@@ -176,6 +176,7 @@ _SIGNATURES = {
     'tm_sched_submit': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, POINTER(c_int64)]),
     'tm_sched_admit': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, POINTER(c_int)]),
     'tm_sched_on_token': (c_int, [c_void_p, c_int, c_int, POINTER(c_int)]),
+    'tm_sched_admit_ready': (c_int, [c_void_p, POINTER(c_int)]),
     'tm_sched_cancel': (c_int, [c_void_p, c_int64, POINTER(c_int)]),
     'tm_sched_query': (c_int, [c_void_p, c_int64, POINTER(c_int), POINTER(c_int), POINTER(c_int), POINTER(c_int)]),
     'tm_sched_counts': (c_int, [c_void_p, POINTER(c_int), POINTER(c_int), POINTER(c_int)]),

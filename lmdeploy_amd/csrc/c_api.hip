@@ -597,6 +597,13 @@ int tm_sched_query(tm_sched* s, int64_t req_id, int* status, int* slot, int* n_g
     return 0;
 }
 
+int tm_sched_admit_ready(tm_sched* s, int* ready)
+{
+    TM_REQUIRE(s && ready, "null pointer");
+    *ready = s->impl.admit_ready() ? 1 : 0;
+    return 0;
+}
+
 int tm_sched_counts(tm_sched* s, int* n_active, int* n_waiting, int* n_free_blocks)
 {
     TM_REQUIRE(s, "null pointer");

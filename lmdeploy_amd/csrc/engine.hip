@@ -120,6 +120,15 @@ __global__ void advance_active_kernel(int* k_len, const int* active, int batch)
     }
 }
 
+// continuous batching: a finished / cancelled slot goes back to the scratch block (no host memory involved: the launch needs
+// no synchronisation, so it can queue up behind a decode step that is still running)
+__global__ void park_slot_kernel(int* active, int* k_len, uint64_t* block_row, int slot, uint64_t dummy_block_ptr)
+{
+    active[slot] = 0;
+    k_len[slot]  = 1;
+    block_row[0] = dummy_block_ptr;
+}
+
 // ids -> generated[b][step]; step++ (single thread does the counter after everybody read it)
 __global__ void record_kernel(const int* ids, int* generated, int* step_counter, int batch, int max_new)
 {
@@ -305,9 +314,25 @@ struct tm_engine {
     int*             d_pf_k_len  = nullptr;  // prefill-local arrays (the decode arrays stay live during an admission)
     int*             d_pf_cu_q   = nullptr;
     int*             d_first_ids = nullptr;  // [max_batch] first tokens of an admission's earlier prefill iterations (mixed steps)
-    std::vector<int> h_active, h_step_ids;
+    std::vector<int> h_active;
     int              dummy_block = -1;
     hipGraphExec_t   graph_cb    = nullptr;
+    // Two-phase schedule / forward overlap (reference: the two alternating batch phases of turbomind.cc:171, engine.cc:770-870):
+    // a pure decode step is ISSUED (graph launch + result copy into a pinned buffer + event) and RETIRED (event wait, tokens to
+    // the scheduler, finished slots parked) by different scheduler steps -- step N+1 is issued before step N is retired, so the
+    // host's bookkeeping, the caller's polling and the next launch run under the device's step N+1.  A sequence that ends in
+    // step N rides one more step as a dead row (its token is dropped: the slot's request id no longer matches).
+    // TM_ASYNC_STEP=0 retires every step in the call that issued it.
+    struct PendingStep {
+        bool                 valid = false;
+        int                  buf   = 0;
+        std::vector<int64_t> ids;  // request of every slot whose token this step produces (-1: free, parked, prefilled by this step)
+    } pending;
+    bool       async_step_on = true;
+    int*       h_step_pin[2] = {nullptr, nullptr};  // pinned [max_batch + 1]: next ids of the slots, then the communicator's give-up mark
+    hipEvent_t ev_step[2]    = {nullptr, nullptr};
+    int        issue_count   = 0;
+    int64_t    overlapped_steps = 0;  // decode steps issued while the previous one was still unretired
 
     // stochastic sampling (tm_engine_set_sampling / tm_engine_submit_ex); off = arg-max
     bool      sampling_on = false, graph_sampling = false, graph_cb_sampling = false;
@@ -1857,7 +1882,15 @@ static int cb_enter(tm_engine* e)
     e->sched.reset(new BatchScheduler(B, (int)e->num_blocks - 1, e->cfg.session_len, e->cfg.cache_block_seq_len));
     e->free_blocks.clear();
     e->h_active.assign(B, 0);
-    e->h_step_ids.assign(B, 0);
+    if (!e->h_step_pin[0]) {
+        const char* as   = getenv("TM_ASYNC_STEP");
+        e->async_step_on = !(as && !atoi(as));
+        for (int i = 0; i < 2; ++i) {
+            TM_HIP_CHECK(hipHostMalloc((void**)&e->h_step_pin[i], ((size_t)B + 1) * 4, hipHostMallocDefault));
+            TM_HIP_CHECK(hipEventCreateWithFlags(&e->ev_step[i], hipEventDisableTiming));
+        }
+    }
+    e->pending.valid = false;
     std::vector<int>      ones(B, 1), zeros(B, 0), cu_q(B + 1);
     std::vector<uint64_t> ptrs((size_t)B * e->max_blocks_per_seq,
                                (uint64_t)(e->pool + (int64_t)e->dummy_block * e->block_bytes));
@@ -1889,13 +1922,10 @@ static int decode_step_cb(tm_engine* e)
 // park a slot again after its sequence finished / was cancelled
 static int cb_park_slot(tm_engine* e, int slot)
 {
-    const int      one = 1, zero = 0;
-    const uint64_t dp  = (uint64_t)(e->pool + (int64_t)e->dummy_block * e->block_bytes);
-    e->h_active[slot]  = 0;
-    TM_HIP_CHECK(hipMemcpyAsync(e->d_active + slot, &zero, 4, hipMemcpyHostToDevice, e->stream));
-    TM_HIP_CHECK(hipMemcpyAsync(e->d_k_len + slot, &one, 4, hipMemcpyHostToDevice, e->stream));
-    TM_HIP_CHECK(hipMemcpyAsync(e->d_block_ptrs + (size_t)slot * e->max_blocks_per_seq, &dp, 8, hipMemcpyHostToDevice, e->stream));
-    TM_HIP_CHECK(hipStreamSynchronize(e->stream));  // the sources are stack variables
+    const uint64_t dp = (uint64_t)(e->pool + (int64_t)e->dummy_block * e->block_bytes);
+    e->h_active[slot] = 0;
+    park_slot_kernel<<<1, 1, 0, e->stream>>>(e->d_active, e->d_k_len, e->d_block_ptrs + (size_t)slot * e->max_blocks_per_seq, slot, dp);
+    TM_HIP_CHECK(hipGetLastError());
     return 0;
 }
 
@@ -1999,6 +2029,7 @@ int tm_engine_release(tm_engine* e)
     if (e->stream) {
         TM_HIP_CHECK(hipStreamSynchronize(e->stream));
     }
+    e->pending.valid = false;  // a look-ahead decode step of the session that ends here: its tokens belong to nobody
     for (auto& blks : e->h_blocks) {
         for (int b : blks) {
             e->free_blocks.push_back(b);
@@ -2308,12 +2339,113 @@ int tm_engine_submit(tm_engine* e, const int* host_ids, int n, int max_new_token
     return tm_engine_submit_ex(e, host_ids, n, max_new_tokens, eos_id, nullptr, req_id);
 }
 
+// ---- issue / retire of a decode step (two-phase overlap, see tm_engine::PendingStep) ----
+// the decode step of every slot, as a graph replay when graphs are on (captured on first use)
+static int cb_launch_decode(tm_engine* e)
+{
+    if (e->graph_cb && (e->graph_cb_sampling != e->sampling_on || e->graph_cb_logits != e->logits_on)) {
+        (void)hipGraphExecDestroy(e->graph_cb);
+        e->graph_cb = nullptr;
+    }
+    if (graph_enabled(e) && !e->graph_cb) {
+        TM_TRY(decode_step_cb(e));  // one eager step first (lazy module loading must not happen inside a capture)
+        TM_HIP_CHECK(hipStreamSynchronize(e->stream));
+        TM_TRY(capture_step(e, decode_step_cb, &e->graph_cb));
+        e->graph_cb_sampling = e->sampling_on;
+        e->graph_cb_logits   = e->logits_on;
+        return 0;
+    }
+    if (graph_enabled(e) && e->graph_cb) {
+        TM_HIP_CHECK(hipGraphLaunch(e->graph_cb, e->stream));
+        return 0;
+    }
+    return decode_step_cb(e);
+}
+
+// behind a launched step: its tokens (d_ids after the step) and the communicator's give-up mark go to a pinned buffer, an event
+// marks the hand-over.  `skip`: slots that were prefilled by this very forward (their first token was handed over already)
+static int cb_issue(tm_engine* e, tm_engine::PendingStep* p, const std::vector<int>& skip)
+{
+    const int B = e->cfg.max_batch_size;
+    p->buf      = e->issue_count++ & 1;
+    p->ids.assign(B, -1);
+    for (int b = 0; b < B; ++b) {
+        if (e->h_active[b] && std::find(skip.begin(), skip.end(), b) == skip.end()) {
+            p->ids[b] = e->sched->slot_request(b);
+        }
+    }
+    int* const h = e->h_step_pin[p->buf];
+    h[B]         = 0;
+    TM_HIP_CHECK(hipMemcpyAsync(h, e->d_ids, (size_t)B * 4, hipMemcpyDeviceToHost, e->stream));
+    if (e->p2p_state) {
+        TM_HIP_CHECK(hipMemcpyAsync(h + B, e->p2p_state + 3, 4, hipMemcpyDeviceToHost, e->stream));
+    }
+    TM_HIP_CHECK(hipEventRecord(e->ev_step[p->buf], e->stream));
+    p->valid = true;
+    return 0;
+}
+
+// wait for an issued step, hand its tokens to the scheduler, park the slots whose sequence ended.  A slot counts only if it still
+// runs the request it ran when the step was issued (finished one step earlier / cancelled / re-admitted since: token dropped)
+static int cb_retire(tm_engine* e, tm_engine::PendingStep* p, std::vector<StepUpdate>* updates)
+{
+    if (!p->valid) {
+        return 0;
+    }
+    p->valid    = false;
+    const int B = e->cfg.max_batch_size;
+    TM_HIP_CHECK(hipEventSynchronize(e->ev_step[p->buf]));
+    const int* const h = e->h_step_pin[p->buf];
+    if (e->p2p_state && h[B]) {
+        e->h_mark = (unsigned)h[B];
+    }
+    TM_TRY(device_marks_check(e));  // -> the serve loop ends every unfinished request with kFail
+    for (int b = 0; b < B; ++b) {
+        const int64_t id = p->ids[b];
+        if (id < 0 || !e->h_active[b] || e->sched->slot_request(b) != id) {
+            continue;
+        }
+        const bool finished = e->sched->on_token(b, h[b]);
+        if (updates) {
+            const SchedRequest* r = e->sched->find(id);
+            updates->push_back({id, r->status, (int)r->out.size()});
+        }
+        if (finished) {
+            TM_TRY(cb_park_slot(e, b));
+        }
+    }
+    return 0;
+}
+
+// does any running sequence need a token beyond the ones that are already on their way (the unretired step)?
+static bool cb_more_tokens_needed(const tm_engine* e)
+{
+    const int B = e->cfg.max_batch_size;
+    for (int b = 0; b < B; ++b) {
+        const int64_t id = e->sched->slot_request(b);
+        if (id < 0 || !e->h_active[b]) {
+            continue;
+        }
+        const SchedRequest* r        = e->sched->find(id);
+        const int           underway = e->pending.valid && e->pending.ids[b] == id ? 1 : 0;
+        if (r && (int)r->out.size() + underway < r->max_new) {
+            return true;
+        }
+    }
+    return false;
+}
+
 // one scheduler step; the caller holds e->mu.  `updates` (optional): requests that produced a token / finished
 static int step_locked(tm_engine* e, int* n_active, int* n_waiting, std::vector<StepUpdate>* updates)
 {
     TM_TRY(cb_enter(e));
     TM_HIP_CHECK(hipSetDevice(e->cfg.device));
     const int B = e->cfg.max_batch_size;
+    // 0. an admission is due: everything from here to the end of this call is synchronous (the admission's first tokens are read
+    //    back, the block accounting of the scheduler must be current) -- retire the step that is still in flight first
+    if (e->pending.valid && e->sched->admit_ready()) {
+        TM_TRY(cb_retire(e, &e->pending, updates));
+    }
     // 1. admission + prefill (budget = max_prefill_token_num tokens of prompts per step)
     // Mixed steps (TM_MIXED_STEP, default on): when something is already decoding, the decode step rides on the admission's
     // last prefill forward -- one weight stream for both (reference: the unified batch of unified_attention_layer.cc:310-311).
@@ -2326,50 +2458,39 @@ static int step_locked(tm_engine* e, int* n_active, int* n_waiting, std::vector<
     std::vector<int> fresh;
     const std::vector<SchedAdmit> admits = e->sched->admit(e->max_tokens);
     if (!admits.empty()) {
+        TM_TRY(cb_retire(e, &e->pending, updates));  // (admit_ready() said so above; kept for the invariant: no step in flight here)
         TM_TRY(cb_prefill_admitted(e, admits, updates, can_mix ? &merged : nullptr, &fresh));
+        // 2a. the decode step of this call: rode on the admission's forward, or a launch of its own; retired at once
+        if (e->sched->n_active() > 0) {
+            if (merged) {
+                ++e->mixed_steps;
+            }
+            else {
+                TM_TRY(cb_launch_decode(e));
+            }
+            tm_engine::PendingStep now;
+            TM_TRY(cb_issue(e, &now, fresh));
+            TM_TRY(cb_retire(e, &now, updates));
+        }
     }
-    // 2. one decode step for everything that is running
-    if (e->sched->n_active() > 0) {
-        if (merged) {
-            ++e->mixed_steps;  // the decode rows went through the admission's forward
+    else if (e->sched->n_active() > 0 && cb_more_tokens_needed(e)) {
+        // 2b. pure decode step: issue step N+1, THEN retire step N (the device runs N+1 under the host's bookkeeping)
+        TM_TRY(cb_launch_decode(e));
+        tm_engine::PendingStep next;
+        TM_TRY(cb_issue(e, &next, fresh));
+        if (e->pending.valid) {
+            ++e->overlapped_steps;
         }
-        else if (e->graph_cb && (e->graph_cb_sampling != e->sampling_on || e->graph_cb_logits != e->logits_on)) {
-            (void)hipGraphExecDestroy(e->graph_cb);
-            e->graph_cb = nullptr;
-        }
-        if (merged) {
-        }
-        else if (graph_enabled(e) && !e->graph_cb) {
-            TM_TRY(decode_step_cb(e));  // one eager step first (lazy module loading must not happen inside a capture)
-            TM_HIP_CHECK(hipStreamSynchronize(e->stream));
-            TM_TRY(capture_step(e, decode_step_cb, &e->graph_cb));
-            e->graph_cb_sampling = e->sampling_on;
-            e->graph_cb_logits   = e->logits_on;
-        }
-        else if (graph_enabled(e) && e->graph_cb) {
-            TM_HIP_CHECK(hipGraphLaunch(e->graph_cb, e->stream));
+        TM_TRY(cb_retire(e, &e->pending, updates));
+        if (e->async_step_on) {
+            e->pending = std::move(next);
         }
         else {
-            TM_TRY(decode_step_cb(e));
+            TM_TRY(cb_retire(e, &next, updates));
         }
-        TM_HIP_CHECK(hipMemcpyAsync(e->h_step_ids.data(), e->d_ids, (size_t)B * 4, hipMemcpyDeviceToHost, e->stream));
-        TM_TRY(device_marks_fetch(e, true));
-        TM_HIP_CHECK(hipStreamSynchronize(e->stream));
-        TM_TRY(device_marks_check(e));  // -> the serve loop ends every unfinished request with kFail
-        for (int b = 0; b < B; ++b) {
-            const int64_t id = e->sched->slot_request(b);
-            if (!e->h_active[b] || id < 0 || std::find(fresh.begin(), fresh.end(), b) != fresh.end()) {
-                continue;  // free, or prefilled by this step's mixed forward: its first token was handed over above
-            }
-            const bool finished = e->sched->on_token(b, e->h_step_ids[b]);
-            if (updates) {
-                const SchedRequest* r = e->sched->find(id);
-                updates->push_back({id, r->status, (int)r->out.size()});
-            }
-            if (finished) {
-                TM_TRY(cb_park_slot(e, b));
-            }
-        }
+    }
+    else {
+        TM_TRY(cb_retire(e, &e->pending, updates));  // nothing to issue: the tokens on their way end every running sequence
     }
     if (n_active) {
         *n_active = e->sched->n_active();
@@ -2476,6 +2597,7 @@ static void serve_loop(tm_engine* e)
                 for (int b = 0; b < B; ++b) {
                     e->h_active[b] = 0;
                 }
+                e->pending.valid = false;
                 e->sched->abort_all(TM_FAIL);
             }
             lk.unlock();
@@ -2657,6 +2779,11 @@ int tm_engine_debug_read(tm_engine* e, int what, int a, int b, void* host_out, i
         *(int64_t*)host_out = e->mixed_steps;
         return 0;
     }
+    if (what == 3) {  // int64: decode steps issued while the previous one was unretired (two-phase overlap, TM_ASYNC_STEP)
+        TM_REQUIRE(bytes == 8, "byte count must be 8");
+        *(int64_t*)host_out = e->overlapped_steps;
+        return 0;
+    }
     set_last_error("tm_engine_debug_read: unknown selector");
     return 1;
 }
@@ -2730,6 +2857,12 @@ int tm_engine_destroy(tm_engine* e)
         (void)hipStreamDestroy(e->aux_stream);
         (void)hipEventDestroy(e->ev_aux_fork);
         (void)hipEventDestroy(e->ev_aux_join);
+    }
+    for (int i = 0; i < 2; ++i) {
+        if (e->h_step_pin[i]) {
+            (void)hipHostFree(e->h_step_pin[i]);
+            (void)hipEventDestroy(e->ev_step[i]);
+        }
     }
     for (void* q : {(void*)e->d_active, (void*)e->d_pf_k_len, (void*)e->d_pf_cu_q, (void*)e->d_pf_block_ptrs, (void*)e->d_first_ids, (void*)e->d_temp, (void*)e->d_topp, (void*)e->d_minp,
                     (void*)e->d_u, (void*)e->d_topk, (void*)e->d_seed, e->d_sample_ws, (void*)e->d_logits_gather, (void*)e->d_logits_full,

@@ -119,6 +119,24 @@ public:
         return out;
     }
 
+    // would admit() admit anything right now?  (const: the engine asks before it decides to keep a decode step in flight)
+    bool admit_ready() const
+    {
+        for (int64_t id : waiting_) {
+            auto it = reqs_.find(id);
+            if (it == reqs_.end() || it->second.status != 0) {
+                continue;  // cancelled while waiting: admit() drops it
+            }
+            const SchedRequest& r    = it->second;
+            bool                slot = false;
+            for (int b = 0; b < max_batch_ && !slot; ++b) {
+                slot = slot_req_[b] < 0;
+            }
+            return slot && blocks_for((int)r.prompt.size() + r.max_new) <= (int)free_blocks_.size();  // head of the line decides
+        }
+        return false;
+    }
+
     // a token was produced for the sequence in `slot`; returns true if the sequence finished (slot + blocks released)
     bool on_token(int slot, int token)
     {

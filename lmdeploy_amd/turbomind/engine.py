@@ -184,6 +184,13 @@ class Engine:
         _ffi.check(self._lib.tm_engine_debug_read(self._h, 2, 0, 0, out.ctypes.data, 8))
         return int(out[0])
 
+    def overlapped_steps(self) -> int:
+        """continuous batching: decode steps issued while the previous one was still unretired (the two-phase schedule /
+        forward overlap of the reference, turbomind.cc:171; TM_ASYNC_STEP=0 switches it off)"""
+        out = np.zeros(1, np.int64)
+        _ffi.check(self._lib.tm_engine_debug_read(self._h, 3, 0, 0, out.ctypes.data, 8))
+        return int(out[0])
+
     # ---- continuous batching (tm_engine_submit / step / poll / cancel) -----------------------------
     def submit(self, prompt: Sequence[int], max_new_tokens: int, eos_id: int = -1, sampling=None, logits=None) -> int:
         """Queue one request; returns its id.  eos_id < 0 = ignore_eos.  sampling = (temperature, top_k, top_p, min_p,

@@ -134,9 +134,13 @@ def test_engine_gemm_tuning_roundtrip(cuda, tmp_path, B, pf_class):
     assert err.max() <= 4e-2, err.max()
 
 
+@pytest.mark.parametrize('async_step', [1, 0])
 @pytest.mark.parametrize('slots', [1, 3])
-def test_continuous_batching_matches_static(cuda, slots):
-    """the engine scheduler (submit / step / poll / cancel).  9 requests through 1 or 3 batch slots,
+def test_continuous_batching_matches_static(cuda, monkeypatch, slots, async_step):
+    """async_step = 1 (default): the two-phase schedule / forward overlap (reference: turbomind.cc:171) -- a pure decode step is
+    issued before the previous one is retired, a sequence that ended rides one more step as a dead row; the test insists that
+    steps overlapped.  async_step = 0 (TM_ASYNC_STEP=0): every step is retired by the call that issued it.  Same token streams.
+    SURVEY 8f-1: the engine scheduler (submit / step / poll / cancel).  9 requests through 1 or 3 batch slots,
     different prompt lengths and generation lengths, one with an EOS stop, one cancelled mid-flight, one chunked prompt
     (longer than max_prefill_token_num); slots and blocks are reused.
     slots = 1: every request runs exactly the kernels of the static single-prompt run -> tokens must be identical.
@@ -152,6 +156,7 @@ def test_continuous_batching_matches_static(cuda, slots):
     prompts = [rng.integers(0, cfg.vocab, n).astype(np.int32) for n in lens]
     weights = export_weights(cfg, w)
 
+    monkeypatch.setenv('TM_ASYNC_STEP', str(async_step))
     # reference: every prompt alone through the static path (tokens + top-2 margin of every step)
     eng = Engine.from_model_config(cfg, max_batch_size=slots, session_len=256, quant_policy=8, max_prefill_token_num=96)
     eng.load_weights(weights)
@@ -199,6 +204,7 @@ def test_continuous_batching_matches_static(cuda, slots):
             if st != 0:
                 done[i] = (st, toks.copy())
     assert max_active <= slots
+    assert (eng.overlapped_steps() > 0) if async_step else (eng.overlapped_steps() == 0), eng.overlapped_steps()
     for i, (st, toks) in done.items():
         if i == cancel_req:
             assert st == 8

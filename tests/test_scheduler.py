@@ -44,6 +44,11 @@ class Sched:
         rc = self.lib.tm_sched_query(self.h, rid, C.byref(st), C.byref(slot), C.byref(ng), C.byref(nb))
         return rc, st.value, slot.value, ng.value, nb.value
 
+    def admit_ready(self):
+        r = C.c_int(0)
+        _ffi.check(self.lib.tm_sched_admit_ready(self.h, C.byref(r)))
+        return bool(r.value)
+
     def counts(self):
         a, w, f = C.c_int(0), C.c_int(0), C.c_int(0)
         _ffi.check(self.lib.tm_sched_counts(self.h, C.byref(a), C.byref(w), C.byref(f)))
@@ -255,3 +260,167 @@ def test_random_operation_sequences_keep_the_invariants(seed):
         for rid, m in model.items():
             rc, st, slot, ng, nb = s.query(rid)
             assert (rc, st, slot, ng, nb) == (0, m['status'], -1 if m['slot'] is None else m['slot'], m['out'], m['blocks']), (step, rid)
+
+
+def test_admit_ready_is_admit_without_side_effects():
+    s = Sched(max_batch=2, num_blocks=4, session_len=4096)
+    assert s.admit_ready() is False                           # nothing queued
+    a = s.submit(100, 28)[1]                                  # 2 blocks
+    b = s.submit(130, 62)[1]                                  # 3 blocks
+    c = s.submit(10, 10)[1]
+    assert s.admit_ready() is True and s.counts() == (0, 3, 4)
+    assert s.admit() == [(a, 0)]
+    assert s.admit_ready() is False                           # b needs 3 of the 2 free blocks: the head of the line decides
+    s.cancel(b)                                               # cancelled while waiting: admit() drops it, c is the new head
+    assert s.admit_ready() is True
+    assert s.admit() == [(c, 1)]
+    d = s.submit(10, 10)[1]
+    assert s.admit_ready() is False                           # no free slot
+    for _ in range(28):
+        s.on_token(0, 1)
+    assert s.admit_ready() is True and s.admit() == [(d, 0)]
+
+
+class _DeviceModel:
+    """What the decode step does to the per-slot device state of the engine (active flag, position in the sequence): a token
+    is the pair (request the slot was prefilled for, index of the token in that request's output)."""
+    def __init__(self, slots):
+        self.active, self.req, self.k = [0] * slots, [-1] * slots, [0] * slots
+
+    def prefill(self, slot, rid):          # first token = (rid, 0); the slot joins the decode table
+        self.active[slot], self.req[slot], self.k[slot] = 1, rid, 1
+        return (rid, 0)
+
+    def step(self):                        # every active slot produces its next token (parked slots: garbage)
+        out = []
+        for b in range(len(self.active)):
+            out.append((self.req[b], self.k[b]) if self.active[b] else None)
+            self.k[b] += self.active[b]
+        return out
+
+    def park(self, slot):
+        self.active[slot] = 0
+
+
+@pytest.mark.parametrize('async_on', [True, False])
+@pytest.mark.parametrize('slots,seed', [(1, 0), (3, 1), (3, 2), (8, 3)])
+def test_two_phase_step_protocol_model(slots, seed, async_on):
+    """The issue / retire protocol of the engine's scheduler step (engine.hip: step_locked, cb_issue, cb_retire; reference: the
+    two alternating phases of turbomind.cc:171) replayed on the CPU against the REAL scheduler and a model of the device state:
+    a pure decode step N+1 is issued before step N is retired; a slot's token counts only if the slot still runs the request it
+    ran at issue time.  Invariants: every request receives exactly its tokens 0 .. n-1, once, in order (EOS / length / cancel
+    included); tokens of dead rows (a sequence that ended one step earlier, a cancelled one) are dropped; no step stays in flight
+    across an admission; with the overlap off the same token streams come out."""
+    rng = np.random.default_rng(seed)
+    n_req = 24
+    s = Sched(max_batch=slots, num_blocks=64, session_len=1024)
+    spec = {}
+    for _ in range(n_req):
+        n, m = int(rng.integers(1, 200)), int(rng.integers(1, 20))
+        rid = s.submit(n, m)[1]
+        spec[rid] = dict(max_new=m, eos_at=int(rng.integers(0, m)) if rng.random() < 0.3 else None,
+                         cancel_at=int(rng.integers(1, m)) if m > 1 and rng.random() < 0.2 else None)
+    dev = _DeviceModel(slots)
+    slot_req, h_active = [-1] * slots, [0] * slots
+    out = {rid: [] for rid in spec}
+    status = {rid: 0 for rid in spec}
+    pending, calls, overlapped, issued = None, 0, 0, 0
+
+    # (the scheduler's own EOS test needs an eos id: model EOS by cancelling nothing -- use on_token's length rule and an
+    #  explicit finish through a stop token: submit() above passed eos = -1, so EOS is modelled on this side)
+    def on_token(slot, tok):
+        rid = slot_req[slot]
+        assert tok == (rid, len(out[rid])), f'slot {slot}: token {tok} handed to request {rid} with {len(out[rid])} tokens'
+        out[rid].append(tok)
+        fin = s.on_token(slot, 1)
+        if not fin and spec[rid]['eos_at'] == tok[1]:
+            assert s.cancel(rid) == (0, slot)                # stands in for an EOS hit: the request ends here
+            status[rid] = FINISH
+            fin = True
+        elif fin:
+            status[rid] = FINISH
+        if fin:
+            slot_req[slot], h_active[slot] = -1, 0
+            dev.park(slot)
+        return fin
+
+    def issue(skip=()):
+        nonlocal issued
+        issued += 1
+        toks = dev.step()
+        return dict(ids=[slot_req[b] if h_active[b] and b not in skip else -1 for b in range(slots)], toks=toks)
+
+    def retire(p):
+        if p is None:
+            return
+        for b in range(slots):
+            rid = p['ids'][b]
+            if rid < 0 or not h_active[b] or slot_req[b] != rid:
+                continue
+            on_token(b, p['toks'][b])
+
+    def more_needed():
+        for b in range(slots):
+            rid = slot_req[b]
+            if rid >= 0 and h_active[b]:
+                underway = 1 if pending is not None and pending['ids'][b] == rid else 0
+                if len(out[rid]) + underway < spec[rid]['max_new']:
+                    return True
+        return False
+
+    while any(st == 0 for st in status.values()):
+        calls += 1
+        assert calls < 2000, 'no progress'
+        # API calls between two steps: cancels (as the pipeline / a client would issue them after polling)
+        for rid, sp in spec.items():
+            if status[rid] == 0 and sp['cancel_at'] is not None and len(out[rid]) >= sp['cancel_at']:
+                rc, slot = s.cancel(rid)
+                assert rc == 0
+                status[rid] = CANCEL
+                if slot >= 0:
+                    slot_req[slot], h_active[slot] = -1, 0
+                    dev.park(slot)
+        if pending is not None and s.admit_ready():
+            retire(pending)
+            pending = None
+        n_act_before = sum(r >= 0 for r in slot_req)
+        admits = s.admit(96)
+        if admits:
+            assert pending is None, 'a step is in flight across an admission'
+            fresh = []
+            for rid, slot in admits:
+                slot_req[slot] = rid
+            for rid, slot in admits:                          # prefill: first tokens
+                tok = dev.prefill(slot, rid)
+                h_active[slot] = 1
+                fresh.append(slot)
+                on_token(slot, tok)
+            merged = n_act_before > 0
+            if any(r >= 0 for r in slot_req):
+                if merged:
+                    # the decode rows rode on the prefill forward: the fresh slots did not decode in it
+                    for b in fresh:
+                        dev.k[b] -= dev.active[b]
+                now = issue(skip=fresh if merged else ())
+                retire(now)
+        elif any(r >= 0 for r in slot_req) and more_needed():
+            nxt = issue()
+            overlapped += pending is not None
+            retire(pending)
+            pending = nxt if async_on else None
+            if not async_on:
+                retire(nxt)
+        else:
+            retire(pending)
+            pending = None
+    for rid, sp in spec.items():
+        n = len(out[rid])
+        if status[rid] == CANCEL:
+            assert sp['cancel_at'] <= n <= sp['max_new']
+        elif sp['eos_at'] is not None:
+            assert n == sp['eos_at'] + 1
+        else:
+            assert n == sp['max_new']
+        assert out[rid] == [(rid, k) for k in range(n)]
+    assert s.counts()[0] == 0 and s.counts()[2] == 64
+    assert (overlapped > 0) == (async_on and True)
