@@ -400,6 +400,10 @@ def main():
             tilings[name] = dict(zip(('shape', 'splits'), Engine.pick_tiling(kk, nn, B, role=role)))
             # 4 / 5 = the fused 128-row W4A16 tiles, 12 = the 256 x 256 tile with the dequant through LDS (gemm_prefill.hip)
             prefill_tilings[name] = dict(zip(('shape', 'splits'), Engine.pick_tiling(kk, nn, pf_rows, role=role)))
+    # the fp16 lm_head runs the general kernel: (tiles per wave, split-K) from the measured table (`G` lines) or the heuristic
+    head_tiling = None
+    if B <= 256 and (model['vocab'] // world) % 16 == 0:
+        head_tiling = dict(zip(('nt', 'splits'), Engine.pick_general(1, 5, H_, model['vocab'] // world, B)[:2]))
     if weight_type != 0 or model.get('moe_experts'):
         # formats other than AWQ u4 / MoE: the weight bytes are what the engine actually streams (packed weights + scales +
         # lm_head); with batch 64 and top-2 of 8 every expert is hit every step
@@ -423,7 +427,8 @@ def main():
                        'decode_splits': stats['decode_splits'], 'hipgraph': cinfo['hipgraph'],
                        'gemm_dispatch': ('measured at start-up (tm_engine_tune_gemm' + (', rank 0\'s table broadcast' if world > 1 else '') + ')')
                                         if tuned else 'heuristic',
-                       'gemm_tilings': tilings, 'prefill_rows': pf_rows, 'prefill_gemm_tilings': prefill_tilings},
+                       'gemm_tilings': tilings, 'lm_head_tiling': head_tiling, 'prefill_rows': pf_rows,
+                       'prefill_gemm_tilings': prefill_tilings},
             'ttft_p50_ms': round(float(np.median(ttft)), 2), 'prefill_total_s': round(prefill_s, 3),
             'prefill_tokens_per_s': round(B * S / prefill_s, 1),
             'step_roofline': {'bound': 'hbm', 'algorithmic_bytes_per_step': int(step_bytes),

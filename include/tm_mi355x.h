@@ -265,6 +265,14 @@ int tm_debug_set_gemm_trace(void* dev_buf);
  * (gemm_decode.hip), 11 the loader / consumer decode kernel (gemm_decode_lc.hip, M <= 64), 12 the 256 x 256 prefill tile with
  * the weights dequantised once per workgroup tile through LDS (gemm_prefill.hip, M > 64).  (10 was a vendor-library path: gone.) */
 int tm_debug_pick_tiling(int K, int N, int M, int use_table, int* shape, int* splits);
+/* Host-only: the tiling of the general kernel (gemm_w4a16.hip: the fp16 lm_head, e4m3 weight-only linears, u4 with N % 32 != 0)
+ * for a K x N linear of `weight_type` (TM_WEIGHT_*) and `role` (0 any, 1 w_qkv, 2 wo, 3 w1w3, 4 w2, 5 lm_head) at M rows:
+ * config4 = {tiles per wave, split-K, waves, k-phases} -- the measured entry (tm_engine_tune_gemm / tm_gemm_import, `G` lines)
+ * first, then the heuristic.  Reference: the same DispatchCache serves every GEMM of the model (gemm.cu:92-224). */
+int tm_debug_pick_general(int weight_type, int role, int K, int N, int M, int* config4);
+/* Host-only: the measured row-tile height of the grouped expert GEMMs (u4: 16 / 32 / 64, e4m3 on the fp8 matrix cores: 32 / 64)
+ * for `tokens` rows per forward; *rows = 0: no entry, the launcher's own rule (twice the expected rows per expert) applies. */
+int tm_debug_grouped_tile(int weight_type, int K, int N, int tokens, int* rows);
 /* Host-only: every (shape, splits) pair the start-up tuner (tm_engine_tune_gemm; gemm::Gemm::Run's dispatch candidates,
  * src/turbomind/kernels/gemm/gemm.cu:92-224) may pick for a K x N linear at M rows; *count = how many exist (<= 128), the first
  * min(cap, *count) are written.  The full-size parity tests sweep exactly this list. */

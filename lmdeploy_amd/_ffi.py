@@ -121,6 +121,8 @@ _SIGNATURES = {
     'tm_gemm_import': (c_int, [c_char_p]),
     'tm_debug_set_block_stride': (c_int, [c_int]),
     'tm_debug_pick_tiling': (c_int, [c_int, c_int, c_int, c_int, POINTER(c_int), POINTER(c_int)]),
+    'tm_debug_pick_general': (c_int, [c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    'tm_debug_grouped_tile': (c_int, [c_int, c_int, c_int, c_int, POINTER(c_int)]),
     'tm_engine_comm_drop_rccl': (c_int, [c_void_p]),
     'tm_engine_comm_info': (c_int, [c_void_p, POINTER(c_int), POINTER(c_int), POINTER(c_int)]),
     'tm_debug_tiling_candidates': (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_int, POINTER(c_int)]),

@@ -750,6 +750,28 @@ int tm_debug_pick_tiling(int K, int N, int M, int use_table, int* shape, int* sp
     return 0;
 }
 
+int tm_debug_pick_general(int weight_type, int role, int K, int N, int M, int* config4)
+{
+    TM_REQUIRE(config4 && K > 0 && N > 0 && M > 0 && weight_type >= 0 && weight_type <= 2 && role >= 0 && role <= 7, "arguments");
+    TM_REQUIRE(K % 128 == 0 && N % 16 == 0, "gemm_kernel takes K % 128 == 0, N % 16 == 0");
+    LinearWeight w{};
+    w.K    = K;
+    w.N    = N;
+    w.type = weight_type;
+    w.role = role;
+    const GemmConfig c = gemm_pick_config_general(w, M);
+    config4[0] = c.nt, config4[1] = c.splits, config4[2] = c.waves, config4[3] = c.kphases;
+    return 0;
+}
+
+int tm_debug_grouped_tile(int weight_type, int K, int N, int tokens, int* rows)
+{
+    TM_REQUIRE(rows && K > 0 && N > 0 && tokens > 0 && (weight_type == 0 || weight_type == 2), "arguments");
+    int tv[4];
+    *rows = gen_table_get(kGenGrouped + weight_type, 0, K, N, dec32_m_bucket(tokens), tv) ? tv[0] : 0;
+    return 0;
+}
+
 int tm_debug_tiling_candidates(int K, int N, int M, int* shapes, int* splits, int cap, int* count)
 {
     TM_REQUIRE(shapes && splits && count && cap >= 0 && K > 0 && N > 0 && M > 0, "arguments");

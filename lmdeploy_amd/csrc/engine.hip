@@ -18,6 +18,7 @@
 #include <cmath>
 #include <condition_variable>
 #include <cstring>
+#include <functional>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -997,7 +998,7 @@ int tm_engine_create(tm_engine** out, const tm_engine_config* c)
     }
     e->slots["tok_embeddings.weight"].bytes = (int64_t)m.vocab * m.hidden * 2;  // replicated
     e->slots["norm.weight"].bytes           = (int64_t)m.hidden * 2;
-    add_linear(e, e->output, "output", m.hidden, e->vocab_local, TM_WEIGHT_F16);
+    add_linear(e, e->output, "output", m.hidden, e->vocab_local, TM_WEIGHT_F16, 5);
     *out = e;
     return 0;
 }
@@ -1449,6 +1450,239 @@ static int tune_decode_gemms(tm_engine* e, int M, bool verbose)
     return rc;
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// The same for everything that is not a P32 kernel: the dense linears gemm_kernel serves (e4m3 weight-only
+// w_qkv / wo / w1w3 / w2, the fp16 lm_head) and the grouped expert GEMMs (row-tile height; u4 through gemm_kernel<GRP>, e4m3 on
+// the fp8 matrix cores).  Same method: one hipGraph per candidate over the model's own weights, min of 5 replays, a measured
+// winner replaces the heuristic only when it is >= 7 % faster.  Results enter gen_table (tm_kernels.h) and travel in the same
+// export / import file as the P32 entries.
+// ------------------------------------------------------------------------------------------------------------------
+static int time_graph_us(tm_engine* e, const std::function<int()>& chain, float* us_out)
+{
+    hipStream_t    st = e->stream;
+    hipGraph_t     g  = nullptr;
+    hipGraphExec_t ge = nullptr;
+    hipEvent_t     e0 = nullptr, e1 = nullptr;
+    float          us = 1e30f;
+    auto           run = [&]() -> int {
+        TM_TRY(chain());  // eager once: lazy module loading, function attributes
+        TM_HIP_CHECK(hipEventCreate(&e0));
+        TM_HIP_CHECK(hipEventCreate(&e1));
+        TM_HIP_CHECK(hipStreamSynchronize(st));
+        TM_HIP_CHECK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+        const int        crc = chain();
+        const hipError_t erc = hipStreamEndCapture(st, &g);  // always ends the capture: a failed candidate must not leave the stream capturing
+        if (crc) {
+            return crc;
+        }
+        TM_HIP_CHECK(erc);
+        TM_HIP_CHECK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+        for (int rep = 0; rep < 6; ++rep) {
+            TM_HIP_CHECK(hipEventRecord(e0, st));
+            TM_HIP_CHECK(hipGraphLaunch(ge, st));
+            TM_HIP_CHECK(hipEventRecord(e1, st));
+            TM_HIP_CHECK(hipEventSynchronize(e1));
+            float ms = 0.f;
+            TM_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+            if (rep > 0) {
+                us = std::min(us, ms * 1000.f);
+            }
+        }
+        return 0;
+    };
+    const int rc = run();
+    if (ge) {
+        (void)hipGraphExecDestroy(ge);
+    }
+    if (g) {
+        (void)hipGraphDestroy(g);
+    }
+    if (e0) {
+        (void)hipEventDestroy(e0);
+    }
+    if (e1) {
+        (void)hipEventDestroy(e1);
+    }
+    *us_out = us;
+    return rc;
+}
+
+static int tune_aux_gemms(tm_engine* e, int M, bool verbose)
+{
+    hipStream_t st = e->stream;
+    const int   Mb = dec32_m_bucket(M);
+    int         tv[4];
+    // ---- dense linears of the general kernel: per role over the layers (with the consumer of wo / w2), then the lm_head ----
+    struct Role {
+        const char*   name;
+        int           which;  // 0 qkv, 1 wo, 2 w13, 3 w2, 4 lm_head
+        const half_t* x;
+        int           ldx;
+        half_t*       y;
+        int           ldy;
+        bool          gated;
+    };
+    half_t* const norm_out = M <= e->cfg.max_batch_size ? e->d_last : e->d_x;
+    const Role roles[5] = {{"w_qkv", 0, e->d_x, e->hidden, e->d_qkv, e->qkv_n, false},
+                           {"wo", 1, e->d_attn, e->q_heads * e->D, e->d_tmp, e->hidden, false},
+                           {"w1w3", 2, e->d_x, e->hidden, e->d_act, e->inter, true},
+                           {"w2", 3, e->d_act, e->inter, e->d_tmp, e->hidden, false},
+                           {"lm_head", 4, e->d_last, e->hidden, e->d_logits, e->vocab_local, false}};
+    TM_TRY(launch_fill_uniform_f16(e->d_x, (size_t)M * e->hidden, 1.7f, 1u, st));
+    TM_TRY(launch_fill_uniform_f16(e->d_attn, (size_t)M * e->q_heads * e->D, 0.5f, 2u, st));
+    TM_TRY(launch_fill_uniform_f16(e->d_act, (size_t)M * e->inter, 0.5f, 3u, st));
+    for (const Role& r : roles) {
+        std::vector<const LinearWeight*> ws;
+        if (r.which == 4) {
+            if (M <= e->cfg.max_batch_size) {  // logits exist for batch-slot rows only
+                TM_TRY(launch_fill_uniform_f16(e->d_last, (size_t)M * e->hidden, 1.7f, 4u, st));
+                ws.push_back(&e->output.w);
+            }
+        }
+        else {
+            for (Layer& L : e->layers) {
+                if (r.which >= 2 && L.is_moe) {
+                    continue;
+                }
+                const LinearWeight* w = r.which == 0 ? &L.qkv.w : r.which == 1 ? &L.wo.w : r.which == 2 ? &L.w13.w : &L.w2.w;
+                if (!dec32_supported(*w, M)) {
+                    ws.push_back(w);
+                }
+            }
+        }
+        if (ws.empty() || (r.which < 4 && ws.size() < 2)) {
+            continue;
+        }
+        const LinearWeight& w0 = *ws[0];
+        if (gen_table_get(kGenDense + w0.type, w0.role, w0.K, w0.N, Mb, tv)) {
+            continue;  // imported / tuned already
+        }
+        GemmConfig cand[16];
+        int        nc = gen_dense_candidates(w0, M, e->gemm_ws_bytes, cand, 15);
+        if (nc == 0) {
+            continue;
+        }
+        const GemmConfig heur = gemm_pick_config_general(w0, M);
+        auto same = [](const GemmConfig& a, const GemmConfig& b) { return a.nt == b.nt && a.splits == b.splits; };
+        bool has = false;
+        for (int i = 0; i < nc; ++i) {
+            has = has || same(cand[i], heur);
+        }
+        if (!has) {
+            cand[nc++] = heur;
+        }
+        const bool norm_consumer = (r.which == 1 || r.which == 3) && !e->use_comm;
+        float      best = 1e30f, t_heur = 1e30f;
+        GemmConfig bc = heur;
+        for (int i = 0; i < nc; ++i) {
+            const GemmConfig cfg = cand[i];
+            if (gemm_workspace_bytes(M, w0.N, cfg.splits) > e->gemm_ws_bytes) {
+                continue;
+            }
+            auto chain = [&]() -> int {
+                for (const LinearWeight* w : ws) {
+                    int slabs = 1;
+                    TM_TRY(launch_linear(*w, r.x, r.ldx, r.y, r.ldy, M, r.gated, cfg, e->d_gemm_ws, norm_consumer && cfg.splits > 1, &slabs, st));
+                    if (norm_consumer) {
+                        TM_TRY(launch_residual_rmsnorm(norm_out, e->d_resid, slabs > 1 ? nullptr : e->d_tmp, slabs > 1 ? e->d_gemm_ws : nullptr,
+                                                       slabs, nullptr, e->final_norm, e->cfg.model.rms_eps, M, e->hidden, st));
+                    }
+                    else if (r.which == 4) {  // the head's consumer
+                        TM_TRY(launch_argmax(e->d_next_ids, nullptr, e->d_logits, M, e->vocab_local, e->vocab_local, 0, st));
+                    }
+                }
+                return 0;
+            };
+            if (norm_consumer) {
+                TM_HIP_CHECK(hipMemsetAsync(e->d_resid, 0, (size_t)M * e->hidden * 2, st));
+            }
+            float us = 1e30f;
+            TM_TRY(time_graph_us(e, chain, &us));
+            us /= (float)ws.size();
+            if (same(cfg, heur)) {
+                t_heur = us;
+            }
+            if (us < best) {
+                best = us;
+                bc   = cfg;
+            }
+            if (verbose) {
+                fprintf(stderr, "[tm tune] %-7s K=%d N=%d M=%d general nt %d splits %d: %8.2f us%s\n", r.name, w0.K, w0.N, M, cfg.nt, cfg.splits, us,
+                        same(cfg, heur) ? "  <- heuristic" : "");
+            }
+        }
+        if (!(best < 0.93f * t_heur)) {
+            bc = heur;
+        }
+        const int v[4] = {bc.nt, bc.splits, bc.waves, bc.kphases < 1 ? 1 : bc.kphases};
+        gen_table_set(kGenDense + w0.type, w0.role, w0.K, w0.N, Mb, v);
+        if (verbose) {
+            fprintf(stderr, "[tm tune] %-7s K=%d N=%d M=%d -> general nt %d splits %d (%.2f us; heuristic %.2f us)\n", r.name, w0.K, w0.N, M, bc.nt,
+                    bc.splits, best, t_heur);
+        }
+    }
+    // ---- grouped expert GEMMs: the row-tile height, first of w1w3 (w2 on its heuristic), then of w2 ----
+    std::vector<Layer*> moe;
+    for (Layer& L : e->layers) {
+        if (L.is_moe) {
+            moe.push_back(&L);
+        }
+    }
+    if (moe.size() >= 2 && e->d_moe_ws) {
+        auto chain = [&]() -> int {
+            for (Layer* L : moe) {
+                TM_TRY(moe_forward(L->moe, e->d_tmp, e->hidden, e->d_x, e->hidden, M, e->d_moe_ws, nullptr, nullptr, st));
+            }
+            return 0;
+        };
+        for (int which = 0; which < 2; ++which) {
+            const LinearWeight& proto = which == 0 ? moe[0]->moe.w13[0] : moe[0]->moe.w2[0];
+            const int           kind  = kGenGrouped + proto.type;
+            if (gen_table_get(kind, 0, proto.K, proto.N, Mb, tv)) {
+                continue;
+            }
+            int       rows[4];
+            const int nc = gen_grouped_candidates(proto, M, rows, 4);
+            if (nc < 2) {
+                continue;
+            }
+            float t_heur = 1e30f, best = 1e30f;
+            int   br = 0;
+            TM_TRY(time_graph_us(e, chain, &t_heur));  // no entry: the launchers' own rule
+            for (int i = 0; i < nc; ++i) {
+                const int v[4] = {rows[i], 0, 0, 0};
+                gen_table_set(kind, 0, proto.K, proto.N, Mb, v);
+                float     us = 1e30f;
+                const int rc = time_graph_us(e, chain, &us);
+                gen_table_erase(kind, 0, proto.K, proto.N, Mb);
+                if (rc) {
+                    return rc;
+                }
+                if (verbose) {
+                    fprintf(stderr, "[tm tune] experts %s K=%d N=%d tokens=%d rows/tile %2d: %9.2f us per MoE FFN (heuristic %.2f)\n",
+                            which == 0 ? "w1w3" : "w2", proto.K, proto.N, M, rows[i], us / (float)moe.size(), t_heur / (float)moe.size());
+                }
+                if (us < best) {
+                    best = us;
+                    br   = rows[i];
+                }
+            }
+            if (br && best < 0.93f * t_heur) {  // else: no entry, the heuristic stays
+                const int v[4] = {br, 0, 0, 0};
+                gen_table_set(kind, 0, proto.K, proto.N, Mb, v);
+            }
+            if (verbose) {
+                fprintf(stderr, "[tm tune] experts %s K=%d N=%d tokens=%d -> %s (best %.2f us, heuristic %.2f us per MoE FFN)\n", which == 0 ? "w1w3" : "w2",
+                        proto.K, proto.N, M, (br && best < 0.93f * t_heur) ? "measured tile" : "heuristic", best / (float)moe.size(),
+                        t_heur / (float)moe.size());
+            }
+        }
+    }
+    TM_HIP_CHECK(hipMemsetAsync(e->d_resid, 0, (size_t)M * e->hidden * 2, st));
+    TM_HIP_CHECK(hipStreamSynchronize(st));
+    return 0;
+}
+
 int tm_engine_tune_gemm(tm_engine* e, int M, const char* export_path)
 {
     TM_REQUIRE(e && e->started, "engine not started");
@@ -1456,6 +1690,7 @@ int tm_engine_tune_gemm(tm_engine* e, int M, const char* export_path)
     TM_HIP_CHECK(hipSetDevice(e->cfg.device));
     const char* v = getenv("TM_GEMM_TUNE_VERBOSE");
     TM_TRY(tune_decode_gemms(e, M, v && atoi(v)));
+    TM_TRY(tune_aux_gemms(e, M, v && atoi(v)));
     if (export_path && *export_path) {
         return dec32_table_export(export_path);
     }
@@ -1882,9 +2117,9 @@ static int cb_enter(tm_engine* e)
     e->sched.reset(new BatchScheduler(B, (int)e->num_blocks - 1, e->cfg.session_len, e->cfg.cache_block_seq_len));
     e->free_blocks.clear();
     e->h_active.assign(B, 0);
+    const char* as   = getenv("TM_ASYNC_STEP");  // read when a continuous-batching session starts
+    e->async_step_on = !(as && !atoi(as));
     if (!e->h_step_pin[0]) {
-        const char* as   = getenv("TM_ASYNC_STEP");
-        e->async_step_on = !(as && !atoi(as));
         for (int i = 0; i < 2; ++i) {
             TM_HIP_CHECK(hipHostMalloc((void**)&e->h_step_pin[i], ((size_t)B + 1) * 4, hipHostMallocDefault));
             TM_HIP_CHECK(hipEventCreateWithFlags(&e->ev_step[i], hipEventDisableTiming));

@@ -1053,6 +1053,7 @@ int dec32_table_export(const char* path)
         fprintf(f, "%d %d %d %d %d %d\n", std::get<1>(kv.first), std::get<2>(kv.first), std::get<3>(kv.first), kv.second.first,
                 kv.second.second, std::get<0>(kv.first));
     }
+    gen_table_export_lines(f);  // `G ...` lines: the general kernel / grouped GEMMs (older parsers skip them)
     fclose(f);
     return 0;
 }
@@ -1067,6 +1068,10 @@ int dec32_table_import(const char* path)
     int  K, N, M, shape, splits, n = 0;
     char line[160];
     while (fgets(line, sizeof line, f)) {
+        if (line[0] == 'G') {
+            n += gen_table_import_line(line) ? 1 : 0;
+            continue;
+        }
         int       role = 0;
         const int got  = sscanf(line, "%d %d %d %d %d %d", &K, &N, &M, &shape, &splits, &role);
         if (got < 5 || role < 0 || role > 4) {

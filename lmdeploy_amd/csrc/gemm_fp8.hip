@@ -510,7 +510,9 @@ int launch_linear_fp8_grouped(const LinearWeight& proto, const void* d_groups, i
     p.kb_per_split = p.KB;
     p.epilogue     = gated_silu ? 1 : 0;
     const int want = std::min(m_cap, std::max(1, 2 * m_hint));
-    if (want <= 32) {
+    int       tv[4];
+    const bool measured = gen_table_get(kGenGrouped + 2, 0, proto.K, proto.N, dec32_m_bucket(m_cap), tv);  // tm_engine_tune_gemm
+    if (measured ? tv[0] == 32 : want <= 32) {
         p.zper = (m_cap + 31) / 32;
         dim3 grid((p.ncg + 3) / 4, 1, E * p.zper);
         return launch_fp8_one<1, 4, 4, true>(p, grid, st);

@@ -26,6 +26,10 @@
 #include "tm_common.h"
 #include "tm_kernels.h"
 #include <stdlib.h>
+#include <array>
+#include <map>
+#include <mutex>
+#include <tuple>
 
 namespace tmk {
 
@@ -726,6 +730,127 @@ static int env_int(const char* name, int dflt)
     return v ? atoi(v) : dflt;
 }
 
+// ---- measured dispatch of the general kernel and of the grouped GEMMs (tm_kernels.h: gen_table_*) ----
+static std::map<std::tuple<int, int, int, int, int>, std::array<int, 4>> g_gen_table;  // (kind, role, K, N, M bucket)
+static std::mutex                                                      g_gen_mutex;
+
+void gen_table_set(int kind, int role, int K, int N, int M, const int v[4])
+{
+    std::lock_guard<std::mutex> lk(g_gen_mutex);
+    g_gen_table[std::make_tuple(kind, role, K, N, M)] = {v[0], v[1], v[2], v[3]};
+}
+
+bool gen_table_get(int kind, int role, int K, int N, int M, int v[4])
+{
+    std::lock_guard<std::mutex> lk(g_gen_mutex);
+    auto                        it = g_gen_table.find(std::make_tuple(kind, role, K, N, M));
+    if (it == g_gen_table.end() && role != 0) {
+        it = g_gen_table.find(std::make_tuple(kind, 0, K, N, M));
+    }
+    if (it == g_gen_table.end()) {
+        return false;
+    }
+    for (int i = 0; i < 4; ++i) {
+        v[i] = it->second[i];
+    }
+    return true;
+}
+
+void gen_table_erase(int kind, int role, int K, int N, int M)
+{
+    std::lock_guard<std::mutex> lk(g_gen_mutex);
+    g_gen_table.erase(std::make_tuple(kind, role, K, N, M));
+}
+
+int gen_table_export_lines(FILE* f)
+{
+    std::lock_guard<std::mutex> lk(g_gen_mutex);
+    for (const auto& kv : g_gen_table) {
+        fprintf(f, "G %d %d %d %d %d %d %d %d %d\n", std::get<0>(kv.first), std::get<1>(kv.first), std::get<2>(kv.first),
+                std::get<3>(kv.first), std::get<4>(kv.first), kv.second[0], kv.second[1], kv.second[2], kv.second[3]);
+    }
+    return (int)g_gen_table.size();
+}
+
+// a config the launchers accept for this kind (they clamp per weight type, so validity here = sane ranges)
+static bool gen_entry_valid(int kind, int role, int K, int N, int M, const int v[4])
+{
+    if (role < 0 || role > 7 || K <= 0 || N <= 0 || M <= 0 || K % 128 != 0 || N % 16 != 0 || M != dec32_m_bucket(M)) {
+        return false;
+    }
+    if (kind >= kGenDense && kind <= kGenDense + 2) {
+        return (v[0] == 1 || v[0] == 2 || v[0] == 4) && v[1] >= 1 && v[1] <= 16 && (v[2] == 4 || v[2] == 8 || v[2] == 16)
+               && (v[3] == 1 || v[3] == 2);
+    }
+    if (kind == kGenGrouped) {  // u4 experts: 16 / 32 / 64-row tiles (decode batches only)
+        return (v[0] == 16 || v[0] == 32 || v[0] == 64) && M <= 64;
+    }
+    if (kind == kGenGrouped + 2) {  // e4m3 experts on the fp8 matrix cores: 32 / 64-row tiles
+        return v[0] == 32 || v[0] == 64;
+    }
+    return false;
+}
+
+bool gen_table_import_line(const char* line)
+{
+    int kind, role, K, N, M, v[4];
+    if (sscanf(line, "G %d %d %d %d %d %d %d %d %d", &kind, &role, &K, &N, &M, &v[0], &v[1], &v[2], &v[3]) != 9
+        || !gen_entry_valid(kind, role, K, N, M, v)) {
+        return false;
+    }
+    gen_table_set(kind, role, K, N, M, v);
+    return true;
+}
+
+// every tiling of gemm_kernel worth timing for a dense linear that the P32 kernels do not serve.  fp16 (lm_head): 64- or
+// 128-column workgroups; e4m3 weight-only: one or two tiles per wave; both with the split-K counts that keep >= 8 k-blocks per
+// slice and whose slabs fit the workspace.  (u4 linears of this kernel -- N % 32 != 0 -- keep the heuristic: no model of
+// BASELINE.json has one.)
+int gen_dense_candidates(const LinearWeight& w, int M, size_t workspace_bytes, GemmConfig* out, int cap)
+{
+    if ((w.type != 1 && w.type != 2) || M > 256) {
+        return 0;
+    }
+    const int KB = w.K / 128;
+    int       n  = 0;
+    for (int nt = 1; nt <= 2; ++nt) {
+        for (int sp = 1; sp <= 8; sp *= 2) {
+            if (sp > 1 && (KB % sp != 0 || KB / sp < 8 || gemm_workspace_bytes(M, w.N, sp) > workspace_bytes)) {
+                continue;
+            }
+            if (n < cap) {
+                out[n]         = GemmConfig{};
+                out[n].nt      = nt;
+                out[n].splits  = sp;
+                out[n].waves   = w.type == 1 ? 4 : 8;
+                out[n].kphases = 1;
+                ++n;
+            }
+        }
+    }
+    return n;
+}
+
+int gen_grouped_candidates(const LinearWeight& proto, int m_cap, int* rows_out, int cap)
+{
+    int n = 0;
+    if (proto.type == 0 && m_cap <= 64) {
+        for (int r : {16, 32, 64}) {
+            if (n < cap && (r == 16 || r / 2 < m_cap)) {
+                rows_out[n++] = r;
+            }
+        }
+    }
+    else if (proto.type == 2) {
+        for (int r : {32, 64}) {
+            if (n < cap && (r == 32 || m_cap > 32)) {
+                rows_out[n++] = r;
+            }
+        }
+    }
+    return n;
+}
+
 GemmConfig gemm_pick_config(const LinearWeight& w, int M)
 {
     if (dec32_supported(w, M)) {  // decode batch: the weight-streaming kernel of gemm_decode.hip
@@ -747,6 +872,14 @@ GemmConfig gemm_pick_config_general(const LinearWeight& w, int M)
     const int  ntiles = w.N / 16;
     const int  KB     = w.K / 128;
     const int  mblk   = (M + 63) / 64;
+    int        tv[4];
+    if (gen_table_get(kGenDense + w.type, w.role, w.K, w.N, dec32_m_bucket(M), tv)) {  // measured for this problem (tm_engine_tune_gemm)
+        cfg.nt      = tv[0];
+        cfg.splits  = tv[1] > KB ? KB : tv[1];
+        cfg.waves   = tv[2];
+        cfg.kphases = tv[3];
+        return cfg;
+    }
     cfg.kphases       = 1;
     if (w.type == 1) {
         cfg.nt     = 2;
@@ -1133,7 +1266,11 @@ int launch_linear_grouped(const LinearWeight& proto, const void* d_groups, int E
         // sized for twice that, the (rare) overflow goes to further row blocks -- a 64-row tile for ~16 real rows would
         // spend 3/4 of the MFMA and LDS work on clamped duplicates
         const int want = std::min(m_cap, std::max(1, 2 * m_hint));
-        const int mt   = want <= 16 ? 1 : (want <= 32 ? 2 : 4);
+        int       mt   = want <= 16 ? 1 : (want <= 32 ? 2 : 4);
+        int       tv[4];
+        if (gen_table_get(kGenGrouped + proto.type, 0, proto.K, proto.N, dec32_m_bucket(m_cap), tv)) {
+            mt = tv[0] / 16;  // measured (tm_engine_tune_gemm): 16 / 32 / 64-row tiles
+        }
         p.zper         = (m_cap + 16 * mt - 1) / (16 * mt);
         dim3 grid((ntiles + 7) / 8, 1, E * p.zper);
         if (proto.type == 0) {

@@ -1,5 +1,6 @@
 // Internal launcher declarations (host side of every HIP kernel in this library).
 #pragma once
+#include <stdio.h>
 #include "tm_common.h"
 #include <vector>
 
@@ -166,6 +167,20 @@ int    dec32_table_export(const char* path);
 int    dec32_table_import(const char* path);
 int    dec32_candidates(const LinearWeight& w, int M, int (*out)[2], int cap);
 int    dec32_m_bucket(int M);  // table key of a forward with M rows: M itself up to 256, then 512, 1024, ... 8192
+// Measured dispatch of everything that is NOT a P32 kernel (reference: gemm.cu:92-224 caches every problem the
+// warm-up of turbomind.cc:363-487 meets, not only the dense u4 ones).  One table, key (kind, role, K, N, M bucket):
+//   kind kGenDense + type   : gemm_kernel of a dense linear (fp16 lm_head, e4m3 weight-only, u4 with N % 32 != 0) -> {nt, splits, waves, kphases}
+//   kind kGenGrouped + type : row-tile height of the grouped expert GEMMs (u4: 16 / 32 / 64 rows, fp8 MFMA: 32 / 64) -> {rows, 0, 0, 0}
+// Text form (same file as the P32 table): `G kind role K N M a b c d`.  role 5 = lm_head; grouped entries use role 0.
+constexpr int kGenDense   = 16;
+constexpr int kGenGrouped = 32;
+void   gen_table_set(int kind, int role, int K, int N, int M, const int v[4]);
+bool   gen_table_get(int kind, int role, int K, int N, int M, int v[4]);  // the role's entry, else the role-0 entry
+void   gen_table_erase(int kind, int role, int K, int N, int M);
+int    gen_table_export_lines(FILE* f);      // appends the G lines; returns their number
+bool   gen_table_import_line(const char* line);  // a `G ...` line; false = not valid (ignored)
+int    gen_dense_candidates(const LinearWeight& w, int M, size_t workspace_bytes, GemmConfig* out, int cap);
+int    gen_grouped_candidates(const LinearWeight& proto, int m_cap, int* rows_out, int cap);
 int    launch_linear_dec32(const LinearWeight& w, const half_t* x, int ldx, half_t* y, int ldy, int M, bool gated_silu, int shape,
                            int splits, float* workspace, int* slabs_out, hipStream_t st);
 

@@ -100,6 +100,14 @@ class Engine:
         _ffi.check(self._lib.tm_gemm_import(path.encode()))
 
     @staticmethod
+    def pick_general(weight_type: int, role: int, K: int, N: int, M: int):
+        """(tiles per wave, split-K, waves, k-phases) of the general kernel for a dense linear that the P32 kernels do not serve
+        (fp16 lm_head: weight_type 1, role 5; e4m3 weight-only: weight_type 2) -- measured entry first, then the heuristic"""
+        v = (C.c_int * 4)()
+        _ffi.check(_ffi.load().tm_debug_pick_general(int(weight_type), int(role), int(K), int(N), int(M), v))
+        return tuple(v)
+
+    @staticmethod
     def pick_tiling(K: int, N: int, M: int, use_table: bool = True, role: int = 0):
         """(shape, split-K) the decode GEMM dispatch runs a K x N W4A16 linear with at M rows (measured table first); role: 0 any,
         1 w_qkv, 2 wo, 3 w1w3, 4 w2 -- the measured table is keyed (role, K, N, M)"""

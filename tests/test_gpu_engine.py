@@ -109,13 +109,18 @@ def test_engine_gemm_tuning_roundtrip(cuda, tmp_path, B, pf_class):
     eng.load_weights(export_weights(cfg, w))
     eng.start()
     eng.tune_gemm(B, path)     # B = 80: the 64 < M <= 256 decode path (128-row tiles vs the 32-row-block shapes)
-    rows = [tuple(int(v) for v in ln.split()) for ln in open(path).read().splitlines() if int(ln.split()[2]) == B]
+    lines = open(path).read().splitlines()
+    rows = [tuple(int(v) for v in ln.split()) for ln in lines if not ln.startswith('G') and int(ln.split()[2]) == B]
     assert len(rows) == 4 and all(r[4] >= 1 for r in rows), rows        # w_qkv, wo, w1w3, w2 at M = B
+    # the fp16 lm_head goes through the general kernel: its measured tiling travels as a `G 17 5 K N M nt splits waves kphases` line
+    head = [ln.split() for ln in lines if ln.startswith('G 17 5 ')]
+    assert len(head) == 1 and head[0][3:6] == ['512', '1024', str(B)] and head[0][6] in ('1', '2'), head
     assert {(r[0], r[1]) for r in rows} == {(512, 1024), (512, 512), (512, 2048), (1024, 512)}
     assert {(r[0], r[1], r[5]) for r in rows} == {(512, 1024, 1), (512, 512, 2), (512, 2048, 3), (1024, 512, 4)}    # keyed by role
     if pf_class:               # one 385-token prefill forward: size class 512
         eng.tune_gemm(pf_class, path)
-        rows = [tuple(int(v) for v in ln.split()) for ln in open(path).read().splitlines() if int(ln.split()[2]) == pf_class]
+        rows = [tuple(int(v) for v in ln.split()) for ln in open(path).read().splitlines()
+                if not ln.startswith('G') and int(ln.split()[2]) == pf_class]
         assert len(rows) == 4 and all(r[3] >= 4 for r in rows), rows     # 128-row tiles or 32-row-block shapes
     prompts = (prompts * ((B + 3) // 4))[:B]
     eng.prefill(prompts, max_new_tokens=5)
@@ -666,6 +671,64 @@ def test_engine_moe_matches_oracle(cuda, fmt):
     for s_ in range(steps + 1):
         d = np.abs(logits[s_].astype(np.float32) - ref[s_].astype(np.float32))
         assert d.max() <= 3e-2, f'step {s_}: max logit diff {d.max()}'
+
+
+@pytest.mark.parametrize('fmt', ['fp8', 'u4'])
+def test_engine_moe_measured_dispatch(cuda, tmp_path, fmt):
+    """Measured dispatch for what is not a dense u4 linear: the start-up tuner also times the e4m3
+    weight-only attention linears and the fp16 lm_head (general kernel: tiles per wave x split-K) and the row-tile height of the
+    grouped expert GEMMs, over the model's own layers; the winners travel as `G` lines of the table file.  Whatever the tuner or
+    an imported table selects is the same arithmetic: (a) after tuning at the decode batch and at a 64-token forward the engine
+    reproduces the oracle; (b) every row-tile height the grouped kernels have, forced through an imported line, reproduces it too
+    on a 64-token prefill forward (the size the entry is keyed by) followed by decode steps."""
+    cfg = o.ModelConfig(hidden=256, layers=2, q_heads=4, kv_heads=2, head_dim=128, inter=256, vocab=512, kv_bits=8,
+                        rope=o.RopeParam(128, 1000000.0, 'default', 1.0, 1.0, 4.0, 8192), weight_format=fmt,
+                        moe_experts=4, moe_top_k=2, moe_fp8_act=True)
+    w = o.make_synthetic_weights(cfg, seed=5)
+    weights = export_weights(cfg, w)
+    rng = np.random.default_rng(8)
+    prompts = [rng.integers(0, cfg.vocab, n).astype(np.int32) for n in (40, 9, 15)]      # one 64-token prefill forward
+
+    def run(table_line=None, tune=False):
+        eng = Engine.from_model_config(cfg, weight_type=2 if fmt == 'fp8' else 0, max_batch_size=3, session_len=128, quant_policy=8)
+        eng.load_weights(weights)
+        eng.start()
+        path = str(tmp_path / 'table.txt')
+        if tune:
+            eng.tune_gemm(3, path)
+            eng.tune_gemm(64, path)
+        elif table_line:
+            open(path, 'w').write(table_line + '\n')
+            eng.import_gemm_table(path)
+        eng.prefill(prompts, max_new_tokens=3)
+        lg = [eng.fetch_logits()]
+        for _ in range(2):
+            eng.decode(1)
+            lg.append(eng.fetch_logits())
+        toks = eng.fetch()
+        eng.close()
+        return toks, lg, (open(path).read().splitlines() if tune else [])
+
+    def check(toks, lg, what):
+        om2 = o.OracleModel(cfg, w, batch=3, max_ctx=128)
+        _, ref = om2.forward(prompts)
+        for s_ in range(3):
+            d = np.abs(lg[s_].astype(np.float32) - ref.astype(np.float32))
+            assert d.max() <= 3e-2, f'{what}: step {s_}: max logit diff {d.max()}'
+            if s_ < 2:
+                _, ref = om2.forward([[int(t)] for t in toks[:, s_]])
+
+    toks, lg, lines = run(tune=True)
+    check(toks, lg, 'tuned')
+    g = [ln.split() for ln in lines if ln.startswith('G')]
+    assert any(x[1] == '17' and x[2] == '5' and x[5] == '3' for x in g), lines           # the lm_head at the decode batch
+    if fmt == 'fp8':     # the dense e4m3 linears (w_qkv, wo: weight-only through the general kernel) at both sizes
+        assert {(x[2], x[5]) for x in g if x[1] == '18'} == {('1', '3'), ('2', '3'), ('1', '64'), ('2', '64')}, lines
+    kind = 34 if fmt == 'fp8' else 32
+    for K, N in ((256, 512), (256, 256)):                                                  # experts' w1w3 and w2
+        for rows in ((32, 64) if fmt == 'fp8' else (16, 32, 64)):
+            t2, l2, _ = run(table_line=f'G {kind} 0 {K} {N} 64 {rows} 0 0 0')
+            check(t2, l2, f'experts K={K} N={N} forced {rows}-row tiles')
 
 
 def test_engine_errors_are_status_codes(cuda):

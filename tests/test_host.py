@@ -554,3 +554,49 @@ def test_product_code_never_imports_the_oracle():
                 if re.search(r'^\s*(from|import)\s+oracle\b', src, re.M) or 'tm_oracle' in src:
                     bad.append(fn)
     assert not bad, bad
+
+
+def test_general_kernel_dispatch_table(tmp_path):
+    """Measured dispatch beyond the dense u4 linears (the reference's DispatchCache serves every GEMM the
+    warm-up meets, gemm.cu:92-224, turbomind.cc:363-487): `G kind role K N M a b c d` lines of the table file carry the tiling
+    of the general kernel (kind 16 + weight type: fp16 lm_head = 17, e4m3 weight-only = 18) and the row-tile height of the
+    grouped expert GEMMs (kind 32 + weight type).  Host-side: import -> pick -> export -> import round trip, the role's own
+    entry wins over the role-less one, invalid lines are ignored, prefill-sized M is keyed by size class."""
+    lib = _ffi.load()
+
+    def pick(wt, role, K, N, M):
+        v = (_ffi.C.c_int * 4)()
+        _ffi.check(lib.tm_debug_pick_general(wt, role, K, N, M, v))
+        return tuple(v)
+
+    def tile(wt, K, N, tokens):
+        r = _ffi.C.c_int(-1)
+        _ffi.check(lib.tm_debug_grouped_tile(wt, K, N, tokens, _ffi.C.byref(r)))
+        return r.value
+
+    K, N = 5120, 100352
+    heur = pick(1, 5, K, N, 64)
+    assert heur[:3] == (2, 1, 4)                                     # fp16: 4 waves x 2 tiles, no split-K
+    assert tile(2, 5120, 20480, 64) == 0 and tile(0, 5120, 20480, 64) == 0
+    f = tmp_path / 't.txt'
+    f.write_text(f'G 17 5 {K} {N} 64 1 2 4 1\n'                       # lm_head at M = 64: 64-column workgroups, 2 slices
+                 f'G 18 0 {K} 6144 64 2 4 8 1\n'                      # e4m3 weight-only, any role
+                 f'G 18 2 {K} 6144 64 1 2 8 1\n'                      # ... and wo's own entry
+                 f'G 34 0 5120 20480 64 64 0 0 0\n'                   # fp8 experts: 64-row tiles for 64-token forwards
+                 f'G 32 0 5120 20480 64 16 0 0 0\n'                   # u4 experts: 16-row tiles
+                 f'G 17 5 {K} {N} 64 3 1 4 1\n'                       # invalid: nt = 3
+                 f'G 34 0 5120 20480 64 16 0 0 0\n'                   # invalid: the fp8 grouped kernel has 32 / 64-row tiles
+                 f'G 32 0 5120 20480 128 32 0 0 0\n'                  # invalid: u4 grouped tiles are a decode-batch choice
+                 f'G 18 0 {K} 6144 300 1 1 8 1\n'                     # invalid: 300 is not a table key (257 .. 512 -> 512)
+                 f'{K} 6144 64 6 2 1\n')                              # a P32 line in the same file
+    assert lib.tm_gemm_import(str(f).encode()) == 0
+    assert pick(1, 5, K, N, 64) == (1, 2, 4, 1) and pick(1, 5, K, N, 32)[:2] == heur[:2]       # keyed by M
+    assert pick(2, 1, K, 6144, 64) == (2, 4, 8, 1) and pick(2, 2, K, 6144, 64) == (1, 2, 8, 1)
+    assert tile(2, 5120, 20480, 64) == 64 and tile(0, 5120, 20480, 64) == 16 and tile(0, 5120, 20480, 128) == 0
+    out = tmp_path / 'o.txt'
+    g_lines = [ln for ln in f.read_text().splitlines() if ln.startswith('G')]
+    assert len(g_lines) == 9
+    out.write_text('\n'.join(g_lines[:5]) + '\n')
+    assert lib.tm_gemm_import(str(out).encode()) == 0
+    out.write_text('\n'.join(g_lines[5:]) + '\n')                       # only invalid lines: an error, like an empty table
+    assert lib.tm_gemm_import(str(out).encode()) == 1

@@ -23,6 +23,10 @@ def main():
     ap.add_argument('--prompt', default='64,1024')
     ap.add_argument('--out', default='32,256')
     ap.add_argument('--tune', type=int, default=1)
+    ap.add_argument('--modes', default='1', help='comma list of TM_ASYNC_STEP values: one timed session per entry on ONE engine (A/B of the '
+                    'two-phase schedule / forward overlap on one box); the LAST entry is the line\'s headline value')
+    ap.add_argument('--export-table', default='', help='write the measured GEMM dispatch table here')
+    ap.add_argument('--import-table', default='', help='load a dispatch table instead of measuring (profiling runs: no tuner launches)')
     args = ap.parse_args()
     from lmdeploy_amd.turbomind.engine import Engine
     p0, p1 = map(int, args.prompt.split(','))
@@ -34,9 +38,11 @@ def main():
                                    max_prefill_token_num=8192)
     eng.init_synthetic(seed=0)
     eng.start()
-    if args.tune:   # measured GEMM dispatch: the decode batch and every prefill size class an admission can produce
+    if args.import_table:
+        eng.import_gemm_table(args.import_table)
+    elif args.tune:   # measured GEMM dispatch: the decode batch and every prefill size class an admission can produce
         for m in (args.batch, 512, 1024, 2048, 4096, 8192):
-            eng.tune_gemm(m)
+            eng.tune_gemm(m, args.export_table)
     prompts = [rng.integers(0, LLAMA3_8B['vocab'], n).astype(np.int32) for n in plen]
     # warm-up: one short session (graph capture, lazy module loads)
     for p in prompts[:2]:
@@ -45,25 +51,39 @@ def main():
         pass
     eng.release()
     eng.sync()
-    t0 = time.perf_counter()
-    ids = [eng.submit(p, int(n)) for p, n in zip(prompts, olen)]
-    steps, occ = 0, 0
-    while True:
-        na, nw = eng.step()
-        steps += 1
-        occ += na
-        if na == 0 and nw == 0:
-            break
-    dt = time.perf_counter() - t0
-    got = sum(len(eng.poll(r)[1]) for r in ids)
-    assert got == int(olen.sum()), (got, int(olen.sum()))
+    sessions = []
+    for mode in args.modes.split(','):
+        os.environ['TM_ASYNC_STEP'] = mode      # read by the engine when a continuous-batching session starts
+        ov0 = eng.overlapped_steps()
+        mx0 = eng.mixed_steps()
+        t0 = time.perf_counter()
+        ids = [eng.submit(p, int(n)) for p, n in zip(prompts, olen)]
+        steps, occ = 0, 0
+        while True:
+            na, nw = eng.step()
+            steps += 1
+            occ += na
+            if na == 0 and nw == 0:
+                break
+        eng.sync()
+        dt = time.perf_counter() - t0
+        got = sum(len(eng.poll(r)[1]) for r in ids)
+        assert got == int(olen.sum()), (got, int(olen.sum()))
+        sessions.append({'TM_ASYNC_STEP': mode, 'value': round(got / dt, 1), 'wall_s': round(dt, 3), 'scheduler_steps': steps,
+                         'mean_active_slots': round(occ / steps, 1), 'mixed_steps': eng.mixed_steps() - mx0,
+                         'overlapped_steps': eng.overlapped_steps() - ov0})
+        eng.release()
+    last = sessions[-1]
     print(json.dumps({'metric': 'continuous batching, output tokens/s (request stream, all submitted at t=0)',
-                      'value': round(got / dt, 1), 'unit': 'tokens/s', 'requests': args.requests, 'requests_per_s': round(args.requests / dt, 2),
+                      'value': last['value'], 'unit': 'tokens/s', 'requests': args.requests, 'requests_per_s': round(args.requests / last['wall_s'], 2),
                       'batch_slots': args.batch, 'prompt_len': [p0, p1], 'output_len': [o0, o1], 'prompt_tokens': int(plen.sum()),
-                      'output_tokens': got, 'wall_s': round(dt, 3), 'scheduler_steps': steps,
-                      'mean_active_slots': round(occ / steps, 1), 'total_tokens_per_s': round((got + int(plen.sum())) / dt, 1),
-                      'mixed_steps': eng.mixed_steps(), 'TM_MIXED_STEP': os.environ.get('TM_MIXED_STEP', '1'),
-                      'gemm_dispatch': 'measured (decode batch + prefill size classes 512 .. 8192)' if args.tune else 'heuristic'}))
+                      'output_tokens': int(olen.sum()), 'wall_s': last['wall_s'], 'scheduler_steps': last['scheduler_steps'],
+                      'mean_active_slots': last['mean_active_slots'],
+                      'total_tokens_per_s': round((int(olen.sum()) + int(plen.sum())) / last['wall_s'], 1),
+                      'mixed_steps': last['mixed_steps'], 'overlapped_steps': last['overlapped_steps'],
+                      'TM_MIXED_STEP': os.environ.get('TM_MIXED_STEP', '1'), 'TM_ASYNC_STEP': last['TM_ASYNC_STEP'], 'sessions': sessions,
+                      'gemm_dispatch': ('imported table' if args.import_table else 'measured (decode batch + prefill size classes 512 .. 8192)')
+                                       if (args.tune or args.import_table) else 'heuristic'}))
     eng.close()
 
 

@@ -9,7 +9,42 @@ def main():
     by_grid = '--by-grid' in sys.argv   # one line per (kernel, grid): separates the four decode linears of one template
     if by_grid:
         sys.argv.remove('--by-grid')
+    window_s = None
+    if '--window-s' in sys.argv:   # device-busy analysis of the LAST x seconds of the trace (a timed region that ends the process)
+        i = sys.argv.index('--window-s')
+        window_s = float(sys.argv[i + 1])
+        del sys.argv[i:i + 2]
     db = sqlite3.connect(sys.argv[1])
+    if window_s is not None:
+        cur = db.cursor()
+        t_end = cur.execute("select max(end) from kernels").fetchone()[0]
+        t_lo = t_end - int(window_s * 1e9)
+        iv = sorted(cur.execute("select start, end from kernels where start >= ?", (t_lo,)).fetchall())
+        busy, cur_s, cur_e, gaps = 0, None, None, []
+        for s_, e_ in iv:
+            if cur_e is None or s_ > cur_e:
+                if cur_e is not None:
+                    busy += cur_e - cur_s
+                    gaps.append(s_ - cur_e)
+                cur_s, cur_e = s_, e_
+            else:
+                cur_e = max(cur_e, e_)
+        if cur_e is not None:
+            busy += cur_e - cur_s
+        span = (iv[-1][1] - iv[0][0]) if iv else 0
+        big = sorted(gaps, reverse=True)
+        print(f'window: last {window_s:.3f} s of the trace: {len(iv)} kernels, span {span / 1e6:.1f} ms, device busy (union of kernel intervals) '
+              f'{busy / 1e6:.1f} ms = {100.0 * busy / max(span, 1):.1f} %, idle {(span - busy) / 1e6:.1f} ms')
+        for lo, hi in ((0, 2e3), (2e3, 1e4), (1e4, 1e5), (1e5, 1e6), (1e6, 1e12)):
+            sel = [g for g in gaps if lo <= g < hi]
+            print(f'  gaps {lo / 1e3:8.0f} .. {hi / 1e3:10.0f} us: {len(sel):7d}, {sum(sel) / 1e6:9.2f} ms')
+        print('  largest gaps (us): ' + ', '.join(f'{g / 1e3:.0f}' for g in big[:12]))
+        rows = list(cur.execute("select name, grid_x/workgroup_x*grid_y/workgroup_y*grid_z/workgroup_z, count(*), sum(end-start), avg(end-start) from kernels "
+                                "where start >= ? group by 1, 2 order by 4 desc", (t_lo,)))
+        print(f'{"kernel":60s} {"wgs":>8s} {"calls":>7s} {"total_ms":>10s} {"avg_us":>9s}')
+        for r in rows[:45]:
+            print(f'{r[0][:60]:60s} {int(r[1]):8d} {r[2]:7d} {r[3] / 1e6:10.3f} {r[4] / 1e3:9.2f}')
+        return
     like = f'%{sys.argv[2]}%' if len(sys.argv) > 2 else '%'
     cur = db.cursor()
     if by_grid:
