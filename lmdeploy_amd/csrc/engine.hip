@@ -2579,6 +2579,7 @@ int tm_engine_submit(tm_engine* e, const int* host_ids, int n, int max_new_token
 static int cb_launch_decode(tm_engine* e)
 {
     if (e->graph_cb && (e->graph_cb_sampling != e->sampling_on || e->graph_cb_logits != e->logits_on)) {
+        TM_HIP_CHECK(hipStreamSynchronize(e->stream));  // (a replay of the old graph may still be running)
         (void)hipGraphExecDestroy(e->graph_cb);
         e->graph_cb = nullptr;
     }
