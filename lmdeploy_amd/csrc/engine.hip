@@ -323,13 +323,13 @@ struct tm_engine {
     // the scheduler, finished slots parked) by different scheduler steps -- step N+1 is issued before step N is retired, so the
     // host's bookkeeping, the caller's polling and the next launch run under the device's step N+1.  A sequence that ends in
     // step N rides one more step as a dead row (its token is dropped: the slot's request id no longer matches).
-    // TM_ASYNC_STEP=0 retires every step in the call that issued it.
+    // TM_ASYNC_STEP=1 switches the overlap on; by default every step is retired by the call that issued it (see cb_enter).
     struct PendingStep {
         bool                 valid = false;
         int                  buf   = 0;
         std::vector<int64_t> ids;  // request of every slot whose token this step produces (-1: free, parked, prefilled by this step)
     } pending;
-    bool       async_step_on = true;
+    bool       async_step_on = false;
     int*       h_step_pin[2] = {nullptr, nullptr};  // pinned [max_batch + 1]: next ids of the slots, then the communicator's give-up mark
     hipEvent_t ev_step[2]    = {nullptr, nullptr};
     int        issue_count   = 0;
@@ -2117,8 +2117,11 @@ static int cb_enter(tm_engine* e)
     e->sched.reset(new BatchScheduler(B, (int)e->num_blocks - 1, e->cfg.session_len, e->cfg.cache_block_seq_len));
     e->free_blocks.clear();
     e->h_active.assign(B, 0);
-    const char* as   = getenv("TM_ASYNC_STEP");  // read when a continuous-batching session starts
-    e->async_step_on = !(as && !atoi(as));
+    // read when a continuous-batching session starts.  Default OFF -- measured (profiles/r04_request_stream_device_busy.txt): the device
+    // is 97.9 % busy over the request-stream benchmark with synchronous steps, so the overlap has no idle time to hide, while a
+    // sequence that ends rides one dead row and every admission waits one more step: 7 899 vs 7 932 output tok/s (A/B on one engine)
+    const char* as   = getenv("TM_ASYNC_STEP");
+    e->async_step_on = as && atoi(as);
     if (!e->h_step_pin[0]) {
         for (int i = 0; i < 2; ++i) {
             TM_HIP_CHECK(hipHostMalloc((void**)&e->h_step_pin[i], ((size_t)B + 1) * 4, hipHostMallocDefault));

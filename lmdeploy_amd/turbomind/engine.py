@@ -194,7 +194,7 @@ class Engine:
 
     def overlapped_steps(self) -> int:
         """continuous batching: decode steps issued while the previous one was still unretired (the two-phase schedule /
-        forward overlap of the reference, turbomind.cc:171; TM_ASYNC_STEP=0 switches it off)"""
+        forward overlap of the reference, turbomind.cc:171; TM_ASYNC_STEP=1 switches it on)"""
         out = np.zeros(1, np.int64)
         _ffi.check(self._lib.tm_engine_debug_read(self._h, 3, 0, 0, out.ctypes.data, 8))
         return int(out[0])

@@ -23,7 +23,7 @@ def main():
     ap.add_argument('--prompt', default='64,1024')
     ap.add_argument('--out', default='32,256')
     ap.add_argument('--tune', type=int, default=1)
-    ap.add_argument('--modes', default='1', help='comma list of TM_ASYNC_STEP values: one timed session per entry on ONE engine (A/B of the '
+    ap.add_argument('--modes', default='0', help='comma list of TM_ASYNC_STEP values: one timed session per entry on ONE engine (A/B of the '
                     'two-phase schedule / forward overlap on one box); the LAST entry is the line\'s headline value')
     ap.add_argument('--export-table', default='', help='write the measured GEMM dispatch table here')
     ap.add_argument('--import-table', default='', help='load a dispatch table instead of measuring (profiling runs: no tuner launches)')
