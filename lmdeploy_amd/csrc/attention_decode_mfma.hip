@@ -248,7 +248,7 @@ __global__ __launch_bounds__(256, 2) void decode_attention_i8_mfma_kernel(Decode
             // int8: token (lane/8 + 8r), 16-byte chunk lane%8 of its 128 bytes; int4: token (lane/4 + 16r), chunk lane%4 of 64
             const int row = BITS == 8 ? (lane >> 3) + 8 * r : (lane >> 2) + 16 * r;
             const int off = BITS == 8 ? min(row, last) * 128 + (lane & 7) * 16 : min(row, last) * 64 + (lane & 3) * 16;
-            // non-temporal: every cache byte is read ONCE per launch by ONE workgroup -- measured (tools/r03_calls/call8.sh,
+            // non-temporal: every cache byte is read ONCE per launch by ONE workgroup -- measured (round 3, call 8;
             // profiles/r03_attention_nontemporal_loads.txt) 32.4 -> 30.3 us at ctx 1040, 43.3 -> 39.5 us at ctx 1536
             kreg[r]       = __builtin_nontemporal_load((const u32x4*)(base + koff + off));
             vreg[r]       = __builtin_nontemporal_load((const u32x4*)(base + voff + off));

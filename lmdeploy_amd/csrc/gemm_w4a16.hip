@@ -318,7 +318,7 @@ __device__ __forceinline__ half8_t dequant8(uint32_t w, half2_t s2, half2_t z2, 
 //   * KS > 1 exists because an iteration costs a fixed ~1200 cycles of exposed latencies (barrier, LDS round trip,
 //     waitcnt) that nothing hides while all waves of the CU move in lockstep (measured by ablation: the phases of an
 //     iteration are additive): more k-blocks per barrier amortise that chain.
-// ABL: ablation bit mask for tools/ablate_gemm.sh (timing experiments only, results are garbage):
+// ABL: ablation bit mask (timing experiments of -DTM_EXPERIMENTS builds only, results are garbage):
 //   1 no dequant VALU, 2 no MFMA, 4 no LDS x reads, 8 no x staging (loads + LDS writes), 16 no weight loads in the loop,
 //   32 half of the activation loads, 64 half of the activation LDS writes
 template<int WT, int MT, int NT, int WN, int WK, int KS, int PF, int ABL = 0, bool GRP = false>
@@ -980,8 +980,9 @@ static int launch_u4_nt1(const GemmParams& p, dim3 grid, int ks, hipStream_t st)
 {
     if constexpr (WK == 1) {
       if (ks == 4) {
+#ifdef TM_EXPERIMENTS  // timing-ablation instantiations (results are garbage by design): not in the shipped library
         if constexpr (MT == 4) {
-            switch (env_int("TM_GEMM_ABL", 0)) {  // ablation timing experiments (tools/ablate_gemm.sh)
+            switch (env_int("TM_GEMM_ABL", 0)) {  // ablation timing experiments (round 1)
                 case 1: return launch_one<0, MT, 1, WN, WK, 4, 2, 1>(p, grid, st);
                 case 2: return launch_one<0, MT, 1, WN, WK, 4, 2, 2>(p, grid, st);
                 case 4: return launch_one<0, MT, 1, WN, WK, 4, 2, 4>(p, grid, st);
@@ -999,6 +1000,7 @@ static int launch_u4_nt1(const GemmParams& p, dim3 grid, int ks, hipStream_t st)
                 default: break;
             }
         }
+#endif
         return launch_one<0, MT, 1, WN, WK, 4, 2>(p, grid, st);
       }
     }
@@ -1145,7 +1147,7 @@ int launch_linear(const LinearWeight& w,
     p.dbg      = nullptr;  // set below, once the grid is known
     // k-blocks per grid.y slice: whole iterations of ks*wk k-blocks, for every slice including the last one.
     // ks (k-blocks per barrier) = the largest of {4, 2, 1} (capped by cfg.kstage) that divides the slice.
-    // measured (tools/ablate_gemm.sh): more k-blocks per barrier does NOT pay (the loop is issue-bound, not
+    // measured (round 1 ablations): more k-blocks per barrier does NOT pay (the loop is issue-bound, not
     // barrier-bound), so the default is 1; TM_GEMM_KSTAGE=2|4 keeps the experiment reachable.
     int ks_cap = cfg.kstage > 0 ? cfg.kstage : 1;
     if (w.type != 0 || (waves == 4 && nt == 4) || waves == 16) {
