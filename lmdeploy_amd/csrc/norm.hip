@@ -5,7 +5,7 @@
 // Arithmetic (rms_norm_utils.cuh:6-15): r = h(r + hcur) [then h(r + bias)];
 //   inv = rsqrtf(sum f32(r)^2 / H + eps);  y = h( h(f32(r) * inv) * w ).
 // One workgroup per token row; 16-byte vector accesses; the row lives in registers between the two
-// passes (norm_row.h: the same device function closes the row-parallel decode GEMMs in-launch).  HBM-bound (tiny): the point is fusing the split-K reduce of the
+// passes (norm_row.h).  Latency-bound (tiny): the point is fusing the split-K reduce of the
 // preceding row-parallel GEMM so that no extra launch / HBM round trip is spent on it.
 #include "tm_common.h"
 #include "tm_kernels.h"

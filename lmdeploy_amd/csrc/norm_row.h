@@ -1,5 +1,4 @@
-// One token row of (split-K reduce +) residual + RMSNorm, shared by rmsnorm_kernel (norm.hip) and by the in-launch
-// consumer at the end of the row-parallel decode GEMMs (gemm_decode.hip) so that both produce the same bits.
+// One token row of (split-K reduce +) residual + RMSNorm: the body of rmsnorm_kernel (norm.hip).
 //
 // Arithmetic (src/turbomind/kernels/norm/rms_norm.cu:286-362, rms_norm_utils.cuh:6-15): r = h(r + hcur) [then h(r + bias)];
 //   inv = rsqrtf(sum f32(r)^2 / H + eps);  y = h( h(f32(r) * inv) * w ).
@@ -38,29 +37,14 @@ __device__ __forceinline__ float norm_block_sum(float v, float* smem, int tid, i
     return t;
 }
 
-// 16-byte slab load: plain, or `sc1` through a buffer descriptor (aux bit 4; L1-bypassing: the slabs were written by other
-// workgroups of the SAME launch with write-through stores -- cdna_hip_programming.md Guideline 16 R1; nothing another CU
-// stored is ever taken from this CU's L1).  `off` = float index into the slab workspace.
-template<bool SC1>
-__device__ __forceinline__ floatx4 norm_slab_load(const float* base, size_t off)
-{
-    if constexpr (SC1) {
-        const auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0x7fffffff, 0x00020000);
-        return bit_cast<floatx4>(__builtin_amdgcn_raw_buffer_load_b128(rs, (int)(off * 4), 0, /*sc1*/ 16));
-    }
-    else {
-        return *(const floatx4*)(base + off);
-    }
-}
-
 // MODE 0: y = rmsnorm(x)
 // MODE 1: r += h ; y = rmsnorm(r)         (h fp16)
 // MODE 2: r += h(sum_s partial[s]) ; ...  (h given as S fp32 split-K slabs [S][M][H])
 // Row `row`, executed by threads tid < nthreads of the workgroup (all threads call; `red` = 8 floats of LDS).  The row is a
 // pure latency chain, so EVERY load a thread needs -- residual, hidden or the first four slabs, and the norm weight -- is
 // issued before anything is consumed.  Threads past the row end load clamped (valid) addresses and skip the stores.
-// Two halves so that the in-launch consumer can fetch what does not depend on the other workgroups (residual, norm weight)
-// BEFORE it waits for them: norm_row_load, then norm_row_finish (slabs -> sum -> residual add -> norm -> stores).
+// Two halves: norm_row_load (what does not depend on the producing GEMM: residual, norm weight), then norm_row_finish
+// (slabs -> sum -> residual add -> norm -> stores).
 template<int NV>
 struct NormRowRegs {
     half8_t wv[NV], r[NV], hc[NV], bv[NV];
@@ -91,8 +75,7 @@ __device__ __forceinline__ void norm_row_load(NormRowRegs<NV>& g, const half_t* 
     }
 }
 
-// SC1: the slab loads bypass L1 (in-launch consumer, see norm_slab_load).
-template<int MODE, bool HAS_BIAS, int NV, bool SC1 = false>
+template<int MODE, bool HAS_BIAS, int NV>
 __device__ __forceinline__ void norm_row_finish(NormRowRegs<NV>& g, half_t* __restrict__ y, half_t* __restrict__ resid,
                                                 const float* __restrict__ partial, int splits, float eps, int M, int H, int tid,
                                                 int nthreads, float* red)
@@ -105,8 +88,8 @@ __device__ __forceinline__ void norm_row_finish(NormRowRegs<NV>& g, half_t* __re
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const size_t p0 = g.off[i] + (size_t)min(u, splits - 1) * slab;
-                a[i][u][0]      = norm_slab_load<SC1>(partial, p0);
-                a[i][u][1]      = norm_slab_load<SC1>(partial, p0 + 4);
+                a[i][u][0]      = *(const floatx4*)(partial + p0);
+                a[i][u][1]      = *(const floatx4*)(partial + p0 + 4);
             }
         }
     }
@@ -131,8 +114,8 @@ __device__ __forceinline__ void norm_row_finish(NormRowRegs<NV>& g, half_t* __re
             }
             for (int s = 4; s < splits; ++s) {
                 const size_t  p0 = g.off[i] + (size_t)s * slab;
-                const floatx4 a0 = norm_slab_load<SC1>(partial, p0);
-                const floatx4 a1 = norm_slab_load<SC1>(partial, p0 + 4);
+                const floatx4 a0 = *(const floatx4*)(partial + p0);
+                const floatx4 a1 = *(const floatx4*)(partial + p0 + 4);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     acc[e] += a0[e];
@@ -178,7 +161,7 @@ __device__ __forceinline__ void norm_row_finish(NormRowRegs<NV>& g, half_t* __re
     }
 }
 
-template<int MODE, bool HAS_BIAS, int NV, bool SC1 = false>
+template<int MODE, bool HAS_BIAS, int NV>
 __device__ __forceinline__ void norm_row(half_t* __restrict__ y, half_t* __restrict__ resid, const half_t* __restrict__ hidden,
                                          const float* __restrict__ partial, int splits, const half_t* __restrict__ bias,
                                          const half_t* __restrict__ weight, float eps, int M, int H, int row, int tid, int nthreads,
@@ -186,7 +169,7 @@ __device__ __forceinline__ void norm_row(half_t* __restrict__ y, half_t* __restr
 {
     NormRowRegs<NV> g;
     norm_row_load<MODE, HAS_BIAS, NV>(g, resid, hidden, bias, weight, H, row, tid, nthreads);
-    norm_row_finish<MODE, HAS_BIAS, NV, SC1>(g, y, resid, partial, splits, eps, M, H, tid, nthreads, red);
+    norm_row_finish<MODE, HAS_BIAS, NV>(g, y, resid, partial, splits, eps, M, H, tid, nthreads, red);
 }
 
 }  // namespace tmk
