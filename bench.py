@@ -216,6 +216,9 @@ def main():
     ap.add_argument('--allow-shared-devices', action='store_true',
                     help='let several ranks share one GPU when the box has fewer GPUs than --gpus (launcher / bring-up tests only: the '
                          'record then says so and is not a scaling result)')
+    ap.add_argument('--max-prefill-tokens', type=int, default=8192, choices=[512, 1024, 2048, 4096, 8192],
+                    help='TurbomindEngineConfig.max_prefill_token_num: tokens per prefill forward (the reference default is 8192).  The p50 '
+                         'TTFT of B simultaneous prompts is quantised by it: sequences get their first token when THEIR chunk is done')
     ap.add_argument('--decode-splits', type=int, default=0, help='split-KV count of the decode attention (0: the engine\'s heuristic)')
     ap.add_argument('--emulate-tp', type=int, default=0,
                     help='SURVEY 8(e) on a 1-GPU box: run ONE rank\'s shard of a TP=N job (heads / inter / vocab divided by N, '
@@ -269,7 +272,7 @@ def main():
     weight_type = int(model.pop('weight_type', 0))
     eng = Engine.from_model_config(_Cfg(model), weight_type=weight_type, tp=world, rank=rank, device=local_dev, max_batch_size=B,
                                    session_len=S + max_new + 1, quant_policy=args.quant_policy,
-                                   max_prefill_token_num=8192, use_graph=0 if args.no_graph else 1, decode_splits=args.decode_splits)
+                                   max_prefill_token_num=args.max_prefill_tokens, use_graph=0 if args.no_graph else 1, decode_splits=args.decode_splits)
     dog = Watchdog(world > 1, rank)
     comm_note = ''
     if world > 1:
@@ -313,8 +316,8 @@ def main():
                 with tempfile.TemporaryDirectory() as td:
                     path = os.path.join(td, 'gemm_table.txt')
                     eng.tune_gemm(B, path)
-                    if B * S >= 8192:          # the prefill forwards of this run are 8192-token chunks: their size class as well
-                        eng.tune_gemm(8192, path)
+                    if B * S >= args.max_prefill_tokens:   # the prefill forwards of this run are chunks of that size: their size class as well
+                        eng.tune_gemm(args.max_prefill_tokens, path)
                     table = open(path).read()
             except Exception as exc:    # noqa: BLE001 -- the heuristics are the measured winners on these shapes anyway
                 print(f'[bench] GEMM tuning skipped: {exc}', file=sys.stderr)
@@ -393,7 +396,7 @@ def main():
     hq_l, hkv_l = model['q_heads'] // world, max(1, model['kv_heads'] // world)
     D_, H_, I_l = model['head_dim'], model['hidden'], model['inter'] // world
     tilings, prefill_tilings = {}, {}
-    pf_rows = min(B * S, 8192)     # rows of a prefill forward of this run (max_prefill_token_num chunks)
+    pf_rows = min(B * S, args.max_prefill_tokens)     # rows of a prefill forward of this run (max_prefill_token_num chunks)
     if weight_type == 0 and not model.get('moe_experts') and B <= 256:
         for role, (name, (kk, nn)) in enumerate(dict(w_qkv=(H_, (hq_l + 2 * hkv_l) * D_), wo=(hq_l * D_, H_), w1w3=(H_, 2 * I_l),
                                                       w2=(I_l, H_)).items(), start=1):
