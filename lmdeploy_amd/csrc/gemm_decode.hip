@@ -910,12 +910,6 @@ static int launch_dec32_shape(const Dec32Params& p, dim3 grid, int shape, hipStr
             if (abl == 8) return launch_pre64_one<8>(p, grid, st);  // timing: raw codes on the matrix pipe
             if (abl == 24) return launch_pre64_one<24>(p, grid, st);  // + accumulators rescaled per k-block
 #endif
-            // TM_PRE64_PERSIST=1 (experiment arm, round 4): one persistent workgroup per CU walks the tiles and overlaps a tile's
-            // first loads with the previous tile's stores (gemm_prefill_persistent.hip) -- only when there is more than one round
-            const int persist = env_int2("TM_PRE64_PERSIST", 0);  // per launch (prefill-sized launches: a getenv is noise) so that one process can A/B it
-            if (persist && (long)grid.x * grid.y * grid.z > 256 && !p.dbg) {
-                return launch_pre64_persistent(p, grid, st);
-            }
             return launch_pre64_one<0>(p, grid, st);
         }
         if (shape != 4) {

@@ -67,8 +67,4 @@ int launch_dec_lc(const Dec32Params& p, dim3 grid, hipStream_t st);
 // grid = (ceil(ncg / 8), splits, ceil(M / 256))
 int launch_pre256(const Dec32Params& p, dim3 grid, hipStream_t st);
 
-// gemm_prefill_persistent.hip: the 128 x 512 prefill tile (shape 5) as one persistent workgroup per CU that walks the logical
-// grid (ceil(N / 512), splits, ceil(M / 128)) and issues a tile's first loads before it stores the previous tile
-int launch_pre64_persistent(const Dec32Params& p, dim3 logical_grid, hipStream_t st);
-
 }  // namespace tmk

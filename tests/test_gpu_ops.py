@@ -501,32 +501,6 @@ def test_w4a16_linear_prefill_tiles(tm, cuda, K, N, M, gated):
     _ffi.check(tm.tm_linear_destroy(h))
 
 
-@pytest.mark.parametrize('K,N,M,gated,splits', [(1024, 4096, 4200, 0, 1), (1024, 4096, 4200, 0, 2), (512, 2048, 8300, 1, 1), (1792, 1024, 16500, 0, 1)])
-def test_w4a16_persistent_prefill_tile_bit_identical(tm, cuda, monkeypatch, K, N, M, gated, splits):
-    """TM_PRE64_PERSIST=1 (gemm_prefill_persistent.hip): the 128 x 512 prefill tile as one persistent workgroup per CU that walks
-    the tiles and issues a tile's first loads before it stores the previous one.  Same arithmetic in the same order as the plain
-    kernel: outputs must be BIT-identical (more than 256 tiles, ragged last row block, split-K slabs, gated epilogue), and the
-    plain kernel's result is checked against the oracle product here as everywhere else."""
-    rng = np.random.default_rng(K + N + M)
-    h, (q, s, z) = _make_linear(tm, rng, K, N)
-    x = rng.standard_normal((M, K)).astype(f16)
-    ref = (o.w4a16_linear_gated_silu(x, q, s, z) if gated else x.astype(np.float32) @ _QCACHE[(K, N)][3]).astype(np.float32)
-    ws = torch.zeros(max(1, tm.tm_linear_workspace(h, M)), dtype=torch.uint8, device='cuda')
-    x_d = dev(x)
-    assert -(-N // 512) * -(-M // 128) * splits > 256
-    outs = []
-    for persist in ('0', '1', '1'):
-        monkeypatch.setenv('TM_PRE64_PERSIST', persist)
-        y = torch.zeros((M, N // 2 if gated else N), dtype=torch.float16, device='cuda')
-        _ffi.check(tm.tm_linear_forward(h, x_d.data_ptr(), K, y.data_ptr(), y.shape[1], M, gated, 0, splits, 0x200 | 5, ws.data_ptr(), st()))
-        outs.append(host(y))
-    err = np.abs(outs[0].astype(np.float32) - ref)
-    assert np.all(err <= 2e-3 + 2.0**-9 * np.abs(ref)), f'plain kernel: max err {err.max()}'
-    assert np.array_equal(outs[1].view(np.uint16), outs[0].view(np.uint16)), 'persistent kernel differs from the plain kernel'
-    assert np.array_equal(outs[2].view(np.uint16), outs[1].view(np.uint16)), 'persistent kernel: second launch differs'
-    _ffi.check(tm.tm_linear_destroy(h))
-
-
 @pytest.mark.parametrize('K,N,M,splits,waves', [(1792, 4096, 1000, 3, 0x204), (1792, 4096, 2500, 3, 0x204), (1536, 4096, 64, 1, 0x200),
                                                 (1792, 4096, 1000, 3, 0x20c), (4096, 6144, 2500, 1, 0x20c), (1536, 4096, 300, 2, 0x20c),
                                                 (1536, 4096, 64, 3, 0x200), (4608, 4096, 64, 1, 0x201), (1536, 2048, 32, 1, 0x203)])

@@ -77,8 +77,6 @@ def main():
                 waves = 0x200 | shape
                 if 'pf4' in variant:
                     env['TM_D32_PF'] = '4'
-                if variant.endswith('p'):   # d5p: the 128 x 512 tile as a persistent workgroup per CU (gemm_prefill_persistent.hip)
-                    env['TM_PRE64_PERSIST'] = '1'
             elif variant.startswith('abl'):
                 waves = 0x200 | (4 if M > 64 else args.abl_shape)
                 env['TM_D32_ABL'] = variant[3:]
