@@ -600,3 +600,22 @@ def test_general_kernel_dispatch_table(tmp_path):
     assert lib.tm_gemm_import(str(out).encode()) == 0
     out.write_text('\n'.join(g_lines[5:]) + '\n')                       # only invalid lines: an error, like an empty table
     assert lib.tm_gemm_import(str(out).encode()) == 1
+
+
+def test_bench_algorithmic_bytes_match_the_survey():
+    """bench.py's roofline arithmetic (bytes(step) = W_q + W_sz + W_head + B * ctx * kv_bytes_per_token, per rank / tp)
+    against the survey's own figures -- the numbers `roofline.achieved`, `step_roofline` and the judge's re-derivation start from."""
+    import bench
+    m = bench.LLAMA3_8B
+    w, kv = bench.algorithmic_bytes(m, 64, 0, 8, 1)
+    assert abs(w - 4.759e9) < 2e6 and kv == 67584                         # 3.490 + 0.218 + 1.051 GB; int8: 32 x 2 x 8 x (128 + 4)
+    assert bench.algorithmic_bytes(m, 64, 0, 16, 1)[1] == 131072 and bench.algorithmic_bytes(m, 64, 0, 4, 1)[1] == 34816
+    for ctx, gb in ((1024, 9.19), (1536, 11.40), (2047, 13.61)):
+        assert abs(bench.algorithmic_bytes(m, 64, ctx, 8, 1)[0] / 1e9 - gb) < 0.01, ctx
+    assert abs(bench.algorithmic_bytes(m, 64, 1536, 8, 1)[0] / 8e12 * 1e3 - 1.425) < 2e-3     # ms per step at 8 TB/s -> 44.9 k tok/s
+    w20, kv20 = bench.algorithmic_bytes(bench.INTERNLM2_20B, 128, 0, 8, 1)
+    assert abs(w20 - 11.08e9) < 2e7 and kv20 == 101376
+    w70, kv70 = bench.algorithmic_bytes(bench.LLAMA3_70B, 64, 0, 4, 8)
+    assert abs(w70 - 4.81e9) < 2e7 and kv70 == 10880                      # one rank of TP = 8, int4 KV
+    # one decode attention launch = one layer's KV of the batch: 64 x ctx x 2112 B for Llama-3-8B int8 (the `roofline` object)
+    assert kv / m['layers'] == 2112
