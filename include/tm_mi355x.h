@@ -414,6 +414,8 @@ int tm_engine_release(tm_engine* e);
  * TM_GEMM_EXPORT=<file>, TM_GEMM_IMPORT=<file>; TM_GEMM_TUNE_VERBOSE=1 prints every measurement to stderr. */
 int tm_engine_tune_gemm(tm_engine* e, int M, const char* export_path);
 int tm_gemm_import(const char* path);
+/* write the process's measured dispatch tables (P32 lines + `G` lines) without an engine: what rank 0 hands to the other ranks */
+int tm_gemm_export(const char* path);
 
 
 /* ----------------------------------------------------------------------------------------------

@@ -119,6 +119,7 @@ _SIGNATURES = {
     'tm_debug_set_gemm_trace': (c_int, [c_void_p]),
     'tm_engine_tune_gemm': (c_int, [c_void_p, c_int, c_char_p]),
     'tm_gemm_import': (c_int, [c_char_p]),
+    'tm_gemm_export': (c_int, [c_char_p]),
     'tm_debug_set_block_stride': (c_int, [c_int]),
     'tm_debug_pick_tiling': (c_int, [c_int, c_int, c_int, c_int, POINTER(c_int), POINTER(c_int)]),
     'tm_debug_pick_general': (c_int, [c_int, c_int, c_int, c_int, c_int, c_void_p]),

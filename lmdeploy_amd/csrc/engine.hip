@@ -1703,6 +1703,12 @@ int tm_gemm_import(const char* path)
     return dec32_table_import(path);
 }
 
+int tm_gemm_export(const char* path)
+{
+    TM_REQUIRE(path && *path, "path");
+    return dec32_table_export(path);
+}
+
 int tm_engine_start(tm_engine* e)
 {
     TM_REQUIRE(e, "null pointer");

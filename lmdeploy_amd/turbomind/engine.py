@@ -100,6 +100,11 @@ class Engine:
         _ffi.check(self._lib.tm_gemm_import(path.encode()))
 
     @staticmethod
+    def export_gemm_table(path: str):
+        """write this process's measured dispatch tables (the reference's TM_GEMM_EXPORT) -- P32 lines and `G` lines"""
+        _ffi.check(_ffi.load().tm_gemm_export(path.encode()))
+
+    @staticmethod
     def pick_general(weight_type: int, role: int, K: int, N: int, M: int):
         """(tiles per wave, split-K, waves, k-phases) of the general kernel for a dense linear that the P32 kernels do not serve
         (fp16 lm_head: weight_type 1, role 5; e4m3 weight-only: weight_type 2) -- measured entry first, then the heuristic"""

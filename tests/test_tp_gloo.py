@@ -182,3 +182,55 @@ def test_tp2_sampling_gathers_logits_and_draws_identically():
         assert np.array_equal(full.view(np.uint16), logits.view(np.uint16))
         assert toks == want
     assert want[1] == int(np.argmax(logits[1].astype(np.float32)))      # top_k = 1 row = greedy
+
+
+def _table_worker(rank, world, port, tmpdir, ret):
+    """bench.py's start-up protocol for tp > 1: rank 0 holds the measured dispatch tables (here: imported lines stand in for the
+    tuner), exports them as text, the text is broadcast, every other rank imports it -- all ranks must then pick the same tilings"""
+    import ctypes as C
+
+    from lmdeploy_amd import _ffi
+    from lmdeploy_amd.turbomind.engine import Engine
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    lib = _ffi.load()
+    table = None
+    if rank == 0:
+        src = os.path.join(tmpdir, 'measured.txt')
+        open(src, 'w').write('5120 768 64 3 4 1\n640 5120 64 6 1 2\n5120 3584 64 2 2 3\n1792 5120 64 6 1 4\n5120 768 8192 12 1 1\n'
+                             'G 17 5 5120 16032 64 1 2 4 1\nG 18 2 640 5120 64 2 4 8 1\nG 34 0 5120 3584 64 64 0 0 0\n')
+        assert lib.tm_gemm_import(src.encode()) == 0
+        out = os.path.join(tmpdir, 'export.txt')
+        Engine.export_gemm_table(out)
+        table = open(out).read()
+    box = [table]
+    dist.broadcast_object_list(box, src=0)
+    if rank != 0:
+        path = os.path.join(tmpdir, f'import{rank}.txt')
+        open(path, 'w').write(box[0])
+        assert lib.tm_gemm_import(path.encode()) == 0
+    picks = []
+    for role, (K, N) in enumerate(((5120, 768), (640, 5120), (5120, 3584), (1792, 5120)), start=1):
+        picks.append(Engine.pick_tiling(K, N, 64, role=role))
+    picks.append(Engine.pick_tiling(5120, 768, 8192, role=1))
+    picks.append(Engine.pick_general(1, 5, 5120, 16032, 64))
+    picks.append(Engine.pick_general(2, 2, 640, 5120, 64))
+    r = C.c_int(-1)
+    _ffi.check(lib.tm_debug_grouped_tile(2, 5120, 3584, 64, C.byref(r)))
+    picks.append(r.value)
+    ret[rank] = picks
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_tp2_measured_dispatch_tables_travel_from_rank0(tmp_path):
+    """tp > 1: rank 0's measured GEMM dispatch (P32 lines keyed by role + the `G` lines of the general kernel / grouped GEMMs) is
+    exported as text, broadcast and imported by the other ranks (bench.py does exactly this), so that every rank runs identical
+    tilings -- a rank-local winner could differ by measurement noise and desynchronise the ranks' step times."""
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_table_worker, args=(2, _free_port(), str(tmp_path), ret), nprocs=2, join=True)
+    assert ret[0] == ret[1]
+    assert ret[0][:5] == [(3, 4), (6, 1), (2, 2), (6, 1), (12, 1)]
+    assert ret[0][5] == (1, 2, 4, 1) and ret[0][6] == (2, 4, 8, 1) and ret[0][7] == 64
