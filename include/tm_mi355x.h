@@ -177,12 +177,27 @@ int    tm_linear_dequant_f16(const tm_linear* w, void* out_nk, tm_stream_t st);
 /* Row-parallel linear closed by residual + RMSNorm -- wo / w2 of a decoder layer at the decode batch: LlamaLinear::Forward
  * followed by invokeResidualBiasRMSNorm (src/turbomind/models/llama/unified_decoder.cc:149,226; kernels/norm/rms_norm.cu:286-362):
  *   resid += fp16(x . W);  y = RMSNorm(resid) * norm_w.
- * The GEMM (fp32 split-K slabs when it splits), then the reduce-norm kernel.  `fused` must be 0 and `sync` is ignored: round 3's
- * in-launch consumer (the GEMM's last workgroups ran the norm) was bit-identical but slower than the kernel boundary it replaced
- * and was removed in round 4 (TM_INVALID for fused != 0).
- * shape: decode tile 0..3 / 6..9 / 11, -1 = dispatch; splits: 0 = dispatch.  workspace >= tm_linear_workspace(w, M) + M * N * 2 bytes. */
+ * The GEMM (fp32 split-K slabs when it splits), then the reduce-norm kernel.
+ * shape: decode tile 0..3 / 6..9 / 11, -1 = dispatch; splits: 0 = dispatch.  workspace >= tm_linear_workspace(w, M) + M * N * 2 bytes.
+ * (Round 3's in-launch consumer behind a `fused` flag was removed in round 4; its two dead parameters left the signature in round 5.) */
 int    tm_linear_residual_norm(const tm_linear* w, const void* x, int ldx, void* y, void* resid, const void* norm_w, float eps, int M,
-                               int shape, int splits, int fused, void* workspace, void* sync, tm_stream_t st);
+                               int shape, int splits, void* workspace, tm_stream_t st);
+/* The same pair of operators with the RMSNorm FOLDED into the two GEMMs around it (round 5; the engine's decode step at tp = 1):
+ *   RMSNorm(r) . W2 = inv[m] * sum_k (r[m,k] g[k]) W2[k,n],   inv[m] = 1 / sqrt(sum_k r[m,k]^2 / H + eps)
+ * tm_linear_fold_produce -- the row-parallel linear (wo / w2): resid += fp16(x . W) in the GEMM's own epilogue (bit-identical to
+ *   tm_linear_residual_norm's residual stream, split-K included: the last-arriving slice of a column tile sums the slices' fp32 slabs in
+ *   slice order), xg = fp16(f32(resid) * f32(norm_w)) (saturating), ss[tile][m] = sum of f32(resid)^2 over the tile's columns;
+ *   *ss_tiles = tiles written (<= N / 64).  ss holds (N / 64) * M floats; workspace >= tm_linear_fold_workspace(w, M).
+ * tm_linear_fold_consume -- the linear fed with xg: y = [gated SiLU](inv[m] * (xg . W)); norm_h = H of the folded norm.
+ * Replaces invokeResidualBiasRMSNorm + the following LlamaLinear::Forward (unified_decoder.cc:226,278,328; rms_norm.cu:286-362;
+ * epilogue.h:159-176): two launches instead of three; the normalised activations carry ONE fp16 rounding (r * g) instead of two and
+ * the row factor is applied to fp32 accumulators -- tests/test_gpu_ops.py::test_w4a16_folded_norm states the bound next to the
+ * unfused sequence's.  shape: decode tile 0..3 / 6..9, -1 = dispatch; splits: 0 = dispatch. */
+size_t tm_linear_fold_workspace(const tm_linear* w, int M);
+int    tm_linear_fold_produce(const tm_linear* w, const void* x, int ldx, void* xg, void* resid, const void* norm_w, float* ss,
+                              int* ss_tiles, int M, int shape, int splits, void* workspace, tm_stream_t st);
+int    tm_linear_fold_consume(const tm_linear* w, const void* xg, int ldx, void* y, int ldy, int M, int gated_silu, const float* ss,
+                              int ss_tiles, int norm_h, float eps, int shape, int splits, void* workspace, tm_stream_t st);
 /* FP8 x FP8 linear on the fp8 matrix cores -- the reference's path for e4m3 weights on fp8 tensor cores:
  * LlamaLinear::Forward quantises the activations per row and 128-channel group (QuantizeSymm,
  * src/turbomind/kernels/quantization.cu:28-125, called at models/llama/LlamaLinear.cu:67-93) and runs the fp8 GEMM with
@@ -257,6 +272,16 @@ int tm_p2p_allreduce_norm_2shot(void* const* segs, int tp, int me, void* state, 
  * entry, loop entry, loop exit, exit, ...) of every GEMM / decode-attention workgroup launched afterwards; launches of more
  * than 8192 workgroups are not traced; NULL switches it off. */
 int tm_debug_set_gemm_trace(void* dev_buf);
+/* Arena form of the same trace (round 5, tools/fixed_cost_table.py): every traced launch (decode GEMMs, decode attention, the
+ * norm kernels) is given ITS OWN region of `dev_buf` (capacity_workgroups x 8 uint64), in launch order -- so the launches of a
+ * captured hipGraph keep distinct regions and one replay leaves the stamps of every kernel of the decode step.  Slots per
+ * workgroup: 0 entry, 5 prologue loads issued, 1 activations landed (first stage barrier), 6 wave 0's first weight unit landed,
+ * 2 loop exit, 7 k-phase merge barrier, 3 stores drained, 4 (XCC id << 32 | HW_ID); attention: 1 prologue done, 2 / 6 / 7
+ * waves 0 / 1 / 3 done, 5 all waves done.  NULL switches it off and forgets the records.
+ * tm_debug_trace_records: text, one line per traced launch `index tag grid.x grid.y grid.z offset_in_workgroups`; returns the
+ * bytes the text needs.  Host-side bookkeeping is not thread-safe against concurrent LAUNCHES from other engines. */
+int     tm_debug_trace_arena(void* dev_buf, int64_t capacity_workgroups);
+int64_t tm_debug_trace_records(char* host_out, int64_t cap);
 /* Host-only: the (workgroup shape, split-K) the decode GEMM dispatch picks for a W4A16 linear of K x N at M rows --
  * use_table bit 0: the measured table first (tm_engine_tune_gemm / tm_gemm_import), then the heuristic; clear: heuristic only;
  * bits 8 .. 11: the linear's role -- 0 any, 1 w_qkv, 2 wo, 3 w1w3, 4 w2 (the table is keyed (role, K, N, M): the tuner times each

@@ -107,8 +107,13 @@ _SIGNATURES = {
     'tm_linear_forward': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
                                   c_void_p, c_void_p]),
     'tm_linear_dequant_f16': (c_int, [c_void_p, c_void_p, c_void_p]),
-    'tm_linear_residual_norm': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_float, c_int, c_int, c_int, c_int,
-                                        c_void_p, c_void_p, c_void_p]),
+    'tm_linear_residual_norm': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_float, c_int, c_int, c_int,
+                                        c_void_p, c_void_p]),
+    'tm_linear_fold_workspace': (c_size_t, [c_void_p, c_int]),
+    'tm_linear_fold_produce': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, POINTER(c_int), c_int, c_int,
+                                       c_int, c_void_p, c_void_p]),
+    'tm_linear_fold_consume': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_float, c_int,
+                                       c_int, c_void_p, c_void_p]),
     'tm_linear_destroy': (c_int, [c_void_p]),
     'tm_linear_prepare_fp8_gated': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
     'tm_linear_fp8_workspace': (c_size_t, [c_void_p, c_int]),
@@ -117,6 +122,8 @@ _SIGNATURES = {
     'tm_quantize_groupwise': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                                       c_void_p]),
     'tm_debug_set_gemm_trace': (c_int, [c_void_p]),
+    'tm_debug_trace_arena': (c_int, [c_void_p, c_int64]),
+    'tm_debug_trace_records': (c_int64, [c_char_p, c_int64]),
     'tm_engine_tune_gemm': (c_int, [c_void_p, c_int, c_char_p]),
     'tm_gemm_import': (c_int, [c_char_p]),
     'tm_gemm_export': (c_int, [c_char_p]),

@@ -419,7 +419,6 @@ int launch_decode_attention(const DecodeAttnParams& p, hipStream_t st)
                 return launch_bits<8>(p, st);
             }
             DecodeAttnParams pt = p;
-            pt.dbg              = gemm_trace_for((size_t)p.batch * p.q_heads * p.splits);
             int rc = launch_decode_attention_i8_mfma(pt, st);
             if (rc) {
                 return rc;
@@ -437,7 +436,6 @@ int launch_decode_attention(const DecodeAttnParams& p, hipStream_t st)
                 return launch_bits<4>(p, st);
             }
             DecodeAttnParams pt = p;
-            pt.dbg              = gemm_trace_for((size_t)p.batch * p.q_heads * p.splits);
             int rc = launch_decode_attention_i8_mfma(pt, st);
             if (rc) {
                 return rc;

@@ -523,8 +523,10 @@ __global__ __launch_bounds__(256, 2) void decode_attention_i8_mfma_kernel(Decode
         }
     }
 
-    if (p.dbg && threadIdx.x == 0) {
-        p.dbg[wgid * 8 + 2] = __builtin_amdgcn_s_memrealtime();  // wave 0 done with its blocks
+    if (p.dbg && lane == 0) {  // slots 2, 6, 7: waves 0, 1, 3 done with their blocks (wave 0 owns the newest block and the prologue)
+        if (wave != 2) {
+            p.dbg[wgid * 8 + (wave == 0 ? 2 : wave == 1 ? 6 : 7)] = __builtin_amdgcn_s_memrealtime();
+        }
     }
     // ---- per-wave totals, then merge the 4 waves through LDS ------------------------------------------------
     lsum += __shfl_xor(lsum, 16);
@@ -590,9 +592,10 @@ __global__ __launch_bounds__(256, 2) void decode_attention_i8_mfma_kernel(Decode
     }
 }
 
-int launch_decode_attention_i8_mfma(const DecodeAttnParams& p, hipStream_t st)
+int launch_decode_attention_i8_mfma(const DecodeAttnParams& p_in, hipStream_t st)
 {
-    const int group = p.q_heads / p.cache.layout.kv_heads;
+    DecodeAttnParams p     = p_in;
+    const int        group = p.q_heads / p.cache.layout.kv_heads;
     int       hpw   = group;
     while (hpw > 16) {  // largest divisor of the GQA group that fits the 16 MFMA columns
         int d = 2;
@@ -603,6 +606,7 @@ int launch_decode_attention_i8_mfma(const DecodeAttnParams& p, hipStream_t st)
     }
     const int chunks = group / hpw;
     dim3      grid(p.cache.layout.kv_heads * chunks, p.batch, p.splits);
+    p.dbg = gemm_trace_for((size_t)grid.x * grid.y * grid.z, "attn", grid.x, grid.y, grid.z);
     // 4 wave-private images (+ 4 KB q exchange for the fused prologue); the merge buffers overlay the images
     static_assert(4 * kWaveLds + 4096 > 4 * 16 * 128 * 4 + 4 * 16 * 2 * 4, "merge buffers must fit");
     const int lds = 4 * kWaveLds + 4096;

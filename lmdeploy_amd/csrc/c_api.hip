@@ -330,7 +330,7 @@ int tm_linear_forward(const tm_linear* w, const void* x, int ldx, void* y, int l
 }
 
 int tm_linear_residual_norm(const tm_linear* w, const void* x, int ldx, void* y, void* resid, const void* norm_w, float eps, int M,
-                            int shape, int splits, int fused, void* workspace, void* sync, tm_stream_t st)
+                            int shape, int splits, void* workspace, tm_stream_t st)
 {
     TM_REQUIRE(w && x && y && resid && norm_w && workspace, "null pointer");
     const int N = w->w.N;
@@ -344,16 +344,81 @@ int tm_linear_residual_norm(const tm_linear* w, const void* x, int ldx, void* y,
         cfg.splits = splits;
     }
     TM_REQUIRE(cfg.splits <= 16, "splits <= 16");
-    // fused != 0 was the in-launch consumer of round 3 (the GEMM's last workgroups ran the norm): parity-green but 2.8 us SLOWER per
-    // instance than the kernel boundary it replaced (profiles/r03_gemm_tail_trace.txt) -- removed in round 4
-    TM_REQUIRE(!fused, "the in-launch residual-norm consumer was removed (round 4): pass fused = 0");
-    (void)sync;
-    // unfused: slabs (or, with one slice, the fp16 product parked at the end of the workspace) + the reduce-norm kernel
+    // slabs (or, with one slice, the fp16 product parked at the end of the workspace) + the reduce-norm kernel
     int     slabs = 1;
     half_t* tmp   = (half_t*)((char*)workspace + gemm_workspace_bytes(M, N, 16));
     TM_TRY_RC(launch_linear(w->w, (const half_t*)x, ldx, tmp, N, M, false, cfg, (float*)workspace, cfg.splits > 1, &slabs, (hipStream_t)st));
     return launch_residual_rmsnorm((half_t*)y, (half_t*)resid, slabs > 1 ? nullptr : tmp, slabs > 1 ? (const float*)workspace : nullptr,
                                    slabs, nullptr, (const half_t*)norm_w, eps, M, N, (hipStream_t)st);
+}
+
+size_t tm_linear_fold_workspace(const tm_linear* w, int M)
+{
+    return w ? gemm_workspace_bytes(M, w->w.N, 16) + 4096 : 0;
+}
+
+static int fold_tile_pick(const tm_linear* w, int M, int* shape, int* splits)
+{
+    int sh = *shape, sp = *splits;
+    if (sh < 0) {
+        dec32_pick(w->w, M, &sh, &sp);
+        if (!dec32_fold_shape(sh)) {
+            dec32_pick_ex(w->w, M, &sh, &sp, false);
+        }
+        if (*splits > 0) {
+            sp = *splits;
+        }
+    }
+    else if (sp <= 0) {
+        sp = 1;
+    }
+    TM_REQUIRE(dec32_fold_shape(sh) && sp >= 1 && sp <= 16, "folded RMSNorm: decode tile 0..3 / 6..9, 1 <= splits <= 16");
+    *shape  = sh;
+    *splits = sp;
+    return 0;
+}
+
+int tm_linear_fold_produce(const tm_linear* w, const void* x, int ldx, void* xg, void* resid, const void* norm_w, float* ss,
+                           int* ss_tiles, int M, int shape, int splits, void* workspace, tm_stream_t st)
+{
+    TM_REQUIRE(w && x && xg && resid && norm_w && ss && ss_tiles && workspace, "null pointer");
+    TM_REQUIRE(dec32_supported(w->w, M) && M <= 64 && w->w.N % 64 == 0, "folded RMSNorm: u4 decode linear, M <= 64, N % 64 == 0");
+    TM_TRY_RC(fold_tile_pick(w, M, &shape, &splits));
+    unsigned* tickets = (unsigned*)((char*)workspace + gemm_workspace_bytes(M, w->w.N, 16));
+    TM_HIP_CHECK(hipMemsetAsync(tickets, 0, 4096, (hipStream_t)st));
+    TM_REQUIRE((size_t)(w->w.N / 64) * 2 * sizeof(unsigned) <= 4096, "folded RMSNorm: N <= 32768");
+    NormFold nf{};
+    nf.resid   = (half_t*)resid;
+    nf.norm_w  = (const half_t*)norm_w;
+    nf.ss_out  = ss;
+    nf.tickets = tickets;
+    TM_TRY_RC(launch_linear_dec32(w->w, (const half_t*)x, ldx, (half_t*)xg, w->w.N, M, false, shape, splits, (float*)workspace, nullptr,
+                                  (hipStream_t)st, &nf));
+    *ss_tiles = nf.tiles_out;
+    return 0;
+}
+
+int tm_linear_fold_consume(const tm_linear* w, const void* xg, int ldx, void* y, int ldy, int M, int gated_silu, const float* ss,
+                           int ss_tiles, int norm_h, float eps, int shape, int splits, void* workspace, tm_stream_t st)
+{
+    TM_REQUIRE(w && xg && y && ss, "null pointer");
+    TM_REQUIRE(dec32_supported(w->w, M) && M <= 64 && ss_tiles >= 1 && norm_h >= 1, "folded RMSNorm: u4 decode linear, M <= 64");
+    TM_TRY_RC(fold_tile_pick(w, M, &shape, &splits));
+    if (!workspace) {
+        splits = 1;
+    }
+    NormFold nf{};
+    nf.ss_in    = ss;
+    nf.ss_tiles = ss_tiles;
+    nf.inv_h    = 1.0f / (float)norm_h;
+    nf.eps      = eps;
+    int nslab   = 1;
+    TM_TRY_RC(launch_linear_dec32(w->w, (const half_t*)xg, ldx, (half_t*)y, ldy, M, gated_silu != 0, shape, splits, (float*)workspace, &nslab,
+                                  (hipStream_t)st, &nf));
+    if (nslab > 1) {  // the slabs carry the row factor already (the engine hands them to the attention prologue as they are)
+        return launch_splitk_reduce((half_t*)y, ldy, (const float*)workspace, nslab, M, w->w.N, gated_silu != 0, (hipStream_t)st);
+    }
+    return 0;
 }
 
 int tm_linear_prepare_fp8_gated(tm_linear* w, const void* weight, const void* scales, tm_stream_t st)
@@ -800,6 +865,18 @@ int tm_debug_set_gemm_trace(void* dev_buf)
 {
     tmk::g_gemm_dbg = (uint64_t*)dev_buf;
     return 0;
+}
+
+int tm_debug_trace_arena(void* dev_buf, int64_t capacity_workgroups)
+{
+    TM_REQUIRE(!dev_buf || capacity_workgroups > 0, "trace arena: capacity in workgroups (8 x 8 bytes each)");
+    tmk::trace_arena_set((uint64_t*)dev_buf, dev_buf ? (size_t)capacity_workgroups : 0);
+    return 0;
+}
+
+int64_t tm_debug_trace_records(char* host_out, int64_t cap)
+{
+    return (int64_t)tmk::trace_arena_records(host_out, cap > 0 ? (size_t)cap : 0);
 }
 
 int tm_quantize_groupwise(void* qweight, void* scales, void* zeros, void* dequant, const void* w, int K, int N,

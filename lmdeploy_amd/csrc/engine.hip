@@ -268,6 +268,11 @@ struct tm_engine {
     half_t* d_last   = nullptr;
     float*  d_gemm_ws = nullptr;
     size_t  gemm_ws_bytes = 0;
+    // RMSNorm folded into the decode GEMMs (NormFold, tm_kernels.h): per-tile sums of squares [hidden / 64][64] and the split-K
+    // arrival counters of the producing GEMM; TM_FOLD_NORM=0 keeps the reduce-norm launches
+    float*    d_ss      = nullptr;
+    unsigned* d_tickets = nullptr;
+    bool      fold_norm = false;
     unsigned  h_mark = 0;             // host copy of the native communicator's give-up mark (device_marks_fetch)
     bool      comm_failed = false;    // a give-up mark was seen: the ranks' call sequences may have diverged (sticky, see device_marks_check)
     float*  d_attn_ws = nullptr;
@@ -622,6 +627,66 @@ static int linear_plain(tm_engine* e, LinearSlots& l, const half_t* x, int ldx, 
     return launch_linear(l.w, x, ldx, y, ldy, M, gated, cfg, e->d_gemm_ws, false, nullptr, e->stream);
 }
 
+// ---- RMSNorm folded into the decode GEMMs (tp = 1, dense u4 layers, M <= 64; NormFold in tm_kernels.h) ----------------------------
+// the tiling of a folded launch: the measured / heuristic pick when its kernel carries the folded epilogue, else the heuristic's
+static void fold_tiling(tm_engine* e, const LinearWeight& w, int M, int* shape, int* splits)
+{
+    dec32_pick(w, M, shape, splits);
+    if (!dec32_fold_shape(*shape)) {
+        dec32_pick_ex(w, M, shape, splits, false);
+    }
+    if (!dec32_fold_shape(*shape)) {
+        *shape  = 0;
+        *splits = 1;
+    }
+    if (gemm_workspace_bytes(M, w.N, *splits) > e->gemm_ws_bytes) {
+        *splits = 1;
+    }
+}
+
+static bool fold_ok(const tm_engine* e, const Layer& L, int M)
+{
+    return e->fold_norm && !L.is_moe && M <= 64 && dec32_supported(L.qkv.w, M) && dec32_supported(L.wo.w, M) && dec32_supported(L.w13.w, M)
+           && dec32_supported(L.w2.w, M);
+}
+
+// consumer: y = (x . W) * inv[m] (x = r . g of the producing GEMM); ss_tiles == 0: x is already normalised (plain GEMM)
+static int linear_fold_consume(tm_engine* e, LinearSlots& l, const half_t* x, int ldx, half_t* y, int ldy, int M, bool gated, int ss_tiles,
+                               bool slabs_ok, int* slabs)
+{
+    int shape, splits;
+    fold_tiling(e, l.w, M, &shape, &splits);
+    if (!slabs_ok) {
+        splits = 1;
+    }
+    NormFold nf{};
+    nf.ss_in    = ss_tiles > 0 ? e->d_ss : nullptr;
+    nf.ss_tiles = ss_tiles;
+    nf.inv_h    = 1.0f / (float)e->hidden;
+    nf.eps      = e->cfg.model.rms_eps;
+    int nslab   = 1;
+    TM_TRY(launch_linear_dec32(l.w, x, ldx, y, ldy, M, gated, shape, splits, e->d_gemm_ws, &nslab, e->stream, ss_tiles > 0 ? &nf : nullptr));
+    if (slabs) {
+        *slabs = nslab;
+    }
+    return 0;
+}
+
+// producer: d_resid += x . W ; d_x = d_resid . norm_w (not normalised) ; d_ss = per-tile sums of squares -> *ss_tiles
+static int linear_fold_produce(tm_engine* e, LinearSlots& l, const half_t* x, int ldx, int M, const half_t* norm_w, int* ss_tiles)
+{
+    int shape, splits;
+    fold_tiling(e, l.w, M, &shape, &splits);
+    NormFold nf{};
+    nf.resid   = e->d_resid;
+    nf.norm_w  = norm_w;
+    nf.ss_out  = e->d_ss;
+    nf.tickets = e->d_tickets;
+    TM_TRY(launch_linear_dec32(l.w, x, ldx, e->d_x, e->hidden, M, false, shape, splits, e->d_gemm_ws, nullptr, e->stream, &nf));
+    *ss_tiles = nf.tiles_out;
+    return 0;
+}
+
 // One forward over M tokens.  decode: one token per sequence (cu_q = 0..B); prefill: nseq sequences.
 // Mixed forward (continuous batching, the reference's unified batch: unified_attention_layer.cc:310-311 puts the decode rows
 // first): `md` != nullptr and !decode -> rows [0, md->rows) are the decode tokens of batch slots 0 .. md->rows-1 (their KV
@@ -648,14 +713,25 @@ static int forward(tm_engine* e, const int* d_ids, int M, int nseq, bool decode,
     TM_PROF(P_EMBED, TM_TRY(launch_embedding(e->d_resid, e->tok_embeddings, d_ids, M, e->hidden, m.vocab, st)));
     TM_PROF(P_RES_NORM, TM_TRY(launch_rmsnorm(e->d_x, e->d_resid, e->layers[0].attn_norm, m.rms_eps, M, e->hidden, st)));
     const float scale_log2 = (1.0f / std::sqrt((float)e->D)) * 1.4426950408889634f;
+    int         ss_tiles   = 0;  // > 0: d_x holds r . g of a folded producer, d_ss its sums of squares (the next GEMM applies the row factor)
     for (int li = 0; li < m.layers; ++li) {
         Layer& L = e->layers[li];
         KvCacheView cv = cache_view(e, li);
+        const bool fold = decode && fold_ok(e, L, M);
+        TM_REQUIRE(ss_tiles == 0 || fold, "internal: folded norm without a folded consumer");
         // decode + int8 KV: the attention kernel consumes the qkv GEMM's raw output (fp32 split-K slabs or fp16),
         // applies RoPE and quantises/stores the new K/V itself -> no splitk_reduce, no kv_rope_store launch
         const bool fuse_qkv = decode && e->fuse_qkv;
         int        qkv_slabs = 1;
-        if (fuse_qkv) {
+        if (fold) {
+            TM_PROF(P_GEMM_QKV, TM_TRY(linear_fold_consume(e, L.qkv, e->d_x, e->hidden, e->d_qkv, e->qkv_n, M, false, ss_tiles, fuse_qkv, &qkv_slabs)));
+            ss_tiles = 0;
+            if (!fuse_qkv) {
+                TM_PROF(P_KV_STORE, TM_TRY(launch_kv_rope_store(qkv_p, e->q_heads, e->d_cu_q, e->d_k_len, nseq, M - nd, e->d_rope,
+                                                               e->rope_max_pos, cv, st)));
+            }
+        }
+        else if (fuse_qkv) {
             GemmConfig cfg = gemm_pick_config(L.qkv.w, M);
             if (gemm_workspace_bytes(M, L.qkv.w.N, cfg.splits) > e->gemm_ws_bytes) {
                 cfg.splits = 1;
@@ -753,8 +829,23 @@ static int forward(tm_engine* e, const int* d_ids, int M, int nseq, bool decode,
                 TM_HIP_CHECK(hipStreamWaitEvent(st, e->ev_aux_join, 0));  // join: wo reads the decode rows' attention output too
             }
         }
-        TM_TRY(linear_residual_norm(e, L.wo, e->d_attn, e->q_heads * e->D, M, L.ffn_norm, P_GEMM_O));
         const half_t* next_norm = li + 1 < m.layers ? e->layers[li + 1].attn_norm : e->final_norm;
+        if (fold) {
+            // wo's epilogue updates the residual stream and hands r . g + sums of squares to w1w3, whose accumulators take the row
+            // factor before the gated SiLU; w2 does the same for the next layer's w_qkv (the last layer's w2 feeds the final norm
+            // and the fp16 lm_head: reduce-norm launch as before).  5 launches per layer instead of 7.
+            TM_PROF(P_GEMM_O, TM_TRY(linear_fold_produce(e, L.wo, e->d_attn, e->q_heads * e->D, M, L.ffn_norm, &ss_tiles)));
+            TM_PROF(P_GEMM_GATE_UP, TM_TRY(linear_fold_consume(e, L.w13, e->d_x, e->hidden, e->d_act, e->inter, M, true, ss_tiles, false, nullptr)));
+            ss_tiles = 0;
+            if (li + 1 < m.layers && fold_ok(e, e->layers[li + 1], M)) {
+                TM_PROF(P_GEMM_DOWN, TM_TRY(linear_fold_produce(e, L.w2, e->d_act, e->inter, M, next_norm, &ss_tiles)));
+            }
+            else {
+                TM_TRY(linear_residual_norm(e, L.w2, e->d_act, e->inter, M, next_norm, P_GEMM_DOWN));
+            }
+            continue;
+        }
+        TM_TRY(linear_residual_norm(e, L.wo, e->d_attn, e->q_heads * e->D, M, L.ffn_norm, P_GEMM_O));
         if (L.is_moe) {
             // router + grouped expert FFNs + combine -> d_tmp, then (all-reduce +) residual + RMSNorm as for the dense FFN
             TM_PROF(P_GEMM_GATE_UP, TM_TRY(moe_forward(L.moe, e->d_tmp, e->hidden, e->d_x, e->hidden, M, e->d_moe_ws, nullptr,
@@ -1313,6 +1404,7 @@ static int tune_decode_gemms(tm_engine* e, int M, bool verbose)
     TM_TRY(launch_fill_uniform_f16(e->d_attn, (size_t)M * e->q_heads * e->D, 0.5f, 2u, st));
     TM_TRY(launch_fill_uniform_f16(e->d_act, (size_t)M * e->inter, 0.5f, 3u, st));
     TM_HIP_CHECK(hipMemsetAsync(e->d_resid, 0, (size_t)M * e->hidden * 2, st));
+    TM_HIP_CHECK(hipMemsetAsync(e->d_ss, 0x3f, (size_t)(e->hidden / 64) * 64 * sizeof(float), st));  // finite stand-in sums of squares (0.747)
     int rc = 0;
     for (const Role& r : roles) {
         std::vector<const LinearWeight*> ws;
@@ -1358,7 +1450,30 @@ static int tune_decode_gemms(tm_engine* e, int M, bool verbose)
                 continue;
             }
             const bool norm_consumer = (r.which == 1 || r.which == 3) && !e->use_comm;
+            // decode batches of an engine that folds the RMSNorm into the GEMMs (linear_fold_*): the candidates are timed as they
+            // will run -- wo / w2 with the residual / sums-of-squares epilogue (and the in-launch slab merge) instead of the
+            // reduce-norm launch, w_qkv / w1w3 with the row factor from d_ss -- and only tiles whose kernel carries that code
+            const bool folded = e->fold_norm && M <= 64 && !e->layers[0].is_moe;
+            const bool slabs_ok = norm_consumer || (r.which == 0 && e->fuse_qkv);  // folded: who can take fp32 slabs
+            if (folded && (!dec32_fold_shape(cand[i][0]) || (cfg.splits > 1 && !slabs_ok))) {
+                continue;
+            }
             auto chain = [&]() -> int {
+                if (folded) {
+                    const int tiles = e->hidden / 64;
+                    for (const LinearWeight* w : ws) {
+                        NormFold nf{};
+                        if (norm_consumer) {
+                            nf.resid = e->d_resid, nf.norm_w = e->final_norm, nf.ss_out = e->d_ss, nf.tickets = e->d_tickets;
+                        }
+                        else {
+                            nf.ss_in = e->d_ss, nf.ss_tiles = tiles, nf.inv_h = 1.0f / (float)e->hidden, nf.eps = e->cfg.model.rms_eps;
+                        }
+                        TM_TRY(launch_linear_dec32(*w, r.x, r.ldx, norm_consumer ? norm_out : r.y, norm_consumer ? e->hidden : r.ldy, M, r.gated,
+                                                   cfg.d32_shape, cfg.splits, e->d_gemm_ws, nullptr, st, &nf));
+                    }
+                    return 0;
+                }
                 for (const LinearWeight* w : ws) {
                     int slabs = 1;
                     TM_TRY(launch_linear(*w, r.x, r.ldx, r.y, r.ldy, M, r.gated, cfg, e->d_gemm_ws, norm_consumer && cfg.splits > 1, &slabs, st));
@@ -1738,6 +1853,14 @@ int tm_engine_start(tm_engine* e)
     // split-K workspace: decode-sized problems only (M <= 64 rows x widest N x 16 slabs)
     e->gemm_ws_bytes = (size_t)16 * 64 * std::max(std::max(e->qkv_n, 2 * e->inter), e->hidden) * sizeof(float);
     TM_HIP_CHECK(hipMalloc((void**)&e->d_gemm_ws, e->gemm_ws_bytes));
+    {
+        const size_t tiles = (size_t)(e->hidden + 63) / 64;
+        TM_TRY(dmalloc(&e->d_ss, tiles * 64));
+        TM_TRY(dmalloc(&e->d_tickets, tiles * 2));
+        TM_HIP_CHECK(hipMemset(e->d_tickets, 0, tiles * 2 * sizeof(unsigned)));
+        const char* fold = getenv("TM_FOLD_NORM");
+        e->fold_norm     = !(fold && !atoi(fold)) && !e->use_comm && m.weight_type == 0 && m.moe_experts == 0 && e->hidden % 64 == 0;
+    }
     if (m.moe_experts > 0) {
         TM_HIP_CHECK(hipMalloc(&e->d_moe_ws, moe_workspace_bytes(e->layers[0].moe, e->max_tokens)));
     }
@@ -3143,7 +3266,7 @@ int tm_engine_destroy(tm_engine* e)
     void* bufs[] = {e->pool, e->d_block_ptrs, e->d_cu_block_nums, e->d_resid, e->d_x, e->d_qkv, e->d_attn, e->d_act,
                     e->d_tmp, e->d_logits, e->d_last, e->d_gemm_ws, e->d_attn_ws, e->d_kflat, e->d_vflat, e->d_rope,
                     e->d_ids, e->d_k_len, e->d_cu_q, e->d_cu_koff, e->d_rows, e->d_generated, e->d_step,
-                    e->d_prefill_ids, e->d_argmax_val, e->d_cand, e->d_cand_all, e->d_next_ids};
+                    e->d_prefill_ids, e->d_argmax_val, e->d_cand, e->d_cand_all, e->d_next_ids, e->d_ss, e->d_tickets};
     for (void* p : bufs) {
         if (p) {
             (void)hipFree(p);

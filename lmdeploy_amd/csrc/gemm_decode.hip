@@ -177,6 +177,9 @@ __global__ __launch_bounds__(CG* WK * 64) void gemm_dec32_kernel(Dec32Params p)
     if constexpr (ABL & 32) {  // launch cost only
         return;
     }
+    // held in SGPRs until the end (a store here would join the hand-counted vmcnt queues): prologue loads issued / wave 0's first
+    // weight unit landed (= the first MFMA can issue)
+    uint64_t ts_issued = 0, ts_w0 = 0;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int cgl  = wave % CG;
@@ -206,6 +209,29 @@ __global__ __launch_bounds__(CG* WK * 64) void gemm_dec32_kernel(Dec32Params p)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             acc[h][r] = 0.f;
+        }
+    }
+
+    // ---- folded RMSNorm, consumer side (p.ss_in): the producing GEMM left, per column tile, partial row sums of squares of the
+    // residual rows.  T / ROWS threads per row fetch them (up to 8 loads each, issued here, OLDER than every load of the prologue:
+    // the prologue's own counted wait covers them), the row factor is finished after the main loop.
+    constexpr int LDSX   = 2 * STG > REDB ? 2 * STG : REDB;  // scratch behind the stage buffers / the reduction image
+    constexpr int PARTS  = T / ROWS;
+    float*        part_s = (float*)(smem + LDSX);            // [PARTS][ROWS]
+    float*        inv_s  = part_s + PARTS * ROWS;            // [ROWS]
+    static_assert(PARTS * ROWS * 4 + ROWS * 4 + 16 <= kDec32NormLds, "norm scratch");
+    const bool    scaled = p.ss_in != nullptr;               // uniform
+    float         ssv[8], ss_extra = 0.f;
+    if (scaled) {
+        const int    part = tid / ROWS;
+        const float* src  = p.ss_in + min(m0 + tid % ROWS, p.M - 1);
+        for (int t = part + 8 * PARTS; t < p.ss_tiles; t += PARTS) {  // more tiles than 8 per thread (wide models, narrow workgroups)
+            ss_extra += src[(size_t)t * p.M];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int t = part + u * PARTS;
+            ssv[u]      = t < p.ss_tiles ? src[(size_t)t * p.M] : 0.f;
         }
     }
 
@@ -298,6 +324,9 @@ __global__ __launch_bounds__(CG* WK * 64) void gemm_dec32_kernel(Dec32Params p)
                 D32_LOAD_W(q, phys(q / BPS) * S + wk + (q % BPS) * WK);
                 __builtin_amdgcn_sched_barrier(0);
             }
+            if (p.dbg) {
+                ts_issued = __builtin_amdgcn_s_memrealtime();
+            }
             asm volatile("s_waitcnt vmcnt(%0)" ::"i"((ABL & 0x1000) ? 0 : 3 * PF0) : "memory");
         }
         else {
@@ -321,6 +350,14 @@ __global__ __launch_bounds__(CG* WK * 64) void gemm_dec32_kernel(Dec32Params p)
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
+        if (scaled) {  // fixed order: tiles part, part + PARTS, ... then the tail
+            float t = ssv[0];
+#pragma unroll
+            for (int u = 1; u < 8; ++u) {
+                t += ssv[u];
+            }
+            part_s[tid] = t + ss_extra;  // [tid / ROWS][tid % ROWS]
+        }
         __syncthreads();
         if (p.dbg && tid == 0) {
             p.dbg[wgid * 8 + 1] = __builtin_amdgcn_s_memrealtime();
@@ -338,6 +375,9 @@ __global__ __launch_bounds__(CG* WK * 64) void gemm_dec32_kernel(Dec32Params p)
 #pragma unroll
                 for (int i = 0; i < BPS; ++i) {
                     asm volatile("" ::"v"(ring[u * BPS + i][0]), "v"(ring[u * BPS + i][1]), "v"(sring[u * BPS + i]));
+                }
+                if (p.dbg && t == 0) {
+                    ts_w0 = __builtin_amdgcn_s_memrealtime();
                 }
                 // Not behind the last stage: nobody would read it, and the refills that the counted wait below relies on
                 // are dead code there (hipcc drops them in the remainder stage), so that DMA could still be landing when the
@@ -498,6 +538,15 @@ __global__ __launch_bounds__(CG* WK * 64) void gemm_dec32_kernel(Dec32Params p)
         }
         return;
     }
+    // folded RMSNorm, consumer side: inv[m] = 1 / sqrt(sum over tiles / H + eps), parts summed in a fixed order
+    if (scaled && tid < ROWS) {
+        float t = part_s[tid];
+#pragma unroll
+        for (int q = 1; q < PARTS; ++q) {
+            t += part_s[q * ROWS + tid];
+        }
+        inv_s[tid] = 1.0f / __builtin_sqrtf(t * p.ss_inv_h + p.ss_eps);
+    }
     // ---- the WK k-phase partial tiles meet in LDS: red[wk][row][c4 ^ (row & 7)] (floatx4 units, CG*8 per row) --------
     // lane holds, per half h and register r: row m = 32h + (l & 31), column 32 cgl + 8 (r >> 2) + 4 (l >> 5) + (r & 3)
     {
@@ -518,19 +567,125 @@ __global__ __launch_bounds__(CG* WK * 64) void gemm_dec32_kernel(Dec32Params p)
             p.dbg[wgid * 8 + 7] = __builtin_amdgcn_s_memrealtime();
         }
         constexpr int NE = ROWS * C4;  // floatx4 elements of the output tile
+        static_assert(NE % T == 0, "whole epilogue passes");
         const int     ncol0 = blockIdx.x * CG * 32;
-#pragma unroll
-        for (int e0 = 0; e0 < NE; e0 += T) {
-            const int e = e0 + tid;
-            if (NE % T != 0 && e >= NE) {
-                break;
-            }
-            const int m  = e / C4;
-            const int c4 = e % C4;
-            floatx4   a  = red[m * C4 + (c4 ^ (m & 7))];
+        auto tile_sum = [&](int m, int c4) __attribute__((always_inline)) {
+            floatx4 a = red[m * C4 + (c4 ^ (m & 7))];
 #pragma unroll
             for (int k = 1; k < WK; ++k) {  // fixed order: deterministic
                 a += red[(k * ROWS + m) * C4 + (c4 ^ (m & 7))];
+            }
+            return a;
+        };
+        if (p.epilogue == 3) {
+            // ---- folded RMSNorm, producer side: residual add + next norm's weight + per-tile sums of squares -------------------
+            const int      splits = gridDim.y;
+            const size_t   slab   = (size_t)p.M * p.N;
+            unsigned*      flag   = (unsigned*)(smem + LDSX + kDec32NormLds - 16);
+            if (splits > 1) {
+                // every slice parks its fp32 tile write-through, then takes a ticket: the LAST arriver of the tile sums the slices in
+                // slice order (its own from LDS -- the same bits it stored) and runs the epilogue; the others are done
+#pragma unroll
+                for (int e0 = 0; e0 < NE; e0 += T) {
+                    const int e = e0 + tid, m = e / C4, c4 = e % C4;
+                    const int n = ncol0 + c4 * 4;
+                    if (m < Mloc && n < p.N) {
+                        store_wt((floatx4*)(p.partial + (size_t)blockIdx.y * slab + ((size_t)m0 + m) * p.N + n), tile_sum(m, c4), 1);
+                    }
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                unsigned* const tk = p.tickets + blockIdx.z * gridDim.x + blockIdx.x;
+                if (tid == 0) {
+                    *flag = __hip_atomic_fetch_add(tk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                __syncthreads();
+                if (*flag != (unsigned)(splits - 1)) {
+                    if (p.dbg && tid == 0) {
+                        p.dbg[wgid * 8 + 3] = __builtin_amdgcn_s_memrealtime();
+                        p.dbg[wgid * 8 + 5] = ts_issued;
+                        p.dbg[wgid * 8 + 6] = ts_w0;
+                    }
+                    return;
+                }
+                if (tid == 0) {
+                    __hip_atomic_store(tk, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // every other slice has arrived
+                }
+            }
+#pragma unroll
+            for (int e0 = 0; e0 < NE; e0 += T) {
+                const int    e = e0 + tid, m = e / C4, c4 = e % C4;
+                const int    n = ncol0 + c4 * 4;
+                const bool   ok = m < Mloc && n < p.N;
+                const size_t mg = (size_t)m0 + (ok ? m : 0);
+                const int    nc = ok ? n : 0;
+                const floatx4 own = tile_sum(m, c4);
+                floatx4       a   = own;
+                if (splits > 1) {
+                    // slice order, from zero: the bits of the reduce-norm kernel (norm_row.h).  The first four slices' loads are
+                    // issued together (clamped, unconditional); the own slice comes from LDS
+                    const float* src = p.partial + mg * p.N + nc;
+                    floatx4      v[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        v[u] = load_agent(src + (size_t)min(u, splits - 1) * slab);
+                    }
+                    a = floatx4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        if (u < splits) {
+                            a += u == (int)blockIdx.y ? own : v[u];
+                        }
+                    }
+                    for (int sl = 4; sl < splits; ++sl) {
+                        a += sl == (int)blockIdx.y ? own : load_agent(src + (size_t)sl * slab);
+                    }
+                }
+                const half4_t hc = {(half_t)a[0], (half_t)a[1], (half_t)a[2], (half_t)a[3]};  // the GEMM's fp16 output rounding
+                half4_t       r4 = *(const half4_t*)(p.resid + mg * p.N + nc);
+                const half4_t g4 = *(const half4_t*)(p.norm_w + nc);
+                r4               = r4 + hc;  // fp16 add, one rounding per element
+                half4_t xg;
+                float   ss = 0.f;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float f = (float)r4[q];
+                    ss            = __builtin_fmaf(f, f, ss);
+                    xg[q]         = (half_t)fminf(fmaxf(f * (float)g4[q], -65504.f), 65504.f);
+                }
+                if (ok) {
+                    *(half4_t*)(p.resid + mg * p.N + nc) = r4;
+                    *(half4_t*)(p.y + mg * p.ldy + nc)   = xg;
+                }
+                else {
+                    ss = 0.f;
+                }
+                // the C4 threads of row m are C4 consecutive lanes (C4 = 16 / 32 / 64 divides 64): butterfly in a fixed pattern
+#pragma unroll
+                for (int d = 1; d < C4; d <<= 1) {
+                    ss += __shfl_xor(ss, d);
+                }
+                if (ok && c4 == 0) {
+                    p.ss_out[(size_t)blockIdx.x * p.M + mg] = ss;
+                }
+            }
+            if (p.dbg && tid == 0) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                p.dbg[wgid * 8 + 3] = __builtin_amdgcn_s_memrealtime();
+                p.dbg[wgid * 8 + 5] = ts_issued;
+                p.dbg[wgid * 8 + 6] = ts_w0;
+            }
+            return;
+        }
+#pragma unroll
+        for (int e0 = 0; e0 < NE; e0 += T) {
+            const int e = e0 + tid;
+            const int m  = e / C4;
+            const int c4 = e % C4;
+            floatx4   a  = tile_sum(m, c4);
+            if (scaled) {
+                const float iv = inv_s[m];
+                a              = a * floatx4{iv, iv, iv, iv};
             }
             const int n = ncol0 + c4 * 4;
             if (m >= Mloc || n >= p.N) {
@@ -573,6 +728,8 @@ __global__ __launch_bounds__(CG* WK * 64) void gemm_dec32_kernel(Dec32Params p)
     if (p.dbg && tid == 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         p.dbg[wgid * 8 + 3] = __builtin_amdgcn_s_memrealtime();
+        p.dbg[wgid * 8 + 5] = ts_issued;
+        p.dbg[wgid * 8 + 6] = ts_w0;
     }
 }
 
@@ -587,7 +744,7 @@ static int launch_dec32_one(const Dec32Params& p, dim3 grid, hipStream_t st)
 {
     constexpr int stage = 2 * S * 32 * MH * 256;
     constexpr int red   = WK * 32 * MH * CG * 128;
-    constexpr int lds   = stage > red ? stage : red;
+    constexpr int lds   = (stage > red ? stage : red) + kDec32NormLds;  // + the folded-norm scratch (a few KB)
     if (const int rc = ensure_dynamic_lds((const void*)gemm_dec32_kernel<MH, CG, WK, S, PF, ABL>, lds)) {
         return rc;
     }
@@ -1252,9 +1409,19 @@ void dec32_pick_ex(const LinearWeight& w, int M, int* shape_out, int* splits_out
 }
 
 // y / slabs as launch_linear: *slabs_out = number of fp32 slabs written into `workspace` (1 = direct epilogue)
-int launch_linear_dec32(const LinearWeight& w, const half_t* x, int ldx, half_t* y, int ldy, int M, bool gated_silu, int shape,
-                        int splits, float* workspace, int* slabs_out, hipStream_t st)
+bool dec32_fold_shape(int shape)
 {
+    return (shape >= 0 && shape <= 3) || (shape >= 6 && shape <= 9);  // gemm_dec32_kernel with <= 64-row blocks
+}
+
+int launch_linear_dec32(const LinearWeight& w, const half_t* x, int ldx, half_t* y, int ldy, int M, bool gated_silu, int shape,
+                        int splits, float* workspace, int* slabs_out, hipStream_t st, NormFold* nf)
+{
+    const bool produce = nf && nf->resid != nullptr;
+    const bool consume = nf && nf->ss_in != nullptr;
+    TM_REQUIRE(!nf || (dec32_fold_shape(shape) && M <= 64), "folded RMSNorm: the <= 64-row decode tiles (shapes 0..3, 6..9), M <= 64");
+    TM_REQUIRE(!produce || (!gated_silu && nf->norm_w && nf->ss_out && ldy % 4 == 0), "folded RMSNorm, producer: residual, norm weight, sums");
+    TM_REQUIRE(!consume || (nf->ss_tiles >= 1 && nf->inv_h > 0.f), "folded RMSNorm, consumer: tiles and 1 / H");
     TM_REQUIRE(w.packed32 != nullptr && w.N % 32 == 0, "decode GEMM: P32 layout missing");
     TM_REQUIRE(M >= 1 && shape >= 0 && (shape <= 9 || shape == kShapeLC || shape == kShapePre256)
                    && (shape >= 6 || (M <= 64) == (shape < 4)) && (shape != kShapeLC || M <= 64) && (shape != kShapePre256 || M > 64),
@@ -1280,12 +1447,26 @@ int launch_linear_dec32(const LinearWeight& w, const half_t* x, int ldx, half_t*
     splits    = (p.KB + per - 1) / per;
     TM_REQUIRE(splits == 1 || workspace != nullptr, "split-K needs a workspace");
     p.kb_per_split = per;
-    p.epilogue     = splits > 1 ? 2 : (gated_silu ? 1 : 0);
+    p.epilogue     = produce ? 3 : splits > 1 ? 2 : (gated_silu ? 1 : 0);
+    if (produce) {
+        TM_REQUIRE(splits == 1 || nf->tickets != nullptr, "folded RMSNorm, producer with split-K: arrival counters");
+        p.resid   = nf->resid;
+        p.norm_w  = nf->norm_w;
+        p.ss_out  = nf->ss_out;
+        p.tickets = nf->tickets;
+    }
+    if (consume) {
+        p.ss_in    = nf->ss_in;
+        p.ss_tiles = nf->ss_tiles;
+        p.ss_inv_h = nf->inv_h;
+        p.ss_eps   = nf->eps;
+    }
     static const int wt = env_int2("TM_D32_WT", 1);  // measured (tools/trace_boundary.py, profiles/r02_gemm_boundary_gap.txt): -0.4..-0.9 us per split-K launch
     p.wt           = wt;
     dim3      grid((p.ncg + cgn - 1) / cgn, splits,
                    shape == kShapePre256 ? (M + 255) / 256 : shape == kShapeLC ? 1 : shape >= 6 ? (M + 31) / 32 : shape >= 4 ? (M + 127) / 128 : 1);
-    p.dbg        = gemm_trace_for((size_t)grid.x * grid.y * grid.z);
+    static const char* const role_tag[6] = {"gemm", "w_qkv", "wo", "w1w3", "w2", "lm_head"};
+    p.dbg        = gemm_trace_for((size_t)grid.x * grid.y * grid.z, role_tag[w.role >= 0 && w.role <= 5 ? w.role : 0], grid.x, grid.y, grid.z);
     const int rc = shape == kShapePre256 ? launch_pre256(p, grid, st) :
                    shape == kShapeLC ? launch_dec_lc(p, grid, st) :
                    shape >= 6 ? launch_dec32_shape<1>(p, grid, dec32_base_shape(shape), st) :
@@ -1294,6 +1475,10 @@ int launch_linear_dec32(const LinearWeight& w, const half_t* x, int ldx, half_t*
                                 launch_dec32_shape<2>(p, grid, shape, st);
     if (rc) {
         return rc;
+    }
+    if (produce) {
+        nf->tiles_out = (int)grid.x;
+        splits        = 1;  // the slabs were consumed inside the launch
     }
     if (slabs_out) {
         *slabs_out = splits;

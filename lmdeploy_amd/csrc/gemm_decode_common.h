@@ -25,7 +25,34 @@ struct Dec32Params {
                              // release writes them back (the kernel boundary then waits for MBs of fp32 slabs)
     uint64_t*     dbg;       // optional [workgroups][8] s_memrealtime stamps (tm_debug_set_gemm_trace): start, loop, epilogue, end,
                              // hw id, -, -, after the k-phase reduction barrier
+    // ---- RMSNorm folded into the neighbouring decode GEMMs (round 5; gemm_dec32_kernel only) ------------------------------
+    // y = RMSNorm(r) . W = inv[m] * sum_k (r[m,k] g[k]) W[k,n]: the GEMM that PRODUCES r (epilogue 3) adds its fp16 output to
+    // the residual stream (bit-exact: r = h(r + h(acc)), rms_norm.cu:286-362), writes xg = h(f32(r) * f32(g)) as the next
+    // GEMM's activations and, per column tile, the partial row sums of f32(r)^2; the GEMM that CONSUMES xg multiplies its fp32
+    // accumulators by inv[m] = 1 / sqrt(sum_tiles ss / H + eps) before its epilogue (fp16 / gated SiLU / slabs).
+    half_t*       resid;     // epilogue 3: [M][N] residual stream, updated in place
+    const half_t* norm_w;    // epilogue 3: [N] weight g of the RMSNorm that follows
+    float*        ss_out;    // epilogue 3: [gridDim.x][M] per-tile sums of squares of the updated residual rows
+    unsigned*     tickets;   // epilogue 3 with split-K: one arrival counter per (column tile, row block); the last arriver of a tile
+                             // sums the slices' slabs in slice order and runs the epilogue; it leaves the counter at 0
+    const float*  ss_in;     // consumer: [ss_tiles][M] partial sums written by the producing GEMM (nullptr: x is already normalised)
+    int           ss_tiles;
+    float         ss_inv_h;  // 1 / H of the norm
+    float         ss_eps;
 };
+constexpr int kDec32NormLds = 32 * 64 * 4 + 512;  // consumer scratch behind the stage buffers / reduction image: [parts][rows] sums + inv[rows]
+
+// 16 bytes another workgroup of THIS launch stored write-through (store_wt, sc1): agent-scope relaxed loads (global_load ... sc1)
+// bypass this CU's vector L1; valid after the producer drained its stores and bumped an agent-scope counter that this workgroup
+// read (MI355X_MICROARCH.md, inter-workgroup visibility: "sc1 loads may replace the acquire only when the producer stored sc1")
+__device__ __forceinline__ floatx4 load_agent(const float* src)
+{
+    typedef unsigned long long u64;
+    const u64 lo = __hip_atomic_load((const u64*)src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const u64 hi = __hip_atomic_load((const u64*)src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return floatx4{__builtin_bit_cast(float, (uint32_t)lo), __builtin_bit_cast(float, (uint32_t)(lo >> 32)),
+                   __builtin_bit_cast(float, (uint32_t)hi), __builtin_bit_cast(float, (uint32_t)(hi >> 32))};
+}
 
 __device__ __forceinline__ void store_wt(floatx4* dst, floatx4 v, int mode = 1)
 {

@@ -29,7 +29,10 @@
 #include <array>
 #include <map>
 #include <mutex>
+#include <string>
 #include <tuple>
+#include <vector>
+#include <stdio.h>
 
 namespace tmk {
 
@@ -724,6 +727,59 @@ size_t gemm_workspace_bytes(int M, int N, int splits)
 
 uint64_t* g_gemm_dbg = nullptr;  // set through tm_debug_set_gemm_trace (timing experiments)
 
+// trace arena (tm_debug_trace_arena): see tm_kernels.h
+static std::mutex               g_arena_mutex;
+static uint64_t*                g_arena_base = nullptr;
+static size_t                   g_arena_cap = 0, g_arena_used = 0;
+static std::vector<TraceRecord> g_arena_recs;
+
+bool trace_arena_active()
+{
+    return g_arena_base != nullptr;
+}
+
+uint64_t* trace_arena_alloc(size_t workgroups, const char* tag, int gx, int gy, int gz)
+{
+    std::lock_guard<std::mutex> lk(g_arena_mutex);
+    if (!g_arena_base || g_arena_used + workgroups > g_arena_cap) {
+        return nullptr;
+    }
+    TraceRecord r{};
+    snprintf(r.tag, sizeof r.tag, "%s", tag ? tag : "");
+    r.gx = gx, r.gy = gy, r.gz = gz;
+    r.offset_wgs = g_arena_used;
+    g_arena_recs.push_back(r);
+    uint64_t* out = g_arena_base + g_arena_used * 8;
+    g_arena_used += workgroups;
+    return out;
+}
+
+void trace_arena_set(uint64_t* base, size_t cap_wgs)
+{
+    std::lock_guard<std::mutex> lk(g_arena_mutex);
+    g_arena_base = base;
+    g_arena_cap  = base ? cap_wgs : 0;
+    g_arena_used = 0;
+    g_arena_recs.clear();
+}
+
+// text: one line per traced launch, `index tag gx gy gz offset_wgs`; returns the bytes needed (incl. the terminator)
+size_t trace_arena_records(char* out, size_t cap)
+{
+    std::lock_guard<std::mutex> lk(g_arena_mutex);
+    std::string                 s;
+    char                        line[128];
+    for (size_t i = 0; i < g_arena_recs.size(); ++i) {
+        const TraceRecord& r = g_arena_recs[i];
+        snprintf(line, sizeof line, "%zu %s %d %d %d %zu\n", i, r.tag[0] ? r.tag : "-", r.gx, r.gy, r.gz, r.offset_wgs);
+        s += line;
+    }
+    if (out && cap > 0) {
+        snprintf(out, cap, "%s", s.c_str());
+    }
+    return s.size() + 1;
+}
+
 static int env_int(const char* name, int dflt)
 {
     const char* v = getenv(name);
@@ -1176,7 +1232,7 @@ int launch_linear(const LinearWeight& w,
     const int wn     = waves / wk;
     const int ntiles = w.N / 16;
     dim3      grid((ntiles + wn * nt - 1) / (wn * nt), splits, (M + 16 * mt - 1) / (16 * mt));
-    p.dbg        = gemm_trace_for((size_t)grid.x * grid.y * grid.z);
+    p.dbg        = gemm_trace_for((size_t)grid.x * grid.y * grid.z, w.role == 5 ? "lm_head" : "gemm_general", grid.x, grid.y, grid.z);
     int       rc = 0;
     if (w.type == 0 && mt == 8) {
         static const int xpin = env_int("TM_GEMM_XPIN", 1);  // pinned next-iteration dequant (see the main loop): +2..6 % at M = 8192

@@ -23,10 +23,19 @@ __global__ __launch_bounds__(kNormMaxThreads) void rmsnorm_kernel(half_t* __rest
                                                                   const half_t* __restrict__ weight,
                                                                   float eps,
                                                                   int   M,
-                                                                  int   H)
+                                                                  int   H,
+                                                                  uint64_t* dbg)
 {
     __shared__ float red[8];
+    if (dbg && threadIdx.x == 0) {
+        dbg[blockIdx.x * 8 + 0] = __builtin_amdgcn_s_memrealtime();
+        dbg[blockIdx.x * 8 + 4] = ((uint64_t)__builtin_amdgcn_s_getreg(20 | (31 << 11)) << 32) | (uint32_t)__builtin_amdgcn_s_getreg(4 | (31 << 11));
+    }
     norm_row<MODE, HAS_BIAS, NV>(y, resid, hidden, partial, splits, bias, weight, eps, M, H, blockIdx.x, threadIdx.x, blockDim.x, red);
+    if (dbg && threadIdx.x == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        dbg[blockIdx.x * 8 + 3] = __builtin_amdgcn_s_memrealtime();
+    }
 }
 
 int launch_rmsnorm(half_t* y, const half_t* x, const half_t* w, float eps, int M, int H, hipStream_t st)
@@ -37,11 +46,12 @@ int launch_rmsnorm(half_t* y, const half_t* x, const half_t* w, float eps, int M
     }
     int threads, nv;
     norm_geometry(H, &threads, &nv);
+    uint64_t* const dbg = gemm_trace_for((size_t)M, "norm", M, 1, 1);
     if (nv == 1) {
-        rmsnorm_kernel<0, false, 1><<<M, threads, 0, st>>>(y, nullptr, x, nullptr, 0, nullptr, w, eps, M, H);
+        rmsnorm_kernel<0, false, 1><<<M, threads, 0, st>>>(y, nullptr, x, nullptr, 0, nullptr, w, eps, M, H, dbg);
     }
     else {
-        rmsnorm_kernel<0, false, 2><<<M, threads, 0, st>>>(y, nullptr, x, nullptr, 0, nullptr, w, eps, M, H);
+        rmsnorm_kernel<0, false, 2><<<M, threads, 0, st>>>(y, nullptr, x, nullptr, 0, nullptr, w, eps, M, H, dbg);
     }
     TM_HIP_CHECK(hipGetLastError());
     return 0;
@@ -67,12 +77,13 @@ int launch_residual_rmsnorm(half_t*       y,
     }
     int threads, nv;
     norm_geometry(H, &threads, &nv);
+    uint64_t* const dbg = gemm_trace_for((size_t)M, partial ? "reduce_norm" : "resid_norm", M, 1, 1);
 #define TM_NORM_LAUNCH(MODE, BIAS)                                                                                    \
     if (nv == 1) {                                                                                                    \
-        rmsnorm_kernel<MODE, BIAS, 1><<<M, threads, 0, st>>>(y, resid, hidden, partial, splits, bias, w, eps, M, H);  \
+        rmsnorm_kernel<MODE, BIAS, 1><<<M, threads, 0, st>>>(y, resid, hidden, partial, splits, bias, w, eps, M, H, dbg);  \
     }                                                                                                                 \
     else {                                                                                                            \
-        rmsnorm_kernel<MODE, BIAS, 2><<<M, threads, 0, st>>>(y, resid, hidden, partial, splits, bias, w, eps, M, H);  \
+        rmsnorm_kernel<MODE, BIAS, 2><<<M, threads, 0, st>>>(y, resid, hidden, partial, splits, bias, w, eps, M, H, dbg);  \
     }
     if (partial) {
         if (bias) {

@@ -181,8 +181,26 @@ int    gen_table_export_lines(FILE* f);      // appends the G lines; returns the
 bool   gen_table_import_line(const char* line);  // a `G ...` line; false = not valid (ignored)
 int    gen_dense_candidates(const LinearWeight& w, int M, size_t workspace_bytes, GemmConfig* out, int cap);
 int    gen_grouped_candidates(const LinearWeight& proto, int m_cap, int* rows_out, int cap);
+// RMSNorm folded into the neighbouring decode GEMMs (round 5; gemm_decode_common.h has the arithmetic).  One struct, two roles:
+//   producer (resid != nullptr): the row-parallel GEMM (wo / w2) adds its fp16 output to the residual stream in its own epilogue
+//     (split-K: the last-arriving slice of a column tile sums the slices' slabs in slice order), writes y = h(f32(r) * f32(g)) and
+//     ss_out[tile][m] = partial sum of f32(r)^2 over the tile's columns; tiles_out = column tiles written (set by the launcher)
+//   consumer (ss_in != nullptr): the GEMM fed with that y multiplies its fp32 accumulators by 1 / sqrt(sum_tiles ss / H + eps)
+// Replaces: invokeResidualBiasRMSNorm behind wo / w2 (rms_norm.cu:286-362, unified_decoder.cc:226,278,328) -- the residual stream is
+// bit-identical to the unfused sequence; the normalised activations differ by one fp16 rounding (applied after the contraction).
+struct NormFold {
+    const float*  ss_in    = nullptr;
+    int           ss_tiles = 0;
+    float         inv_h = 0.f, eps = 0.f;
+    half_t*       resid   = nullptr;
+    const half_t* norm_w  = nullptr;
+    float*        ss_out  = nullptr;
+    unsigned*     tickets = nullptr;
+    int           tiles_out = 0;
+};
+bool   dec32_fold_shape(int shape);  // shapes whose kernel carries the folded-norm epilogue / prologue (0..3, 6..9)
 int    launch_linear_dec32(const LinearWeight& w, const half_t* x, int ldx, half_t* y, int ldy, int M, bool gated_silu, int shape,
-                           int splits, float* workspace, int* slabs_out, hipStream_t st);
+                           int splits, float* workspace, int* slabs_out, hipStream_t st, NormFold* nf = nullptr);
 
 // ---- gemm_fp8.hip: fp8 x fp8 linear on v_mfma_f32_32x32x16_fp8_fp8 (activations quantised per row and 128 channels) ---
 size_t p8_bytes(int K, int N);
@@ -259,8 +277,24 @@ extern uint64_t* g_gemm_dbg;  // gemm_w4a16.hip: optional per-workgroup timing s
 // device write the library had: a trace buffer sized for one kernel left set while a larger grid ran -- the probable origin of
 // the one-off "memory access fault" of a round-2 diagnostic script; tests/test_gpu_fullsize.py::..._with_canaries is clean.)
 constexpr size_t kTraceMaxWorkgroups = 8192;
-inline uint64_t* gemm_trace_for(size_t workgroups)
+// Arena mode (tm_debug_trace_arena, round 5): every traced launch gets ITS OWN region of a caller-sized buffer, handed out in
+// launch order, and a host-side record (tag, grid, offset) -- so that the launches of a captured hipGraph keep distinct regions
+// and one replay leaves the stamps of every kernel of the step (tools/fixed_cost_table.py).  Allocation happens on the host at
+// launch / capture time; launches that no longer fit are not traced.
+struct TraceRecord {
+    char   tag[24];
+    int    gx, gy, gz;
+    size_t offset_wgs;
+};
+uint64_t* trace_arena_alloc(size_t workgroups, const char* tag, int gx, int gy, int gz);  // nullptr: no arena / full
+bool      trace_arena_active();
+void      trace_arena_set(uint64_t* base, size_t cap_wgs);
+size_t    trace_arena_records(char* out, size_t cap);
+inline uint64_t* gemm_trace_for(size_t workgroups, const char* tag = "", int gx = 0, int gy = 0, int gz = 0)
 {
+    if (trace_arena_active()) {
+        return trace_arena_alloc(workgroups, tag, gx, gy, gz);
+    }
     return workgroups <= kTraceMaxWorkgroups ? g_gemm_dbg : nullptr;
 }
 

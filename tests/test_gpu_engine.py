@@ -15,10 +15,14 @@ from oracle import tm_oracle as o
 pytestmark = pytest.mark.gpu
 
 
+@pytest.mark.parametrize('fold', [1, 0])
 @pytest.mark.parametrize('kv_bits,use_graph', [(8, 1), (4, 0), (16, 1)])
-def test_engine_matches_oracle(cuda, monkeypatch, kv_bits, use_graph):
+def test_engine_matches_oracle(cuda, monkeypatch, kv_bits, use_graph, fold):
     """prefill + 6 decode steps of a ragged batch against the oracle model: logits of every step, greedy tokens (eager and
-    graph-replayed)."""
+    graph-replayed).  fold = 1 (the default): the decode steps run the RMSNorms folded into the GEMMs (5 launches per layer) --
+    the oracle stays the reference's unfused sequence and the bound stays the unfused engine's (3e-2 on O(1) logits; measured
+    max differences are printed for both arms)."""
+    monkeypatch.setenv('TM_FOLD_NORM', str(fold))
     cfg = o.ModelConfig(hidden=256, layers=2, q_heads=4, kv_heads=2, head_dim=128, inter=512, vocab=1024,
                         kv_bits=kv_bits, rope=o.RopeParam(128, 500000.0, 'llama3', 8.0, 1.0, 4.0, 8192))
     w = o.make_synthetic_weights(cfg, seed=3)
@@ -47,12 +51,15 @@ def test_engine_matches_oracle(cuda, monkeypatch, kv_bits, use_graph):
         ref_logits.append(lg)
         ref_toks.append(ids)
         cur = toks[:, s + 1]
+    worst = 0.0
     for s in range(steps + 1):
         d = np.abs(logits[s].astype(np.float32) - ref_logits[s].astype(np.float32))
+        worst = max(worst, float(d.max()))
         assert d.max() <= 3e-2, f'step {s}: max logit diff {d.max()}'
         top2 = np.sort(ref_logits[s].astype(np.float32), -1)[:, -2:]
         safe = (top2[:, 1] - top2[:, 0]) > 6e-2
         assert np.array_equal(toks[safe, s], ref_toks[s][safe]), f'step {s}: greedy tokens differ'
+    print(f'[engine vs oracle] kv_bits {kv_bits} graph {use_graph} folded norm {fold}: max logit diff over {steps + 1} steps {worst:.5f}')
 
 
 @pytest.mark.parametrize('graph_comm,side_stream', [(0, 0), (1, 0), (1, 1), (0, 1)])
@@ -75,6 +82,7 @@ def test_engine_collective_path_single_rank(cuda, monkeypatch, graph_comm, side_
             monkeypatch.setenv('TM_COMM_STREAM', str(side_stream))
         else:
             monkeypatch.delenv('TM_FORCE_COMM', raising=False)
+            monkeypatch.setenv('TM_FOLD_NORM', '0')     # the collective-free engine with the SAME arithmetic: reduce-norm launches, not the folded norm
         eng = Engine.from_model_config(cfg, max_batch_size=4, session_len=128, quant_policy=8, use_graph=1)
         if force:
             eng.comm_init(Engine.comm_unique_id())

@@ -608,6 +608,78 @@ def test_w4a16_gated_silu(tm, cuda, K, N, M):
     _ffi.check(tm.tm_linear_destroy(h))
 
 
+@pytest.mark.parametrize('M', [64, 33, 7])
+def test_w4a16_folded_norm(tm, cuda, M):
+    """RMSNorm folded into the two decode GEMMs around it (tm_linear_fold_produce / _consume; the engine's tp = 1 decode step):
+    the producing row-parallel GEMM updates the residual stream in its epilogue -- BIT-IDENTICAL to the unfused device sequence
+    (tm_linear_residual_norm: GEMM [+ fp32 slabs] -> reduce-norm kernel), for every tile and split-K count, the in-launch slab
+    merge by the last-arriving slice included -- writes xg = h(f32(r) * f32(g)) (bit-exact against numpy on the device's own r)
+    and the per-tile sums of squares; the consuming GEMM applies inv[m] to its fp32 accumulators.
+    Tolerance of the consumer's output against the oracle's unfused sequence h(h(r * inv) * g) . W: the SAME bound as the unfused
+    device sequence (2e-3 + 2^-9 |ref|) -- the folded form carries one fp16 rounding of the normalised activations instead of two
+    -- and its mean error against the exact (fp64) result must not exceed the unfused device sequence's."""
+    rng = np.random.default_rng(100 + M)
+    H, K1, N2 = 1024, 2048, 1024      # producer: [K1] -> H (wo / w2 role, 16 k-blocks: up to 4 slices of one stage); consumer: H -> N2 (w_qkv / w1w3 role)
+    eps = 1e-5
+    hp, (qp, sp, zp) = _make_linear(tm, rng, K1, H)
+    hc, (qc, sc, zc) = _make_linear(tm, rng, H, N2)
+    wp, wc = _QCACHE[(K1, H)][3], _QCACHE[(H, N2)][3]
+    x = (rng.standard_normal((M, K1)) * 2).astype(f16)
+    resid0 = rng.standard_normal((M, H)).astype(f16)
+    resid0[:, 5] *= 40.0                                  # an outlier channel, as real residual streams have
+    g = (1.0 + 0.2 * rng.standard_normal(H)).astype(f16)
+    ws = torch.zeros(int(tm.tm_linear_fold_workspace(hp, M)) + M * H * 2 + 4096, dtype=torch.uint8, device='cuda')
+    wsc = torch.zeros(max(1, int(tm.tm_linear_workspace(hc, M))), dtype=torch.uint8, device='cuda')
+    x_d, g_d = dev(x), dev(g)
+    # the oracle's unfused sequence and the exact result
+    r_ref, n_ref = o.residual_rmsnorm(resid0, o.w4a16_linear(x, qp, sp, zp), g, eps)
+    exact_r = r_ref.astype(np.float64)
+    exact_n = exact_r / np.sqrt((exact_r**2).mean(-1, keepdims=True) + eps) * g.astype(np.float64)
+    for gated in (0, 1):
+        ref_y = (o.w4a16_linear_gated_silu(n_ref, qc, sc, zc) if gated else o.w4a16_linear(n_ref, qc, sc, zc)).astype(np.float32)
+        acc = exact_n @ wc.astype(np.float64)
+        exact_y = (acc[:, 0::2] / (1.0 + np.exp(-acc[:, 0::2])) * acc[:, 1::2]) if gated else acc
+        for shape, splits in ((3, 1), (3, 2), (3, 4), (6, 1), (6, 2), (0, 1), (0, 2), (2, 2), (7, 2), (8, 1), (-1, 0)):
+            # unfused device sequence with the same tile: the residual stream to reproduce bit for bit
+            r_u = dev(resid0.copy())
+            n_u = torch.zeros((M, H), dtype=torch.float16, device='cuda')
+            _ffi.check(tm.tm_linear_residual_norm(hp, x_d.data_ptr(), K1, n_u.data_ptr(), r_u.data_ptr(), g_d.data_ptr(), eps, M, shape, splits,
+                                                  ws.data_ptr(), st()))
+            y_u = torch.zeros((M, N2 // 2 if gated else N2), dtype=torch.float16, device='cuda')
+            _ffi.check(tm.tm_linear_forward(hc, n_u.data_ptr(), H, y_u.data_ptr(), y_u.shape[1], M, gated, 0, 1, 0x200 | 3, wsc.data_ptr(), st()))
+            # folded
+            r_f = dev(resid0.copy())
+            xg = torch.zeros((M, H), dtype=torch.float16, device='cuda')
+            ss = torch.full((H // 64, M), float('nan'), dtype=torch.float32, device='cuda')
+            tiles = _ffi.C.c_int(0)
+            for rep in range(2):      # twice: the arrival counters must come back to zero
+                r_f.copy_(torch.from_numpy(resid0).cuda())
+                _ffi.check(tm.tm_linear_fold_produce(hp, x_d.data_ptr(), K1, xg.data_ptr(), r_f.data_ptr(), g_d.data_ptr(), ss.data_ptr(),
+                                                     _ffi.C.byref(tiles), M, shape, splits, ws.data_ptr(), st()))
+            torch.cuda.synchronize()
+            r_dev = host(r_f)
+            assert np.array_equal(r_dev.view(np.uint16), host(r_u).view(np.uint16)), f'residual stream differs from the unfused sequence {shape, splits}'
+            ulp = ulp_diff_f16(r_dev, r_ref)
+            assert ulp.max() <= 1 and (ulp > 0).mean() < 2e-3, 'residual stream vs the oracle'
+            want_xg = np.clip(r_dev.astype(np.float32) * g.astype(np.float32), -65504, 65504).astype(f16)
+            assert np.array_equal(host(xg).view(np.uint16), want_xg.view(np.uint16)), f'xg {shape, splits}'
+            ss_h = host(ss)[:tiles.value].astype(np.float64).sum(0)
+            want_ss = (r_dev.astype(np.float64)**2).sum(-1)
+            assert 1 <= tiles.value <= H // 64 and np.all(np.abs(ss_h - want_ss) <= 1e-5 * want_ss), f'sums of squares {shape, splits}'
+            for cshape, csplits in ((3, 1), (0, 1), (6, 1), (3, 2), (-1, 0)):
+                y = torch.zeros((M, N2 // 2 if gated else N2), dtype=torch.float16, device='cuda')
+                _ffi.check(tm.tm_linear_fold_consume(hc, xg.data_ptr(), H, y.data_ptr(), y.shape[1], M, gated, ss.data_ptr(), tiles.value, H, eps,
+                                                     cshape, csplits, wsc.data_ptr(), st()))
+                yf = host(y).astype(np.float32)
+                err = np.abs(yf - ref_y)
+                assert np.all(err <= 2e-3 + 2.0**-9 * np.abs(ref_y)), f'folded consumer {cshape, csplits} after {shape, splits}: max err {err.max()}'
+                e_f = np.abs(yf - exact_y).mean()
+                e_u = np.abs(host(y_u).astype(np.float32) - exact_y).mean()
+                assert e_f <= 1.05 * e_u + 1e-6, f'folded form is further from the exact result than the unfused one: {e_f} vs {e_u}'
+    _ffi.check(tm.tm_linear_destroy(hp))
+    _ffi.check(tm.tm_linear_destroy(hc))
+
+
 @pytest.mark.parametrize('tp', [2, 4])
 def test_tp_sharded_ffn_sequential_shards(tm, cuda, tp):
     """tensor-parallel numerics validated on ONE GPU -- column-parallel w1w3 (gate/up interleaved, fused
