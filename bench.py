@@ -32,6 +32,8 @@ LLAMA3_70B = dict(hidden=8192, layers=80, q_heads=64, kv_heads=8, head_dim=128, 
 # config 5: Mixtral-8x7B, fp8 block-scaled weights, 8 experts / top-2 (TP = 2 in BASELINE.json; --emulate-tp 2 = one rank)
 MIXTRAL_8X7B = dict(hidden=4096, layers=32, q_heads=32, kv_heads=8, head_dim=128, inter=14336, vocab=32000, rms_eps=1e-5,
                     moe_experts=8, moe_top_k=2, weight_type=2)
+# config 1 (BASELINE.json configs[0]): the reference's own CPU-runnable case -- `--cpu-config0` times it on the host cores, no GPU involved
+INTERNLM2_1_8B = dict(hidden=2048, layers=24, q_heads=16, kv_heads=8, head_dim=128, inter=8192, vocab=92544, rms_eps=1e-5)
 MODELS = {'llama3_8b': LLAMA3_8B, 'internlm2_20b': INTERNLM2_20B, 'llama3_70b': LLAMA3_70B, 'mixtral_8x7b': MIXTRAL_8X7B}
 HBM_PEAK_GBPS = 8000.0     # MI355X HBM3E spec (/opt/skills/guides/MI355X_MICROARCH.md); 6290 measured copy
 
@@ -223,7 +225,20 @@ def main():
     ap.add_argument('--emulate-tp', type=int, default=0,
                     help='SURVEY 8(e) on a 1-GPU box: run ONE rank\'s shard of a TP=N job (heads / inter / vocab divided by N, '
                          'collectives through a 1-rank RCCL communicator): per-rank kernel time only, labelled as such')
+    ap.add_argument('--cpu-config0', action='store_true',
+                    help='BASELINE.json configs[0] only: InternLM2-1.8B fp16 greedy decode on the host cores (oracle/cpu_baseline.py::run_config0, the '
+                         'torch-CPU port of the reference\'s default-backend ops); prints its own JSON line; no GPU is touched')
     args = ap.parse_args()
+    if args.cpu_config0:
+        from oracle import cpu_baseline
+        b = 1 if args.batch == 64 else args.batch
+        r = cpu_baseline.run_config0(INTERNLM2_1_8B, batch=b, ctx=args.prompt_len)
+        emit_json({'metric': f'decode tokens/sec, InternLM2-1.8B fp16 greedy decode, batch {b}, ctx {args.prompt_len}, on the host CPU cores '
+                             '(BASELINE.json configs[0]: the reference\'s CPU-runnable plumbing case; NOT the headline config)',
+                   'value': round(r['value'], 3), 'unit': 'tokens/s', 'n_gpus': 0, 'higher_is_better': True, 'dtype': 'f16 storage, f32 contraction',
+                   'data': 'synthetic', 'config': {'workload': 'InternLM2-1.8B shapes, fp16 random weights, fp16 KV, greedy decode', 'batch': b,
+                                                   'ctx': args.prompt_len}, 'cpu_baseline': r})
+        return
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         # plain `python bench.py --gpus N`: bring up the N ranks of this node ourselves, one process per GPU (the
         # reference starts all ranks of a node from one call too: lmdeploy/turbomind/turbomind.py:191-217)

@@ -149,6 +149,14 @@ __global__ __launch_bounds__(256, 2) void decode_attention_i8_mfma_kernel(Decode
     static_assert(BITS == 8 || BITS == 4, "int8 / int4 KV");
     constexpr int D = 128;
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    // every kernel argument of the prologue in ONE batch of scalar loads: hipcc otherwise fetches late-used fields behind branches
+    // -- five dependent s_load round trips in front of the first cache-block load (seen in the ISA, round 5)
+    asm volatile("" ::"s"(p.q), "s"(p.q_stride), "s"(p.out), "s"(p.k_len), "s"(p.batch), "s"(p.q_heads), "s"(p.scale_log2), "s"(p.splits),
+                 "s"(p.partial_o), "s"(p.partial_ml), "s"(p.cache.block_ptrs), "s"(p.cache.cu_block_nums), "s"(p.cache.block_stride),
+                 "s"(p.cache.layer_offset), "s"(p.cache.layout.kv_heads), "s"(p.cache.layout.head_dim), "s"(p.cache.layout.block_len),
+                 "s"(p.cache.layout.bits));
+    asm volatile("" ::"s"(p.qkv_slabs), "s"(p.qkv_f16), "s"(p.qkv_splits), "s"(p.qkv_n), "s"(p.cos_sin), "s"(p.max_pos), "s"(p.dbg),
+                 "s"(head_chunks), "s"(hpw));
     const KvLayout L = p.cache.layout;
 
     const int kv_head = blockIdx.x / head_chunks;

@@ -272,7 +272,7 @@ struct tm_engine {
     // arrival counters of the producing GEMM; TM_FOLD_NORM=0 keeps the reduce-norm launches
     float*    d_ss      = nullptr;
     unsigned* d_tickets = nullptr;
-    bool      fold_norm = false;
+    int       fold_norm = 0;  // bit 0: wo -> w1w3, bit 1: w2 -> the next layer's w_qkv
     unsigned  h_mark = 0;             // host copy of the native communicator's give-up mark (device_marks_fetch)
     bool      comm_failed = false;    // a give-up mark was seen: the ranks' call sequences may have diverged (sticky, see device_marks_check)
     float*  d_attn_ws = nullptr;
@@ -646,7 +646,7 @@ static void fold_tiling(tm_engine* e, const LinearWeight& w, int M, int* shape, 
 
 static bool fold_ok(const tm_engine* e, const Layer& L, int M)
 {
-    return e->fold_norm && !L.is_moe && M <= 64 && dec32_supported(L.qkv.w, M) && dec32_supported(L.wo.w, M) && dec32_supported(L.w13.w, M)
+    return e->fold_norm != 0 && !L.is_moe && M <= 64 && dec32_supported(L.qkv.w, M) && dec32_supported(L.wo.w, M) && dec32_supported(L.w13.w, M)
            && dec32_supported(L.w2.w, M);
 }
 
@@ -834,10 +834,15 @@ static int forward(tm_engine* e, const int* d_ids, int M, int nseq, bool decode,
             // wo's epilogue updates the residual stream and hands r . g + sums of squares to w1w3, whose accumulators take the row
             // factor before the gated SiLU; w2 does the same for the next layer's w_qkv (the last layer's w2 feeds the final norm
             // and the fp16 lm_head: reduce-norm launch as before).  5 launches per layer instead of 7.
-            TM_PROF(P_GEMM_O, TM_TRY(linear_fold_produce(e, L.wo, e->d_attn, e->q_heads * e->D, M, L.ffn_norm, &ss_tiles)));
+            if (e->fold_norm & 1) {
+                TM_PROF(P_GEMM_O, TM_TRY(linear_fold_produce(e, L.wo, e->d_attn, e->q_heads * e->D, M, L.ffn_norm, &ss_tiles)));
+            }
+            else {
+                TM_TRY(linear_residual_norm(e, L.wo, e->d_attn, e->q_heads * e->D, M, L.ffn_norm, P_GEMM_O));
+            }
             TM_PROF(P_GEMM_GATE_UP, TM_TRY(linear_fold_consume(e, L.w13, e->d_x, e->hidden, e->d_act, e->inter, M, true, ss_tiles, false, nullptr)));
             ss_tiles = 0;
-            if (li + 1 < m.layers && fold_ok(e, e->layers[li + 1], M)) {
+            if ((e->fold_norm & 2) && li + 1 < m.layers && fold_ok(e, e->layers[li + 1], M)) {
                 TM_PROF(P_GEMM_DOWN, TM_TRY(linear_fold_produce(e, L.w2, e->d_act, e->inter, M, next_norm, &ss_tiles)));
             }
             else {
@@ -1453,7 +1458,8 @@ static int tune_decode_gemms(tm_engine* e, int M, bool verbose)
             // decode batches of an engine that folds the RMSNorm into the GEMMs (linear_fold_*): the candidates are timed as they
             // will run -- wo / w2 with the residual / sums-of-squares epilogue (and the in-launch slab merge) instead of the
             // reduce-norm launch, w_qkv / w1w3 with the row factor from d_ss -- and only tiles whose kernel carries that code
-            const bool folded = e->fold_norm && M <= 64 && !e->layers[0].is_moe;
+            // (which == 1 / 2: the wo -> w1w3 pair, bit 0; which == 3 / 0: the w2 -> w_qkv pair, bit 1)
+            const bool folded = M <= 64 && !e->layers[0].is_moe && (e->fold_norm & ((r.which == 1 || r.which == 2) ? 1 : 2)) != 0;
             const bool slabs_ok = norm_consumer || (r.which == 0 && e->fuse_qkv);  // folded: who can take fp32 slabs
             if (folded && (!dec32_fold_shape(cand[i][0]) || (cfg.splits > 1 && !slabs_ok))) {
                 continue;
@@ -1859,7 +1865,7 @@ int tm_engine_start(tm_engine* e)
         TM_TRY(dmalloc(&e->d_tickets, tiles * 2));
         TM_HIP_CHECK(hipMemset(e->d_tickets, 0, tiles * 2 * sizeof(unsigned)));
         const char* fold = getenv("TM_FOLD_NORM");
-        e->fold_norm     = !(fold && !atoi(fold)) && !e->use_comm && m.weight_type == 0 && m.moe_experts == 0 && e->hidden % 64 == 0;
+        e->fold_norm     = (!e->use_comm && m.weight_type == 0 && m.moe_experts == 0 && e->hidden % 64 == 0) ? (fold ? atoi(fold) & 3 : 3) : 0;
     }
     if (m.moe_experts > 0) {
         TM_HIP_CHECK(hipMalloc(&e->d_moe_ws, moe_workspace_bytes(e->layers[0].moe, e->max_tokens)));

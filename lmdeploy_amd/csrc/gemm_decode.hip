@@ -170,6 +170,12 @@ __global__ __launch_bounds__(CG* WK * 64) void gemm_dec32_kernel(Dec32Params p)
 
     const int tid  = threadIdx.x;
     const int wgid = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    // every kernel argument the prologue needs, fetched by ONE batch of scalar loads at entry: left to itself hipcc sinks the loads
+    // of late-used fields behind branches -- three dependent s_load round trips on the way to the first HBM request (seen in the ISA;
+    // round 5, profiles/r05_fixed_cost_by_launch.txt: "issue" 0.41 us per launch)
+    asm volatile("" ::"s"(p.x), "s"(p.wp), "s"(p.y), "s"(p.partial), "s"(p.ldx), "s"(p.ldy), "s"(p.M), "s"(p.N), "s"(p.K), "s"(p.KB),
+                 "s"(p.ncg), "s"(p.kb_per_split), "s"(p.epilogue), "s"(p.wt), "s"(p.dbg));
+    asm volatile("" ::"s"(p.ss_in), "s"(p.ss_tiles), "s"(p.ss_inv_h), "s"(p.ss_eps), "s"(p.resid), "s"(p.norm_w), "s"(p.ss_out), "s"(p.tickets));
     if (p.dbg && tid == 0) {
         p.dbg[wgid * 8 + 0] = __builtin_amdgcn_s_memrealtime();
         p.dbg[wgid * 8 + 4] = ((uint64_t)__builtin_amdgcn_s_getreg(20 | (31 << 11)) << 32) | (uint32_t)__builtin_amdgcn_s_getreg(4 | (31 << 11));
@@ -213,25 +219,28 @@ __global__ __launch_bounds__(CG* WK * 64) void gemm_dec32_kernel(Dec32Params p)
     }
 
     // ---- folded RMSNorm, consumer side (p.ss_in): the producing GEMM left, per column tile, partial row sums of squares of the
-    // residual rows.  T / ROWS threads per row fetch them (up to 8 loads each, issued here, OLDER than every load of the prologue:
-    // the prologue's own counted wait covers them), the row factor is finished after the main loop.
+    // residual rows.  T / ROWS threads per row fetch them (up to 8 loads each) right behind the activation DMA of stage 0 (L2 hits
+    // like it, covered by its wait), park their share in LDS before the first barrier; the row factor is finished in the epilogue.
     constexpr int LDSX   = 2 * STG > REDB ? 2 * STG : REDB;  // scratch behind the stage buffers / the reduction image
     constexpr int PARTS  = T / ROWS;
     float*        part_s = (float*)(smem + LDSX);            // [PARTS][ROWS]
-    float*        inv_s  = part_s + PARTS * ROWS;            // [ROWS]
-    static_assert(PARTS * ROWS * 4 + ROWS * 4 + 16 <= kDec32NormLds, "norm scratch");
+    static_assert(PARTS * ROWS * 4 + 16 <= kDec32NormLds, "norm scratch");
     const bool    scaled = p.ss_in != nullptr;               // uniform
-    float         ssv[8], ss_extra = 0.f;
-    if (scaled) {
+    float         ssv[8] = {}, ss_extra = 0.f;
+    auto ss_issue = [&]() __attribute__((always_inline)) {
         const int    part = tid / ROWS;
         const float* src  = p.ss_in + min(m0 + tid % ROWS, p.M - 1);
-        for (int t = part + 8 * PARTS; t < p.ss_tiles; t += PARTS) {  // more tiles than 8 per thread (wide models, narrow workgroups)
-            ss_extra += src[(size_t)t * p.M];
-        }
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const int t = part + u * PARTS;
-            ssv[u]      = t < p.ss_tiles ? src[(size_t)t * p.M] : 0.f;
+            ssv[u]      = src[(size_t)min(t, p.ss_tiles - 1) * p.M];  // clamped, unconditional: a fixed number of loads in the queue
+        }
+    };
+    if (scaled && p.ss_tiles > 8 * PARTS) {  // more tiles than 8 per thread (wide models, narrow workgroups): before anything else
+        const int    part = tid / ROWS;
+        const float* src  = p.ss_in + min(m0 + tid % ROWS, p.M - 1);
+        for (int t = part + 8 * PARTS; t < p.ss_tiles; t += PARTS) {
+            ss_extra += src[(size_t)t * p.M];
         }
     }
 
@@ -318,6 +327,10 @@ __global__ __launch_bounds__(CG* WK * 64) void gemm_dec32_kernel(Dec32Params p)
             // queue: x(0) DMA pieces, then the whole weight ring; the DMA is invisible to hipcc's waitcnt pass, so its
             // completion is waited for by hand: everything older than the 3 * PF ring loads
             D32_DMA_X(phys(0), 0);
+            if (scaled) {  // uniform: the sums-of-squares loads ride between the DMA and the ring: covered by the DMA's own wait below
+                ss_issue();
+                __builtin_amdgcn_sched_barrier(0);
+            }
             constexpr int PF0 = PF;
 #pragma unroll
             for (int q = 0; q < PF0; ++q) {
@@ -330,6 +343,9 @@ __global__ __launch_bounds__(CG* WK * 64) void gemm_dec32_kernel(Dec32Params p)
             asm volatile("s_waitcnt vmcnt(%0)" ::"i"((ABL & 0x1000) ? 0 : 3 * PF0) : "memory");
         }
         else {
+            if (scaled) {
+                ss_issue();
+            }
             D32_LOAD_X(phys(0));
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -350,11 +366,14 @@ __global__ __launch_bounds__(CG* WK * 64) void gemm_dec32_kernel(Dec32Params p)
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-        if (scaled) {  // fixed order: tiles part, part + PARTS, ... then the tail
-            float t = ssv[0];
+        // folded RMSNorm, consumer side: this thread's share of its row's tiles, in a fixed order (tiles part, part + PARTS, ... then
+        // the tail); the row factor is finished per thread in the epilogue
+        if (scaled) {
+            const int part = tid / ROWS;
+            float     t    = 0.f;
 #pragma unroll
-            for (int u = 1; u < 8; ++u) {
-                t += ssv[u];
+            for (int u = 0; u < 8; ++u) {
+                t += part + u * PARTS < p.ss_tiles ? ssv[u] : 0.f;
             }
             part_s[tid] = t + ss_extra;  // [tid / ROWS][tid % ROWS]
         }
@@ -538,15 +557,6 @@ __global__ __launch_bounds__(CG* WK * 64) void gemm_dec32_kernel(Dec32Params p)
         }
         return;
     }
-    // folded RMSNorm, consumer side: inv[m] = 1 / sqrt(sum over tiles / H + eps), parts summed in a fixed order
-    if (scaled && tid < ROWS) {
-        float t = part_s[tid];
-#pragma unroll
-        for (int q = 1; q < PARTS; ++q) {
-            t += part_s[q * ROWS + tid];
-        }
-        inv_s[tid] = 1.0f / __builtin_sqrtf(t * p.ss_inv_h + p.ss_eps);
-    }
     // ---- the WK k-phase partial tiles meet in LDS: red[wk][row][c4 ^ (row & 7)] (floatx4 units, CG*8 per row) --------
     // lane holds, per half h and register r: row m = 32h + (l & 31), column 32 cgl + 8 (r >> 2) + 4 (l >> 5) + (r & 3)
     {
@@ -582,6 +592,17 @@ __global__ __launch_bounds__(CG* WK * 64) void gemm_dec32_kernel(Dec32Params p)
             const int      splits = gridDim.y;
             const size_t   slab   = (size_t)p.M * p.N;
             unsigned*      flag   = (unsigned*)(smem + LDSX + kDec32NormLds - 16);
+            // the residual rows and the norm weight do not depend on anybody's arrival: in flight before the slabs are parked
+            constexpr int NI = NE / T;
+            half4_t       r4v[NI], g4v[NI];
+#pragma unroll
+            for (int it = 0; it < NI; ++it) {
+                const int    e = it * T + tid, m = e / C4, c4 = e % C4;
+                const int    n = ncol0 + c4 * 4;
+                const bool   ok = m < Mloc && n < p.N;
+                r4v[it] = *(const half4_t*)(p.resid + ((size_t)m0 + (ok ? m : 0)) * p.N + (ok ? n : 0));
+                g4v[it] = *(const half4_t*)(p.norm_w + (ok ? n : 0));
+            }
             if (splits > 1) {
                 // every slice parks its fp32 tile write-through, then takes a ticket: the LAST arriver of the tile sums the slices in
                 // slice order (its own from LDS -- the same bits it stored) and runs the epilogue; the others are done
@@ -642,8 +663,8 @@ __global__ __launch_bounds__(CG* WK * 64) void gemm_dec32_kernel(Dec32Params p)
                     }
                 }
                 const half4_t hc = {(half_t)a[0], (half_t)a[1], (half_t)a[2], (half_t)a[3]};  // the GEMM's fp16 output rounding
-                half4_t       r4 = *(const half4_t*)(p.resid + mg * p.N + nc);
-                const half4_t g4 = *(const half4_t*)(p.norm_w + nc);
+                half4_t       r4 = r4v[e0 / T];
+                const half4_t g4 = g4v[e0 / T];
                 r4               = r4 + hc;  // fp16 add, one rounding per element
                 half4_t xg;
                 float   ss = 0.f;
@@ -683,8 +704,13 @@ __global__ __launch_bounds__(CG* WK * 64) void gemm_dec32_kernel(Dec32Params p)
             const int m  = e / C4;
             const int c4 = e % C4;
             floatx4   a  = tile_sum(m, c4);
-            if (scaled) {
-                const float iv = inv_s[m];
+            if (scaled) {  // inv[m] = 1 / sqrt(sum over tiles / H + eps): every thread of a row adds the same PARTS numbers in the same order
+                float t = part_s[m];
+#pragma unroll
+                for (int q = 1; q < PARTS; ++q) {
+                    t += part_s[q * ROWS + m];
+                }
+                const float iv = 1.0f / __builtin_sqrtf(t * p.ss_inv_h + p.ss_eps);
                 a              = a * floatx4{iv, iv, iv, iv};
             }
             const int n = ncol0 + c4 * 4;

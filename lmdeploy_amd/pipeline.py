@@ -37,7 +37,11 @@ SYNTHETIC = {
 class Pipeline:
 
     def __init__(self, model_path: str, backend_config: TurbomindEngineConfig | None = None, rank: int = 0,
-                 comm_unique_id: bytes | None = None, **kwargs):
+                 comm_unique_id: bytes | None = None, _tp_link=None, **kwargs):
+        """tp > 1, the reference's way (lmdeploy/turbomind/turbomind.py:187-217): ONE call -- this process becomes rank 0 and starts
+        the other tp - 1 ranks of the node itself (one process per GPU, turbomind/tp_group.py), broadcasts every request to them and
+        returns rank 0's responses.  Expert path, unchanged: an externally launched process per GPU (torch.distributed.run, ...)
+        passes its `rank` and the broadcast RCCL id (`comm_unique_id`); `_tp_link` is the worker side of the one-call form."""
         if kwargs.get('speculative_config') is not None or kwargs.get('chat_template_config') is not None:
             raise NotImplementedError('speculative decoding / chat templates are outside the MI355X hot path')
         cfg = backend_config or TurbomindEngineConfig()
@@ -59,16 +63,34 @@ class Pipeline:
         session_len = cfg.session_len or self.model_cfg.max_position_embeddings
         self.session_len = int(session_len)
         devices = cfg.devices or list(range(cfg.tp))
+        per_dev = max([sum(1 for r in range(cfg.tp) if devices[r % len(devices)] == d) for d in set(devices)] or [1])
+        if per_dev > 1:     # ranks share a device (bring-up on a smaller box): their persistent two-shot all-reduce grids must fit TOGETHER
+            os.environ.setdefault('TM_P2P_2SHOT_GRID', str(max(8, 256 // per_dev // 2)))
         self.engine = Engine.from_model_config(
             self.model_cfg, weight_type={'u4': 0, 'f16': 1, 'fp8': 2}[self.model_cfg.weight_format if self.model_cfg.quantized
                                                                         else 'f16'], tp=cfg.tp, rank=rank,
             device=devices[rank % len(devices)], max_batch_size=cfg.max_batch_size or 64, session_len=session_len,
             quant_policy=int(cfg.quant_policy), cache_max_entry_count=cfg.cache_max_entry_count,
             max_prefill_token_num=cfg.max_prefill_token_num or 8192)
+        self._group = None
         if cfg.tp > 1:
-            if comm_unique_id is None:
-                raise ValueError('tp > 1: one process per GPU, pass the broadcast RCCL unique id as comm_unique_id')
-            self.engine.comm_init(comm_unique_id)
+            rows = cfg.max_batch_size or 64
+            # ranks that share a device (a 1-GPU box driving tp = 2 for bring-up): RCCL refuses duplicate devices -> native P2P communicator
+            want_rccl = len(set(devices[r % len(devices)] for r in range(cfg.tp))) == cfg.tp
+            if comm_unique_id is not None:              # expert path: the caller launched one process per GPU and broadcast the id
+                self.engine.comm_init(comm_unique_id)
+            elif _tp_link is not None:                  # a worker of the one-call form
+                _tp_link.setup_comm(self.engine, want_rccl, rows)
+            else:                                       # the one-call form: this process is rank 0 and owns the other ranks
+                if rank != 0:
+                    raise ValueError('tp > 1 with rank != 0 needs comm_unique_id (externally launched ranks)')
+                from .turbomind import tp_group
+                self._group = tp_group.ParentLink(cfg.tp, model_path, cfg)
+                try:
+                    self._comm_backend = self._group.setup_comm(self.engine, want_rccl, rows)
+                except Exception:
+                    self._group.close()
+                    raise
         if synthetic:
             self.engine.init_synthetic(seed=0)
         else:
@@ -80,6 +102,14 @@ class Pipeline:
                 self.tokenizer = AutoTokenizer.from_pretrained(model_path)
         self.engine.start()
         self.max_batch_size = cfg.max_batch_size or 64
+        if self._group is not None:
+            from .turbomind import tp_group
+            try:
+                self._group.wait_ready()
+            except Exception:
+                self._group.close()
+                raise
+            self.engine = tp_group.TpEngine(self.engine, self._group, self._comm_backend)
 
     # ---- reference-compatible entry points -----------------------------------------------------------
     def __call__(self, prompts, gen_config: GenerationConfig | None = None, **kwargs):

@@ -1,0 +1,252 @@
+"""`pipeline(model, backend_config=TurbomindEngineConfig(tp=N))` as ONE call: the ranks of the node are started from here.
+
+Reference: lmdeploy/turbomind/turbomind.py:187-217 starts one thread per GPU of the node from the single `TurboMind(...)` call
+(create_context / process_weight / create_engine concurrently), src/turbomind/turbomind.cc:206-279 builds the communicator groups
+with host barriers between the phases.  The MI355X engine is one PROCESS per GPU (one HIP context, one RCCL rank, IPC-mapped
+peer segments for the native communicator), so the same call here owns N - 1 worker processes next to the caller's own rank 0:
+
+    parent (rank 0)                                    worker r = 1 .. N-1 (`python -m lmdeploy_amd.turbomind.tp_group`)
+    ----------------------------------------------     ---------------------------------------------------------
+    Pipeline.__init__                                  Pipeline.__init__(..., rank=r, _tp_link=WorkerLink)
+      Engine(tp=N, rank=0)                               Engine(tp=N, rank=r)
+      link.setup_comm(engine)   <- unique id, oks ->     link.setup_comm(engine)      RCCL; every rank falls back to the native
+                                <- IPC handles    ->                                  P2P communicator TOGETHER when any rank fails
+      weights (rank 0's shard), start                    weights (rank r's shard), start
+      engine = TpEngine(engine, link)                    link.serve(engine): executes the mirrored engine calls until close
+
+Every state-changing engine call of the parent (prefill / decode / submit / step / cancel / release / set_sampling / ...) is sent
+to the workers BEFORE the parent executes it itself (the collectives inside need all ranks in the call), replies are collected
+afterwards; a worker's error is raised in the parent with its status code.  Reads (poll / fetch / stats) are rank 0's: the sampled
+token is identical on every rank (candidate all-gather / identical Philox draw), so the schedulers of all ranks take the same
+decisions from the same call sequence.  The expert path (`rank=`, `comm_unique_id=`, one externally launched process per GPU, e.g.
+torch.distributed.run) is unchanged.
+"""
+from __future__ import annotations
+
+import os
+import traceback
+
+from .. import _ffi
+from .engine import Engine
+
+# engine methods every rank must execute, in the same order (everything else is answered by rank 0 alone)
+MIRRORED = ('prefill', 'decode', 'release', 'set_sampling', 'set_logits_params', 'submit', 'step', 'cancel', 'forget', 'tune_gemm',
+            'import_gemm_table', 'sync')
+_TIMEOUT_S = float(os.environ.get('TM_TP_GROUP_TIMEOUT_S', '600'))
+
+
+def _setup_comm(eng: Engine, want_rccl: bool, uid: bytes, all_gather, rows: int) -> str:
+    """The same sequence on every rank: RCCL unless the ranks share a device (RCCL refuses duplicate devices); if ANY rank failed,
+    ALL ranks drop RCCL and bring up the native P2P communicator (fused all-reduce + residual + RMSNorm, comm_p2p.hip)."""
+    ok = False
+    if want_rccl:
+        try:
+            eng.comm_init(uid)
+            ok = True
+        except Exception:       # noqa: BLE001 -- reported through the gather below, every rank takes the same branch
+            ok = False
+    oks = all_gather(ok)
+    if want_rccl and all(oks):
+        return 'rccl'
+    if want_rccl and ok:
+        eng.comm_drop_rccl()
+    eng.comm_native_setup(all_gather, rows=rows)
+    return 'native-p2p'
+
+
+class ParentLink:
+    """rank 0's end: one authenticated localhost connection per worker process.  The workers are fresh interpreters
+    (`python -m lmdeploy_amd.turbomind.tp_group`), not forks / multiprocessing children: no HIP context is inherited and the caller's
+    script is not re-imported (pipeline() may be called from unguarded top-level code, as with the reference's in-process ranks)."""
+
+    def __init__(self, tp: int, model_path: str, backend_config, conns=None):
+        import subprocess
+        import sys
+        from multiprocessing.connection import Listener
+        self.tp = tp
+        self.conns, self.procs = [], []
+        if conns is not None:       # established connections (tests drive the protocol with stub engines on threads)
+            self.conns = list(conns)
+            return
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')      # dmabuf IPC: what RCCL and the native segments need on this pool
+        key = os.urandom(16)
+        root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        env = dict(os.environ, TM_TP_GROUP_KEY=key.hex(),
+                   PYTHONPATH=root + (os.pathsep + os.environ['PYTHONPATH'] if os.environ.get('PYTHONPATH') else ''))
+        with Listener(('127.0.0.1', 0), authkey=key) as srv:
+            port = srv.address[1]
+            for r in range(1, tp):
+                self.procs.append(subprocess.Popen([sys.executable, '-m', 'lmdeploy_amd.turbomind.tp_group', str(port), str(r)], env=env,
+                                                   stdout=sys.stderr))        # a worker never writes to the caller's stdout
+            by_rank = {}
+            try:
+                srv._listener._socket.settimeout(_TIMEOUT_S)      # accept() must not wait forever for a worker that died at import
+            except AttributeError:
+                pass
+            try:
+                for _ in range(1, tp):
+                    c = srv.accept()
+                    by_rank[c.recv()] = c
+            except OSError as e:       # socket.timeout: a worker never connected
+                self._kill()
+                raise _ffi.TmError(5, f'tensor-parallel workers did not connect within {_TIMEOUT_S:.0f} s: {e}') from None
+        self.conns = [by_rank[r] for r in range(1, tp)]
+        self.broadcast((model_path, backend_config))
+
+    def _kill(self):
+        for p in self.procs:
+            if p.poll() is None:
+                p.terminate()
+
+    def _recv(self, i):
+        c = self.conns[i]
+        if not c.poll(_TIMEOUT_S):
+            raise _ffi.TmError(5, f'tensor-parallel rank {i + 1} did not answer within {_TIMEOUT_S:.0f} s')
+        try:
+            return c.recv()
+        except EOFError:
+            code = self.procs[i].poll() if i < len(self.procs) else None
+            raise _ffi.TmError(5, f'tensor-parallel rank {i + 1} exited (exit code {code})') from None
+
+    def broadcast(self, obj):
+        for c in self.conns:
+            c.send(obj)
+
+    def all_gather(self, mine):
+        """host-side all-gather in rank order; the workers call WorkerLink.all_gather at the same point of the same sequence"""
+        vals = [mine]
+        for i in range(len(self.conns)):
+            tag, v = self._recv(i)
+            if tag != 'gather':
+                raise _ffi.TmError(5, f'tensor-parallel rank {i + 1}: {v}' if tag == 'error' else f'protocol: expected gather, got {tag}')
+            vals.append(v)
+        self.broadcast(vals)
+        return vals
+
+    def setup_comm(self, eng: Engine, want_rccl: bool, rows: int) -> str:
+        uid = Engine.comm_unique_id()
+        self.broadcast(('comm', want_rccl, uid, rows))
+        return _setup_comm(eng, want_rccl, uid, self.all_gather, rows)
+
+    def wait_ready(self):
+        """every worker reports ('ready', rank) once its engine has its weights and is started"""
+        for i in range(len(self.conns)):
+            rep = self._recv(i)
+            if rep[0] != 'ready':
+                raise _ffi.TmError(5, f'tensor-parallel rank {i + 1} failed to start: {rep[1] if len(rep) > 1 else rep}')
+
+    def collect(self):
+        """one reply per worker for the call just mirrored: ('ok', value) | ('error', status, message)"""
+        out = []
+        for i in range(len(self.conns)):
+            out.append(self._recv(i))
+        return out
+
+    def close(self):
+        for c in self.conns:
+            try:
+                c.send(None)
+            except (BrokenPipeError, OSError):
+                pass
+        for p in self.procs:
+            try:
+                p.wait(timeout=30)
+            except Exception:       # noqa: BLE001 -- subprocess.TimeoutExpired
+                p.terminate()
+        for c in self.conns:
+            c.close()
+        self.conns, self.procs = [], []
+
+
+class WorkerLink:
+    """a worker's end of its pipe to rank 0"""
+
+    def __init__(self, conn):
+        self.conn = conn
+
+    def all_gather(self, mine):
+        self.conn.send(('gather', mine))
+        return self.conn.recv()
+
+    def setup_comm(self, eng: Engine, want_rccl: bool, rows: int) -> str:
+        tag, want, uid, rows0 = self.conn.recv()
+        assert tag == 'comm', tag
+        return _setup_comm(eng, want, uid, self.all_gather, rows0)
+
+    def serve(self, eng: Engine):
+        """execute the parent's mirrored calls until it closes the group"""
+        while True:
+            try:
+                msg = self.conn.recv()
+            except EOFError:
+                break
+            if msg is None:
+                break
+            name, args, kwargs = msg
+            try:
+                self.conn.send(('ok', getattr(eng, name)(*args, **kwargs)))
+            except _ffi.TmError as e:
+                self.conn.send(('error', e.status, str(e)))
+            except Exception as e:      # noqa: BLE001 -- the parent must hear about it instead of waiting for the timeout
+                self.conn.send(('error', 5, f'{type(e).__name__}: {e}'))
+
+
+class TpEngine:
+    """rank 0's Engine + the mirrored workers behind the interface Pipeline uses"""
+
+    def __init__(self, eng: Engine, link: ParentLink, backend: str):
+        self._eng, self._link, self.comm_backend = eng, link, backend
+
+    def __getattr__(self, name):
+        attr = getattr(self._eng, name)
+        if name not in MIRRORED:
+            return attr
+
+        def call(*args, **kwargs):
+            self._link.broadcast((name, args, kwargs))
+            err = None
+            try:
+                out = attr(*args, **kwargs)
+            except _ffi.TmError as e:
+                err, out = e, None
+            replies = self._link.collect()
+            if err is not None:
+                raise err
+            for r, rep in enumerate(replies, start=1):
+                if rep[0] == 'error':
+                    raise _ffi.TmError(rep[1], f'tensor-parallel rank {r}: {rep[2]}')
+            return out
+        return call
+
+    def close(self):
+        try:
+            self._link.close()
+        finally:
+            self._eng.close()
+
+
+def worker_main(port: int, rank: int):
+    """a worker process: the same Pipeline construction as the caller's, for rank `rank`, then the serve loop"""
+    from multiprocessing.connection import Client
+    conn = Client(('127.0.0.1', port), authkey=bytes.fromhex(os.environ['TM_TP_GROUP_KEY']))
+    conn.send(rank)
+    try:
+        model_path, backend_config = conn.recv()
+        from ..pipeline import Pipeline
+        link = WorkerLink(conn)
+        pipe = Pipeline(model_path, backend_config, rank=rank, _tp_link=link)
+        conn.send(('ready', rank))
+        link.serve(pipe.engine)
+        pipe.engine.close()
+    except Exception as e:      # noqa: BLE001
+        try:
+            conn.send(('error', f'{type(e).__name__}: {e}\n{traceback.format_exc()}'))
+        except (BrokenPipeError, OSError):
+            pass
+    finally:
+        conn.close()
+
+
+if __name__ == '__main__':
+    import sys
+    worker_main(int(sys.argv[1]), int(sys.argv[2]))

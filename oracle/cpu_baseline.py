@@ -140,3 +140,64 @@ def run(model: dict, batch: int, ctx: int, sample_layers: int = 2, seed: int = 0
                 sample=(f'{sample_layers} of {model["layers"]} decoder layers + lm_head, one decode step, batch {batch}, '
                         f'ctx {ctx}, int8 KV; 1 warm-up + {len(per_layer)} timed passes (median {t_layer:.2f} s / layer, '
                         f'{t_head:.2f} s head); fp32 contraction on CPU; extrapolated to {model["layers"]} layers'))
+
+
+def run_config0(model: dict, batch: int = 1, ctx: int = 1024, steps: int = 4, seed: int = 0, threads: int | None = None,
+                budget_s: float = 25.0) -> dict:
+    """BASELINE.json configs[0]: InternLM2-1.8B, fp16 weights, fp16 KV, greedy decode on the host cores (the reference's own
+    CPU-runnable case is its PyTorch engine's default op backend: pytorch/backends/default/{norm,activation,apply_rotary_emb}.py --
+    plain torch ops; there is no quantised linear and no KV quantisation in it).  The WHOLE model runs (24 layers: no
+    extrapolation): one untimed warm-up step, then up to `steps` timed decode steps of `batch` sequences at context `ctx` within
+    `budget_s` seconds.  The contraction runs in fp32 over fp16-rounded weights (CPU fp16 matmul is slow / partly unsupported)."""
+    threads = threads or physical_cores()
+    torch.set_num_threads(threads)
+    g = torch.Generator().manual_seed(seed)
+    H, D = model['hidden'], model['head_dim']
+    Hq, Hkv, I, V, NL = model['q_heads'], model['kv_heads'], model['inter'], model['vocab'], model['layers']
+
+    def lin(K, N):      # fp16-rounded values kept in fp32: what `x.float() @ w.float()` would read, without a per-step conversion
+        return (torch.randn((K, N), generator=g) * (0.5 / K ** 0.5)).to(torch.float16).float()
+
+    layers = [dict(qkv=lin(H, (Hq + 2 * Hkv) * D), wo=lin(Hq * D, H), w13=lin(H, 2 * I), w2=lin(I, H),
+                   n1=torch.ones(H, dtype=torch.float16), n2=torch.ones(H, dtype=torch.float16),
+                   k=torch.randn((batch, Hkv, ctx, D), generator=g).to(torch.float16),
+                   v=torch.randn((batch, Hkv, ctx, D), generator=g).to(torch.float16)) for _ in range(NL)]
+    emb = (torch.randn((V, H), generator=g) * 0.02).to(torch.float16)
+    w_out = lin(H, V)
+    cos = torch.ones((batch, 1, D // 2), dtype=torch.float16)
+    sin = torch.zeros((batch, 1, D // 2), dtype=torch.float16)
+    rep = Hq // Hkv
+
+    def step(ids):
+        resid = emb[ids]
+        x, _ = _rmsnorm(resid, layers[0]['n1'], 1e-5)
+        for li, L in enumerate(layers):
+            qkv = (x.float() @ L['qkv']).to(torch.float16)
+            q = _rope(qkv[:, :Hq * D].view(batch, Hq, D), cos, sin)
+            k = _rope(qkv[:, Hq * D:(Hq + Hkv) * D].view(batch, Hkv, D), cos, sin).view(batch, Hkv, 1, D)
+            v = qkv[:, (Hq + Hkv) * D:].view(batch, Hkv, 1, D)
+            L['k'][:, :, -1:], L['v'][:, :, -1:] = k, v          # the new token's K / V take the last cache position
+            o = torch.nn.functional.scaled_dot_product_attention(q.view(batch, Hq, 1, D).float(), L['k'].float().repeat_interleave(rep, 1),
+                                                                 L['v'].float().repeat_interleave(rep, 1))
+            h = (o.view(batch, Hq * D) @ L['wo']).to(torch.float16)
+            x, resid = _rmsnorm(h, L['n2'], 1e-5, resid)
+            gu = (x.float() @ L['w13']).to(torch.float16)
+            act = torch.nn.functional.silu(gu[:, 0::2].float()).to(torch.float16) * gu[:, 1::2]
+            d = (act.float() @ L['w2']).to(torch.float16)
+            x, resid = _rmsnorm(d, layers[li + 1]['n1'] if li + 1 < NL else layers[0]['n1'], 1e-5, resid)
+        return (x.float() @ w_out).argmax(-1)
+
+    with torch.no_grad():
+        ids = torch.randint(0, V, (batch,), generator=g)
+        ids = step(ids)                                          # warm-up
+        times, t_begin = [], time.perf_counter()
+        for _ in range(max(1, steps)):
+            t0 = time.perf_counter()
+            ids = step(ids)
+            times.append(time.perf_counter() - t0)
+            if time.perf_counter() - t_begin > budget_s:
+                break
+    t = sorted(times)[len(times) // 2]
+    return dict(value=batch / t, unit='tokens/s', cores=threads, logical_cpus=os.cpu_count(), kind='port',
+                sample=(f'the whole model ({NL} layers + lm_head), fp16 weights and fp16 KV, greedy decode, batch {batch}, ctx {ctx}: 1 warm-up + '
+                        f'{len(times)} timed steps (median {t * 1e3:.1f} ms / step); fp32 contraction on CPU; no extrapolation'))

@@ -15,11 +15,12 @@ from oracle import tm_oracle as o
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize('fold', [1, 0])
+@pytest.mark.parametrize('fold', [3, 1, 2, 0])
 @pytest.mark.parametrize('kv_bits,use_graph', [(8, 1), (4, 0), (16, 1)])
 def test_engine_matches_oracle(cuda, monkeypatch, kv_bits, use_graph, fold):
     """prefill + 6 decode steps of a ragged batch against the oracle model: logits of every step, greedy tokens (eager and
-    graph-replayed).  fold = 1 (the default): the decode steps run the RMSNorms folded into the GEMMs (5 launches per layer) --
+    graph-replayed).  fold = 3 (the default; bit 0: wo -> w1w3, bit 1: w2 -> next w_qkv): the decode steps run the RMSNorms folded into the
+    GEMMs (5 launches per layer) --
     the oracle stays the reference's unfused sequence and the bound stays the unfused engine's (3e-2 on O(1) logits; measured
     max differences are printed for both arms)."""
     monkeypatch.setenv('TM_FOLD_NORM', str(fold))
@@ -773,3 +774,53 @@ def test_pipeline_surface_on_gpu(cuda):
     too_long = pipe([list(range(300))], lmdeploy_amd.GenerationConfig(max_new_tokens=5))
     assert too_long[0].finish_reason == 'error' and too_long[0].error_code == 'INPUT_LENGTH_ERROR'
     pipe.close()
+
+
+def test_two_engines_from_two_threads_of_one_process(cuda):
+    """SURVEY 8(b) threading row: the per-rank set-up calls are callable concurrently (the reference drives create_context /
+    process_weight / create_engine from one thread per GPU of ONE process, lmdeploy/turbomind/turbomind.py:187-217).  Two engines with
+    different weights are created, loaded, started, tuned, driven (prefill + graph-captured decode) and destroyed from two threads at
+    the same time, twice over; each must produce exactly the tokens it produces alone (errors / last-error text are per thread,
+    the dispatch tables are shared behind a mutex)."""
+    import threading
+    cfg = o.ModelConfig(hidden=256, layers=2, q_heads=4, kv_heads=2, head_dim=128, inter=512, vocab=1024, kv_bits=8,
+                        rope=o.RopeParam(128, 500000.0, 'llama3', 8.0, 1.0, 4.0, 8192))
+    ws = [export_weights(cfg, o.make_synthetic_weights(cfg, seed=s)) for s in (31, 32)]
+    rng = np.random.default_rng(4)
+    prompts = [[rng.integers(0, cfg.vocab, n).astype(np.int32) for n in lens] for lens in ((33, 7), (12, 64, 5))]
+
+    def run(i, out, barrier=None):
+        try:
+            if barrier:
+                barrier.wait()
+            eng = Engine.from_model_config(cfg, max_batch_size=4, session_len=128, quant_policy=8, use_graph=1)
+            eng.load_weights(ws[i])
+            eng.start()
+            if barrier:
+                barrier.wait()
+            eng.tune_gemm(4)
+            eng.prefill(prompts[i], max_new_tokens=8)
+            eng.decode(7)
+            out[i] = eng.fetch().copy()
+            if barrier:
+                barrier.wait()
+            eng.close()
+        except Exception as e:      # noqa: BLE001 -- reported by the main thread
+            out[i] = e
+
+    alone = [None, None]
+    for i in range(2):
+        run(i, alone)
+        assert not isinstance(alone[i], Exception), alone[i]
+    for _ in range(2):
+        together = [None, None]
+        bar = threading.Barrier(2)
+        ts = [threading.Thread(target=run, args=(i, together, bar)) for i in range(2)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join(timeout=300)
+            assert not t.is_alive(), 'an engine thread hangs'
+        for i in range(2):
+            assert not isinstance(together[i], Exception), together[i]
+            assert np.array_equal(together[i], alone[i]), f'engine {i} driven beside another engine differs from its solo run'

@@ -659,8 +659,12 @@ def test_w4a16_folded_norm(tm, cuda, M):
             torch.cuda.synchronize()
             r_dev = host(r_f)
             assert np.array_equal(r_dev.view(np.uint16), host(r_u).view(np.uint16)), f'residual stream differs from the unfused sequence {shape, splits}'
-            ulp = ulp_diff_f16(r_dev, r_ref)
-            assert ulp.max() <= 1 and (ulp > 0).mean() < 2e-3, 'residual stream vs the oracle'
+            # vs the oracle: the device's fp32 accumulation order may round the GEMM output h(acc) one fp16 step away from numpy's on a
+            # few elements (then r differs by that step of h(acc), whatever r's own magnitude is)
+            hc_ref = o.w4a16_linear(x, qp, sp, zp).astype(np.float32)
+            dr = np.abs(r_dev.astype(np.float32) - r_ref.astype(np.float32))
+            assert np.all(dr <= 2.0**-10 * np.abs(hc_ref) + 2.0**-10 * np.abs(r_ref.astype(np.float32)) + 1e-7) and (dr > 0).mean() < 2e-3, \
+                'residual stream vs the oracle'
             want_xg = np.clip(r_dev.astype(np.float32) * g.astype(np.float32), -65504, 65504).astype(f16)
             assert np.array_equal(host(xg).view(np.uint16), want_xg.view(np.uint16)), f'xg {shape, splits}'
             ss_h = host(ss)[:tiles.value].astype(np.float64).sum(0)

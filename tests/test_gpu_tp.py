@@ -90,3 +90,25 @@ def test_tp2_sampling_and_mixed_steps_on_the_native_communicator(cuda):
     assert res['sampling_mismatch'] == 0 and res['sampling_same_tokens'], res
     assert res['cb_finished'] and res['cb_same_tokens'], res
     assert res['cb_mixed_steps'] >= 2 and res['cb_token_mismatch'] == 0 and res['cb_checked'] >= 4, res
+
+
+@pytest.mark.timeout(600)
+def test_pipeline_tp2_single_call(cuda, tmp_path):
+    """VERDICT r04 item 3 / SURVEY 8(b): `pipeline(path, backend_config=TurbomindEngineConfig(tp=2))` is ONE call, as in the reference
+    (lmdeploy/turbomind/turbomind.py:187-217 starts every rank of the node itself): no externally launched ranks, no `rank=`, no
+    `comm_unique_id=`.  On the one-GPU box both ranks share cuda:0 (devices=[0, 0]) over the native communicator; the tokens are the
+    unsharded oracle's and the continuous-batching path (every scheduler call mirrored to rank 1) reproduces the static one."""
+    env = dict(os.environ)
+    env['GPU_MAX_HW_QUEUES'] = '8'
+    env['HSA_ENABLE_IPC_MODE_LEGACY'] = '0'
+    script = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'tp_pipeline_script.py')
+    pr = subprocess.run([sys.executable, script, str(tmp_path)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=480)
+    res = None
+    for line in reversed(pr.stdout.strip().splitlines()):
+        if line.startswith('{'):
+            res = json.loads(line)
+            break
+    assert res is not None and res['ok'], pr.stdout[-4000:]
+    assert res['backend'] == 'native-p2p' and res['info']['backend'].startswith('native-p2p'), res
+    assert res['checked'] >= 12 and res['mismatch'] == 0, res
+    assert res['cont_equals_static'], res

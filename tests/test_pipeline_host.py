@@ -213,3 +213,104 @@ def test_one_generation_config_per_prompt(pipe):
     assert (res[1].token_ids, res[1].finish_reason) == _expect(prompts[1], 9, {stop})
     with pytest.raises(ValueError):
         pipe(prompts, gs[:2])
+
+
+# ---- pipeline(tp = N) as ONE call: the rank group's host protocol (lmdeploy_amd/turbomind/tp_group.py) ---------------------------------
+class _StubRank:
+    """the engine surface the group drives, recording every call; rank 1's RCCL bring-up can be made to fail"""
+
+    def __init__(self, rank, rccl_fails=False):
+        self.rank, self.rccl_fails, self.calls, self.handles = rank, rccl_fails, [], None
+
+    def comm_init(self, uid):
+        self.calls.append(('comm_init', len(uid)))
+        if self.rccl_fails:
+            raise _ffi.TmError(5, 'ncclCommInitRank: Duplicate GPU detected')
+
+    def comm_drop_rccl(self):
+        self.calls.append(('comm_drop_rccl',))
+
+    def comm_native_setup(self, all_gather, rows):
+        self.handles = all_gather(b'handle-of-rank-%d' % self.rank)
+        self.calls.append(('comm_native_setup', rows))
+
+    def prefill(self, prompts, max_new_tokens):
+        self.calls.append(('prefill', [list(map(int, p)) for p in prompts], max_new_tokens))
+
+    def decode(self, n):
+        self.calls.append(('decode', n))
+        if n == 13 and self.rank == 1:
+            raise _ffi.TmError(6, 'rank 1 says no')
+
+    def submit(self, prompt, max_new, eos=-1, sampling=None, logits=None):
+        self.calls.append(('submit', list(map(int, prompt)), max_new, eos, sampling, logits))
+        return 40 + len(self.calls)
+
+    def step(self):
+        self.calls.append(('step',))
+        return (1, 0)
+
+    def release(self):
+        self.calls.append(('release',))
+
+    def poll(self, rid):
+        return 0, np.asarray([self.rank], np.int32)
+
+    def close(self):
+        self.calls.append(('close',))
+
+
+@pytest.mark.parametrize('rccl_fails_on', [None, 1, 2])
+def test_tp_group_protocol_with_stub_engines(rccl_fails_on):
+    """three ranks: rank 0 = ParentLink + TpEngine in this thread, ranks 1 / 2 = WorkerLink.serve on threads over real duplex pipes.
+    Every rank must take the SAME communicator branch (RCCL only when every rank's init succeeded, else all drop it and exchange
+    the native communicator's handles in rank order), see the same mirrored calls in the same order, and a worker's error must
+    surface in the caller with its status code after every rank answered."""
+    import multiprocessing as mp
+    import threading
+    from lmdeploy_amd.turbomind import tp_group
+    tp = 3
+    pipes = [mp.Pipe(duplex=True) for _ in range(tp - 1)]
+    ranks = [_StubRank(r, rccl_fails=(r == rccl_fails_on)) for r in range(tp)]
+    backends = [None] * tp
+
+    def worker(r):
+        link = tp_group.WorkerLink(pipes[r - 1][1])
+        backends[r] = link.setup_comm(ranks[r], True, 0)
+        pipes[r - 1][1].send(('ready', r))
+        link.serve(ranks[r])
+
+    threads = [threading.Thread(target=worker, args=(r,), daemon=True) for r in range(1, tp)]
+    for t in threads:
+        t.start()
+    link = tp_group.ParentLink(tp, 'unused', None, conns=[p[0] for p in pipes])
+    backends[0] = link.setup_comm(ranks[0], True, 64)
+    link.wait_ready()
+    eng = tp_group.TpEngine(ranks[0], link, backends[0])
+    want = 'rccl' if rccl_fails_on is None else 'native-p2p'
+    assert backends == [want] * tp
+    for r in ranks:
+        if want == 'rccl':
+            assert [c[0] for c in r.calls] == ['comm_init']
+        else:
+            assert r.handles == [b'handle-of-rank-%d' % q for q in range(tp)], 'handles must arrive in rank order on every rank'
+            assert ('comm_native_setup', 64) in r.calls, 'rows of the parent reach every rank'
+            assert (('comm_drop_rccl',) in r.calls) == (r.rank != rccl_fails_on), 'exactly the ranks whose RCCL came up drop it'
+    n0 = [len(r.calls) for r in ranks]
+    eng.prefill([np.asarray([1, 2, 3], np.int32), [4, 5]], max_new_tokens=7)
+    eng.decode(6)
+    rid = eng.submit(np.asarray([9, 8], np.int32), 5, 2, (0.8, 40, 0.9, 0.0, 123), dict(repetition_penalty=1.1, min_new_tokens=0, bad_ids=[3], stop_ids=[]))
+    assert eng.step() == (1, 0)
+    st, toks = eng.poll(rid)                     # a read: rank 0 alone
+    assert toks.tolist() == [0]
+    with pytest.raises(_ffi.TmError) as ei:      # rank 1 refuses; the others ran the call; the caller sees rank 1's status
+        eng.decode(13)
+    assert ei.value.status == 6 and 'rank 1' in str(ei.value)
+    eng.release()
+    mirrored = [r.calls[n:] for r, n in zip(ranks, n0)]
+    assert mirrored[0] == mirrored[1] == mirrored[2], 'every rank must see the same calls in the same order'
+    assert [c[0] for c in mirrored[0]] == ['prefill', 'decode', 'submit', 'step', 'decode', 'release']
+    eng.close()
+    for t in threads:
+        t.join(timeout=10)
+        assert not t.is_alive(), 'workers must leave their serve loop when the group closes'

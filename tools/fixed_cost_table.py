@@ -36,6 +36,7 @@ def main():
     ap.add_argument('--tune', type=int, default=1)
     ap.add_argument('--quant-policy', type=int, default=8)
     ap.add_argument('--per-layer', action='store_true', help='also print the wall of every layer')
+    ap.add_argument('--attn-detail', action='store_true', help='straggler analysis of the decode attention workgroups')
     args = ap.parse_args()
     import ctypes as C
 
@@ -131,6 +132,42 @@ def main():
             print(f'{"":28s} attention waves: wave 0 loop {m["loop"]:.2f}, wave 1 {m["w1"]:.2f}, wave 3 {m["w3"]:.2f} us after the prologue; '
                   f'first -> last wave done {m["wave_spread"]:.2f} us')
     print(f'# sum of per-layer launches (wall): {tot:.2f} us')
+    if args.attn_detail:
+        # who are the stragglers of the decode attention?  per-workgroup duration by XCC, by kv head (blockIdx.x), by CU occupancy
+        atts = [(tag, gx, gy, gz, off) for tag, gx, gy, gz, off in step if tag == 'attn']
+        dur_all, xcc_all, cu_all, bx_all, st_all = [], [], [], [], []
+        for tag, gx, gy, gz, off in atts[4:-4]:
+            n = gx * gy * gz
+            r = raw[off:off + n]
+            dur_all.append((r[:, 3] - r[:, 0]) / 100.0)
+            st_all.append((r[:, 0] - r[:, 0].min()) / 100.0)
+            xcc_all.append((r[:, 4] >> 32) & 0xf)
+            hwid = r[:, 4] & 0xffffffff
+            cu_all.append(((hwid >> 8) & 0xff) | (((r[:, 4] >> 32) & 0xf) << 8))   # HW_ID bits 8..15 (CU_ID, SH_ID, SE_ID) | XCC
+            bx_all.append(np.arange(n) % gx)
+        dur, xcc, cu, bx, stt = map(np.concatenate, (dur_all, xcc_all, cu_all, bx_all, st_all))
+        print(f'# attention workgroups ({len(dur)} over {len(atts) - 8} launches): duration mean {dur.mean():.2f} p50 {np.percentile(dur, 50):.2f} '
+              f'p90 {np.percentile(dur, 90):.2f} p99 {np.percentile(dur, 99):.2f} max {dur.max():.2f} us')
+        print('#   by XCC:      ' + ' '.join(f'{dur[xcc == k].mean():6.2f}' for k in range(8)))
+        print('#   by kv head:  ' + ' '.join(f'{dur[bx == k].mean():6.2f}' for k in range(int(bx.max()) + 1)))
+        for tag, gx, gy, gz, off in atts[8:9]:
+            n = gx * gy * gz
+            r = raw[off:off + n]
+            hwid = r[:, 4] & 0xffffffff
+            key = ((hwid >> 8) & 0xff) | (((r[:, 4] >> 32) & 0xf) << 8)
+            cnt = np.bincount(np.unique(key, return_inverse=True)[1])
+            print(f'#   one launch: workgroups per (XCC, SE, CU) slot: ' + ', '.join(f'{c} on {np.sum(cnt == c)} CUs' for c in np.unique(cnt)))
+            dd = (r[:, 3] - r[:, 0]) / 100.0
+            order = np.argsort(dd)[-8:]
+            print('#   slowest workgroups of that launch (dur us, start us, xcc, kv head, seq): ' +
+                  '; '.join(f'{dd[i]:.1f} {((r[i, 0] - r[:, 0].min()) / 100.0):.2f} {int((r[i, 4] >> 32) & 0xf)} {i % gx} {i // gx}' for i in order))
+            # per CU: sum of its workgroups' spans vs the launch
+            per_cu_end = {}
+            for i in range(n):
+                per_cu_end[key[i]] = max(per_cu_end.get(key[i], 0), r[i, 3])
+            ends = (np.array(list(per_cu_end.values())) - r[:, 0].min()) / 100.0
+            print(f'#   per-CU finish time: mean {ends.mean():.2f} p10 {np.percentile(ends, 10):.2f} p90 {np.percentile(ends, 90):.2f} max {ends.max():.2f} us '
+                  f'over {len(ends)} CUs')
     if args.per_layer:
         print('# layer walls: ' + ' '.join(f'{w:.1f}' for w in walls))
     eng.close()
