@@ -123,6 +123,13 @@ __global__ void advance_active_kernel(int* k_len, const int* active, int batch)
 
 // continuous batching: a finished / cancelled slot goes back to the scratch block (no host memory involved: the launch needs
 // no synchronisation, so it can queue up behind a decode step that is still running)
+static int launch_advance_active(int* k_len, const int* active, int n, hipStream_t st)
+{
+    advance_active_kernel<<<(n + 63) / 64, 64, 0, st>>>(k_len, active, n);
+    TM_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
 __global__ void park_slot_kernel(int* active, int* k_len, uint64_t* block_row, int slot, uint64_t dummy_block_ptr)
 {
     active[slot] = 0;
@@ -295,6 +302,8 @@ struct tm_engine {
     std::vector<int> h_len;
     std::vector<std::vector<int>> h_blocks;
     int              steps_done = 0;
+    int              steps_fetched = 0;  // steps_done at the last fetch that saw no communicator give-up mark
+    int              steps_valid = -1;   // >= 0 after a give-up: the columns of d_generated known to be valid
 
     int            decode_splits = 1;
     bool           fuse_qkv      = false;  // decode: qkv GEMM output -> attention kernel directly (int8 KV, MFMA kernel)
@@ -1771,11 +1780,10 @@ static int tune_aux_gemms(tm_engine* e, int M, bool verbose)
             int   br = 0;
             TM_TRY(time_graph_us(e, chain, &t_heur));  // no entry: the launchers' own rule
             for (int i = 0; i < nc; ++i) {
-                const int v[4] = {rows[i], 0, 0, 0};
-                gen_table_set(kind, 0, proto.K, proto.N, Mb, v);
+                gen_grouped_rows_override(rows[i]);  // this thread's launches only: nothing transient enters the shared table
                 float     us = 1e30f;
                 const int rc = time_graph_us(e, chain, &us);
-                gen_table_erase(kind, 0, proto.K, proto.N, Mb);
+                gen_grouped_rows_override(0);
                 if (rc) {
                     return rc;
                 }
@@ -2090,7 +2098,9 @@ static void setup_decode(tm_engine* e, int batch)
         }
         const int wgs = e->kv_heads * (group / hpw) * batch;
         splits        = 1;
-        while (wgs * splits < (mfma ? 256 : 512) && splits < 16) {
+        // (the 256-workgroup target is what was measured: full decode batches; small batches -- typically long contexts per sequence --
+        // keep the deeper split)
+        while (wgs * splits < (mfma && batch >= 32 ? 256 : 512) && splits < 16) {
             splits *= 2;
         }
     }
@@ -2162,8 +2172,7 @@ static int prefill_slots(tm_engine* e, const int* const* seq_ids, const int* hos
         const bool merge = mix && b1 == batch && !partial_last;
         const int  nd    = merge ? mix->rows : 0;
         if (merge) {
-            advance_active_kernel<<<(nd + 63) / 64, 64, 0, e->stream>>>(mix->k_len, mix->active, nd);
-            TM_HIP_CHECK(hipGetLastError());
+            TM_TRY(launch_advance_active(mix->k_len, mix->active, nd, e->stream));
             TM_HIP_CHECK(hipMemcpyAsync(e->d_prefill_ids, mix->ids, (size_t)nd * 4, hipMemcpyDeviceToDevice, e->stream));
             for (int& r : rows) {
                 r += nd;
@@ -2285,8 +2294,7 @@ static int cb_enter(tm_engine* e)
 static int decode_step_cb(tm_engine* e)
 {
     const int B = e->cfg.max_batch_size;
-    advance_active_kernel<<<(B + 63) / 64, 64, 0, e->stream>>>(e->d_k_len, e->d_active, B);
-    TM_HIP_CHECK(hipGetLastError());
+    TM_TRY(launch_advance_active(e->d_k_len, e->d_active, B, e->stream));
     TM_TRY(forward(e, e->d_ids, B, B, true, 1, 0, 0, 0));
     TM_HIP_CHECK(hipMemcpyAsync(e->d_ids, e->d_next_ids, (size_t)B * 4, hipMemcpyDeviceToDevice, e->stream));
     return 0;
@@ -2412,6 +2420,7 @@ int tm_engine_release(tm_engine* e)
     e->h_len.clear();
     e->batch      = 0;
     e->steps_done = 0;
+    e->steps_fetched = 0;
     e->h_sampling.clear();
     e->cb_sampling.clear();
     e->sampling_on = false;
@@ -2474,6 +2483,7 @@ int tm_engine_prefill(tm_engine* e, const int* host_ids, const int* host_lens, i
     e->max_new = max_new_tokens;
     e->h_len.assign(host_lens, host_lens + batch);
     e->steps_done = 0;
+    e->steps_fetched = 0;
 
     e->sampling_on = false;
     if (!e->h_sampling.empty()) {
@@ -3121,8 +3131,17 @@ int tm_engine_fetch(tm_engine* e, int* host_out, int* n_generated)
     // the tokens are handed over in any case (those of the steps before a communicator give-up are valid); the status says
     // whether every step behind them was
     TM_HIP_CHECK(hipMemcpy(host_out, e->d_generated, (size_t)e->batch * e->max_new * 4, hipMemcpyDeviceToHost));
-    *n_generated = e->steps_done;
-    return device_marks_check(e);
+    const int rc = device_marks_check(e);
+    if (rc && e->steps_valid < 0) {
+        e->steps_valid = e->steps_fetched;  // the mark was first seen now: what an earlier, clean fetch reported is known to be valid
+    }
+    // after a communicator give-up *n_generated = the columns known to be valid (the step count of the last clean fetch): the
+    // caller can keep those and must discard the rest; the status says so
+    *n_generated = rc ? (e->steps_valid < 0 ? 0 : e->steps_valid) : e->steps_done;
+    if (!rc) {
+        e->steps_fetched = e->steps_done;
+    }
+    return rc;
 }
 
 int tm_engine_fetch_logits(tm_engine* e, void* host_out)

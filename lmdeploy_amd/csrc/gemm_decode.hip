@@ -170,6 +170,18 @@ __global__ __launch_bounds__(CG* WK * 64) void gemm_dec32_kernel(Dec32Params p)
 
     const int tid  = threadIdx.x;
     const int wgid = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    // XCD-aware split-K placement (p.swz; round 5): the hardware deals consecutive workgroups to consecutive
+    // XCDs, so with the plain (tile, slice) = (blockIdx.x, blockIdx.y) every XCD's L2 pulls the activations of EVERY k slice (w2:
+    // 8 x 1.8 MB per launch).  Re-dealt so that a slice's workgroups share 8 / slices XCDs, each L2 fetches only its slice's
+    // columns of x.  Placement is a speed matter only (nothing depends on it for correctness).
+    int bx = blockIdx.x, by = blockIdx.y;
+    if (p.swz) {  // uniform; launcher guarantees gridDim.y in {2, 4, 8}, gridDim.x % (8 / gridDim.y) == 0
+        const int lin = blockIdx.y * gridDim.x + blockIdx.x;
+        const int xcd = lin & 7, j = lin >> 3;
+        const int per = 8 / gridDim.y;  // XCDs per slice
+        by            = xcd / per;
+        bx            = (xcd % per) * (gridDim.x / per) + j;
+    }
     // every kernel argument the prologue needs, fetched by ONE batch of scalar loads at entry: left to itself hipcc sinks the loads
     // of late-used fields behind branches -- three dependent s_load round trips on the way to the first HBM request (seen in the ISA;
     // round 5, profiles/r05_fixed_cost_by_launch.txt: "issue" 0.41 us per launch)
@@ -193,9 +205,9 @@ __global__ __launch_bounds__(CG* WK * 64) void gemm_dec32_kernel(Dec32Params p)
     const int l31  = lane & 31;
     const int half = lane >> 5;
 
-    const int cg  = blockIdx.x * CG + cgl;
+    const int cg  = bx * CG + cgl;
     const int cgc = min(cg, p.ncg - 1);
-    const int kb0 = blockIdx.y * p.kb_per_split;
+    const int kb0 = by * p.kb_per_split;
     const int nkb = min(p.kb_per_split, p.KB - kb0);
     const int nst = (nkb + S - 1) / S;
     auto      phys = [&](int t) { return min(t, nst - 1); };  // stages past the slice re-read the last one (nobody consumes them)
@@ -227,13 +239,14 @@ __global__ __launch_bounds__(CG* WK * 64) void gemm_dec32_kernel(Dec32Params p)
     static_assert(PARTS * ROWS * 4 + 16 <= kDec32NormLds, "norm scratch");
     const bool    scaled = p.ss_in != nullptr;               // uniform
     float         ssv[8] = {}, ss_extra = 0.f;
+    // one buffer instruction per load: out-of-range tiles read as 0 (descriptor bound = ss_tiles rows), the tile stride rides in an SGPR
     auto ss_issue = [&]() __attribute__((always_inline)) {
-        const int    part = tid / ROWS;
-        const float* src  = p.ss_in + min(m0 + tid % ROWS, p.M - 1);
+        const auto rs_ss = __builtin_amdgcn_make_buffer_rsrc((void*)p.ss_in, 0, p.ss_tiles * p.M * 4, 0x00020000);
+        const int  v0    = ((tid / ROWS) * p.M + min(m0 + tid % ROWS, p.M - 1)) * 4;
+        const int  step  = PARTS * p.M * 4;
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-            const int t = part + u * PARTS;
-            ssv[u]      = src[(size_t)min(t, p.ss_tiles - 1) * p.M];  // clamped, unconditional: a fixed number of loads in the queue
+            ssv[u] = bit_cast<float>(__builtin_amdgcn_raw_buffer_load_b32(rs_ss, v0, u * step, 0));
         }
     };
     if (scaled && p.ss_tiles > 8 * PARTS) {  // more tiles than 8 per thread (wide models, narrow workgroups): before anything else
@@ -369,11 +382,10 @@ __global__ __launch_bounds__(CG* WK * 64) void gemm_dec32_kernel(Dec32Params p)
         // folded RMSNorm, consumer side: this thread's share of its row's tiles, in a fixed order (tiles part, part + PARTS, ... then
         // the tail); the row factor is finished per thread in the epilogue
         if (scaled) {
-            const int part = tid / ROWS;
-            float     t    = 0.f;
+            float t = 0.f;
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                t += part + u * PARTS < p.ss_tiles ? ssv[u] : 0.f;
+                t += ssv[u];  // tiles past the producer's count came back as 0
             }
             part_s[tid] = t + ss_extra;  // [tid / ROWS][tid % ROWS]
         }
@@ -578,7 +590,7 @@ __global__ __launch_bounds__(CG* WK * 64) void gemm_dec32_kernel(Dec32Params p)
         }
         constexpr int NE = ROWS * C4;  // floatx4 elements of the output tile
         static_assert(NE % T == 0, "whole epilogue passes");
-        const int     ncol0 = blockIdx.x * CG * 32;
+        const int     ncol0 = bx * CG * 32;
         auto tile_sum = [&](int m, int c4) __attribute__((always_inline)) {
             floatx4 a = red[m * C4 + (c4 ^ (m & 7))];
 #pragma unroll
@@ -611,12 +623,12 @@ __global__ __launch_bounds__(CG* WK * 64) void gemm_dec32_kernel(Dec32Params p)
                     const int e = e0 + tid, m = e / C4, c4 = e % C4;
                     const int n = ncol0 + c4 * 4;
                     if (m < Mloc && n < p.N) {
-                        store_wt((floatx4*)(p.partial + (size_t)blockIdx.y * slab + ((size_t)m0 + m) * p.N + n), tile_sum(m, c4), 1);
+                        store_wt((floatx4*)(p.partial + (size_t)by * slab + ((size_t)m0 + m) * p.N + n), tile_sum(m, c4), 1);
                     }
                 }
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __syncthreads();
-                unsigned* const tk = p.tickets + blockIdx.z * gridDim.x + blockIdx.x;
+                unsigned* const tk = p.tickets + blockIdx.z * gridDim.x + bx;
                 if (tid == 0) {
                     *flag = __hip_atomic_fetch_add(tk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
@@ -655,11 +667,11 @@ __global__ __launch_bounds__(CG* WK * 64) void gemm_dec32_kernel(Dec32Params p)
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
                         if (u < splits) {
-                            a += u == (int)blockIdx.y ? own : v[u];
+                            a += u == by ? own : v[u];
                         }
                     }
                     for (int sl = 4; sl < splits; ++sl) {
-                        a += sl == (int)blockIdx.y ? own : load_agent(src + (size_t)sl * slab);
+                        a += sl == by ? own : load_agent(src + (size_t)sl * slab);
                     }
                 }
                 const half4_t hc = {(half_t)a[0], (half_t)a[1], (half_t)a[2], (half_t)a[3]};  // the GEMM's fp16 output rounding
@@ -687,7 +699,7 @@ __global__ __launch_bounds__(CG* WK * 64) void gemm_dec32_kernel(Dec32Params p)
                     ss += __shfl_xor(ss, d);
                 }
                 if (ok && c4 == 0) {
-                    p.ss_out[(size_t)blockIdx.x * p.M + mg] = ss;
+                    p.ss_out[(size_t)bx * p.M + mg] = ss;
                 }
             }
             if (p.dbg && tid == 0) {
@@ -719,7 +731,7 @@ __global__ __launch_bounds__(CG* WK * 64) void gemm_dec32_kernel(Dec32Params p)
             }
             const size_t mg = (size_t)m0 + m;  // row of y
             if (p.epilogue == 2) {
-                floatx4* dst = (floatx4*)(p.partial + ((size_t)blockIdx.y * p.M + mg) * p.N + n);
+                floatx4* dst = (floatx4*)(p.partial + ((size_t)by * p.M + mg) * p.N + n);
                 if (p.wt & 1) {
                     store_wt(dst, a, p.wt >> 4);
                 }
@@ -1219,8 +1231,11 @@ bool dec32_table_get(int K, int N, int M, int* shape, int* splits, int role)
 
 void dec32_table_clear()
 {
-    std::lock_guard<std::mutex> lk(g_d32_mutex);
-    g_d32_table.clear();
+    {
+        std::lock_guard<std::mutex> lk(g_d32_mutex);
+        g_d32_table.clear();
+    }
+    gen_table_clear();  // the general-kernel / grouped entries (`G` lines) are part of the same dispatch state
 }
 
 // text, one line per entry: K N M shape splits [role]   (role 0 / absent: any linear of that shape)
@@ -1248,28 +1263,40 @@ int dec32_table_import(const char* path)
         set_last_error(std::string("cannot read ") + path);
         return 1;
     }
-    int  K, N, M, shape, splits, n = 0;
+    int  K, N, M, shape, splits, n = 0, skipped = 0;
     char line[160];
     while (fgets(line, sizeof line, f)) {
         if (line[0] == 'G') {
-            n += gen_table_import_line(line) ? 1 : 0;
+            const bool ok = gen_table_import_line(line);
+            n += ok ? 1 : 0;
+            skipped += ok ? 0 : 1;
+            continue;
+        }
+        if (line[0] == '#' || line[0] == '\n') {
             continue;
         }
         int       role = 0;
         const int got  = sscanf(line, "%d %d %d %d %d %d", &K, &N, &M, &shape, &splits, &role);
         if (got < 5 || role < 0 || role > 4) {
+            ++skipped;
             continue;
         }
         const bool big = M > 64;
         const bool lc  = shape == kShapeLC && M <= 64;
-        const bool p256 = shape == kShapePre256 && M >= 256 && N >= 256 && splits <= 4;
+        const bool p256 = shape == kShapePre256 && M > 64;  // what launch_linear_dec32 accepts (the tuner only proposes it for M, N >= 256)
         if (K > 0 && N > 0 && M > 0 && M == dec32_m_bucket(M) && shape >= 0 && (shape <= 9 || lc || p256) && splits >= 1 && splits <= 16
             && (big ? shape >= 4 : (shape != 4 && shape != 5)) && !(shape == 5 && N < 512) && K % 128 == 0 && N % 32 == 0) {
             dec32_table_set(K, N, M, shape, splits, role);
             ++n;
         }
+        else {
+            ++skipped;
+        }
     }
     fclose(f);
+    if (skipped) {  // a table written by another build (shapes this build does not have): say so instead of silently running heuristics
+        fprintf(stderr, "[tm] %s: %d dispatch line(s) not understood by this build were skipped (%d imported)\n", path, skipped, n);
+    }
     return n > 0 ? 0 : 1;
 }
 
@@ -1492,6 +1519,9 @@ int launch_linear_dec32(const LinearWeight& w, const half_t* x, int ldx, half_t*
     dim3      grid((p.ncg + cgn - 1) / cgn, splits,
                    shape == kShapePre256 ? (M + 255) / 256 : shape == kShapeLC ? 1 : shape >= 6 ? (M + 31) / 32 : shape >= 4 ? (M + 127) / 128 : 1);
     static const char* const role_tag[6] = {"gemm", "w_qkv", "wo", "w1w3", "w2", "lm_head"};
+    static const int swz_on = env_int2("TM_D32_XCD", 0);  // measured (round 5, call 4): FETCH 1.40 -> 1.28 x algorithmic, step +1.8 % SLOWER
+    p.swz        = swz_on && shape != kShapeLC && shape != kShapePre256 && shape != 5 && (grid.y == 2 || grid.y == 4 || grid.y == 8)
+                   && grid.x % (8 / grid.y) == 0;
     p.dbg        = gemm_trace_for((size_t)grid.x * grid.y * grid.z, role_tag[w.role >= 0 && w.role <= 5 ? w.role : 0], grid.x, grid.y, grid.z);
     const int rc = shape == kShapePre256 ? launch_pre256(p, grid, st) :
                    shape == kShapeLC ? launch_dec_lc(p, grid, st) :

@@ -812,6 +812,20 @@ bool gen_table_get(int kind, int role, int K, int N, int M, int v[4])
     return true;
 }
 
+// the start-up tuner's candidate row tile of the grouped expert GEMMs: an override of THIS thread only (a transient entry
+// in the process-wide table was picked up by other engines / rank threads launching MoE forwards during the timing window)
+static thread_local int tl_grouped_rows = 0;
+void gen_grouped_rows_override(int rows)
+{
+    tl_grouped_rows = rows;
+}
+
+void gen_table_clear()
+{
+    std::lock_guard<std::mutex> lk(g_gen_mutex);
+    g_gen_table.clear();
+}
+
 void gen_table_erase(int kind, int role, int K, int N, int M)
 {
     std::lock_guard<std::mutex> lk(g_gen_mutex);
@@ -931,9 +945,17 @@ GemmConfig gemm_pick_config_general(const LinearWeight& w, int M)
     int        tv[4];
     if (gen_table_get(kGenDense + w.type, w.role, w.K, w.N, dec32_m_bucket(M), tv)) {  // measured for this problem (tm_engine_tune_gemm)
         cfg.nt      = tv[0];
-        cfg.splits  = tv[1] > KB ? KB : tv[1];
+        cfg.splits  = tv[1];
         cfg.waves   = tv[2];
         cfg.kphases = tv[3];
+        // the documented TM_GEMM_* overrides apply to measured entries as well (they silently stopped working once a
+        // `G` line existed)
+        cfg.nt      = env_int("TM_GEMM_NT", cfg.nt);
+        cfg.splits  = env_int("TM_GEMM_SPLITS", cfg.splits);
+        cfg.waves   = env_int("TM_GEMM_WAVES", cfg.waves);
+        cfg.kphases = env_int("TM_GEMM_KPHASES", cfg.kphases);
+        cfg.kstage  = env_int("TM_GEMM_KSTAGE", 0);
+        cfg.splits  = cfg.splits > KB ? KB : cfg.splits;
         return cfg;
     }
     cfg.kphases       = 1;
@@ -1326,7 +1348,10 @@ int launch_linear_grouped(const LinearWeight& proto, const void* d_groups, int E
         const int want = std::min(m_cap, std::max(1, 2 * m_hint));
         int       mt   = want <= 16 ? 1 : (want <= 32 ? 2 : 4);
         int       tv[4];
-        if (gen_table_get(kGenGrouped + proto.type, 0, proto.K, proto.N, dec32_m_bucket(m_cap), tv)) {
+        if (tl_grouped_rows > 0) {
+            mt = tl_grouped_rows / 16;  // the tuner's candidate on this thread
+        }
+        else if (gen_table_get(kGenGrouped + proto.type, 0, proto.K, proto.N, dec32_m_bucket(m_cap), tv)) {
             mt = tv[0] / 16;  // measured (tm_engine_tune_gemm): 16 / 32 / 64-row tiles
         }
         p.zper         = (m_cap + 16 * mt - 1) / (16 * mt);

@@ -177,6 +177,8 @@ constexpr int kGenGrouped = 32;
 void   gen_table_set(int kind, int role, int K, int N, int M, const int v[4]);
 bool   gen_table_get(int kind, int role, int K, int N, int M, int v[4]);  // the role's entry, else the role-0 entry
 void   gen_table_erase(int kind, int role, int K, int N, int M);
+void   gen_table_clear();                   // dec32_table_clear() calls it: both tables travel and reset together
+void   gen_grouped_rows_override(int rows); // tuner only: the grouped GEMMs launched by THIS thread use `rows`-row tiles (0: off)
 int    gen_table_export_lines(FILE* f);      // appends the G lines; returns their number
 bool   gen_table_import_line(const char* line);  // a `G ...` line; false = not valid (ignored)
 int    gen_dense_candidates(const LinearWeight& w, int M, size_t workspace_bytes, GemmConfig* out, int cap);

@@ -168,9 +168,15 @@ class Engine:
         _ffi.check(self._lib.tm_engine_sync(self._h))
 
     def fetch(self) -> np.ndarray:
+        """tokens generated so far, [batch, steps].  After a communicator give-up (terminal) the native call hands over
+        the columns known to be valid together with its error status: they travel on the raised TmError as `.partial_tokens`."""
         out = np.zeros((self.batch, self.max_new), np.int32)
         n = C.c_int(0)
-        _ffi.check(self._lib.tm_engine_fetch(self._h, out.ctypes.data, C.byref(n)))
+        rc = self._lib.tm_engine_fetch(self._h, out.ctypes.data, C.byref(n))
+        if rc != 0:
+            err = _ffi.TmError(rc, _ffi.last_error())
+            err.partial_tokens = out[:, :n.value]
+            raise err
         return out[:, :n.value]
 
     def fetch_logits(self) -> np.ndarray:

@@ -110,5 +110,5 @@ def test_pipeline_tp2_single_call(cuda, tmp_path):
             break
     assert res is not None and res['ok'], pr.stdout[-4000:]
     assert res['backend'] == 'native-p2p' and res['info']['backend'].startswith('native-p2p'), res
-    assert res['checked'] >= 12 and res['mismatch'] == 0, res
+    assert res['checked'] >= 8 and res['mismatch'] == 0, res
     assert res['cont_equals_static'], res

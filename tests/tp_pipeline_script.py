@@ -38,7 +38,7 @@ def main():
     mism, checked = 0, 0
     for s in range(N):
         top2 = np.sort(lg.astype(np.float32), -1)[:, -2:]
-        safe = (top2[:, 1] - top2[:, 0]) > 8e-2
+        safe = (top2[:, 1] - top2[:, 0]) > 1.5e-2     # logits of this small model are O(0.3); tp = 2 vs the unsharded sums differ by ~1e-3
         mism += int(np.sum(np.asarray([static[b][s] for b in range(len(prompts))])[safe] != ids[safe]))
         checked += int(safe.sum())
         ids, lg = om.forward([[int(static[b][s])] for b in range(len(prompts))])
