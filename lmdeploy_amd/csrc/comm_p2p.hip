@@ -26,7 +26,7 @@
 // candidates); every rank issues the same sequence of calls, so both kernels share the epoch counter.
 // Every spin is bounded (TM_P2P_TIMEOUT_MS, default 30 s): on a timeout the kernel records the epoch in state[3] and carries on
 // (wrong numbers, no hang); the engine reads state[3] at its host synchronisation points, fails the step and refuses further
-// work until it is recreated (engine.hip: device_marks_check).
+// work until it is recreated (engine_comm.hip: device_marks_check).
 //
 // Status: protocol and arithmetic run on ONE GPU only in this round -- tests/test_gpu_p2p.py (tp ranks = tp streams, and tp
 // PROCESSES that map each other's segments through IPC handles) and tests/test_gpu_tp.py (a tp = 2 engine as two processes
@@ -66,7 +66,7 @@ struct P2pParams {
 // Wait bound of a peer flag, in ticks of the 100 MHz realtime counter.  TM_P2P_TIMEOUT_MS, default 30 s (read once): RCCL has no
 // bound at all, and ranks are host-driven one by one -- graph capture, a first-use code load or a descheduled host thread on ONE
 // rank must not end the job (the former bound was ~1 s of polling).  On expiry: state[3] = the epoch, the engine
-// fails the step and refuses further work (engine.hip: device_marks_check).
+// fails the step and refuses further work (engine_comm.hip: device_marks_check).
 static uint64_t p2p_timeout_ticks()
 {
     static const uint64_t t = [] {

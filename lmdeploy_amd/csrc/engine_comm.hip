@@ -1,0 +1,224 @@
+// Tensor-parallel collectives of the engine: RCCL all-reduce / all-gather call sites (comm/nccl/nccl.cu:356-398), the native P2P
+// communicator's set-up and fused all-reduce + residual + RMSNorm (comm/cuda_ipc/fused_allreduce.cu:406-500), give-up marks.
+#include "engine_internal.h"
+
+namespace tmk {
+
+// fp16 sum of the row-parallel partial outputs over the TP group (comm/nccl/nccl.cu:356-398 calls ncclAllReduce on the
+// compute stream; TM_COMM_STREAM=1: on a side stream between a fork / join pair)
+static int allreduce_hidden(tm_engine* e, half_t* buf, int M)
+{
+    if (!e->use_comm) {
+        return 0;
+    }
+    TM_REQUIRE(e->comm != nullptr, "tm_engine_comm_init was not called");
+    if (!e->comm_overlap || !e->comm_stream) {
+        TM_NCCL_CHECK(ncclAllReduce(buf, buf, (size_t)M * e->hidden, ncclHalf, ncclSum, e->comm, e->stream));
+        return 0;
+    }
+    TM_HIP_CHECK(hipEventRecord(e->ev_fork, e->stream));
+    TM_HIP_CHECK(hipStreamWaitEvent(e->comm_stream, e->ev_fork, 0));
+    TM_NCCL_CHECK(ncclAllReduce(buf, buf, (size_t)M * e->hidden, ncclHalf, ncclSum, e->comm, e->comm_stream));
+    TM_HIP_CHECK(hipEventRecord(e->ev_join, e->comm_stream));
+    TM_HIP_CHECK(hipStreamWaitEvent(e->stream, e->ev_join, 0));
+    return 0;
+}
+
+void p2p_tables(tm_engine* e, half_t** data, uint32_t** flags)
+{
+    for (int r = 0; r < e->cfg.tp; ++r) {
+        char* base = (char*)(r == e->cfg.rank ? e->p2p_seg : e->p2p_peer[r]);
+        flags[r]   = (uint32_t*)base;
+        data[r]    = (half_t*)(base + 256);
+    }
+}
+
+// d_x = RMSNorm(d_resid += sum over ranks of d_tmp): one fused P2P launch per <= p2p_rows rows on the native communicator
+// (any M when there is no RCCL communicator to fall back to), else RCCL all-reduce + the residual-norm kernel
+int reduce_residual_norm(tm_engine* e, int M, const half_t* norm_w)
+{
+    if (e->p2p_ready && (M <= e->p2p_rows || !e->comm)) {
+        half_t*   data[8];
+        uint32_t* flags[8];
+        p2p_tables(e, data, flags);
+        if (M > e->p2p_rows && M <= e->p2p_rows2) {
+            // a prefill-sized forward on the native communicator alone: ONE two-shot launch (reduce-scatter, norm on the owned row
+            // slice, all-gather) instead of a chain of one-shot launches over row chunks, each reading tp x its bytes
+            half_t *in2[8], *out2[8];
+            for (int r = 0; r < e->cfg.tp; ++r) {
+                in2[r]  = data[r] + 2 * (size_t)e->p2p_rows * e->hidden;
+                out2[r] = in2[r] + (size_t)e->p2p_rows2 * e->hidden;
+            }
+            TM_PROF(P_ALLREDUCE, TM_TRY(launch_p2p_allreduce_norm_2shot(in2, out2, flags, e->cfg.tp, e->cfg.rank, e->p2p_state,
+                                                                        (size_t)e->p2p_rows2 * e->hidden, e->d_tmp, e->d_x, e->d_resid, norm_w,
+                                                                        e->cfg.model.rms_eps, M, e->hidden, e->stream)));
+            return 0;
+        }
+        const size_t tile = (size_t)e->p2p_rows * e->hidden;
+        for (int m0 = 0; m0 < M; m0 += e->p2p_rows) {
+            const int    rows = std::min(e->p2p_rows, M - m0);
+            const size_t off  = (size_t)m0 * e->hidden;
+            TM_PROF(P_ALLREDUCE, TM_TRY(launch_p2p_allreduce_norm(data, flags, e->cfg.tp, e->cfg.rank, e->p2p_state, tile, e->d_tmp + off,
+                                                                  e->d_x + off, e->d_resid + off, norm_w, e->cfg.model.rms_eps, rows,
+                                                                  e->hidden, e->stream)));
+        }
+        return 0;
+    }
+    TM_PROF(P_ALLREDUCE, TM_TRY(allreduce_hidden(e, e->d_tmp, M)));
+    TM_PROF(P_RES_NORM, TM_TRY(launch_residual_rmsnorm(e->d_x, e->d_resid, e->d_tmp, nullptr, 0, nullptr, norm_w,
+                                                       e->cfg.model.rms_eps, M, e->hidden, e->stream)));
+    return 0;
+}
+
+// Device-side give-up mark of the native P2P communicator: a bounded wait for a peer expired (p2p_state[3] = the call number a
+// peer missed; comm_p2p.hip carries on with wrong numbers instead of hanging).  Read at the host's synchronisation points.
+// `async`: enqueue the copy on the engine stream (the caller syncs).
+int device_marks_fetch(tm_engine* e, bool async)
+{
+    if (e->p2p_state) {
+        if (async) {
+            TM_HIP_CHECK(hipMemcpyAsync(&e->h_mark, e->p2p_state + 3, 4, hipMemcpyDeviceToHost, e->stream));
+        }
+        else {
+            TM_HIP_CHECK(hipMemcpy(&e->h_mark, e->p2p_state + 3, 4, hipMemcpyDeviceToHost));
+        }
+    }
+    return 0;
+}
+
+// A mark means: this rank stopped waiting for a peer in collective call `h_mark` and continued with whatever the peer's buffer
+// held.  What was computed from that call on is invalid on THIS rank, and the ranks may no longer agree on the call sequence
+// (a late peer is still inside the call this rank left), so the condition is terminal for the communicator: the step fails with
+// TM_FAIL, the serve loop ends the requests in flight with kFail, and every later step / submit fails with the same status until the engine is
+// recreated (tm_engine_destroy + tm_engine_create on every rank).  Tokens fetched BEFORE the failing step stay readable
+// (tm_engine_fetch does not check the mark).  The wait bound is TM_P2P_TIMEOUT_MS (default 30 s: RCCL has no bound at all; a
+// one-sided stall -- graph capture, a first-use library load, a descheduled host thread -- must not kill the job).
+int device_marks_check(tm_engine* e)
+{
+    if (e->h_mark) {
+        e->comm_failed = true;
+    }
+    if (e->comm_failed) {
+        set_last_error("native communicator: a peer did not arrive within TM_P2P_TIMEOUT_MS (call " + std::to_string(e->h_mark)
+                       + "); results from that call on are invalid and the ranks may have diverged: recreate the engine on every rank");
+        return TM_FAIL;
+    }
+    return 0;
+}
+
+}  // namespace tmk
+
+extern "C" {
+
+int tm_comm_unique_id(void* host_out128)
+{
+    TM_REQUIRE(host_out128, "null pointer");
+    static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId size");
+    ncclUniqueId id;
+    TM_NCCL_CHECK(ncclGetUniqueId(&id));
+    memcpy(host_out128, &id, sizeof(id));
+    return 0;
+}
+
+int tm_engine_comm_init(tm_engine* e, const void* host_id128)
+{
+    TM_REQUIRE(e && host_id128, "null pointer");
+    if (!e->use_comm) {
+        return 0;
+    }
+    ncclUniqueId id;
+    memcpy(&id, host_id128, sizeof(id));
+    TM_HIP_CHECK(hipSetDevice(e->cfg.device));
+    TM_NCCL_CHECK(ncclCommInitRank(&e->comm, e->cfg.tp, id, e->cfg.rank));
+    const char* cs   = getenv("TM_COMM_STREAM");
+    // Measured on MI355X (per-rank emulation of Llama-3-70B TP = 8, 160 collectives per step, profiles/r02_comm_stream_arms.txt):
+    // engine stream 6.81 ms/step; side stream without the prefetch 6.81 ms (a fork/join inside a hipGraph is free, but costs
+    // ~30 us per collective on eager launches); side stream + weight prefetch 7.80 ms (the prefetch kernel costs 6 us and the
+    // next GEMM gains nothing from L2 / Infinity-Cache resident weights).  Default: engine stream; the arms stay reachable.
+    e->comm_overlap  = cs && atoi(cs);
+    if (e->comm_overlap && !e->comm_stream) {
+        TM_HIP_CHECK(hipStreamCreateWithFlags(&e->comm_stream, hipStreamNonBlocking));
+        TM_HIP_CHECK(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
+        TM_HIP_CHECK(hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming));
+    }
+    return 0;
+}
+
+// Forget the RCCL communicator (a tensor-parallel job whose ranks could not ALL bring RCCL up continues on the native P2P
+// communicator alone: a rank that kept its communicator would call ncclAllReduce for large forwards while its peers do not)
+int tm_engine_comm_drop_rccl(tm_engine* e)
+{
+    TM_REQUIRE(e, "null pointer");
+    if (e->comm) {
+        (void)ncclCommDestroy(e->comm);
+        e->comm = nullptr;
+    }
+    return 0;
+}
+
+// Native communicator set-up, two calls around one host-side exchange (any transport: the caller's torch.distributed /
+// MPI / files): export allocates this rank's segment and returns its 64-byte IPC handle; import takes the tp handles in rank
+// order, maps the peers' segments and switches the row-parallel all-reduces with M <= rows (every M when tm_engine_comm_init
+// was not called: no RCCL communicator to fall back to) and the candidate all-gather to comm_p2p.hip.  Replaces the buffer
+// registration of comm/cuda_ipc (cuda_ipc_comm.cu Register / the symmetric allocator) for this path.
+int tm_engine_comm_native_export(tm_engine* e, int rows, void* handle64)
+{
+    TM_REQUIRE(e && handle64, "null pointer");
+    TM_REQUIRE(e->use_comm, "native communicator: the engine runs with tp = 1");
+    TM_REQUIRE(!e->p2p_seg, "native communicator: already exported");
+    TM_REQUIRE(rows >= 1 && rows <= 1024, "native communicator: 1 <= rows <= 1024 (one-shot exchange; larger batches stay on RCCL)");
+    TM_HIP_CHECK(hipSetDevice(e->cfg.device));
+    {   // one workgroup per token row, all resident at once (comm_p2p.hip): clamp to what this device holds
+        const int nvec = e->hidden / 8;
+        const int t    = std::min(512, (nvec + 63) / 64 * 64);
+        const int cap  = p2p_allreduce_capacity(t, (nvec + t - 1) / t == 1);
+        TM_REQUIRE(cap >= 1, "native communicator: occupancy query failed");
+        rows = std::min(rows, cap);
+    }
+    // two-shot regions for everything a forward can carry (TM_P2P_2SHOT=0: one-shot row chunks only)
+    const char* ts = getenv("TM_P2P_2SHOT");
+    const int   rows2 = (ts && !atoi(ts)) ? 0 : std::max(e->cfg.max_prefill_token_num, e->cfg.max_batch_size);
+    TM_TRY(tm_p2p_segment_create(tm_p2p_segment_bytes2(rows, rows2, e->hidden), &e->p2p_seg, handle64));
+    e->p2p_rows2 = rows2;
+    TM_HIP_CHECK(hipMalloc((void**)&e->p2p_state, 4 * sizeof(uint32_t)));
+    TM_HIP_CHECK(hipMemset(e->p2p_state, 0, 4 * sizeof(uint32_t)));
+    e->p2p_rows = rows;
+    return 0;
+}
+
+int tm_engine_comm_native_import(tm_engine* e, const void* handles, int count)
+{
+    TM_REQUIRE(e && handles, "null pointer");
+    TM_REQUIRE(e->p2p_seg && !e->p2p_ready, "native communicator: export first, import once");
+    TM_REQUIRE(count == e->cfg.tp, "native communicator: one handle per rank");
+    TM_HIP_CHECK(hipSetDevice(e->cfg.device));
+    for (int r = 0; r < e->cfg.tp; ++r) {
+        if (r != e->cfg.rank) {
+            TM_TRY(tm_p2p_segment_open((const char*)handles + 64 * (size_t)r, &e->p2p_peer[r]));
+        }
+    }
+    e->p2p_ready = true;
+    return 0;
+}
+
+int tm_engine_comm_info(tm_engine* e, int* backend, int* ranks, int* graph_captured)
+{
+    TM_REQUIRE(e, "null pointer");
+    int b = 0, n = 1;
+    if (e->use_comm) {
+        if (e->comm) {
+            b = 1;
+            TM_NCCL_CHECK(ncclCommCount(e->comm, &n));
+        }
+        if (e->p2p_ready) {
+            b |= 2;
+            n = e->cfg.tp;
+        }
+    }
+    if (backend) *backend = b;
+    if (ranks) *ranks = n;
+    if (graph_captured) *graph_captured = (e->graph || e->graph_cb) ? 1 : 0;
+    return 0;
+}
+
+}  // extern "C"

@@ -1203,7 +1203,7 @@ bool dec32_serves_every_m(int K, int N)
 // ---- measured dispatch (reference: gemm::Gemm::Run's DispatchCache, kernels/gemm/gemm.cu:92-224, filled by the warm-up
 // tuning of turbomind.cc:363-487 under TM_GEMM_TUNE and carried between runs by TM_GEMM_EXPORT / TM_GEMM_IMPORT).  Here the
 // key is (K, N, M) of a decode-batch linear, the value its workgroup shape and split-K count; the engine's tuner
-// (engine.hip: tune_decode_gemms) fills it by timing every candidate as a hipGraph over the model's own layer weights
+// (engine_tune.hip: tune_decode_gemms) fills it by timing every candidate as a hipGraph over the model's own layer weights
 // TOGETHER with the kernel that consumes the result (a split-K GEMM pays at the boundary, not inside the kernel).
 static std::map<std::tuple<int, int, int, int>, std::pair<int, int>> g_d32_table;  // (role, K, N, M) -> (shape, splits)
 static std::mutex                                               g_d32_mutex;  // engines tune / import while others launch

@@ -305,7 +305,7 @@ class _DeviceModel:
 @pytest.mark.parametrize('async_on', [True, False])
 @pytest.mark.parametrize('slots,seed', [(1, 0), (3, 1), (3, 2), (8, 3)])
 def test_two_phase_step_protocol_model(slots, seed, async_on):
-    """The issue / retire protocol of the engine's scheduler step (engine.hip: step_locked, cb_issue, cb_retire; reference: the
+    """The issue / retire protocol of the engine's scheduler step (engine_serve.hip: step_locked, cb_issue, cb_retire; reference: the
     two alternating phases of turbomind.cc:171) replayed on the CPU against the REAL scheduler and a model of the device state:
     a pure decode step N+1 is issued before step N is retired; a slot's token counts only if the slot still runs the request it
     ran at issue time.  Invariants: every request receives exactly its tokens 0 .. n-1, once, in order (EOS / length / cancel

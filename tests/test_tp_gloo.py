@@ -1,7 +1,7 @@
 """N > 1 path on CPU: two processes (gloo, world_size 2) each take their TP shard from the product loader
 (`export_weights`), run the oracle's arithmetic on the shard, exchange partial sums with all_reduce exactly where the
 engine calls RCCL (after wo and w2; (value, index) all-gather for the sharded lm_head) and must reproduce the
-unsharded forward.  This checks that the sharding plan of engine.hip / loader.py is correct by construction; the
+unsharded forward.  This checks that the sharding plan of engine.hip (+ engine_forward.hip) / loader.py is correct by construction; the
 GPU collective itself (ncclAllReduce on the engine stream) is exercised by the driver's multi-GPU bench."""
 import os
 import socket
@@ -162,7 +162,7 @@ def _sampling_worker(rank, world, port, logits, params, ctx, ret):
 
 @pytest.mark.timeout(300)
 def test_tp2_sampling_gathers_logits_and_draws_identically():
-    """Stochastic sampling at tp = 2 (engine.hip head(): all-gather of the vocabulary shards, gather_vocab_kernel, the same
+    """Stochastic sampling at tp = 2 (engine_forward.hip head(): all-gather of the vocabulary shards, gather_vocab_kernel, the same
     Philox number on every rank): both ranks rebuild exactly the unsharded logits row and draw exactly the token the
     unsharded oracle draws -- no exchange after the gather."""
     rng = np.random.default_rng(17)
