@@ -599,6 +599,7 @@ __global__ __launch_bounds__(CG* WK * 64) void gemm_dec32_kernel(Dec32Params p)
             }
             return a;
         };
+        if constexpr (MH <= 2)  // (decode row blocks only: the 128-row prefill tile never produces for a folded norm)
         if (p.epilogue == 3) {
             // ---- folded RMSNorm, producer side: residual add + next norm's weight + per-tile sums of squares -------------------
             const int      splits = gridDim.y;
@@ -645,6 +646,22 @@ __global__ __launch_bounds__(CG* WK * 64) void gemm_dec32_kernel(Dec32Params p)
                     __hip_atomic_store(tk, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // every other slice has arrived
                 }
             }
+            // the other slices' slabs of EVERY pass of this thread are requested before any is consumed (one memory round trip on the last
+            // arriver's critical path, not one per pass); the first four slices' loads are clamped and unconditional
+            floatx4 vv[NI][4];
+            if (splits > 1) {
+#pragma unroll
+                for (int it = 0; it < NI; ++it) {
+                    const int    e = it * T + tid, m = e / C4, c4 = e % C4;
+                    const int    n = ncol0 + c4 * 4;
+                    const bool   ok = m < Mloc && n < p.N;
+                    const float* src = p.partial + ((size_t)m0 + (ok ? m : 0)) * p.N + (ok ? n : 0);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        vv[it][u] = load_agent(src + (size_t)min(u, splits - 1) * slab);
+                    }
+                }
+            }
 #pragma unroll
             for (int e0 = 0; e0 < NE; e0 += T) {
                 const int    e = e0 + tid, m = e / C4, c4 = e % C4;
@@ -655,19 +672,13 @@ __global__ __launch_bounds__(CG* WK * 64) void gemm_dec32_kernel(Dec32Params p)
                 const floatx4 own = tile_sum(m, c4);
                 floatx4       a   = own;
                 if (splits > 1) {
-                    // slice order, from zero: the bits of the reduce-norm kernel (norm_row.h).  The first four slices' loads are
-                    // issued together (clamped, unconditional); the own slice comes from LDS
+                    // slice order, from zero: the bits of the reduce-norm kernel (norm_row.h); the own slice comes from LDS
                     const float* src = p.partial + mg * p.N + nc;
-                    floatx4      v[4];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        v[u] = load_agent(src + (size_t)min(u, splits - 1) * slab);
-                    }
                     a = floatx4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
                         if (u < splits) {
-                            a += u == by ? own : v[u];
+                            a += u == by ? own : vv[e0 / T][u];
                         }
                     }
                     for (int sl = 4; sl < splits; ++sl) {
