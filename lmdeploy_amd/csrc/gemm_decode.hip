@@ -170,18 +170,11 @@ __global__ __launch_bounds__(CG* WK * 64) void gemm_dec32_kernel(Dec32Params p)
 
     const int tid  = threadIdx.x;
     const int wgid = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
-    // XCD-aware split-K placement (p.swz; round 5): the hardware deals consecutive workgroups to consecutive
-    // XCDs, so with the plain (tile, slice) = (blockIdx.x, blockIdx.y) every XCD's L2 pulls the activations of EVERY k slice (w2:
-    // 8 x 1.8 MB per launch).  Re-dealt so that a slice's workgroups share 8 / slices XCDs, each L2 fetches only its slice's
-    // columns of x.  Placement is a speed matter only (nothing depends on it for correctness).
-    int bx = blockIdx.x, by = blockIdx.y;
-    if (p.swz) {  // uniform; launcher guarantees gridDim.y in {2, 4, 8}, gridDim.x % (8 / gridDim.y) == 0
-        const int lin = blockIdx.y * gridDim.x + blockIdx.x;
-        const int xcd = lin & 7, j = lin >> 3;
-        const int per = 8 / gridDim.y;  // XCDs per slice
-        by            = xcd / per;
-        bx            = (xcd % per) * (gridDim.x / per) + j;
-    }
+    // (Round 5 measured an XCD-aware re-deal of split-K grids -- one slice's workgroups on 8 / slices XCDs, so that each L2 pulls only its
+    // slice's columns of x: FETCH 1.40 -> 1.28 x the weight bytes and the step 1.8 % SLOWER, because the plain mapping below keeps the
+    // slices of one column tile on ONE XCD, blockIdx.x % 8, which is what the slab merge wants.  Removed;
+    // profiles/r05_fold_modes_and_xcd_placement_ab.txt.)
+    const int bx = blockIdx.x, by = blockIdx.y;
     // every kernel argument the prologue needs, fetched by ONE batch of scalar loads at entry: left to itself hipcc sinks the loads
     // of late-used fields behind branches -- three dependent s_load round trips on the way to the first HBM request (seen in the ISA;
     // round 5, profiles/r05_fixed_cost_by_launch.txt: "issue" 0.41 us per launch)
@@ -1530,9 +1523,6 @@ int launch_linear_dec32(const LinearWeight& w, const half_t* x, int ldx, half_t*
     dim3      grid((p.ncg + cgn - 1) / cgn, splits,
                    shape == kShapePre256 ? (M + 255) / 256 : shape == kShapeLC ? 1 : shape >= 6 ? (M + 31) / 32 : shape >= 4 ? (M + 127) / 128 : 1);
     static const char* const role_tag[6] = {"gemm", "w_qkv", "wo", "w1w3", "w2", "lm_head"};
-    static const int swz_on = env_int2("TM_D32_XCD", 0);  // measured (round 5, call 4): FETCH 1.40 -> 1.28 x algorithmic, step +1.8 % SLOWER
-    p.swz        = swz_on && shape != kShapeLC && shape != kShapePre256 && shape != 5 && (grid.y == 2 || grid.y == 4 || grid.y == 8)
-                   && grid.x % (8 / grid.y) == 0;
     p.dbg        = gemm_trace_for((size_t)grid.x * grid.y * grid.z, role_tag[w.role >= 0 && w.role <= 5 ? w.role : 0], grid.x, grid.y, grid.z);
     const int rc = shape == kShapePre256 ? launch_pre256(p, grid, st) :
                    shape == kShapeLC ? launch_dec_lc(p, grid, st) :

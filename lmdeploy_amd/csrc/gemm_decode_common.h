@@ -25,7 +25,6 @@ struct Dec32Params {
                              // release writes them back (the kernel boundary then waits for MBs of fp32 slabs)
     uint64_t*     dbg;       // optional [workgroups][8] s_memrealtime stamps (tm_debug_set_gemm_trace): start, loop, epilogue, end,
                              // hw id, -, -, after the k-phase reduction barrier
-    int           swz;       // gemm_dec32_kernel: XCD-aware (tile, slice) placement of split-K grids (see the kernel)
     // ---- RMSNorm folded into the neighbouring decode GEMMs (round 5; gemm_dec32_kernel only) ------------------------------
     // y = RMSNorm(r) . W = inv[m] * sum_k (r[m,k] g[k]) W[k,n]: the GEMM that PRODUCES r (epilogue 3) adds its fp16 output to
     // the residual stream (bit-exact: r = h(r + h(acc)), rms_norm.cu:286-362), writes xg = h(f32(r) * f32(g)) as the next

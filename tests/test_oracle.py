@@ -410,3 +410,13 @@ def test_p2p_allreduce_norm_restatement():
     h = ((parts[0].astype(np.float32) + parts[1].astype(np.float32)) + parts[2].astype(np.float32)) + parts[3].astype(np.float32)
     r5, y5 = o.residual_rmsnorm(resid, h.astype(np.float16), w, 1e-5)
     assert np.array_equal(r4.view(np.uint16), r5.view(np.uint16)) and np.array_equal(y4.view(np.uint16), y5.view(np.uint16))
+
+
+def test_cpu_baseline_config0_runs_on_a_tiny_model():
+    """bench.py --cpu-config0 (BASELINE.json configs[0]: InternLM2-1.8B fp16 on the host cores): the whole-model fp16 decode loop of
+    oracle/cpu_baseline.py::run_config0 on a tiny model -- finite, positive rate, the sample string says what was timed."""
+    from oracle import cpu_baseline
+    tiny = dict(hidden=256, layers=2, q_heads=4, kv_heads=2, head_dim=64, inter=512, vocab=300)
+    r = cpu_baseline.run_config0(tiny, batch=2, ctx=16, steps=2, threads=2, budget_s=5.0)
+    assert r['value'] > 0 and np.isfinite(r['value']) and r['kind'] == 'port' and r['cores'] == 2
+    assert 'whole model (2 layers' in r['sample'] and 'no extrapolation' in r['sample']
