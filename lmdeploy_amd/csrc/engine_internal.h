@@ -79,9 +79,10 @@ struct tm_engine {
 
     hipStream_t  stream = nullptr;
     ncclComm_t   comm   = nullptr;
-    // tensor-parallel collectives run on their own stream, forked from / joined to the engine stream by events (inside
-    // a hipGraph capture the pair becomes a parallel branch): while RCCL moves the partial sums over xGMI the engine
-    // stream pulls the NEXT linear's weights towards the Infinity Cache (weight_prefetch_kernel)
+    // TM_COMM_STREAM=1 (opt-in): tensor-parallel collectives on their own stream, forked from / joined to the engine stream by events
+    // (inside a hipGraph capture the pair becomes a parallel branch).  Nothing is scheduled between the fork and the join: a weight
+    // prefetch of the next linear under the collective was measured in round 2 on a 1-rank communicator (pure added cost there,
+    // profiles/r02_comm_stream_arms.txt) and removed; what a real xGMI all-reduce leaves to hide is unmeasured
     hipStream_t  comm_stream = nullptr;
     hipEvent_t   ev_fork = nullptr, ev_join = nullptr;
     // mixed forwards: the decode rows' attention runs on this stream beside the prefill rows' K/V store -> flatten -> attention
