@@ -224,11 +224,6 @@ int forward(tm_engine* e, const int* d_ids, int M, int nseq, bool decode, int ma
     TM_PROF(P_RES_NORM, TM_TRY(launch_rmsnorm(e->d_x, e->d_resid, e->layers[0].attn_norm, m.rms_eps, M, e->hidden, st)));
     const float scale_log2 = (1.0f / std::sqrt((float)e->D)) * 1.4426950408889634f;
     int         ss_tiles   = 0;  // > 0: d_x holds r . g of a folded producer, d_ss its sums of squares (the next GEMM applies the row factor)
-    if (decode && e->fold_norm && M <= 64) {
-        // the arrival counters of the folded split-K merges: every launch leaves them at zero, but a launch that died half way (device
-        // error, aborted graph) would poison every later step silently -- one memset node per step restates the invariant (~2 us of 3 ms)
-        TM_HIP_CHECK(hipMemsetAsync(e->d_tickets, 0, (size_t)((e->hidden + 63) / 64) * 2 * sizeof(unsigned), st));
-    }
     for (int li = 0; li < m.layers; ++li) {
         Layer& L = e->layers[li];
         KvCacheView cv = cache_view(e, li);
