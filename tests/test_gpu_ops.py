@@ -608,8 +608,8 @@ def test_w4a16_gated_silu(tm, cuda, K, N, M):
     _ffi.check(tm.tm_linear_destroy(h))
 
 
-@pytest.mark.parametrize('M', [64, 33, 7])
-def test_w4a16_folded_norm(tm, cuda, M):
+@pytest.mark.parametrize('M,H', [(64, 1024), (33, 1024), (7, 1024), (64, 6144)])
+def test_w4a16_folded_norm(tm, cuda, M, H):
     """RMSNorm folded into the two decode GEMMs around it (tm_linear_fold_produce / _consume; the engine's tp = 1 decode step):
     the producing row-parallel GEMM updates the residual stream in its epilogue -- BIT-IDENTICAL to the unfused device sequence
     (tm_linear_residual_norm: GEMM [+ fp32 slabs] -> reduce-norm kernel), for every tile and split-K count, the in-launch slab
@@ -618,8 +618,11 @@ def test_w4a16_folded_norm(tm, cuda, M):
     Tolerance of the consumer's output against the oracle's unfused sequence h(h(r * inv) * g) . W: the SAME bound as the unfused
     device sequence (2e-3 + 2^-9 |ref|) -- the folded form carries one fp16 rounding of the normalised activations instead of two
     -- and its mean error against the exact (fp64) result must not exceed the unfused device sequence's."""
-    rng = np.random.default_rng(100 + M)
-    H, K1, N2 = 1024, 2048, 1024      # producer: [K1] -> H (wo / w2 role, 16 k-blocks: up to 4 slices of one stage); consumer: H -> N2 (w_qkv / w1w3 role)
+    rng = np.random.default_rng(100 + M + H)
+    # producer: [K1] -> H (wo / w2 role, 16 k-blocks: up to 4 slices of one stage); consumer: H -> N2 (w_qkv / w1w3 role).  H = 6144 (the
+    # InternLM2-20B width): 96 column tiles -- more than the 8 sums per thread an 8-wave consumer holds in registers (its tail loop runs)
+    K1, N2 = 2048, (1024 if H == 1024 else 512)
+    big = H > 1024
     eps = 1e-5
     hp, (qp, sp, zp) = _make_linear(tm, rng, K1, H)
     hc, (qc, sc, zc) = _make_linear(tm, rng, H, N2)
@@ -639,7 +642,7 @@ def test_w4a16_folded_norm(tm, cuda, M):
         ref_y = (o.w4a16_linear_gated_silu(n_ref, qc, sc, zc) if gated else o.w4a16_linear(n_ref, qc, sc, zc)).astype(np.float32)
         acc = exact_n @ wc.astype(np.float64)
         exact_y = (acc[:, 0::2] / (1.0 + np.exp(-acc[:, 0::2])) * acc[:, 1::2]) if gated else acc
-        for shape, splits in ((3, 1), (3, 2), (3, 4), (6, 1), (6, 2), (0, 1), (0, 2), (2, 2), (7, 2), (8, 1), (-1, 0)):
+        for shape, splits in (((3, 1), (3, 4), (6, 2)) if big else ((3, 1), (3, 2), (3, 4), (6, 1), (6, 2), (0, 1), (0, 2), (2, 2), (7, 2), (8, 1), (-1, 0))):
             # unfused device sequence with the same tile: the residual stream to reproduce bit for bit
             r_u = dev(resid0.copy())
             n_u = torch.zeros((M, H), dtype=torch.float16, device='cuda')
@@ -670,7 +673,7 @@ def test_w4a16_folded_norm(tm, cuda, M):
             ss_h = host(ss)[:tiles.value].astype(np.float64).sum(0)
             want_ss = (r_dev.astype(np.float64)**2).sum(-1)
             assert 1 <= tiles.value <= H // 64 and np.all(np.abs(ss_h - want_ss) <= 1e-5 * want_ss), f'sums of squares {shape, splits}'
-            for cshape, csplits in ((3, 1), (0, 1), (6, 1), (3, 2), (-1, 0)):
+            for cshape, csplits in (((3, 1), (0, 1), (6, 1)) if big else ((3, 1), (0, 1), (6, 1), (3, 2), (-1, 0))):
                 y = torch.zeros((M, N2 // 2 if gated else N2), dtype=torch.float16, device='cuda')
                 _ffi.check(tm.tm_linear_fold_consume(hc, xg.data_ptr(), H, y.data_ptr(), y.shape[1], M, gated, ss.data_ptr(), tiles.value, H, eps,
                                                      cshape, csplits, wsc.data_ptr(), st()))
