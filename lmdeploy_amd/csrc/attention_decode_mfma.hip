@@ -28,7 +28,6 @@
 #include "tm_common.h"
 #include "tm_kernels.h"
 #include <type_traits>
-#include <stdlib.h>
 
 namespace tmk {
 
@@ -49,6 +48,9 @@ constexpr float kTwo24 = 16777216.0f;
 
 constexpr int kWaveLds = 16384 + 512;  // K image 8 KB | V image 8 KB | (k_param, v_param) per token
 
+#define GLOBAL_AS __attribute__((address_space(1)))
+#define CONST_AS __attribute__((address_space(4)))
+
 // 8 consecutive columns of row b of the qkv GEMM output: fp16 result, or the in-order sum of the fp32 split-K slabs
 // rounded to fp16 exactly like the GEMM epilogue / splitk_reduce_kernel would.  Split in an issue half (all loads of
 // the first four slabs in flight, nothing consumed) and a finish half, so that the q, new-K/V and first cache-block
@@ -57,29 +59,27 @@ struct QkvRaw {
     floatx4 a0[4], a1[4];
 };
 
+// Branch-free (round 5): fp16 input and slab input issue the same 8 loads (fp16: eight times the same 16 bytes).  A branch around the loads
+// makes the loaded registers phi values, the compiler copies them (v_mov) where the branches meet -- and a copy waits for the load: the
+// cache-block loads behind it were issued one memory round trip late (seen in the ISA).  Address space 1 spelled out for the same reason
+// as in load_tile.
 __device__ __forceinline__ QkvRaw qkv_issue(const DecodeAttnParams& p, int b, int col)
 {
-    QkvRaw r;
-    if (p.qkv_splits == 0) {
-        r.a0[0] = *(const floatx4*)(p.qkv_f16 + (size_t)b * p.qkv_n + col);  // 8 halves
-        return r;
-    }
-    const size_t slab = (size_t)p.batch * p.qkv_n;
-    const float* base = p.qkv_slabs + (size_t)b * p.qkv_n + col;
+    QkvRaw       r;
+    const bool   f16in = p.qkv_splits == 0;
+    const char*  base  = f16in ? (const char*)(p.qkv_f16 + (size_t)b * p.qkv_n + col) : (const char*)(p.qkv_slabs + (size_t)b * p.qkv_n + col);
+    const size_t slab  = f16in ? 0 : (size_t)p.batch * p.qkv_n * 4;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const float* src = base + (size_t)min(j, p.qkv_splits - 1) * slab;
-        r.a0[j]          = *(const floatx4*)src;
-        r.a1[j]          = *(const floatx4*)(src + 4);
+        const char* src = base + (size_t)min(j, max(p.qkv_splits - 1, 0)) * slab;
+        r.a0[j]         = *(const GLOBAL_AS floatx4*)src;
+        r.a1[j]         = *(const GLOBAL_AS floatx4*)(src + (f16in ? 0 : 16));
     }
     return r;
 }
 
 __device__ __forceinline__ half8_t qkv_finish(const DecodeAttnParams& p, int b, int col, const QkvRaw& r)
 {
-    if (p.qkv_splits == 0) {
-        return bit_cast<half8_t>(r.a0[0]);
-    }
     float acc[8] = {};
 #pragma unroll
     for (int j = 0; j < 4; ++j) {  // in slab order: bit-identical to splitk_reduce_kernel
@@ -91,15 +91,17 @@ __device__ __forceinline__ half8_t qkv_finish(const DecodeAttnParams& p, int b, 
             }
         }
     }
-    const size_t slab = (size_t)p.batch * p.qkv_n;
-    const float* base = p.qkv_slabs + (size_t)b * p.qkv_n + col;
-    for (int s = 4; s < p.qkv_splits; ++s) {  // deeper split-K than the engine uses for this projection: plain loop
-        const floatx4 a0 = *(const floatx4*)(base + s * slab);
-        const floatx4 a1 = *(const floatx4*)(base + s * slab + 4);
+    if (p.qkv_splits > 4) {  // deeper split-K than the engine uses for this projection: plain loop
+        const size_t slab = (size_t)p.batch * p.qkv_n;
+        const float* base = p.qkv_slabs + (size_t)b * p.qkv_n + col;
+        for (int s = 4; s < p.qkv_splits; ++s) {
+            const floatx4 a0 = *(const floatx4*)(base + s * slab);
+            const floatx4 a1 = *(const floatx4*)(base + s * slab + 4);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            acc[e] += a0[e];
-            acc[4 + e] += a1[e];
+            for (int e = 0; e < 4; ++e) {
+                acc[e] += a0[e];
+                acc[4 + e] += a1[e];
+            }
         }
     }
     half8_t o;
@@ -107,7 +109,8 @@ __device__ __forceinline__ half8_t qkv_finish(const DecodeAttnParams& p, int b, 
     for (int e = 0; e < 8; ++e) {
         o[e] = (half_t)acc[e];
     }
-    return o;
+    const half8_t direct = bit_cast<half8_t>(r.a0[0]);
+    return p.qkv_splits == 0 ? direct : o;
 }
 
 // interleaved-pair RoPE in fp16 (rotary_embedding.h:169-181): cs = 4 (cos, sin) pairs for these 8 channels
@@ -182,32 +185,18 @@ __global__ __launch_bounds__(256, 2) void decode_attention_i8_mfma_kernel(Decode
     char* Vt = Kt + 8192;
     char* Pm = Kt + 16384;
 
-    // Block pointers.  Rectangular table (block_stride > 0): lane i fetches the pointer of block i of this sequence right
-    // here -- its address needs nothing but kernel arguments, so the load flies together with k_len[b] -- and a block's
-    // pointer is then a v_readlane away: no pointer load in front of the first cache block and none inside the block loop
-    // (it used to be a dependent hop per block: offset -> pointer -> data).  Contexts beyond 64 blocks re-fetch the window.
+    // Context length and block pointers are SCALAR loads (constant address space spelled out: the table and k_len are read-only during the
+    // launch): a few hundred ns each through the scalar cache instead of a VMEM round trip, and no vector load whose result the block
+    // loop would have to wait for with vmcnt(0).  Round 4 kept 64 pointers in a VGPR (v_readlane per block) and re-fetched the window
+    // with a vector load; the pointer of the NEXT block to prefetch is now loaded one iteration ahead (ptr_next below).
     const int       bstride = p.cache.block_stride;
-    const uint64_t* blocks  = p.cache.block_ptrs + (bstride > 0 ? (size_t)b * bstride : (size_t)p.cache.cu_block_nums[b]);
-    uint64_t        bp      = 0;
-    int             bwin    = 0;
-    if (bstride > 0) {
-        bp = blocks[min(lane, bstride - 1)];
-    }
+    const uint64_t* blocks  = p.cache.block_ptrs
+                             + (bstride > 0 ? (size_t)b * bstride : (size_t) * (const CONST_AS int*)(p.cache.cu_block_nums + b));
     auto block_ptr = [&](int tile) -> const char* {  // tile: wave-uniform
-        if (bstride <= 0) {
-            return (const char*)blocks[tile];
-        }
-        const int ut = __builtin_amdgcn_readfirstlane(tile);
-        if ((ut & ~63) != bwin) {
-            bwin = ut & ~63;
-            bp   = blocks[min(bwin + lane, bstride - 1)];
-        }
-        const uint32_t lo = __builtin_amdgcn_readlane((uint32_t)bp, ut & 63);
-        const uint32_t hi = __builtin_amdgcn_readlane((uint32_t)(bp >> 32), ut & 63);
-        return (const char*)(((uint64_t)hi << 32) | lo);
+        return (const char*)*(const CONST_AS uint64_t*)(blocks + __builtin_amdgcn_readfirstlane(tile));
     };
 
-    const int ctx        = p.k_len[b];
+    const int ctx        = *(const CONST_AS int*)(p.k_len + b);
     const int tiles      = (ctx + 63) >> 6;
     const int per_split  = (tiles + p.splits - 1) / p.splits;
     const int tile_begin = split * per_split;
@@ -217,17 +206,6 @@ __global__ __launch_bounds__(256, 2) void decode_attention_i8_mfma_kernel(Decode
     half8_t    qf[4];
     float      q1 = 0.f;  // sum_d q[head][d]
     const bool hv = i16 < hpw;
-    if constexpr (!FUSED) {
-        const half_t* qp = p.q + (size_t)b * p.q_stride + (size_t)(head0 + (hv ? i16 : 0)) * D;
-#pragma unroll
-        for (int dd = 0; dd < 4; ++dd) {
-            half8_t t = *(const half8_t*)(qp + dd * 32 + g * 8);
-            if (!hv) {
-                t = half8_t{};
-            }
-            qf[dd] = t;
-        }
-    }
 
     floatx4 O[8];
 #pragma unroll
@@ -249,9 +227,11 @@ __global__ __launch_bounds__(256, 2) void decode_attention_i8_mfma_kernel(Decode
     // the context are masked to exactly nothing below whatever the registers hold, so those lanes re-read the last valid row
     // instead (same cache lines: no HBM traffic, no branches) -- on average half a block of HBM reads per (sequence, kv head)
     // and launch, all of it on the critical path of the wave that owns one block more than the others.
-    auto load_tile = [&](int tile, auto FIRST) {
-        const char* base = block_ptr(tile) + p.cache.layer_offset;
-        const int   last = decltype(FIRST)::value ? min(63, ctx - tile * 64 - 1) : 63;
+    // FIRST is issued by EVERY wave, branch-free (a wave without a block -- tile < tile_begin -- reads row 0 of the clamped block with every
+    // lane and never uses it): behind a branch, the static s_waitcnt counts of the prologue would have to assume the worst.
+    auto load_tile = [&](const char* blk, int tile, auto FIRST) {
+        const char* base = blk + p.cache.layer_offset;
+        const int   last = decltype(FIRST)::value ? (tile < tile_begin ? 0 : min(63, ctx - tile * 64 - 1)) : 63;
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
             // int8: token (lane/8 + 8r), 16-byte chunk lane%8 of its 128 bytes; int4: token (lane/4 + 16r), chunk lane%4 of 64
@@ -259,11 +239,13 @@ __global__ __launch_bounds__(256, 2) void decode_attention_i8_mfma_kernel(Decode
             const int off = BITS == 8 ? min(row, last) * 128 + (lane & 7) * 16 : min(row, last) * 64 + (lane & 3) * 16;
             // non-temporal: every cache byte is read ONCE per launch by ONE workgroup -- measured (round 3, call 8;
             // profiles/r03_attention_nontemporal_loads.txt) 32.4 -> 30.3 us at ctx 1040, 43.3 -> 39.5 us at ctx 1536
-            kreg[r]       = __builtin_nontemporal_load((const u32x4*)(base + koff + off));
-            vreg[r]       = __builtin_nontemporal_load((const u32x4*)(base + voff + off));
+            // address space 1 spelled out: a pointer read from the block table is "generic" to the compiler, the loads were FLAT ones
+            // (both counters, waited for with vmcnt(0) lgkmcnt(0)) until round 5
+            kreg[r]       = __builtin_nontemporal_load((const GLOBAL_AS u32x4*)(base + koff + off));
+            vreg[r]       = __builtin_nontemporal_load((const GLOBAL_AS u32x4*)(base + voff + off));
         }
-        kpr = *(const uint32_t*)(base + kpoff + lane * 4);
-        vpr = *(const uint32_t*)(base + vpoff + lane * 4);
+        kpr = *(const GLOBAL_AS uint32_t*)(base + kpoff + lane * 4);
+        vpr = *(const GLOBAL_AS uint32_t*)(base + vpoff + lane * 4);
     };
     auto store_tile = [&]() {
 #pragma unroll
@@ -302,27 +284,28 @@ __global__ __launch_bounds__(256, 2) void decode_attention_i8_mfma_kernel(Decode
     uint32_t   npar        = 0;
     const int  nti         = (ctx - 1) & 63;
     int        tile        = tile_end - 1 - wave;  // newest -> oldest, waves interleaved
+    // pointers of this wave's first and second block (scalar loads; the clamp keeps the address valid when the wave has fewer blocks)
+    auto        in_range = [&](int t) { return min(max(t, tile_begin), tiles - 1); };  // block tiles - 1 always exists (ctx >= 1)
+    const char* ptr_cur  = block_ptr(in_range(tile));
+    const char* ptr_next = block_ptr(in_range(tile - 4));
     if constexpr (FUSED) {
-        const int    pos   = min(ctx - 1, p.max_pos - 1);
-        const int    l16   = lane & 15;
-        const bool   isv   = (lane & 16) != 0;
-        const int    qcol  = (head0 + (hv ? i16 : 0)) * D + wave * 32 + g * 8;
-        const int    kvcol = (p.q_heads + (isv ? L.kv_heads : 0) + kv_head) * D + l16 * 8;
-        const QkvRaw rq    = qkv_issue(p, b, qcol);
-        half8_t      csq{}, csk{};
-        if (p.cos_sin) {
-            csq = *(const half8_t*)((const half_t*)p.cos_sin + (size_t)pos * D + wave * 32 + g * 8);
-        }
-        QkvRaw rk;
-        if (owns_newest) {  // wave-uniform
-            rk = qkv_issue(p, b, kvcol);
-            if (p.cos_sin) {
-                csk = *(const half8_t*)((const half_t*)p.cos_sin + (size_t)pos * D + l16 * 8);
-            }
-        }
-        if (tile >= tile_begin) {
-            load_tile(tile, std::true_type{});
-        }
+        // One fixed order, no branch around a load (round 5): q slice, the new token's K / V slice (every wave loads one, the owner uses
+        // it), the RoPE rows, then the first cache block -- all in flight together, waited for one by one with exact counts.  Before, each
+        // of these waited for the one in front of it (k_len -> pointer window -> qkv slabs -> cache block: four VMEM round trips).
+        const int     pos   = min(ctx - 1, p.max_pos - 1);
+        const int     l16   = lane & 15;
+        const bool    isv   = (lane & 16) != 0;
+        const int     qcol  = (head0 + (hv ? i16 : 0)) * D + wave * 32 + g * 8;
+        const int     kvcol = (p.q_heads + (isv ? L.kv_heads : 0) + kv_head) * D + l16 * 8;
+        // no RoPE table: the rows are read from the (valid, unused) start of the output instead of being skipped
+        const half_t* cs    = p.cos_sin ? (const half_t*)p.cos_sin + (size_t)pos * D : (const half_t*)p.out;
+        const QkvRaw  rq    = qkv_issue(p, b, qcol);
+        const QkvRaw  rk    = qkv_issue(p, b, kvcol);
+        const half8_t csq   = *(const GLOBAL_AS half8_t*)(cs + wave * 32 + g * 8);
+        const half8_t csk   = *(const GLOBAL_AS half8_t*)(cs + l16 * 8);
+        asm volatile("" ::: "memory");  // the scheduler keeps this order
+        load_tile(ptr_cur, tile, std::true_type{});
+        asm volatile("" ::: "memory");
         half8_t t = qkv_finish(p, b, qcol, rq);
         if (p.cos_sin) {
             t = rope8(t, csq);
@@ -367,7 +350,7 @@ __global__ __launch_bounds__(256, 2) void decode_attention_i8_mfma_kernel(Decode
             nq[0] = qv[0] | (qv[1] << 8) | (qv[2] << 16) | (qv[3] << 24);
             nq[1] = qv[4] | (qv[5] << 8) | (qv[6] << 16) | (qv[7] << 24);
             npar  = bit_cast<uint32_t>(half2_t{scale, zero});
-            char* blk = (char*)block_ptr((ctx - 1) >> 6) + p.cache.layer_offset;  // outside the divergent branch (v_readlane)
+            char* blk = (char*)ptr_cur + p.cache.layer_offset;  // the owner's first block IS the newest one
             if (lane < 32) {
                 if constexpr (BITS == 8) {
                     *(u32x2*)(blk + (isv ? L.v_data(kv_head, nti) : L.k_data(kv_head, nti)) + l16 * 8) = nq;
@@ -389,8 +372,15 @@ __global__ __launch_bounds__(256, 2) void decode_attention_i8_mfma_kernel(Decode
         }
     }
     else {
-        if (tile >= tile_begin) {
-            load_tile(tile, std::true_type{});
+        load_tile(ptr_cur, tile, std::true_type{});
+        const half_t* qp = p.q + (size_t)b * p.q_stride + (size_t)(head0 + (hv ? i16 : 0)) * D;
+#pragma unroll
+        for (int dd = 0; dd < 4; ++dd) {
+            half8_t t = *(const half8_t*)(qp + dd * 32 + g * 8);
+            if (!hv) {
+                t = half8_t{};
+            }
+            qf[dd] = t;
         }
     }
 #pragma unroll
@@ -421,7 +411,8 @@ __global__ __launch_bounds__(256, 2) void decode_attention_i8_mfma_kernel(Decode
         }
         const int ntok = min(64, ctx - tile * 64);
         if (tile - 4 >= tile_begin) {
-            load_tile(tile - 4, std::false_type{});  // next block streams in while this one is contracted
+            load_tile(ptr_next, tile - 4, std::false_type{});  // next block streams in while this one is contracted
+            ptr_next = block_ptr(in_range(tile - 8));          // and the pointer of the one after it (scalar load, used next iteration)
         }
 
         // ---- S^T = K q^T on raw codes -----------------------------------------------------------------------
@@ -602,540 +593,6 @@ __global__ __launch_bounds__(256, 2) void decode_attention_i8_mfma_kernel(Decode
 }
 
 
-// ---- two kv heads per workgroup (round 5) ------------------------------------------------------------------------------------------
-// Why: the one-kv-head kernel above deals a (sequence, kv head)'s 64-token blocks to four waves -- 17 blocks at ctx ~ 1.05 k are 5 / 4 / 4 / 4,
-// the launch waits for every workgroup's fifth block (2.7 us, profiles/r05_fixed_cost_by_launch.txt) -- and with 512 workgroups two of
-// them share a CU.  Measured (tools/r05_calls/call12.sh, TM_ATTN_LDS_PAD): ONE workgroup of four waves per CU streams at least as fast per
-// context token (7.2 vs 6.8 TB/s marginal) -- a CU's miss queue is full either way -- while the context-independent part of a launch is
-// smaller with 256 workgroups.  So: a workgroup owns TWO kv heads of a sequence; each wave walks its blocks of head A (newest -> oldest,
-// wave w starts at block T-1-w), then its blocks of head B dealt in the opposite wave order (wave w starts at block T-1-(3-w)): 5+4, 4+4,
-// 4+4, 4+5 at T = 17 -- 8.5 +- 0.5 blocks per wave instead of 4.25 +- 0.75 -- with the first block of head B in flight under the last
-// block of head A (no second prologue, no barrier between the heads).  Per-head state (q fragments, O, m, l) lives in the wave one head
-// at a time; a wave parks its partial (O, m, l) of head A in its own LDS region when it turns to head B; ONE barrier at the end, then the
-// 4-wave merge of both heads.  Fused prologue: every wave builds its 32-channel slice of q for BOTH heads (one LDS exchange, one
-// barrier); the new token's K / V of head A are quantised, stored and patched by wave 0 (owner of A's newest block), those of head B by
-// wave 3.  Arithmetic per block is the one-head kernel's, op for op: the cache bytes are bit-identical, head A's outputs too (same blocks on
-// the same waves, same merge order); head B's differ from the one-head kernel's in the ORDER of fp32 sums only (its blocks sit on the
-// mirrored waves) -- the parity tests hold both kernels to the same bounds against the oracle.
-// Requires: an even number of kv heads, the whole GQA group in one workgroup (<= 16 q heads per kv head), no split-KV.
-#define GLOBAL_AS __attribute__((address_space(1)))
-constexpr int kPairLds = 4 * kWaveLds + 2 * 4096 + 2 * (4 * 16 * 128 * 4) + 2 * (4 * 16 * 2 * 4);
-
-template<bool FUSED, int BITS>
-__global__ __launch_bounds__(256, 1) void decode_attention_i8_mfma_pair_kernel(DecodeAttnParams p, int hpw)
-{
-    static_assert(BITS == 8 || BITS == 4, "int8 / int4 KV");
-    constexpr int D = 128;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    asm volatile("" ::"s"(p.q), "s"(p.q_stride), "s"(p.out), "s"(p.k_len), "s"(p.batch), "s"(p.q_heads), "s"(p.scale_log2),
-                 "s"(p.cache.block_ptrs), "s"(p.cache.cu_block_nums), "s"(p.cache.block_stride), "s"(p.cache.layer_offset),
-                 "s"(p.cache.layout.kv_heads), "s"(p.cache.layout.head_dim), "s"(p.cache.layout.block_len), "s"(p.cache.layout.bits));
-    asm volatile("" ::"s"(p.qkv_slabs), "s"(p.qkv_f16), "s"(p.qkv_splits), "s"(p.qkv_n), "s"(p.cos_sin), "s"(p.max_pos), "s"(p.dbg), "s"(hpw));
-    const KvLayout L = p.cache.layout;
-
-    const int pair  = blockIdx.x;  // kv heads 2 pair, 2 pair + 1
-    const int b     = blockIdx.y;
-    const int group = p.q_heads / L.kv_heads;  // == hpw: the whole group sits in this workgroup
-
-    const int wgid = blockIdx.y * gridDim.x + blockIdx.x;
-    if (p.dbg && threadIdx.x == 0) {
-        p.dbg[wgid * 8 + 0] = __builtin_amdgcn_s_memrealtime();
-        p.dbg[wgid * 8 + 4] = ((uint64_t)__builtin_amdgcn_s_getreg(20 | (31 << 11)) << 32) | (uint32_t)__builtin_amdgcn_s_getreg(4 | (31 << 11));
-    }
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int i16  = lane & 15;
-    const int g    = lane >> 4;
-
-    char*  Kt    = smem + wave * kWaveLds;
-    char*  Vt    = Kt + 8192;
-    char*  Pm    = Kt + 16384;
-    char*  qx    = smem + 4 * kWaveLds;                                  // [2 heads][4 slices][64 lanes][16 B]
-    float* sm_o  = (float*)(smem + 4 * kWaveLds + 2 * 4096);             // [2 heads][4 waves][16][128]
-    float* sm_ml = sm_o + 2 * 4 * 16 * D;                                // [2 heads][4 waves][16][2]
-
-    const int       bstride = p.cache.block_stride;
-    const uint64_t* blocks  = p.cache.block_ptrs + (bstride > 0 ? (size_t)b * bstride : (size_t)p.cache.cu_block_nums[b]);
-    // A block's pointer is a SCALAR load from the (read-only during the launch) block table, constant address space spelled out.  A
-    // vector load here -- what the compiler makes of a plain blocks[tile], and what the one-head kernel's pointer window re-fetch is --
-    // is the newest VMEM operation in flight when its result is needed: waiting for it is vmcnt(0), i.e. for every cache block in
-    // flight, and the second block per wave is lost (seen in the ISA, round 5).
-    auto block_ptr = [&](int tile) -> const char* {  // tile: wave-uniform
-        const int ut = __builtin_amdgcn_readfirstlane(tile);
-        return (const char*)*(const __attribute__((address_space(4))) uint64_t*)(blocks + ut);
-    };
-
-    const int ctx   = *(const __attribute__((address_space(4))) int*)(p.k_len + b);  // scalar load: no VMEM round trip in front of the blocks
-    const int tiles = (ctx + 63) >> 6;
-    // first block of this wave in pass ps (head A: ps = 0, head B: ps = 1); then every fourth one down to block 0
-    auto first_tile = [&](int ps) { return tiles - 1 - (ps ? 3 - wave : wave); };
-
-    half8_t    qf[4];
-    float      q1 = 0.f;
-    const bool hv = i16 < hpw;
-    floatx4    O[8];
-    float      m = -INFINITY, lsum = 0.f, zacc = 0.f;
-    const float sc = p.scale_log2;
-
-    constexpr int NR = BITS == 8 ? 8 : 4;
-    // TWO blocks in flight per wave (register sets R0 / R1, used alternately): with one workgroup per CU a single block per wave leaves
-    // 64 KB in flight per CU and the launch latency-bound (measured: 38.2 us against the one-head kernel's 34.8 at ctx 1040)
-    struct TileRegs {
-        u32x4    k[NR], v[NR];
-        uint32_t kp, vp;
-    };
-    TileRegs R0 = {}, R1 = {};
-    // EVERY call issues the same 2 NR + 2 loads, no branch: s_waitcnt counts are static, and only with one fixed number of loads per step
-    // can the compiler wait for ONE of the two blocks in flight (vmcnt(2 NR + 2 + ...)) instead of vmcnt(0).  A wave that has run out of
-    // items (tile < 0) re-reads row 0 of the sequence's block 0 with every lane -- one cache line per instruction, never consumed.
-    auto load_tile = [&](TileRegs& R, int ps, int tile) {
-        const int   kvh  = 2 * pair + ps;
-        const char* base = block_ptr(max(tile, 0)) + p.cache.layer_offset;
-        const int   last = tile < 0 ? 0 : min(63, ctx - tile * 64 - 1);  // rows past the context re-read the last valid one (masked below)
-        const int   koff = L.k_data(kvh, 0), voff = L.v_data(kvh, 0);
-        asm volatile("" ::: "memory");
-#pragma unroll
-        for (int r = 0; r < NR; ++r) {
-            const int row = BITS == 8 ? (lane >> 3) + 8 * r : (lane >> 2) + 16 * r;
-            const int off = BITS == 8 ? min(row, last) * 128 + (lane & 7) * 16 : min(row, last) * 64 + (lane & 3) * 16;
-            // address space 1 spelled out: a pointer read from the block table is "generic" to the compiler, the loads become FLAT ones,
-            // and a FLAT load can only be waited for with vmcnt(0) -- which serialises the two blocks in flight (seen in the ISA)
-            R.k[r]        = __builtin_nontemporal_load((const GLOBAL_AS u32x4*)(base + koff + off));
-            R.v[r]        = __builtin_nontemporal_load((const GLOBAL_AS u32x4*)(base + voff + off));
-        }
-        R.kp = *(const GLOBAL_AS uint32_t*)(base + L.k_param(kvh, 0) + lane * 4);
-        R.vp = *(const GLOBAL_AS uint32_t*)(base + L.v_param(kvh, 0) + lane * 4);
-        asm volatile("" ::: "memory");  // a set's loads stay together, in this order: the scheduler must not interleave two sets
-    };
-    auto store_tile = [&](const TileRegs& R) {
-#pragma unroll
-        for (int r = 0; r < NR; ++r) {
-            if constexpr (BITS == 8) {
-                const int t   = (lane >> 3) + 8 * r;
-                const int pos = t * 128 + (((lane & 7) ^ ((t >> 1) & 7)) << 4);
-                *(u32x4*)(Kt + pos) = R.k[r];
-                *(u32x4*)(Vt + pos) = R.v[r];
-            }
-            else {
-                const int t  = (lane >> 2) + 16 * r;
-                const int c  = (lane & 3) * 2;
-                const int sw = (t >> 1) & 7;
-                u32x4     a, bb;
-                expand_u4x32(R.k[r], a, bb);
-                *(u32x4*)(Kt + t * 128 + ((c ^ sw) << 4))       = a;
-                *(u32x4*)(Kt + t * 128 + (((c + 1) ^ sw) << 4)) = bb;
-                expand_u4x32(R.v[r], a, bb);
-                *(u32x4*)(Vt + t * 128 + ((c ^ sw) << 4))       = a;
-                *(u32x4*)(Vt + t * 128 + (((c + 1) ^ sw) << 4)) = bb;
-            }
-        }
-        *(u32x2*)(Pm + lane * 8) = u32x2{R.kp, R.vp};
-    };
-
-    // ---- prologue ---------------------------------------------------------------------------------------------------------------------
-    // this wave's items (head, block) in order; advance() steps to the following one (block < 0: none left)
-    auto advance = [&](int& ps_, int& t_) {
-        if (t_ < 0) {
-            return;
-        }
-        t_ -= 4;
-        if (t_ < 0 && ps_ == 0) {  // head A done: on to head B
-            ps_ = 1;
-            t_  = first_tile(1);
-        }
-    };
-    int ps0 = 0, t0 = first_tile(0);
-    if (t0 < 0) {
-        ps0 = 1;
-        t0  = first_tile(1);
-    }
-    int ps1 = ps0, t1 = t0;
-    advance(ps1, t1);
-    // owner of a head's newest block: wave 0 for head A, wave 3 for head B (tiles >= 1: both own one)
-    const bool owner    = FUSED && (wave == 0 || wave == 3);
-    const int  owner_ps = wave == 0 ? 0 : 1;
-    u32x2      nq       = {0u, 0u};
-    uint32_t   npar     = 0;
-    const int  nti      = (ctx - 1) & 63;
-    if constexpr (FUSED) {
-        // Branch-free, in one fixed order (static s_waitcnt counts, see load_tile): q slices of both heads, the new token's K / V slice
-        // (every wave loads one; only the two owners use it), the RoPE rows, THEN the first two cache blocks -- whose loads are in flight
-        // while q is summed, rotated and exchanged.  With the kernel's inputs as the compiler sees them in the one-head kernel (branches
-        // around loads, pointers of unknown address space) each of these steps waited for the one before: four dependent memory round
-        // trips in front of the first block (seen in the ISA, round 5).
-        const int pos = min(ctx - 1, p.max_pos - 1);
-        const int l16 = lane & 15;
-        const bool isv = (lane & 16) != 0;
-        const bool f16in = p.qkv_splits == 0;
-        auto issue = [&](int col) {
-            QkvRaw       r;
-            const char*  base = f16in ? (const char*)(p.qkv_f16 + (size_t)b * p.qkv_n + col) : (const char*)(p.qkv_slabs + (size_t)b * p.qkv_n + col);
-            const size_t slab = f16in ? 0 : (size_t)p.batch * p.qkv_n * 4;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const char* src = base + (size_t)min(j, max(p.qkv_splits - 1, 0)) * slab;
-                r.a0[j]         = *(const GLOBAL_AS floatx4*)src;
-                r.a1[j]         = *(const GLOBAL_AS floatx4*)(src + (f16in ? 0 : 16));
-            }
-            return r;
-        };
-        auto finish = [&](const QkvRaw& r) {  // the launcher sends deeper split-K than 4 to the one-head kernel
-            float acc[8] = {};
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {  // in slab order: bit-identical to splitk_reduce_kernel
-                if (j < p.qkv_splits) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        acc[e] += r.a0[j][e];
-                        acc[4 + e] += r.a1[j][e];
-                    }
-                }
-            }
-            half8_t o;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                o[e] = (half_t)acc[e];
-            }
-            const half8_t direct = bit_cast<half8_t>(r.a0[0]);
-            return f16in ? direct : o;
-        };
-        // no RoPE table: the rows are read from the (valid, unused) start of the output instead of being skipped
-        const half_t* cs = p.cos_sin ? (const half_t*)p.cos_sin + (size_t)pos * D : (const half_t*)p.out;
-        int           qcol[2];
-        QkvRaw        rq[2];
-#pragma unroll
-        for (int h2 = 0; h2 < 2; ++h2) {
-            qcol[h2] = ((2 * pair + h2) * group + (hv ? i16 : 0)) * D + wave * 32 + g * 8;
-            rq[h2]   = issue(qcol[h2]);
-        }
-        const int     kvcol = (p.q_heads + (isv ? L.kv_heads : 0) + 2 * pair + owner_ps) * D + l16 * 8;
-        const QkvRaw  rk    = issue(kvcol);
-        const half8_t csq   = *(const GLOBAL_AS half8_t*)(cs + wave * 32 + g * 8);
-        const half8_t csk   = *(const GLOBAL_AS half8_t*)(cs + l16 * 8);
-        load_tile(R0, ps0, t0);
-        load_tile(R1, ps1, t1);
-#pragma unroll
-        for (int h2 = 0; h2 < 2; ++h2) {
-            half8_t t = finish(rq[h2]);
-            if (p.cos_sin) {
-                t = rope8(t, csq);
-            }
-            if (!hv) {
-                t = half8_t{};
-            }
-            *(half8_t*)(qx + h2 * 4096 + (wave * 64 + lane) * 16) = t;
-        }
-        if (owner) {
-            const int kvh = 2 * pair + owner_ps;
-            half8_t   x   = finish(rk);
-            if (!isv && p.cos_sin) {
-                x = rope8(x, csk);
-            }
-            float mx = -INFINITY, mnn = -INFINITY;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                mx  = fmaxf(mx, (float)x[e]);
-                mnn = fmaxf(mnn, -(float)x[e]);
-            }
-            mx  = fmaxf(mx, dpp_f32<DPP_XOR1>(mx));
-            mx  = fmaxf(mx, dpp_f32<DPP_XOR2>(mx));
-            mx  = fmaxf(mx, dpp_f32<DPP_HMIRR>(mx));
-            mx  = fmaxf(mx, dpp_f32<DPP_ROR8>(mx));
-            mnn = fmaxf(mnn, dpp_f32<DPP_XOR1>(mnn));
-            mnn = fmaxf(mnn, dpp_f32<DPP_XOR2>(mnn));
-            mnn = fmaxf(mnn, dpp_f32<DPP_HMIRR>(mnn));
-            mnn = fmaxf(mnn, dpp_f32<DPP_ROR8>(mnn));
-            const float  mn    = -mnn;
-            const half_t scale = (half_t)((mx - mn) * (1.0f / (float)((1 << BITS) - 1)));
-            const half_t zero  = (half_t)mn;
-            const half_t inv   = (half_t)(1.0f / (float)scale);
-            uint32_t     qv[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const half_t d = x[e] - zero;
-                const half_t y = d * inv;
-                float        r = __builtin_rintf((float)y);
-                r              = (r == r) ? r : 0.0f;
-                r              = fminf(fmaxf(r, 0.0f), BITS == 8 ? 255.0f : 15.0f);
-                qv[e]          = (uint32_t)r;
-            }
-            nq[0] = qv[0] | (qv[1] << 8) | (qv[2] << 16) | (qv[3] << 24);
-            nq[1] = qv[4] | (qv[5] << 8) | (qv[6] << 16) | (qv[7] << 24);
-            npar  = bit_cast<uint32_t>(half2_t{scale, zero});
-            char* blk = (char*)block_ptr((ctx - 1) >> 6) + p.cache.layer_offset;
-            if (lane < 32) {
-                if constexpr (BITS == 8) {
-                    *(u32x2*)(blk + (isv ? L.v_data(kvh, nti) : L.k_data(kvh, nti)) + l16 * 8) = nq;
-                }
-                else {
-                    const uint32_t w4 = qv[0] | (qv[2] << 4) | (qv[4] << 8) | (qv[6] << 12) | (qv[1] << 16) | (qv[3] << 20) | (qv[5] << 24)
-                                        | (qv[7] << 28);
-                    *(uint32_t*)(blk + (isv ? L.v_data(kvh, nti) : L.k_data(kvh, nti)) + l16 * 4) = w4;
-                }
-                if (l16 == 0) {
-                    *(uint32_t*)(blk + (isv ? L.v_param(kvh, nti) : L.k_param(kvh, nti))) = npar;
-                }
-            }
-        }
-    }
-    else {
-        load_tile(R0, ps0, t0);
-        load_tile(R1, ps1, t1);
-        // q slices of both heads through the same LDS exchange: wave w brings the 32-channel slice w
-#pragma unroll
-        for (int h2 = 0; h2 < 2; ++h2) {
-            const half_t* qp = p.q + (size_t)b * p.q_stride + (size_t)((2 * pair + h2) * group + (hv ? i16 : 0)) * D;
-            half8_t       t  = *(const half8_t*)(qp + wave * 32 + g * 8);
-            if (!hv) {
-                t = half8_t{};
-            }
-            *(half8_t*)(qx + h2 * 4096 + (wave * 64 + lane) * 16) = t;
-        }
-    }
-    __syncthreads();
-    if (p.dbg && threadIdx.x == 0) {
-        p.dbg[wgid * 8 + 1] = __builtin_amdgcn_s_memrealtime();
-    }
-
-    // a head's state is live in the wave one head at a time
-    auto begin_head = [&](int h2) {
-        q1 = 0.f;
-#pragma unroll
-        for (int dd = 0; dd < 4; ++dd) {
-            qf[dd] = *(const half8_t*)(qx + h2 * 4096 + (dd * 64 + lane) * 16);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                q1 += (float)qf[dd][e];
-            }
-        }
-        q1 += __shfl_xor(q1, 16);
-        q1 += __shfl_xor(q1, 32);
-#pragma unroll
-        for (int dt = 0; dt < 8; ++dt) {
-            O[dt] = floatx4{0.f, 0.f, 0.f, 0.f};
-        }
-        m = -INFINITY, lsum = 0.f, zacc = 0.f;
-    };
-    // park this wave's partial of head h2 in ITS region (no barrier: nobody else touches it before the final one)
-    auto park_head = [&](int h2) {
-        float ls = lsum, za_all = zacc;
-        ls += __shfl_xor(ls, 16);
-        ls += __shfl_xor(ls, 32);
-        za_all += __shfl_xor(za_all, 16);
-        za_all += __shfl_xor(za_all, 32);
-        float* so = sm_o + (size_t)h2 * 4 * 16 * D;
-        float* sl = sm_ml + h2 * 4 * 16 * 2;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int   h  = 4 * g + r;
-            const float za = __shfl(za_all, h);
-            if (h < hpw) {
-#pragma unroll
-                for (int dt = 0; dt < 8; ++dt) {
-                    so[(wave * 16 + h) * D + dt * 16 + i16] = __builtin_fmaf(O[dt][r], kTwo24, za);
-                }
-            }
-        }
-        if (g == 0 && i16 < hpw) {
-            sl[(wave * 16 + i16) * 2]     = m;
-            sl[(wave * 16 + i16) * 2 + 1] = ls;
-        }
-    };
-
-    int live = -1;  // head whose state is in the registers
-    // one block: R holds it (loaded two items ago); (nps, nt) is the item two ahead, loaded into R as soon as R is in LDS
-    // NO path through a step skips its loads or its LDS stores (an item-less step -- tile < 0, at most one at the end of a wave's list --
-    // stores the never-consumed dummy rows and returns before the arithmetic): the loop is "R0 step, R1 step" without a break in between,
-    // so that on every path R0's blocks are older than R1's and the waits are vmcnt(2 NR + 2 + ...), not vmcnt(0).
-    auto step = [&](TileRegs& R, int ps, int tile, int nps, int nt) {
-        if (tile >= 0 && ps != live) {  // wave-uniform
-            if (live >= 0) {
-                park_head(live);
-            }
-            else if (ps == 1) {  // no block of head A for this wave
-                begin_head(0);
-                park_head(0);
-            }
-            begin_head(ps);
-            live = ps;
-        }
-        store_tile(R);  // wave-private LDS: in-order DS pipeline, no barrier needed
-        if (FUSED && owner && ps == owner_ps && tile == tiles - 1) {  // wave-uniform: the new token's codes -> LDS image
-            if (lane < 32) {
-                const int l16 = lane & 15;
-                char*     img = lane >= 16 ? Vt : Kt;
-                *(u32x2*)(img + nti * 128 + ((((l16 >> 1) ^ ((nti >> 1) & 7))) << 4) + (l16 & 1) * 8) = nq;
-                if (l16 == 0) {
-                    *(uint32_t*)(Pm + nti * 8 + (lane >= 16 ? 4 : 0)) = npar;
-                }
-            }
-        }
-        const int ntok = min(64, ctx - tile * 64);
-        load_tile(R, nps, nt);  // head B's first blocks stream in under head A's last ones
-        if (tile < 0) {
-            return;
-        }
-
-        // ---- S^T = K q^T on raw codes -----------------------------------------------------------------------
-        floatx4 S[4];
-#pragma unroll
-        for (int tt = 0; tt < 4; ++tt) {
-            S[tt]       = floatx4{0.f, 0.f, 0.f, 0.f};
-            const int t = 16 * tt + i16;
-#pragma unroll
-            for (int dd = 0; dd < 4; ++dd) {
-                const int   u   = 4 * dd + g;
-                const int   off = t * 128 + ((((u >> 1) ^ ((t >> 1) & 7))) << 4) + (u & 1) * 8;
-                const u32x2 kb  = *(const u32x2*)(Kt + off);
-                const half8_t a = bytes8_to_f16_subnormal(kb);
-                S[tt]           = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, qf[dd], S[tt], 0, 0, 0);
-            }
-        }
-        uint32_t kp[4][4], vp[4][4];
-#pragma unroll
-        for (int tt = 0; tt < 4; ++tt) {
-            const u32x4 pa_ = *(const u32x4*)(Pm + (16 * tt + 4 * g) * 8);
-            const u32x4 pb_ = *(const u32x4*)(Pm + (16 * tt + 4 * g) * 8 + 16);
-            kp[tt][0] = pa_[0], kp[tt][1] = pa_[2], kp[tt][2] = pb_[0], kp[tt][3] = pb_[2];
-            vp[tt][0] = pa_[1], vp[tt][1] = pa_[3], vp[tt][2] = pb_[1], vp[tt][3] = pb_[3];
-        }
-        const bool partial = ntok < 64;
-        float sv[4][4];
-#pragma unroll
-        for (int tt = 0; tt < 4; ++tt) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const half2_t kk = bit_cast<half2_t>(kp[tt][r]);
-                sv[tt][r]        = __builtin_fmaf((float)kk[0] * kTwo24, S[tt][r], (float)kk[1] * q1);
-            }
-        }
-        if (partial) {
-#pragma unroll
-            for (int tt = 0; tt < 4; ++tt) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    if (16 * tt + 4 * g + r >= ntok) {
-                        sv[tt][r] = -INFINITY;
-                        vp[tt][r] = 0u;
-                    }
-                }
-            }
-        }
-        float tmax = -INFINITY;
-#pragma unroll
-        for (int tt = 0; tt < 4; ++tt) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                tmax = fmaxf(tmax, sv[tt][r]);
-            }
-        }
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 16));
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
-        const float mnew  = fmaxf(m, tmax);
-        const float alpha = (m == -INFINITY) ? 0.f : fast_exp2((m - mnew) * sc);
-        if (__builtin_amdgcn_readfirstlane((int)__any(mnew != m))) {
-            lsum *= alpha;
-            zacc *= alpha;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float ar = __shfl(alpha, 4 * g + r);
-#pragma unroll
-                for (int dt = 0; dt < 8; ++dt) {
-                    O[dt][r] *= ar;
-                }
-            }
-        }
-        m = mnew;
-        const float msc = mnew * sc;
-        half8_t pa[2];
-#pragma unroll
-        for (int tt = 0; tt < 4; ++tt) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const half2_t vv = bit_cast<half2_t>(vp[tt][r]);
-                const float   pf = fast_exp2(__builtin_fmaf(sv[tt][r], sc, -msc));
-                lsum += pf;
-                zacc            = __builtin_fmaf(pf, (float)vv[1], zacc);
-                pa[tt >> 1][(tt & 1) * 4 + r] = (half_t)(pf * (float)vv[0]);
-            }
-        }
-#pragma unroll
-        for (int a = 0; a < 2; ++a) {
-            const int j = i16 >> 1;
-            const int T = 32 * a + (j < 4 ? 4 * g + j : 16 + 4 * g + (j - 4));
-            const char* vrow = Vt + T * 128 + (i16 & 1) * 8;
-            const int   swz  = (T >> 1) & 7;
-#pragma unroll
-            for (int dt = 0; dt < 8; ++dt) {
-                const v2i vb = __builtin_amdgcn_ds_read_tr8_b64_v2i32(
-                    (__attribute__((address_space(3))) v2i*)(vrow + ((dt ^ swz) << 4)));
-                const half8_t bq = bytes8_to_f16_subnormal(u32x2{(uint32_t)vb[0], (uint32_t)vb[1]});
-                O[dt]            = __builtin_amdgcn_mfma_f32_16x16x32_f16(pa[a], bq, O[dt], 0, 0, 0);
-            }
-        }
-    };
-    // Everything the prologue left in flight (first two blocks, conditional loads, the new token's stores) is waited for HERE, once: the
-    // compiler's counting then starts the loop from a clean slate.  Without it the prologue's stores and branch-dependent loads stay
-    // "possibly pending" on the loop's entry edge for ever, and every wait inside the loop is a vmcnt(0) (seen in the ISA).
-    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), nothing else
-    while (t0 >= 0) {  // R0 holds item 0, R1 item 1; every step reloads its register set with the item two ahead
-        int ps2 = ps1, t2 = t1;
-        advance(ps2, t2);
-        step(R0, ps0, t0, ps2, t2);
-        int ps3 = ps2, t3 = t2;
-        advance(ps3, t3);
-        step(R1, ps1, t1, ps3, t3);
-        ps0 = ps2, t0 = t2, ps1 = ps3, t1 = t3;
-    }
-    if (p.dbg && lane == 0 && wave != 2) {
-        p.dbg[wgid * 8 + (wave == 0 ? 2 : wave == 1 ? 6 : 7)] = __builtin_amdgcn_s_memrealtime();
-    }
-    // whatever is live goes to its region; heads this wave never touched park an empty partial (m = -inf)
-    if (live < 0) {
-        begin_head(0);
-        park_head(0);
-        park_head(1);
-    }
-    else if (live == 0) {
-        park_head(0);
-        begin_head(1);
-        park_head(1);
-    }
-    else {
-        park_head(1);
-    }
-    __syncthreads();
-    if (p.dbg && threadIdx.x == 0) {
-        p.dbg[wgid * 8 + 5] = __builtin_amdgcn_s_memrealtime();
-    }
-    for (int idx = threadIdx.x; idx < 2 * hpw * D; idx += 256) {
-        const int h2 = idx / (hpw * D);
-        const int hd = idx - h2 * hpw * D;
-        const int h  = hd / D;
-        const int d  = hd - h * D;
-        const float* so = sm_o + (size_t)h2 * 4 * 16 * D;
-        const float* sl = sm_ml + h2 * 4 * 16 * 2;
-        float        ms = -INFINITY;
-#pragma unroll
-        for (int w = 0; w < 4; ++w) {
-            ms = fmaxf(ms, sl[(w * 16 + h) * 2]);
-        }
-        float o = 0.f, l = 0.f;
-#pragma unroll
-        for (int w = 0; w < 4; ++w) {
-            const float mw = sl[(w * 16 + h) * 2];
-            const float wt = (mw == -INFINITY) ? 0.f : fast_exp2((mw - ms) * sc);
-            o += wt * so[(w * 16 + h) * D + d];
-            l += wt * sl[(w * 16 + h) * 2 + 1];
-        }
-        p.out[(size_t)b * p.q_heads * D + (size_t)((2 * pair + h2) * group + h) * D + d] = (half_t)(o / l);
-    }
-    if (p.dbg && threadIdx.x == 0) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        p.dbg[wgid * 8 + 3] = __builtin_amdgcn_s_memrealtime();
-    }
-}
-
 int launch_decode_attention_i8_mfma(const DecodeAttnParams& p_in, hipStream_t st)
 {
     DecodeAttnParams p     = p_in;
@@ -1149,45 +606,10 @@ int launch_decode_attention_i8_mfma(const DecodeAttnParams& p_in, hipStream_t st
         hpw /= d;
     }
     const int chunks = group / hpw;
-    // TM_ATTN_PAIR: 0 (default) = never, 1 = when the pairs alone fill the chip (>= one workgroup per CU), 2 = whenever the shape allows
-    // (parity tests).  Read per call: a launch inside a captured graph is recorded once, an eager one costs a getenv.
-    // OFF by default -- measured slower (round 5, profiles/r05_attention_pair_kernel.txt): 38.2 / 41.4 us (one / two blocks in flight
-    // per wave) against 34.4 us at ctx 1040; four waves per CU issue the per-block arithmetic more slowly than eight.
-    const char* const pair_env = getenv("TM_ATTN_PAIR");
-    const int         pair_on  = pair_env ? atoi(pair_env) : 0;
-    const bool        pair_fit = chunks == 1 && p.splits == 1 && p.cache.layout.kv_heads % 2 == 0 && p.qkv_splits <= 4;
-    if (pair_fit && (pair_on == 2 || (pair_on == 1 && (size_t)(p.cache.layout.kv_heads / 2) * p.batch >= (size_t)256))) {  // 256 CUs
-        // two kv heads per workgroup: 8.5 +- 0.5 blocks per wave instead of 4.25 +- 0.75, one workgroup per CU (see the kernel)
-        dim3 grid2(p.cache.layout.kv_heads / 2, p.batch, 1);
-        p.dbg = gemm_trace_for((size_t)grid2.x * grid2.y, "attn", grid2.x, grid2.y, 1);
-        const bool fused = p.qkv_slabs || p.qkv_f16;
-        TM_REQUIRE(!fused || (p.qkv_n % 8 == 0 && (p.qkv_splits == 0) == (p.qkv_slabs == nullptr)), "fused qkv input");
-        const void* const k2 = fused ? (p.cache.layout.bits == 4 ? (const void*)decode_attention_i8_mfma_pair_kernel<true, 4> :
-                                                                    (const void*)decode_attention_i8_mfma_pair_kernel<true, 8>) :
-                                       (p.cache.layout.bits == 4 ? (const void*)decode_attention_i8_mfma_pair_kernel<false, 4> :
-                                                                    (const void*)decode_attention_i8_mfma_pair_kernel<false, 8>);
-        if (const int rc = ensure_dynamic_lds(k2, kPairLds)) {
-            return rc;
-        }
-        if (fused) {
-            if (p.cache.layout.bits == 4) {
-                decode_attention_i8_mfma_pair_kernel<true, 4><<<grid2, 256, kPairLds, st>>>(p, hpw);
-            }
-            else {
-                decode_attention_i8_mfma_pair_kernel<true, 8><<<grid2, 256, kPairLds, st>>>(p, hpw);
-            }
-        }
-        else {
-            if (p.cache.layout.bits == 4) {
-                decode_attention_i8_mfma_pair_kernel<false, 4><<<grid2, 256, kPairLds, st>>>(p, hpw);
-            }
-            else {
-                decode_attention_i8_mfma_pair_kernel<false, 8><<<grid2, 256, kPairLds, st>>>(p, hpw);
-            }
-        }
-        TM_HIP_CHECK(hipGetLastError());
-        return 0;
-    }
+    // A variant with TWO kv heads per workgroup (one workgroup per CU, 9 / 8 / 8 / 9 blocks per wave instead of 5 / 4 / 4 / 4, one or two
+    // blocks in flight per wave) was built and measured in round 5 and is in the history (commit eff45b9): parity-green, 38.2-41.4 us
+    // against this kernel's 34.4 at ctx 1040 -- four waves per CU issue the per-block arithmetic more slowly than eight
+    // (profiles/r05_attention_pair_kernel.txt).
     dim3      grid(p.cache.layout.kv_heads * chunks, p.batch, p.splits);
     p.dbg = gemm_trace_for((size_t)grid.x * grid.y * grid.z, "attn", grid.x, grid.y, grid.z);
     // 4 wave-private images (+ 4 KB q exchange for the fused prologue); the merge buffers overlay the images

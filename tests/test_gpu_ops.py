@@ -225,11 +225,7 @@ def _fill_cache(rng, L, klen, layer, spike=False):
     (8, 1, [257], 4), (2, 2, [31], 1), (12, 4, [513, 64], 16), (32, 8, [1000, 37, 1089, 4], 1), (16, 4, [513, 64, 129], 1),
     (32, 2, [255, 256, 257], 1),
 ])
-@pytest.mark.parametrize('pair', [0, 2])
-def test_decode_attention(tm, cuda, monkeypatch, bits, Hq, Hkv, klen, splits, pair):
-    """pair = 2 forces the two-kv-heads-per-workgroup kernel wherever its shape rule allows (even kv heads, no split-KV, group <= 16);
-    pair = 0 pins the one-head kernel.  Both are held to the same bounds against the oracle."""
-    monkeypatch.setenv('TM_ATTN_PAIR', str(pair))
+def test_decode_attention(tm, cuda, bits, Hq, Hkv, klen, splits):
     rng = np.random.default_rng(bits + Hq + sum(klen) + splits)
     layer = 1
     L = o.BlockLayout(2, Hkv, 128, 64, bits)
@@ -259,13 +255,11 @@ def test_decode_attention(tm, cuda, monkeypatch, bits, Hq, Hkv, klen, splits, pa
 
 
 @pytest.mark.parametrize('bits', [8, 4])
-@pytest.mark.parametrize('pair', [0, 2])
-def test_decode_attention_rectangular_block_table(tm, cuda, monkeypatch, bits, pair):
+def test_decode_attention_rectangular_block_table(tm, cuda, bits):
     """The engine's block table is rectangular (sequence b at b * stride): the MFMA decode kernel then keeps a sequence's
     block pointers in one register (v_readlane per block) instead of loading offset -> pointer in front of every block.
     Same bits as the ragged-table path (which the tests above pin on the oracle): plain and fused kernels, split-KV,
     contexts of more than 64 blocks (pointer window re-fetch), cache bytes written by the fused prologue."""
-    monkeypatch.setenv('TM_ATTN_PAIR', str(pair))
     rng = np.random.default_rng(bits)
     Hq, Hkv = 8, 2
     klen = [4200, 1, 64, 65, 4097, 700, 8190]
@@ -317,12 +311,10 @@ def test_decode_attention_rectangular_block_table(tm, cuda, monkeypatch, bits, p
     (32, 8, [1000, 37, 128, 129, 1089], 1, 4, True), (64, 8, [77, 192, 1], 1, 0, True), (16, 2, [320, 2, 65], 1, 2, False),
 ])
 @pytest.mark.parametrize('bits', [8, 4])
-@pytest.mark.parametrize('pair', [0, 2])
-def test_decode_attention_fused_prologue(tm, cuda, monkeypatch, bits, Hq, Hkv, klen, splits, qkv_splits, rope, pair):
+def test_decode_attention_fused_prologue(tm, cuda, bits, Hq, Hkv, klen, splits, qkv_splits, rope):
     """Fused decode prologue (RoPE + K/V quantise-store inside the attention kernel) == kv_rope_store followed by
     decode attention: cache bytes bit-exact against the oracle's process_kv, output bit-identical to the unfused
     device sequence (same q bits, same cache bits, same kernel arithmetic)."""
-    monkeypatch.setenv('TM_ATTN_PAIR', str(pair))
     rng = np.random.default_rng(Hq + sum(klen) + splits + qkv_splits)
     layer = 1
     L = o.BlockLayout(2, Hkv, 128, 64, bits)
