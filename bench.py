@@ -370,6 +370,7 @@ def main():
     dog.arm('timed decode steps', 300 + K)
     t0 = time.perf_counter()
     eng.decode(K)                       # exactly K steps
+    dt_enqueue = time.perf_counter() - t0   # host time to enqueue the K graph replays (the call returns without a device sync)
     barrier()
     dt = time.perf_counter() - t0
     dog.arm('after the timed region', 1800)
@@ -451,6 +452,8 @@ def main():
                                         if tuned else 'heuristic',
                        'gemm_tilings': tilings, 'lm_head_tiling': head_tiling, 'prefill_rows': pf_rows,
                        'prefill_gemm_tilings': prefill_tilings},
+            # host side of the timed region: the K hipGraphLaunch calls return long before the device is done when the step is device-bound
+            'host_enqueue_ms_per_step': round(dt_enqueue / K * 1e3, 4),
             'ttft_p50_ms': round(float(np.median(ttft)), 2), 'prefill_total_s': round(prefill_s, 3),
             'prefill_tokens_per_s': round(B * S / prefill_s, 1),
             'step_roofline': {'bound': 'hbm', 'algorithmic_bytes_per_step': int(step_bytes),
