@@ -1,6 +1,6 @@
-// Split-K paged flash-decode for int8 KV on the matrix cores (gfx950) -- the kernel the headline metric runs.
+// Split-K paged flash-decode for int8 / int4 KV on the matrix cores (gfx950) -- the kernel the headline metric runs.
 //
-// Same contract as attention_decode.hip (which stays the path for int4 / fp16 KV): replaces dispatchDecoding +
+// Same contract as attention_decode.hip (which stays the path for fp16 KV): replaces dispatchDecoding +
 // invokeReduceV3 (src/turbomind/kernels/attention/decoding.cu:12-39, attention_universal.h:355-553,
 // impl_81616.h:313-349,510-591, reduce.cu:13-226).
 //
@@ -18,8 +18,9 @@
 // (no per-element fp16 rounding of k^ / v^): results agree with it to ~1e-3 relative, inside the stated tolerance
 // (reference Compare thresholds rtol 1e-2 / atol 1e-4, kernels/attention/test_utils.h:12-14).
 //
-// Data path per wave and 64-token cache block: 16 coalesced 16-B global loads (8 whole 128-B rows per instruction)
-// -> registers (next block in flight while this one is contracted) -> wave-private LDS image [token][128 B] with the
+// Data path per wave and 64-token cache block: the block's pointer by a scalar load from the block table (one block ahead), 16
+// coalesced 16-B global_load (8 whole 128-B rows per instruction; address space 1 spelled out -- FLAT loads can only be waited for
+// with vmcnt(0) lgkmcnt(0), see load_tile) -> registers (next block in flight while this one is contracted) -> wave-private LDS image [token][128 B] with the
 // 16-B chunks XOR-swizzled by (token>>1)&7 -> K operand by ds_read_b64 (token rows, conflict free), V operand by
 // ds_read_b64_tr_b8 (the hardware byte transpose: 8 tokens of one head-dim column per lane).
 // The score tile comes out of the MFMA as S^T with 4 consecutive tokens per lane; the second contraction uses the
