@@ -462,6 +462,16 @@ def main():
         }
         if comm_note:
             out['config']['collectives_note'] = comm_note
+        if world > 1 or emu > 1:
+            # prefill-sized forwards: all-reduces on the side stream under the other row half's GEMMs (TM_COMM_STREAM, default on)
+            out['config']['prefill_allreduce_overlap'] = {
+                'side_stream': cinfo['side_stream'], 'overlapped_forwards': cinfo['overlapped_forwards'],
+                'side_stream_allreduces': cinfo['side_stream_allreduces']}
+            if emu > 1 and float(os.environ.get('TM_EMULATE_AR_GBPS', '0') or 0) > 0:
+                out['config']['prefill_allreduce_overlap']['emulated_exchange_gbps'] = float(os.environ['TM_EMULATE_AR_GBPS'])
+                out['config']['prefill_allreduce_overlap']['note'] = (
+                    'one rank: the all-reduce is the identity; an idle one-workgroup kernel holds the stream for 10 us + bytes / that '
+                    'bandwidth behind every prefill all-reduce -- shows what the choreography hides, not a multi-GPU result')
         if ranks_per_device > 1:
             out['config']['devices_shared'] = True
             out['config']['ranks_per_device'] = ranks_per_device

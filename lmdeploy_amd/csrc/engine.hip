@@ -708,11 +708,12 @@ int tm_engine_destroy(tm_engine* e)
     }
     if (e->comm) {
         (void)ncclCommDestroy(e->comm);
-        if (e->comm_stream) {
-            (void)hipStreamDestroy(e->comm_stream);
-            (void)hipEventDestroy(e->ev_fork);
-            (void)hipEventDestroy(e->ev_join);
-        }
+    }
+    if (e->comm_stream) {
+        (void)hipStreamDestroy(e->comm_stream);
+    }
+    for (hipEvent_t ev : e->pipe_events) {
+        (void)hipEventDestroy(ev);
     }
     if (e->stream) {
         (void)hipStreamDestroy(e->stream);

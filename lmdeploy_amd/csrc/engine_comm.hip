@@ -4,23 +4,95 @@
 
 namespace tmk {
 
+// Stand-in for the duration of an exchange, for the ONE-rank emulation of a tensor-parallel rank only (TM_FORCE_COMM=1 / `bench.py
+// --emulate-tp N`: the communicator has one rank, its all-reduce is the identity and takes no time).  TM_EMULATE_AR_GBPS = g > 0: every
+// all-reduce of a prefill-sized forward is followed, on the stream it was enqueued on, by one idle workgroup that waits
+// 10 us + bytes / g -- what an all-reduce with algorithm bandwidth g GB/s would hold that stream for.  It lets a 1-GPU box show what the
+// two-row-half choreography hides and what it leaves exposed (profiles/r05_prefill_overlap_emulated_exchange.txt); it moves no data, is
+// never armed with more than one rank, and is not a scaling result.
+__global__ void exchange_standin_kernel(unsigned ticks)
+{
+    const uint64_t t0 = __builtin_amdgcn_s_memrealtime();  // 100 MHz
+    while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) {
+        __builtin_amdgcn_s_sleep(64);
+    }
+}
+
+static int exchange_standin(tm_engine* e, size_t bytes, hipStream_t st)
+{
+    if (e->emulate_ar_gbps > 0.f && e->cfg.tp == 1) {
+        const double us = 10.0 + (double)bytes / ((double)e->emulate_ar_gbps * 1e3);
+        exchange_standin_kernel<<<1, 64, 0, st>>>((unsigned)(us * 100.0));
+        TM_HIP_CHECK(hipGetLastError());
+    }
+    return 0;
+}
+
 // fp16 sum of the row-parallel partial outputs over the TP group (comm/nccl/nccl.cu:356-398 calls ncclAllReduce on the
-// compute stream; TM_COMM_STREAM=1: on a side stream between a fork / join pair)
+// compute stream).  Decode-sized forwards always take this form: a decode layer is one dependent chain, a collective between two
+// of its kernels has nothing to run beside (round 2 measured a side stream with and without a weight prefetch under it:
+// profiles/r02_comm_stream_arms.txt).  Prefill-sized forwards overlap for real: allreduce_rows_side below.
 static int allreduce_hidden(tm_engine* e, half_t* buf, int M)
 {
     if (!e->use_comm) {
         return 0;
     }
     TM_REQUIRE(e->comm != nullptr, "tm_engine_comm_init was not called");
-    if (!e->comm_overlap || !e->comm_stream) {
-        TM_NCCL_CHECK(ncclAllReduce(buf, buf, (size_t)M * e->hidden, ncclHalf, ncclSum, e->comm, e->stream));
-        return 0;
+    TM_NCCL_CHECK(ncclAllReduce(buf, buf, (size_t)M * e->hidden, ncclHalf, ncclSum, e->comm, e->stream));
+    if (M >= 2 * e->pipe_min_rows) {
+        TM_TRY(exchange_standin(e, (size_t)M * e->hidden * 2, e->stream));
     }
-    TM_HIP_CHECK(hipEventRecord(e->ev_fork, e->stream));
-    TM_HIP_CHECK(hipStreamWaitEvent(e->comm_stream, e->ev_fork, 0));
-    TM_NCCL_CHECK(ncclAllReduce(buf, buf, (size_t)M * e->hidden, ncclHalf, ncclSum, e->comm, e->comm_stream));
-    TM_HIP_CHECK(hipEventRecord(e->ev_join, e->comm_stream));
-    TM_HIP_CHECK(hipStreamWaitEvent(e->stream, e->ev_join, 0));
+    return 0;
+}
+
+// ---- prefill forwards of a tensor-parallel rank: all-reduce on the side stream UNDER the other row half's GEMMs --------------------
+// Every operator between the attention of a layer and the attention of the next (wo, all-reduce, residual + RMSNorm, w1w3, w2,
+// all-reduce, residual + RMSNorm, next w_qkv) is row-wise, so a forward of M rows runs them as two row halves A / B
+// (forward_tail_two_halves, engine_forward.hip): while RCCL sums half A's partial outputs over xGMI on `comm_stream`, the engine
+// stream contracts half B -- the north star's "RCCL all-reduce overlapped on a side HIP stream".  The reference hides its collective
+// inside a fused kernel instead (comm/cuda_ipc/fused_allreduce.cu:406-500); at prefill sizes (8192 x 4096 fp16 = 64 MB per
+// all-reduce, two per layer) the exchange is bandwidth, not latency, and a second stream is the form that hides bandwidth.
+// Events come from a per-engine pool (one pair per all-reduce of a forward: nothing is re-recorded while a wait on it may be pending).
+static int pipe_event(tm_engine* e, hipEvent_t* ev)
+{
+    if (e->pipe_events_used == e->pipe_events.size()) {
+        hipEvent_t n;
+        TM_HIP_CHECK(hipEventCreateWithFlags(&n, hipEventDisableTiming));
+        e->pipe_events.push_back(n);
+    }
+    *ev = e->pipe_events[e->pipe_events_used++];
+    return 0;
+}
+
+bool prefill_pipe_ok(const tm_engine* e, int M)
+{
+    // RCCL is what serves a forward of this size (reduce_residual_norm's first branch takes the native communicator), the side
+    // stream exists, and both halves are whole prefill tiles
+    return e->use_comm && e->comm && e->comm_overlap && e->comm_stream && !(e->p2p_ready && M <= e->p2p_rows)
+           && M >= 2 * e->pipe_min_rows;
+}
+
+// rows [r0, r0 + rows) of d_tmp, produced by what the engine stream holds so far: summed over the ranks on the side stream; `*done`
+// fires behind the sum (the consumer on the engine stream waits for it: pipe_wait)
+int allreduce_rows_side(tm_engine* e, int r0, int rows, hipEvent_t* done)
+{
+    TM_REQUIRE(e->comm && e->comm_stream, "internal: side-stream all-reduce without a communicator");
+    hipEvent_t ready;
+    TM_TRY(pipe_event(e, &ready));
+    TM_TRY(pipe_event(e, done));
+    half_t* buf = e->d_tmp + (size_t)r0 * e->hidden;
+    TM_HIP_CHECK(hipEventRecord(ready, e->stream));
+    TM_HIP_CHECK(hipStreamWaitEvent(e->comm_stream, ready, 0));
+    TM_NCCL_CHECK(ncclAllReduce(buf, buf, (size_t)rows * e->hidden, ncclHalf, ncclSum, e->comm, e->comm_stream));
+    TM_TRY(exchange_standin(e, (size_t)rows * e->hidden * 2, e->comm_stream));
+    TM_HIP_CHECK(hipEventRecord(*done, e->comm_stream));
+    e->pipe_allreduces += 1;
+    return 0;
+}
+
+int pipe_wait(tm_engine* e, hipEvent_t done)
+{
+    TM_HIP_CHECK(hipStreamWaitEvent(e->stream, done, 0));
     return 0;
 }
 
@@ -130,16 +202,18 @@ int tm_engine_comm_init(tm_engine* e, const void* host_id128)
     memcpy(&id, host_id128, sizeof(id));
     TM_HIP_CHECK(hipSetDevice(e->cfg.device));
     TM_NCCL_CHECK(ncclCommInitRank(&e->comm, e->cfg.tp, id, e->cfg.rank));
+    // TM_COMM_STREAM (default 1): prefill-sized forwards run their all-reduces on a side stream under the other row half's GEMMs
+    // (allreduce_rows_side above); 0 = every collective on the engine stream.  TM_PIPE_MIN_ROWS (1024): smallest row half -- a forward splits from 2048 rows
+    // (16 MB per all-reduce at hidden 4096): below that the eight cross-stream hand-offs per layer (~5 us each, measured as +14 % on a
+    // prefill whose exchange is free, profiles/r05_prefill_overlap_emulated_exchange.txt) cost more than the exchange they hide.
     const char* cs   = getenv("TM_COMM_STREAM");
-    // Measured on MI355X (per-rank emulation of Llama-3-70B TP = 8, 160 collectives per step, profiles/r02_comm_stream_arms.txt):
-    // engine stream 6.81 ms/step; side stream without the prefetch 6.81 ms (a fork/join inside a hipGraph is free, but costs
-    // ~30 us per collective on eager launches); side stream + weight prefetch 7.80 ms (the prefetch kernel costs 6 us and the
-    // next GEMM gains nothing from L2 / Infinity-Cache resident weights).  Default: engine stream; the arms stay reachable.
-    e->comm_overlap  = cs && atoi(cs);
+    const char* pm   = getenv("TM_PIPE_MIN_ROWS");
+    const char* em   = getenv("TM_EMULATE_AR_GBPS");
+    e->emulate_ar_gbps = em && e->cfg.tp == 1 ? (float)atof(em) : 0.f;
+    e->comm_overlap  = !cs || atoi(cs) != 0;
+    e->pipe_min_rows = pm && atoi(pm) >= 64 ? atoi(pm) / 64 * 64 : 1024;
     if (e->comm_overlap && !e->comm_stream) {
         TM_HIP_CHECK(hipStreamCreateWithFlags(&e->comm_stream, hipStreamNonBlocking));
-        TM_HIP_CHECK(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
-        TM_HIP_CHECK(hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming));
     }
     return 0;
 }
@@ -218,6 +292,15 @@ int tm_engine_comm_info(tm_engine* e, int* backend, int* ranks, int* graph_captu
     if (backend) *backend = b;
     if (ranks) *ranks = n;
     if (graph_captured) *graph_captured = (e->graph || e->graph_cb) ? 1 : 0;
+    return 0;
+}
+
+int tm_engine_comm_overlap_info(tm_engine* e, int* side_stream, int64_t* forwards, int64_t* allreduces)
+{
+    TM_REQUIRE(e, "null pointer");
+    if (side_stream) *side_stream = (e->use_comm && e->comm && e->comm_overlap && e->comm_stream) ? 1 : 0;
+    if (forwards) *forwards = e->pipe_forwards;
+    if (allreduces) *allreduces = e->pipe_allreduces;
     return 0;
 }
 

@@ -145,6 +145,48 @@ static int linear_plain(tm_engine* e, LinearSlots& l, const half_t* x, int ldx, 
     return launch_linear(l.w, x, ldx, y, ldy, M, gated, cfg, e->d_gemm_ws, false, nullptr, e->stream);
 }
 
+// Tensor-parallel prefill forward, dense layer, from the attention output to the next layer's QKV projection, as two row halves
+// A = [0, Ma), B = [Ma, M): every operator here is row-wise, so a half's all-reduce (RCCL on the side stream, engine_comm.hip) runs
+// under the other half's GEMMs on the engine stream --
+//   engine stream:  wo A | wo B | norm A  w1w3 A  w2 A | norm B  w1w3 B  w2 B | norm A  qkv' A | norm B  qkv' B
+//   side stream:         | AR A        | AR B                 | AR A                   | AR B
+// (qkv' = the NEXT layer's w_qkv: it hides the last exchange; absent behind the last layer).  Same kernels, same per-row arithmetic
+// as the unsplit sequence (reduce_residual_norm's RCCL branch): a row's result does not depend on which rows share its launch, as
+// long as both forms pick the same tiling -- they pick per launch size, so equality with the unsplit forward is to rounding, and the
+// parity gate is the engine's usual one against the oracle.  Reference role: the overlap the reference gets from its fused
+// all-reduce + norm kernel (unified_decoder.cc:278,328; comm/cuda_ipc/fused_allreduce.cu:406-500).
+static int forward_tail_two_halves(tm_engine* e, Layer& L, int M, int Ma, const half_t* next_norm, Layer* next)
+{
+    const int    r0[2] = {0, Ma}, nr[2] = {Ma, M - Ma};
+    const int    kq = e->q_heads * e->D, H = e->hidden;
+    const float  eps = e->cfg.model.rms_eps;
+    hipStream_t  st = e->stream;
+    hipEvent_t   done[2];
+    for (int h = 0; h < 2; ++h) {
+        TM_PROF(P_GEMM_O, TM_TRY(linear_plain(e, L.wo, e->d_attn + (size_t)r0[h] * kq, kq, e->d_tmp + (size_t)r0[h] * H, H, nr[h], false)));
+        TM_TRY(allreduce_rows_side(e, r0[h], nr[h], &done[h]));
+    }
+    for (int h = 0; h < 2; ++h) {
+        const size_t off = (size_t)r0[h] * H;
+        TM_TRY(pipe_wait(e, done[h]));
+        TM_PROF(P_RES_NORM, TM_TRY(launch_residual_rmsnorm(e->d_x + off, e->d_resid + off, e->d_tmp + off, nullptr, 0, nullptr, L.ffn_norm, eps,
+                                                           nr[h], H, st)));
+        TM_PROF(P_GEMM_GATE_UP, TM_TRY(linear_plain(e, L.w13, e->d_x + off, H, e->d_act + (size_t)r0[h] * e->inter, e->inter, nr[h], true)));
+        TM_PROF(P_GEMM_DOWN, TM_TRY(linear_plain(e, L.w2, e->d_act + (size_t)r0[h] * e->inter, e->inter, e->d_tmp + off, H, nr[h], false)));
+        TM_TRY(allreduce_rows_side(e, r0[h], nr[h], &done[h]));
+    }
+    for (int h = 0; h < 2; ++h) {
+        const size_t off = (size_t)r0[h] * H;
+        TM_TRY(pipe_wait(e, done[h]));
+        TM_PROF(P_RES_NORM, TM_TRY(launch_residual_rmsnorm(e->d_x + off, e->d_resid + off, e->d_tmp + off, nullptr, 0, nullptr, next_norm, eps,
+                                                           nr[h], H, st)));
+        if (next) {
+            TM_PROF(P_GEMM_QKV, TM_TRY(linear_plain(e, next->qkv, e->d_x + off, H, e->d_qkv + (size_t)r0[h] * e->qkv_n, e->qkv_n, nr[h], false)));
+        }
+    }
+    return 0;
+}
+
 // ---- RMSNorm folded into the decode GEMMs (tp = 1, dense u4 layers, M <= 64; NormFold in tm_kernels.h) ----------------------------
 // the tiling of a folded launch: the measured / heuristic pick when its kernel carries the folded epilogue, else the heuristic's
 static void fold_tiling(tm_engine* e, const LinearWeight& w, int M, int* shape, int* splits)
@@ -223,6 +265,12 @@ int forward(tm_engine* e, const int* d_ids, int M, int nseq, bool decode, int ma
     TM_PROF(P_EMBED, TM_TRY(launch_embedding(e->d_resid, e->tok_embeddings, d_ids, M, e->hidden, m.vocab, st)));
     TM_PROF(P_RES_NORM, TM_TRY(launch_rmsnorm(e->d_x, e->d_resid, e->layers[0].attn_norm, m.rms_eps, M, e->hidden, st)));
     const float scale_log2 = (1.0f / std::sqrt((float)e->D)) * 1.4426950408889634f;
+    // tp > 1 prefill through RCCL: the row-wise part of every dense layer as two row halves, all-reduces on the side stream
+    e->pipe_events_used = 0;
+    const bool  pipe     = !decode && !md && prefill_pipe_ok(e, M);
+    const int   Ma       = pipe ? (M / 2 + 63) / 64 * 64 : 0;
+    e->pipe_forwards += pipe ? 1 : 0;
+    bool        qkv_done = false;  // the previous layer's two-halves tail already projected this layer's QKV
     int         ss_tiles   = 0;  // > 0: d_x holds r . g of a folded producer, d_ss its sums of squares (the next GEMM applies the row factor)
     for (int li = 0; li < m.layers; ++li) {
         Layer& L = e->layers[li];
@@ -250,7 +298,10 @@ int forward(tm_engine* e, const int* d_ids, int M, int nseq, bool decode, int ma
                                                      e->d_gemm_ws, cfg.splits > 1, &qkv_slabs, st)));
         }
         else {
-            TM_PROF(P_GEMM_QKV, TM_TRY(linear_plain(e, L.qkv, e->d_x, e->hidden, e->d_qkv, e->qkv_n, M, false)));
+            if (!qkv_done) {
+                TM_PROF(P_GEMM_QKV, TM_TRY(linear_plain(e, L.qkv, e->d_x, e->hidden, e->d_qkv, e->qkv_n, M, false)));
+            }
+            qkv_done = false;
             TM_PROF(P_KV_STORE, TM_TRY(launch_kv_rope_store(qkv_p, e->q_heads, e->d_cu_q, e->d_k_len, nseq, M - nd, e->d_rope,
                                                            e->rope_max_pos, cv, st)));
         }
@@ -340,6 +391,12 @@ int forward(tm_engine* e, const int* d_ids, int M, int nseq, bool decode, int ma
             }
         }
         const half_t* next_norm = li + 1 < m.layers ? e->layers[li + 1].attn_norm : e->final_norm;
+        if (pipe && !L.is_moe) {
+            Layer* const nxt = li + 1 < m.layers ? &e->layers[li + 1] : nullptr;
+            TM_TRY(forward_tail_two_halves(e, L, M, Ma, next_norm, nxt));
+            qkv_done = nxt != nullptr;
+            continue;
+        }
         if (fold) {
             // wo's epilogue updates the residual stream and hands r . g + sums of squares to w1w3, whose accumulators take the row
             // factor before the gated SiLU; w2 does the same for the next layer's w_qkv (the last layer's w2 feeds the final norm
@@ -413,13 +470,6 @@ int forward(tm_engine* e, const int* d_ids, int M, int nseq, bool decode, int ma
                                                     cnt / 2));
                     }
                 }
-                else if (e->comm_overlap && e->comm_stream) {
-                    TM_HIP_CHECK(hipEventRecord(e->ev_fork, st));
-                    TM_HIP_CHECK(hipStreamWaitEvent(e->comm_stream, e->ev_fork, 0));
-                    TM_NCCL_CHECK(ncclAllGather(logits, e->d_logits_gather, cnt, ncclHalf, e->comm, e->comm_stream));
-                    TM_HIP_CHECK(hipEventRecord(e->ev_join, e->comm_stream));
-                    TM_HIP_CHECK(hipStreamWaitEvent(st, e->ev_join, 0));
-                }
                 else {
                     TM_NCCL_CHECK(ncclAllGather(logits, e->d_logits_gather, cnt, ncclHalf, e->comm, st));
                 }
@@ -446,14 +496,6 @@ int forward(tm_engine* e, const int* d_ids, int M, int nseq, bool decode, int ma
                 p2p_tables(e, data, flags);
                 TM_TRY(launch_p2p_allgather(data, flags, e->cfg.tp, e->cfg.rank, e->p2p_state, (size_t)e->p2p_rows * e->hidden, e->d_cand,
                                             e->d_cand_all, n * 2, st));
-            }
-            // the same communicator is only ever driven from ONE stream (the side stream when it exists)
-            else if (e->comm_overlap && e->comm_stream) {
-                TM_HIP_CHECK(hipEventRecord(e->ev_fork, st));
-                TM_HIP_CHECK(hipStreamWaitEvent(e->comm_stream, e->ev_fork, 0));
-                TM_NCCL_CHECK(ncclAllGather(e->d_cand, e->d_cand_all, (size_t)n * 2, ncclFloat, e->comm, e->comm_stream));
-                TM_HIP_CHECK(hipEventRecord(e->ev_join, e->comm_stream));
-                TM_HIP_CHECK(hipStreamWaitEvent(st, e->ev_join, 0));
             }
             else {
                 TM_NCCL_CHECK(ncclAllGather(e->d_cand, e->d_cand_all, (size_t)n * 2, ncclFloat, e->comm, st));

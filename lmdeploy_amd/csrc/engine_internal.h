@@ -79,12 +79,16 @@ struct tm_engine {
 
     hipStream_t  stream = nullptr;
     ncclComm_t   comm   = nullptr;
-    // TM_COMM_STREAM=1 (opt-in): tensor-parallel collectives on their own stream, forked from / joined to the engine stream by events
-    // (inside a hipGraph capture the pair becomes a parallel branch).  Nothing is scheduled between the fork and the join: a weight
-    // prefetch of the next linear under the collective was measured in round 2 on a 1-rank communicator (pure added cost there,
-    // profiles/r02_comm_stream_arms.txt) and removed; what a real xGMI all-reduce leaves to hide is unmeasured
+    // TM_COMM_STREAM (default 1): the all-reduces of PREFILL-sized tensor-parallel forwards run on their own stream under the other
+    // row half's GEMMs (engine_comm.hip: allreduce_rows_side; engine_forward.hip: forward_tail_two_halves).  Decode-sized forwards
+    // keep every collective on the engine stream: a decode layer is one dependent chain, a side stream had nothing to run beside it
+    // (profiles/r02_comm_stream_arms.txt; the fork / join arm of rounds 2-4 is gone)
     hipStream_t  comm_stream = nullptr;
-    hipEvent_t   ev_fork = nullptr, ev_join = nullptr;
+    std::vector<hipEvent_t> pipe_events;      // (ready, done) pairs of the side-stream all-reduces of ONE forward
+    size_t       pipe_events_used = 0;
+    int          pipe_min_rows    = 1024;     // TM_PIPE_MIN_ROWS: smallest row half (forwards below twice this stay unsplit)
+    int64_t      pipe_forwards = 0, pipe_allreduces = 0;   // tm_engine_comm_overlap_info
+    float        emulate_ar_gbps = 0.f;       // TM_EMULATE_AR_GBPS, one-rank emulation only: stand-in for an exchange's duration (engine_comm.hip)
     // mixed forwards: the decode rows' attention runs on this stream beside the prefill rows' K/V store -> flatten -> attention
     // on the engine stream (reference: aux_stream_ + event fork / join, unified_attention_layer.cc:613-651)
     hipStream_t  aux_stream = nullptr;
@@ -100,7 +104,7 @@ struct tm_engine {
     int          p2p_rows = 0;
     int          p2p_rows2 = 0;  // rows of the segment's two-shot regions (in2 / out2): forwards larger than p2p_rows (prefill) without RCCL
     bool         p2p_ready = false;
-    bool         comm_overlap = false;   // TM_COMM_STREAM=1: collectives on a side stream (fork / join around each)
+    bool         comm_overlap = false;   // TM_COMM_STREAM != 0 and an RCCL communicator: prefill all-reduces on comm_stream
     bool         graph_comm_failed = false;  // capturing the RCCL calls failed once: stay eager
     bool         use_comm = false;  // collectives on the data path: tp > 1 (or TM_FORCE_COMM=1: single-rank communicator,
                                     // exercises the RCCL code path on a 1-GPU box)
@@ -307,6 +311,9 @@ int launch_advance_active(int* k_len, const int* active, int n, hipStream_t st);
 size_t prof_event(tm_engine* e);
 void p2p_tables(tm_engine* e, half_t** data, uint32_t** flags);
 int reduce_residual_norm(tm_engine* e, int M, const half_t* norm_w);
+bool prefill_pipe_ok(const tm_engine* e, int M);
+int allreduce_rows_side(tm_engine* e, int r0, int rows, hipEvent_t* done);
+int pipe_wait(tm_engine* e, hipEvent_t done);
 int forward(tm_engine* e, const int* d_ids, int M, int nseq, bool decode, int max_q_len, int max_k_len, int kflat_stride, int slot0,
             const MixedDecode* md = nullptr);
 int device_marks_fetch(tm_engine* e, bool async);

@@ -68,8 +68,8 @@ def test_engine_collective_path_single_rank(cuda, monkeypatch, graph_comm, side_
     """The tp > 1 data path (RCCL all-reduce after wo / w2, vocabulary-sharded lm_head + candidate all-gather), driven
     on one GPU through a 1-rank communicator (TM_FORCE_COMM=1): must reproduce the collective-free engine exactly
     (a 1-rank sum is the identity; the non-deferred split-K reduce rounds the same fp32 sums).  graph_comm=1 also
-    captures the RCCL calls into the decode hipGraph; side_stream=1 is the opt-in arm with the collectives on a side stream
-    (fork / join)."""
+    captures the RCCL calls into the decode hipGraph; side_stream = TM_COMM_STREAM (prefill-sized forwards only: these prompts
+    stay below the split size, so both values must behave identically here; the overlapped form has its own test below)."""
     cfg = o.ModelConfig(hidden=256, layers=2, q_heads=4, kv_heads=2, head_dim=128, inter=512, vocab=1024,
                         kv_bits=8, rope=o.RopeParam(128, 500000.0, 'llama3', 8.0, 1.0, 4.0, 8192))
     w = o.make_synthetic_weights(cfg, seed=5)
@@ -99,6 +99,59 @@ def test_engine_collective_path_single_rank(cuda, monkeypatch, graph_comm, side_
     t1, l1 = run(True)
     assert np.array_equal(t0, t1)
     assert np.abs(l0.astype(np.float32) - l1.astype(np.float32)).max() <= 2e-3
+
+
+@pytest.mark.parametrize('min_rows,chunk', [(256, 1024), (64, 1024), (64, 448)])
+def test_engine_prefill_allreduce_on_side_stream(cuda, monkeypatch, min_rows, chunk):
+    """Tensor-parallel prefill forwards split their row-wise part (wo .. next w_qkv) into two row halves and run each half's RCCL
+    all-reduce on the side stream under the other half's GEMMs (engine_forward.hip: forward_tail_two_halves; TM_COMM_STREAM, default
+    on).  Driven on one GPU through a 1-rank communicator (TM_FORCE_COMM=1, a 1-rank sum is the identity): the event choreography, the
+    row offsets of every buffer and the hand-over of the next layer's QKV projection must reproduce (a) the same engine with every
+    collective on the engine stream (TM_COMM_STREAM=0) and (b) the collective-free engine -- tokens equal, logits to the rounding of
+    a different GEMM tiling per launch size -- and (c) the oracle.  chunk = 448: the prompts span two forwards (uneven halves, a
+    short last forward that stays unsplit); the decode steps behind the prefill run on the engine stream as before."""
+    cfg = o.ModelConfig(hidden=256, layers=3, q_heads=4, kv_heads=2, head_dim=128, inter=512, vocab=1024,
+                        kv_bits=8, rope=o.RopeParam(128, 500000.0, 'llama3', 8.0, 1.0, 4.0, 8192))
+    w = o.make_synthetic_weights(cfg, seed=5)
+    rng = np.random.default_rng(2)
+    prompts = [rng.integers(0, cfg.vocab, n).astype(np.int32) for n in (300, 77, 190, 33)]     # 600 tokens
+
+    def run(force, side):
+        monkeypatch.setenv('TM_PIPE_MIN_ROWS', str(min_rows))
+        monkeypatch.setenv('TM_COMM_STREAM', str(side))
+        if force:
+            monkeypatch.setenv('TM_FORCE_COMM', '1')
+        else:
+            monkeypatch.delenv('TM_FORCE_COMM', raising=False)
+            monkeypatch.setenv('TM_FOLD_NORM', '0')
+        eng = Engine.from_model_config(cfg, max_batch_size=4, session_len=512, quant_policy=8, max_prefill_token_num=chunk, use_graph=1)
+        if force:
+            eng.comm_init(Engine.comm_unique_id())
+        eng.load_weights(export_weights(cfg, w))
+        eng.start()
+        eng.prefill(prompts, max_new_tokens=5)
+        lg0 = eng.fetch_logits().copy()
+        eng.decode(4)
+        out = eng.fetch().copy(), lg0, eng.fetch_logits().copy(), eng.comm_info()
+        eng.close()
+        return out
+
+    base = run(False, 1)
+    serial = run(True, 0)
+    piped = run(True, 1)
+    assert base[3]['side_stream'] is False and base[3]['overlapped_forwards'] == 0
+    assert serial[3]['side_stream'] is False and serial[3]['side_stream_allreduces'] == 0
+    # 600 tokens: one forward of 600 rows, or 448 + 152 (the second one splits only when both halves reach min_rows)
+    want_fw = 1 if chunk == 1024 else (2 if 152 >= 2 * min_rows else 1)
+    assert piped[3]['side_stream'] is True and piped[3]['overlapped_forwards'] == want_fw, piped[3]
+    assert piped[3]['side_stream_allreduces'] == 4 * cfg.layers * want_fw, piped[3]
+    for other in (base, serial):
+        assert np.array_equal(piped[0], other[0])
+        for a, b in ((piped[1], other[1]), (piped[2], other[2])):
+            assert np.abs(a.astype(np.float32) - b.astype(np.float32)).max() <= 2e-3
+    om = o.OracleModel(cfg, w, batch=4, max_ctx=512)
+    _, ref = om.forward([p.tolist() for p in prompts])
+    assert np.abs(piped[1].astype(np.float32) - ref.astype(np.float32)).max() <= 3e-2
 
 
 @pytest.mark.parametrize('B,pf_class', [(4, 0), (80, 0), (4, 512)])
