@@ -466,6 +466,7 @@ def main():
             # prefill-sized forwards: all-reduces on the side stream under the other row half's GEMMs (TM_COMM_STREAM, default on)
             out['config']['prefill_allreduce_overlap'] = {
                 'side_stream': cinfo['side_stream'], 'overlapped_forwards': cinfo['overlapped_forwards'],
+                'microbatch_forwards': cinfo['microbatch_forwards'],
                 'side_stream_allreduces': cinfo['side_stream_allreduces']}
             if emu > 1 and float(os.environ.get('TM_EMULATE_AR_GBPS', '0') or 0) > 0:
                 out['config']['prefill_allreduce_overlap']['emulated_exchange_gbps'] = float(os.environ['TM_EMULATE_AR_GBPS'])

@@ -520,11 +520,13 @@ tm_stream_t tm_engine_stream(tm_engine* e);
 int tm_engine_comm_info(tm_engine* e, int* backend, int* ranks, int* graph_captured);
 /* The overlap the north star names ("RCCL all-reduce over xGMI overlapped on a side HIP stream"), as counters a benchmark / test can read
  * (any pointer may be NULL): side_stream = 1 when prefill-sized tensor-parallel forwards run their all-reduces on the engine's side stream
- * under the other row half's GEMMs (TM_COMM_STREAM, default on; needs the RCCL communicator); forwards = forwards that ran that way so far;
- * allreduces = all-reduces enqueued on the side stream so far (4 per dense layer of such a forward).  The reference hides the exchange
+ * under the other half's kernels (TM_COMM_STREAM, default on; needs the RCCL communicator); forwards = forwards that ran that way so far;
+ * microbatch_forwards = how many of them split at a sequence boundary into two micro-batches that leapfrog through all layers (the rest
+ * split the row-wise part of every layer into two row halves); allreduces = all-reduces enqueued on the side stream so far (4 per dense
+ * layer of such a forward).  The reference hides the exchange
  * inside a fused kernel (comm/cuda_ipc/fused_allreduce.cu:406-500, unified_decoder.cc:278,328); decode-sized forwards do the same here
  * (comm_p2p.hip) or call RCCL on the engine stream. */
-int tm_engine_comm_overlap_info(tm_engine* e, int* side_stream, int64_t* forwards, int64_t* allreduces);
+int tm_engine_comm_overlap_info(tm_engine* e, int* side_stream, int64_t* forwards, int64_t* microbatch_forwards, int64_t* allreduces);
 int tm_engine_stats(tm_engine* e, int64_t* weight_bytes, int64_t* kv_bytes_per_token, int64_t* num_blocks,
                     int* decode_splits);
 

@@ -473,6 +473,7 @@ int tm_engine_start(tm_engine* e)
     TM_TRY(dmalloc(&e->d_next_ids, (size_t)B));
     TM_TRY(dmalloc(&e->d_k_len, (size_t)B));
     TM_TRY(dmalloc(&e->d_cu_q, (size_t)B + 1));
+    TM_TRY(dmalloc(&e->d_cu_q_b, (size_t)B + 1));
     TM_TRY(dmalloc(&e->d_cu_koff, (size_t)B + 1));
     TM_TRY(dmalloc(&e->d_rows, (size_t)B));
     TM_TRY(dmalloc(&e->d_generated, (size_t)B * c.session_len));
@@ -692,7 +693,7 @@ int tm_engine_destroy(tm_engine* e)
     }
     void* bufs[] = {e->pool, e->d_block_ptrs, e->d_cu_block_nums, e->d_resid, e->d_x, e->d_qkv, e->d_attn, e->d_act,
                     e->d_tmp, e->d_logits, e->d_last, e->d_gemm_ws, e->d_attn_ws, e->d_kflat, e->d_vflat, e->d_rope,
-                    e->d_ids, e->d_k_len, e->d_cu_q, e->d_cu_koff, e->d_rows, e->d_generated, e->d_step,
+                    e->d_ids, e->d_k_len, e->d_cu_q, e->d_cu_q_b, e->d_cu_koff, e->d_rows, e->d_generated, e->d_step,
                     e->d_prefill_ids, e->d_argmax_val, e->d_cand, e->d_cand_all, e->d_next_ids, e->d_ss, e->d_tickets};
     for (void* p : bufs) {
         if (p) {

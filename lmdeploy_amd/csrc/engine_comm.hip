@@ -295,11 +295,12 @@ int tm_engine_comm_info(tm_engine* e, int* backend, int* ranks, int* graph_captu
     return 0;
 }
 
-int tm_engine_comm_overlap_info(tm_engine* e, int* side_stream, int64_t* forwards, int64_t* allreduces)
+int tm_engine_comm_overlap_info(tm_engine* e, int* side_stream, int64_t* forwards, int64_t* microbatch_forwards, int64_t* allreduces)
 {
     TM_REQUIRE(e, "null pointer");
     if (side_stream) *side_stream = (e->use_comm && e->comm && e->comm_overlap && e->comm_stream) ? 1 : 0;
     if (forwards) *forwards = e->pipe_forwards;
+    if (microbatch_forwards) *microbatch_forwards = e->pipe_mb_forwards;
     if (allreduces) *allreduces = e->pipe_allreduces;
     return 0;
 }

@@ -187,6 +187,87 @@ static int forward_tail_two_halves(tm_engine* e, Layer& L, int M, int Ma, const 
     return 0;
 }
 
+// Tensor-parallel prefill forward whose sequences split into two micro-batches A = sequences [0, seqs_a) = rows [0, rows_a) and B = the
+// rest (prefill_slots decides; e->mb): between the embedding and the lm_head the two share nothing -- not even the attention -- so they
+// leapfrog through ALL layers, every all-reduce of one running on the side stream under a whole block of the other:
+//   engine stream:  attn-block A | attn-block B | ffn A | ffn B | attn-block' A | attn-block' B | ...
+//   side stream:                 | AR(wo A)     | AR(wo B)  | AR(w2 A) | AR(w2 B)       | ...
+// attn-block = (residual + RMSNorm of the previous layer's w2 sum,) w_qkv, RoPE + K/V quantise-store, flatten, attention, wo;
+// ffn = residual + RMSNorm of the wo sum, w1w3 + gated SiLU, w2.  The row-half schedule inside a layer (forward_tail_two_halves) can
+// hide AR(wo A) only under wo B and AR(w2 B) only under the next w_qkv A; here every exchange has a third to a half of the other
+// micro-batch's layer to hide under (measured with the 1-rank exchange stand-in: profiles/r05_prefill_overlap_emulated_exchange.txt).
+// Same kernels and per-row arithmetic as the unsplit forward; dense layers only.
+static int forward_layers_two_microbatches(tm_engine* e, int M, int nseq, int max_q_len, int max_k_len, int kflat_stride, float scale_log2)
+{
+    const tm_model_config& m  = e->cfg.model;
+    hipStream_t            st = e->stream;
+    struct Part {
+        int        r0, rows, s0, nseq;
+        const int* cu_q;  // counted from the part's first row
+    };
+    const Part   part[2] = {{0, e->mb.rows_a, 0, e->mb.seqs_a, e->d_cu_q},
+                            {e->mb.rows_a, M - e->mb.rows_a, e->mb.seqs_a, nseq - e->mb.seqs_a, e->d_cu_q_b}};
+    const int    H = e->hidden, kq = e->q_heads * e->D;
+    const float  eps = m.rms_eps;
+    hipEvent_t   done[2] = {nullptr, nullptr};
+    for (int li = 0; li < m.layers; ++li) {
+        Layer& L = e->layers[li];
+        TM_REQUIRE(!L.is_moe, "internal: micro-batch schedule on a MoE layer");
+        for (int h = 0; h < 2; ++h) {
+            const Part&  P   = part[h];
+            const size_t off = (size_t)P.r0 * H;
+            if (li > 0) {  // this micro-batch's w2 partial sums of the previous layer are summed by now (or the stream waits here)
+                TM_TRY(pipe_wait(e, done[h]));
+                TM_PROF(P_RES_NORM, TM_TRY(launch_residual_rmsnorm(e->d_x + off, e->d_resid + off, e->d_tmp + off, nullptr, 0, nullptr, L.attn_norm,
+                                                                   eps, P.rows, H, st)));
+            }
+            half_t* const qkv = e->d_qkv + (size_t)P.r0 * e->qkv_n;
+            TM_PROF(P_GEMM_QKV, TM_TRY(linear_plain(e, L.qkv, e->d_x + off, H, qkv, e->qkv_n, P.rows, false)));
+            KvCacheView cv = cache_view(e, li);
+            cv.block_ptrs += (size_t)P.s0 * e->max_blocks_per_seq;  // cu_block_nums[b] = b * max_blocks_per_seq: the part's sequence 0
+            TM_PROF(P_KV_STORE, TM_TRY(launch_kv_rope_store(qkv, e->q_heads, P.cu_q, e->d_k_len + P.s0, P.nseq, P.rows, e->d_rope, e->rope_max_pos,
+                                                           cv, st)));
+            TM_PROF(P_KV_STORE, TM_TRY(launch_flatten_kv(e->d_kflat, e->d_vflat, 1, e->d_cu_koff + P.s0, e->d_k_len + P.s0, P.nseq, max_k_len,
+                                                        kflat_stride, cv, st)));
+            PrefillAttnParams p{};
+            p.q          = qkv;
+            p.q_stride   = e->qkv_n;
+            p.out        = e->d_attn + (size_t)P.r0 * kq;
+            p.k          = e->d_kflat;
+            p.vt         = e->d_vflat;
+            p.k_stride   = kflat_stride;
+            p.cu_q_len   = P.cu_q;
+            p.cu_k_off   = e->d_cu_koff + P.s0;   // offsets into the flat K / V^T scratch of the WHOLE forward
+            p.k_len      = e->d_k_len + P.s0;
+            p.batch      = P.nseq;
+            p.max_q_len  = max_q_len;
+            p.q_heads    = e->q_heads;
+            p.kv_heads   = e->kv_heads;
+            p.scale_log2 = scale_log2;
+            TM_PROF(P_ATTN, TM_TRY(launch_prefill_attention(p, st)));
+            TM_PROF(P_GEMM_O, TM_TRY(linear_plain(e, L.wo, e->d_attn + (size_t)P.r0 * kq, kq, e->d_tmp + off, H, P.rows, false)));
+            TM_TRY(allreduce_rows_side(e, P.r0, P.rows, &done[h]));
+        }
+        for (int h = 0; h < 2; ++h) {
+            const Part&  P   = part[h];
+            const size_t off = (size_t)P.r0 * H;
+            TM_TRY(pipe_wait(e, done[h]));
+            TM_PROF(P_RES_NORM, TM_TRY(launch_residual_rmsnorm(e->d_x + off, e->d_resid + off, e->d_tmp + off, nullptr, 0, nullptr, L.ffn_norm, eps,
+                                                               P.rows, H, st)));
+            TM_PROF(P_GEMM_GATE_UP, TM_TRY(linear_plain(e, L.w13, e->d_x + off, H, e->d_act + (size_t)P.r0 * e->inter, e->inter, P.rows, true)));
+            TM_PROF(P_GEMM_DOWN, TM_TRY(linear_plain(e, L.w2, e->d_act + (size_t)P.r0 * e->inter, e->inter, e->d_tmp + off, H, P.rows, false)));
+            TM_TRY(allreduce_rows_side(e, P.r0, P.rows, &done[h]));
+        }
+    }
+    for (int h = 0; h < 2; ++h) {
+        const size_t off = (size_t)part[h].r0 * H;
+        TM_TRY(pipe_wait(e, done[h]));
+        TM_PROF(P_RES_NORM, TM_TRY(launch_residual_rmsnorm(e->d_x + off, e->d_resid + off, e->d_tmp + off, nullptr, 0, nullptr, e->final_norm, eps,
+                                                           part[h].rows, H, st)));
+    }
+    return 0;
+}
+
 // ---- RMSNorm folded into the decode GEMMs (tp = 1, dense u4 layers, M <= 64; NormFold in tm_kernels.h) ----------------------------
 // the tiling of a folded launch: the measured / heuristic pick when its kernel carries the folded epilogue, else the heuristic's
 static void fold_tiling(tm_engine* e, const LinearWeight& w, int M, int* shape, int* splits)
@@ -270,9 +351,17 @@ int forward(tm_engine* e, const int* d_ids, int M, int nseq, bool decode, int ma
     const bool  pipe     = !decode && !md && prefill_pipe_ok(e, M);
     const int   Ma       = pipe ? (M / 2 + 63) / 64 * 64 : 0;
     e->pipe_forwards += pipe ? 1 : 0;
+    bool two_mb = pipe && e->mb.seqs_a > 0 && e->mb.seqs_a < nseq && e->mb.rows_a > 0 && e->mb.rows_a < M;
+    for (int li = 0; two_mb && li < m.layers; ++li) {
+        two_mb = !e->layers[li].is_moe;
+    }
+    if (two_mb) {
+        e->pipe_mb_forwards += 1;
+        TM_TRY(forward_layers_two_microbatches(e, M, nseq, max_q_len, max_k_len, kflat_stride, scale_log2));
+    }
     bool        qkv_done = false;  // the previous layer's two-halves tail already projected this layer's QKV
     int         ss_tiles   = 0;  // > 0: d_x holds r . g of a folded producer, d_ss its sums of squares (the next GEMM applies the row factor)
-    for (int li = 0; li < m.layers; ++li) {
+    for (int li = 0; li < (two_mb ? 0 : m.layers); ++li) {
         Layer& L = e->layers[li];
         KvCacheView cv = cache_view(e, li);
         const bool fold = decode && fold_ok(e, L, M);
@@ -749,6 +838,28 @@ int prefill_slots(tm_engine* e, const int* const* seq_ids, const int* host_lens,
         TM_HIP_CHECK(hipMemcpyAsync(e->d_k_len, klen.data(), klen.size() * 4, hipMemcpyHostToDevice, e->stream));
         TM_HIP_CHECK(hipMemcpyAsync(e->d_cu_koff, koff.data(), koff.size() * 4, hipMemcpyHostToDevice, e->stream));
         TM_HIP_CHECK(hipMemcpyAsync(e->d_rows, rows.data(), rows.size() * 4, hipMemcpyHostToDevice, e->stream));
+        // tensor-parallel forward through RCCL: the sequence boundary nearest to half the rows makes two micro-batches that leapfrog
+        // through the layers (forward_layers_two_microbatches); none with both sides >= pipe_min_rows / 2 -> the row-half schedule
+        e->mb = {};
+        std::vector<int> cu_q_b;  // lives until the synchronisation at the end of this iteration, like the vectors above
+        static const bool mb_on = !getenv("TM_PIPE_MICROBATCH") || atoi(getenv("TM_PIPE_MICROBATCH")) != 0;  // A/B switch: 0 = row halves only
+        if (mb_on && !merge && nseq >= 2 && prefill_pipe_ok(e, tokens)) {
+            int best = 1;
+            for (int s2 = 2; s2 < nseq; ++s2) {
+                if (std::abs(2 * cu_q[s2] - tokens) < std::abs(2 * cu_q[best] - tokens)) {
+                    best = s2;
+                }
+            }
+            if (2 * std::min(cu_q[best], tokens - cu_q[best]) >= e->pipe_min_rows) {
+                cu_q_b.assign(cu_q.begin() + best, cu_q.end());
+                for (int& v : cu_q_b) {
+                    v -= cu_q[best];
+                }
+                TM_HIP_CHECK(hipMemcpyAsync(e->d_cu_q_b, cu_q_b.data(), cu_q_b.size() * 4, hipMemcpyHostToDevice, e->stream));
+                e->mb.seqs_a = best;
+                e->mb.rows_a = cu_q[best];
+            }
+        }
         // shift the block tables so that slot 0 of this iteration is sequence b0
         uint64_t* saved_ptrs = e->d_block_ptrs;
         e->d_block_ptrs += (size_t)(slot0 + b0) * e->max_blocks_per_seq;
@@ -757,6 +868,7 @@ int prefill_slots(tm_engine* e, const int* const* seq_ids, const int* host_lens,
         const int rc    = forward(e, e->d_prefill_ids, nd + tokens, nseq, false, max_q, max_k, e->kflat_stride, slot0 + b0,
                                   merge ? &md : nullptr);
         e->d_block_ptrs = saved_ptrs;
+        e->mb           = {};
         if (rc) {
             return rc;
         }

@@ -87,7 +87,11 @@ struct tm_engine {
     std::vector<hipEvent_t> pipe_events;      // (ready, done) pairs of the side-stream all-reduces of ONE forward
     size_t       pipe_events_used = 0;
     int          pipe_min_rows    = 1024;     // TM_PIPE_MIN_ROWS: smallest row half (forwards below twice this stay unsplit)
-    int64_t      pipe_forwards = 0, pipe_allreduces = 0;   // tm_engine_comm_overlap_info
+    int64_t      pipe_forwards = 0, pipe_mb_forwards = 0, pipe_allreduces = 0;   // tm_engine_comm_overlap_info
+    // set by prefill_slots() around ONE forward: the forward's sequences [0, seqs_a) own its rows [0, rows_a) -- two micro-batches that
+    // share nothing between the embedding and the lm_head (forward_layers_two_microbatches); seqs_a = 0: no such split (one sequence,
+    // a lopsided boundary, a mixed forward) -> the row-half schedule inside every layer (forward_tail_two_halves)
+    struct { int seqs_a = 0, rows_a = 0; } mb;
     float        emulate_ar_gbps = 0.f;       // TM_EMULATE_AR_GBPS, one-rank emulation only: stand-in for an exchange's duration (engine_comm.hip)
     // mixed forwards: the decode rows' attention runs on this stream beside the prefill rows' K/V store -> flatten -> attention
     // on the engine stream (reference: aux_stream_ + event fork / join, unified_attention_layer.cc:613-651)
@@ -149,6 +153,7 @@ struct tm_engine {
     // batch state (device)
     int *d_next_ids = nullptr;
     int *d_ids = nullptr, *d_k_len = nullptr, *d_cu_q = nullptr, *d_cu_koff = nullptr, *d_rows = nullptr;
+    int *d_cu_q_b = nullptr;   // cu_q of the second micro-batch of a tensor-parallel prefill forward, counted from ITS first row
     int *d_generated = nullptr, *d_step = nullptr;
     int *d_prefill_ids = nullptr;
     half_t* d_argmax_val = nullptr;

@@ -288,11 +288,11 @@ class Engine:
         b, n, g = C.c_int(), C.c_int(), C.c_int()
         _ffi.check(self._lib.tm_engine_comm_info(self._h, C.byref(b), C.byref(n), C.byref(g)))
         name = {0: 'none', 1: 'rccl', 2: 'native-p2p', 3: 'native-p2p (decode) + rccl (large forwards)'}[b.value]
-        ss, fw, ar = C.c_int(), C.c_int64(), C.c_int64()
-        _ffi.check(self._lib.tm_engine_comm_overlap_info(self._h, C.byref(ss), C.byref(fw), C.byref(ar)))
+        ss, fw, mbf, ar = C.c_int(), C.c_int64(), C.c_int64(), C.c_int64()
+        _ffi.check(self._lib.tm_engine_comm_overlap_info(self._h, C.byref(ss), C.byref(fw), C.byref(mbf), C.byref(ar)))
         # side_stream: prefill-sized forwards run their all-reduces on a side stream under the other row half's GEMMs
         return dict(backend=name, ranks=n.value, hipgraph=bool(g.value), side_stream=bool(ss.value), overlapped_forwards=fw.value,
-                    side_stream_allreduces=ar.value)
+                    microbatch_forwards=mbf.value, side_stream_allreduces=ar.value)
 
     def close(self):
         if self._h:

@@ -101,20 +101,26 @@ def test_engine_collective_path_single_rank(cuda, monkeypatch, graph_comm, side_
     assert np.abs(l0.astype(np.float32) - l1.astype(np.float32)).max() <= 2e-3
 
 
-@pytest.mark.parametrize('min_rows,chunk', [(256, 1024), (64, 1024), (64, 448)])
-def test_engine_prefill_allreduce_on_side_stream(cuda, monkeypatch, min_rows, chunk):
-    """Tensor-parallel prefill forwards split their row-wise part (wo .. next w_qkv) into two row halves and run each half's RCCL
-    all-reduce on the side stream under the other half's GEMMs (engine_forward.hip: forward_tail_two_halves; TM_COMM_STREAM, default
-    on).  Driven on one GPU through a 1-rank communicator (TM_FORCE_COMM=1, a 1-rank sum is the identity): the event choreography, the
-    row offsets of every buffer and the hand-over of the next layer's QKV projection must reproduce (a) the same engine with every
-    collective on the engine stream (TM_COMM_STREAM=0) and (b) the collective-free engine -- tokens equal, logits to the rounding of
-    a different GEMM tiling per launch size -- and (c) the oracle.  chunk = 448: the prompts span two forwards (uneven halves, a
-    short last forward that stays unsplit); the decode steps behind the prefill run on the engine stream as before."""
+@pytest.mark.parametrize('min_rows,chunk,lens,want_fw,want_mb', [
+    (256, 1024, (300, 77, 190, 33), 1, 1),    # one forward, boundary 300 | 300: two micro-batches
+    (64, 448, (300, 77, 190, 33), 2, 2),      # two forwards (448 + 152 rows, the second starts inside a sequence: history), uneven parts
+    (64, 1024, (560, 20), 1, 0),              # lopsided boundary: the row-half schedule inside every layer
+    (256, 1024, (600,), 1, 0),                # one sequence: row halves
+])
+def test_engine_prefill_allreduce_on_side_stream(cuda, monkeypatch, min_rows, chunk, lens, want_fw, want_mb):
+    """Tensor-parallel prefill forwards run their RCCL all-reduces on the side stream under the other half's kernels (TM_COMM_STREAM,
+    default on): at a sequence boundary near half the rows the forward becomes two micro-batches that leapfrog through ALL layers
+    (engine_forward.hip: forward_layers_two_microbatches), otherwise the row-wise part of every layer (wo .. next w_qkv) runs as two
+    row halves (forward_tail_two_halves).  Driven on one GPU through a 1-rank communicator (TM_FORCE_COMM=1, a 1-rank sum is the
+    identity): the event choreography, the row / sequence offsets of every buffer, the shifted block table and the rebased cu_q of the
+    second micro-batch must reproduce (a) the same engine with every collective on the engine stream (TM_COMM_STREAM=0), (b) the
+    collective-free engine -- tokens equal, logits to the rounding of a different GEMM tiling per launch size -- and (c) the oracle.
+    The decode steps behind the prefill run on the engine stream as before."""
     cfg = o.ModelConfig(hidden=256, layers=3, q_heads=4, kv_heads=2, head_dim=128, inter=512, vocab=1024,
                         kv_bits=8, rope=o.RopeParam(128, 500000.0, 'llama3', 8.0, 1.0, 4.0, 8192))
     w = o.make_synthetic_weights(cfg, seed=5)
     rng = np.random.default_rng(2)
-    prompts = [rng.integers(0, cfg.vocab, n).astype(np.int32) for n in (300, 77, 190, 33)]     # 600 tokens
+    prompts = [rng.integers(0, cfg.vocab, n).astype(np.int32) for n in lens]
 
     def run(force, side):
         monkeypatch.setenv('TM_PIPE_MIN_ROWS', str(min_rows))
@@ -124,7 +130,7 @@ def test_engine_prefill_allreduce_on_side_stream(cuda, monkeypatch, min_rows, ch
         else:
             monkeypatch.delenv('TM_FORCE_COMM', raising=False)
             monkeypatch.setenv('TM_FOLD_NORM', '0')
-        eng = Engine.from_model_config(cfg, max_batch_size=4, session_len=512, quant_policy=8, max_prefill_token_num=chunk, use_graph=1)
+        eng = Engine.from_model_config(cfg, max_batch_size=4, session_len=1024, quant_policy=8, max_prefill_token_num=chunk, use_graph=1)
         if force:
             eng.comm_init(Engine.comm_unique_id())
         eng.load_weights(export_weights(cfg, w))
@@ -141,15 +147,14 @@ def test_engine_prefill_allreduce_on_side_stream(cuda, monkeypatch, min_rows, ch
     piped = run(True, 1)
     assert base[3]['side_stream'] is False and base[3]['overlapped_forwards'] == 0
     assert serial[3]['side_stream'] is False and serial[3]['side_stream_allreduces'] == 0
-    # 600 tokens: one forward of 600 rows, or 448 + 152 (the second one splits only when both halves reach min_rows)
-    want_fw = 1 if chunk == 1024 else (2 if 152 >= 2 * min_rows else 1)
-    assert piped[3]['side_stream'] is True and piped[3]['overlapped_forwards'] == want_fw, piped[3]
-    assert piped[3]['side_stream_allreduces'] == 4 * cfg.layers * want_fw, piped[3]
+    info = piped[3]
+    assert info['side_stream'] is True and (info['overlapped_forwards'], info['microbatch_forwards']) == (want_fw, want_mb), info
+    assert info['side_stream_allreduces'] == 4 * cfg.layers * want_fw, info
     for other in (base, serial):
         assert np.array_equal(piped[0], other[0])
         for a, b in ((piped[1], other[1]), (piped[2], other[2])):
             assert np.abs(a.astype(np.float32) - b.astype(np.float32)).max() <= 2e-3
-    om = o.OracleModel(cfg, w, batch=4, max_ctx=512)
+    om = o.OracleModel(cfg, w, batch=len(prompts), max_ctx=1024)
     _, ref = om.forward([p.tolist() for p in prompts])
     assert np.abs(piped[1].astype(np.float32) - ref.astype(np.float32)).max() <= 3e-2
 
