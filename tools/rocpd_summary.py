@@ -14,7 +14,49 @@ def main():
         i = sys.argv.index('--window-s')
         window_s = float(sys.argv[i + 1])
         del sys.argv[i:i + 2]
+    overlap = None
+    if '--overlap' in sys.argv:    # how much of the kernels named *x* ran WHILE other kernels ran (side-stream concurrency evidence)
+        i = sys.argv.index('--overlap')
+        overlap = sys.argv[i + 1]
+        del sys.argv[i:i + 2]
     db = sqlite3.connect(sys.argv[1])
+    if overlap is not None:
+        cur = db.cursor()
+        mine = sorted(cur.execute("select start, end from kernels where name like ?", (f'%{overlap}%',)).fetchall())
+        rest = sorted(cur.execute("select start, end, name from kernels where name not like ?", (f'%{overlap}%',)).fetchall())
+        # union of the other kernels' intervals
+        uni = []
+        for s_, e_, _ in rest:
+            if uni and s_ <= uni[-1][1]:
+                uni[-1][1] = max(uni[-1][1], e_)
+            else:
+                uni.append([s_, e_])
+        import bisect
+        starts = [u[0] for u in uni]
+        tot = cov = 0
+        for s_, e_ in mine:
+            tot += e_ - s_
+            j = max(0, bisect.bisect_right(starts, s_) - 1)
+            while j < len(uni) and uni[j][0] < e_:
+                cov += max(0, min(e_, uni[j][1]) - max(s_, uni[j][0]))
+                j += 1
+        by = {}
+        k = 0
+        for s_, e_, n_ in rest:       # which kernels ran under them (by time)
+            while k < len(mine) and mine[k][1] <= s_:
+                k += 1
+            j = k
+            while j < len(mine) and mine[j][0] < e_:
+                ov = min(e_, mine[j][1]) - max(s_, mine[j][0])
+                if ov > 0:
+                    by[n_] = by.get(n_, 0) + ov
+                j += 1
+        print(f'kernels named *{overlap}*: {len(mine)} launches, {tot / 1e6:.2f} ms in total; {cov / 1e6:.2f} ms = {100.0 * cov / max(tot, 1):.1f} % of that time '
+              f'at least one OTHER kernel was running on the device (union of {len(rest)} other launches)')
+        print('other kernels by the time they spent under them:')
+        for n_, v in sorted(by.items(), key=lambda kv: -kv[1])[:12]:
+            print(f'  {n_[:90]:90s} {v / 1e6:9.2f} ms')
+        return
     if window_s is not None:
         cur = db.cursor()
         t_end = cur.execute("select max(end) from kernels").fetchone()[0]
