@@ -491,6 +491,12 @@ int tm_engine_wait(tm_engine* e, int64_t req_id, int have_tokens, int timeout_ms
 
 /* The scheduler by itself (host-only bookkeeping: queue, slots, block accounting) -- what the engine embeds,
  * exported so that its policy is testable without a GPU (engine/scheduler.cc:1018-1078 at the level used here). */
+/* Host-only, exported for the CPU tests like the scheduler below: where a tensor-parallel prefill forward of nseq sequences (row offsets
+ * cu_q[0 .. nseq], cu_q[0] = 0) splits into the two micro-batches whose all-reduces overlap the other one's kernels (DESIGN.md 6;
+ * no reference counterpart: the reference hides the exchange in a fused kernel, comm/cuda_ipc/fused_allreduce.cu:406-500).
+ * *seqs_a = sequences of the first micro-batch, *rows_a = its rows; 0 / 0: no usable boundary (fewer than two sequences, or the smaller side
+ * below min_rows / 2 rows) -- the engine then splits the row-wise part of every layer by rows instead. */
+int tm_prefill_split(const int* cu_q, int nseq, int min_rows, int* seqs_a, int* rows_a);
 typedef struct tm_sched tm_sched;
 int tm_sched_create(tm_sched** out, int max_batch, int num_blocks, int session_len);
 int tm_sched_destroy(tm_sched* s);

@@ -133,6 +133,7 @@ _SIGNATURES = {
     'tm_debug_grouped_tile': (c_int, [c_int, c_int, c_int, c_int, POINTER(c_int)]),
     'tm_engine_comm_drop_rccl': (c_int, [c_void_p]),
     'tm_engine_comm_info': (c_int, [c_void_p, POINTER(c_int), POINTER(c_int), POINTER(c_int)]),
+    'tm_prefill_split': (c_int, [c_void_p, c_int, c_int, POINTER(c_int), POINTER(c_int)]),
     'tm_engine_comm_overlap_info': (c_int, [c_void_p, POINTER(c_int), POINTER(c_int64), POINTER(c_int64), POINTER(c_int64)]),
     'tm_debug_tiling_candidates': (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_int, POINTER(c_int)]),
     'tm_engine_comm_native_export': (c_int, [c_void_p, c_int, c_void_p]),

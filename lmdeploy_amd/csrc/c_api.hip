@@ -603,6 +603,18 @@ struct tm_sched {
     tm_sched(int b, int n, int s): impl(b, n, s) {}
 };
 
+int tm_prefill_split(const int* cu_q, int nseq, int min_rows, int* seqs_a, int* rows_a)
+{
+    TM_REQUIRE(cu_q && seqs_a && rows_a, "null pointer");
+    TM_REQUIRE(nseq >= 1 && cu_q[0] == 0, "cu_q: nseq + 1 ascending row offsets from 0");
+    for (int s = 0; s < nseq; ++s) {
+        TM_REQUIRE(cu_q[s + 1] > cu_q[s], "cu_q: nseq + 1 ascending row offsets from 0");
+    }
+    *seqs_a = tmk::prefill_microbatch_split(cu_q, nseq, min_rows);
+    *rows_a = *seqs_a > 0 ? cu_q[*seqs_a] : 0;
+    return 0;
+}
+
 int tm_sched_create(tm_sched** out, int max_batch, int num_blocks, int session_len)
 {
     TM_REQUIRE(out && max_batch >= 1 && num_blocks >= 1 && session_len >= 2, "bad scheduler geometry");

@@ -844,13 +844,8 @@ int prefill_slots(tm_engine* e, const int* const* seq_ids, const int* host_lens,
         std::vector<int> cu_q_b;  // lives until the synchronisation at the end of this iteration, like the vectors above
         static const bool mb_on = !getenv("TM_PIPE_MICROBATCH") || atoi(getenv("TM_PIPE_MICROBATCH")) != 0;  // A/B switch: 0 = row halves only
         if (mb_on && !merge && nseq >= 2 && prefill_pipe_ok(e, tokens)) {
-            int best = 1;
-            for (int s2 = 2; s2 < nseq; ++s2) {
-                if (std::abs(2 * cu_q[s2] - tokens) < std::abs(2 * cu_q[best] - tokens)) {
-                    best = s2;
-                }
-            }
-            if (2 * std::min(cu_q[best], tokens - cu_q[best]) >= e->pipe_min_rows) {
+            const int best = prefill_microbatch_split(cu_q.data(), nseq, e->pipe_min_rows);  // scheduler.h
+            if (best > 0) {
                 cu_q_b.assign(cu_q.begin() + best, cu_q.end());
                 for (int& v : cu_q_b) {
                     v -= cu_q[best];

@@ -279,4 +279,27 @@ private:
     std::map<int64_t, SchedRequest> reqs_;
 };
 
+// Tensor-parallel prefill forward of `nseq` sequences with row offsets cu_q[0 .. nseq] (cu_q[0] = 0): the sequence boundary nearest to
+// half the rows, so that the forward can run as two micro-batches that leapfrog through the layers (engine_forward.hip:
+// forward_layers_two_microbatches; each one's all-reduce on the side stream under the other's kernels).  Returns the number of
+// sequences of the first micro-batch, 0 when there is no usable boundary: fewer than two sequences, or the smaller side would fall
+// below min_rows / 2 rows (a lopsided split hides little and halves nothing; the forward then splits by rows inside every layer).
+// Ties go to the earlier boundary.  Pure host logic: tm_prefill_split exports it for the CPU tests.
+inline int prefill_microbatch_split(const int* cu_q, int nseq, int min_rows)
+{
+    if (nseq < 2) {
+        return 0;
+    }
+    const int tokens = cu_q[nseq];
+    int       best   = 1;
+    for (int s = 2; s < nseq; ++s) {
+        const int d0 = 2 * cu_q[best] - tokens, d1 = 2 * cu_q[s] - tokens;
+        if ((d1 < 0 ? -d1 : d1) < (d0 < 0 ? -d0 : d0)) {
+            best = s;
+        }
+    }
+    const int small = cu_q[best] < tokens - cu_q[best] ? cu_q[best] : tokens - cu_q[best];
+    return 2 * small >= min_rows && small > 0 ? best : 0;
+}
+
 }  // namespace tmk

@@ -424,3 +424,34 @@ def test_two_phase_step_protocol_model(slots, seed, async_on):
         assert out[rid] == [(rid, k) for k in range(n)]
     assert s.counts()[0] == 0 and s.counts()[2] == 64
     assert (overlapped > 0) == (async_on and True)
+
+
+def test_prefill_microbatch_split():
+    """Tensor-parallel prefill: the forward splits at the sequence boundary nearest to half its rows into two micro-batches
+    whose all-reduces run under the other one's kernels; no usable boundary -> 0 (row halves inside every layer).  Pure host logic of
+    the engine (scheduler.h: prefill_microbatch_split), driven through the C-ABI without a GPU."""
+    lib = _ffi.load()
+
+    def split(lens, min_rows):
+        cu = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+        sa, ra = C.c_int(-1), C.c_int(-1)
+        _ffi.check(lib.tm_prefill_split(cu.ctypes.data, len(lens), min_rows, C.byref(sa), C.byref(ra)))
+        assert ra.value == (int(cu[sa.value]) if sa.value else 0)
+        return sa.value, ra.value
+
+    assert split([1024] * 8, 1024) == (4, 4096)                 # the bench's prefill forward: 8 x 1024 tokens
+    assert split([300, 77, 190, 33], 256) == (1, 300)           # 300 | 300
+    assert split([300, 77, 71], 64) == (1, 300)                 # 300 | 148: nearer to half than 377 | 71
+    assert split([119, 33], 64) == (1, 119)                     # smaller side 33 rows: 66 >= 64
+    assert split([119, 31], 64) == (0, 0)                       # 62 < 64: lopsided -> row halves
+    assert split([560, 20], 64) == (0, 0)
+    assert split([600], 64) == (0, 0)                           # one sequence
+    assert split([10, 10, 10, 10, 2000], 64) == (4, 40)         # the only boundaries are far from the middle: the nearest one, 80 >= 64
+    assert split([10, 10, 10, 10, 2000], 128) == (0, 0)
+    assert split([500, 500, 500, 500], 64) == (2, 1000)         # exact middle
+    assert split([400, 200, 200, 400], 64) == (2, 600)          # ties (400 | 800 vs 800 | 400 do not occur here): the middle boundary
+    assert split([100, 400, 100], 64) == (1, 100)               # |200 - 600| = |1000 - 600|: the earlier boundary
+    # malformed offsets are refused
+    bad = np.array([0, 5, 5], np.int32)
+    sa, ra = C.c_int(), C.c_int()
+    assert lib.tm_prefill_split(bad.ctypes.data, 2, 64, C.byref(sa), C.byref(ra)) != 0
