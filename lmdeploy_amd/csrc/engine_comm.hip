@@ -45,13 +45,18 @@ static int allreduce_hidden(tm_engine* e, half_t* buf, int M)
     return 0;
 }
 
-// ---- prefill forwards of a tensor-parallel rank: all-reduce on the side stream UNDER the other row half's GEMMs --------------------
-// Every operator between the attention of a layer and the attention of the next (wo, all-reduce, residual + RMSNorm, w1w3, w2,
-// all-reduce, residual + RMSNorm, next w_qkv) is row-wise, so a forward of M rows runs them as two row halves A / B
-// (forward_tail_two_halves, engine_forward.hip): while RCCL sums half A's partial outputs over xGMI on `comm_stream`, the engine
-// stream contracts half B -- the north star's "RCCL all-reduce overlapped on a side HIP stream".  The reference hides its collective
-// inside a fused kernel instead (comm/cuda_ipc/fused_allreduce.cu:406-500); at prefill sizes (8192 x 4096 fp16 = 64 MB per
-// all-reduce, two per layer) the exchange is bandwidth, not latency, and a second stream is the form that hides bandwidth.
+// ---- prefill forwards of a tensor-parallel rank: all-reduces on the side stream UNDER the other half's kernels ----------------------
+// The north star's "RCCL all-reduce over xGMI overlapped on a side HIP stream".  A prefill-sized forward runs as two halves whose
+// all-reduces (RCCL, `comm_stream`) sit under the other half's kernels on the engine stream (engine_forward.hip):
+//   * two MICRO-BATCHES split at a sequence boundary (prefill_slots -> scheduler.h: prefill_microbatch_split): they share nothing between
+//     the embedding and the lm_head, attention included, and leapfrog through all layers (forward_layers_two_microbatches) -- the default;
+//   * without a usable boundary, two ROW HALVES of the row-wise part of every layer: wo, all-reduce, residual + RMSNorm, w1w3, w2,
+//     all-reduce, residual + RMSNorm, next w_qkv (forward_tail_two_halves).
+// The reference hides its collective inside a fused kernel instead (comm/cuda_ipc/fused_allreduce.cu:406-500); at prefill sizes
+// (8192 x 4096 fp16 = 64 MB per all-reduce, two per layer) the exchange is bandwidth, not latency, and a second stream is the form that
+// hides bandwidth.  One communicator, two streams, never concurrently: the engine stream waits for the side stream's last event before
+// it enqueues a collective of its own (lm_head all-gather, decode steps).  Measured against an emulated exchange on one GPU only
+// (profiles/r05_prefill_overlap_emulated_exchange.txt, profiles/r05_prefill_overlap_kernel_trace.txt).
 // Events come from a per-engine pool (one pair per all-reduce of a forward: nothing is re-recorded while a wait on it may be pending).
 static int pipe_event(tm_engine* e, hipEvent_t* ev)
 {
@@ -67,7 +72,7 @@ static int pipe_event(tm_engine* e, hipEvent_t* ev)
 bool prefill_pipe_ok(const tm_engine* e, int M)
 {
     // RCCL is what serves a forward of this size (reduce_residual_norm's first branch takes the native communicator), the side
-    // stream exists, and both halves are whole prefill tiles
+    // stream exists, and the forward is large enough for an exchange to be worth eight cross-stream hand-offs per layer
     return e->use_comm && e->comm && e->comm_overlap && e->comm_stream && !(e->p2p_ready && M <= e->p2p_rows)
            && M >= 2 * e->pipe_min_rows;
 }
@@ -202,10 +207,11 @@ int tm_engine_comm_init(tm_engine* e, const void* host_id128)
     memcpy(&id, host_id128, sizeof(id));
     TM_HIP_CHECK(hipSetDevice(e->cfg.device));
     TM_NCCL_CHECK(ncclCommInitRank(&e->comm, e->cfg.tp, id, e->cfg.rank));
-    // TM_COMM_STREAM (default 1): prefill-sized forwards run their all-reduces on a side stream under the other row half's GEMMs
-    // (allreduce_rows_side above); 0 = every collective on the engine stream.  TM_PIPE_MIN_ROWS (1024): smallest row half -- a forward splits from 2048 rows
-    // (16 MB per all-reduce at hidden 4096): below that the eight cross-stream hand-offs per layer (~5 us each, measured as +14 % on a
-    // prefill whose exchange is free, profiles/r05_prefill_overlap_emulated_exchange.txt) cost more than the exchange they hide.
+    // TM_COMM_STREAM (default 1): prefill-sized forwards run their all-reduces on a side stream under the other half's kernels
+    // (allreduce_rows_side above); 0 = every collective on the engine stream.  TM_PIPE_MIN_ROWS (1024): a forward splits from 2048 rows
+    // (16 MB per all-reduce at hidden 4096): below that the doubled launches and the eight cross-stream hand-offs per layer (measured as
+    // + 14 ... 28 % on a prefill whose exchange is free, profiles/r05_prefill_overlap_emulated_exchange.txt) cost more than the exchange
+    // they hide; a micro-batch may be as small as half of it (prefill_microbatch_split).
     const char* cs   = getenv("TM_COMM_STREAM");
     const char* pm   = getenv("TM_PIPE_MIN_ROWS");
     const char* em   = getenv("TM_EMULATE_AR_GBPS");
