@@ -234,3 +234,97 @@ def test_tp2_measured_dispatch_tables_travel_from_rank0(tmp_path):
     assert ret[0] == ret[1]
     assert ret[0][:5] == [(3, 4), (6, 1), (2, 2), (6, 1), (12, 1)]
     assert ret[0][5] == (1, 2, 4, 1) and ret[0][6] == (2, 4, 8, 1) and ret[0][7] == 64
+
+
+def _mb_worker(rank, world, port, cfg, w, seqs, split, ret):
+    """One rank of a tp = 2 prefill forward over several sequences, twice: `serial` = every collective over all rows where the engine
+    calls RCCL on its own stream; `piped` = the engine's two-micro-batch choreography (engine_forward.hip:
+    forward_layers_two_microbatches) with ASYNCHRONOUS all-reduces issued in the engine's order -- attention block A, AR(wo A) in
+    flight under attention block B, AR(wo B) under FFN A, AR(w2 A) under FFN B, AR(w2 B) under the next attention block A -- and
+    waited for exactly where the engine stream waits for the side stream's event."""
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    s = loader.export_weights(cfg, w, world, rank)
+    D = cfg.head_dim
+    hq, hkv = cfg.q_heads // world, max(1, cfg.kv_heads // world)
+    cu = np.concatenate([[0], np.cumsum([len(t) for t in seqs])])
+    ids = np.concatenate(seqs)
+
+    def attn_block(x, s0, s1):
+        """rows of sequences [s0, s1): w_qkv, RoPE, causal attention per sequence (local heads), wo -> partial sums"""
+        r0, r1 = cu[s0], cu[s1]
+        qkv = _lin(s, p + '.attention.w_qkv', x[r0:r1])
+        out = np.zeros((r1 - r0, hq * D), f16)
+        for b in range(s0, s1):
+            a, e = cu[b] - r0, cu[b + 1] - r0
+            T = e - a
+            cos, sin = o.rope_cos_sin(cfg.rope, np.arange(T))
+            q = o.rope_apply(qkv[a:e, :hq * D].reshape(T, hq, D), cos, sin)
+            k = o.rope_apply(qkv[a:e, hq * D:(hq + hkv) * D].reshape(T, hkv, D), cos, sin)
+            v = qkv[a:e, (hq + hkv) * D:].reshape(T, hkv, D)
+            out[a:e] = o.prefill_attention(q, k.transpose(1, 0, 2), v.transpose(1, 0, 2)).reshape(T, hq * D)
+        return _lin(s, p + '.attention.wo', out)
+
+    class Async:
+        """fp16 partial rows -> all-reduce in flight (the side stream); .wait() = the engine stream's wait for its event"""
+        def __init__(self, x):
+            self.t = torch.from_numpy(x.astype(np.float32))
+            self.h = dist.all_reduce(self.t, async_op=True)
+
+        def wait(self):
+            self.h.wait()
+            return self.t.numpy().astype(f16)
+
+    out = {}
+    for mode in ('serial', 'piped'):
+        resid = s['tok_embeddings.weight'][ids].copy()
+        x = o.rmsnorm(resid, s['layers.0.attention_norm.weight'], cfg.rms_eps)
+        parts = [(0, len(seqs))] if mode == 'serial' else [(0, split), (split, len(seqs))]
+        rows = [slice(cu[a], cu[b]) for a, b in parts]
+        pend = [None] * len(parts)
+        for li in range(cfg.layers):
+            p = f'layers.{li}'
+            for i, (a, b) in enumerate(parts):
+                if li > 0:      # this part's w2 sum of the previous layer
+                    resid[rows[i]], x[rows[i]] = o.residual_rmsnorm(resid[rows[i]], pend[i].wait(), s[p + '.attention_norm.weight'], cfg.rms_eps)
+                pend[i] = Async(attn_block(x, a, b))                                  # collective #1 of the part, in flight
+            for i in range(len(parts)):
+                resid[rows[i]], x[rows[i]] = o.residual_rmsnorm(resid[rows[i]], pend[i].wait(), s[p + '.ffn_norm.weight'], cfg.rms_eps)
+                act = _lin(s, p + '.feed_forward.w1w3', x[rows[i]], gated=True)
+                pend[i] = Async(_lin(s, p + '.feed_forward.w2', act))                 # collective #2 of the part, in flight
+        for i in range(len(parts)):
+            resid[rows[i]], x[rows[i]] = o.residual_rmsnorm(resid[rows[i]], pend[i].wait(), s['norm.weight'], cfg.rms_eps)
+        out[mode] = (resid.copy(), x.copy())
+    if rank == 0:
+        ret['serial'], ret['piped'] = out['serial'], out['piped']
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_tp2_prefill_two_microbatches_match_serial_collectives():
+    """The overlap schedule of tensor-parallel prefill on CPU, world size 2 over gloo: the forward is split where the
+    engine's own policy splits it (tm_prefill_split), the two micro-batches leapfrog through the layers with their all-reduces in
+    flight under the other one's blocks, both ranks issue the collectives in the same order (no deadlock), and the residual stream
+    and the final normed rows equal the serial schedule's BIT FOR BIT -- every operator between two attention blocks is row-wise and
+    attention never crosses a sequence, so which rows share a collective cannot change a row.  Also against the unsharded oracle."""
+    import ctypes as C
+    from lmdeploy_amd import _ffi
+    cfg = o.ModelConfig(hidden=256, layers=2, q_heads=4, kv_heads=2, head_dim=128, inter=512, vocab=512, kv_bits=16)
+    w = o.make_synthetic_weights(cfg, seed=11)
+    rng = np.random.default_rng(5)
+    seqs = [rng.integers(0, cfg.vocab, n) for n in (7, 5, 9)]
+    cu = np.concatenate([[0], np.cumsum([len(t) for t in seqs])]).astype(np.int32)
+    sa, ra = C.c_int(), C.c_int()
+    _ffi.check(_ffi.load().tm_prefill_split(cu.ctypes.data, len(seqs), 8, C.byref(sa), C.byref(ra)))
+    assert (sa.value, ra.value) == (2, 12)                  # 12 | 9 rows
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_mb_worker, args=(2, _free_port(), cfg, w, seqs, sa.value, ret), nprocs=2, join=True)
+    for a, b, what in zip(ret['serial'], ret['piped'], ('residual stream', 'final normed rows')):
+        assert a.shape == (21, 256) and np.array_equal(a.view(np.uint16), b.view(np.uint16)), what
+    m = o.OracleModel(cfg, w, batch=3, max_ctx=64)
+    m.forward(seqs)
+    r, rr = ret['piped'][0].astype(np.float32), m.last_resid.astype(np.float32)
+    assert r.shape == rr.shape
+    assert np.all(np.abs(r - rr) <= 4e-3 + 2.0**-8 * np.abs(rr)), f'sharded residual stream differs: {np.abs(r - rr).max()}'
