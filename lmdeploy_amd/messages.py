@@ -237,8 +237,10 @@ class TurbomindEngineConfig:
         for k, default in unsupported.items():
             if getattr(self, k) != default:
                 raise NotImplementedError(f'TurbomindEngineConfig.{k}={getattr(self, k)!r} is outside the MI355X hot path')
-        if self.communicator != 'nccl':
-            raise NotImplementedError('communicator must be "nccl" (RCCL on ROCm)')
+        # the reference's values (src/turbomind/comm/device_comm.cc:14-30): 'nccl' = RCCL on ROCm; 'native' / 'cuda-ipc' = its in-house
+        # communicator -> here the native P2P communicator (csrc/comm_p2p.hip) for the decode-sized exchanges, RCCL kept for prefill
+        if self.communicator not in ('nccl', 'native', 'cuda-ipc'):
+            raise ValueError(f'communicator={self.communicator!r}: "nccl" (RCCL on ROCm), "native" or "cuda-ipc" (the native P2P communicator)')
 
 
 @dataclass

@@ -77,17 +77,21 @@ class Pipeline:
             rows = cfg.max_batch_size or 64
             # ranks that share a device (a 1-GPU box driving tp = 2 for bring-up): RCCL refuses duplicate devices -> native P2P communicator
             want_rccl = len(set(devices[r % len(devices)] for r in range(cfg.tp))) == cfg.tp
+            want_native = cfg.communicator in ('native', 'cuda-ipc')    # the reference's names for its in-house communicator
             if comm_unique_id is not None:              # expert path: the caller launched one process per GPU and broadcast the id
+                if want_native:
+                    raise ValueError(f'communicator={cfg.communicator!r} needs the one-call form (the ranks exchange IPC handles through '
+                                     f'the rank group); externally launched ranks run on RCCL, or call Engine.comm_native_setup themselves')
                 self.engine.comm_init(comm_unique_id)
             elif _tp_link is not None:                  # a worker of the one-call form
-                _tp_link.setup_comm(self.engine, want_rccl, rows)
+                _tp_link.setup_comm(self.engine, want_rccl, rows, want_native)
             else:                                       # the one-call form: this process is rank 0 and owns the other ranks
                 if rank != 0:
                     raise ValueError('tp > 1 with rank != 0 needs comm_unique_id (externally launched ranks)')
                 from .turbomind import tp_group
                 self._group = tp_group.ParentLink(cfg.tp, model_path, cfg)
                 try:
-                    self._comm_backend = self._group.setup_comm(self.engine, want_rccl, rows)
+                    self._comm_backend = self._group.setup_comm(self.engine, want_rccl, rows, want_native)
                 except Exception:
                     self._group.close()
                     raise

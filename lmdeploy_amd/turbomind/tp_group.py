@@ -35,9 +35,13 @@ MIRRORED = ('prefill', 'decode', 'release', 'set_sampling', 'set_logits_params',
 _TIMEOUT_S = float(os.environ.get('TM_TP_GROUP_TIMEOUT_S', '600'))
 
 
-def _setup_comm(eng: Engine, want_rccl: bool, uid: bytes, all_gather, rows: int) -> str:
+def _setup_comm(eng: Engine, want_rccl: bool, uid: bytes, all_gather, rows: int, want_native: bool = False) -> str:
     """The same sequence on every rank: RCCL unless the ranks share a device (RCCL refuses duplicate devices); if ANY rank failed,
-    ALL ranks drop RCCL and bring up the native P2P communicator (fused all-reduce + residual + RMSNorm, comm_p2p.hip)."""
+    ALL ranks drop RCCL and bring up the native P2P communicator (fused all-reduce + residual + RMSNorm, comm_p2p.hip).
+    want_native (`TurbomindEngineConfig.communicator` = 'native' / 'cuda-ipc', the reference's names for its own in-house communicator,
+    src/turbomind/comm/device_comm.cc:14-30): the native communicator serves the decode-sized forwards -- one fused launch per
+    exchange, as the reference's AllreduceResidualBiasRMSnorm -- and RCCL, where it came up on every rank, keeps the prefill-sized
+    ones (side-stream overlap)."""
     ok = False
     if want_rccl:
         try:
@@ -47,7 +51,10 @@ def _setup_comm(eng: Engine, want_rccl: bool, uid: bytes, all_gather, rows: int)
             ok = False
     oks = all_gather(ok)
     if want_rccl and all(oks):
-        return 'rccl'
+        if not want_native:
+            return 'rccl'
+        eng.comm_native_setup(all_gather, rows=rows)
+        return 'native-p2p (decode) + rccl (large forwards)'
     if want_rccl and ok:
         eng.comm_drop_rccl()
     eng.comm_native_setup(all_gather, rows=rows)
@@ -123,10 +130,10 @@ class ParentLink:
         self.broadcast(vals)
         return vals
 
-    def setup_comm(self, eng: Engine, want_rccl: bool, rows: int) -> str:
+    def setup_comm(self, eng: Engine, want_rccl: bool, rows: int, want_native: bool = False) -> str:
         uid = Engine.comm_unique_id()
-        self.broadcast(('comm', want_rccl, uid, rows))
-        return _setup_comm(eng, want_rccl, uid, self.all_gather, rows)
+        self.broadcast(('comm', want_rccl, uid, rows, want_native))
+        return _setup_comm(eng, want_rccl, uid, self.all_gather, rows, want_native)
 
     def wait_ready(self):
         """every worker reports ('ready', rank) once its engine has its weights and is started"""
@@ -168,10 +175,10 @@ class WorkerLink:
         self.conn.send(('gather', mine))
         return self.conn.recv()
 
-    def setup_comm(self, eng: Engine, want_rccl: bool, rows: int) -> str:
-        tag, want, uid, rows0 = self.conn.recv()
+    def setup_comm(self, eng: Engine, want_rccl: bool, rows: int, want_native: bool = False) -> str:
+        tag, want, uid, rows0, native0 = self.conn.recv()     # rank 0's decisions, not this rank's guesses
         assert tag == 'comm', tag
-        return _setup_comm(eng, want, uid, self.all_gather, rows0)
+        return _setup_comm(eng, want, uid, self.all_gather, rows0, native0)
 
     def serve(self, eng: Engine):
         """execute the parent's mirrored calls until it closes the group"""

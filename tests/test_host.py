@@ -485,9 +485,14 @@ def test_api_surface_and_validation():
         TurbomindEngineConfig(quant_policy=16)              # FP8 KV is rejected by the reference for TurboMind too
     assert TurbomindEngineConfig(model_format='fp8').model_format == 'fp8'
     for bad in (dict(dp=2), dict(enable_prefix_caching=True), dict(dtype='bfloat16'), dict(model_format='gptq'),
-                dict(cache_block_seq_len=128), dict(communicator='native')):
+                dict(cache_block_seq_len=128)):
         with pytest.raises(NotImplementedError):
             TurbomindEngineConfig(**bad)
+    # the reference's communicator names (src/turbomind/comm/device_comm.cc:14-30): 'native' / 'cuda-ipc' = the in-house communicator
+    for comm in ('nccl', 'native', 'cuda-ipc'):
+        assert TurbomindEngineConfig(tp=2, communicator=comm).communicator == comm
+    with pytest.raises(ValueError):
+        TurbomindEngineConfig(communicator='mpi')
     g = GenerationConfig(max_new_tokens=7, ignore_eos=True)
     assert g.top_k == 50 and not g.do_sample
     assert g.sampling_params() is None                        # do_sample=False is greedy whatever top_k says

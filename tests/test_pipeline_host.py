@@ -260,12 +260,14 @@ class _StubRank:
         self.calls.append(('close',))
 
 
-@pytest.mark.parametrize('rccl_fails_on', [None, 1, 2])
-def test_tp_group_protocol_with_stub_engines(rccl_fails_on):
+@pytest.mark.parametrize('rccl_fails_on,want_native', [(None, False), (1, False), (2, False), (None, True), (2, True)])
+def test_tp_group_protocol_with_stub_engines(rccl_fails_on, want_native):
     """three ranks: rank 0 = ParentLink + TpEngine in this thread, ranks 1 / 2 = WorkerLink.serve on threads over real duplex pipes.
     Every rank must take the SAME communicator branch (RCCL only when every rank's init succeeded, else all drop it and exchange
     the native communicator's handles in rank order), see the same mirrored calls in the same order, and a worker's error must
-    surface in the caller with its status code after every rank answered."""
+    surface in the caller with its status code after every rank answered.  want_native = TurbomindEngineConfig.communicator 'native' /
+    'cuda-ipc': the native communicator comes up ON TOP of a healthy RCCL (decode-sized exchanges native, prefill-sized RCCL); rank 0's
+    choice reaches the workers with the unique id -- a worker never decides for itself."""
     import multiprocessing as mp
     import threading
     from lmdeploy_amd.turbomind import tp_group
@@ -276,7 +278,7 @@ def test_tp_group_protocol_with_stub_engines(rccl_fails_on):
 
     def worker(r):
         link = tp_group.WorkerLink(pipes[r - 1][1])
-        backends[r] = link.setup_comm(ranks[r], True, 0)
+        backends[r] = link.setup_comm(ranks[r], True, 0, not want_native)    # the worker's own arguments are ignored: rank 0's travel
         pipes[r - 1][1].send(('ready', r))
         link.serve(ranks[r])
 
@@ -284,14 +286,17 @@ def test_tp_group_protocol_with_stub_engines(rccl_fails_on):
     for t in threads:
         t.start()
     link = tp_group.ParentLink(tp, 'unused', None, conns=[p[0] for p in pipes])
-    backends[0] = link.setup_comm(ranks[0], True, 64)
+    backends[0] = link.setup_comm(ranks[0], True, 64, want_native)
     link.wait_ready()
     eng = tp_group.TpEngine(ranks[0], link, backends[0])
-    want = 'rccl' if rccl_fails_on is None else 'native-p2p'
+    want = 'native-p2p' if rccl_fails_on is not None else ('native-p2p (decode) + rccl (large forwards)' if want_native else 'rccl')
     assert backends == [want] * tp
     for r in ranks:
         if want == 'rccl':
             assert [c[0] for c in r.calls] == ['comm_init']
+        elif rccl_fails_on is None:     # both communicators: RCCL kept, the native one's handles exchanged in rank order
+            assert [c[0] for c in r.calls] == ['comm_init', 'comm_native_setup'] and ('comm_native_setup', 64) in r.calls
+            assert r.handles == [b'handle-of-rank-%d' % q for q in range(tp)]
         else:
             assert r.handles == [b'handle-of-rank-%d' % q for q in range(tp)], 'handles must arrive in rank order on every rank'
             assert ('comm_native_setup', 64) in r.calls, 'rows of the parent reach every rank'

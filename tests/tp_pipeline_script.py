@@ -25,7 +25,8 @@ def main():
     prompts = [rng.integers(3, cfg.vocab, n).astype(np.int32).tolist() for n in (19, 5, 40)]
     N = 6
     pipe = pipeline(tmp, backend_config=TurbomindEngineConfig(model_format='awq', quant_policy=8, max_batch_size=3, session_len=128, tp=2,
-                                                              devices=[0, 0]))
+                                                              devices=[0, 0], communicator='cuda-ipc'))   # the reference's name for its
+    # in-house communicator (device_comm.cc:14-30) -> the native P2P communicator; with both ranks on one device RCCL is not tried at all
     g = GenerationConfig(max_new_tokens=N, ignore_eos=True)
     static = [r.token_ids for r in pipe(prompts, g)]
     cont = [r.token_ids for r in sorted(pipe.generate_continuous(prompts + prompts[:2], g), key=lambda r: r.index)]
