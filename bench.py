@@ -279,6 +279,9 @@ def main():
         model.update(q_heads=model['q_heads'] // emu, kv_heads=max(1, model['kv_heads'] // emu), inter=model['inter'] // emu,
                      vocab=model['vocab'] // emu)
         os.environ['TM_FORCE_COMM'] = '1'      # the rank's collective code path, through a 1-rank communicator
+        # a 1-rank exchange takes no time, so splitting the prefill forwards to hide it would only add launches: the emulation reports the
+        # rank's kernel time unsplit, unless the run asks for the exchange stand-in (TM_EMULATE_AR_GBPS: the overlap experiment)
+        os.environ.setdefault('TM_COMM_STREAM', '1' if float(os.environ.get('TM_EMULATE_AR_GBPS', '0') or 0) > 0 else '0')
     K, W, B, S = args.steps, args.warmup, args.batch, args.prompt_len
     P = args.profile_steps
     child = args.traffic_child
