@@ -278,7 +278,7 @@ size_t tm_linear_workspace(const tm_linear* w, int M)
     if (!w) {
         return 0;
     }
-    return gemm_workspace_bytes(M, w->w.N, 16);
+    return gemm_workspace_bytes(M, w->w.N, 16) + 8192;  // + the arrival counters of the in-launch merged split-K tiles (kShapeMerge)
 }
 
 int tm_linear_dequant_f16(const tm_linear* w, void* out_nk, tm_stream_t st)
@@ -310,9 +310,17 @@ int tm_linear_forward(const tm_linear* w, const void* x, int ldx, void* y, int l
         TM_REQUIRE(dec32_supported(w->w, M), "decode kernel: u4 weights, N % 32 == 0");
         cfg.d32_shape = waves & 0xff;
         TM_REQUIRE((cfg.d32_shape >= 6 && cfg.d32_shape <= 9) || (cfg.d32_shape <= 5 && (cfg.d32_shape >= 4) == (M > 64))
-                       || (cfg.d32_shape == kShapeLC && M <= 64) || (cfg.d32_shape == kShapePre256 && M > 64),
-                   "P32 kernel shape 0..3 / 11 (M <= 64), 4 / 5 / 12 (M > 64) or 6..9 (32-row blocks, any M)");
+                       || (cfg.d32_shape == kShapeWide2 && M <= 64)
+                       || (cfg.d32_shape == kShapeLC && M <= 64) || (cfg.d32_shape == kShapePre256 && M > 64)
+                       || (dec32_is_merge_shape(cfg.d32_shape) && M <= 64),
+                   "P32 kernel shape 0..3 / 11 (M <= 64), 4 / 5 / 12 (M > 64), 6..9 (32-row blocks, any M) or 16 + (0..3 | 6..9) "
+                   "(M <= 64: split-K merged inside the launch)");
         waves = 0;
+    }
+    if (dec32_is_merge_shape(cfg.d32_shape) && workspace && cfg.splits > 1) {
+        // arrival counters of the in-launch merge: the 8 KB behind the 16 slabs (tm_linear_workspace)
+        cfg.tickets = (unsigned*)((char*)workspace + gemm_workspace_bytes(M, w->w.N, 16));
+        TM_HIP_CHECK(hipMemsetAsync(cfg.tickets, 0, 8192, (hipStream_t)st));
     }
     if (waves > 0) {
         // waves per workgroup (4 | 8); + 0x100 = split K two ways INSIDE the workgroup (8 waves only)
@@ -336,7 +344,7 @@ int tm_linear_residual_norm(const tm_linear* w, const void* x, int ldx, void* y,
     const int N = w->w.N;
     GemmConfig cfg = gemm_pick_config(w->w, M);
     if (shape >= 0) {
-        TM_REQUIRE(dec32_supported(w->w, M) && (shape <= 3 || (shape >= 6 && shape <= 9) || shape == kShapeLC) && M <= 64,
+        TM_REQUIRE(dec32_supported(w->w, M) && (shape <= 3 || (shape >= 6 && shape <= 10) || shape == kShapeLC) && M <= 64,
                    "decode tile 0..3 / 6..9 / 11, M <= 64");
         cfg.d32_shape = shape;
     }

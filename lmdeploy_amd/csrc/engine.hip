@@ -446,8 +446,10 @@ int tm_engine_start(tm_engine* e)
     {
         const size_t tiles = (size_t)(e->hidden + 63) / 64;
         TM_TRY(dmalloc(&e->d_ss, tiles * 64));
-        TM_TRY(dmalloc(&e->d_tickets, tiles * 2));
-        TM_HIP_CHECK(hipMemset(e->d_tickets, 0, tiles * 2 * sizeof(unsigned)));
+        // arrival counters: one per (column tile, row block) of the widest decode linear at its narrowest tile (64 columns, 32 rows)
+        const size_t ntk = (size_t)(std::max(std::max(e->qkv_n, 2 * e->inter), e->hidden) + 63) / 64 * 2;
+        TM_TRY(dmalloc(&e->d_tickets, ntk));
+        TM_HIP_CHECK(hipMemset(e->d_tickets, 0, ntk * sizeof(unsigned)));
         const char* fold = getenv("TM_FOLD_NORM");
         e->fold_norm     = (!e->use_comm && m.weight_type == 0 && m.moe_experts == 0 && e->hidden % 64 == 0) ? (fold ? atoi(fold) & 3 : 3) : 0;
     }

@@ -142,6 +142,7 @@ static int linear_plain(tm_engine* e, LinearSlots& l, const half_t* x, int ldx, 
     if (gemm_workspace_bytes(M, l.w.N, cfg.splits) > e->gemm_ws_bytes) {
         cfg.splits = 1;
     }
+    cfg.tickets = e->d_tickets;
     return launch_linear(l.w, x, ldx, y, ldy, M, gated, cfg, e->d_gemm_ws, false, nullptr, e->stream);
 }
 
@@ -297,7 +298,8 @@ static int linear_fold_consume(tm_engine* e, LinearSlots& l, const half_t* x, in
 {
     int shape, splits;
     fold_tiling(e, l.w, M, &shape, &splits);
-    if (!slabs_ok) {
+    const bool mrg = dec32_is_merge_shape(shape);  // split-K merged in the launch: no slab leaves it, whoever consumes
+    if (!slabs_ok && !mrg) {
         splits = 1;
     }
     NormFold nf{};
@@ -305,8 +307,9 @@ static int linear_fold_consume(tm_engine* e, LinearSlots& l, const half_t* x, in
     nf.ss_tiles = ss_tiles;
     nf.inv_h    = 1.0f / (float)e->hidden;
     nf.eps      = e->cfg.model.rms_eps;
+    nf.tickets  = e->d_tickets;
     int nslab   = 1;
-    TM_TRY(launch_linear_dec32(l.w, x, ldx, y, ldy, M, gated, shape, splits, e->d_gemm_ws, &nslab, e->stream, ss_tiles > 0 ? &nf : nullptr));
+    TM_TRY(launch_linear_dec32(l.w, x, ldx, y, ldy, M, gated, shape, splits, e->d_gemm_ws, &nslab, e->stream, (ss_tiles > 0 || mrg) ? &nf : nullptr));
     if (slabs) {
         *slabs = nslab;
     }

@@ -99,9 +99,14 @@ int tune_decode_gemms(tm_engine* e, int M, bool verbose)
             // (which == 1 / 2: the wo -> w1w3 pair, bit 0; which == 3 / 0: the w2 -> w_qkv pair, bit 1)
             const bool folded = M <= 64 && !e->layers[0].is_moe && (e->fold_norm & ((r.which == 1 || r.which == 2) ? 1 : 2)) != 0;
             const bool slabs_ok = norm_consumer || (r.which == 0 && e->fuse_qkv);  // folded: who can take fp32 slabs
-            if (folded && (!dec32_fold_shape(cand[i][0]) || (cfg.splits > 1 && !slabs_ok))) {
+            const bool mrg = dec32_is_merge_shape(cand[i][0]);  // split-K merged in the launch: nothing for a slab consumer to do
+            if (mrg && norm_consumer) {
+                continue;  // wo / w2: the folded producer merges in the launch anyway, the unfolded one hands its slabs to the reduce-norm
+            }
+            if (folded && (!dec32_fold_shape(cand[i][0]) || (cfg.splits > 1 && !slabs_ok && !mrg))) {
                 continue;
             }
+            cfg.tickets = e->d_tickets;
             auto chain = [&]() -> int {
                 if (folded) {
                     const int tiles = e->hidden / 64;
@@ -112,6 +117,7 @@ int tune_decode_gemms(tm_engine* e, int M, bool verbose)
                         }
                         else {
                             nf.ss_in = e->d_ss, nf.ss_tiles = tiles, nf.inv_h = 1.0f / (float)e->hidden, nf.eps = e->cfg.model.rms_eps;
+                            nf.tickets = e->d_tickets;
                         }
                         TM_TRY(launch_linear_dec32(*w, r.x, r.ldx, norm_consumer ? norm_out : r.y, norm_consumer ? e->hidden : r.ldy, M, r.gated,
                                                    cfg.d32_shape, cfg.splits, e->d_gemm_ws, nullptr, st, &nf));

@@ -714,12 +714,81 @@ __global__ __launch_bounds__(CG* WK * 64) void gemm_dec32_kernel(Dec32Params p)
             }
             return;
         }
+        // ---- split-K merged in the launch (p.merge; fp16 / gated-SiLU epilogues): park, ticket, the last arriver of the tile goes on --
+        constexpr int NIg = NE / T;
+        floatx4       vm[MH <= 2 ? NIg : 1][4];
+        bool          merged = false;
+        if constexpr (MH <= 2) {
+            if (p.merge && gridDim.y > 1) {  // uniform
+                const int    splits = gridDim.y;
+                const size_t slab   = (size_t)p.M * p.N;
+                unsigned*    flag   = (unsigned*)(smem + LDSX + kDec32NormLds - 16);
+#pragma unroll
+                for (int e0 = 0; e0 < NE; e0 += T) {
+                    const int e = e0 + tid, m = e / C4, c4 = e % C4;
+                    const int n = ncol0 + c4 * 4;
+                    if (m < Mloc && n < p.N) {
+                        store_wt((floatx4*)(p.partial + (size_t)by * slab + ((size_t)m0 + m) * p.N + n), tile_sum(m, c4), 1);
+                    }
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                unsigned* const tk = p.tickets + blockIdx.z * gridDim.x + bx;
+                if (tid == 0) {
+                    *flag = __hip_atomic_fetch_add(tk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                __syncthreads();
+                if (*flag != (unsigned)(splits - 1)) {
+                    if (p.dbg && tid == 0) {
+                        p.dbg[wgid * 8 + 3] = __builtin_amdgcn_s_memrealtime();
+                        p.dbg[wgid * 8 + 5] = ts_issued;
+                        p.dbg[wgid * 8 + 6] = ts_w0;
+                    }
+                    return;
+                }
+                if (tid == 0) {
+                    __hip_atomic_store(tk, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // every other slice has arrived
+                }
+                // all passes' slab loads of the first four slices in flight before any is consumed (clamped, unconditional)
+#pragma unroll
+                for (int it = 0; it < NIg; ++it) {
+                    const int    e = it * T + tid, m = e / C4, c4 = e % C4;
+                    const int    n = ncol0 + c4 * 4;
+                    const bool   ok = m < Mloc && n < p.N;
+                    const float* src = p.partial + ((size_t)m0 + (ok ? m : 0)) * p.N + (ok ? n : 0);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        vm[it][u] = load_agent(src + (size_t)min(u, splits - 1) * slab);
+                    }
+                }
+                merged = true;
+            }
+        }
 #pragma unroll
         for (int e0 = 0; e0 < NE; e0 += T) {
             const int e = e0 + tid;
             const int m  = e / C4;
             const int c4 = e % C4;
             floatx4   a  = tile_sum(m, c4);
+            if constexpr (MH <= 2) {
+                if (merged) {  // slice order, from zero: the bits of splitk_reduce_kernel; the own slice comes from LDS
+                    const int     splits = gridDim.y;
+                    const floatx4 own    = a;
+                    const int     n_     = ncol0 + c4 * 4;
+                    const bool    ok     = m < Mloc && n_ < p.N;
+                    const float*  src    = p.partial + ((size_t)m0 + (ok ? m : 0)) * p.N + (ok ? n_ : 0);
+                    a                    = floatx4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        if (u < splits) {
+                            a += u == by ? own : vm[e0 / T][u];
+                        }
+                    }
+                    for (int sl = 4; sl < splits; ++sl) {
+                        a += sl == by ? own : load_agent(src + (size_t)sl * (size_t)p.M * p.N);
+                    }
+                }
+            }
             if (scaled) {  // inv[m] = 1 / sqrt(sum over tiles / H + eps): every thread of a row adds the same PARTS numbers in the same order
                 float t = part_s[m];
 #pragma unroll
@@ -1151,6 +1220,9 @@ static int launch_dec32_shape(const Dec32Params& p, dim3 grid, int shape, hipStr
             return launch_dec32_one<MH, 4, 2, 4, 4, kD32Mode>(p, grid, st);
         case 3:  // 8 waves: 2 column groups x 4 k-phases (64 columns per workgroup)
             return launch_dec32_one<MH, 2, 4, 4, 2, kD32Mode>(p, grid, st);
+        case kShapeWide2:  // 16 waves: 8 column groups x 2 k-phases (256 columns per workgroup) on 2-k-block stages, ring depth 2: shape 0's
+                           // per-wave rhythm (one k-block per wave and stage) without shape 1's register spills (60 B / lane at 128 VGPRs)
+            return launch_dec32_one<MH, 8, 2, 2, 2, kD32Mode>(p, grid, st);
         default: break;
     }
     set_last_error("gemm_dec32: unknown shape");
@@ -1165,6 +1237,9 @@ static int launch_dec32_shape(const Dec32Params& p, dim3 grid, int shape, hipStr
 static int dec32_base_shape(int shape)
 {
     static const int base[4] = {3, 0, 2, 1};
+    if (dec32_is_merge_shape(shape)) {
+        shape -= kShapeMerge;
+    }
     return shape >= 6 && shape <= 9 ? base[shape - 6] : shape;
 }
 
@@ -1183,6 +1258,11 @@ static void dec32_shape_dims(int shape, int* cg, int* s)
         return;
     }
     shape = dec32_base_shape(shape);
+    if (shape == kShapeWide2) {
+        *cg = 8;
+        *s  = 2;
+        return;
+    }
     *cg = cgs[shape < 0 || shape > 5 ? 0 : shape];
     *s  = shape == 5 ? 1 : (shape == 4 ? 2 : 4);
 }
@@ -1288,7 +1368,9 @@ int dec32_table_import(const char* path)
         const bool big = M > 64;
         const bool lc  = shape == kShapeLC && M <= 64;
         const bool p256 = shape == kShapePre256 && M > 64;  // what launch_linear_dec32 accepts (the tuner only proposes it for M, N >= 256)
-        if (K > 0 && N > 0 && M > 0 && M == dec32_m_bucket(M) && shape >= 0 && (shape <= 9 || lc || p256) && splits >= 1 && splits <= 16
+        const bool mrg = dec32_is_merge_shape(shape) && M <= 64 && splits >= 2;  // in-launch merged split-K (decode batches only)
+        const bool w2k = shape == kShapeWide2 && M <= 64;
+        if (K > 0 && N > 0 && M > 0 && M == dec32_m_bucket(M) && shape >= 0 && (shape <= 9 || lc || p256 || mrg || w2k) && splits >= 1 && splits <= 16
             && (big ? shape >= 4 : (shape != 4 && shape != 5)) && !(shape == 5 && N < 512) && K % 128 == 0 && N % 32 == 0) {
             dec32_table_set(K, N, M, shape, splits, role);
             ++n;
@@ -1323,8 +1405,11 @@ int dec32_candidates(const LinearWeight& w, int M, int (*out)[2], int cap)
 {
     const int ncg = w.N / 32, KB = w.K / 128;
     int       n   = 0;
-    for (int shape = 0; shape < 10 && M <= 8192; ++shape) {
-        const bool rows32 = shape >= 6;  // 32-row blocks on grid.z: any M
+    for (int shape = 0; shape <= kShapeWide2 && M <= 8192; ++shape) {
+        if (shape == kShapeWide2 && M > 64) {
+            continue;
+        }
+        const bool rows32 = shape >= 6 && shape <= 9;  // 32-row blocks on grid.z: any M
         if (rows32 ? (M <= 32 || M > 1024) : ((shape == 4 || shape == 5) != (M > 64))) {
             continue;  // one row block: identical to the base shape / 64-row shapes take M <= 64, 128-row tiles M > 64; beyond
                        // 1024 rows a 32-row block re-reads every weight unit > 32 times: never competitive
@@ -1347,6 +1432,19 @@ int dec32_candidates(const LinearWeight& w, int M, int (*out)[2], int cap)
             if (n < cap) {
                 out[n][0] = shape;
                 out[n][1] = s;
+                ++n;
+            }
+        }
+    }
+    if (M <= 64) {
+        // in-launch merged split-K (kShapeMerge + shape, round 6): 2 .. 4 slices of the <= 64-row tiles.  The last arriver of a tile reads
+        // (slices - 1) x 64 x columns x 4 bytes on its critical path -- beyond 4 slices that is longer than the reduce launch it replaces
+        const int base = n;
+        for (int i = 0; i < base; ++i) {
+            const int sh = out[i][0], sp = out[i][1];
+            if (dec32_fold_shape(sh) && sh < kShapeMerge && sp >= 2 && sp <= 4 && n < cap) {
+                out[n][0] = kShapeMerge + sh;
+                out[n][1] = sp;
                 ++n;
             }
         }
@@ -1468,7 +1566,10 @@ void dec32_pick_ex(const LinearWeight& w, int M, int* shape_out, int* splits_out
 // y / slabs as launch_linear: *slabs_out = number of fp32 slabs written into `workspace` (1 = direct epilogue)
 bool dec32_fold_shape(int shape)
 {
-    return (shape >= 0 && shape <= 3) || (shape >= 6 && shape <= 9);  // gemm_dec32_kernel with <= 64-row blocks
+    if (dec32_is_merge_shape(shape)) {
+        shape -= kShapeMerge;  // the same kernels; consumers only (a folded producer merges in the launch whatever its shape says)
+    }
+    return (shape >= 0 && shape <= 3) || (shape >= 6 && shape <= 9) || shape == kShapeWide2;  // gemm_dec32_kernel with <= 64-row blocks
 }
 
 int launch_linear_dec32(const LinearWeight& w, const half_t* x, int ldx, half_t* y, int ldy, int M, bool gated_silu, int shape,
@@ -1476,13 +1577,20 @@ int launch_linear_dec32(const LinearWeight& w, const half_t* x, int ldx, half_t*
 {
     const bool produce = nf && nf->resid != nullptr;
     const bool consume = nf && nf->ss_in != nullptr;
-    TM_REQUIRE(!nf || (dec32_fold_shape(shape) && M <= 64), "folded RMSNorm: the <= 64-row decode tiles (shapes 0..3, 6..9), M <= 64");
+    bool       merge   = false;
+    if (dec32_is_merge_shape(shape)) {  // split-K merged in the launch (fp16 / gated epilogues); a producer does that anyway
+        shape -= kShapeMerge;
+        merge = !produce && splits > 1;
+        TM_REQUIRE(!merge || (nf && nf->tickets && M <= 64), "merged split-K: arrival counters (NormFold::tickets), M <= 64");
+    }
+    TM_REQUIRE(!nf || !(produce || consume) || (dec32_fold_shape(shape) && M <= 64), "folded RMSNorm: the <= 64-row decode tiles (shapes 0..3, 6..9), M <= 64");
     TM_REQUIRE(!produce || (!gated_silu && nf->norm_w && nf->ss_out && ldy % 4 == 0), "folded RMSNorm, producer: residual, norm weight, sums");
     TM_REQUIRE(!consume || (nf->ss_tiles >= 1 && nf->inv_h > 0.f), "folded RMSNorm, consumer: tiles and 1 / H");
     TM_REQUIRE(w.packed32 != nullptr && w.N % 32 == 0, "decode GEMM: P32 layout missing");
-    TM_REQUIRE(M >= 1 && shape >= 0 && (shape <= 9 || shape == kShapeLC || shape == kShapePre256)
-                   && (shape >= 6 || (M <= 64) == (shape < 4)) && (shape != kShapeLC || M <= 64) && (shape != kShapePre256 || M > 64),
-               "decode GEMM: shapes 0..3 and 11 take M <= 64, shapes 4 / 5 / 12 take M > 64, shapes 6..9 any M");
+    TM_REQUIRE(M >= 1 && shape >= 0 && (shape <= 9 || shape == kShapeWide2 || shape == kShapeLC || shape == kShapePre256)
+                   && (shape >= 6 || (M <= 64) == (shape < 4)) && (shape != kShapeLC || M <= 64) && (shape != kShapePre256 || M > 64)
+                   && (shape != kShapeWide2 || M <= 64),
+               "decode GEMM: shapes 0..3, 10 and 11 take M <= 64, shapes 4 / 5 / 12 take M > 64, shapes 6..9 any M");
     TM_REQUIRE(ldx % 8 == 0, "x rows must be 16-byte aligned");
     int cgn, S;
     dec32_shape_dims(shape, &cgn, &S);
@@ -1504,7 +1612,12 @@ int launch_linear_dec32(const LinearWeight& w, const half_t* x, int ldx, half_t*
     splits    = (p.KB + per - 1) / per;
     TM_REQUIRE(splits == 1 || workspace != nullptr, "split-K needs a workspace");
     p.kb_per_split = per;
-    p.epilogue     = produce ? 3 : splits > 1 ? 2 : (gated_silu ? 1 : 0);
+    merge          = merge && splits > 1;
+    p.epilogue     = produce ? 3 : (splits > 1 && !merge) ? 2 : (gated_silu ? 1 : 0);
+    if (merge) {
+        p.merge   = 1;
+        p.tickets = nf->tickets;
+    }
     if (produce) {
         TM_REQUIRE(splits == 1 || nf->tickets != nullptr, "folded RMSNorm, producer with split-K: arrival counters");
         p.resid   = nf->resid;
@@ -1521,11 +1634,12 @@ int launch_linear_dec32(const LinearWeight& w, const half_t* x, int ldx, half_t*
     static const int wt = env_int2("TM_D32_WT", 1);  // measured (tools/trace_boundary.py, profiles/r02_gemm_boundary_gap.txt): -0.4..-0.9 us per split-K launch
     p.wt           = wt;
     dim3      grid((p.ncg + cgn - 1) / cgn, splits,
-                   shape == kShapePre256 ? (M + 255) / 256 : shape == kShapeLC ? 1 : shape >= 6 ? (M + 31) / 32 : shape >= 4 ? (M + 127) / 128 : 1);
+                   shape == kShapePre256 ? (M + 255) / 256 : (shape == kShapeLC || shape == kShapeWide2) ? 1 : shape >= 6 ? (M + 31) / 32 : shape >= 4 ? (M + 127) / 128 : 1);
     static const char* const role_tag[6] = {"gemm", "w_qkv", "wo", "w1w3", "w2", "lm_head"};
     p.dbg        = gemm_trace_for((size_t)grid.x * grid.y * grid.z, role_tag[w.role >= 0 && w.role <= 5 ? w.role : 0], grid.x, grid.y, grid.z);
     const int rc = shape == kShapePre256 ? launch_pre256(p, grid, st) :
                    shape == kShapeLC ? launch_dec_lc(p, grid, st) :
+                   shape == kShapeWide2 ? (M <= 32 ? launch_dec32_shape<1>(p, grid, shape, st) : launch_dec32_shape<2>(p, grid, shape, st)) :
                    shape >= 6 ? launch_dec32_shape<1>(p, grid, dec32_base_shape(shape), st) :
                    shape >= 4 ? launch_dec32_shape<4>(p, grid, shape, st) :
                    M <= 32    ? launch_dec32_shape<1>(p, grid, shape, st) :
@@ -1536,6 +1650,9 @@ int launch_linear_dec32(const LinearWeight& w, const half_t* x, int ldx, half_t*
     if (produce) {
         nf->tiles_out = (int)grid.x;
         splits        = 1;  // the slabs were consumed inside the launch
+    }
+    if (merge) {
+        splits = 1;
     }
     if (slabs_out) {
         *slabs_out = splits;

@@ -39,6 +39,11 @@ struct Dec32Params {
     int           ss_tiles;
     float         ss_inv_h;  // 1 / H of the norm
     float         ss_eps;
+    // ---- split-K merged INSIDE the launch for the fp16 / gated-SiLU epilogues (round 6; shapes kShapeMerge + 0..3 / 6..9): the slices
+    // park their fp32 tiles write-through and take a ticket exactly as epilogue 3 does; the last arriver of a column tile sums the
+    // slices in slice order from zero (the bits of splitk_reduce_kernel) and runs the epilogue.  No slab leaves the launch, no reduce
+    // launch follows: what a 256-column tile with a 2-way cross-CU k-split needs for the gated w1w3.
+    int           merge;     // 1: epilogues 0 / 1 with gridDim.y > 1 merge in the launch (tickets != nullptr)
 };
 constexpr int kDec32NormLds = 32 * 64 * 4 + 512;  // consumer scratch behind the stage buffers / reduction image: [parts][rows] sums + inv[rows]
 
@@ -54,20 +59,24 @@ __device__ __forceinline__ floatx4 load_agent(const float* src)
                    __builtin_bit_cast(float, (uint32_t)hi), __builtin_bit_cast(float, (uint32_t)(hi >> 32))};
 }
 
+// The 16-byte asm stores END WITH `s_nop 1`: hipcc neither counts nor pads an asm statement, and a VALU write to the store's data
+// registers within two wait states of a > 64-bit store corrupts what the store reads (cdna_hip_programming.md 5.7 item 1).  Round 6 found
+// it the hard way: the merged split-K park loop put `v_or_b32 v6, ...` one instruction behind `global_store_dwordx4 v[2:3], v[6:9]` --
+// dword 0 of lanes 12..15 of every 16-lane row arrived in the slab as 0.0 on some launches (tools/r06_dbg_merge.py).
 __device__ __forceinline__ void store_wt(floatx4* dst, floatx4 v, int mode = 1)
 {
     // mode (TM_D32_WT >> 4, experiment arms): 0/1 sc1, 2 sc0 sc1, 3 nt, 4 nt sc0 sc1
     if (mode <= 1) {
-        asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(v) : "memory");
+        asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(dst), "v"(v) : "memory");
     }
     else if (mode == 2) {
-        asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(dst), "v"(v) : "memory");
+        asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(dst), "v"(v) : "memory");
     }
     else if (mode == 3) {
-        asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(dst), "v"(v) : "memory");
+        asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" ::"v"(dst), "v"(v) : "memory");
     }
     else {
-        asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt" ::"v"(dst), "v"(v) : "memory");
+        asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt\n\ts_nop 1" ::"v"(dst), "v"(v) : "memory");
     }
 }
 __device__ __forceinline__ void store_wt(half4_t* dst, half4_t v)

@@ -1149,7 +1149,13 @@ int launch_linear(const LinearWeight& w,
         int       nslab = 1;
         const int sp    = workspace ? (cfg.splits < 1 ? 1 : cfg.splits) : 1;
         TM_REQUIRE(!defer_reduce || sp > 1, "defer_reduce only with split-K");
-        const int rc = launch_linear_dec32(w, x, ldx, y, ldy, M, gated_silu, cfg.d32_shape, sp, workspace, &nslab, st);
+        NormFold  tk{};  // kShapeMerge shapes: the arrival counters ride in a NormFold that neither produces nor consumes
+        tk.tickets = cfg.tickets;
+        int shape  = cfg.d32_shape;
+        if (dec32_is_merge_shape(shape) && (!cfg.tickets || M > 64 || defer_reduce)) {
+            shape -= kShapeMerge;  // no counters / the caller wants the slabs: the plain form of the same tile
+        }
+        const int rc = launch_linear_dec32(w, x, ldx, y, ldy, M, gated_silu, shape, sp, workspace, &nslab, st, cfg.tickets ? &tk : nullptr);
         if (rc) {
             return rc;
         }

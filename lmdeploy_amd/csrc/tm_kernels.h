@@ -129,10 +129,24 @@ struct GemmConfig {
     int kphases; // split-K inside the workgroup: 1 or 2 (8 waves only)
     int kstage;  // max k-blocks per barrier (0 = auto: 4)
     int d32_shape = -1;  // >= 0: a P32 kernel (gemm_decode.hip / gemm_decode_lc.hip / gemm_prefill.hip) with this workgroup shape
+    unsigned* tickets = nullptr;  // arrival counters (zero between launches) of the kShapeMerge shapes: >= ceil(N / 64) * ceil(M / 32) words
 };
 // (shape 10 was "dequantise + the vendor library's fp16 GEMM" in round 3: removed -- no vendor GEMM on any path of this library)
 constexpr int kShapePre256     = 12;   // gemm_prefill.hip: 256 x 256 tiles, weights dequantised once per workgroup tile through LDS (M > 64)
 constexpr int kShapeLC         = 11;   // gemm_decode_lc.hip: 8 consumer + 4 loader waves, 128 columns x M <= 64 rows per workgroup
+// kShapeMerge + s (s = 0..3, 6..9; round 6): the decode tile s whose split-K slices are merged INSIDE the launch by the last-arriving
+// slice of each column tile, for the fp16 / gated-SiLU epilogues (the folded-norm producers, epilogue 3, always merge that way): a
+// gated w1w3 can then split K across CUs (256-column tiles, half the activation bytes per CU) without slabs leaving the launch.
+// Needs arrival counters: NormFold::tickets (engine) / the tail of the workspace (tm_linear_forward).
+constexpr int kShapeMerge      = 16;
+// 256 columns x 2 k-phases x 16 waves on 2-k-block stages (gemm_dec32_kernel<MH, 8, 2, 2, 2>; round 6): the 256-column decode tile that does not
+// spill (shape 1 = the same wave layout on 4-k-block stages with a 4-deep ring: 60 B / lane of scratch at the 128-register cap)
+constexpr int kShapeWide2      = 10;
+inline bool dec32_is_merge_shape(int shape)
+{
+    const int b = shape - kShapeMerge;
+    return (b >= 0 && b <= 3) || (b >= 6 && b <= 10);
+}
 // Load-time repack (reference: LinearWeight::prepare, models/linear_weight.cc:101-324)
 // p32_only: build ONLY the P32 image (gemm_decode.hip) -- for linears that every M dispatches to those kernels
 // (dec32_serves_every_m): the 16-column image of gemm_kernel would never be read.

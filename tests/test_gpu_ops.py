@@ -580,6 +580,46 @@ def test_w4a16_loader_consumer_tiles(tm, cuda, K, N, M, gated):
     _ffi.check(tm.tm_linear_destroy(h))
 
 
+@pytest.mark.parametrize('K,N,gated', [(4096, 1024, 1), (2048, 512, 0), (1792, 4096, 0), (4096, 6144, 1)])
+@pytest.mark.parametrize('M', [1, 33, 64])
+def test_w4a16_split_k_merged_in_launch(tm, cuda, K, N, M, gated):
+    """Round 6: shapes 16 + s -- the split-K slices of a decode tile merged INSIDE the launch by the last-arriving slice
+    of each column tile, for the fp16 and the gated-SiLU epilogue (what a 256-column w1w3 tile with a cross-CU k-split needs) -- and
+    shape 10, the 256-column x 2-k-phase tile on 2-k-block stages.  Oracle + tolerance of the other decode tiles; the fp16 epilogue is
+    bit-identical to the same tile's slabs summed by the reduce kernel (slice order, fp32); three launches bit-identical (the arrival
+    counters are left at zero by every launch)."""
+    rng = np.random.default_rng(K + N + M + 16)
+    h, (q, s, z) = _make_linear(tm, rng, K, N)
+    x = rng.standard_normal((M, K)).astype(f16)
+    ref = (o.w4a16_linear_gated_silu(x, q, s, z) if gated else x.astype(np.float32) @ _QCACHE[(K, N)][3]).astype(np.float32)
+    ws = torch.zeros(max(1, tm.tm_linear_workspace(h, M)), dtype=torch.uint8, device='cuda')
+    x_d = dev(x)
+    cols = N // 2 if gated else N
+    for base in (0, 3, 6, 10):
+        for splits in (1, 2, 4):
+            if splits > max(1, K // 512):
+                continue
+            plain = torch.zeros((M, cols), dtype=torch.float16, device='cuda')
+            _ffi.check(tm.tm_linear_forward(h, x_d.data_ptr(), K, plain.data_ptr(), cols, M, gated, 0, splits, 0x200 | base, ws.data_ptr(), st()))
+            err = np.abs(host(plain).astype(np.float32) - ref)
+            assert np.all(err <= 2e-3 + 2.0**-9 * np.abs(ref)), f'shape {base} splits {splits}: max err {err.max()}'
+            if splits == 1:
+                continue
+            first = None
+            for rep in range(3):
+                y = torch.zeros((M, cols), dtype=torch.float16, device='cuda')
+                _ffi.check(tm.tm_linear_forward(h, x_d.data_ptr(), K, y.data_ptr(), cols, M, gated, 0, splits, 0x200 | (16 + base), ws.data_ptr(), st()))
+                got = host(y)
+                err = np.abs(got.astype(np.float32) - ref)
+                assert np.all(err <= 2e-3 + 2.0**-9 * np.abs(ref)), f'merged shape {base} splits {splits} launch {rep}: max err {err.max()}'
+                if first is None:
+                    first = got
+                assert np.array_equal(got.view(np.uint16), first.view(np.uint16)), f'merged shape {base} splits {splits}: launch {rep} differs'
+            if not gated:   # same slabs, same order: the reduce kernel's bits
+                assert np.array_equal(first.view(np.uint16), host(plain).view(np.uint16)), f'merged shape {base} splits {splits} != slabs + reduce'
+    _ffi.check(tm.tm_linear_destroy(h))
+
+
 def test_w4a16_loader_consumer_identity(tm, cuda):
     """x = rows of the identity through shape 11: the dequantised weights come back bit for bit (operand = the reference's)."""
     rng = np.random.default_rng(5)

@@ -1,0 +1,73 @@
+#!/usr/bin/env python
+"""Host cost of the one-call rank group: microseconds per mirrored engine call at tp = 2 / 4 / 8 with stub engines
+(a call that returns at once), over the same authenticated localhost connections the product uses -- what a continuous-batching session
+pays per scheduler step ON TOP of the device time when every `step` is mirrored one by one.
+
+  python tools/tp_group_host_cost.py [--calls 2000]            prints one JSON line per tp
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+class StubEngine:
+    def step(self, n=1):
+        return (1, 0)
+
+    def step_many(self, n, **kw):
+        return (n, 0, 0)
+
+    def close(self):
+        pass
+
+
+def child(port, key):
+    from multiprocessing.connection import Client
+    from lmdeploy_amd.turbomind import tp_group
+    conn = Client(('127.0.0.1', port), authkey=bytes.fromhex(key))
+    conn.send(0)
+    tp_group.WorkerLink(conn).serve(StubEngine())
+    conn.close()
+
+
+def measure(tp, calls):
+    from multiprocessing.connection import Listener
+    from lmdeploy_amd.turbomind import tp_group
+    key = os.urandom(16)
+    with Listener(('127.0.0.1', 0), authkey=key) as srv:
+        port = srv.address[1]
+        procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), '--child', str(port), key.hex()]) for _ in range(tp - 1)]
+        conns = []
+        for _ in range(tp - 1):
+            c = srv.accept()
+            c.recv()
+            conns.append(c)
+    link = tp_group.ParentLink(tp, 'unused', None, conns=conns)
+    eng = tp_group.TpEngine(StubEngine(), link, 'stub')
+    for _ in range(200):
+        eng.step()
+    t0 = time.perf_counter()
+    for _ in range(calls):
+        eng.step()
+    us = (time.perf_counter() - t0) / calls * 1e6
+    link.close()
+    for p in procs:
+        p.wait(timeout=10)
+    return us
+
+
+if __name__ == '__main__':
+    if len(sys.argv) > 1 and sys.argv[1] == '--child':
+        child(int(sys.argv[2]), sys.argv[3])
+        sys.exit(0)
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--calls', type=int, default=2000)
+    a = ap.parse_args()
+    for tp in (2, 4, 8):
+        print(json.dumps({'tp': tp, 'us_per_mirrored_call': round(measure(tp, a.calls), 1), 'calls': a.calls, 'host_cpus': os.cpu_count()}))
