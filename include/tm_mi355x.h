@@ -463,6 +463,10 @@ int tm_engine_submit_ex(tm_engine* e, const int* host_ids, int n, int max_new_to
 int tm_engine_submit_gen(tm_engine* e, const int* host_ids, int n, int max_new_tokens, int eos_id, const tm_sampling* sampling,
                          const tm_logits_param* logits_param, int64_t* req_id);
 int tm_engine_step(tm_engine* e, int* n_active, int* n_waiting);
+/* tm_engine_step_many: up to max_steps iterations of tm_engine_step in one call (stops when nothing runs and nothing waits); *steps_done =
+ * iterations executed.  What a tensor-parallel rank group mirrors to its ranks instead of single steps -- the per-rank engine loops of
+ * src/turbomind/engine/engine.cc:770-870 exchange admissions, not steps -- and the cheaper host loop at tp = 1 (one poll per burst). */
+int tm_engine_step_many(tm_engine* e, int max_steps, int* steps_done, int* n_active, int* n_waiting);
 int tm_engine_poll(tm_engine* e, int64_t req_id, int* status, int* host_tokens, int cap, int* n_tokens);
 int tm_engine_cancel(tm_engine* e, int64_t req_id);
 /* drop the record of a FINISHED request (status != 0) once its tokens were read: a long-lived serving session would

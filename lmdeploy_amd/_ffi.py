@@ -175,6 +175,7 @@ _SIGNATURES = {
     'tm_engine_submit_ex': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, POINTER(c_int64)]),
     'tm_engine_submit': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, POINTER(c_int64)]),
     'tm_engine_step': (c_int, [c_void_p, POINTER(c_int), POINTER(c_int)]),
+    'tm_engine_step_many': (c_int, [c_void_p, c_int, POINTER(c_int), POINTER(c_int), POINTER(c_int)]),
     'tm_engine_poll': (c_int, [c_void_p, c_int64, POINTER(c_int), c_void_p, c_int, POINTER(c_int)]),
     'tm_engine_cancel': (c_int, [c_void_p, c_int64]),
     'tm_engine_forget': (c_int, [c_void_p, c_int64]),

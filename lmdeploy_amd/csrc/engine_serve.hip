@@ -433,6 +433,39 @@ int tm_engine_step(tm_engine* e, int* n_active, int* n_waiting)
     return step_locked(e, n_active, n_waiting, nullptr);
 }
 
+// Up to `max_steps` scheduler iterations in ONE call; stops early when nothing runs and nothing waits.  What a tensor-parallel rank group
+// mirrors instead of single steps: the ranks' schedulers take the same decisions from the same call sequence, so a burst of steps needs one
+// host round trip, not one per step (reference: every rank's engine thread loops on its own, src/turbomind/engine/engine.cc:770-870 --
+// the host exchanges admissions, not steps).  Also the cheaper host loop at tp = 1: a session polls once per burst.
+int tm_engine_step_many(tm_engine* e, int max_steps, int* steps_done, int* n_active, int* n_waiting)
+{
+    TM_REQUIRE(e && steps_done && max_steps >= 1, "arguments");
+    if (e->loop_on.load()) {
+        set_last_error("the engine thread owns the scheduler loop (tm_engine_serve_stop first)");
+        return TM_CONFLICT;
+    }
+    ApiLock lock(e);
+    int     na = 0, nw = 0;
+    *steps_done = 0;
+    for (int i = 0; i < max_steps; ++i) {
+        const int rc = step_locked(e, &na, &nw, nullptr);
+        if (rc) {
+            return rc;
+        }
+        ++*steps_done;
+        if (na == 0 && nw == 0) {
+            break;
+        }
+    }
+    if (n_active) {
+        *n_active = na;
+    }
+    if (n_waiting) {
+        *n_waiting = nw;
+    }
+    return 0;
+}
+
 static int poll_locked(tm_engine* e, int64_t req_id, int* status, int* host_tokens, int cap, int* n_tokens)
 {
     TM_REQUIRE(e->sched, "no continuous-batching session (submit first)");

@@ -65,7 +65,7 @@ class Pipeline:
         devices = cfg.devices or list(range(cfg.tp))
         per_dev = max([sum(1 for r in range(cfg.tp) if devices[r % len(devices)] == d) for d in set(devices)] or [1])
         if per_dev > 1:     # ranks share a device (bring-up on a smaller box): their persistent two-shot all-reduce grids must fit TOGETHER
-            os.environ.setdefault('TM_P2P_2SHOT_GRID', str(max(8, 256 // per_dev // 2)))
+            os.environ.setdefault('TM_P2P_2SHOT_GRID', str(max(8, 256 // per_dev // 2)))     # (read by this rank's engine and inherited by the workers)
         self.engine = Engine.from_model_config(
             self.model_cfg, weight_type={'u4': 0, 'f16': 1, 'fp8': 2}[self.model_cfg.weight_format if self.model_cfg.quantized
                                                                         else 'f16'], tp=cfg.tp, rank=rank,
@@ -95,25 +95,26 @@ class Pipeline:
                 except Exception:
                     self._group.close()
                     raise
-        if synthetic:
-            self.engine.init_synthetic(seed=0)
-        else:
-            w = checkpoint.load_hf_weights(model_path, self.model_cfg)
-            self.engine.load_weights(export_weights(self.model_cfg, w, cfg.tp, rank))
-            if os.path.exists(os.path.join(model_path, 'tokenizer.json')) or \
-                    os.path.exists(os.path.join(model_path, 'tokenizer.model')):
-                from transformers import AutoTokenizer
-                self.tokenizer = AutoTokenizer.from_pretrained(model_path)
-        self.engine.start()
-        self.max_batch_size = cfg.max_batch_size or 64
-        if self._group is not None:
-            from .turbomind import tp_group
-            try:
+        try:
+            if synthetic:
+                self.engine.init_synthetic(seed=0)
+            else:
+                w = checkpoint.load_hf_weights(model_path, self.model_cfg)
+                self.engine.load_weights(export_weights(self.model_cfg, w, cfg.tp, rank))
+                if os.path.exists(os.path.join(model_path, 'tokenizer.json')) or \
+                        os.path.exists(os.path.join(model_path, 'tokenizer.model')):
+                    from transformers import AutoTokenizer
+                    self.tokenizer = AutoTokenizer.from_pretrained(model_path)
+            self.engine.start()
+            self.max_batch_size = cfg.max_batch_size or 64
+            if self._group is not None:
+                from .turbomind import tp_group
                 self._group.wait_ready()
-            except Exception:
+                self.engine = tp_group.TpEngine(self.engine, self._group, self._comm_backend)
+        except BaseException:      # weights / tokenizer / start / a worker that failed to come up: the workers (and their GPU memory) must not
+            if self._group is not None:     # outlive the failed constructor
                 self._group.close()
-                raise
-            self.engine = tp_group.TpEngine(self.engine, self._group, self._comm_backend)
+            raise
 
     # ---- reference-compatible entry points -----------------------------------------------------------
     def __call__(self, prompts, gen_config: GenerationConfig | None = None, **kwargs):
@@ -215,9 +216,20 @@ class Pipeline:
                 rt = STATUS_TO_RESPONSE.get(e.status, ResponseType.INTERNAL_ENGINE_ERROR)
                 out_of_engine.append(Response('', 0, len(p), 'error', [], index=i, error_code=rt.name, error_message=str(e)))
         yield from out_of_engine
+        # scheduler steps per host iteration: one native call runs the burst (requests finish / are admitted INSIDE it, step by step); the
+        # host polls once per burst.  At tp > 1 every engine call is mirrored to the other ranks over localhost connections -- 0.05 ms
+        # (tp = 2) to several ms (tp = 8) per call on a busy host (tools/tp_group_host_cost.py) against a 1.5 .. 3 ms device step -- so
+        # a burst is one round trip, not one per step (the reference's per-rank engine threads exchange admissions, not steps:
+        # src/turbomind/engine/engine.cc:770-870).  Streaming keeps single steps at tp = 1 (a Response per token) and short bursts above.
+        tp = self.backend_config.tp
+        burst = int(os.environ.get('TM_STREAM_BURST', '4' if tp > 1 else '1')) if stream else int(os.environ.get('TM_STEP_BURST', '8'))
+        step_many = getattr(self.engine, 'step_many', None) if burst > 1 else None
         try:
             while pending:
-                self.engine.step()
+                if step_many is not None:
+                    step_many(burst)
+                else:
+                    self.engine.step()
                 for rid, i in list(pending.items()):
                     st, toks = self.engine.poll(rid)
                     toks = toks.tolist()

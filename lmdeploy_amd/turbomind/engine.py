@@ -232,6 +232,13 @@ class Engine:
         _ffi.check(self._lib.tm_engine_step(self._h, C.byref(na), C.byref(nw)))
         return na.value, nw.value
 
+    def step_many(self, max_steps: int):
+        """Up to max_steps scheduler iterations in one native call (stops when nothing runs and nothing waits).  Returns
+        (steps_done, n_active, n_waiting).  The call a tensor-parallel rank group mirrors instead of single steps (tp_group.py)."""
+        nd, na, nw = C.c_int(0), C.c_int(0), C.c_int(0)
+        _ffi.check(self._lib.tm_engine_step_many(self._h, int(max_steps), C.byref(nd), C.byref(na), C.byref(nw)))
+        return nd.value, na.value, nw.value
+
     def poll(self, req_id: int, cap: int = 0):
         """(status, tokens generated so far) -- status 0 = waiting / running, 7 = finished, 8 = cancelled."""
         st, n = C.c_int(0), C.c_int(0)

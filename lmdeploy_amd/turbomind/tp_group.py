@@ -29,9 +29,15 @@ import traceback
 from .. import _ffi
 from .engine import Engine
 
-# engine methods every rank must execute, in the same order (everything else is answered by rank 0 alone)
-MIRRORED = ('prefill', 'decode', 'release', 'set_sampling', 'set_logits_params', 'submit', 'step', 'cancel', 'forget', 'tune_gemm',
+# engine methods every rank must execute, in the same order
+MIRRORED = ('prefill', 'decode', 'release', 'set_sampling', 'set_logits_params', 'submit', 'step', 'step_many', 'cancel', 'forget', 'tune_gemm',
             'import_gemm_table', 'sync')
+# reads rank 0 answers alone: they touch no collective and change no state the other ranks would have to follow
+RANK0_READS = ('poll', 'fetch', 'fetch_logits', 'fetch_residual', 'fetch_kv_block', 'stats', 'comm_info', 'prefill_times_ms', 'mixed_steps',
+               'overlapped_steps', 'pick_tiling', 'pick_general', 'export_gemm_table', 'stream', 'cfg', 'batch', 'max_new', 'PROF_CATEGORIES')
+# everything else of Engine either runs a forward or changes engine state on ONE rank (serve_start / serve_stop / wait: the engine thread;
+# profile_decode; init_synthetic / load_weights / start / comm_*: construction): rank 0 alone would enter collectives the workers never
+# join (RCCL: hangs without bound; native communicator: its 30 s give-up, terminal) -- refused loudly
 _TIMEOUT_S = float(os.environ.get('TM_TP_GROUP_TIMEOUT_S', '600'))
 
 
@@ -97,6 +103,9 @@ class ParentLink:
             except OSError as e:       # socket.timeout: a worker never connected
                 self._kill()
                 raise _ffi.TmError(5, f'tensor-parallel workers did not connect within {_TIMEOUT_S:.0f} s: {e}') from None
+            except BaseException:      # e.g. multiprocessing.AuthenticationError from accept(): no worker may outlive the failed constructor
+                self._kill()
+                raise
         self.conns = [by_rank[r] for r in range(1, tp)]
         self.broadcast((model_path, backend_config))
 
@@ -160,6 +169,10 @@ class ParentLink:
                 p.wait(timeout=30)
             except Exception:       # noqa: BLE001 -- subprocess.TimeoutExpired
                 p.terminate()
+                try:
+                    p.wait(timeout=5)
+                except Exception:   # noqa: BLE001
+                    p.kill()
         for c in self.conns:
             c.close()
         self.conns, self.procs = [], []
@@ -206,17 +219,30 @@ class TpEngine:
 
     def __getattr__(self, name):
         attr = getattr(self._eng, name)
-        if name not in MIRRORED:
+        if name in RANK0_READS or name.startswith('_'):
             return attr
+        if name not in MIRRORED:
+            if not callable(attr):
+                return attr
+
+            def refuse(*_a, **_k):
+                raise NotImplementedError(f'Engine.{name} on a one-call tensor-parallel pipeline: it would run on rank 0 alone while the other '
+                                          f'ranks wait in a collective; mirrored calls: {", ".join(MIRRORED)}')
+            return refuse
 
         def call(*args, **kwargs):
             self._link.broadcast((name, args, kwargs))
             err = None
             try:
                 out = attr(*args, **kwargs)
-            except _ffi.TmError as e:
-                err, out = e, None
-            replies = self._link.collect()
+            except BaseException as e:      # noqa: BLE001 -- ANY failure of rank 0's own call (a ValueError from argument conversion as well as
+                err, out = e, None          # a TmError): the workers ran the call and queued a reply each -- drain them, or every later call
+            try:                            # reads the previous call's replies and the ranks drift apart
+                replies = self._link.collect()
+            except BaseException:           # noqa: BLE001 -- a worker died / timed out: rank 0's own error is the more useful one
+                if err is not None:
+                    raise err
+                raise
             if err is not None:
                 raise err
             for r, rep in enumerate(replies, start=1):

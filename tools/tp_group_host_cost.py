@@ -28,6 +28,8 @@ class StubEngine:
 
 
 def child(port, key):
+    import faulthandler
+    faulthandler.dump_traceback_later(15, exit=True, file=open(f'/tmp/tpcost_child_{os.getpid()}.txt', 'w'))
     from multiprocessing.connection import Client
     from lmdeploy_amd.turbomind import tp_group
     conn = Client(('127.0.0.1', port), authkey=bytes.fromhex(key))
@@ -36,13 +38,14 @@ def child(port, key):
     conn.close()
 
 
-def measure(tp, calls):
+def measure(tp, calls, burst=8):
     from multiprocessing.connection import Listener
     from lmdeploy_amd.turbomind import tp_group
     key = os.urandom(16)
     with Listener(('127.0.0.1', 0), authkey=key) as srv:
         port = srv.address[1]
-        procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), '--child', str(port), key.hex()]) for _ in range(tp - 1)]
+        procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), '--child', str(port), key.hex()], stdout=subprocess.DEVNULL,
+                                  stderr=subprocess.DEVNULL, stdin=subprocess.DEVNULL) for _ in range(tp - 1)]
         conns = []
         for _ in range(tp - 1):
             c = srv.accept()
@@ -50,24 +53,36 @@ def measure(tp, calls):
             conns.append(c)
     link = tp_group.ParentLink(tp, 'unused', None, conns=conns)
     eng = tp_group.TpEngine(StubEngine(), link, 'stub')
-    for _ in range(200):
-        eng.step()
-    t0 = time.perf_counter()
-    for _ in range(calls):
-        eng.step()
-    us = (time.perf_counter() - t0) / calls * 1e6
-    link.close()
-    for p in procs:
-        p.wait(timeout=10)
-    return us
+    try:
+        for _ in range(50):
+            eng.step()
+        t0 = time.perf_counter()
+        for _ in range(calls):
+            eng.step()
+        us = (time.perf_counter() - t0) / calls * 1e6
+        t0 = time.perf_counter()
+        for _ in range(max(1, calls // burst)):
+            eng.step_many(burst)
+        us_burst = (time.perf_counter() - t0) / (max(1, calls // burst) * burst) * 1e6
+    finally:
+        link.close()
+        for p in procs:
+            try:
+                p.wait(timeout=10)
+            except Exception:       # noqa: BLE001
+                p.kill()
+    return us, us_burst
 
 
 if __name__ == '__main__':
     if len(sys.argv) > 1 and sys.argv[1] == '--child':
         child(int(sys.argv[2]), sys.argv[3])
         sys.exit(0)
+    import faulthandler; faulthandler.dump_traceback_later(int(os.environ.get("TM_DUMP_S", "100000")), exit=True)
     ap = argparse.ArgumentParser()
     ap.add_argument('--calls', type=int, default=2000)
     a = ap.parse_args()
     for tp in (2, 4, 8):
-        print(json.dumps({'tp': tp, 'us_per_mirrored_call': round(measure(tp, a.calls), 1), 'calls': a.calls, 'host_cpus': os.cpu_count()}))
+        us, usb = measure(tp, a.calls)
+        print(json.dumps({'tp': tp, 'us_per_mirrored_step': round(us, 1), 'us_per_step_in_bursts_of_8': round(usb, 1), 'calls': a.calls,
+                          'host_cpus': os.cpu_count()}), flush=True)
