@@ -93,7 +93,9 @@ int tm_flatten_kv(void* k_out, void* v_out, int transpose_v, const int* cu_k_off
 
 /* Paged flash-decode, one query token per sequence (dispatchDecoding).  q fp16 [batch][q_stride] already
  * rotated (head h at h*128), out fp16 [batch][q_heads*128].  splits >= 1; workspace of
- * tm_decode_attention_workspace() bytes needed when splits > 1.  softmax_scale <= 0 -> 1/sqrt(128). */
+ * tm_decode_attention_workspace() bytes needed when splits > 1.  softmax_scale <= 0 -> 1/sqrt(128).
+ * Every k_len[b] >= 1 and the first block-table entry of every sequence is a mapped block (the engine parks free batch slots on a
+ * dummy block with k_len = 1); a k_len = 0 entry reads that first block and produces no meaningful row. */
 size_t tm_decode_attention_workspace(int batch, int q_heads, int splits);
 int    tm_decode_attention(void* out, const void* q, int q_stride, const int* k_len, int batch, int q_heads,
                            float softmax_scale, int splits, void* workspace, const tm_kv_cache* cache,

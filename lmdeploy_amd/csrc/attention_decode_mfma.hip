@@ -286,7 +286,10 @@ __global__ __launch_bounds__(256, 2) void decode_attention_i8_mfma_kernel(Decode
     const int  nti         = (ctx - 1) & 63;
     int        tile        = tile_end - 1 - wave;  // newest -> oldest, waves interleaved
     // pointers of this wave's first and second block (scalar loads; the clamp keeps the address valid when the wave has fewer blocks)
-    auto        in_range = [&](int t) { return min(max(t, tile_begin), tiles - 1); };  // block tiles - 1 always exists (ctx >= 1)
+    // block tiles - 1 always exists for ctx >= 1 (the contract: tm_decode_attention* require k_len >= 1; the engine parks free slots on a
+    // dummy block with k_len = 1).  The outer max keeps the index at 0 for a k_len = 0 entry all the same: its first block-table entry is
+    // read (and must be a mapped block), never blocks[-1]
+    auto        in_range = [&](int t) { return max(min(max(t, tile_begin), tiles - 1), 0); };
     const char* ptr_cur  = block_ptr(in_range(tile));
     const char* ptr_next = block_ptr(in_range(tile - 4));
     if constexpr (FUSED) {

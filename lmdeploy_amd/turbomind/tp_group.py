@@ -48,6 +48,15 @@ def _setup_comm(eng: Engine, want_rccl: bool, uid: bytes, all_gather, rows: int,
     src/turbomind/comm/device_comm.cc:14-30): the native communicator serves the decode-sized forwards -- one fused launch per
     exchange, as the reference's AllreduceResidualBiasRMSnorm -- and RCCL, where it came up on every rank, keeps the prefill-sized
     ones (side-stream overlap)."""
+    # the switches that decide HOW MANY collectives a forward issues are read by every rank from its own environment (engine_comm.hip:
+    # TM_COMM_STREAM / TM_PIPE_MIN_ROWS / TM_PIPE_MICROBATCH select the two-micro-batch prefill schedule): a mismatch would change the
+    # collective sequence on one rank only and deadlock the group -- compare them before any communicator exists (ADVICE r05)
+    knobs = tuple(os.environ.get(k, '') for k in ('TM_COMM_STREAM', 'TM_PIPE_MIN_ROWS', 'TM_PIPE_MICROBATCH', 'TM_COMM', 'TM_GRAPH_COMM',
+                                                  'TM_FOLD_NORM', 'TM_P2P_DECODE_ROWS'))
+    seen = all_gather(knobs)
+    if any(k != seen[0] for k in seen):
+        raise _ffi.TmError(1, f'tensor-parallel ranks disagree on the collective schedule switches (TM_COMM_STREAM, TM_PIPE_MIN_ROWS, '
+                              f'TM_PIPE_MICROBATCH, TM_COMM, TM_GRAPH_COMM, TM_FOLD_NORM, TM_P2P_DECODE_ROWS) per rank: {seen}')
     ok = False
     if want_rccl:
         try:
