@@ -252,6 +252,19 @@ __global__ __launch_bounds__(CG* WK * 64) void gemm_dec32_kernel(Dec32Params p)
 
     u32x4    ring[PF][2];
     uint32_t sring[PF];
+    // ---- L2 prefetch of the weight stream (ABL 0x4000 / 0x8000: one / two stages beyond the ring; round 6) ----------------------------
+    // The ring holds PF k-blocks per wave: a unit is requested UNR stages before its first use, and VMEM returns in order -- one late HBM
+    // line holds up every younger load of the wave at its next counted wait, and the stage barrier passes the stall to the other 15
+    // waves.  One more instruction per refill touches the unit the wave will request a stage (two) LATER: lane i reads 4 bytes of the
+    // unit's 64-byte sector i (34 sectors = 2176 B), `sc1` (no L1 allocation), into a register nobody reads -- the HBM request is in
+    // flight a stage earlier, the ring's own `nt` load of that unit finds the line in (or on its way into) the XCD's L2.  HBM bytes are
+    // unchanged; L1 -> L2 requests grow by one 64-lane dword load per 2 KB of weights.
+    constexpr bool L2PF = (ABL & 0xc000) != 0;
+    constexpr int  PFD  = (ABL & 0x8000) ? 2 : 1;  // stages beyond the ring
+    constexpr int  NLD  = L2PF ? 4 : 3;            // compiler-visible VMEM loads per ring slot refill
+    static_assert(!L2PF || (ABL & 0x100), "the L2 prefetch is written for the LDS-DMA staging mode");
+    uint32_t  pfv[L2PF ? PF : 1];
+    const int vpf = min(tid & 63, 33) * 64;
     u32x4    xr[XR];
     int      xoff[XR], xlds[XR];
 #pragma unroll
@@ -312,6 +325,10 @@ __global__ __launch_bounds__(CG* WK * 64) void gemm_dec32_kernel(Dec32Params p)
         ring[slot][0] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, vw, uo_, /*nt*/ 2);                           \
         ring[slot][1] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, vw + 1024, uo_, /*nt*/ 2);                    \
         sring[slot]   = __builtin_amdgcn_raw_buffer_load_b32(rs_w, vs, uo_, 0);                                   \
+        if constexpr (L2PF) {                                                                                     \
+            const int up_ = ((kb0 + min((b) + PFD * S, nkb - 1)) * p.ncg + cgc) * kP32Unit;                       \
+            pfv[slot]     = __builtin_amdgcn_raw_buffer_load_b32(rs_w, vpf, up_, /*sc1*/ 16);                     \
+        }                                                                                                         \
     }
 #define D32_LOAD_X(t)                                                                                             \
     _Pragma("unroll") for (int r = 0; r < XR; ++r)                                                                \
@@ -346,7 +363,7 @@ __global__ __launch_bounds__(CG* WK * 64) void gemm_dec32_kernel(Dec32Params p)
             if (p.dbg) {
                 ts_issued = __builtin_amdgcn_s_memrealtime();
             }
-            asm volatile("s_waitcnt vmcnt(%0)" ::"i"((ABL & 0x1000) ? 0 : 3 * PF0) : "memory");
+            asm volatile("s_waitcnt vmcnt(%0)" ::"i"((ABL & 0x1000) ? 0 : NLD * PF0) : "memory");
         }
         else {
             if (scaled) {
@@ -399,6 +416,9 @@ __global__ __launch_bounds__(CG* WK * 64) void gemm_dec32_kernel(Dec32Params p)
 #pragma unroll
                 for (int i = 0; i < BPS; ++i) {
                     asm volatile("" ::"v"(ring[u * BPS + i][0]), "v"(ring[u * BPS + i][1]), "v"(sring[u * BPS + i]));
+                    if constexpr (L2PF) {  // issued right behind them, UNR stages ago: keeps the load alive and hipcc's counts exact
+                        asm volatile("" ::"v"(pfv[u * BPS + i]));
+                    }
                 }
                 if (p.dbg && t == 0) {
                     ts_w0 = __builtin_amdgcn_s_memrealtime();
@@ -531,7 +551,7 @@ __global__ __launch_bounds__(CG* WK * 64) void gemm_dec32_kernel(Dec32Params p)
             if constexpr (DMA && !(ABL & 8)) {
                 // my DMA pieces of stage t+1 have landed when at most the 3 * BPS refills issued after them are in flight.  In
                 // the remainder those refills are dead code (nobody consumes them, hipcc drops them): drain instead.
-                asm volatile("s_waitcnt vmcnt(%0)" ::"i"((rem || (ABL & (16 | 0x2000))) ? 0 : 3 * BPS) : "memory");
+                asm volatile("s_waitcnt vmcnt(%0)" ::"i"((rem || (ABL & (16 | 0x2000))) ? 0 : NLD * BPS) : "memory");
             }
             __syncthreads();
         };
@@ -1160,6 +1180,11 @@ static int launch_pre64_one(const Dec32Params& p, dim3 grid, hipStream_t st)
 // measured neutral, the rotated k walk neutral at M = 64 and -5..-10 % at M = 8192: it breaks the L2 reuse of the weights
 // between row blocks)
 constexpr int kD32Mode = 0x900;
+#ifdef TM_EXPERIMENTS
+constexpr bool l2pf_compiled = true;
+#else
+constexpr bool l2pf_compiled = false;
+#endif
 
 // TM_EXPERIMENTS (compile-time, off in the shipped library): the timing / structure ablations of tools/trace_dec32.py and
 // tools/bench_gemm.py (TM_D32_ABL) -- ~40 further instantiations of the kernel whose results are garbage by design.
@@ -1168,6 +1193,14 @@ static int launch_dec32_shape(const Dec32Params& p, dim3 grid, int shape, hipStr
 {
 #ifdef TM_EXPERIMENTS
     static const int abl = env_int2("TM_D32_ABL", -1);
+#endif
+    // TM_D32_L2PF = 1 / 2 (TM_EXPERIMENTS builds): the weight stream's L2 prefetch one / two stages beyond the ring (ABL 0x4000 / 0x8000; shapes 0, 3 and
+    // their 32-row forms).  Measured negative in round 6 (profiles/r06_l2pf_*: parity-green, w1w3's loop 14.9 -> 16.1 us, driver line -1.5 .. -2 %):
+    // the loop does not wait for late weight lines -- one more request per 2 KB of weights in the CU's load path costs more than it hides.
+#ifdef TM_EXPERIMENTS
+    static const int l2pf = env_int2("TM_D32_L2PF", 0);
+#else
+    constexpr int l2pf = 0;
 #endif
     if constexpr (MH == 4) {
         // row blocks of 128 rows x 256 columns, 8 waves of 32 columns over the whole k slice (M > 64): every dequantised
@@ -1212,6 +1245,10 @@ static int launch_dec32_shape(const Dec32Params& p, dim3 grid, int shape, hipStr
                 }
             }
 #endif
+            if constexpr (l2pf_compiled) {
+                if (l2pf == 1) return launch_dec32_one<MH, 4, 4, 4, 2, kD32Mode | 0x4000>(p, grid, st);
+                if (l2pf == 2) return launch_dec32_one<MH, 4, 4, 4, 2, kD32Mode | 0x8000>(p, grid, st);
+            }
             return launch_dec32_one<MH, 4, 4, 4, 2, kD32Mode>(p, grid, st);
         }
         case 1:  // 16 waves: 8 column groups x 2 k-phases (256 columns per workgroup), two k-blocks per wave per stage
@@ -1219,6 +1256,10 @@ static int launch_dec32_shape(const Dec32Params& p, dim3 grid, int shape, hipStr
         case 2:  // 8 waves: 4 column groups x 2 k-phases
             return launch_dec32_one<MH, 4, 2, 4, 4, kD32Mode>(p, grid, st);
         case 3:  // 8 waves: 2 column groups x 4 k-phases (64 columns per workgroup)
+            if constexpr (l2pf_compiled) {
+                if (l2pf == 1) return launch_dec32_one<MH, 2, 4, 4, 2, kD32Mode | 0x4000>(p, grid, st);
+                if (l2pf == 2) return launch_dec32_one<MH, 2, 4, 4, 2, kD32Mode | 0x8000>(p, grid, st);
+            }
             return launch_dec32_one<MH, 2, 4, 4, 2, kD32Mode>(p, grid, st);
         case kShapeWide2:  // 16 waves: 8 column groups x 2 k-phases (256 columns per workgroup) on 2-k-block stages, ring depth 2: shape 0's
                            // per-wave rhythm (one k-block per wave and stage) without shape 1's register spills (60 B / lane at 128 VGPRs)
