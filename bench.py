@@ -381,7 +381,10 @@ def main():
             out = [None] * world
             dist.all_gather_object(out, h)
             return out
-        want_native = os.environ.get('TM_COMM', 'rccl') == 'native'
+        # default (round 6): RCCL for the prefill-sized forwards + the native fused all-reduce + residual + RMSNorm for the decode-sized
+        # ones, taken only when its bring-up self-test passes on every rank; TM_COMM=rccl keeps RCCL alone, TM_COMM=native drops RCCL
+        mode = os.environ.get('TM_COMM', 'hybrid')
+        want_native = mode == 'native'
         uid = [Engine.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(uid, src=0)
         rccl_ok = True
@@ -395,10 +398,25 @@ def main():
             comm_note = f'RCCL init failed on ranks {[r for r, ok in enumerate(oks) if not ok]} -> native P2P communicator'
             want_native = True
             eng.comm_drop_rccl()
-        if want_native:                 # fused P2P all-reduce + residual + RMSNorm for the decode steps
+        if want_native:                 # TM_COMM=native (or no RCCL): the native communicator without the self-test's fall-back
             eng.comm_native_setup(gather, rows=max(B, 1))
+        elif mode != 'rccl':            # hybrid: the native communicator on top of RCCL, if its self-test passes everywhere
+            try:
+                eng.comm_native_setup(gather, rows=max(B, 1))
+                good = eng.comm_native_selftest()
+            except Exception as exc:    # noqa: BLE001
+                print(f'[bench] rank {rank}: native communicator bring-up failed ({exc})', file=sys.stderr)
+                good = False
+            goods = gather(bool(good))
+            if not all(goods):
+                eng.comm_native_drop()
+                comm_note = (comm_note + '; ' if comm_note else '') + (f'native communicator self-test failed on ranks '
+                                                                       f'{[r for r, g in enumerate(goods) if not g]} -> RCCL + residual-norm launch')
     elif emu > 1:
         eng.comm_init(Engine.comm_unique_id())
+        if os.environ.get('TM_COMM', 'hybrid') != 'rccl':   # the rank's DEFAULT decode collective: the fused launch (one-rank communicator)
+            eng.comm_native_setup(lambda h: [h], rows=max(B, 1))
+            assert eng.comm_native_selftest(), 'native communicator self-test (one rank)'
     dog.arm('weights + engine start', 600)
     eng.init_synthetic(seed=0)          # same seed on every rank: shards are generated per rank-local shape
     eng.start()

@@ -267,6 +267,16 @@ int tm_p2p_allgather(void* const* segs, int tp, int me, void* state, int rows, i
  * [256 B flags | one-shot tile 0 | tile 1 (rows x H each) | in2 | out2 (rows2 x H each)], M <= rows2; shares `state` and the call
  * sequence with the one-shot calls (it advances the epoch by two). */
 size_t tm_p2p_segment_bytes2(int rows, int rows2, int H);
+/* One-shot form whose workgroups do not wait for each other (round 6): one workgroup owns a token row end to end -- its own call counter
+ * (state[4 + row]), write-through system-scope stores of its partial row, ONE flag word per (sender, row) in every peer's segment, system-
+ * scope loads of the peers' rows -- no tickets, no shared epoch, no residency requirement, no L2 write-back / invalidate on the path; same
+ * arithmetic and bits as tm_p2p_allreduce_norm.  Segments of tm_p2p_segment_bytes_rows(rows, rows2, H) bytes = the two-shot layout followed
+ * by [row tile 0 | row tile 1 (rows x H each) | flags [8][rows]]; state = 4 + rows zeroed local words; M <= rows.  Its calls are
+ * independent of the shared call sequence of the other tm_p2p_* entry points (own tiles, own flags).  This is what the engine's decode-sized
+ * exchanges run (fused_allreduce.cu:406-500 called at unified_decoder.cc:278-285,328-335). */
+size_t tm_p2p_segment_bytes_rows(int rows, int rows2, int H);
+int tm_p2p_allreduce_norm_rows(void* const* segs, int tp, int me, void* state, int rows, int rows2, const void* partial, void* y, void* resid,
+                               const void* weight, float eps, int M, int H, tm_stream_t st);
 int tm_p2p_allreduce_norm_2shot(void* const* segs, int tp, int me, void* state, int rows, int rows2, const void* partial, void* y,
                                 void* resid, const void* weight, float eps, int M, int H, tm_stream_t st);
 
@@ -356,6 +366,14 @@ int tm_engine_comm_init(tm_engine* e, const void* host_id128);
 int tm_engine_comm_drop_rccl(tm_engine* e);   /* continue on the native communicator alone (every rank must call it) */
 int tm_engine_comm_native_export(tm_engine* e, int rows, void* handle64);              /* after tm_engine_comm_init */
 int tm_engine_comm_native_import(tm_engine* e, const void* handles, int count);        /* count = tp handles, rank order */
+/* Collective bring-up check of the native communicator (every rank, right after the import): two fused launches over a known pattern;
+ * *ok = 0 -> every rank calls tm_engine_comm_native_drop and the decode-sized exchanges stay on RCCL + the residual-norm launch.  The
+ * hop between devices (system-scope visibility over xGMI) is what no single-GPU test exercises; the default tensor-parallel arrangement
+ * -- native fused all-reduce + residual + RMSNorm for decode-sized forwards (the reference's AllreduceResidualBiasRMSnorm,
+ * src/turbomind/comm/cuda_ipc/fused_allreduce.cu:406-500, called at unified_decoder.cc:278-285,328-335), RCCL for prefill-sized ones --
+ * is taken only when it passed on every rank. */
+int tm_engine_comm_native_selftest(tm_engine* e, int* ok);
+int tm_engine_comm_native_drop(tm_engine* e);
 
 /* Weight hand-off: named Param slots, already TP-sharded / QKV-fused / w1w3-interleaved by the loader
  * (lmdeploy/turbomind/builders/_base.py:72-113).  Names: "layers.{i}.attention.w_qkv.{qweight,scales,zeros}",

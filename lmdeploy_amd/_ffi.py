@@ -138,6 +138,8 @@ _SIGNATURES = {
     'tm_debug_tiling_candidates': (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_int, POINTER(c_int)]),
     'tm_engine_comm_native_export': (c_int, [c_void_p, c_int, c_void_p]),
     'tm_engine_comm_native_import': (c_int, [c_void_p, c_void_p, c_int]),
+    'tm_engine_comm_native_selftest': (c_int, [c_void_p, POINTER(c_int)]),
+    'tm_engine_comm_native_drop': (c_int, [c_void_p]),
     'tm_p2p_segment_create': (c_int, [c_size_t, POINTER(c_void_p), c_void_p]),
     'tm_p2p_segment_open': (c_int, [c_void_p, POINTER(c_void_p)]),
     'tm_p2p_segment_close': (c_int, [c_void_p, c_int]),
@@ -145,6 +147,9 @@ _SIGNATURES = {
     'tm_p2p_allreduce_norm': (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int,
                                c_int, c_void_p]),
     'tm_p2p_segment_bytes2': (c_size_t, [c_int, c_int, c_int]),
+    'tm_p2p_segment_bytes_rows': (c_size_t, [c_int, c_int, c_int]),
+    'tm_p2p_allreduce_norm_rows': (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_float,
+                                           c_int, c_int, c_void_p]),
     'tm_p2p_allreduce_norm_2shot': (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_float,
                                             c_int, c_int, c_void_p]),
     'tm_p2p_allgather': (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p]),

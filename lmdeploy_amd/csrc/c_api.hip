@@ -811,6 +811,26 @@ int tm_p2p_allreduce_norm_2shot(void* const* segs, int tp, int me, void* state, 
                                            (half_t*)resid, (const half_t*)weight, eps, M, H, (hipStream_t)st);
 }
 
+size_t tm_p2p_segment_bytes_rows(int rows, int rows2, int H)
+{
+    return tm_p2p_segment_bytes2(rows, rows2, H) + 2 * (size_t)rows * (size_t)H * sizeof(half_t) + 8 * (size_t)rows * sizeof(uint32_t);
+}
+
+int tm_p2p_allreduce_norm_rows(void* const* segs, int tp, int me, void* state, int rows, int rows2, const void* partial, void* y, void* resid,
+                               const void* weight, float eps, int M, int H, tm_stream_t st)
+{
+    TM_REQUIRE(segs && state && partial && y && resid && weight, "null pointer");
+    TM_REQUIRE(tp >= 1 && tp <= 8 && rows >= 1 && rows2 >= 0, "p2p: 1 <= tp <= 8");
+    half_t*   rdata[8];
+    uint32_t* rflags[8];
+    for (int r = 0; r < tp; ++r) {  // [flags | tile 0 | tile 1 | in2 | out2 | row tile 0 | row tile 1 | row flags [8][rows]]
+        rdata[r]  = (half_t*)((char*)segs[r] + tm_p2p_segment_bytes2(rows, rows2, H));
+        rflags[r] = (uint32_t*)(rdata[r] + 2 * (size_t)rows * H);
+    }
+    return launch_p2p_allreduce_norm_rows(rdata, rflags, rows, tp, me, (uint32_t*)state, (size_t)rows * H, (const half_t*)partial, (half_t*)y,
+                                          (half_t*)resid, (const half_t*)weight, eps, M, H, (hipStream_t)st);
+}
+
 int tm_p2p_allgather(void* const* segs, int tp, int me, void* state, int rows, int H, const void* src, void* dst, int words,
                      tm_stream_t st)
 {

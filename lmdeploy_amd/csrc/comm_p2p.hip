@@ -36,6 +36,7 @@
 #include "tm_kernels.h"
 #include <algorithm>
 #include <stdlib.h>
+#include <atomic>
 
 namespace tmk {
 
@@ -61,13 +62,30 @@ struct P2pParams {
     int             n;
     size_t          dst_stride;
     uint64_t        timeout;  // bound of a peer wait in 100 MHz ticks (p2p_timeout_ticks)
+    // row-flag form (p2p_allreduce_norm_rows_kernel, round 6): its own two tiles and one flag word per (sender, row) in every segment
+    half_t*         rdata[8];
+    uint32_t*       rflags[8];  // [8 senders][rows_cap]
+    int             rows_cap;
 };
 
 // Wait bound of a peer flag, in ticks of the 100 MHz realtime counter.  TM_P2P_TIMEOUT_MS, default 30 s (read once): RCCL has no
 // bound at all, and ranks are host-driven one by one -- graph capture, a first-use code load or a descheduled host thread on ONE
 // rank must not end the job (the former bound was ~1 s of polling).  On expiry: state[3] = the epoch, the engine
 // fails the step and refuses further work (engine_comm.hip: device_marks_check).
+static std::atomic<uint64_t> g_p2p_timeout_cap{0};  // > 0: upper bound of the wait while a bring-up self-test runs (tm_engine_comm_native_selftest)
+void p2p_timeout_cap_ms(long ms)
+{
+    g_p2p_timeout_cap.store(ms > 0 ? (uint64_t)ms * 100000ull : 0);
+}
+
+static uint64_t p2p_timeout_ticks_base();
 static uint64_t p2p_timeout_ticks()
+{
+    const uint64_t cap = g_p2p_timeout_cap.load(), t = p2p_timeout_ticks_base();
+    return cap && cap < t ? cap : t;
+}
+
+static uint64_t p2p_timeout_ticks_base()
 {
     static const uint64_t t = [] {
         const char* v  = getenv("TM_P2P_TIMEOUT_MS");
@@ -81,6 +99,11 @@ static uint64_t p2p_timeout_ticks()
 // THIS launch came before: the entry tickets (state[1]) run monotonically through a launch -- sync k publishes at ticket
 // (k + 1) * gridDim.x - 1 -- and are reset by p2p_exit only, when every workgroup is past its last sync (a reset
 // between two syncs of one launch could wipe an early ticket of the second).
+// WT (round 6, the one-shot kernel): the payload went out through WRITE-THROUGH system-scope stores (sc0 sc1) and the consumer reads the
+// peers' rows with system-scope loads -- the drained stores are the publish, no L2 write-back (release fence, 1.7 .. 6.5 us) and no
+// cache invalidate (acquire fence, ~1.7 us) on the path of a decode-sized exchange (MI355X_MICROARCH.md, valid forms: "{sc0 sc1 stores and
+// loads both sides}"; price list: handoff-flag, drained write-through payload vs plain + release).
+template<bool WT = false>
 __device__ __forceinline__ void p2p_publish_and_wait(const P2pParams& p, uint32_t epoch, uint32_t phase = 0)
 {
     const int tid = threadIdx.x;
@@ -89,7 +112,9 @@ __device__ __forceinline__ void p2p_publish_and_wait(const P2pParams& p, uint32_
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");  // system scope: this XCD's dirty lines of the tile leave the L2
+        if constexpr (!WT) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");  // system scope: this XCD's dirty lines of the tile leave the L2
+        }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const uint32_t t = __hip_atomic_fetch_add(p.state + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (t == (phase + 1) * gridDim.x - 1) {  // every workgroup (hence every XCD that ran one) has written back
@@ -110,7 +135,9 @@ __device__ __forceinline__ void p2p_publish_and_wait(const P2pParams& p, uint32_
                 break;
             }
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");  // system scope
+        if constexpr (!WT) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");  // system scope
+        }
     }
     __syncthreads();
 }
@@ -138,31 +165,33 @@ __global__ __launch_bounds__(512) void p2p_allreduce_norm_kernel(P2pParams p)
         s_epoch = __hip_atomic_load(p.state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
     }
     __syncthreads();
-    const uint32_t epoch = s_epoch;
+    const uint32_t epoch = __builtin_amdgcn_readfirstlane(s_epoch);  // wave-uniform for the compiler too: it becomes part of buffer descriptors
     const size_t   boff  = (size_t)(epoch & 1) * p.tile;
 
     const int row  = blockIdx.x;
     const int nvec = p.H / 8;
-    half8_t   wv[NV], r[NV];
+    half8_t   wv[NV], r[NV], mine[NV];
     size_t    off[NV];
     bool      ok[NV];
     // ---- 0. own partial row -> own segment; the loads that do not depend on the peers are issued here as well -------------
+    // The row leaves through write-through system-scope stores (16 bytes, `sc0 sc1`; the asm ends with s_nop 1: cdna_hip_programming.md 5.7
+    // item 1): once a wave's vmcnt is 0 its part of the row is in memory, where the peers' system-scope loads find it -- no L2 write-back.
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const int vi = tid + i * blockDim.x;
         ok[i]        = vi < nvec;
         const int vc = ok[i] ? vi : nvec - 1;
         off[i]       = (size_t)row * p.H + (size_t)vc * 8;
-        const half8_t mine = *(const half8_t*)(p.partial + off[i]);
+        mine[i]      = *(const half8_t*)(p.partial + off[i]);
         wv[i]        = *(const half8_t*)(p.weight + (size_t)vc * 8);
         r[i]         = *(const half8_t*)(p.resid + off[i]);
-        if (ok[i]) {
-            *(half8_t*)(p.data[p.me] + boff + off[i]) = mine;
+        if (ok[i] && p.tp > 1) {  // (one rank: nobody reads the segment)
+            asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(p.data[p.me] + boff + off[i]), "v"(mine[i]) : "memory");
         }
     }
     __syncthreads();
     // ---- 1 + 2 ------------------------------------------------------------------------------------------------------------
-    p2p_publish_and_wait(p, epoch);
+    p2p_publish_and_wait<true>(p, epoch);
 
     // ---- 3. reduce + residual + RMSNorm of row blockIdx.x (rmsnorm_kernel<1> arithmetic) ---------------------------------
     float ss = 0.f;
@@ -170,8 +199,13 @@ __global__ __launch_bounds__(512) void p2p_allreduce_norm_kernel(P2pParams p)
     for (int i = 0; i < NV; ++i) {
         float acc[8] = {};
         for (int q = 0; q < p.tp; ++q) {  // rank order: the same association on every rank
-            const u32x4   raw = __builtin_nontemporal_load((const u32x4*)(p.data[q] + boff + off[i]));
-            const half8_t v   = bit_cast<half8_t>(raw);
+            // the own row from registers (the bits that were stored); a peer's row by a system-scope load (sc0 sc1: served by memory, not by
+            // this device's caches -- what replaces the acquire fence)
+            half8_t v = mine[i];
+            if (q != p.me) {
+                const auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)(p.data[q] + boff), 0, (int)(p.tile * 2), 0x00020000);
+                v             = bit_cast<half8_t>(__builtin_amdgcn_raw_buffer_load_b128(rs, (int)(off[i] * 2), 0, /*sc0 sc1*/ 17));
+            }
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 acc[e] += (float)v[e];
@@ -215,6 +249,129 @@ __global__ __launch_bounds__(512) void p2p_allreduce_norm_kernel(P2pParams p)
         }
     }
     p2p_exit(p, epoch);
+}
+
+// ---- one-shot form WITHOUT any coupling between the workgroups of a launch (round 6) -----------------------------------------------
+// The kernel above pays, per exchange, a local fan-in (every workgroup's ticket -> the last one publishes the call's epoch), a fan-out
+// (every workgroup polls that one flag) and an exit fan-in (the epoch word): three device-scope round trips on the critical path of a
+// 64-row decode exchange whatever the peers do (8 us per launch with ONE rank, profiles/r06_tp_default_*).  Here a workgroup owns one
+// token row END TO END: it reads the row's call counter (state[4 + row], a local word only it touches), pushes its partial row into its
+// own segment with write-through system-scope stores, drains, stores the counter value into flag [me][row] of every peer's segment,
+// polls flags [q][row] of its own segment, sums the peers' rows (system-scope loads) in rank order, normalises, and writes the counter
+// back.  No ticket, no shared epoch, no requirement that the launch's workgroups are resident together.  Same arithmetic, same bits.
+// Buffer reuse: call c of row m uses tile (c & 1); a rank's call c + 1 starts after its call c has finished (stream order), a peer's flag
+// for c + 1 is stored after that peer's call c + 1 wrote its row -- so when this rank overwrites tile (c & 1) in call c + 2, every peer
+// has finished call c (it published c + 1 before this rank could leave call c + 1's poll).  The tiles and flags are this form's own:
+// the all-gather / two-shot calls keep the shared epoch and their regions.
+// Replaces: the same AllreduceResidualBiasRMSnorm (fused_allreduce.cu:406-500); per-row flags are what its "flags per block" barrier does.
+template<int NV>
+__global__ __launch_bounds__(512) void p2p_allreduce_norm_rows_kernel(P2pParams p)
+{
+    __shared__ float    red[8];
+    __shared__ uint32_t s_epoch;
+    const int tid = threadIdx.x;
+    const int row = blockIdx.x;
+    uint32_t* const ctr = p.state + 4 + row;
+    if (tid == 0) {
+        s_epoch = __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
+    }
+    const int nvec = p.H / 8;
+    half8_t   wv[NV], r[NV], mine[NV];
+    size_t    off[NV];
+    bool      ok[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {  // everything that does not depend on the call counter or the peers
+        const int vi = tid + i * blockDim.x;
+        ok[i]        = vi < nvec;
+        const int vc = ok[i] ? vi : nvec - 1;
+        off[i]       = (size_t)row * p.H + (size_t)vc * 8;
+        mine[i]      = *(const half8_t*)(p.partial + off[i]);
+        wv[i]        = *(const half8_t*)(p.weight + (size_t)vc * 8);
+        r[i]         = *(const half8_t*)(p.resid + off[i]);
+    }
+    __syncthreads();
+    const uint32_t epoch = __builtin_amdgcn_readfirstlane(s_epoch);
+    const size_t   boff  = (size_t)(epoch & 1) * p.tile;
+    if (p.tp > 1) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            if (ok[i]) {
+                asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(p.rdata[p.me] + boff + off[i]), "v"(mine[i]) : "memory");
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every wave: its part of the row is in memory
+        __syncthreads();
+        if (tid < p.tp && tid != p.me) {
+            __hip_atomic_store(p.rflags[tid] + (size_t)p.me * p.rows_cap + row, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            const uint32_t* f  = p.rflags[p.me] + (size_t)tid * p.rows_cap + row;
+            const uint64_t  t0 = __builtin_amdgcn_s_memrealtime();
+            uint32_t        spins = 0;
+            // ">= epoch" (wrap-safe): the peer may be one call ahead (never two: the reuse argument above)
+            while ((int32_t)(__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - epoch) < 0) {
+                __builtin_amdgcn_s_sleep(1);
+                if ((++spins & 63u) == 0 && __builtin_amdgcn_s_memrealtime() - t0 > p.timeout) {
+                    __hip_atomic_store(p.state + 3, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    break;
+                }
+            }
+        }
+        __syncthreads();
+    }
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        float acc[8] = {};
+        for (int q = 0; q < p.tp; ++q) {  // rank order: the same association on every rank
+            half8_t v = mine[i];
+            if (q != p.me) {
+                const auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)(p.rdata[q] + boff), 0, (int)(p.tile * 2), 0x00020000);
+                v             = bit_cast<half8_t>(__builtin_amdgcn_raw_buffer_load_b128(rs, (int)(off[i] * 2), 0, /*sc0 sc1*/ 17));
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                acc[e] += (float)v[e];
+            }
+        }
+        half8_t h;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            h[e] = (half_t)acc[e];
+        }
+        r[i] = r[i] + h;
+        if (ok[i]) {
+            *(half8_t*)(p.resid + off[i]) = r[i];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float f = (float)r[i][e];
+                ss            = __builtin_fmaf(f, f, ss);
+            }
+        }
+    }
+    ss = group_sum<64>(ss);
+    if ((tid & 63) == 0) {
+        red[tid >> 6] = ss;
+    }
+    __syncthreads();
+    float tot = 0.f;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) {
+        tot += red[w];
+    }
+    const float inv = 1.0f / __builtin_sqrtf(tot / (float)p.H + p.eps);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        if (ok[i]) {
+            half8_t o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const half_t n = (half_t)((float)r[i][e] * inv);
+                o[e]           = n * wv[i][e];
+            }
+            *(half8_t*)(p.y + off[i]) = o;
+        }
+    }
+    if (tid == 0) {
+        __hip_atomic_store(ctr, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 
 // ---- two-shot form for large messages ---------------------------------------------------------------------------------------
@@ -459,6 +616,39 @@ int launch_p2p_allreduce_norm(half_t* const* data, uint32_t* const* flags, int t
     }
     else {
         p2p_allreduce_norm_kernel<2><<<M, t, 0, st>>>(p);
+    }
+    TM_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// row-flag form: rdata[r] = rank r's two row tiles (`tile` fp16 elements each), rflags[r] = its [8][rows_cap] flag words, state = 4 +
+// rows_cap local words (zeroed once); any M <= rows_cap (no residency requirement: the workgroups of a launch do not wait for each other)
+int launch_p2p_allreduce_norm_rows(half_t* const* rdata, uint32_t* const* rflags, int rows_cap, int tp, int me, uint32_t* state, size_t tile,
+                                   const half_t* partial, half_t* y, half_t* resid, const half_t* weight, float eps, int M, int H, hipStream_t st)
+{
+    TM_REQUIRE(tp >= 1 && tp <= 8 && me >= 0 && me < tp, "p2p all-reduce: 1 <= tp <= 8");
+    TM_REQUIRE(H % 8 == 0 && H <= 8192, "p2p all-reduce: H % 8 == 0, H <= 8192");
+    TM_REQUIRE(M <= rows_cap && (size_t)rows_cap * H <= tile && tile % 8 == 0, "p2p all-reduce (row flags): M <= rows, the tile holds rows x H");
+    if (M == 0) {
+        return 0;
+    }
+    P2pParams p{};
+    for (int r = 0; r < tp; ++r) {
+        p.rdata[r]  = rdata[r];
+        p.rflags[r] = rflags[r];
+    }
+    p.rows_cap = rows_cap;
+    p.tp = tp, p.me = me, p.state = state, p.tile = tile, p.partial = partial, p.y = y, p.resid = resid, p.weight = weight;
+    p.timeout = p2p_timeout_ticks();
+    p.eps = eps, p.M = M, p.H = H;
+    const int nvec = H / 8;
+    int       t    = (nvec + 63) / 64 * 64;
+    t              = t > 512 ? 512 : t;
+    if ((nvec + t - 1) / t == 1) {
+        p2p_allreduce_norm_rows_kernel<1><<<M, t, 0, st>>>(p);
+    }
+    else {
+        p2p_allreduce_norm_rows_kernel<2><<<M, t, 0, st>>>(p);
     }
     TM_HIP_CHECK(hipGetLastError());
     return 0;

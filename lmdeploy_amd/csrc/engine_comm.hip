@@ -110,6 +110,39 @@ void p2p_tables(tm_engine* e, half_t** data, uint32_t** flags)
     }
 }
 
+// the row-flag form's own tiles and flags: behind the two-shot regions of every segment (tm_p2p_segment_bytes_rows)
+static void p2p_row_tables(tm_engine* e, half_t** rdata, uint32_t** rflags)
+{
+    const size_t off = tm_p2p_segment_bytes2(e->p2p_rows, e->p2p_rows2, e->hidden);
+    for (int r = 0; r < e->cfg.tp; ++r) {
+        char* base = (char*)(r == e->cfg.rank ? e->p2p_seg : e->p2p_peer[r]);
+        rdata[r]   = (half_t*)(base + off);
+        rflags[r]  = (uint32_t*)(rdata[r] + 2 * (size_t)e->p2p_rows * e->hidden);
+    }
+}
+
+// one decode-sized exchange: ONE launch, its workgroups independent of each other (comm_p2p.hip: p2p_allreduce_norm_rows_kernel);
+// TM_P2P_ROWFLAGS=0: the ticket form (p2p_allreduce_norm_kernel)
+static int p2p_oneshot(tm_engine* e, const half_t* partial, half_t* y, half_t* resid, const half_t* norm_w, int rows)
+{
+    static const bool rowflags = [] {
+        const char* v = getenv("TM_P2P_ROWFLAGS");
+        return !v || atoi(v) != 0;
+    }();
+    if (rowflags) {
+        half_t*   rdata[8];
+        uint32_t* rflags[8];
+        p2p_row_tables(e, rdata, rflags);
+        return launch_p2p_allreduce_norm_rows(rdata, rflags, e->p2p_rows, e->cfg.tp, e->cfg.rank, e->p2p_state, (size_t)e->p2p_rows * e->hidden,
+                                              partial, y, resid, norm_w, e->cfg.model.rms_eps, rows, e->hidden, e->stream);
+    }
+    half_t*   data[8];
+    uint32_t* flags[8];
+    p2p_tables(e, data, flags);
+    return launch_p2p_allreduce_norm(data, flags, e->cfg.tp, e->cfg.rank, e->p2p_state, (size_t)e->p2p_rows * e->hidden, partial, y, resid, norm_w,
+                                     e->cfg.model.rms_eps, rows, e->hidden, e->stream);
+}
+
 // d_x = RMSNorm(d_resid += sum over ranks of d_tmp): one fused P2P launch per <= p2p_rows rows on the native communicator
 // (any M when there is no RCCL communicator to fall back to), else RCCL all-reduce + the residual-norm kernel
 int reduce_residual_norm(tm_engine* e, int M, const half_t* norm_w)
@@ -131,13 +164,10 @@ int reduce_residual_norm(tm_engine* e, int M, const half_t* norm_w)
                                                                         e->cfg.model.rms_eps, M, e->hidden, e->stream)));
             return 0;
         }
-        const size_t tile = (size_t)e->p2p_rows * e->hidden;
         for (int m0 = 0; m0 < M; m0 += e->p2p_rows) {
             const int    rows = std::min(e->p2p_rows, M - m0);
             const size_t off  = (size_t)m0 * e->hidden;
-            TM_PROF(P_ALLREDUCE, TM_TRY(launch_p2p_allreduce_norm(data, flags, e->cfg.tp, e->cfg.rank, e->p2p_state, tile, e->d_tmp + off,
-                                                                  e->d_x + off, e->d_resid + off, norm_w, e->cfg.model.rms_eps, rows,
-                                                                  e->hidden, e->stream)));
+            TM_PROF(P_ALLREDUCE, TM_TRY(p2p_oneshot(e, e->d_tmp + off, e->d_x + off, e->d_resid + off, norm_w, rows)));
         }
         return 0;
     }
@@ -258,10 +288,10 @@ int tm_engine_comm_native_export(tm_engine* e, int rows, void* handle64)
     // two-shot regions for everything a forward can carry (TM_P2P_2SHOT=0: one-shot row chunks only)
     const char* ts = getenv("TM_P2P_2SHOT");
     const int   rows2 = (ts && !atoi(ts)) ? 0 : std::max(e->cfg.max_prefill_token_num, e->cfg.max_batch_size);
-    TM_TRY(tm_p2p_segment_create(tm_p2p_segment_bytes2(rows, rows2, e->hidden), &e->p2p_seg, handle64));
+    TM_TRY(tm_p2p_segment_create(tm_p2p_segment_bytes_rows(rows, rows2, e->hidden), &e->p2p_seg, handle64));
     e->p2p_rows2 = rows2;
-    TM_HIP_CHECK(hipMalloc((void**)&e->p2p_state, 4 * sizeof(uint32_t)));
-    TM_HIP_CHECK(hipMemset(e->p2p_state, 0, 4 * sizeof(uint32_t)));
+    TM_HIP_CHECK(hipMalloc((void**)&e->p2p_state, (4 + (size_t)rows) * sizeof(uint32_t)));  // [0..3] shared call state, [4 + row] per-row call counters
+    TM_HIP_CHECK(hipMemset(e->p2p_state, 0, (4 + (size_t)rows) * sizeof(uint32_t)));
     e->p2p_rows = rows;
     return 0;
 }
@@ -278,6 +308,100 @@ int tm_engine_comm_native_import(tm_engine* e, const void* handles, int count)
         }
     }
     e->p2p_ready = true;
+    return 0;
+}
+
+// Bring-up check of the native communicator, called by EVERY rank right after the import (collective): two fused all-reduce + residual +
+// RMSNorm launches (both buffer parities) over `rows` rows of a known pattern -- partial[m][h] = (rank + 1) * (h % 7 + 1) / 8, exact in
+// fp16 for tp <= 8 -- the residual stream must come back as the exact sum over the ranks, the normed row as oracle arithmetic of it, and no
+// peer wait may have expired.  *ok = 0 tells the caller to fall back (tm_engine_comm_native_drop on every rank): the hop between devices --
+// system-scope visibility of the peers' stores over xGMI -- is the one part of this communicator no single-GPU test can exercise, and a
+// default path must not depend on it unverified.  The wait bound of the two launches is min(TM_P2P_TIMEOUT_MS, 5 s).
+int tm_engine_comm_native_selftest(tm_engine* e, int* ok)
+{
+    TM_REQUIRE(e && ok, "null pointer");
+    TM_REQUIRE(e->p2p_ready, "native communicator: export + import first");
+    *ok = 0;
+    TM_HIP_CHECK(hipSetDevice(e->cfg.device));
+    const int    tp = e->cfg.tp, me = e->cfg.rank, H = e->hidden;
+    const int    rows = std::min(e->p2p_rows, 8);
+    const size_t n = (size_t)rows * H;
+    std::vector<half_t> hp(n), hw(H, (half_t)1.0f), hr(n, (half_t)0.0f), hy(n);
+    for (int m = 0; m < rows; ++m) {
+        for (int h = 0; h < H; ++h) {
+            hp[(size_t)m * H + h] = (half_t)((float)(me + 1) * (float)(h % 7 + 1) / 8.0f);
+        }
+    }
+    half_t *dp = nullptr, *dw = nullptr, *dr = nullptr, *dy = nullptr;
+    auto    cleanup = [&]() {
+        (void)hipFree(dp), (void)hipFree(dw), (void)hipFree(dr), (void)hipFree(dy);
+    };
+    int rc = 0;
+    auto run = [&]() -> int {
+        TM_HIP_CHECK(hipMalloc((void**)&dp, n * 2));
+        TM_HIP_CHECK(hipMalloc((void**)&dw, (size_t)H * 2));
+        TM_HIP_CHECK(hipMalloc((void**)&dr, n * 2));
+        TM_HIP_CHECK(hipMalloc((void**)&dy, n * 2));
+        TM_HIP_CHECK(hipMemcpy(dp, hp.data(), n * 2, hipMemcpyHostToDevice));
+        TM_HIP_CHECK(hipMemcpy(dw, hw.data(), (size_t)H * 2, hipMemcpyHostToDevice));
+        bool         good = true;
+        for (int call = 0; call < 2 && good; ++call) {
+            TM_HIP_CHECK(hipMemcpy(dr, hr.data(), n * 2, hipMemcpyHostToDevice));
+            TM_TRY(p2p_oneshot(e, dp, dy, dr, dw, rows));  // the launch the decode steps will use
+            TM_HIP_CHECK(hipStreamSynchronize(e->stream));
+            std::vector<half_t> gr(n);
+            TM_HIP_CHECK(hipMemcpy(gr.data(), dr, n * 2, hipMemcpyDeviceToHost));
+            TM_HIP_CHECK(hipMemcpy(hy.data(), dy, n * 2, hipMemcpyDeviceToHost));
+            uint32_t mark = 0;
+            TM_HIP_CHECK(hipMemcpy(&mark, e->p2p_state + 3, 4, hipMemcpyDeviceToHost));
+            good = mark == 0;
+            const float tri = (float)(tp * (tp + 1) / 2);
+            for (int m = 0; m < rows && good; ++m) {
+                double ss = 0.0;
+                for (int h = 0; h < H; ++h) {
+                    const float want = tri * (float)(h % 7 + 1) / 8.0f;  // exact: <= 36 * 7 / 8
+                    good             = good && (float)gr[(size_t)m * H + h] == want;
+                    ss += (double)want * want;
+                }
+                const float inv = 1.0f / std::sqrt((float)(ss / H) + e->cfg.model.rms_eps);
+                for (int h = 0; h < H && good; h += 97) {  // the normed row: a sample, to the rounding of h(h(r * inv) * 1)
+                    const float want = tri * (float)(h % 7 + 1) / 8.0f * inv;
+                    good             = std::fabs((float)hy[(size_t)m * H + h] - want) <= 2e-3f * std::fabs(want) + 1e-3f;
+                }
+            }
+        }
+        *ok = good ? 1 : 0;
+        return 0;
+    };
+    p2p_timeout_cap_ms(5000);
+    rc = run();
+    p2p_timeout_cap_ms(0);
+    cleanup();
+    return rc;
+}
+
+// Every rank calls it when ANY rank's self-test failed: the decode-sized exchanges go back to RCCL + the residual-norm launch.  The peer
+// mappings stay until the engine is destroyed (a peer may still be inside the failed call); the call counters and the give-up mark are reset.
+int tm_engine_comm_native_drop(tm_engine* e)
+{
+    TM_REQUIRE(e, "null pointer");
+    TM_REQUIRE(e->comm != nullptr || !e->p2p_ready, "native communicator: it is the only communicator of this engine (RCCL was dropped)");
+    if (e->p2p_ready) {
+        TM_HIP_CHECK(hipSetDevice(e->cfg.device));
+        TM_HIP_CHECK(hipStreamSynchronize(e->stream));
+        TM_HIP_CHECK(hipMemset(e->p2p_state, 0, (4 + (size_t)e->p2p_rows) * sizeof(uint32_t)));
+        if (e->graph) {  // a decode step captured with the fused launches: the next decode captures again
+            (void)hipGraphExecDestroy(e->graph);
+            e->graph = nullptr;
+        }
+        if (e->graph_cb) {
+            (void)hipGraphExecDestroy(e->graph_cb);
+            e->graph_cb = nullptr;
+        }
+        e->p2p_ready   = false;
+        e->h_mark      = 0;
+        e->comm_failed = false;
+    }
     return 0;
 }
 

@@ -239,6 +239,9 @@ int launch_p2p_allreduce_norm(half_t* const* data, uint32_t* const* flags, int t
 int launch_p2p_allreduce_norm_2shot(half_t* const* in2, half_t* const* out2, uint32_t* const* flags, int tp, int me, uint32_t* state,
                                     size_t region, const half_t* partial, half_t* y, half_t* resid, const half_t* weight, float eps, int M,
                                     int H, hipStream_t st);
+int launch_p2p_allreduce_norm_rows(half_t* const* rdata, uint32_t* const* rflags, int rows_cap, int tp, int me, uint32_t* state, size_t tile,
+                                   const half_t* partial, half_t* y, half_t* resid, const half_t* weight, float eps, int M, int H, hipStream_t st);
+void p2p_timeout_cap_ms(long ms);  // > 0: cap the peer-wait bound (bring-up self-test); 0: TM_P2P_TIMEOUT_MS again
 int p2p_allreduce_capacity(int threads, bool one_vec);  // token rows per launch: workgroups resident at once on this device
 // dst_stride_words: 32-bit words between the destinations of consecutive ranks (0 = words: dst is [tp][words])
 int launch_p2p_allgather(half_t* const* data, uint32_t* const* flags, int tp, int me, uint32_t* state, size_t tile, const void* src,

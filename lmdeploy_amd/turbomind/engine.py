@@ -74,10 +74,27 @@ class Engine:
         `all_gather(bytes) -> list[bytes]` (rank order) is the caller's host-side exchange, e.g. torch.distributed's
         all_gather_object.  Call after comm_init, before start."""
         buf = C.create_string_buffer(64)
-        _ffi.check(self._lib.tm_engine_comm_native_export(self._h, rows, buf))
-        handles = all_gather(buf.raw)
+        err = None
+        try:
+            _ffi.check(self._lib.tm_engine_comm_native_export(self._h, rows, buf))
+        except _ffi.TmError as e:       # the gather below must still happen on this rank, or the others wait in it forever
+            err = e
+        handles = all_gather(None if err else buf.raw)
+        if err is not None or any(h is None for h in handles):
+            raise err or _ffi.TmError(5, 'native communicator: a peer rank could not export its segment')
         blob = b''.join(handles)
         _ffi.check(self._lib.tm_engine_comm_native_import(self._h, C.create_string_buffer(blob, len(blob)), len(handles)))
+
+    def comm_native_selftest(self) -> bool:
+        """collective (every rank, right after comm_native_setup): two fused all-reduce launches over a known pattern; False = fall back
+        (comm_native_drop on every rank).  The default tp > 1 arrangement takes the native fused decode collective only when this
+        passed everywhere -- the hop between devices is what no single-GPU test covers."""
+        ok = C.c_int(0)
+        _ffi.check(self._lib.tm_engine_comm_native_selftest(self._h, C.byref(ok)))
+        return bool(ok.value)
+
+    def comm_native_drop(self):
+        _ffi.check(self._lib.tm_engine_comm_native_drop(self._h))
 
     @staticmethod
     def comm_unique_id() -> bytes:

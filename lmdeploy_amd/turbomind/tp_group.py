@@ -66,10 +66,24 @@ def _setup_comm(eng: Engine, want_rccl: bool, uid: bytes, all_gather, rows: int,
             ok = False
     oks = all_gather(ok)
     if want_rccl and all(oks):
-        if not want_native:
+        # The DEFAULT arrangement (round 6): RCCL serves the prefill-sized forwards (side-stream overlap), the native
+        # communicator the decode-sized ones -- wo / w2 -> ONE fused all-reduce + residual + RMSNorm launch per exchange, as the
+        # reference's AllreduceResidualBiasRMSnorm (fused_allreduce.cu:406-500, unified_decoder.cc:278-285,328-335) -- provided its bring-up
+        # self-test passes on EVERY rank (the hop between devices is what no single-GPU test covers); else RCCL + the norm launch.
+        # TM_COMM=rccl (or TM_NATIVE_DECODE=0) keeps RCCL alone; `communicator='native' / 'cuda-ipc'` asks for the same arrangement.
+        if os.environ.get('TM_COMM', '') == 'rccl' or os.environ.get('TM_NATIVE_DECODE', '1') == '0':
             return 'rccl'
-        eng.comm_native_setup(all_gather, rows=rows)
-        return 'native-p2p (decode) + rccl (large forwards)'
+        try:
+            eng.comm_native_setup(all_gather, rows=rows)
+            good = eng.comm_native_selftest()
+        except Exception:       # noqa: BLE001 -- reported through the gather: every rank takes the same branch
+            good = False
+        if all(all_gather(bool(good))):
+            return 'native-p2p (decode) + rccl (large forwards)'
+        eng.comm_native_drop()
+        if want_native:
+            raise _ffi.TmError(5, 'communicator="native" / "cuda-ipc": the native communicator failed its bring-up self-test on at least one rank')
+        return 'rccl (native communicator failed its bring-up self-test)'
     if want_rccl and ok:
         eng.comm_drop_rccl()
     eng.comm_native_setup(all_gather, rows=rows)

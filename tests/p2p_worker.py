@@ -36,13 +36,16 @@ def _tables(ptrs):
     return (ctypes.c_void_p * len(ptrs))(*ptrs)
 
 
-def _check(tag, c, state, resid, y, r_ref, y_ref, gathered, g_ref, rows=None):
+def _check(tag, c, state, resid, y, r_ref, y_ref, gathered, g_ref, rows=None, rowform=0):
     """rows: (lo, hi) of the residual rows this rank keeps current (two-shot form), None = all; the two-shot call takes two epochs"""
     st = state.cpu().numpy()
     if st[3] != 0:
         return f'{tag} timed out waiting in call {st[3]}'
-    if st[0] != (3 if rows else 2) * (c + 1) or st[1] != 0 or st[2] != 0:
-        return f'{tag} state after call {c}: {st.tolist()}'
+    per_call = 1 if rowform else (3 if rows else 2)       # row-flag form: only the all-gather uses the shared call counter
+    if st[0] != per_call * (c + 1) or st[1] != 0 or st[2] != 0:
+        return f'{tag} state after call {c}: {st[:4].tolist()}'
+    if rowform and not np.all(st[4:4 + rowform] == c + 1):
+        return f'{tag} per-row call counters after call {c}: {st[4:4 + rowform].tolist()}'
     lo, hi = rows or (0, r_ref.shape[0])
     if not np.array_equal(resid.cpu().numpy()[lo:hi].view(np.uint16), r_ref[lo:hi].view(np.uint16)):
         return f'{tag} residual differs from the oracle in call {c}'
@@ -71,11 +74,14 @@ def run_streams(tp, M, H, calls, two=0):
     w = (1 + 0.02 * rng.standard_normal(H)).astype(f16)
     resid0 = rng.standard_normal((M, H)).astype(f16)
     w_d = torch.from_numpy(w).cuda()
+    rowform = two == 3                        # the row-flag one-shot form (tm_p2p_allreduce_norm_rows): own tiles, own flags, per-row counters
+    two = two if two != 3 else 0
     rows = (M + 3) if not two else 8          # segment capacity need not equal M; two-shot: small one-shot tiles, big regions
     rows2 = M + 5
     words = 2 * M if not two else 2 * rows
-    seg = [torch.zeros(tm.tm_p2p_segment_bytes2(rows, rows2 if two else 0, H), dtype=torch.uint8, device='cuda') for _ in range(tp)]
-    state = [torch.zeros(4, dtype=torch.int32, device='cuda') for _ in range(tp)]
+    nbytes = tm.tm_p2p_segment_bytes_rows(rows, 7, H) if rowform else tm.tm_p2p_segment_bytes2(rows, rows2 if two else 0, H)
+    seg = [torch.zeros(nbytes, dtype=torch.uint8, device='cuda') for _ in range(tp)]
+    state = [torch.zeros(4 + (rows if rowform else 0), dtype=torch.int32, device='cuda') for _ in range(tp)]
     resid = [torch.from_numpy(resid0).cuda() for _ in range(tp)]
     y = [torch.empty((M, H), dtype=torch.float16, device='cuda') for _ in range(tp)]
     gathered = [torch.zeros((tp, words), dtype=torch.int32, device='cuda') for _ in range(tp)]
@@ -93,6 +99,9 @@ def run_streams(tp, M, H, calls, two=0):
             if two:
                 _ffi.check(tm.tm_p2p_allreduce_norm_2shot(segs, tp, r, state[r].data_ptr(), rows, rows2, part_d[r].data_ptr(), y[r].data_ptr(),
                                                          resid[r].data_ptr(), w_d.data_ptr(), 1e-5, M, H, streams[r].cuda_stream))
+            elif rowform:
+                _ffi.check(tm.tm_p2p_allreduce_norm_rows(segs, tp, r, state[r].data_ptr(), rows, 7, part_d[r].data_ptr(), y[r].data_ptr(),
+                                                        resid[r].data_ptr(), w_d.data_ptr(), 1e-5, M, H, streams[r].cuda_stream))
             else:
                 _ffi.check(tm.tm_p2p_allreduce_norm(segs, tp, r, state[r].data_ptr(), rows, part_d[r].data_ptr(), y[r].data_ptr(),
                                                    resid[r].data_ptr(), w_d.data_ptr(), 1e-5, M, H, streams[r].cuda_stream))
@@ -101,7 +110,8 @@ def run_streams(tp, M, H, calls, two=0):
         torch.cuda.synchronize()
         r_ref, y_ref = o.p2p_allreduce_norm(parts, r_ref, w, 1e-5)
         for r in range(tp):
-            why = _check(f'rank {r}', c, state[r], resid[r], y[r], r_ref, y_ref, gathered[r], np.stack(gsrc), _slice(tp, M, r) if two else None)
+            why = _check(f'rank {r}', c, state[r], resid[r], y[r], r_ref, y_ref, gathered[r], np.stack(gsrc), _slice(tp, M, r) if two else None,
+                         rowform=M if rowform else 0)
             if why:
                 return {'ok': False, 'why': why}
             if not torch.equal(y[r], y[0]):
@@ -131,11 +141,14 @@ def run_ipc(d, rank, tp, M, H, calls, two=0):
     rng = np.random.default_rng(5)
     w = (1 + 0.02 * rng.standard_normal(H)).astype(f16)
     resid0 = rng.standard_normal((M, H)).astype(f16)
+    rowform = two == 3
+    two = two if two != 3 else 0
     rows, words = (M, 2 * M) if not two else (8, 16)
     rows2 = M
     mine = ctypes.c_void_p()
     handle = ctypes.create_string_buffer(64)
-    _ffi.check(tm.tm_p2p_segment_create(tm.tm_p2p_segment_bytes2(rows, rows2 if two else 0, H), ctypes.byref(mine), handle))
+    nbytes = tm.tm_p2p_segment_bytes_rows(rows, 0, H) if rowform else tm.tm_p2p_segment_bytes2(rows, rows2 if two else 0, H)
+    _ffi.check(tm.tm_p2p_segment_create(nbytes, ctypes.byref(mine), handle))
     with open(os.path.join(d, f'handle.{rank}.tmp'), 'wb') as f:
         f.write(handle.raw)
     os.rename(os.path.join(d, f'handle.{rank}.tmp'), os.path.join(d, f'handle.{rank}'))
@@ -150,7 +163,7 @@ def run_ipc(d, rank, tp, M, H, calls, two=0):
         base.append(peer.value)
     _barrier(d, rank, tp, 'mapped')
     w_d = torch.from_numpy(w).cuda()
-    state = torch.zeros(4, dtype=torch.int32, device='cuda')
+    state = torch.zeros(4 + (rows if rowform else 0), dtype=torch.int32, device='cuda')
     resid = torch.from_numpy(resid0).cuda()
     y = torch.empty((M, H), dtype=torch.float16, device='cuda')
     gathered = torch.zeros((tp, words), dtype=torch.int32, device='cuda')
@@ -166,6 +179,9 @@ def run_ipc(d, rank, tp, M, H, calls, two=0):
         if two:
             _ffi.check(tm.tm_p2p_allreduce_norm_2shot(segs, tp, rank, state.data_ptr(), rows, rows2, part_d.data_ptr(), y.data_ptr(),
                                                      resid.data_ptr(), w_d.data_ptr(), 1e-5, M, H, stream))
+        elif rowform:
+            _ffi.check(tm.tm_p2p_allreduce_norm_rows(segs, tp, rank, state.data_ptr(), rows, 0, part_d.data_ptr(), y.data_ptr(), resid.data_ptr(),
+                                                    w_d.data_ptr(), 1e-5, M, H, stream))
         else:
             _ffi.check(tm.tm_p2p_allreduce_norm(segs, tp, rank, state.data_ptr(), rows, part_d.data_ptr(), y.data_ptr(), resid.data_ptr(),
                                                w_d.data_ptr(), 1e-5, M, H, stream))
@@ -173,7 +189,8 @@ def run_ipc(d, rank, tp, M, H, calls, two=0):
                                       stream))
         torch.cuda.synchronize()
         r_ref, y_ref = o.p2p_allreduce_norm(parts, r_ref, w, 1e-5)
-        why = _check(f'rank {rank}', c, state, resid, y, r_ref, y_ref, gathered, np.stack(gsrc), _slice(tp, M, rank) if two else None)
+        why = _check(f'rank {rank}', c, state, resid, y, r_ref, y_ref, gathered, np.stack(gsrc), _slice(tp, M, rank) if two else None,
+                     rowform=M if rowform else 0)
         if why:
             out = {'ok': False, 'why': why}
             break

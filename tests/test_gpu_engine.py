@@ -63,13 +63,15 @@ def test_engine_matches_oracle(cuda, monkeypatch, kv_bits, use_graph, fold):
     print(f'[engine vs oracle] kv_bits {kv_bits} graph {use_graph} folded norm {fold}: max logit diff over {steps + 1} steps {worst:.5f}')
 
 
-@pytest.mark.parametrize('graph_comm,side_stream', [(0, 0), (1, 0), (1, 1), (0, 1)])
-def test_engine_collective_path_single_rank(cuda, monkeypatch, graph_comm, side_stream):
+@pytest.mark.parametrize('graph_comm,side_stream,native', [(0, 0, 0), (1, 0, 0), (1, 1, 0), (0, 1, 0), (1, 1, 1), (0, 1, 1)])
+def test_engine_collective_path_single_rank(cuda, monkeypatch, graph_comm, side_stream, native):
     """The tp > 1 data path (RCCL all-reduce after wo / w2, vocabulary-sharded lm_head + candidate all-gather), driven
     on one GPU through a 1-rank communicator (TM_FORCE_COMM=1): must reproduce the collective-free engine exactly
     (a 1-rank sum is the identity; the non-deferred split-K reduce rounds the same fp32 sums).  graph_comm=1 also
     captures the RCCL calls into the decode hipGraph; side_stream = TM_COMM_STREAM (prefill-sized forwards only: these prompts
-    stay below the split size, so both values must behave identically here; the overlapped form has its own test below)."""
+    stay below the split size, so both values must behave identically here; the overlapped form has its own test below).
+    native=1 (round 6): the DEFAULT tp > 1 arrangement -- the native communicator on top of RCCL after its bring-up self-test, so every
+    decode-sized wo / w2 exchange is ONE fused all-reduce + residual + RMSNorm launch (fused_allreduce.cu:406-500) -- same tokens, same logits."""
     cfg = o.ModelConfig(hidden=256, layers=2, q_heads=4, kv_heads=2, head_dim=128, inter=512, vocab=1024,
                         kv_bits=8, rope=o.RopeParam(128, 500000.0, 'llama3', 8.0, 1.0, 4.0, 8192))
     w = o.make_synthetic_weights(cfg, seed=5)
@@ -87,11 +89,22 @@ def test_engine_collective_path_single_rank(cuda, monkeypatch, graph_comm, side_
         eng = Engine.from_model_config(cfg, max_batch_size=4, session_len=128, quant_policy=8, use_graph=1)
         if force:
             eng.comm_init(Engine.comm_unique_id())
+            if native:
+                eng.comm_native_setup(lambda h: [h], rows=4)
+                assert eng.comm_native_selftest(), 'bring-up self-test of the native communicator (one rank)'
+                assert eng.comm_info()['backend'] == 'native-p2p (decode) + rccl (large forwards)'
         eng.load_weights(export_weights(cfg, w))
         eng.start()
         eng.prefill(prompts, max_new_tokens=6)
         eng.decode(5)
         toks, lg = eng.fetch(), eng.fetch_logits()
+        if force and native:    # the fall-back: dropped -> RCCL + the residual-norm launch again, same numbers
+            eng.release()
+            eng.comm_native_drop()
+            assert eng.comm_info()['backend'] == 'rccl'
+            eng.prefill(prompts, max_new_tokens=6)
+            eng.decode(5)
+            assert np.array_equal(eng.fetch(), toks)
         eng.close()
         return toks, lg
 

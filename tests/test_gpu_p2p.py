@@ -91,3 +91,35 @@ def test_p2p_allreduce_norm_two_shot_ipc_processes(cuda, tp, M, H):
         for r, text in enumerate(outs):
             res = _last_json(text)
             assert res['ok'], (r, res)
+
+
+@pytest.mark.timeout(400)
+@pytest.mark.parametrize('tp,M,H', [(2, 64, 4096), (4, 64, 4096), (3, 16, 8192), (2, 1, 2048), (4, 33, 5120), (4, 300, 4096)])
+def test_p2p_allreduce_norm_row_flags_streams(cuda, tp, M, H):
+    """Round 6: the one-shot form whose workgroups do not wait for each other (tm_p2p_allreduce_norm_rows: one flag word per (sender, row),
+    per-row call counters, write-through system-scope stores and system-scope loads, no tickets / no fences / no residency requirement --
+    M = 300 rows exceeds what the ticket form may launch) interleaved with the all-gather of the shared call sequence: the oracle's bits on
+    every rank, per-row counters advanced by one per call, the shared counter by the all-gather alone."""
+    p = subprocess.run([sys.executable, WORKER, 'streams', str(tp), str(M), str(H), '6', '3'], env=_env(), capture_output=True,
+                       text=True, timeout=300)
+    res = _last_json(p.stdout + '\n' + p.stderr)
+    assert res['ok'], res
+
+
+@pytest.mark.timeout(400)
+@pytest.mark.parametrize('tp,M,H', [(2, 64, 4096), (4, 8, 4096), (8, 8, 4096)])
+def test_p2p_allreduce_norm_row_flags_ipc_processes(cuda, tp, M, H):
+    with tempfile.TemporaryDirectory() as d:
+        procs = [subprocess.Popen([sys.executable, WORKER, 'ipc', d, str(r), str(tp), str(M), str(H), '5', '3'], env=_env(),
+                                  stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(tp)]
+        outs = []
+        try:
+            for pr in procs:
+                outs.append(pr.communicate(timeout=300)[0])
+        finally:
+            for pr in procs:
+                if pr.poll() is None:
+                    pr.kill()
+        for r, text in enumerate(outs):
+            res = _last_json(text)
+            assert res['ok'], (r, res)

@@ -234,6 +234,13 @@ class _StubRank:
         self.handles = all_gather(b'handle-of-rank-%d' % self.rank)
         self.calls.append(('comm_native_setup', rows))
 
+    def comm_native_selftest(self):
+        self.calls.append(('comm_native_selftest',))
+        return not getattr(self, 'selftest_fails', False)
+
+    def comm_native_drop(self):
+        self.calls.append(('comm_native_drop',))
+
     def prefill(self, prompts, max_new_tokens):
         self.calls.append(('prefill', [list(map(int, p)) for p in prompts], max_new_tokens))
 
@@ -275,8 +282,9 @@ class _StubRank:
         self.calls.append(('close',))
 
 
-@pytest.mark.parametrize('rccl_fails_on,want_native', [(None, False), (1, False), (2, False), (None, True), (2, True)])
-def test_tp_group_protocol_with_stub_engines(rccl_fails_on, want_native):
+@pytest.mark.parametrize('rccl_fails_on,want_native', [(None, False), (1, False), (2, False), (None, True), (2, True), ('selftest', False),
+                                                       ('rccl-only', False)])
+def test_tp_group_protocol_with_stub_engines(rccl_fails_on, want_native, monkeypatch):
     """three ranks: rank 0 = ParentLink + TpEngine in this thread, ranks 1 / 2 = WorkerLink.serve on threads over real duplex pipes.
     Every rank must take the SAME communicator branch (RCCL only when every rank's init succeeded, else all drop it and exchange
     the native communicator's handles in rank order), see the same mirrored calls in the same order, and a worker's error must
@@ -288,7 +296,19 @@ def test_tp_group_protocol_with_stub_engines(rccl_fails_on, want_native):
     from lmdeploy_amd.turbomind import tp_group
     tp = 3
     pipes = [mp.Pipe(duplex=True) for _ in range(tp - 1)]
+    # round 6: with RCCL up on every rank the DEFAULT is RCCL (large forwards) + the native fused decode collective, taken when the
+    # native communicator's bring-up self-test passes on EVERY rank; 'selftest': rank 1's fails -> all ranks drop it together;
+    # 'rccl-only': TM_COMM=rccl keeps RCCL alone
+    selftest_case, rccl_only = rccl_fails_on == 'selftest', rccl_fails_on == 'rccl-only'
+    if selftest_case or rccl_only:
+        rccl_fails_on = None
+    if rccl_only:
+        monkeypatch.setenv('TM_COMM', 'rccl')
+    else:
+        monkeypatch.delenv('TM_COMM', raising=False)
     ranks = [_StubRank(r, rccl_fails=(r == rccl_fails_on)) for r in range(tp)]
+    if selftest_case:
+        ranks[1].selftest_fails = True
     backends = [None] * tp
 
     def worker(r):
@@ -304,13 +324,16 @@ def test_tp_group_protocol_with_stub_engines(rccl_fails_on, want_native):
     backends[0] = link.setup_comm(ranks[0], True, 64, want_native)
     link.wait_ready()
     eng = tp_group.TpEngine(ranks[0], link, backends[0])
-    want = 'native-p2p' if rccl_fails_on is not None else ('native-p2p (decode) + rccl (large forwards)' if want_native else 'rccl')
+    want = ('native-p2p' if rccl_fails_on is not None else 'rccl' if rccl_only else
+            'rccl (native communicator failed its bring-up self-test)' if selftest_case else 'native-p2p (decode) + rccl (large forwards)')
     assert backends == [want] * tp
     for r in ranks:
-        if want == 'rccl':
+        if rccl_only:
             assert [c[0] for c in r.calls] == ['comm_init']
-        elif rccl_fails_on is None:     # both communicators: RCCL kept, the native one's handles exchanged in rank order
-            assert [c[0] for c in r.calls] == ['comm_init', 'comm_native_setup'] and ('comm_native_setup', 64) in r.calls
+        elif selftest_case:             # one rank's self-test failed: EVERY rank drops the native communicator
+            assert [c[0] for c in r.calls] == ['comm_init', 'comm_native_setup', 'comm_native_selftest', 'comm_native_drop']
+        elif rccl_fails_on is None:     # both communicators: RCCL kept, the native one's handles exchanged in rank order, self-test run
+            assert [c[0] for c in r.calls] == ['comm_init', 'comm_native_setup', 'comm_native_selftest'] and ('comm_native_setup', 64) in r.calls
             assert r.handles == [b'handle-of-rank-%d' % q for q in range(tp)]
         else:
             assert r.handles == [b'handle-of-rank-%d' % q for q in range(tp)], 'handles must arrive in rank order on every rank'
