@@ -328,3 +328,47 @@ def test_tp2_prefill_two_microbatches_match_serial_collectives():
     r, rr = ret['piped'][0].astype(np.float32), m.last_resid.astype(np.float32)
     assert r.shape == rr.shape
     assert np.all(np.abs(r - rr) <= 4e-3 + 2.0**-8 * np.abs(rr)), f'sharded residual stream differs: {np.abs(r - rr).max()}'
+
+
+def _fused_worker(rank, world, port, parts, resid, weight, ret):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        r, outs = resid.copy(), []
+        for call in range(len(parts)):
+            mine = parts[call][rank]
+            # the row-flag one-shot exchange as data flow: every rank makes its partial rows visible to all (all-gather = the pushes into the
+            # segments + the per-row flags), then sums ALL ranks' rows in rank order in fp32, rounds once, residual + RMSNorm locally
+            got = [torch.zeros(mine.shape, dtype=torch.float16) for _ in range(world)]
+            dist.all_gather(got, torch.from_numpy(mine))
+            r_f, y_f = o.p2p_allreduce_norm([g.numpy() for g in got], r, weight, 1e-5)
+            # the RCCL arrangement it replaces: ncclAllReduce(fp16 sum) + the residual-norm launch
+            y_a = _allreduce_f16(mine)
+            r_a, y_n = o.residual_rmsnorm(r, y_a, weight, 1e-5)
+            outs.append((np.array_equal(r_f.view(np.uint16), r_a.view(np.uint16)), np.array_equal(y_f.view(np.uint16), y_n.view(np.uint16)),
+                         r_f.copy(), y_f.copy()))
+            r = r_f
+        ret[rank] = outs
+    finally:
+        dist.destroy_process_group()
+
+
+def test_tp2_fused_allreduce_norm_equals_allreduce_then_norm():
+    """Round 6: at tp > 1 the decode-sized exchanges run as ONE fused all-reduce + residual + RMSNorm launch by default (comm_p2p.hip's
+    row-flag kernel; reference AllreduceResidualBiasRMSnorm, fused_allreduce.cu:406-500 at unified_decoder.cc:278-285,328-335) instead of
+    ncclAllReduce + the residual-norm launch.  World size 2 over gloo, three chained exchanges: the fused form's data flow (every rank sees
+    every rank's rows, rank-ordered fp32 sum, one fp16 rounding) gives the bits of all-reduce-then-norm, and both ranks hold identical
+    residual streams and normed rows -- the schedule change is invisible to the numbers."""
+    rng = np.random.default_rng(3)
+    M, H, world = 5, 256, 2
+    parts = [[(rng.standard_normal((M, H)) * 2).astype(f16) for _ in range(world)] for _ in range(3)]
+    resid = rng.standard_normal((M, H)).astype(f16)
+    weight = (1 + 0.05 * rng.standard_normal(H)).astype(f16)
+    ret = mp.Manager().dict()
+    mp.spawn(_fused_worker, args=(world, _free_port(), parts, resid, weight, ret), nprocs=world, join=True)
+    for call in range(3):
+        for rank in range(world):
+            same_r, same_y, _, _ = ret[rank][call]
+            assert same_r and same_y, (call, rank)
+        assert np.array_equal(ret[0][call][2], ret[1][call][2]) and np.array_equal(ret[0][call][3], ret[1][call][3])
