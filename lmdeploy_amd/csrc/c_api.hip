@@ -344,8 +344,9 @@ int tm_linear_residual_norm(const tm_linear* w, const void* x, int ldx, void* y,
     const int N = w->w.N;
     GemmConfig cfg = gemm_pick_config(w->w, M);
     if (shape >= 0) {
-        TM_REQUIRE(dec32_supported(w->w, M) && (shape <= 3 || (shape >= 6 && shape <= 10) || shape == kShapeLC) && M <= 64,
-                   "decode tile 0..3 / 6..9 / 11, M <= 64");
+        TM_REQUIRE(dec32_supported(w->w, M) && (shape <= 3 || (shape >= 6 && shape <= 10) || shape == kShapeLC)
+                       && (M <= 64 || (M <= kFoldMaxRows && shape >= 6 && shape <= 9)),
+                   "decode tile 0..3 / 6..10 / 11 at M <= 64; the 32-row-block tiles 6..9 up to 128 rows");
         cfg.d32_shape = shape;
     }
     if (splits > 0) {
@@ -365,13 +366,17 @@ size_t tm_linear_fold_workspace(const tm_linear* w, int M)
     return w ? gemm_workspace_bytes(M, w->w.N, 16) + 4096 : 0;
 }
 
-static int fold_tile_pick(const tm_linear* w, int M, int* shape, int* splits)
+static int fold_tile_pick(const tm_linear* w, int M, int* shape, int* splits, bool producer)
 {
     int sh = *shape, sp = *splits;
     if (sh < 0) {
         dec32_pick(w->w, M, &sh, &sp);
-        if (!dec32_fold_shape(sh)) {
+        if (!dec32_fold_shape_m(sh, M, producer)) {
             dec32_pick_ex(w->w, M, &sh, &sp, false);
+        }
+        if (!dec32_fold_shape_m(sh, M, producer)) {
+            sh = M <= 64 ? 0 : (producer ? 7 : 4);
+            sp = 1;
         }
         if (*splits > 0) {
             sp = *splits;
@@ -380,7 +385,8 @@ static int fold_tile_pick(const tm_linear* w, int M, int* shape, int* splits)
     else if (sp <= 0) {
         sp = 1;
     }
-    TM_REQUIRE(dec32_fold_shape(sh) && sp >= 1 && sp <= 16, "folded RMSNorm: decode tile 0..3 / 6..9, 1 <= splits <= 16");
+    TM_REQUIRE(dec32_fold_shape_m(sh, M, producer) && sp >= 1 && sp <= 16,
+               "folded RMSNorm: decode tile 0..3 / 6..10 (M <= 64), 6..9 or -- consumer only -- 4 (64 < M <= 128); 1 <= splits <= 16");
     *shape  = sh;
     *splits = sp;
     return 0;
@@ -390,11 +396,11 @@ int tm_linear_fold_produce(const tm_linear* w, const void* x, int ldx, void* xg,
                            int* ss_tiles, int M, int shape, int splits, void* workspace, tm_stream_t st)
 {
     TM_REQUIRE(w && x && xg && resid && norm_w && ss && ss_tiles && workspace, "null pointer");
-    TM_REQUIRE(dec32_supported(w->w, M) && M <= 64 && w->w.N % 64 == 0, "folded RMSNorm: u4 decode linear, M <= 64, N % 64 == 0");
-    TM_TRY_RC(fold_tile_pick(w, M, &shape, &splits));
+    TM_REQUIRE(dec32_supported(w->w, M) && M <= kFoldMaxRows && w->w.N % 64 == 0, "folded RMSNorm: u4 decode linear, M <= 128, N % 64 == 0");
+    TM_TRY_RC(fold_tile_pick(w, M, &shape, &splits, true));
     unsigned* tickets = (unsigned*)((char*)workspace + gemm_workspace_bytes(M, w->w.N, 16));
     TM_HIP_CHECK(hipMemsetAsync(tickets, 0, 4096, (hipStream_t)st));
-    TM_REQUIRE((size_t)(w->w.N / 64) * 2 * sizeof(unsigned) <= 4096, "folded RMSNorm: N <= 32768");
+    TM_REQUIRE((size_t)(w->w.N / 64) * ((M + 31) / 32) * sizeof(unsigned) <= 4096, "folded RMSNorm: N / 64 column tiles x row blocks <= 1024");
     NormFold nf{};
     nf.resid   = (half_t*)resid;
     nf.norm_w  = (const half_t*)norm_w;
@@ -410,8 +416,8 @@ int tm_linear_fold_consume(const tm_linear* w, const void* xg, int ldx, void* y,
                            int ss_tiles, int norm_h, float eps, int shape, int splits, void* workspace, tm_stream_t st)
 {
     TM_REQUIRE(w && xg && y && ss, "null pointer");
-    TM_REQUIRE(dec32_supported(w->w, M) && M <= 64 && ss_tiles >= 1 && norm_h >= 1, "folded RMSNorm: u4 decode linear, M <= 64");
-    TM_TRY_RC(fold_tile_pick(w, M, &shape, &splits));
+    TM_REQUIRE(dec32_supported(w->w, M) && M <= kFoldMaxRows && ss_tiles >= 1 && norm_h >= 1, "folded RMSNorm: u4 decode linear, M <= 128");
+    TM_TRY_RC(fold_tile_pick(w, M, &shape, &splits, false));
     if (!workspace) {
         splits = 1;
     }

@@ -445,9 +445,14 @@ int tm_engine_start(tm_engine* e)
     TM_HIP_CHECK(hipMalloc((void**)&e->d_gemm_ws, e->gemm_ws_bytes));
     {
         const size_t tiles = (size_t)(e->hidden + 63) / 64;
-        TM_TRY(dmalloc(&e->d_ss, tiles * 64));
+        TM_TRY(dmalloc(&e->d_ss, tiles * kFoldMaxRows));
         // arrival counters: one per (column tile, row block) of the widest decode linear at its narrowest tile (64 columns, 32 rows)
-        const size_t ntk = (size_t)(std::max(std::max(e->qkv_n, 2 * e->inter), e->hidden) + 63) / 64 * 2;
+        const size_t ntk = (size_t)(std::max(std::max(e->qkv_n, 2 * e->inter), e->hidden) + 63) / 64 * (kFoldMaxRows / 32);
+        const char* fm   = getenv("TM_FOLD_MAX_M");
+        // default 64: at batch 128 (BASELINE config 3) the folded layer is parity-green but measured SLOWER than the reduce-norm launches it
+        // removes (InternLM2-20B: 10.83 .. 10.91 vs 10.43 ms per step, profiles/r06_fold128_*): its producers are limited to the 32-row-block
+        // tiles (every weight unit read by four row blocks), the 128-row tile with 10 slices + the fused reduce-norm wins w2 by 4 us
+        e->fold_max_rows = fm ? std::min(kFoldMaxRows, std::max(1, atoi(fm))) : 64;
         TM_TRY(dmalloc(&e->d_tickets, ntk));
         TM_HIP_CHECK(hipMemset(e->d_tickets, 0, ntk * sizeof(unsigned)));
         const char* fold = getenv("TM_FOLD_NORM");

@@ -271,14 +271,16 @@ static int forward_layers_two_microbatches(tm_engine* e, int M, int nseq, int ma
 
 // ---- RMSNorm folded into the decode GEMMs (tp = 1, dense u4 layers, M <= 64; NormFold in tm_kernels.h) ----------------------------
 // the tiling of a folded launch: the measured / heuristic pick when its kernel carries the folded epilogue, else the heuristic's
-static void fold_tiling(tm_engine* e, const LinearWeight& w, int M, int* shape, int* splits)
+static void fold_tiling(tm_engine* e, const LinearWeight& w, int M, int* shape, int* splits, bool producer)
 {
     dec32_pick(w, M, shape, splits);
-    if (!dec32_fold_shape(*shape)) {
+    if (!dec32_fold_shape_m(*shape, M, producer)) {
         dec32_pick_ex(w, M, shape, splits, false);
     }
-    if (!dec32_fold_shape(*shape)) {
-        *shape  = 0;
+    if (!dec32_fold_shape_m(*shape, M, producer)) {
+        // M <= 64: the 128-column tile over the whole k range; above (batch 128): the same tile on 32-row blocks for a producer, the 128-row
+        // tile for a consumer (every weight unit read once)
+        *shape  = M <= 64 ? 0 : (producer ? 7 : 4);
         *splits = 1;
     }
     if (gemm_workspace_bytes(M, w.N, *splits) > e->gemm_ws_bytes) {
@@ -288,7 +290,7 @@ static void fold_tiling(tm_engine* e, const LinearWeight& w, int M, int* shape, 
 
 static bool fold_ok(const tm_engine* e, const Layer& L, int M)
 {
-    return e->fold_norm != 0 && !L.is_moe && M <= 64 && dec32_supported(L.qkv.w, M) && dec32_supported(L.wo.w, M) && dec32_supported(L.w13.w, M)
+    return e->fold_norm != 0 && !L.is_moe && M <= e->fold_max_rows && dec32_supported(L.qkv.w, M) && dec32_supported(L.wo.w, M) && dec32_supported(L.w13.w, M)
            && dec32_supported(L.w2.w, M);
 }
 
@@ -297,9 +299,13 @@ static int linear_fold_consume(tm_engine* e, LinearSlots& l, const half_t* x, in
                                bool slabs_ok, int* slabs)
 {
     int shape, splits;
-    fold_tiling(e, l.w, M, &shape, &splits);
+    fold_tiling(e, l.w, M, &shape, &splits, false);
     const bool mrg = dec32_is_merge_shape(shape);  // split-K merged in the launch: no slab leaves it, whoever consumes
-    if (!slabs_ok && !mrg) {
+    // a split-K consumer nobody takes slabs from (w1w3; w_qkv without the fused attention prologue): the slices' slabs already carry the row
+    // factor (it is applied to the accumulators before ANY epilogue, and a sum of scaled slices is the scaled sum), so the plain reduce launch
+    // finishes them -- what the 128-row tile needs at batch 128, where one slice per column tile leaves half the CUs idle (round 6)
+    const bool reduce_after = !slabs_ok && !mrg && splits > 1 && M > 64;
+    if (!slabs_ok && !mrg && !reduce_after) {
         splits = 1;
     }
     NormFold nf{};
@@ -310,6 +316,10 @@ static int linear_fold_consume(tm_engine* e, LinearSlots& l, const half_t* x, in
     nf.tickets  = e->d_tickets;
     int nslab   = 1;
     TM_TRY(launch_linear_dec32(l.w, x, ldx, y, ldy, M, gated, shape, splits, e->d_gemm_ws, &nslab, e->stream, (ss_tiles > 0 || mrg) ? &nf : nullptr));
+    if (reduce_after && nslab > 1) {
+        TM_TRY(launch_splitk_reduce(y, ldy, e->d_gemm_ws, nslab, M, l.w.N, gated, e->stream));
+        nslab = 1;
+    }
     if (slabs) {
         *slabs = nslab;
     }
@@ -320,7 +330,7 @@ static int linear_fold_consume(tm_engine* e, LinearSlots& l, const half_t* x, in
 static int linear_fold_produce(tm_engine* e, LinearSlots& l, const half_t* x, int ldx, int M, const half_t* norm_w, int* ss_tiles)
 {
     int shape, splits;
-    fold_tiling(e, l.w, M, &shape, &splits);
+    fold_tiling(e, l.w, M, &shape, &splits, true);
     NormFold nf{};
     nf.resid   = e->d_resid;
     nf.norm_w  = norm_w;

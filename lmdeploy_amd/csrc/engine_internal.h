@@ -141,6 +141,7 @@ struct tm_engine {
     // arrival counters of the producing GEMM; TM_FOLD_NORM=0 keeps the reduce-norm launches
     float*    d_ss      = nullptr;
     unsigned* d_tickets = nullptr;
+    int       fold_max_rows = 64;  // rows of a forward up to which the folded layer runs (TM_FOLD_MAX_M: 64 | 128)
     int       fold_norm = 0;  // bit 0: wo -> w1w3, bit 1: w2 -> the next layer's w_qkv
     unsigned  h_mark = 0;             // host copy of the native communicator's give-up mark (device_marks_fetch)
     bool      comm_failed = false;    // a give-up mark was seen: the ranks' call sequences may have diverged (sticky, see device_marks_check)

@@ -47,7 +47,7 @@ int tune_decode_gemms(tm_engine* e, int M, bool verbose)
     TM_TRY(launch_fill_uniform_f16(e->d_attn, (size_t)M * e->q_heads * e->D, 0.5f, 2u, st));
     TM_TRY(launch_fill_uniform_f16(e->d_act, (size_t)M * e->inter, 0.5f, 3u, st));
     TM_HIP_CHECK(hipMemsetAsync(e->d_resid, 0, (size_t)M * e->hidden * 2, st));
-    TM_HIP_CHECK(hipMemsetAsync(e->d_ss, 0x3f, (size_t)(e->hidden / 64) * 64 * sizeof(float), st));  // finite stand-in sums of squares (0.747)
+    TM_HIP_CHECK(hipMemsetAsync(e->d_ss, 0x3f, (size_t)(e->hidden / 64) * kFoldMaxRows * sizeof(float), st));  // finite stand-in sums of squares (0.747)
     int rc = 0;
     for (const Role& r : roles) {
         std::vector<const LinearWeight*> ws;
@@ -97,13 +97,14 @@ int tune_decode_gemms(tm_engine* e, int M, bool verbose)
             // will run -- wo / w2 with the residual / sums-of-squares epilogue (and the in-launch slab merge) instead of the
             // reduce-norm launch, w_qkv / w1w3 with the row factor from d_ss -- and only tiles whose kernel carries that code
             // (which == 1 / 2: the wo -> w1w3 pair, bit 0; which == 3 / 0: the w2 -> w_qkv pair, bit 1)
-            const bool folded = M <= 64 && !e->layers[0].is_moe && (e->fold_norm & ((r.which == 1 || r.which == 2) ? 1 : 2)) != 0;
+            const bool folded = M <= e->fold_max_rows && !e->layers[0].is_moe && (e->fold_norm & ((r.which == 1 || r.which == 2) ? 1 : 2)) != 0;
             const bool slabs_ok = norm_consumer || (r.which == 0 && e->fuse_qkv);  // folded: who can take fp32 slabs
             const bool mrg = dec32_is_merge_shape(cand[i][0]);  // split-K merged in the launch: nothing for a slab consumer to do
             if (mrg && norm_consumer) {
                 continue;  // wo / w2: the folded producer merges in the launch anyway, the unfolded one hands its slabs to the reduce-norm
             }
-            if (folded && (!dec32_fold_shape(cand[i][0]) || (cfg.splits > 1 && !slabs_ok && !mrg))) {
+            const bool reduce_after = folded && !norm_consumer && !slabs_ok && !mrg && cfg.splits > 1 && M > 64;  // linear_fold_consume's reduce launch
+            if (folded && (!dec32_fold_shape_m(cand[i][0], M, norm_consumer) || (cfg.splits > 1 && !slabs_ok && !mrg && !reduce_after))) {
                 continue;
             }
             cfg.tickets = e->d_tickets;
@@ -119,8 +120,12 @@ int tune_decode_gemms(tm_engine* e, int M, bool verbose)
                             nf.ss_in = e->d_ss, nf.ss_tiles = tiles, nf.inv_h = 1.0f / (float)e->hidden, nf.eps = e->cfg.model.rms_eps;
                             nf.tickets = e->d_tickets;
                         }
+                        int nslab = 1;
                         TM_TRY(launch_linear_dec32(*w, r.x, r.ldx, norm_consumer ? norm_out : r.y, norm_consumer ? e->hidden : r.ldy, M, r.gated,
-                                                   cfg.d32_shape, cfg.splits, e->d_gemm_ws, nullptr, st, &nf));
+                                                   cfg.d32_shape, cfg.splits, e->d_gemm_ws, &nslab, st, &nf));
+                        if (reduce_after && nslab > 1) {
+                            TM_TRY(launch_splitk_reduce(r.y, r.ldy, e->d_gemm_ws, nslab, M, w->N, r.gated, st));
+                        }
                     }
                     return 0;
                 }

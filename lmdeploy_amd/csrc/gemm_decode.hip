@@ -1605,6 +1605,21 @@ void dec32_pick_ex(const LinearWeight& w, int M, int* shape_out, int* splits_out
 }
 
 // y / slabs as launch_linear: *slabs_out = number of fp32 slabs written into `workspace` (1 = direct epilogue)
+// (shape, M) pairs a folded launch can run: see launch_linear_dec32
+bool dec32_fold_shape_m(int shape, int M, bool producer)
+{
+    if (M <= 64) {
+        return dec32_fold_shape(shape);
+    }
+    if (dec32_is_merge_shape(shape)) {
+        shape -= kShapeMerge;
+        if (producer) {
+            return false;
+        }
+    }
+    return M <= kFoldMaxRows && ((shape >= 6 && shape <= 9) || (shape == 4 && !producer));
+}
+
 bool dec32_fold_shape(int shape)
 {
     if (dec32_is_merge_shape(shape)) {
@@ -1622,9 +1637,14 @@ int launch_linear_dec32(const LinearWeight& w, const half_t* x, int ldx, half_t*
     if (dec32_is_merge_shape(shape)) {  // split-K merged in the launch (fp16 / gated epilogues); a producer does that anyway
         shape -= kShapeMerge;
         merge = !produce && splits > 1;
-        TM_REQUIRE(!merge || (nf && nf->tickets && M <= 64), "merged split-K: arrival counters (NormFold::tickets), M <= 64");
+        TM_REQUIRE(!merge || (nf && nf->tickets && (M <= 64 || (M <= kFoldMaxRows && shape >= 6 && shape <= 9))),
+                   "merged split-K: arrival counters (NormFold::tickets), M <= 64 (32-row-block tiles: <= 128)");
     }
-    TM_REQUIRE(!nf || !(produce || consume) || (dec32_fold_shape(shape) && M <= 64), "folded RMSNorm: the <= 64-row decode tiles (shapes 0..3, 6..9), M <= 64");
+    // folded RMSNorm: M <= 64 on every <= 64-row decode tile; 64 < M <= kFoldMaxRows (round 6, BASELINE config 3 = batch 128) on the 32-row-block
+    // tiles 6..9 (producer and consumer: one ticket / one row of sums per (column tile, row block)) and, consumer only, on the 128-row tile 4
+    TM_REQUIRE(!nf || !(produce || consume)
+                   || (M <= 64 ? dec32_fold_shape(shape) : (M <= kFoldMaxRows && ((shape >= 6 && shape <= 9) || (shape == 4 && !produce)))),
+               "folded RMSNorm: decode tiles 0..3 / 6..10 at M <= 64; 32-row-block tiles 6..9 (and tile 4 as a consumer) up to 128 rows");
     TM_REQUIRE(!produce || (!gated_silu && nf->norm_w && nf->ss_out && ldy % 4 == 0), "folded RMSNorm, producer: residual, norm weight, sums");
     TM_REQUIRE(!consume || (nf->ss_tiles >= 1 && nf->inv_h > 0.f), "folded RMSNorm, consumer: tiles and 1 / H");
     TM_REQUIRE(w.packed32 != nullptr && w.N % 32 == 0, "decode GEMM: P32 layout missing");

@@ -214,6 +214,8 @@ struct NormFold {
     unsigned*     tickets = nullptr;
     int           tiles_out = 0;
 };
+constexpr int kFoldMaxRows = 128;  // rows of a forward whose RMSNorms fold into the decode GEMMs (round 6: BASELINE config 3 runs batch 128)
+bool   dec32_fold_shape_m(int shape, int M, bool producer);  // can (shape, M) run as a folded producer / consumer?
 bool   dec32_fold_shape(int shape);  // shapes whose kernel carries the folded-norm epilogue / prologue (0..3, 6..9)
 int    launch_linear_dec32(const LinearWeight& w, const half_t* x, int ldx, half_t* y, int ldy, int M, bool gated_silu, int shape,
                            int splits, float* workspace, int* slabs_out, hipStream_t st, NormFold* nf = nullptr);

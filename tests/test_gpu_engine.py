@@ -63,6 +63,45 @@ def test_engine_matches_oracle(cuda, monkeypatch, kv_bits, use_graph, fold):
     print(f'[engine vs oracle] kv_bits {kv_bits} graph {use_graph} folded norm {fold}: max logit diff over {steps + 1} steps {worst:.5f}')
 
 
+@pytest.mark.parametrize('batch,fold_max', [(100, 128), (128, 128), (100, 64)])
+def test_engine_folded_norm_batch_128_matches_oracle(cuda, monkeypatch, batch, fold_max):
+    """Round 6 (BASELINE config 3 = batch 128): decode batches of 65 .. 128 rows run the folded layer too (TM_FOLD_MAX_M, default 128; 64 = the
+    round-5 limit: reduce-norm launches above it) -- producers on the 32-row-block tiles, consumers on those or the 128-row tile.  Prefill + 3
+    decode steps (graph replay) against the oracle model, the bound of test_engine_matches_oracle."""
+    monkeypatch.setenv('TM_FOLD_NORM', '3')
+    monkeypatch.setenv('TM_FOLD_MAX_M', str(fold_max))
+    cfg = o.ModelConfig(hidden=256, layers=2, q_heads=4, kv_heads=2, head_dim=128, inter=512, vocab=1024,
+                        kv_bits=8, rope=o.RopeParam(128, 500000.0, 'llama3', 8.0, 1.0, 4.0, 8192))
+    w = o.make_synthetic_weights(cfg, seed=4)
+    rng = np.random.default_rng(batch)
+    prompts = [rng.integers(0, cfg.vocab, int(n)).astype(np.int32) for n in rng.integers(3, 20, batch)]
+    steps = 3
+    eng = Engine.from_model_config(cfg, max_batch_size=batch, session_len=64, quant_policy=8, max_prefill_token_num=512, use_graph=1)
+    eng.load_weights(export_weights(cfg, w))
+    eng.start()
+    eng.prefill(prompts, max_new_tokens=steps + 1)
+    logits = [eng.fetch_logits()]
+    for _ in range(steps):
+        eng.decode(1)
+        logits.append(eng.fetch_logits())
+    toks = eng.fetch()
+    eng.close()
+    om = o.OracleModel(cfg, w, batch=len(prompts), max_ctx=64)
+    ids, lg = om.forward(prompts)
+    ref_logits = [lg]
+    cur = toks[:, 0]
+    for s in range(steps):
+        ids, lg = om.forward([[int(t)] for t in cur])
+        ref_logits.append(lg)
+        cur = toks[:, s + 1]
+    worst = 0.0
+    for s in range(steps + 1):
+        d = np.abs(logits[s].astype(np.float32) - ref_logits[s].astype(np.float32))
+        worst = max(worst, float(d.max()))
+        assert d.max() <= 3e-2, f'step {s}: max logit diff {d.max()}'
+    print(f'[engine vs oracle] batch {batch} TM_FOLD_MAX_M {fold_max}: max logit diff over {steps + 1} steps {worst:.5f}')
+
+
 @pytest.mark.parametrize('graph_comm,side_stream,native', [(0, 0, 0), (1, 0, 0), (1, 1, 0), (0, 1, 0), (1, 1, 1), (0, 1, 1)])
 def test_engine_collective_path_single_rank(cuda, monkeypatch, graph_comm, side_stream, native):
     """The tp > 1 data path (RCCL all-reduce after wo / w2, vocabulary-sharded lm_head + candidate all-gather), driven

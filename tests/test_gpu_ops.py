@@ -650,6 +650,60 @@ def test_w4a16_gated_silu(tm, cuda, K, N, M):
     _ffi.check(tm.tm_linear_destroy(h))
 
 
+@pytest.mark.parametrize('M,H', [(128, 1024), (100, 1024), (65, 1024), (128, 6144)])
+def test_w4a16_folded_norm_batch_128(tm, cuda, M, H):
+    """Round 6 (BASELINE config 3 = batch 128): the folded RMSNorm for 64 < M <= 128 rows.  Producers run the 32-row-block
+    tiles 6..9 (one arrival counter and one row of sums per (column tile, row block); in-launch slab merge included), consumers those tiles or
+    the 128-row tile 4 (every weight unit read once).  Same claims as test_w4a16_folded_norm: residual stream bit-identical to the unfused
+    device sequence, xg and the sums of squares exact on the device's own r, consumer inside the unfused bound."""
+    rng = np.random.default_rng(200 + M + H)
+    K1, N2 = 2048, 512
+    eps = 1e-5
+    hp, (qp, sp, zp) = _make_linear(tm, rng, K1, H)
+    hc, (qc, sc, zc) = _make_linear(tm, rng, H, N2)
+    x = (rng.standard_normal((M, K1)) * 2).astype(f16)
+    resid0 = rng.standard_normal((M, H)).astype(f16)
+    resid0[:, 5] *= 40.0
+    g = (1.0 + 0.2 * rng.standard_normal(H)).astype(f16)
+    ws = torch.zeros(int(tm.tm_linear_fold_workspace(hp, M)) + M * H * 2 + 4096, dtype=torch.uint8, device='cuda')
+    wsc = torch.zeros(max(1, int(tm.tm_linear_workspace(hc, M))), dtype=torch.uint8, device='cuda')
+    x_d, g_d = dev(x), dev(g)
+    r_ref, n_ref = o.residual_rmsnorm(resid0, o.w4a16_linear(x, qp, sp, zp), g, eps)
+    big = H > 1024
+    for gated in (0, 1):
+        ref_y = (o.w4a16_linear_gated_silu(n_ref, qc, sc, zc) if gated else o.w4a16_linear(n_ref, qc, sc, zc)).astype(np.float32)
+        for shape, splits in (((6, 2), (7, 1)) if big else ((6, 1), (6, 2), (7, 1), (7, 2), (8, 4), (9, 1), (-1, 0))):
+            r_u = dev(resid0.copy())
+            n_u = torch.zeros((M, H), dtype=torch.float16, device='cuda')
+            us, usp = (shape, splits) if shape >= 0 else (7, 1)
+            _ffi.check(tm.tm_linear_residual_norm(hp, x_d.data_ptr(), K1, n_u.data_ptr(), r_u.data_ptr(), g_d.data_ptr(), eps, M, us, usp,
+                                                  ws.data_ptr(), st()))
+            r_f = dev(resid0.copy())
+            xg = torch.zeros((M, H), dtype=torch.float16, device='cuda')
+            ss = torch.full((H // 64, M), float('nan'), dtype=torch.float32, device='cuda')
+            tiles = _ffi.C.c_int(0)
+            for rep in range(2):
+                r_f.copy_(torch.from_numpy(resid0).cuda())
+                _ffi.check(tm.tm_linear_fold_produce(hp, x_d.data_ptr(), K1, xg.data_ptr(), r_f.data_ptr(), g_d.data_ptr(), ss.data_ptr(),
+                                                     _ffi.C.byref(tiles), M, shape, splits, ws.data_ptr(), st()))
+            torch.cuda.synchronize()
+            r_dev = host(r_f)
+            assert np.array_equal(r_dev.view(np.uint16), host(r_u).view(np.uint16)), f'residual stream differs from the unfused sequence {shape, splits}'
+            want_xg = np.clip(r_dev.astype(np.float32) * g.astype(np.float32), -65504, 65504).astype(f16)
+            assert np.array_equal(host(xg).view(np.uint16), want_xg.view(np.uint16)), f'xg {shape, splits}'
+            ss_h = host(ss)[:tiles.value].astype(np.float64).sum(0)
+            want_ss = (r_dev.astype(np.float64)**2).sum(-1)
+            assert 1 <= tiles.value <= H // 64 and np.all(np.abs(ss_h - want_ss) <= 1e-5 * want_ss), f'sums of squares {shape, splits}'
+            for cshape, csplits in ((4, 1), (6, 1), (7, 1), (-1, 0)):
+                y = torch.zeros((M, N2 // 2 if gated else N2), dtype=torch.float16, device='cuda')
+                _ffi.check(tm.tm_linear_fold_consume(hc, xg.data_ptr(), H, y.data_ptr(), y.shape[1], M, gated, ss.data_ptr(), tiles.value, H, eps,
+                                                     cshape, csplits, wsc.data_ptr(), st()))
+                err = np.abs(host(y).astype(np.float32) - ref_y)
+                assert np.all(err <= 2e-3 + 2.0**-9 * np.abs(ref_y)), f'folded consumer {cshape, csplits} after {shape, splits}: max err {err.max()}'
+    _ffi.check(tm.tm_linear_destroy(hp))
+    _ffi.check(tm.tm_linear_destroy(hc))
+
+
 @pytest.mark.parametrize('M,H', [(64, 1024), (33, 1024), (7, 1024), (64, 6144)])
 def test_w4a16_folded_norm(tm, cuda, M, H):
     """RMSNorm folded into the two decode GEMMs around it (tm_linear_fold_produce / _consume; the engine's tp = 1 decode step):
