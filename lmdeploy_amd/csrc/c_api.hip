@@ -305,13 +305,17 @@ int tm_linear_forward(const tm_linear* w, const void* x, int ldx, void* y, int l
             cfg.splits = gemm_pick_config_general(w->w, M).splits;
         }
     }
+    if (waves > 0 && (waves & 0x200) && (waves & 0xff) == kShapeF16 && !w->w.image16) {
+        // operator level: the fp16 image is built on first use (the engine builds it at load)
+        TM_TRY_RC(linear_weight_build_f16_image(const_cast<tm_linear*>(w)->w, (hipStream_t)st));
+    }
     if (waves > 0 && (waves & 0x200)) {
         // 0x200 + shape: the decode kernel (gemm_decode.hip) with an explicit workgroup shape; M <= 64, u4, N % 32 == 0
         TM_REQUIRE(dec32_supported(w->w, M), "decode kernel: u4 weights, N % 32 == 0");
         cfg.d32_shape = waves & 0xff;
         TM_REQUIRE((cfg.d32_shape >= 6 && cfg.d32_shape <= 9) || (cfg.d32_shape <= 5 && (cfg.d32_shape >= 4) == (M > 64))
                        || (cfg.d32_shape == kShapeWide2 && M <= 64)
-                       || (cfg.d32_shape == kShapeLC && M <= 64) || (cfg.d32_shape == kShapePre256 && M > 64)
+                       || (cfg.d32_shape == kShapeLC && M <= 64) || ((cfg.d32_shape == kShapePre256 || cfg.d32_shape == kShapeF16) && M > 64)
                        || (dec32_is_merge_shape(cfg.d32_shape) && M <= 64),
                    "P32 kernel shape 0..3 / 11 (M <= 64), 4 / 5 / 12 (M > 64), 6..9 (32-row blocks, any M) or 16 + (0..3 | 6..9) "
                    "(M <= 64: split-K merged inside the launch)");

@@ -131,6 +131,17 @@ static int prepare_linear(tm_engine* e, LinearSlots& l)
         // gemm_kernel and keep the 16-column image as well
         const bool p32_only = l.prefix.find(".experts.") == std::string::npos && dec32_serves_every_m(l.w.K, l.w.N);
         TM_TRY(linear_weight_prepare_u4(l.w, (const int32_t*)q.dev, (const half_t*)s.dev, (const half_t*)z.dev, e->stream, p32_only));
+        // the resident fp16 image for prefill-sized forwards (gemm_prefill_f16.hip): dense linears of engines whose prefill forwards are
+        // large enough to use it (the 256 x 256 tile is proposed from 1024 rows); TM_PREFILL_F16_IMAGE=1 builds it
+        // (opt-in: measured +15 % on w_qkv, +2 % on wo, -1 .. -5 % on w1w3 / w2 against the fused tiles at M = 8192 -- the tile is bound by the
+        // CU's load path, not by the dequantisation it removes: profiles/r06_prefill_f16_image_ablations.txt -- for 2 bytes per parameter)
+        static const bool f16img = [] {
+            const char* v = getenv("TM_PREFILL_F16_IMAGE");
+            return v && atoi(v) != 0;
+        }();
+        if (f16img && p32_only && l.w.packed32 && e->cfg.max_prefill_token_num >= 1024 && l.w.N >= 256) {
+            TM_TRY(linear_weight_build_f16_image(l.w, e->stream));
+        }
         TM_HIP_CHECK(hipStreamSynchronize(e->stream));
         for (Slot* p : {&q, &s, &z}) {
             TM_HIP_CHECK(hipFree(p->dev));

@@ -1293,7 +1293,7 @@ static void dec32_shape_dims(int shape, int* cg, int* s)
         *s  = 4;
         return;
     }
-    if (shape == kShapePre256) {
+    if (shape == kShapePre256 || shape == kShapeF16) {
         *cg = 8;
         *s  = 1;
         return;
@@ -1408,7 +1408,7 @@ int dec32_table_import(const char* path)
         }
         const bool big = M > 64;
         const bool lc  = shape == kShapeLC && M <= 64;
-        const bool p256 = shape == kShapePre256 && M > 64;  // what launch_linear_dec32 accepts (the tuner only proposes it for M, N >= 256)
+        const bool p256 = (shape == kShapePre256 || (shape == kShapeF16 && splits == 1)) && M > 64;  // what launch_linear_dec32 accepts (the tuner only proposes them for M, N >= 256)
         const bool mrg = dec32_is_merge_shape(shape) && M <= 64 && splits >= 2;  // in-launch merged split-K (decode batches only)
         const bool w2k = shape == kShapeWide2 && M <= 64;
         if (K > 0 && N > 0 && M > 0 && M == dec32_m_bucket(M) && shape >= 0 && (shape <= 9 || lc || p256 || mrg || w2k) && splits >= 1 && splits <= 16
@@ -1504,6 +1504,11 @@ int dec32_candidates(const LinearWeight& w, int M, int (*out)[2], int cap)
                 ++n;
             }
         }
+    }
+    if (M >= 1024 && M <= 8192 && w.N >= 256 && w.image16 != nullptr && n < cap) {  // gemm_prefill_f16.hip: the resident fp16 image, no split-K
+        out[n][0] = kShapeF16;
+        out[n][1] = 1;
+        ++n;
     }
     if (M >= 256 && M <= 8192 && w.N >= 256) {  // gemm_prefill.hip: 256 x 256 tiles (<= 4 slices: slabs of MBs each)
         const int tiles = (ncg + 7) / 8 * ((M + 255) / 256);
@@ -1648,7 +1653,10 @@ int launch_linear_dec32(const LinearWeight& w, const half_t* x, int ldx, half_t*
     TM_REQUIRE(!produce || (!gated_silu && nf->norm_w && nf->ss_out && ldy % 4 == 0), "folded RMSNorm, producer: residual, norm weight, sums");
     TM_REQUIRE(!consume || (nf->ss_tiles >= 1 && nf->inv_h > 0.f), "folded RMSNorm, consumer: tiles and 1 / H");
     TM_REQUIRE(w.packed32 != nullptr && w.N % 32 == 0, "decode GEMM: P32 layout missing");
-    TM_REQUIRE(M >= 1 && shape >= 0 && (shape <= 9 || shape == kShapeWide2 || shape == kShapeLC || shape == kShapePre256)
+    if (shape == kShapeF16 && (w.image16 == nullptr || M <= 64)) {
+        shape = kShapePre256;  // a table entry for a linear without the fp16 image (operator-level handle, TM_PREFILL_F16_IMAGE=0): the fused 256 x 256 tile
+    }
+    TM_REQUIRE(M >= 1 && shape >= 0 && (shape <= 9 || shape == kShapeWide2 || shape == kShapeLC || shape == kShapePre256 || shape == kShapeF16)
                    && (shape >= 6 || (M <= 64) == (shape < 4)) && (shape != kShapeLC || M <= 64) && (shape != kShapePre256 || M > 64)
                    && (shape != kShapeWide2 || M <= 64),
                "decode GEMM: shapes 0..3, 10 and 11 take M <= 64, shapes 4 / 5 / 12 take M > 64, shapes 6..9 any M");
@@ -1658,7 +1666,10 @@ int launch_linear_dec32(const LinearWeight& w, const half_t* x, int ldx, half_t*
     Dec32Params p{};
     p.x       = x;
     p.ldx     = ldx;
-    p.wp      = w.packed32;
+    p.wp      = shape == kShapeF16 ? (const void*)w.image16 : w.packed32;
+    if (shape == kShapeF16) {
+        splits = 1;
+    }
     p.y       = y;
     p.ldy     = ldy;
     p.partial = workspace;
@@ -1695,10 +1706,11 @@ int launch_linear_dec32(const LinearWeight& w, const half_t* x, int ldx, half_t*
     static const int wt = env_int2("TM_D32_WT", 1);  // measured (tools/trace_boundary.py, profiles/r02_gemm_boundary_gap.txt): -0.4..-0.9 us per split-K launch
     p.wt           = wt;
     dim3      grid((p.ncg + cgn - 1) / cgn, splits,
-                   shape == kShapePre256 ? (M + 255) / 256 : (shape == kShapeLC || shape == kShapeWide2) ? 1 : shape >= 6 ? (M + 31) / 32 : shape >= 4 ? (M + 127) / 128 : 1);
+                   (shape == kShapePre256 || shape == kShapeF16) ? (M + 255) / 256 : (shape == kShapeLC || shape == kShapeWide2) ? 1 : shape >= 6 ? (M + 31) / 32 : shape >= 4 ? (M + 127) / 128 : 1);
     static const char* const role_tag[6] = {"gemm", "w_qkv", "wo", "w1w3", "w2", "lm_head"};
     p.dbg        = gemm_trace_for((size_t)grid.x * grid.y * grid.z, role_tag[w.role >= 0 && w.role <= 5 ? w.role : 0], grid.x, grid.y, grid.z);
-    const int rc = shape == kShapePre256 ? launch_pre256(p, grid, st) :
+    const int rc = shape == kShapeF16 ? launch_f16_256(p, grid, st) :
+                   shape == kShapePre256 ? launch_pre256(p, grid, st) :
                    shape == kShapeLC ? launch_dec_lc(p, grid, st) :
                    shape == kShapeWide2 ? (M <= 32 ? launch_dec32_shape<1>(p, grid, shape, st) : launch_dec32_shape<2>(p, grid, shape, st)) :
                    shape >= 6 ? launch_dec32_shape<1>(p, grid, dec32_base_shape(shape), st) :

@@ -102,5 +102,8 @@ int launch_dec_lc(const Dec32Params& p, dim3 grid, hipStream_t st);
 // gemm_prefill.hip: 256 x 256 prefill tiles, weights dequantised once per workgroup tile through LDS (shape kShapePre256),
 // grid = (ceil(ncg / 8), splits, ceil(M / 256))
 int launch_pre256(const Dec32Params& p, dim3 grid, hipStream_t st);
+// gemm_prefill_f16.hip: 256 x 256 tiles over the resident fp16 image (p.wp = LinearWeight::image16), both operands by LDS-DMA (shape kShapeF16),
+// grid = (ceil(N / 256), 1, ceil(M / 256))
+int launch_f16_256(const Dec32Params& p, dim3 grid, hipStream_t st);
 
 }  // namespace tmk

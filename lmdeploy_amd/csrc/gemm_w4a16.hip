@@ -178,6 +178,10 @@ void linear_weight_free(LinearWeight& w)
     if (w.packed8) {
         (void)hipFree(w.packed8);
     }
+    if (w.image16) {
+        (void)hipFree(w.image16);
+    }
+    w.image16 = nullptr;
     w.packed8 = nullptr;
     w.packed   = nullptr;
     w.sz       = nullptr;
@@ -213,6 +217,15 @@ int linear_weight_prepare_u4(LinearWeight& w, const int32_t* qweight, const half
         return launch_repack_p32(w.packed32, qweight, scales, zeros, w.K, w.N, st);
     }
     return 0;
+}
+
+int linear_weight_build_f16_image(LinearWeight& w, hipStream_t st)
+{
+    TM_REQUIRE(w.type == 0 && w.packed32 != nullptr && w.N % 32 == 0 && w.K % 128 == 0, "fp16 image: a u4 linear with its P32 image");
+    if (!w.image16) {
+        TM_HIP_CHECK(hipMalloc((void**)&w.image16, (size_t)w.N * w.K * sizeof(half_t)));
+    }
+    return launch_dequant_p32_f16(w.image16, w, st);
 }
 
 int linear_weight_prepare_fp8(LinearWeight& w, const uint8_t* weight, const float* block_scales, bool gated_scales, hipStream_t st)

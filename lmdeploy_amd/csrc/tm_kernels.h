@@ -121,6 +121,11 @@ struct LinearWeight {
     // their even / odd column block scales)
     void*     packed8 = nullptr;
     size_t    packed8_bytes = 0;
+    // u4 only, optional (linear_weight_build_f16_image; the engine builds it for dense linears unless TM_PREFILL_F16_IMAGE=0): the fp16
+    // [N][K] image of the dequantised weights -- bit for bit the operand the fused tiles build on chip -- that prefill-sized forwards
+    // contract on the matrix pipe without any dequantisation work in the loop (gemm_prefill_f16.hip, shape kShapeF16).  2 bytes per
+    // parameter of HBM next to the 0.53 the decode path streams: 14 GB for an 8 B model on a 288 GB device.
+    half_t*   image16 = nullptr;
 };
 struct GemmConfig {
     int nt;      // n-tiles (16 cols) per wave: 1,2,4
@@ -133,6 +138,7 @@ struct GemmConfig {
 };
 // (shape 10 was "dequantise + the vendor library's fp16 GEMM" in round 3: removed -- no vendor GEMM on any path of this library)
 constexpr int kShapePre256     = 12;   // gemm_prefill.hip: 256 x 256 tiles, weights dequantised once per workgroup tile through LDS (M > 64)
+constexpr int kShapeF16        = 13;   // gemm_prefill_f16.hip: 256 x 256 tiles over the resident fp16 image, both operands by LDS-DMA (M > 64; LinearWeight::image16)
 constexpr int kShapeLC         = 11;   // gemm_decode_lc.hip: 8 consumer + 4 loader waves, 128 columns x M <= 64 rows per workgroup
 // kShapeMerge + s (s = 0..3, 6..9; round 6): the decode tile s whose split-K slices are merged INSIDE the launch by the last-arriving
 // slice of each column tile, for the fp16 / gated-SiLU epilogues (the folded-norm producers, epilogue 3, always merge that way): a
@@ -157,6 +163,7 @@ int    linear_weight_prepare_f16(LinearWeight& w, const half_t* weight /*[K][N]*
 int    linear_weight_prepare_fp8(LinearWeight& w, const uint8_t* weight /*[K][N] e4m3*/, const float* block_scales /*[K/128][ceil(N/128)]*/,
                                  bool gated_scales /* w1w3: scale row = [w1 blocks | w3 blocks] for interleaved columns */, hipStream_t st);
 void   linear_weight_free(LinearWeight& w);
+int    linear_weight_build_f16_image(LinearWeight& w, hipStream_t st);  // u4 linear with its P32 image -> w.image16 ([N][K] fp16)
 int    launch_dequant_p32_f16(half_t* out_nk /*[N][K]*/, const LinearWeight& w, hipStream_t st);  // gemm_decode.hip: the operand as an fp16 image
 size_t gemm_workspace_bytes(int M, int N, int splits);
 int    launch_splitk_reduce(half_t* y, int ldy, const float* partial, int splits, int M, int N, bool gated, hipStream_t st);

@@ -145,9 +145,10 @@ def test_w4a16_dequantised_image_full_size(tm, cuda, K, N):
 
 
 @pytest.mark.parametrize('K,N,gated', [(4096, 28672, 1), (14336, 4096, 0), (4096, 6144, 0)])
-@pytest.mark.parametrize('waves', [0, 0x204, 0x205, 0x20c])
+@pytest.mark.parametrize('waves', [0, 0x204, 0x205, 0x20c, 0x20d])
 def test_w4a16_prefill_full_size(tm, cuda, K, N, gated, waves):
-    """one 8192-token prefill chunk at the Llama-3-8B shapes through the prefill tiles (heuristic, 128 x 256, 128 x 512, 256 x 256 with the dequant through LDS):
+    """one 8192-token prefill chunk at the Llama-3-8B shapes through the prefill tiles (heuristic, 128 x 256, 128 x 512, 256 x 256 with the dequant through LDS,
+    0x20d: 256 x 256 over the resident fp16 image, both operands by LDS-DMA):
     128 sampled rows (incl. the first and the last of the chunk and of a row block) against the fp32 oracle product"""
     h, wd = _linear(tm, K, N)
     M = 8192

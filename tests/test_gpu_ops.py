@@ -493,7 +493,7 @@ def test_w4a16_linear_prefill_tiles(tm, cuda, K, N, M, gated):
     x_d = dev(x)
     # 0x20c = shape 12 (gemm_prefill.hip): 256 x 256 tiles, weights dequantised once per workgroup tile through LDS
     for nt, splits, waves in ((0, 0, 0), (0, 1, 0x204), (0, 2, 0x204), (0, 3, 0x204), (0, 1, 0x205), (0, 2, 0x205), (0, 5, 0x205),
-                              (0, 1, 0x20c), (0, 2, 0x20c), (0, 3, 0x20c), (2, 1, 8), (2, 2, 8), (2, 4, 8), (4, 1, 4)):
+                              (0, 1, 0x20c), (0, 2, 0x20c), (0, 3, 0x20c), (0, 1, 0x20d), (2, 1, 8), (2, 2, 8), (2, 4, 8), (4, 1, 4)):   # 0x20d = shape 13: the fp16 image
         if splits > K // 128:
             continue
         y = torch.zeros((M, N // 2 if gated else N), dtype=torch.float16, device='cuda')
@@ -505,6 +505,7 @@ def test_w4a16_linear_prefill_tiles(tm, cuda, K, N, M, gated):
 
 @pytest.mark.parametrize('K,N,M,splits,waves', [(1792, 4096, 1000, 3, 0x204), (1792, 4096, 2500, 3, 0x204), (1536, 4096, 64, 1, 0x200),
                                                 (1792, 4096, 1000, 3, 0x20c), (4096, 6144, 2500, 1, 0x20c), (1536, 4096, 300, 2, 0x20c),
+                                                (1792, 4096, 1000, 1, 0x20d), (4096, 6144, 2500, 1, 0x20d), (1536, 4096, 300, 1, 0x20d),
                                                 (1536, 4096, 64, 3, 0x200), (4608, 4096, 64, 1, 0x201), (1536, 2048, 32, 1, 0x203)])
 def test_w4a16_odd_stage_count_is_stable(tm, cuda, K, N, M, splits, waves):
     """Regression (round 2): with an odd number of LDS stages per k slice the asynchronous x stage that the LDS-DMA fetched

@@ -86,7 +86,8 @@ def main():
             def launch(h, stream):
                 _ffi.check(tm.tm_linear_forward(h, x.data_ptr(), K, y.data_ptr(), y.shape[1], M, gated, nt, splits, waves,
                                                 ws.data_ptr(), stream))
-            launch(handles[0], torch.cuda.current_stream().cuda_stream)      # warm-up (function attributes, lazy init)
+            for h_ in handles:                                                # warm-up (function attributes, lazy init; shape 13 builds its fp16 image on first use)
+                launch(h_, torch.cuda.current_stream().cuda_stream)
             torch.cuda.synchronize()
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
