@@ -42,8 +42,34 @@ __global__ __launch_bounds__(512) void gemm_f16_256_kernel(Dec32Params p)
     const int wc   = wave & 3;   // column quarter (64 columns)
 
     const int nst  = p.K / BK;
-    const int m0   = blockIdx.z * BM;
-    const int n0   = blockIdx.x * BM;
+    // ---- XCD-aware rasterisation (ABL bit 32): workgroup i runs on XCD i % 8 (dispatch order, MI355X_MICROARCH.md), so the 32 workgroups an
+    // XCD holds at a time are the linear ids {8 l + j}: give every XCD its own band of row blocks and walk it in 4 x 8 patches (4 row
+    // blocks x 8 column tiles), so that what is resident on one L2 together shares its operand slices 8 / 4 ways.  Falls back to the plain
+    // map when the tile counts do not divide (any map is correct: a bijection of the grid).
+    int tm = blockIdx.z, tn = blockIdx.x;
+    if constexpr ((ABL & 32) != 0) {
+        const int TM = gridDim.z, TN = gridDim.x;
+        if (TM % 32 == 0 || (TM % 8 == 0 && TM / 8 >= 1)) {
+            const int wg   = blockIdx.z * TN + blockIdx.x;
+            const int xcd  = wg & 7, loc = wg >> 3;
+            const int rpb  = TM / 8;                      // row blocks of an XCD's band
+            const int pm   = rpb >= 4 ? 4 : rpb;          // patch height
+            const int pn   = 32 / pm;                     // patch width (column tiles); the last patch of a band may be narrower
+            const int per_band_row = pm * TN;             // workgroups of one patch row (pm row blocks x all column tiles)
+            const int br   = loc / per_band_row;          // which group of pm row blocks inside the band
+            const int rem  = loc % per_band_row;
+            const int pc   = rem / (pm * pn);             // patch column
+            const int in   = rem % (pm * pn);
+            const int wlast = TN - pc * pn < pn ? TN - pc * pn : pn;   // width of this patch
+            tm = xcd * rpb + br * pm + in / wlast;
+            tn = pc * pn + in % wlast;
+            if (rpb % pm != 0) {  // ragged band: plain map
+                tm = blockIdx.z, tn = blockIdx.x;
+            }
+        }
+    }
+    const int m0   = tm * BM;
+    const int n0   = tn * BM;
     const int Mloc = min(BM, p.M - m0);
     const int Nloc = min(BM, p.N - n0);
 
@@ -108,10 +134,17 @@ __global__ __launch_bounds__(512) void gemm_f16_256_kernel(Dec32Params p)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         half8_t fa[2][NC] = {}, fb[2][MH] = {};
+        bool    rd_done = false;
         auto    rd = [&](unsigned xa, int q, int j) __attribute__((always_inline)) {
             const unsigned sw = (unsigned)((32 * j) ^ fsw);
             const unsigned ax = xa + (unsigned)fxb + sw;
             const unsigned aw = xa + (unsigned)fwb + sw;
+            if constexpr ((ABL & 64) != 0) {  // timing only: fragments are read during the first stage, then the registers keep that (real) data
+                if (xa != lds0 || rd_done) {
+                    asm volatile("" : "+v"(fa[q][0]), "+v"(fa[q][1]), "+v"(fb[q][0]), "+v"(fb[q][1]), "+v"(fb[q][2]), "+v"(fb[q][3]) : "v"(aw), "v"(ax));
+                    return;
+                }
+            }
             if constexpr (ABL & 4) {  // timing only: no fragment reads (the registers keep whatever they hold)
                 asm volatile("" : "+v"(fa[q][0]), "+v"(fa[q][1]), "+v"(fb[q][0]), "+v"(fb[q][1]), "+v"(fb[q][2]), "+v"(fb[q][3]) : "v"(aw), "v"(ax));
                 return;
@@ -176,6 +209,7 @@ __global__ __launch_bounds__(512) void gemm_f16_256_kernel(Dec32Params p)
             wt(I0{}, IR{});
             mma(I0{});
             wt(I1{}, I0{});  // step 3's fragments are in registers: every LDS read of this buffer has retired
+            rd_done = true;
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the pieces of stage t+1 (issued a stage ago)
             if constexpr ((ABL & 16) != 0) {
                 asm volatile("" ::"v"(pfd0), "v"(pfd1));  // the prefetch registers stay reserved until their loads have landed
@@ -237,7 +271,7 @@ int launch_f16_256(const Dec32Params& p, dim3 grid, hipStream_t st)
         TM_HIP_CHECK(hipGetLastError());                                                       \
         return 0;                                                                              \
     }
-    F16_CASE(2) F16_CASE(4) F16_CASE(8) F16_CASE(12) F16_CASE(6) F16_CASE(16) F16_CASE(18)
+    F16_CASE(2) F16_CASE(4) F16_CASE(8) F16_CASE(12) F16_CASE(6) F16_CASE(16) F16_CASE(18) F16_CASE(32) F16_CASE(34) F16_CASE(64) F16_CASE(72)
 #undef F16_CASE
     if (const int rc = ensure_dynamic_lds((const void*)gemm_f16_256_kernel<0>, lds)) {
         return rc;
