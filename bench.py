@@ -558,7 +558,7 @@ def main():
                        'decode_splits': stats['decode_splits'], 'hipgraph': cinfo['hipgraph'],
                        # RMSNorm folded into the decode GEMMs (tp = 1, dense u4, batch <= 64; TM_FOLD_NORM bit 0: wo -> w1w3, bit 1: w2 ->
                        # w_qkv): 5 launches per layer instead of 7
-                       'rmsnorm_fold': (int(os.environ.get('TM_FOLD_NORM', '3')) & 3) if (world == 1 and emu <= 1 and weight_type == 0
+                       'rmsnorm_fold': (int(os.environ.get('TM_FOLD_NORM', '0')) & 3) if (world == 1 and emu <= 1 and weight_type == 0
                                                                                          and not model.get('moe_experts') and B <= int(os.environ.get('TM_FOLD_MAX_M', '64'))) else 0,
                        'gemm_dispatch': ('measured at start-up (tm_engine_tune_gemm' + (', rank 0\'s table broadcast' if world > 1 else '') + ')')
                                         if tuned else 'heuristic',

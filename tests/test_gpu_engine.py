@@ -19,7 +19,7 @@ pytestmark = pytest.mark.gpu
 @pytest.mark.parametrize('kv_bits,use_graph', [(8, 1), (4, 0), (16, 1)])
 def test_engine_matches_oracle(cuda, monkeypatch, kv_bits, use_graph, fold):
     """prefill + 6 decode steps of a ragged batch against the oracle model: logits of every step, greedy tokens (eager and
-    graph-replayed).  fold = 3 (the default; bit 0: wo -> w1w3, bit 1: w2 -> next w_qkv): the decode steps run the RMSNorms folded into the
+    graph-replayed).  fold = 3 (TM_FOLD_NORM=3; the default is 0 since round 6; bit 0: wo -> w1w3, bit 1: w2 -> next w_qkv): the decode steps run the RMSNorms folded into the
     GEMMs (5 launches per layer) --
     the oracle stays the reference's unfused sequence and the bound stays the unfused engine's (3e-2 on O(1) logits; measured
     max differences are printed for both arms)."""
@@ -65,7 +65,7 @@ def test_engine_matches_oracle(cuda, monkeypatch, kv_bits, use_graph, fold):
 
 @pytest.mark.parametrize('batch,fold_max', [(100, 128), (128, 128), (100, 64)])
 def test_engine_folded_norm_batch_128_matches_oracle(cuda, monkeypatch, batch, fold_max):
-    """Round 6 (BASELINE config 3 = batch 128): decode batches of 65 .. 128 rows run the folded layer too (TM_FOLD_MAX_M, default 128; 64 = the
+    """Round 6 (BASELINE config 3 = batch 128): decode batches of 65 .. 128 rows run the folded layer too (TM_FOLD_MAX_M; default 64 = the
     round-5 limit: reduce-norm launches above it) -- producers on the 32-row-block tiles, consumers on those or the 128-row tile.  Prefill + 3
     decode steps (graph replay) against the oracle model, the bound of test_engine_matches_oracle."""
     monkeypatch.setenv('TM_FOLD_NORM', '3')
