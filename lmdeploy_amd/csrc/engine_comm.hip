@@ -370,6 +370,42 @@ int tm_engine_comm_native_selftest(tm_engine* e, int* ok)
                 }
             }
         }
+        // the all-gather of the lm_head's (value, index) candidates runs on this communicator too (ticket form, shared call counter): one call,
+        // every rank's 64 words must arrive in rank order
+        if (good) {
+            uint32_t *dsrc = nullptr, *ddst = nullptr;
+            TM_HIP_CHECK(hipMalloc((void**)&dsrc, 64 * 4));
+            TM_HIP_CHECK(hipMalloc((void**)&ddst, (size_t)tp * 64 * 4));
+            std::vector<uint32_t> hs(64), hd((size_t)tp * 64);
+            for (int i = 0; i < 64; ++i) {
+                hs[i] = 0x5eed0000u + (uint32_t)me * 256u + (uint32_t)i;
+            }
+            int rc2 = 0;
+            auto body = [&]() -> int {
+                TM_HIP_CHECK(hipMemcpy(dsrc, hs.data(), 64 * 4, hipMemcpyHostToDevice));
+                TM_HIP_CHECK(hipMemset(ddst, 0, (size_t)tp * 64 * 4));
+                half_t*   data[8];
+                uint32_t* flags[8];
+                p2p_tables(e, data, flags);
+                TM_TRY(launch_p2p_allgather(data, flags, tp, me, e->p2p_state, (size_t)e->p2p_rows * H, dsrc, ddst, 64, e->stream));
+                TM_HIP_CHECK(hipStreamSynchronize(e->stream));
+                TM_HIP_CHECK(hipMemcpy(hd.data(), ddst, (size_t)tp * 64 * 4, hipMemcpyDeviceToHost));
+                uint32_t mark = 0;
+                TM_HIP_CHECK(hipMemcpy(&mark, e->p2p_state + 3, 4, hipMemcpyDeviceToHost));
+                good = mark == 0;
+                for (int q = 0; q < tp && good; ++q) {
+                    for (int i = 0; i < 64 && good; ++i) {
+                        good = hd[(size_t)q * 64 + i] == 0x5eed0000u + (uint32_t)q * 256u + (uint32_t)i;
+                    }
+                }
+                return 0;
+            };
+            rc2 = body();
+            (void)hipFree(dsrc), (void)hipFree(ddst);
+            if (rc2) {
+                return rc2;
+            }
+        }
         *ok = good ? 1 : 0;
         return 0;
     };
