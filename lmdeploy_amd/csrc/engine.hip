@@ -310,7 +310,12 @@ int tm_engine_init_synthetic(tm_engine* e, uint64_t seed)
             TM_HIP_CHECK(hipMalloc((void**)&master, n * 2));
             master_elems = n;
         }
-        TM_TRY(fill_normal(e, master, n, 0.f, 0.1f / std::sqrt((float)l.w.K), ++sd));
+        // TM_SYNTH_WEIGHT_SCALE (diagnostics only: `0` = all-zero linear weights, the low-toggle arm of the power experiment in DESIGN 3.8)
+        static const float wscale = [] {
+            const char* v = getenv("TM_SYNTH_WEIGHT_SCALE");
+            return v ? (float)atof(v) : 1.0f;
+        }();
+        TM_TRY(fill_normal(e, master, n, 0.f, wscale * 0.1f / std::sqrt((float)l.w.K), ++sd));
         Slot *q = nullptr, *s = nullptr, *z = nullptr;
         TM_TRY(ensure_slot(e, l.prefix + ".qweight", &q));
         TM_TRY(ensure_slot(e, l.prefix + ".scales", &s));
