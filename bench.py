@@ -223,6 +223,36 @@ def measure_in_graph_durations(args, table_text, ctx_target, layers, batch):
         shutil.rmtree(tmp, ignore_errors=True)
 
 
+def run_canary(args, rank, world, timeout_s=240):
+    """Multi-GPU runs only: before THIS process touches the device for real, a child copy of the bench (its own rendezvous port) pushes a
+    2-layer model of the same width through every collective code path the real run will take with the CURRENT switches -- RCCL bring-up,
+    the native communicator + its self-test, a prefill forward large enough for the side-stream micro-batch schedule, graph-captured decode
+    steps -- under a hard time limit.  No multi-rank collective of this engine has ever crossed xGMI before the driver's scaling run,
+    and a hang inside a collective cannot be recovered in-process: the canary turns "hang -> no record at all" into "fall back to the most
+    conservative switches and measure".  Returns True when the child exited 0 within the limit."""
+    import subprocess
+    port = int(os.environ.get('MASTER_PORT', '29500')) + 17
+    env = dict(os.environ, MASTER_PORT=str(port), TM_BENCH_CANARY='1')
+    cmd = [sys.executable, os.path.abspath(__file__), '--gpus', str(world), '--steps', '6', '--warmup', '3', '--layers', '2', '--batch', str(args.batch),
+           '--prompt-len', '64', '--max-prefill-tokens', '4096', '--quant-policy', str(args.quant_policy), '--model', args.model, '--profile-steps', '0',
+           '--no-cpu-baseline', '--no-traffic', '--no-full-run', '--tune', '0']
+    if args.allow_shared_devices:
+        cmd.append('--allow-shared-devices')
+    try:
+        p = subprocess.Popen(cmd, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    except OSError:
+        return False
+    try:
+        return p.wait(timeout=timeout_s) == 0
+    except subprocess.TimeoutExpired:
+        p.kill()            # this exact child: a rank stuck in a collective
+        try:
+            p.wait(timeout=20)
+        except subprocess.TimeoutExpired:
+            pass
+        return False
+
+
 class Watchdog:
     """Multi-GPU runs only: a rank that makes no progress (a collective that never completes, a peer that died before its
     first step) would otherwise hang until the launcher's own limit.  Every phase of the run re-arms the timer; when it
@@ -347,9 +377,22 @@ def main():
         os.environ.setdefault('TM_P2P_2SHOT_GRID', str(max(8, 256 // ranks_per_device // 2)))
     local_dev = local_rank % ndev
     torch.cuda.set_device(local_dev)
+    canary_note = ''
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group('gloo', rank=rank, world_size=world)   # control plane only; data plane = RCCL in C++
+        # the canary (run_canary): every rank's child forms its own group; ANY failure -> all ranks take the conservative switches together
+        if not os.environ.get('TM_BENCH_CANARY') and os.environ.get('TM_BENCH_NO_CANARY', '0') == '0' \
+                and (ranks_per_device == 1 or os.environ.get('TM_BENCH_CANARY_SHARED', '0') == '1'):     # (the latter: mechanism test on a 1-GPU box)
+            ok = run_canary(args, rank, world)
+            oks = [None] * world
+            dist.all_gather_object(oks, bool(ok))
+            if not all(oks):
+                for k, v in (('TM_COMM', 'rccl'), ('TM_COMM_STREAM', '0'), ('TM_GRAPH_COMM', '0')):
+                    os.environ[k] = v
+                canary_note = (f'canary run failed or hung on ranks {[r for r, o_ in enumerate(oks) if not o_]} with the default collective switches -> '
+                               f'RCCL only, collectives on the engine stream, eager (TM_COMM=rccl TM_COMM_STREAM=0 TM_GRAPH_COMM=0)')
+                print(f'[bench] rank {rank}: {canary_note}', file=sys.stderr)
 
     model = dict(MODELS[args.model])
     if args.layers:
@@ -572,6 +615,8 @@ def main():
                               'achieved': round(step_bytes / (dt / K) / 1e9, 1), 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
                               'frac': round(step_bytes / (dt / K) / 1e9 / HBM_PEAK_GBPS, 4)},
         }
+        if canary_note:
+            comm_note = (comm_note + '; ' if comm_note else '') + canary_note
         if comm_note:
             out['config']['collectives_note'] = comm_note
         if world > 1 or emu > 1:
