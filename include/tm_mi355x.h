@@ -128,6 +128,17 @@ size_t tm_sample_workspace(int batch);
 int    tm_sample(int* out_ids, int* kept_out, const void* logits, int batch, int vocab, int ld, const float* temperature,
                  const int* top_k, const float* top_p, const float* min_p, const float* uniform, void* workspace,
                  tm_stream_t st);
+/* tm_sample + the logprobs of the kept candidates (the `sampled_logprobs / sampled_indexes / sampled_nums` outputs of
+ * invokeSampling, kernels/sampling_kernels.cu:67-90, which generation/sampling.cc:173-178 arms when a request asks for
+ * output_logprobs): per row the first min(kept, cap) candidates in sampling order -- idx [batch][cap] token ids, vals [batch][cap]
+ * logf of their renormalised probability (-inf for zero-probability candidates), num [batch] their count -- and sel [batch], the
+ * drawn token's own logprob.  cap = TM_MAX_LOGPROBS reproduces the reference's layout: a drawn token beyond the first 1024
+ * candidates replaces entry 1023.  Smaller caps keep the first cap candidates untouched (the drawn token's logprob is in sel).
+ * All arrays are device memory; kept_out is required. */
+#define TM_MAX_LOGPROBS 1024
+int    tm_sample_logprobs(int* out_ids, int* kept_out, float* vals, int* idx, int* num, float* sel, int cap, const void* logits,
+                          int batch, int vocab, int ld, const float* temperature, const int* top_k, const float* top_p,
+                          const float* min_p, const float* uniform, void* workspace, tm_stream_t st);
 /* the engine's uniform draw: Philox4x32-10, key = request seed, counter = context length -> [0, 1) (host function) */
 float  tm_philox_uniform(uint64_t seed, uint32_t counter);
 
@@ -432,6 +443,14 @@ typedef struct tm_sampling {
  * are all-gathered and every rank draws the same token from the full row (models/language_model.cc:304-333 gathers the
  * logits as well) -- over RCCL, or through the native P2P segments when no RCCL communicator exists. */
 int tm_engine_set_sampling(tm_engine* e, const tm_sampling* host_params, int batch);
+/* Static batch: the NEXT tm_engine_prefill records, for every generated token of every sequence, the first n (1 .. TM_MAX_LOGPROBS;
+ * 0 = off) kept candidates with their logprobs and the drawn token's own logprob -- GenerationConfig.logprobs, i.e. the request's
+ * output_logprobs of generation/sampling.cc:173-178,229-279 seen through lmdeploy/turbomind/turbomind.py:472-503.  The draw then runs
+ * through the sampling kernels (greedy sequences as top_k = 1 rows: one kept candidate with logprob 0, as upstream).  Cleared by
+ * tm_engine_release.  tm_engine_fetch_logprobs copies the records to the host: vals / idx [batch][max_new_tokens][n] (entries beyond
+ * num are undefined), num / sel [batch][max_new_tokens] (columns beyond the generated steps: num = 0). */
+int tm_engine_set_logprobs(tm_engine* e, int n);
+int tm_engine_fetch_logprobs(tm_engine* e, float* host_vals, int* host_idx, int* host_num, float* host_sel);
 /* Per-sequence logits processors (GenerationConfig: repetition_penalty, min_new_tokens, bad_token_ids,
  * stop_token_ids; applied in the reference's order, see tm_logits_process).  stop ids end a sequence of the
  * continuous-batching path like its eos id and are banned with it until min_new_tokens tokens exist; the static

@@ -100,6 +100,8 @@ _SIGNATURES = {
     'tm_moe_destroy': (c_int, [c_void_p]),
     'tm_sample': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                           c_void_p, c_void_p]),
+    'tm_sample_logprobs': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p,
+                                   c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     'tm_philox_uniform': (C.c_float, [C.c_uint64, C.c_uint32]),
     'tm_linear_create': (c_int, [POINTER(c_void_p), c_int, c_int, c_int, c_int]),
     'tm_linear_prepare': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
@@ -173,6 +175,8 @@ _SIGNATURES = {
     'tm_engine_release': (c_int, [c_void_p]),
     'tm_engine_set_sampling': (c_int, [c_void_p, c_void_p, c_int]),
     'tm_engine_set_logits_params': (c_int, [c_void_p, c_void_p, c_int]),
+    'tm_engine_set_logprobs': (c_int, [c_void_p, c_int]),
+    'tm_engine_fetch_logprobs': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     'tm_engine_submit_gen': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, POINTER(c_int64)]),
     'tm_seen_update': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     'tm_logits_process': (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p,

@@ -509,6 +509,15 @@ int tm_sample(int* out_ids, int* kept_out, const void* logits, int batch, int vo
                          uniform, workspace, (hipStream_t)st);
 }
 
+int tm_sample_logprobs(int* out_ids, int* kept_out, float* vals, int* idx, int* num, float* sel, int cap, const void* logits,
+                       int batch, int vocab, int ld, const float* temperature, const int* top_k, const float* top_p,
+                       const float* min_p, const float* uniform, void* workspace, tm_stream_t st)
+{
+    const SampleLogprobs lp{vals, idx, num, sel, cap, nullptr, 0, 1, 0, 1};
+    return launch_sample(out_ids, kept_out, (const half_t*)logits, batch, vocab, ld, temperature, top_k, top_p, min_p,
+                         uniform, workspace, (hipStream_t)st, &lp);
+}
+
 float tm_philox_uniform(uint64_t seed, uint32_t counter)
 {
     return philox_uniform_host(seed, counter);

@@ -690,7 +690,8 @@ int tm_engine_destroy(tm_engine* e)
     for (void* q : {(void*)e->d_active, (void*)e->d_pf_k_len, (void*)e->d_pf_cu_q, (void*)e->d_pf_block_ptrs, (void*)e->d_first_ids, (void*)e->d_temp, (void*)e->d_topp, (void*)e->d_minp,
                     (void*)e->d_u, (void*)e->d_topk, (void*)e->d_seed, e->d_sample_ws, (void*)e->d_logits_gather, (void*)e->d_logits_full,
                     (void*)e->d_seen, (void*)e->d_lp_rep,
-                    (void*)e->d_lp_minlen, (void*)e->d_lp_ban, (void*)e->d_lp_end}) {
+                    (void*)e->d_lp_minlen, (void*)e->d_lp_ban, (void*)e->d_lp_end, (void*)e->d_lpr_vals, (void*)e->d_lpr_idx, (void*)e->d_lpr_num,
+                    (void*)e->d_lpr_sel, (void*)e->d_kept}) {
         if (q) {
             (void)hipFree(q);
         }

@@ -582,8 +582,12 @@ int forward(tm_engine* e, const int* d_ids, int M, int nseq, bool decode, int ma
                 lg = e->d_logits_full;
             }
             TM_PROF(P_SAMPLE, TM_TRY(launch_sample_uniform(e->d_u + slot, e->d_seed + slot, k_len, n, st)));
-            TM_PROF(P_SAMPLE, TM_TRY(launch_sample(ids, nullptr, lg, n, V, V, e->d_temp + slot, e->d_topk + slot, e->d_topp + slot,
-                                                   e->d_minp + slot, e->d_u + slot, e->d_sample_ws, st)));
+            // static batch with tm_engine_set_logprobs: the kept candidates' logprobs of this step join the record of (slot, step)
+            const bool           lpr = e->logprobs_on && !e->sched;
+            const SampleLogprobs lp{e->d_lpr_vals, e->d_lpr_idx, e->d_lpr_num, e->d_lpr_sel, e->logprobs_n, e->d_step, 1, e->max_new, slot,
+                                    e->max_new};
+            TM_PROF(P_SAMPLE, TM_TRY(launch_sample(ids, lpr ? e->d_kept + slot : nullptr, lg, n, V, V, e->d_temp + slot, e->d_topk + slot,
+                                                   e->d_topp + slot, e->d_minp + slot, e->d_u + slot, e->d_sample_ws, st, lpr ? &lp : nullptr)));
         }
         else if (!e->use_comm) {
             TM_PROF(P_SAMPLE, TM_TRY(launch_argmax(ids, nullptr, logits, n, e->vocab_local, e->vocab_local, 0, st)));
@@ -937,6 +941,8 @@ int tm_engine_release(tm_engine* e)
     e->h_sampling.clear();
     e->cb_sampling.clear();
     e->sampling_on = false;
+    e->logprobs_next = 0;
+    e->logprobs_on   = false;
     e->h_logits.clear();
     e->cb_logits.clear();
     e->logits_on = false;
@@ -1004,6 +1010,35 @@ int tm_engine_prefill(tm_engine* e, const int* host_ids, const int* host_lens, i
         TM_TRY(sampling_upload(e, e->h_sampling.data(), 0, batch));
         e->sampling_on = true;
     }
+    e->logprobs_on = false;
+    if (e->logprobs_next > 0) {
+        // the logprobs come out of the sampling kernels: greedy rows are their top_k = 1 rows (kept = 1: the token with logprob 0,
+        // what the reference reports for top_k = 1 as well)
+        if (!e->sampling_on) {
+            std::vector<tm_sampling> greedy(batch, tm_sampling{1.f, 1, 1.f, 0.f, 0});
+            TM_TRY(sampling_upload(e, greedy.data(), 0, batch));
+            e->sampling_on = true;
+        }
+        const size_t records = (size_t)batch * max_new_tokens, entries = records * e->logprobs_next;
+        if (records > e->lpr_records || entries > e->lpr_entries || !e->d_kept) {
+            TM_HIP_CHECK(hipStreamSynchronize(e->stream));
+            (void)hipFree(e->d_lpr_vals), (void)hipFree(e->d_lpr_idx), (void)hipFree(e->d_lpr_num), (void)hipFree(e->d_lpr_sel);
+            e->d_lpr_vals = nullptr, e->d_lpr_idx = nullptr, e->d_lpr_num = nullptr, e->d_lpr_sel = nullptr;
+            e->lpr_records = e->lpr_entries = 0;
+            TM_TRY(dmalloc(&e->d_lpr_vals, entries));
+            TM_TRY(dmalloc(&e->d_lpr_idx, entries));
+            TM_TRY(dmalloc(&e->d_lpr_num, records));
+            TM_TRY(dmalloc(&e->d_lpr_sel, records));
+            if (!e->d_kept) {
+                TM_TRY(dmalloc(&e->d_kept, (size_t)e->cfg.max_batch_size));
+            }
+            e->lpr_records = records;
+            e->lpr_entries = entries;
+        }
+        TM_HIP_CHECK(hipMemsetAsync(e->d_lpr_num, 0, records * 4, e->stream));
+        e->logprobs_n  = e->logprobs_next;
+        e->logprobs_on = true;
+    }
     e->logits_on = false;
     if (!e->h_logits.empty()) {
         TM_REQUIRE((int)e->h_logits.size() == batch, "tm_engine_set_logits_params: batch size differs from the prefill's");
@@ -1036,7 +1071,8 @@ int tm_engine_prefill(tm_engine* e, const int* host_ids, const int* host_lens, i
 
     setup_decode(e, batch);
     if (e->graph && (e->graph_batch != batch || e->graph_max_new != max_new_tokens || e->graph_sampling != e->sampling_on
-                     || e->graph_logits != e->logits_on)) {
+                     || e->graph_logits != e->logits_on || e->graph_logprobs != e->logprobs_on || e->logprobs_on)) {
+        // (with logprobs on the record pointers and the cap are captured kernel arguments: always re-capture)
         (void)hipGraphExecDestroy(e->graph);
         e->graph = nullptr;
     }
@@ -1117,6 +1153,7 @@ int tm_engine_decode(tm_engine* e, int steps)
         e->graph_max_new  = e->max_new;
         e->graph_sampling = e->sampling_on;
         e->graph_logits   = e->logits_on;
+        e->graph_logprobs = e->logprobs_on;
     }
     for (int i = 0; i < steps; ++i) {
         if (graph_enabled(e) && e->graph) {
@@ -1145,6 +1182,30 @@ int tm_engine_set_sampling(tm_engine* e, const tm_sampling* host_params, int bat
         TM_REQUIRE(host_params[i].temperature > 0.f, "sampling: temperature must be > 0");
     }
     e->h_sampling.assign(host_params, host_params + batch);
+    return 0;
+}
+
+int tm_engine_set_logprobs(tm_engine* e, int n)
+{
+    TM_REQUIRE(e, "null pointer");
+    TM_REQUIRE(e->batch == 0 && !e->sched, "set the logprobs count before tm_engine_prefill");
+    TM_REQUIRE(n >= 0 && n <= kMaxLogProb, "0 <= logprobs <= TM_MAX_LOGPROBS");
+    TM_REQUIRE(n == 0 || !e->use_comm || e->comm || e->p2p_ready,
+               "logprobs with tp > 1 gather the logits like stochastic sampling: tm_engine_comm_init or the native communicator first");
+    e->logprobs_next = n;
+    return 0;
+}
+
+int tm_engine_fetch_logprobs(tm_engine* e, float* host_vals, int* host_idx, int* host_num, float* host_sel)
+{
+    TM_REQUIRE(e && host_vals && host_idx && host_num && host_sel, "null pointer");
+    TM_REQUIRE(e->batch > 0 && !e->sched && e->logprobs_on, "no admitted static batch with logprobs (tm_engine_set_logprobs before the prefill)");
+    TM_HIP_CHECK(hipStreamSynchronize(e->stream));
+    const size_t records = (size_t)e->batch * e->max_new;
+    TM_HIP_CHECK(hipMemcpy(host_vals, e->d_lpr_vals, records * e->logprobs_n * 4, hipMemcpyDeviceToHost));
+    TM_HIP_CHECK(hipMemcpy(host_idx, e->d_lpr_idx, records * e->logprobs_n * 4, hipMemcpyDeviceToHost));
+    TM_HIP_CHECK(hipMemcpy(host_num, e->d_lpr_num, records * 4, hipMemcpyDeviceToHost));
+    TM_HIP_CHECK(hipMemcpy(host_sel, e->d_lpr_sel, records * 4, hipMemcpyDeviceToHost));
     return 0;
 }
 

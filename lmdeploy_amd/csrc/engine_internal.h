@@ -222,6 +222,12 @@ struct tm_engine {
     half_t*   d_logits_gather = nullptr;  // tp > 1 + sampling: [tp][max_batch][vocab / tp] all-gathered shards ...
     half_t*   d_logits_full   = nullptr;  // ... and the full rows [max_batch][vocab] every rank samples from
     void*     d_moe_ws    = nullptr;  // routing tables + expert activations of one forward (moe_workspace_bytes)
+    // logprobs of the generated tokens (tm_engine_set_logprobs, static batch): records [batch][max_new] x [cap] next to d_generated
+    int    logprobs_next = 0, logprobs_n = 0;
+    bool   logprobs_on = false, graph_logprobs = false;
+    float *d_lpr_vals = nullptr, *d_lpr_sel = nullptr;
+    int *  d_lpr_idx = nullptr, *d_lpr_num = nullptr, *d_kept = nullptr;
+    size_t lpr_records = 0, lpr_entries = 0;  // allocated records / records x cap
     std::vector<tm_sampling>       h_sampling;      // static batch: parameters of the next prefill
     std::map<int64_t, tm_sampling> cb_sampling;     // continuous batching: per request
 

@@ -29,6 +29,9 @@ __device__ __forceinline__ uint32_t key_of(uint16_t h)
     if ((h & 0x7c00u) == 0x7c00u && (h & 0x03ffu)) {
         return 0u;  // NaN
     }
+    if (h == 0x8000u) {
+        return 0x8000u;  // -0.0 sorts with +0.0 (equal values: the tie goes by token id, as in a stable sort on the float value)
+    }
     return (h & 0x8000u) ? (uint32_t)(uint16_t)~h : (uint32_t)(h | 0x8000u);
 }
 
@@ -103,7 +106,8 @@ __global__ __launch_bounds__(1024) void sample_select_kernel(int* __restrict__ o
                                                              const float* __restrict__ top_p,
                                                              const float* __restrict__ min_p,
                                                              const float* __restrict__ uniform,
-                                                             int* __restrict__ kept_out)
+                                                             int* __restrict__ kept_out,
+                                                             int keep_hist)
 {
     __shared__ double   s_d[16];
     __shared__ long long s_l[16];
@@ -308,9 +312,11 @@ __global__ __launch_bounds__(1024) void sample_select_kernel(int* __restrict__ o
     if (tid == 0 && kept_out) {
         kept_out[b] = (int)kept;
     }
-    // the histogram is left zeroed for the next step
-    for (int q = 0; q < 64; ++q) {
-        h[kBins - 1 - (tid * 64 + q)] = 0u;
+    // the histogram is left zeroed for the next step (keep_hist: sample_logprobs_kernel reads it first and zeroes it)
+    if (!keep_hist) {
+        for (int q = 0; q < 64; ++q) {
+            h[kBins - 1 - (tid * 64 + q)] = 0u;
+        }
     }
 
     // ---- pass C: the sel_m-th token (ascending id) whose logit has the drawn value ----------------------------------
@@ -358,6 +364,177 @@ __global__ __launch_bounds__(1024) void sample_select_kernel(int* __restrict__ o
     }
 }
 
+// ---- logprobs of the kept candidates (sampling_kernels.cu:67-90 + the Python side's view of it, turbomind.py:472-503) --------
+// After sample_select_kernel (keep_hist = 1): the first L = min(kept, cap) candidates of the row in sampling order (descending
+// probability, ties by ascending id) with logf of their RENORMALISED probability (the reference's `logits` array holds the kept
+// candidates' probabilities divided by their mass when invokeSampling runs), their count, and the drawn token's own logprob.
+// force_last (the reference's layout, cap = kMaxLogProb): a drawn token beyond the first `cap` candidates replaces entry cap - 1.
+// Records land at row (*step) * step_stride + (row0 + b) * row_stride of the output arrays (step = nullptr: 0); nothing is written
+// when that step is >= max_steps.  Structure: thread t owns 64 descending bins like the selection kernel; one pass over the row in id order
+// compacts the tokens of the strictly better bins into an LDS list (< cap <= 1024 entries, bitonic sort by (bin, id)) and writes the
+// first tokens of the cut bin behind them (already in id order).  Leaves the histogram zeroed.
+__global__ __launch_bounds__(1024) void sample_logprobs_kernel(float* __restrict__ out_vals, int* __restrict__ out_idx,
+                                                               int* __restrict__ out_num, float* __restrict__ out_sel, int cap,
+                                                               int force_last, uint32_t* __restrict__ hist,
+                                                               const half_t* __restrict__ logits, int V, int ld,
+                                                               const float* __restrict__ temperature,
+                                                               const int* __restrict__ kept, const int* __restrict__ sel_ids,
+                                                               const int* __restrict__ step, int step_stride, int row_stride,
+                                                               int row0, int max_steps)
+{
+    __shared__ double             s_d[16];
+    __shared__ long long          s_l[16];
+    __shared__ int                s_i[4];
+    __shared__ unsigned long long s_a[1024];
+    const int  b   = blockIdx.x;
+    const int  tid = threadIdx.x;
+    uint32_t*  h   = hist + (size_t)b * kBins;
+    const int  st  = step ? *step : 0;
+    const bool rec = st < max_steps;
+    const size_t row = (size_t)st * step_stride + (size_t)(row0 + b) * row_stride;
+    const float T    = temperature ? temperature[b] : 1.0f;
+    const float invT = 1.0f / (T > 0.f ? T : 1.0f);
+    long long   n    = kept[b];
+    const int   sel  = sel_ids[b];
+
+    auto bin = [&](int q) -> long long { return (long long)h[kBins - 1 - (tid * 64 + q)]; };
+    long long mine  = 0;
+    int       first = kBins;
+    for (int q = 63; q >= 0; --q) {
+        const long long c = bin(q);
+        mine += c;
+        if (c) {
+            first = tid * 64 + q;
+        }
+    }
+    if (tid < 4) {
+        s_i[tid] = tid == 0 ? kBins : -1;
+    }
+    __syncthreads();
+    atomicMin(&s_i[0], first);
+    __syncthreads();
+    const float vmax = value_of_key(kBins - 1 - min(s_i[0], kBins - 1));
+    long long       tot_cnt;
+    const long long before = block_exclusive_scan<long long>(mine, s_l, &tot_cnt);
+    n = n < 0 ? 0 : (n > tot_cnt ? tot_cnt : n);
+    const long long L = n < cap ? n : cap;
+    auto wbin = [&](int dbin) -> double {
+        const float  v = value_of_key(kBins - 1 - dbin);
+        const double w = exp((double)((v - vmax) * invT));
+        return w == w ? w : 0.0;
+    };
+    auto clip = [](long long room, long long raw) -> long long { return room <= 0 ? 0 : (room < raw ? room : raw); };
+    // mass of the first n candidates; the cut bin of the first L: prefix P < L <= P + count
+    double msum = 0.0;
+    {
+        long long run = before;
+        for (int q = 0; q < 64; ++q) {
+            const long long raw = bin(q);
+            const long long c   = clip(n - run, raw);
+            if (c) {
+                msum += wbin(tid * 64 + q) * (double)c;
+            }
+            if (raw && run < L && L <= run + raw) {
+                s_i[1] = tid * 64 + q;
+                s_i[2] = (int)run;
+            }
+            run += raw;
+        }
+    }
+    double S;
+    (void)block_exclusive_scan<double>(msum, s_d, &S);
+    const bool ok   = L > 0 && S > 0.0 && S < 1e300 && __builtin_fabsf(vmax) <= 65504.f;
+    const int  jc   = s_i[1];            // descending index of the cut bin
+    const int  nA   = s_i[2];            // candidates in strictly better bins (< L <= 1024)
+    const int  nB   = (int)L - nA;       // candidates taken from the cut bin, lowest ids first
+    auto lp_of = [&](int dbin) -> float { return logf((float)(wbin(dbin) / S)); };
+    for (int q = 0; q < 64; ++q) {       // every thread has read its bins for the last time
+        h[kBins - 1 - (tid * 64 + q)] = 0u;
+    }
+    s_a[tid] = ~0ull;
+    if (!ok) {
+        if (tid == 0 && rec) {
+            out_num[row] = 0;
+            out_sel[row] = 0.f;
+        }
+        return;
+    }
+    const uint16_t* lrow  = (const uint16_t*)(logits + (size_t)b * ld);
+    const int       per   = (V + 1023) / 1024;
+    const int       begin = tid * per;
+    const int       end   = min(begin + per, V);
+    long long cnt = 0;                   // (A count << 32) | B count of my id range
+    for (int i = begin; i < end; ++i) {
+        const int dbin = kBins - 1 - (int)key_of(lrow[i]);
+        cnt += dbin < jc ? (1ll << 32) : (dbin == jc ? 1ll : 0ll);
+    }
+    long long tot;
+    const long long prior = block_exclusive_scan<long long>(cnt, s_l, &tot);
+    int pa = (int)(prior >> 32), pb = (int)(prior & 0xffffffffll);
+    float*  vals = out_vals + row * (size_t)cap;
+    int*    idx  = out_idx + row * (size_t)cap;
+    for (int i = begin; i < end; ++i) {
+        const int dbin = kBins - 1 - (int)key_of(lrow[i]);
+        bool      in   = false;
+        if (dbin < jc) {
+            s_a[pa++] = ((unsigned long long)dbin << 32) | (uint32_t)i;
+            in        = true;
+        }
+        else if (dbin == jc) {
+            if (pb < nB) {
+                if (rec) {
+                    vals[nA + pb] = lp_of(dbin);
+                    idx[nA + pb]  = i;
+                }
+                in = true;
+            }
+            ++pb;
+        }
+        if (i == sel) {
+            s_i[3] = in ? 1 : 0;
+            if (rec) {
+                out_sel[row] = lp_of(dbin);
+            }
+        }
+    }
+    __syncthreads();
+    // bitonic sort of the strictly-better list by (descending bin index, id): 1024 slots, unused = ~0
+    for (int k = 2; k <= 1024; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            const int partner = tid ^ j;
+            if (partner > tid) {
+                const unsigned long long x = s_a[tid], y = s_a[partner];
+                const bool up = (tid & k) == 0;
+                if ((x > y) == up) {
+                    s_a[tid]     = y;
+                    s_a[partner] = x;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    if (rec) {
+        if (tid < nA) {
+            const unsigned long long e = s_a[tid];
+            vals[tid] = lp_of((int)(e >> 32));
+            idx[tid]  = (int)(uint32_t)e;
+        }
+        if (tid == 0) {
+            out_num[row] = (int)L;
+            if (s_i[3] < 0) {            // a drawn id outside the row (cannot happen behind sample_select_kernel)
+                out_sel[row] = 0.f;
+            }
+        }
+    }
+    if (rec && force_last && n > cap && s_i[3] == 0) {
+        __syncthreads();                 // entry cap - 1 was written above by another thread
+        if (tid == 0 && sel >= 0 && sel < V) {
+            vals[cap - 1] = lp_of(kBins - 1 - (int)key_of(lrow[sel]));
+            idx[cap - 1]  = sel;
+        }
+    }
+}
+
 // Philox4x32-10 (Salmon et al., SC'11): counter = (ctr, 0, 0, 0), key = seed; u = top 24 bits / 2^24 in [0, 1)
 __host__ __device__ inline float philox_uniform(uint64_t seed, uint32_t ctr)
 {
@@ -401,12 +578,17 @@ int launch_sample_uniform(float* u, const uint64_t* seeds, const int* counters, 
 }
 
 // workspace: batch * 65536 uint32, ZERO on entry (the kernel leaves it zero again)
+// lp != nullptr: the kept candidates' logprobs as well (sample_logprobs_kernel); kept_out must then be given
 int launch_sample(int* out_ids, int* kept_out, const half_t* logits, int batch, int V, int ld, const float* temperature,
                   const int* top_k, const float* top_p, const float* min_p, const float* uniform, void* workspace,
-                  hipStream_t st)
+                  hipStream_t st, const SampleLogprobs* lp)
 {
     TM_REQUIRE(out_ids && logits && workspace, "null pointer");
     TM_REQUIRE(V >= 1 && ld >= V && ld % 8 == 0, "sampling: ld must be a multiple of 8 and >= vocab");
+    if (lp) {
+        TM_REQUIRE(kept_out && lp->vals && lp->idx && lp->num && lp->sel, "sampling logprobs: null pointer");
+        TM_REQUIRE(lp->cap >= 1 && lp->cap <= kMaxLogProb, "sampling logprobs: 1 <= cap <= 1024");
+    }
     if (batch == 0) {
         return 0;
     }
@@ -414,8 +596,14 @@ int launch_sample(int* out_ids, int* kept_out, const half_t* logits, int batch, 
     sample_hist_kernel<<<dim3(chunks, batch), 256, 0, st>>>((uint32_t*)workspace, logits, V, ld);
     TM_HIP_CHECK(hipGetLastError());
     sample_select_kernel<<<batch, 1024, 0, st>>>(out_ids, (uint32_t*)workspace, logits, V, ld, temperature, top_k, top_p,
-                                                 min_p, uniform, kept_out);
+                                                 min_p, uniform, kept_out, lp ? 1 : 0);
     TM_HIP_CHECK(hipGetLastError());
+    if (lp) {
+        sample_logprobs_kernel<<<batch, 1024, 0, st>>>(lp->vals, lp->idx, lp->num, lp->sel, lp->cap, lp->cap == kMaxLogProb,
+                                                       (uint32_t*)workspace, logits, V, ld, temperature, kept_out, out_ids,
+                                                       lp->step, lp->step_stride, lp->row_stride, lp->row0, lp->max_steps);
+        TM_HIP_CHECK(hipGetLastError());
+    }
     return 0;
 }
 

@@ -258,9 +258,21 @@ int launch_p2p_allgather(half_t* const* data, uint32_t* const* flags, int tp, in
 
 // sampling.hip: temperature / top-k / top-p / min-p sampling without a sort (see the file header)
 size_t sample_workspace_bytes(int batch);
+// logprobs of the kept candidates next to the draw (sample_logprobs_kernel): record r = (*step) * step_stride + (row0 + b) * row_stride
+// of vals / idx ([records][cap]), num / sel ([records]); step == nullptr: 0; records of steps >= max_steps are dropped
+constexpr int kMaxLogProb = 1024;  // = TM_MAX_LOGPROBS (src/turbomind/utils/constant.h:7)
+struct SampleLogprobs {
+    float*     vals;
+    int*       idx;
+    int*       num;
+    float*     sel;
+    int        cap;
+    const int* step;
+    int        step_stride, row_stride, row0, max_steps;
+};
 int    launch_sample(int* out_ids, int* kept_out, const half_t* logits, int batch, int V, int ld, const float* temperature,
                      const int* top_k, const float* top_p, const float* min_p, const float* uniform, void* workspace,
-                     hipStream_t st);
+                     hipStream_t st, const SampleLogprobs* lp = nullptr);
 int    launch_sample_uniform(float* u, const uint64_t* seeds, const int* counters, int batch, hipStream_t st);
 float  philox_uniform_host(uint64_t seed, uint32_t ctr);
 

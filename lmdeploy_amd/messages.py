@@ -37,6 +37,8 @@ class ResponseType(enum.Enum):
     OUT_OF_MEMORY = enum.auto()
 
 
+MAX_LOGPROBS = 1024     # lmdeploy/turbomind/turbomind.py:45 = kMaxLogProb (src/turbomind/utils/constant.h:7)
+
 # native status code (src/turbomind/engine/request.h:120-131) -> ResponseType (lmdeploy/turbomind/turbomind.py:587-599)
 STATUS_TO_RESPONSE = {
     0: ResponseType.SUCCESS, 1: ResponseType.INTERNAL_ENGINE_ERROR, 2: ResponseType.PREFIX_CACHE_CONFLICT,
@@ -90,7 +92,7 @@ class GenerationConfig:
         assert self.temperature >= 0 and self.temperature <= 2
         assert 0 <= self.min_p <= 1
         assert self.repetition_penalty > 0, 'repetition_penalty must be > 0'
-        unsupported = {'n': 1, 'logprobs': None, 'response_format': None, 'logits_processors': None,
+        unsupported = {'n': 1, 'response_format': None, 'logits_processors': None,
                        'output_logits': None, 'output_last_hidden_state': None, 'return_ppl': False, 'with_cache': False,
                        'preserve_cache': False, 'migration_request': None, 'return_routed_experts': False,
                        'repetition_ngram_size': 0, 'repetition_ngram_threshold': 0}
@@ -100,7 +102,13 @@ class GenerationConfig:
             if getattr(self, k) != default:
                 raise NotImplementedError(f'GenerationConfig.{k}={getattr(self, k)!r}: the MI355X hot path implements '
                                           f'greedy decoding, temperature / top-k / top-p / min-p sampling, repetition '
-                                          f'penalty, min_new_tokens, bad_token_ids and stop_token_ids only')
+                                          f'penalty, min_new_tokens, bad_token_ids, stop_token_ids and logprobs only')
+        if self.logprobs is not None:
+            assert isinstance(self.logprobs, int) and self.logprobs >= 0, 'logprobs must be a non-negative integer'
+            if self.logprobs > MAX_LOGPROBS:      # the reference clamps with a warning (lmdeploy/turbomind/turbomind.py:840-845)
+                import warnings
+                warnings.warn(f'logprobs should be in range [1, {MAX_LOGPROBS}]: update logprobs={MAX_LOGPROBS}')
+                self.logprobs = MAX_LOGPROBS
 
 
     def convert_stop_bad_words_to_ids(self, tokenizer):

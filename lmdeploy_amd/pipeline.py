@@ -34,6 +34,16 @@ SYNTHETIC = {
 }
 
 
+def logprobs_of_token(vals, idx, num: int, sel: float, token: int, topn: int) -> dict:
+    """One generated token's entry of Response.logprobs, the reference's rule (lmdeploy/turbomind/turbomind.py:472-503): the first
+    min(num, topn) kept candidates as {token id: logprob}, the generated token itself added when it is not among them, -inf dropped."""
+    n = min(num, topn)
+    res = {int(i): float(v) for i, v in zip(idx[:n], vals[:n])}
+    if token not in res:
+        res[int(token)] = sel
+    return {k: v for k, v in res.items() if v != float('-inf')}
+
+
 class Pipeline:
 
     def __init__(self, model_path: str, backend_config: TurbomindEngineConfig | None = None, rank: int = 0,
@@ -175,6 +185,9 @@ class Pipeline:
             yield from sorted(self.generate_continuous(prompts, g), key=lambda r: r.index)
             return
         self._resolve_words(g)
+        if g.logprobs:                              # the logprob records live with the static batch (tm_engine_set_logprobs)
+            yield from self._generate_static(prompts, g)
+            return
         if len(prompts) > self.max_batch_size:      # more work than batch slots: let the engine schedule it
             yield from sorted(self.generate_continuous(prompts, g), key=lambda r: r.index)
             return
@@ -191,6 +204,9 @@ class Pipeline:
             gs = [gi or GenerationConfig() for gi in g]
         else:
             gs = [g or GenerationConfig()] * len(ids)
+        if any(gi.logprobs for gi in gs):
+            raise NotImplementedError('GenerationConfig.logprobs with streaming or per-request generation configs: the logprob records are '
+                                      'kept by the static batch path (one GenerationConfig for all prompts, infer / __call__)')
         stops = []
         pending, out_of_engine, sent = {}, [], {}
         for i, p in enumerate(ids):
@@ -282,6 +298,7 @@ class Pipeline:
                 self.engine.set_sampling([g.sampling_params(i) for i in idx] if g.sampling_params() else None)
                 lp = g.logits_params(sorted(stop)[:_ffi.MAX_STOP_IDS])
                 self.engine.set_logits_params([lp] * len(chunk) if lp else None)
+                self.engine.set_logprobs(g.logprobs or 0)
                 self.engine.prefill(chunk, max_new_tokens=max_new)
                 done = 1
                 while done < max_new:
@@ -293,6 +310,7 @@ class Pipeline:
                         if all(any(int(t) in stop for t in row) for row in toks):
                             break
                 toks = self.engine.fetch()
+                records = self.engine.fetch_logprobs() if g.logprobs else None
             except _ffi.TmError as e:
                 self.engine.release()
                 rt = STATUS_TO_RESPONSE.get(e.status, ResponseType.INTERNAL_ENGINE_ERROR)
@@ -300,7 +318,7 @@ class Pipeline:
                     yield Response('', 0, len(p), 'error', [], index=i, error_code=rt.name, error_message=str(e))
                 continue
             self.engine.release()
-            for i, p, row in zip(idx, chunk, toks):
+            for b, (i, p, row) in enumerate(zip(idx, chunk, toks)):
                 out, reason = [], 'length'
                 for tkn in row.tolist():
                     if tkn in stop:
@@ -308,4 +326,8 @@ class Pipeline:
                         break
                     out.append(tkn)
                 text = self.tokenizer.decode(out, skip_special_tokens=g.skip_special_tokens) if self.tokenizer else ''
-                yield Response(text, len(out), len(p), reason, out, index=i)
+                lps = None
+                if records is not None:
+                    lps = [logprobs_of_token(records[0][b, s], records[1][b, s], int(records[2][b, s]), float(records[3][b, s]), tkn,
+                                             g.logprobs) for s, tkn in enumerate(out)]
+                yield Response(text, len(out), len(p), reason, out, logprobs=lps, index=i)

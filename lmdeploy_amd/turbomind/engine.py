@@ -156,6 +156,25 @@ class Engine:
         arr = (_ffi.LogitsParam * len(items))(*items)
         _ffi.check(self._lib.tm_engine_set_logits_params(self._h, arr, len(items)))
 
+    def set_logprobs(self, n: int):
+        """Static batch: the NEXT prefill records the first n kept candidates (and the drawn token's own logprob) of every
+        generated token (GenerationConfig.logprobs; 0 / None = off)."""
+        _ffi.check(self._lib.tm_engine_set_logprobs(self._h, int(n or 0)))
+        self._logprobs_n = int(n or 0)
+
+    def fetch_logprobs(self):
+        """(vals [batch, max_new, n] float32, idx [batch, max_new, n] int32, num [batch, max_new] int32, sel [batch, max_new]
+        float32): the records of tm_engine_set_logprobs; columns beyond the generated steps have num = 0."""
+        n = getattr(self, '_logprobs_n', 0)
+        if n < 1:
+            raise ValueError('no logprobs were requested (set_logprobs before prefill)')
+        vals = np.zeros((self.batch, self.max_new, n), np.float32)
+        idx = np.zeros((self.batch, self.max_new, n), np.int32)
+        num = np.zeros((self.batch, self.max_new), np.int32)
+        sel = np.zeros((self.batch, self.max_new), np.float32)
+        _ffi.check(self._lib.tm_engine_fetch_logprobs(self._h, vals.ctypes.data, idx.ctypes.data, num.ctypes.data, sel.ctypes.data))
+        return vals, idx, num, sel
+
     def prefill(self, prompts: Sequence[Sequence[int]], max_new_tokens: int):
         lens = np.asarray([len(p) for p in prompts], np.int32)
         ids = np.concatenate([np.asarray(p, np.int32) for p in prompts]).astype(np.int32)

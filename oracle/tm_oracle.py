@@ -908,6 +908,30 @@ def sample_filter(logits: np.ndarray, temperature: float = 1.0, top_k: int = 0, 
     return cand[:kept], p[:kept] / ksum
 
 
+def sample_logprobs(ids: np.ndarray, probs: np.ndarray, selected: int, cap: int = 1024):
+    """The `sampled_logprobs / sampled_indexes / sampled_nums` outputs of the reference's sampling kernel
+    (kernels/sampling_kernels.cu:67-90; kMaxLogProb = 1024, utils/constant.h:7) for one row whose kept candidates are
+    (ids, probs) = sample_filter(...): the first min(n, cap) candidates with logf(p); with cap == 1024 a drawn token at
+    position >= 1024 replaces entry 1023 (:76-81).  Returns (token ids, float32 logprobs, logprob of `selected`)."""
+    n = min(len(ids), cap)
+    with np.errstate(divide='ignore'):
+        lp = np.log(np.asarray(probs, np.float64).astype(np.float32)).astype(np.float32)
+    out_ids, out_lp = np.asarray(ids[:n]).copy(), lp[:n].copy()
+    pos = int(np.flatnonzero(np.asarray(ids) == selected)[0])
+    if cap == 1024 and len(ids) > cap and pos >= cap:
+        out_ids[cap - 1], out_lp[cap - 1] = selected, lp[pos]
+    return out_ids, out_lp, lp[pos]
+
+
+def logprobs_view(ids, lps, sel_lp, token: int, topn: int) -> dict:
+    """What the Python side makes of one generated token's record (lmdeploy/turbomind/turbomind.py:472-503): the first
+    min(n, topn) candidates as {token id: logprob}, the generated token added when it is not among them, -inf entries dropped."""
+    res = {int(i): float(v) for i, v in zip(ids[:topn], lps[:topn])}
+    if token not in res:
+        res[int(token)] = float(sel_lp)
+    return {k: v for k, v in res.items() if v != float('-inf')}
+
+
 def sample_draw(ids: np.ndarray, probs: np.ndarray, u: float) -> int:
     """first candidate whose inclusive prefix sum exceeds u, else the last one (sampling_kernels.cu:46-63)"""
     cum = np.cumsum(probs)

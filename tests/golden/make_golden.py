@@ -98,6 +98,7 @@ def main():
     logits_process_golden()
     more_golden(wf)
     api_fields_golden()
+    logprobs_view_golden()
 
 
 def more_golden(wf):
@@ -227,6 +228,41 @@ def logits_process_golden():
                         penalty=penalty.numpy(), penalised_fp32=scores.numpy(), bad=bad.numpy(),
                         banned_mask=torch.isinf(banned).numpy())
     print('wrote', os.path.join(OUT, 'reference_logits_process.npz'))
+
+
+def logprobs_view_golden():
+    """reference_logprobs_view.json: lmdeploy/turbomind/turbomind.py:472-503 (_get_logprobs_impl) -- how the Python side turns the
+    engine's (logprob_vals, logprob_indexes, logprob_nums) buffers into Response.logprobs.  The module cannot be imported here
+    (_turbomind, mmengine), so the one leaf function is taken out of the file with `ast` and executed as it stands; only its inputs
+    and outputs are committed."""
+    import ast
+    import json
+    tree = ast.parse(open(f'{REF}/lmdeploy/turbomind/turbomind.py').read())
+    fn = next(n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == '_get_logprobs_impl')
+    ns = {'torch': torch}
+    exec(compile(ast.Module([fn], []), 'turbomind.py:_get_logprobs_impl', 'exec'), ns)
+    g = torch.Generator().manual_seed(5)
+    T, W, V = 6, 1024, 5000
+    cases = []
+    for topn, offset in ((1, 0), (5, 0), (3, 2), (1024, 1)):
+        idx = torch.stack([torch.randperm(V, generator=g)[:W] for _ in range(T)]).int()
+        vals = -torch.rand(T, W, generator=g).sort(dim=-1).values * 9
+        nums = torch.tensor([1, 3, 40, 1024, 7, 2])
+        vals[2, 1] = float('-inf')                      # a zero-probability candidate inside the top-n is dropped
+        n_out = T - offset
+        toks = []
+        for t in range(offset, T):
+            n = int(nums[t])
+            pick = 0 if t % 2 == 0 else n - 1           # the generated token: the best candidate / the last kept one
+            toks.append(int(idx[t, pick]))
+        got = ns['_get_logprobs_impl'](vals, idx, nums, toks, topn, offset)
+        cases.append(dict(topn=topn, offset=offset, tokens=toks, nums=nums.tolist(),
+                          idx=[idx[t, :int(nums[t])].tolist() for t in range(T)],
+                          vals=[[float(v) if v != float('-inf') else '-inf' for v in vals[t, :int(nums[t])].tolist()] for t in range(T)],
+                          expect=[[[int(k), float(v)] for k, v in d.items()] for d in got]))
+        assert len(got) == n_out
+    json.dump(cases, open(os.path.join(OUT, 'reference_logprobs_view.json'), 'w'))
+    print('wrote', os.path.join(OUT, 'reference_logprobs_view.json'), len(cases), 'cases')
 
 
 if __name__ == '__main__':

@@ -727,6 +727,74 @@ def test_engine_sampling_static_and_continuous(cuda):
     assert g[1, 0] == toks[1, 0]
 
 
+def test_engine_logprobs_static_batch(cuda):
+    """GenerationConfig.logprobs inside the engine (tm_engine_set_logprobs): for every generated token of a mixed batch -- two
+    stochastic sequences and a greedy one -- the record of (sequence, step) must be what the oracle makes of the engine's own logits
+    of that step (sample_filter -> sample_logprobs): candidate ids exact, logprobs within 1e-5, the drawn token's logprob; the tokens
+    themselves must not change when logprobs are switched on; eager first step, captured graph afterwards; a second batch with another
+    count re-captures; the pipeline hands the reference's dictionaries out."""
+    cfg = o.ModelConfig(hidden=256, layers=2, q_heads=4, kv_heads=2, head_dim=128, inter=512, vocab=1024,
+                        kv_bits=8, rope=o.RopeParam(128, 500000.0, 'llama3', 8.0, 1.0, 4.0, 8192))
+    w = o.make_synthetic_weights(cfg, seed=21)
+    rng = np.random.default_rng(2)
+    prompts = [rng.integers(0, cfg.vocab, n).astype(np.int32) for n in (12, 70, 7)]
+    params = [(0.9, 30, 0.95, 0.0, 111), None, (1.4, 0, 0.8, 0.02, 222)]          # row 1 stays greedy
+    steps = 6
+    eng = Engine.from_model_config(cfg, max_batch_size=3, session_len=128, quant_policy=8, max_prefill_token_num=64)   # two prefill iterations
+    eng.load_weights(export_weights(cfg, w))
+    eng.start()
+
+    def run(n_lp):
+        eng.set_sampling(params)
+        eng.set_logprobs(n_lp)
+        eng.prefill(prompts, max_new_tokens=steps + 2)
+        logits = [eng.fetch_logits()]
+        for _ in range(steps - 1):
+            eng.decode(1)
+            logits.append(eng.fetch_logits())
+        toks = eng.fetch().copy()
+        rec = eng.fetch_logprobs() if n_lp else None
+        eng.release()
+        return toks, logits, rec
+
+    plain, _, _ = run(0)
+    for n_lp in (4, 1024, 2):
+        toks, logits, (vals, idx, num, sel) = run(n_lp)
+        assert np.array_equal(toks, plain), 'switching logprobs on changed the tokens'
+        assert vals.shape == (3, steps + 2, n_lp) and np.all(num[:, steps:] == 0)
+        for b, p in enumerate(params):
+            for s_ in range(steps):
+                row = logits[s_][b]
+                ids, pr = o.sample_filter(row, *(p[:4] if p else (1.0, 1, 1.0, 0.0)))
+                e_ids, e_lp, e_sel = o.sample_logprobs(ids, pr, int(toks[b, s_]), n_lp)
+                n = len(e_ids)
+                assert num[b, s_] == n, f'n={n_lp} seq {b} step {s_}: {num[b, s_]} vs {n}'
+                assert np.array_equal(idx[b, s_, :n], e_ids), f'n={n_lp} seq {b} step {s_}'
+                fin = np.isfinite(e_lp)
+                assert np.array_equal(np.isfinite(vals[b, s_, :n]), fin)
+                assert np.all(np.abs(vals[b, s_, :n][fin] - e_lp[fin]) <= 1e-5 + 1e-6 * np.abs(e_lp[fin]))
+                assert abs(sel[b, s_] - e_sel) <= 1e-5 + 1e-6 * abs(e_sel)
+                if p is None:
+                    assert n == 1 and vals[b, s_, 0] == 0.0 and idx[b, s_, 0] == toks[b, s_]
+    with pytest.raises(_ffi.TmError):
+        eng.set_logprobs(1025)
+    eng.close()
+    # the pipeline surface: greedy -> every token's dictionary is {token: 0.0}; sampling -> the token is in its dictionary, at most n + 1 entries
+    import lmdeploy_amd
+    pipe = lmdeploy_amd.pipeline('synthetic:tiny', backend_config=lmdeploy_amd.TurbomindEngineConfig(quant_policy=8, session_len=128,
+                                                                                                      max_batch_size=2))
+    ps = [list(range(5, 40)), list(range(100, 103)), list(range(7, 30))]
+    res = pipe(ps, lmdeploy_amd.GenerationConfig(max_new_tokens=5, ignore_eos=True, logprobs=3))
+    assert all(r.logprobs == [{t: 0.0} for t in r.token_ids] and r.generate_token_len == 5 for r in res)
+    res = pipe(ps, lmdeploy_amd.GenerationConfig(max_new_tokens=5, ignore_eos=True, logprobs=3, do_sample=True, top_k=50, temperature=1.5,
+                                                 random_seed=5))
+    for r in res:
+        assert len(r.logprobs) == 5
+        for t, d in zip(r.token_ids, r.logprobs):
+            assert t in d and 3 <= len(d) <= 4 and all(v <= 0.0 for v in d.values())
+    pipe.close()
+
+
 @pytest.mark.parametrize('q_heads,kv_heads,kv_bits,hidden', [(6, 1, 8, 384), (8, 1, 4, 512), (12, 2, 16, 256)])
 def test_engine_other_config_shapes(cuda, q_heads, kv_heads, kv_bits, hidden):
     """BASELINE.json configs 2-4 scaled down: GQA group 6 with int8 KV (InternLM2-20B: 48 q / 8 kv heads), one kv head

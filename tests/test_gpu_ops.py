@@ -870,6 +870,64 @@ def test_sampling_matches_oracle(tm, cuda, V, ld):
     assert not ws.any()
 
 
+@pytest.mark.parametrize('V,ld,cap', [(1000, 1000, 1024), (4099, 4104, 1024), (4099, 4104, 5), (128256, 128256, 1024), (128256, 128256, 20)])
+def test_sampling_logprobs_match_oracle(tm, cuda, V, ld, cap):
+    """tm_sample_logprobs = tm_sample + the kept candidates' logprobs (sampling_kernels.cu:67-90): same draw and kept count as
+    tm_sample; the first min(kept, cap) candidates come out in sampling order (token ids EXACT, ties by id included), their logprobs
+    = logf(renormalised probability) within 1e-5 (absolute, or relative for large magnitudes; -inf where the probability is 0), the
+    drawn token's own logprob, and -- in the reference's layout (cap = 1024) -- a drawn token beyond the first 1024 candidates in
+    entry 1023.  The workspace is left zeroed."""
+    rng = np.random.default_rng(V + cap)
+    rows = [dict(), dict(top_k=1), dict(top_k=40), dict(top_k=40, top_p=0.8), dict(top_p=0.9), dict(top_p=0.3, temperature=0.7),
+            dict(min_p=0.05), dict(top_k=2000, top_p=0.999, temperature=1.3), dict(top_p=0.0), dict(top_k=V + 5),
+            dict(temperature=0.01), dict(top_p=0.999, temperature=2.0), dict(top_k=1500, temperature=4.0)]
+    B = len(rows)
+    logits = (rng.standard_normal((B, ld)) * 2.5).astype(f16)
+    logits[:, ::3] = np.round(logits[:, ::3].astype(np.float32) * 4).astype(f16) / f16(4)       # lots of exact ties
+    logits[:, 5:50:7] = f16(-np.inf)
+    logits[2, :] = f16(1.5)                                                                       # a completely flat row
+    logits[9, 100:] = f16(0.25)                                                                   # one huge tie across the cap
+    if ld > V:
+        logits[:, V:] = f16(100.0)
+    u = rng.random(B).astype(np.float32)
+    u[0], u[4], u[9], u[12] = 0.0, np.float32(1.0 - 2.0**-24), 0.97, 0.999                        # rows 9 / 12: a draw deep in the tail
+    arr = lambda k, d, t: np.asarray([r.get(k, d) for r in rows], t)
+    temp, topk, topp, minp = arr('temperature', 1.0, np.float32), arr('top_k', 0, np.int32), arr('top_p', 1.0, np.float32), arr('min_p', 0.0, np.float32)
+    ws = torch.zeros(tm.tm_sample_workspace(B), dtype=torch.uint8, device='cuda')
+    out, kept = torch.full((B,), -1, dtype=torch.int32, device='cuda'), torch.zeros(B, dtype=torch.int32, device='cuda')
+    out0, kept0 = torch.full((B,), -1, dtype=torch.int32, device='cuda'), torch.zeros(B, dtype=torch.int32, device='cuda')
+    vals = torch.full((B, cap), 7.0, dtype=torch.float32, device='cuda')
+    idx = torch.full((B, cap), -5, dtype=torch.int32, device='cuda')
+    num = torch.full((B,), -1, dtype=torch.int32, device='cuda')
+    sel = torch.full((B,), 7.0, dtype=torch.float32, device='cuda')
+    dl = dev(logits)
+    args = (dl.data_ptr(), B, V, ld, dev(temp).data_ptr(), dev(topk).data_ptr(), dev(topp).data_ptr(), dev(minp).data_ptr(),
+            dev(u).data_ptr(), ws.data_ptr(), st())
+    _ffi.check(tm.tm_sample(out0.data_ptr(), kept0.data_ptr(), *args))
+    tail_draws = 0
+    for rep in range(2):
+        _ffi.check(tm.tm_sample_logprobs(out.data_ptr(), kept.data_ptr(), vals.data_ptr(), idx.data_ptr(), num.data_ptr(), sel.data_ptr(),
+                                         cap, *args))
+        assert np.array_equal(host(out), host(out0)) and np.array_equal(host(kept), host(kept0))
+        g_vals, g_idx, g_num, g_sel, g_out = host(vals), host(idx), host(num), host(sel), host(out)
+        for b, r in enumerate(rows):
+            ids, p = o.sample_filter(logits[b, :V], float(temp[b]), int(topk[b]), float(topp[b]), float(minp[b]))
+            e_ids, e_lp, e_sel = o.sample_logprobs(ids, p, int(g_out[b]), cap)
+            n = len(e_ids)
+            assert g_num[b] == n == min(len(ids), cap), f'row {b} {r}: num {g_num[b]} vs {n}'
+            assert np.array_equal(g_idx[b, :n], e_ids), f'row {b} {r}: candidate order'
+            fin = np.isfinite(e_lp)
+            assert np.array_equal(np.isfinite(g_vals[b, :n]), fin) and np.all(g_vals[b, :n][~fin] == -np.inf), f'row {b} {r}'
+            assert np.all(np.abs(g_vals[b, :n][fin] - e_lp[fin]) <= 1e-5 + 1e-6 * np.abs(e_lp[fin])), f'row {b} {r}'
+            assert abs(g_sel[b] - e_sel) <= 1e-5 + 1e-6 * abs(e_sel) or (g_sel[b] == e_sel), f'row {b} {r}: drawn token'
+            assert np.all(g_idx[b, n:] == -5) and np.all(g_vals[b, n:] == 7.0), 'entries beyond num must stay untouched'
+            pos = int(np.flatnonzero(ids == g_out[b])[0])
+            tail_draws += pos >= cap
+    if V > 1024:
+        assert tail_draws > 0, 'no row drew a token beyond the cap: the forced-last / sel path was not exercised'
+    assert not ws.any()
+
+
 def test_sampling_degenerate_rows_get_a_defined_token(tm, cuda):
     """Rows whose logits do not form a distribution (all NaN, a +inf maximum, all -inf) must still produce a DEFINED
     token -- the arg-max over the finite logits, lowest id on ties, token 0 when nothing is finite -- not the previous

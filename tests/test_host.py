@@ -506,8 +506,9 @@ def test_api_surface_and_validation():
     assert (lp.n_bad_ids, lp.bad_ids[1], lp.n_stop_ids, lp.stop_ids[0], lp.min_new_tokens) == (2, 9, 1, 2, 3)
     with pytest.raises(ValueError):
         _ffi.LogitsParam.make(bad_ids=list(range(40)))
+    assert GenerationConfig(logprobs=3).logprobs == 3            # round 6: served (tm_engine_set_logprobs)
     with pytest.raises(NotImplementedError):
-        GenerationConfig(logprobs=3)
+        GenerationConfig(output_logits='all')
 
     class Tok:          # a tiny HF-like tokenizer: one token per known word
         vocab = {'<s>': 0, 'foo': 1, '\u2581foo': 2, 'food': 3, 'bar': 4, '\u2581': 5, 'a\u2581': 6, 'x': 7}

@@ -420,3 +420,42 @@ def test_cpu_baseline_config0_runs_on_a_tiny_model():
     r = cpu_baseline.run_config0(tiny, batch=2, ctx=16, steps=2, threads=2, budget_s=5.0)
     assert r['value'] > 0 and np.isfinite(r['value']) and r['kind'] == 'port' and r['cores'] == 2
     assert 'whole model (2 layers' in r['sample'] and 'no extrapolation' in r['sample']
+
+
+def test_logprobs_view_matches_reference_python():
+    """Response.logprobs: oracle.logprobs_view and the product's lmdeploy_amd.pipeline.logprobs_of_token against the outputs of the
+    reference's own _get_logprobs_impl (lmdeploy/turbomind/turbomind.py:472-503), executed on these inputs by tests/golden/make_golden.py."""
+    import json
+    import sys
+    import lmdeploy_amd  # noqa: F401
+    of_token = sys.modules['lmdeploy_amd.pipeline'].logprobs_of_token
+    cases = json.load(open(os.path.join(os.path.dirname(__file__), 'golden', 'reference_logprobs_view.json')))
+    assert len(cases) >= 4
+    for c in cases:
+        for k, tok in enumerate(c['tokens']):
+            t = k + c['offset']
+            idx = np.asarray(c['idx'][t], np.int32)
+            vals = np.asarray([float(v) for v in c['vals'][t]], np.float32)
+            sel = float(vals[np.flatnonzero(idx == tok)[0]])
+            want = {int(a): float(np.float32(b)) for a, b in c['expect'][k]}
+            assert o.logprobs_view(idx, vals, sel, tok, c['topn']) == want
+            assert of_token(vals, idx, int(c['nums'][t]), sel, tok, c['topn']) == want
+
+
+def test_sample_logprobs_semantics():
+    """oracle.sample_logprobs restates sampling_kernels.cu:67-90: min(n, cap) entries of logf(p) in sampling order; only in the
+    reference's 1024-entry layout does a drawn token beyond the buffer replace the last entry."""
+    rng = np.random.default_rng(0)
+    logits = (rng.standard_normal(3000) * 2).astype(np.float16)
+    ids, p = o.sample_filter(logits, 1.0, 0, 1.0, 0.0)
+    assert len(ids) == 3000 and abs(p.sum() - 1) < 1e-9
+    deep = int(ids[2000])
+    e_ids, e_lp, e_sel = o.sample_logprobs(ids, p, deep, 1024)
+    assert len(e_ids) == 1024 and np.array_equal(e_ids[:1023], ids[:1023]) and e_ids[1023] == deep
+    assert e_lp[1023] == e_sel == np.float32(np.log(np.float32(p[2000])))
+    e_ids, e_lp, e_sel = o.sample_logprobs(ids, p, deep, 8)
+    assert np.array_equal(e_ids, ids[:8]) and e_sel == np.float32(np.log(np.float32(p[2000])))
+    assert np.all(np.diff(e_lp) <= 0)
+    ids1, p1 = o.sample_filter(logits, 1.0, 1, 1.0, 0.0)          # greedy = top_k 1: one candidate with logprob 0
+    e_ids, e_lp, e_sel = o.sample_logprobs(ids1, p1, int(ids1[0]), 1024)
+    assert list(e_ids) == [int(np.argmax(logits.astype(np.float32)))] and e_lp[0] == 0.0 and e_sel == 0.0

@@ -26,7 +26,7 @@ class FakeEngine:
     def __init__(self, max_batch_size, session_len):
         self.B, self.session_len = max_batch_size, session_len
         self.reqs, self.next_id, self.static = {}, 1, None
-        self.sampling, self.logits, self.released = None, None, 0
+        self.sampling, self.logits, self.released, self.logprobs = None, None, 0, 0
         FakeEngine.instances.append(self)
 
     @classmethod
@@ -41,6 +41,23 @@ class FakeEngine:
     # ---- static batch -----------------------------------------------------------------------
     def set_sampling(self, p): self.sampling = p
     def set_logits_params(self, p): self.logits = p
+    def set_logprobs(self, n): self.logprobs = n
+
+    def fetch_logprobs(self):
+        """records like Engine.fetch_logprobs: candidate k of step s = (token + k) % VOCAB with logprob -k - 0.5 s (so the generated token is
+        the best candidate), except every third step, whose generated token is NOT among the first candidates (its logprob is in sel)"""
+        n, B, S = self.logprobs, len(self.static), self.max_new
+        vals, idx = np.zeros((B, S, n), np.float32), np.zeros((B, S, n), np.int32)
+        num, sel = np.zeros((B, S), np.int32), np.zeros((B, S), np.float32)
+        for b, p in enumerate(self.static):
+            for s_ in range(self.done):
+                t = _tok(p, s_)
+                off = 1 if s_ % 3 == 2 else 0
+                idx[b, s_] = [(t + k + off) % VOCAB for k in range(n)]
+                vals[b, s_] = [-k - 0.5 * s_ for k in range(n)]
+                num[b, s_] = max(1, n - (s_ % 2))
+                sel[b, s_] = -9.0 if off else vals[b, s_, 0]
+        return vals, idx, num, sel
 
     def prefill(self, prompts, max_new_tokens):
         assert len(prompts) <= self.B
@@ -56,6 +73,7 @@ class FakeEngine:
 
     def release(self):
         self.static, self.reqs, self.released = None, {}, self.released + 1
+        self.logprobs = 0          # like tm_engine_release
 
     # ---- scheduler --------------------------------------------------------------------------
     def submit(self, prompt, max_new, eos_id=-1, sampling=None, logits=None):
@@ -198,6 +216,33 @@ def test_errors_become_responses_and_processors_reach_the_engine(pipe):
     assert eng.logits == [lp]
     with pytest.raises(NotImplementedError):
         P.Pipeline('synthetic:tiny', backend_config=TurbomindEngineConfig(), chat_template_config=object())
+
+
+def test_logprobs_reach_the_responses(pipe):
+    """GenerationConfig.logprobs: the request runs as a static batch (also with more prompts than slots), the engine is armed with
+    set_logprobs(n), and every generated token gets the reference's dictionary (turbomind.py:472-503): the first min(num, n) candidates,
+    plus the generated token itself when it is not among them; streaming / per-request configs refuse it loudly."""
+    prompts = [[1, 2, 3], [9, 9], [4, 5, 6, 7]]
+    res = pipe(prompts, GenerationConfig(max_new_tokens=6, logprobs=3, ignore_eos=True))
+    eng = FakeEngine.instances[-1]
+    assert [r.index for r in res] == [0, 1, 2]
+    for r, p in zip(res, prompts):
+        assert len(r.logprobs) == r.generate_token_len == 6
+        for s_, (tok, d) in enumerate(zip(r.token_ids, r.logprobs)):
+            n = max(1, 3 - (s_ % 2))
+            if s_ % 3 == 2:
+                assert d == {**{(tok + k + 1) % VOCAB: -k - 0.5 * s_ for k in range(n)}, tok: -9.0}
+            else:
+                assert d == {(tok + k) % VOCAB: -k - 0.5 * s_ for k in range(n)}
+    plain = pipe(prompts, GenerationConfig(max_new_tokens=6, ignore_eos=True))
+    assert eng.logprobs == 0 and all(r.logprobs is None for r in plain)
+    assert [r.token_ids for r in plain] == [r.token_ids for r in res]
+    with pytest.raises(NotImplementedError):
+        list(pipe.stream_infer(prompts, GenerationConfig(max_new_tokens=3, logprobs=2)))
+    with pytest.raises(NotImplementedError):
+        pipe(prompts, [GenerationConfig(max_new_tokens=3, logprobs=2)] * 3)
+    with pytest.warns(UserWarning):
+        assert GenerationConfig(logprobs=5000).logprobs == 1024
 
 
 def test_one_generation_config_per_prompt(pipe):
