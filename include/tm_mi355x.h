@@ -450,6 +450,14 @@ int tm_engine_set_sampling(tm_engine* e, const tm_sampling* host_params, int bat
  * tm_engine_release.  tm_engine_fetch_logprobs copies the records to the host: vals / idx [batch][max_new_tokens][n] (entries beyond
  * num are undefined), num / sel [batch][max_new_tokens] (columns beyond the generated steps: num = 0). */
 int tm_engine_set_logprobs(tm_engine* e, int n);
+/* Continuous batching: the same records for ONE queued request (call right after its submit, before the next scheduler step): every
+ * token the request generates from then on carries its first n kept candidates.  tm_engine_poll_logprobs copies the records of the
+ * first min(max_tokens, generated) tokens: vals / idx [tokens][n] (entries beyond num[t]: 0 / -1), num / sel [tokens]; *n_tokens =
+ * tokens recorded, *n_per_token = n (0: the request did not ask).  The arrays may be NULL to query the counts.  While any request with
+ * logprobs is in the session the decode step does not ride on prefill forwards (no mixed steps). */
+int tm_engine_request_logprobs(tm_engine* e, int64_t req_id, int n);
+int tm_engine_poll_logprobs(tm_engine* e, int64_t req_id, float* host_vals, int* host_idx, int* host_num, float* host_sel, int max_tokens,
+                            int* n_tokens, int* n_per_token);
 int tm_engine_fetch_logprobs(tm_engine* e, float* host_vals, int* host_idx, int* host_num, float* host_sel);
 /* Per-sequence logits processors (GenerationConfig: repetition_penalty, min_new_tokens, bad_token_ids,
  * stop_token_ids; applied in the reference's order, see tm_logits_process).  stop ids end a sequence of the

@@ -177,6 +177,8 @@ _SIGNATURES = {
     'tm_engine_set_logits_params': (c_int, [c_void_p, c_void_p, c_int]),
     'tm_engine_set_logprobs': (c_int, [c_void_p, c_int]),
     'tm_engine_fetch_logprobs': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'tm_engine_request_logprobs': (c_int, [c_void_p, c_int64, c_int]),
+    'tm_engine_poll_logprobs': (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int, POINTER(c_int), POINTER(c_int)]),
     'tm_engine_submit_gen': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, POINTER(c_int64)]),
     'tm_seen_update': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     'tm_logits_process': (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p,

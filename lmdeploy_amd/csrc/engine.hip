@@ -682,6 +682,11 @@ int tm_engine_destroy(tm_engine* e)
         (void)hipEventDestroy(e->ev_aux_join);
     }
     for (int i = 0; i < 2; ++i) {
+        for (void* q : {(void*)e->h_cb_lp_vals[i], (void*)e->h_cb_lp_idx[i], (void*)e->h_cb_lp_num[i], (void*)e->h_cb_lp_sel[i]}) {
+            if (q) {
+                (void)hipHostFree(q);
+            }
+        }
         if (e->h_step_pin[i]) {
             (void)hipHostFree(e->h_step_pin[i]);
             (void)hipEventDestroy(e->ev_step[i]);
@@ -691,7 +696,7 @@ int tm_engine_destroy(tm_engine* e)
                     (void*)e->d_u, (void*)e->d_topk, (void*)e->d_seed, e->d_sample_ws, (void*)e->d_logits_gather, (void*)e->d_logits_full,
                     (void*)e->d_seen, (void*)e->d_lp_rep,
                     (void*)e->d_lp_minlen, (void*)e->d_lp_ban, (void*)e->d_lp_end, (void*)e->d_lpr_vals, (void*)e->d_lpr_idx, (void*)e->d_lpr_num,
-                    (void*)e->d_lpr_sel, (void*)e->d_kept}) {
+                    (void*)e->d_lpr_sel, (void*)e->d_kept, (void*)e->d_cb_lp_vals, (void*)e->d_cb_lp_idx, (void*)e->d_cb_lp_num, (void*)e->d_cb_lp_sel}) {
         if (q) {
             (void)hipFree(q);
         }

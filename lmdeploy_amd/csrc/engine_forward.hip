@@ -583,9 +583,12 @@ int forward(tm_engine* e, const int* d_ids, int M, int nseq, bool decode, int ma
             }
             TM_PROF(P_SAMPLE, TM_TRY(launch_sample_uniform(e->d_u + slot, e->d_seed + slot, k_len, n, st)));
             // static batch with tm_engine_set_logprobs: the kept candidates' logprobs of this step join the record of (slot, step)
-            const bool           lpr = e->logprobs_on && !e->sched;
-            const SampleLogprobs lp{e->d_lpr_vals, e->d_lpr_idx, e->d_lpr_num, e->d_lpr_sel, e->logprobs_n, e->d_step, 1, e->max_new, slot,
-                                    e->max_new};
+            // continuous batching with tm_engine_request_logprobs: the record of (slot, this step), handed to the host behind the step
+            const bool           lpr_cb = e->sched && e->cb_logprobs_on;
+            const bool           lpr    = (e->logprobs_on && !e->sched) || lpr_cb;
+            const SampleLogprobs lp = lpr_cb ? SampleLogprobs{e->d_cb_lp_vals, e->d_cb_lp_idx, e->d_cb_lp_num, e->d_cb_lp_sel, kMaxLogProb, nullptr, 0, 1, slot, 1}
+                                             : SampleLogprobs{e->d_lpr_vals, e->d_lpr_idx, e->d_lpr_num, e->d_lpr_sel, e->logprobs_n, e->d_step, 1, e->max_new,
+                                                              slot, e->max_new};
             TM_PROF(P_SAMPLE, TM_TRY(launch_sample(ids, lpr ? e->d_kept + slot : nullptr, lg, n, V, V, e->d_temp + slot, e->d_topk + slot,
                                                    e->d_topp + slot, e->d_minp + slot, e->d_u + slot, e->d_sample_ws, st, lpr ? &lp : nullptr)));
         }
@@ -943,6 +946,8 @@ int tm_engine_release(tm_engine* e)
     e->sampling_on = false;
     e->logprobs_next = 0;
     e->logprobs_on   = false;
+    e->cb_logprobs_on = false;
+    e->cb_lp_used     = 0;
     e->h_logits.clear();
     e->cb_logits.clear();
     e->logits_on = false;

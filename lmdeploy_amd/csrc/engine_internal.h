@@ -204,6 +204,7 @@ struct tm_engine {
     // TM_ASYNC_STEP=1 switches the overlap on; by default every step is retired by the call that issued it (see cb_enter).
     struct PendingStep {
         bool                 valid = false;
+        bool                 lp    = false;  // the step's logprob records were copied into the pinned buffers of `buf` as well
         int                  buf   = 0;
         std::vector<int64_t> ids;  // request of every slot whose token this step produces (-1: free, parked, prefilled by this step)
     } pending;
@@ -228,6 +229,13 @@ struct tm_engine {
     float *d_lpr_vals = nullptr, *d_lpr_sel = nullptr;
     int *  d_lpr_idx = nullptr, *d_lpr_num = nullptr, *d_kept = nullptr;
     size_t lpr_records = 0, lpr_entries = 0;  // allocated records / records x cap
+    // continuous batching (tm_engine_request_logprobs): the record of the CURRENT step per batch slot, [max_batch][kMaxLogProb] on the
+    // device, copied behind every step into the pinned buffer of the step's parity (first cb_lp_used columns) and appended to the
+    // requests that asked for logprobs when the step is retired
+    bool   cb_logprobs_on = false, graph_cb_logprobs = false;
+    int    cb_lp_used = 0;
+    float *d_cb_lp_vals = nullptr, *d_cb_lp_sel = nullptr, *h_cb_lp_vals[2] = {nullptr, nullptr}, *h_cb_lp_sel[2] = {nullptr, nullptr};
+    int *  d_cb_lp_idx = nullptr, *d_cb_lp_num = nullptr, *h_cb_lp_idx[2] = {nullptr, nullptr}, *h_cb_lp_num[2] = {nullptr, nullptr};
     std::vector<tm_sampling>       h_sampling;      // static batch: parameters of the next prefill
     std::map<int64_t, tm_sampling> cb_sampling;     // continuous batching: per request
 

@@ -166,6 +166,18 @@ static int cb_prefill_admitted(tm_engine* e, const std::vector<SchedAdmit>& admi
         }
         // decode state of the new slots: context length, current token; first tokens go to the host
         std::vector<int> first(n), ones(n, 1);
+        std::vector<float> lp_vals, lp_sel;
+        std::vector<int>   lp_idx, lp_num;
+        const int          lpw = e->cb_logprobs_on ? e->cb_lp_used : 0;  // the first tokens' logprob records (written by the prefill's head)
+        if (lpw > 0) {
+            lp_vals.resize((size_t)n * lpw), lp_idx.resize((size_t)n * lpw), lp_num.resize(n), lp_sel.resize(n);
+            TM_HIP_CHECK(hipMemcpy2DAsync(lp_vals.data(), (size_t)lpw * 4, e->d_cb_lp_vals + (size_t)slot0 * kMaxLogProb, (size_t)kMaxLogProb * 4,
+                                          (size_t)lpw * 4, n, hipMemcpyDeviceToHost, e->stream));
+            TM_HIP_CHECK(hipMemcpy2DAsync(lp_idx.data(), (size_t)lpw * 4, e->d_cb_lp_idx + (size_t)slot0 * kMaxLogProb, (size_t)kMaxLogProb * 4,
+                                          (size_t)lpw * 4, n, hipMemcpyDeviceToHost, e->stream));
+            TM_HIP_CHECK(hipMemcpyAsync(lp_num.data(), e->d_cb_lp_num + slot0, n * 4, hipMemcpyDeviceToHost, e->stream));
+            TM_HIP_CHECK(hipMemcpyAsync(lp_sel.data(), e->d_cb_lp_sel + slot0, n * 4, hipMemcpyDeviceToHost, e->stream));
+        }
         TM_HIP_CHECK(hipMemcpyAsync(e->d_k_len + slot0, lens.data(), n * 4, hipMemcpyHostToDevice, e->stream));
         TM_HIP_CHECK(hipMemcpyAsync(e->d_ids + slot0, e->d_next_ids + slot0, n * 4, hipMemcpyDeviceToDevice, e->stream));
         TM_HIP_CHECK(hipMemcpyAsync(first.data(), e->d_next_ids + slot0, n * 4, hipMemcpyDeviceToHost, e->stream));
@@ -174,6 +186,9 @@ static int cb_prefill_admitted(tm_engine* e, const std::vector<SchedAdmit>& admi
         for (int k = 0; k < n; ++k) {
             e->h_active[slot0 + k] = 1;
             const int64_t rid      = e->sched->slot_request(slot0 + k);
+            if (lpw > 0) {
+                e->sched->on_logprobs(slot0 + k, lp_vals.data() + (size_t)k * lpw, lp_idx.data() + (size_t)k * lpw, lp_num[k], lp_sel[k]);
+            }
             const bool    finished = e->sched->on_token(slot0 + k, first[k]);
             if (updates) {
                 const SchedRequest* r = e->sched->find(rid);
@@ -254,6 +269,68 @@ int tm_engine_submit_gen(tm_engine* e, const int* host_ids, int n, int max_new_t
     return 0;
 }
 
+int tm_engine_request_logprobs(tm_engine* e, int64_t req_id, int n)
+{
+    TM_REQUIRE(e, "null pointer");
+    TM_REQUIRE(n >= 1 && n <= kMaxLogProb, "1 <= logprobs <= TM_MAX_LOGPROBS");
+    TM_REQUIRE(!e->use_comm || e->comm || e->p2p_ready,
+               "logprobs with tp > 1 gather the logits like stochastic sampling: tm_engine_comm_init or the native communicator first");
+    ApiLock lock(e);
+    TM_REQUIRE(e->sched, "no continuous-batching session (submit first)");
+    TM_HIP_CHECK(hipSetDevice(e->cfg.device));
+    if (e->sched->set_logprobs(req_id, n)) {
+        set_last_error("unknown request id, or the request is already running (ask for logprobs right after the submit)");
+        return TM_INVALID;
+    }
+    const int B = e->cfg.max_batch_size;
+    if (!e->d_cb_lp_vals) {
+        TM_TRY(dmalloc(&e->d_cb_lp_vals, (size_t)B * kMaxLogProb));
+        TM_TRY(dmalloc(&e->d_cb_lp_idx, (size_t)B * kMaxLogProb));
+        TM_TRY(dmalloc(&e->d_cb_lp_num, (size_t)B));
+        TM_TRY(dmalloc(&e->d_cb_lp_sel, (size_t)B));
+        for (int i = 0; i < 2; ++i) {
+            TM_HIP_CHECK(hipHostMalloc((void**)&e->h_cb_lp_vals[i], (size_t)B * kMaxLogProb * 4));
+            TM_HIP_CHECK(hipHostMalloc((void**)&e->h_cb_lp_idx[i], (size_t)B * kMaxLogProb * 4));
+            TM_HIP_CHECK(hipHostMalloc((void**)&e->h_cb_lp_num[i], (size_t)B * 4));
+            TM_HIP_CHECK(hipHostMalloc((void**)&e->h_cb_lp_sel[i], (size_t)B * 4));
+        }
+    }
+    if (!e->d_kept) {
+        TM_TRY(dmalloc(&e->d_kept, (size_t)B));
+    }
+    if (!e->sampling_on) {  // the records come out of the sampling kernels: greedy rows are their top_k = 1 rows
+        std::vector<tm_sampling> greedy(B, tm_sampling{1.f, 1, 1.f, 0.f, 0});
+        TM_TRY(sampling_upload(e, greedy.data(), 0, B));
+        e->sampling_on = true;
+    }
+    e->cb_lp_used     = std::max(e->cb_lp_used, n);  // columns copied to the host behind every step from now on
+    e->cb_logprobs_on = true;                        // (a captured step without the records is re-captured by cb_launch_decode)
+    return 0;
+}
+
+int tm_engine_poll_logprobs(tm_engine* e, int64_t req_id, float* host_vals, int* host_idx, int* host_num, float* host_sel, int max_tokens,
+                            int* n_tokens, int* n_per_token)
+{
+    TM_REQUIRE(e && n_tokens && n_per_token, "null pointer");
+    ApiLock lock(e);
+    TM_REQUIRE(e->sched, "no continuous-batching session (submit first)");
+    const SchedRequest* r = e->sched->find(req_id);
+    if (!r) {
+        set_last_error("unknown request id");
+        return TM_INVALID;
+    }
+    *n_per_token = r->lp_n;
+    *n_tokens    = (int)r->lp_num.size();
+    const size_t t = (size_t)std::max(0, std::min(max_tokens, *n_tokens));
+    if (host_vals && host_idx && host_num && host_sel && t > 0) {
+        memcpy(host_vals, r->lp_vals.data(), t * r->lp_n * 4);
+        memcpy(host_idx, r->lp_idx.data(), t * r->lp_n * 4);
+        memcpy(host_num, r->lp_num.data(), t * 4);
+        memcpy(host_sel, r->lp_sel.data(), t * 4);
+    }
+    return 0;
+}
+
 int tm_engine_submit(tm_engine* e, const int* host_ids, int n, int max_new_tokens, int eos_id, int64_t* req_id)
 {
     return tm_engine_submit_ex(e, host_ids, n, max_new_tokens, eos_id, nullptr, req_id);
@@ -263,7 +340,7 @@ int tm_engine_submit(tm_engine* e, const int* host_ids, int n, int max_new_token
 // the decode step of every slot, as a graph replay when graphs are on (captured on first use)
 static int cb_launch_decode(tm_engine* e)
 {
-    if (e->graph_cb && (e->graph_cb_sampling != e->sampling_on || e->graph_cb_logits != e->logits_on)) {
+    if (e->graph_cb && (e->graph_cb_sampling != e->sampling_on || e->graph_cb_logits != e->logits_on || e->graph_cb_logprobs != e->cb_logprobs_on)) {
         TM_HIP_CHECK(hipStreamSynchronize(e->stream));  // (a replay of the old graph may still be running)
         (void)hipGraphExecDestroy(e->graph_cb);
         e->graph_cb = nullptr;
@@ -274,6 +351,7 @@ static int cb_launch_decode(tm_engine* e)
         TM_TRY(capture_step(e, decode_step_cb, &e->graph_cb));
         e->graph_cb_sampling = e->sampling_on;
         e->graph_cb_logits   = e->logits_on;
+        e->graph_cb_logprobs = e->cb_logprobs_on;
         return 0;
     }
     if (graph_enabled(e) && e->graph_cb) {
@@ -301,6 +379,14 @@ static int cb_issue(tm_engine* e, tm_engine::PendingStep* p, const std::vector<i
     if (e->p2p_state) {
         TM_HIP_CHECK(hipMemcpyAsync(h + B, e->p2p_state + 3, 4, hipMemcpyDeviceToHost, e->stream));
     }
+    p->lp = e->cb_logprobs_on && e->cb_lp_used > 0;
+    if (p->lp) {  // this step's logprob records: the first cb_lp_used candidates of every slot
+        const size_t w = (size_t)e->cb_lp_used * 4, pitch = (size_t)kMaxLogProb * 4;
+        TM_HIP_CHECK(hipMemcpy2DAsync(e->h_cb_lp_vals[p->buf], pitch, e->d_cb_lp_vals, pitch, w, B, hipMemcpyDeviceToHost, e->stream));
+        TM_HIP_CHECK(hipMemcpy2DAsync(e->h_cb_lp_idx[p->buf], pitch, e->d_cb_lp_idx, pitch, w, B, hipMemcpyDeviceToHost, e->stream));
+        TM_HIP_CHECK(hipMemcpyAsync(e->h_cb_lp_num[p->buf], e->d_cb_lp_num, (size_t)B * 4, hipMemcpyDeviceToHost, e->stream));
+        TM_HIP_CHECK(hipMemcpyAsync(e->h_cb_lp_sel[p->buf], e->d_cb_lp_sel, (size_t)B * 4, hipMemcpyDeviceToHost, e->stream));
+    }
     TM_HIP_CHECK(hipEventRecord(e->ev_step[p->buf], e->stream));
     p->valid = true;
     return 0;
@@ -325,6 +411,10 @@ static int cb_retire(tm_engine* e, tm_engine::PendingStep* p, std::vector<StepUp
         const int64_t id = p->ids[b];
         if (id < 0 || !e->h_active[b] || e->sched->slot_request(b) != id) {
             continue;
+        }
+        if (p->lp) {
+            e->sched->on_logprobs(b, e->h_cb_lp_vals[p->buf] + (size_t)b * kMaxLogProb, e->h_cb_lp_idx[p->buf] + (size_t)b * kMaxLogProb,
+                                  e->h_cb_lp_num[p->buf][b], e->h_cb_lp_sel[p->buf][b]);
         }
         const bool finished = e->sched->on_token(b, h[b]);
         if (updates) {
@@ -374,7 +464,8 @@ static int step_locked(tm_engine* e, int* n_active, int* n_waiting, std::vector<
     // Every configuration mixes: tp > 1 (the row-parallel reductions of the merged forward take the large-message path),
     // logits processors (the seen-mask update skips decode rows whose slot holds no running sequence), fp16 KV (the decode
     // rows' K/V go through kv_rope_store instead of the fused prologue), admissions of any size (see prefill_slots).
-    const bool        can_mix  = mixed_on && e->sched->n_active() > 0 && e->max_tokens - B >= 16;
+    // (not with logprob records: the merged forward's decode head would overwrite the records of the admission's earlier iterations)
+    const bool        can_mix  = mixed_on && e->sched->n_active() > 0 && e->max_tokens - B >= 16 && !e->cb_logprobs_on;
     bool             merged = false;
     std::vector<int> fresh;
     const std::vector<SchedAdmit> admits = e->sched->admit(e->max_tokens);

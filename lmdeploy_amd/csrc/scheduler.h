@@ -32,6 +32,12 @@ struct SchedRequest {
     bool             running  = false;
     std::vector<int> blocks;         // KV blocks owned while running
     std::vector<int> out;            // generated tokens so far
+    // GenerationConfig.logprobs (set_logprobs): per generated token the first lp_n kept candidates (entries beyond lp_num[t] are
+    // padding), their count and the token's own logprob -- the request's logprob_vals / logprob_indexes / logprob_nums outputs
+    // (src/turbomind/engine/model_request.cc:88-90)
+    int                lp_n = 0;
+    std::vector<float> lp_vals, lp_sel;
+    std::vector<int>   lp_idx, lp_num;
 };
 
 struct SchedAdmit {
@@ -155,6 +161,38 @@ public:
             return true;
         }
         return false;
+    }
+
+    // the logprob record of the token that on_token() is about to hand over for `slot` (call it first: on_token may free the slot);
+    // vals / idx hold at least min(num, lp_n) entries
+    void on_logprobs(int slot, const float* vals, const int* idx, int num, float sel)
+    {
+        const int64_t id = slot_req_[slot];
+        if (id < 0) {
+            return;
+        }
+        SchedRequest& r = reqs_[id];
+        if (r.lp_n <= 0) {
+            return;
+        }
+        const int n = num < 0 ? 0 : (num < r.lp_n ? num : r.lp_n);
+        r.lp_vals.insert(r.lp_vals.end(), vals, vals + n);
+        r.lp_idx.insert(r.lp_idx.end(), idx, idx + n);
+        r.lp_vals.resize(r.lp_vals.size() + (r.lp_n - n), 0.f);
+        r.lp_idx.resize(r.lp_idx.size() + (r.lp_n - n), -1);
+        r.lp_num.push_back(n);
+        r.lp_sel.push_back(sel);
+    }
+
+    // logprobs of a QUEUED request (nothing generated yet); 1 = unknown id / already running
+    int set_logprobs(int64_t id, int n)
+    {
+        auto it = reqs_.find(id);
+        if (it == reqs_.end() || it->second.running || !it->second.out.empty() || it->second.status != 0) {
+            return 1;
+        }
+        it->second.lp_n = n;
+        return 0;
     }
 
     // additional stop ids of a queued / running request; 1 = unknown id

@@ -185,9 +185,6 @@ class Pipeline:
             yield from sorted(self.generate_continuous(prompts, g), key=lambda r: r.index)
             return
         self._resolve_words(g)
-        if g.logprobs:                              # the logprob records live with the static batch (tm_engine_set_logprobs)
-            yield from self._generate_static(prompts, g)
-            return
         if len(prompts) > self.max_batch_size:      # more work than batch slots: let the engine schedule it
             yield from sorted(self.generate_continuous(prompts, g), key=lambda r: r.index)
             return
@@ -204,9 +201,6 @@ class Pipeline:
             gs = [gi or GenerationConfig() for gi in g]
         else:
             gs = [g or GenerationConfig()] * len(ids)
-        if any(gi.logprobs for gi in gs):
-            raise NotImplementedError('GenerationConfig.logprobs with streaming or per-request generation configs: the logprob records are '
-                                      'kept by the static batch path (one GenerationConfig for all prompts, infer / __call__)')
         stops = []
         pending, out_of_engine, sent = {}, [], {}
         for i, p in enumerate(ids):
@@ -227,7 +221,8 @@ class Pipeline:
                 if len(p) < 1 or room < 1:
                     raise _ffi.TmError(6, 'empty prompt' if len(p) < 1 else
                                        f'prompt ({len(p)}) leaves no room for a new token in session_len ({self.session_len})')
-                pending[self.engine.submit(p, min(gi.max_new_tokens, room), eos, gi.sampling_params(i), lp)] = i
+                pending[self.engine.submit(p, min(gi.max_new_tokens, room), eos, gi.sampling_params(i), lp,
+                                           **({'logprobs': gi.logprobs} if gi.logprobs else {}))] = i
             except _ffi.TmError as e:
                 rt = STATUS_TO_RESPONSE.get(e.status, ResponseType.INTERNAL_ENGINE_ERROR)
                 out_of_engine.append(Response('', 0, len(p), 'error', [], index=i, error_code=rt.name, error_message=str(e)))
@@ -260,16 +255,23 @@ class Pipeline:
                     reason = None if st == 0 else ('stop' if cut is not None else 'length')
                     if st != 0:
                         del pending[rid]
+                    def lps(first, toks_):    # Response.logprobs of tokens first .. first + len(toks_) of this request
+                        if not g.logprobs or not toks_:
+                            return None
+                        v, ix, nm, sl = self.engine.poll_logprobs(rid)
+                        return [logprobs_of_token(v[first + k], ix[first + k], int(nm[first + k]), float(sl[first + k]), t, g.logprobs)
+                                for k, t in enumerate(toks_)]
                     if stream:          # the delta since the last Response of this request
-                        new = out[sent.get(rid, 0):]
+                        first = sent.get(rid, 0)
+                        new = out[first:]
                         sent[rid] = len(out)
                         if not new and st == 0:
                             continue
                         text = self.tokenizer.decode(new, skip_special_tokens=g.skip_special_tokens) if self.tokenizer else ''
-                        yield Response(text, len(out), len(ids[i]), reason, new, index=i)
+                        yield Response(text, len(out), len(ids[i]), reason, new, logprobs=lps(first, new), index=i)
                         continue
                     text = self.tokenizer.decode(out, skip_special_tokens=g.skip_special_tokens) if self.tokenizer else ''
-                    yield Response(text, len(out), len(ids[i]), reason, out, index=i)
+                    yield Response(text, len(out), len(ids[i]), reason, out, logprobs=lps(0, out), index=i)
         finally:
             self.engine.release()
 

@@ -247,10 +247,11 @@ class Engine:
         return int(out[0])
 
     # ---- continuous batching (tm_engine_submit / step / poll / cancel) -----------------------------
-    def submit(self, prompt: Sequence[int], max_new_tokens: int, eos_id: int = -1, sampling=None, logits=None) -> int:
+    def submit(self, prompt: Sequence[int], max_new_tokens: int, eos_id: int = -1, sampling=None, logits=None, logprobs: int = 0) -> int:
         """Queue one request; returns its id.  eos_id < 0 = ignore_eos.  sampling = (temperature, top_k, top_p, min_p,
-        seed) or None (greedy); logits = dict(repetition_penalty, min_new_tokens, bad_ids, stop_ids) or None.  Raises
-        TmError with the reference's status code (TM_TOO_LONG, TM_OOM, TM_INVALID) when the request can never run."""
+        seed) or None (greedy); logits = dict(repetition_penalty, min_new_tokens, bad_ids, stop_ids) or None; logprobs = n > 0:
+        every generated token carries its first n kept candidates (poll_logprobs).  Raises TmError with the reference's status
+        code (TM_TOO_LONG, TM_OOM, TM_INVALID) when the request can never run."""
         ids = np.ascontiguousarray(np.asarray(prompt, np.int32))
         rid = C.c_int64(0)
         sp = C.byref(_ffi.Sampling(*sampling)) if sampling is not None else None
@@ -259,7 +260,22 @@ class Engine:
         lp = C.byref(logits) if logits is not None else None
         _ffi.check(self._lib.tm_engine_submit_gen(self._h, ids.ctypes.data, int(ids.size), int(max_new_tokens), int(eos_id), sp,
                                                   lp, C.byref(rid)))
+        if logprobs:
+            _ffi.check(self._lib.tm_engine_request_logprobs(self._h, rid.value, int(logprobs)))
         return rid.value
+
+    def poll_logprobs(self, req_id: int):
+        """(vals [tokens, n] float32, idx [tokens, n] int32, num [tokens] int32, sel [tokens] float32) recorded so far for a request
+        submitted with logprobs = n (entries beyond num[t]: 0 / -1)."""
+        nt, n = C.c_int(0), C.c_int(0)
+        _ffi.check(self._lib.tm_engine_poll_logprobs(self._h, req_id, None, None, None, None, 0, C.byref(nt), C.byref(n)))
+        t, w = nt.value, n.value     # the engine thread may append between the two calls: copy what the first call saw
+        vals, idx = np.zeros((max(t, 1), max(w, 1)), np.float32), np.zeros((max(t, 1), max(w, 1)), np.int32)
+        num, sel = np.zeros(max(t, 1), np.int32), np.zeros(max(t, 1), np.float32)
+        if t and w:
+            _ffi.check(self._lib.tm_engine_poll_logprobs(self._h, req_id, vals.ctypes.data, idx.ctypes.data, num.ctypes.data, sel.ctypes.data,
+                                                         t, C.byref(nt), C.byref(n)))
+        return vals[:t, :w], idx[:t, :w], num[:t], sel[:t]
 
     def step(self):
         """One scheduler iteration: admit + prefill waiting requests, then one decode step for everything running.

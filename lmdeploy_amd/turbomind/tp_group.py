@@ -33,7 +33,7 @@ from .engine import Engine
 MIRRORED = ('prefill', 'decode', 'release', 'set_sampling', 'set_logits_params', 'set_logprobs', 'submit', 'step', 'step_many', 'cancel', 'forget', 'tune_gemm',
             'import_gemm_table', 'sync')
 # reads rank 0 answers alone: they touch no collective and change no state the other ranks would have to follow
-RANK0_READS = ('poll', 'fetch', 'fetch_logprobs', 'fetch_logits', 'fetch_residual', 'fetch_kv_block', 'stats', 'comm_info', 'prefill_times_ms', 'mixed_steps',
+RANK0_READS = ('poll', 'poll_logprobs', 'fetch', 'fetch_logprobs', 'fetch_logits', 'fetch_residual', 'fetch_kv_block', 'stats', 'comm_info', 'prefill_times_ms', 'mixed_steps',
                'overlapped_steps', 'pick_tiling', 'pick_general', 'export_gemm_table', 'stream', 'cfg', 'batch', 'max_new', 'PROF_CATEGORIES')
 # everything else of Engine either runs a forward or changes engine state on ONE rank (serve_start / serve_stop / wait: the engine thread;
 # profile_decode; init_synthetic / load_weights / start / comm_*: construction): rank 0 alone would enter collectives the workers never

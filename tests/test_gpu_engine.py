@@ -727,12 +727,15 @@ def test_engine_sampling_static_and_continuous(cuda):
     assert g[1, 0] == toks[1, 0]
 
 
-def test_engine_logprobs_static_batch(cuda):
+@pytest.mark.parametrize('async_step', [0, 1])
+def test_engine_logprobs_static_batch(cuda, monkeypatch, async_step):
     """GenerationConfig.logprobs inside the engine (tm_engine_set_logprobs): for every generated token of a mixed batch -- two
     stochastic sequences and a greedy one -- the record of (sequence, step) must be what the oracle makes of the engine's own logits
     of that step (sample_filter -> sample_logprobs): candidate ids exact, logprobs within 1e-5, the drawn token's logprob; the tokens
     themselves must not change when logprobs are switched on; eager first step, captured graph afterwards; a second batch with another
-    count re-captures; the pipeline hands the reference's dictionaries out."""
+    count re-captures; the scheduler path (tm_engine_request_logprobs) records the same per request; the pipeline hands the reference's
+    dictionaries out, streamed or not."""
+    monkeypatch.setenv('TM_ASYNC_STEP', str(async_step))      # the scheduler part: steps retired by the call that issued them / one call later
     cfg = o.ModelConfig(hidden=256, layers=2, q_heads=4, kv_heads=2, head_dim=128, inter=512, vocab=1024,
                         kv_bits=8, rope=o.RopeParam(128, 500000.0, 'llama3', 8.0, 1.0, 4.0, 8192))
     w = o.make_synthetic_weights(cfg, seed=21)
@@ -778,6 +781,33 @@ def test_engine_logprobs_static_batch(cuda):
                     assert n == 1 and vals[b, s_, 0] == 0.0 and idx[b, s_, 0] == toks[b, s_]
     with pytest.raises(_ffi.TmError):
         eng.set_logprobs(1025)
+    # continuous batching: the same requests, each asking for its own count; the per-request records equal the static batch's (same
+    # kernels on the same rows); a request without logprobs records nothing; a late request joins a running session
+    toks, _, (vals, idx, num, sel) = run(4)
+    want_n = [4, 0, 2]
+    ids = [eng.submit(p_, steps, -1, sp, None, n_) for p_, sp, n_ in zip(prompts, params, want_n)]
+    eng.step()
+    late = eng.submit(prompts[0], steps, -1, params[0], None, 3)
+    while eng.step() != (0, 0):
+        pass
+    for b, rid in enumerate(ids + [late]):
+        ref_b = b if b < 3 else 0
+        n_ = want_n[b] if b < 3 else 3
+        st_, t = eng.poll(rid)
+        v, ix, nm, sl = eng.poll_logprobs(rid)
+        assert st_ == 7 and np.array_equal(t, toks[ref_b, :steps]), f'request {b}'
+        if n_ == 0:
+            assert v.shape[0] == 0
+            continue
+        assert v.shape == (steps, n_) and np.array_equal(nm, np.minimum(num[ref_b, :steps], n_)), f'request {b}'
+        for s_ in range(steps):
+            k = nm[s_]
+            assert np.array_equal(ix[s_, :k], idx[ref_b, s_, :k]) and np.all(ix[s_, k:] == -1), f'request {b} step {s_}'
+            assert np.allclose(v[s_, :k], vals[ref_b, s_, :k], rtol=0, atol=2e-3), f'request {b} step {s_}'
+        assert np.allclose(sl, sel[ref_b, :steps], rtol=0, atol=2e-3)
+    with pytest.raises(_ffi.TmError):
+        _ffi.check(eng._lib.tm_engine_request_logprobs(eng._h, ids[0], 2))      # not queued any more
+    eng.release()
     eng.close()
     # the pipeline surface: greedy -> every token's dictionary is {token: 0.0}; sampling -> the token is in its dictionary, at most n + 1 entries
     import lmdeploy_amd
@@ -792,6 +822,15 @@ def test_engine_logprobs_static_batch(cuda):
         assert len(r.logprobs) == 5
         for t, d in zip(r.token_ids, r.logprobs):
             assert t in d and 3 <= len(d) <= 4 and all(v <= 0.0 for v in d.values())
+    # streaming through the scheduler: the deltas carry their tokens' dictionaries, together they equal the non-streamed answer
+    g5 = lmdeploy_amd.GenerationConfig(max_new_tokens=5, ignore_eos=True, logprobs=3, do_sample=True, top_k=50, temperature=1.5, random_seed=5)
+    acc = {}
+    for r in pipe.stream_infer(ps, g5):
+        assert len(r.logprobs) == len(r.token_ids)
+        acc.setdefault(r.index, []).extend(r.logprobs)
+    sched = pipe(ps, g5)
+    for i, r in enumerate(sched):
+        assert len(acc[i]) == 5 and [sorted(d) for d in acc[i]] == [sorted(d) for d in r.logprobs]
     pipe.close()
 
 

@@ -76,14 +76,28 @@ class FakeEngine:
         self.logprobs = 0          # like tm_engine_release
 
     # ---- scheduler --------------------------------------------------------------------------
-    def submit(self, prompt, max_new, eos_id=-1, sampling=None, logits=None):
+    def submit(self, prompt, max_new, eos_id=-1, sampling=None, logits=None, logprobs=0):
         if len(prompt) + max_new > self.session_len:
             raise _ffi.TmError(6, 'prompt + max_new_tokens exceeds session_len')
         stops = {eos_id} | set((logits or {}).get('stop_ids', []) if isinstance(logits, dict) else [])
         rid, self.next_id = self.next_id, self.next_id + 1
         self.reqs[rid] = dict(prompt=list(map(int, prompt)), max_new=max_new, stops=stops - {-1}, out=[], status=0, slot=None,
-                              logits=logits)
+                              logits=logits, logprobs=logprobs)
         return rid
+
+    def poll_logprobs(self, rid):
+        """the same fake records as fetch_logprobs, per request"""
+        r = self.reqs[rid]
+        n, T = r['logprobs'], len(r['out'])
+        vals, idx = np.zeros((T, n), np.float32), np.zeros((T, n), np.int32)
+        num, sel = np.zeros(T, np.int32), np.zeros(T, np.float32)
+        for s_, t in enumerate(r['out']):
+            off = 1 if s_ % 3 == 2 else 0
+            idx[s_] = [(t + k + off) % VOCAB for k in range(n)]
+            vals[s_] = [-k - 0.5 * s_ for k in range(n)]
+            num[s_] = max(1, n - (s_ % 2))
+            sel[s_] = -9.0 if off else vals[s_, 0]
+        return vals, idx, num, sel
 
     def step(self):
         running = [r for r in self.reqs.values() if r['status'] == 0 and r['slot'] is not None]
@@ -221,7 +235,8 @@ def test_errors_become_responses_and_processors_reach_the_engine(pipe):
 def test_logprobs_reach_the_responses(pipe):
     """GenerationConfig.logprobs: the request runs as a static batch (also with more prompts than slots), the engine is armed with
     set_logprobs(n), and every generated token gets the reference's dictionary (turbomind.py:472-503): the first min(num, n) candidates,
-    plus the generated token itself when it is not among them; streaming / per-request configs refuse it loudly."""
+    plus the generated token itself when it is not among them; the scheduler path (more prompts than slots, per-request configs,
+    streaming deltas) hands out the same dictionaries from the per-request records."""
     prompts = [[1, 2, 3], [9, 9], [4, 5, 6, 7]]
     res = pipe(prompts, GenerationConfig(max_new_tokens=6, logprobs=3, ignore_eos=True))
     eng = FakeEngine.instances[-1]
@@ -237,10 +252,29 @@ def test_logprobs_reach_the_responses(pipe):
     plain = pipe(prompts, GenerationConfig(max_new_tokens=6, ignore_eos=True))
     assert eng.logprobs == 0 and all(r.logprobs is None for r in plain)
     assert [r.token_ids for r in plain] == [r.token_ids for r in res]
-    with pytest.raises(NotImplementedError):
-        list(pipe.stream_infer(prompts, GenerationConfig(max_new_tokens=3, logprobs=2)))
-    with pytest.raises(NotImplementedError):
-        pipe(prompts, [GenerationConfig(max_new_tokens=3, logprobs=2)] * 3)
+
+    def want(tok, s_, n_req):
+        n = max(1, n_req - (s_ % 2))
+        d = {(tok + k + (1 if s_ % 3 == 2 else 0)) % VOCAB: -k - 0.5 * s_ for k in range(n)}
+        if s_ % 3 == 2:
+            d[tok] = -9.0
+        return d
+    # the scheduler path (more prompts than slots -> continuous batching; per-request configs; streaming deltas)
+    many = prompts + [[8, 8, 8]]
+    sched = pipe(many, GenerationConfig(max_new_tokens=5, logprobs=2, ignore_eos=True))
+    for r in sched:
+        assert r.logprobs == [want(t, s_, 2) for s_, t in enumerate(r.token_ids)] and len(r.token_ids) == 5
+    per = pipe(prompts, [GenerationConfig(max_new_tokens=4, logprobs=2, ignore_eos=True), GenerationConfig(max_new_tokens=4, ignore_eos=True),
+                         GenerationConfig(max_new_tokens=4, logprobs=3, ignore_eos=True)])
+    assert per[1].logprobs is None
+    assert per[0].logprobs == [want(t, s_, 2) for s_, t in enumerate(per[0].token_ids)]
+    assert per[2].logprobs == [want(t, s_, 3) for s_, t in enumerate(per[2].token_ids)]
+    got = {}
+    for r in pipe.stream_infer(prompts, GenerationConfig(max_new_tokens=4, logprobs=2, ignore_eos=True)):
+        assert len(r.logprobs) == len(r.token_ids)
+        got.setdefault(r.index, []).extend(zip(r.token_ids, r.logprobs))
+    for i in range(3):
+        assert [d for _, d in got[i]] == [want(t, s_, 2) for s_, (t, _) in enumerate(got[i])] and len(got[i]) == 4
     with pytest.warns(UserWarning):
         assert GenerationConfig(logprobs=5000).logprobs == 1024
 
