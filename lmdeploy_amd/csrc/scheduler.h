@@ -14,6 +14,7 @@
 // engine drives it.
 #pragma once
 
+#include <cstddef>
 #include <cstdint>
 #include <deque>
 #include <map>

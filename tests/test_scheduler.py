@@ -3,6 +3,7 @@ tm_sched_* exactly as the engine drives it (reference: engine/engin
 arrival-order admission, slot reuse, 64-token block accounting for prompt + max_new_tokens, prefill token budget,
 finish on EOS / length / cancel, reference status codes."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -455,3 +456,21 @@ def test_prefill_microbatch_split():
     bad = np.array([0, 5, 5], np.int32)
     sa, ra = C.c_int(), C.c_int()
     assert lib.tm_prefill_split(bad.ctypes.data, 2, 64, C.byref(sa), C.byref(ra)) != 0
+
+
+def test_scheduler_under_sanitizers(tmp_path):
+    """scheduler.h is pure host C++: a seeded random stream of the engine's calls (submit / admit / logprob record + token / cancel / forget, abort)
+    with the block, slot and logprob-record invariants checked after every call, built with AddressSanitizer + UndefinedBehaviorSanitizer
+    (tests/cpp/scheduler_sanitizer.cpp; the GPU side cannot be sanitised on this pool)."""
+    import shutil
+    import subprocess
+    if shutil.which('g++') is None:
+        pytest.skip('g++ not available')
+    src = os.path.join(os.path.dirname(__file__), 'cpp', 'scheduler_sanitizer.cpp')
+    exe = str(tmp_path / 'sched_san')
+    build = subprocess.run(['g++', '-std=c++17', '-O1', '-g', '-fsanitize=address,undefined', '-fno-sanitize-recover=all', '-o', exe, src],
+                           capture_output=True, text=True)
+    assert build.returncode == 0, build.stderr
+    for args in (['1'], ['2', 'abort'], ['77']):
+        run = subprocess.run([exe] + args, capture_output=True, text=True, timeout=120)
+        assert run.returncode == 0 and run.stdout.startswith('ok seed'), run.stdout + run.stderr
