@@ -223,7 +223,7 @@ def measure_in_graph_durations(args, table_text, ctx_target, layers, batch):
         shutil.rmtree(tmp, ignore_errors=True)
 
 
-def run_canary(args, rank, world, timeout_s=240):
+def run_canary(args, rank, world, timeout_s=240, extra_env=None):
     """Multi-GPU runs only: before THIS process touches the device for real, a child copy of the bench (its own rendezvous port) pushes a
     2-layer model of the same width through every collective code path the real run will take with the CURRENT switches -- RCCL bring-up,
     the native communicator + its self-test, a prefill forward large enough for the side-stream micro-batch schedule, graph-captured decode
@@ -232,7 +232,9 @@ def run_canary(args, rank, world, timeout_s=240):
     conservative switches and measure".  Returns True when the child exited 0 within the limit."""
     import subprocess
     port = int(os.environ.get('MASTER_PORT', '29500')) + 17
-    env = dict(os.environ, MASTER_PORT=str(port), TM_BENCH_CANARY='1')
+    env = dict(os.environ, MASTER_PORT=str(port), TM_BENCH_CANARY='1', **(extra_env or {}))
+    if extra_env:           # second attempt: its own rendezvous port (ranks of the first attempt may still be dying)
+        env['MASTER_PORT'] = str(port + 13)
     cmd = [sys.executable, os.path.abspath(__file__), '--gpus', str(world), '--steps', '6', '--warmup', '3', '--layers', '2', '--batch', str(args.batch),
            '--prompt-len', '64', '--max-prefill-tokens', '4096', '--quant-policy', str(args.quant_policy), '--model', args.model, '--profile-steps', '0',
            '--no-cpu-baseline', '--no-traffic', '--no-full-run', '--tune', '0']
@@ -355,6 +357,8 @@ def main():
         # reference starts all ranks of a node from one call too: lmdeploy/turbomind/turbomind.py:191-217)
         sys.exit(self_launch(args.gpus))
 
+    if os.environ.get('TM_BENCH_CANARY') and os.environ.get('TM_BENCH_CANARY_FAIL', '0') == '1':
+        sys.exit(3)         # test hook: a canary child that fails at once (tests/test_gpu_bench_launcher.py)
     claim_stdout()
     import torch
     import torch.distributed as dist
@@ -378,6 +382,7 @@ def main():
     local_dev = local_rank % ndev
     torch.cuda.set_device(local_dev)
     canary_note = ''
+    replicas = False          # set when the tensor-parallel path cannot run on this node at all (see the canaries below)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group('gloo', rank=rank, world_size=world)   # control plane only; data plane = RCCL in C++
@@ -388,12 +393,24 @@ def main():
             oks = [None] * world
             dist.all_gather_object(oks, bool(ok))
             if not all(oks):
-                for k, v in (('TM_COMM', 'rccl'), ('TM_COMM_STREAM', '0'), ('TM_GRAPH_COMM', '0')):
-                    os.environ[k] = v
+                safe = {'TM_COMM': 'rccl', 'TM_COMM_STREAM': '0', 'TM_GRAPH_COMM': '0'}
+                second = dict(safe, TM_BENCH_CANARY_FAIL='0')
                 canary_note = (f'canary run failed or hung on ranks {[r for r, o_ in enumerate(oks) if not o_]} with the default collective switches -> '
                                f'RCCL only, collectives on the engine stream, eager (TM_COMM=rccl TM_COMM_STREAM=0 TM_GRAPH_COMM=0)')
                 print(f'[bench] rank {rank}: {canary_note}', file=sys.stderr)
+                # the conservative switches get a canary of their own: if the tensor-parallel path cannot finish even so on this node, the run
+                # still produces a record -- N independent TP = 1 replicas (no collective at all), labelled as such -- instead of a hang
+                ok2 = os.environ.get('TM_BENCH_FORCE_REPLICAS', '0') != '1' and run_canary(args, rank, world, extra_env=second)
+                dist.all_gather_object(oks, bool(ok2))
+                if all(oks):
+                    os.environ.update(safe)
+                else:
+                    replicas = True
+                    canary_note += (f'; a second canary with those switches failed or hung on ranks {[r for r, o_ in enumerate(oks) if not o_]} -> THIS LINE IS NOT '
+                                    f'TENSOR PARALLEL: {world} independent TP = 1 replicas, one per GPU, batch {args.batch} each (weak scaling, no collective)')
+                    print(f'[bench] rank {rank}: {canary_note}', file=sys.stderr)
 
+    tp = 1 if replicas else world     # model-parallel degree; `world` stays the number of processes / GPUs of the job
     model = dict(MODELS[args.model])
     if args.layers:
         model['layers'] = args.layers
@@ -412,12 +429,12 @@ def main():
     full_run = (not args.no_full_run) and not child and 1 + W + K < 1024     # continue to 1024 generated tokens after the timed region
     max_new = max(1 + W + K + P + 2, (1024 + P + 2) if full_run else 0)
     weight_type = int(model.pop('weight_type', 0))
-    eng = Engine.from_model_config(_Cfg(model), weight_type=weight_type, tp=world, rank=rank, device=local_dev, max_batch_size=B,
+    eng = Engine.from_model_config(_Cfg(model), weight_type=weight_type, tp=tp, rank=rank if tp > 1 else 0, device=local_dev, max_batch_size=B,
                                    session_len=S + max_new + 1, quant_policy=args.quant_policy,
                                    max_prefill_token_num=args.max_prefill_tokens, use_graph=0 if args.no_graph else 1, decode_splits=args.decode_splits)
     dog = Watchdog(world > 1, rank)
     comm_note = ''
-    if world > 1:
+    if tp > 1:
         dog.arm('communicator set-up', 300)
 
         def gather(h):
@@ -537,7 +554,7 @@ def main():
     ctx_first = S + 1 + W               # context length (incl. the new token) of the first timed step
     ctx_mean = ctx_first + (K - 1) / 2.0
     kv_bits = 16 if args.quant_policy == 0 else args.quant_policy
-    step_bytes, kv_tok = algorithmic_bytes(model, B, ctx_mean, kv_bits, world)
+    step_bytes, kv_tok = algorithmic_bytes(model, B, ctx_mean, kv_bits, tp)
 
     # ---- per-kernel durations: HIP events on the engine stream, eager steps right after the timed region ----
     prof = eng.profile_decode(P) if P > 0 else {}
@@ -558,14 +575,14 @@ def main():
             tt = torch.tensor([dt_r], dtype=torch.float64)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dt_r = float(tt.item())
-        full = dict(value=round(B * (K + R) / (dt + dt_r), 1), steps=K + R, ctx_first=ctx_first, ctx_last=S + 1024,
+        full = dict(value=round(B * (world if replicas else 1) * (K + R) / (dt + dt_r), 1), steps=K + R, ctx_first=ctx_first, ctx_last=S + 1024,
                     ms_per_step=round((dt + dt_r) / (K + R) * 1e3, 4))
     toks = eng.fetch()
     stats = eng.stats()
     cinfo = eng.comm_info()
     # the tilings the timed steps ran (measured table first, then the heuristic): per decode linear (shape, split-K) at M = B
-    hq_l, hkv_l = model['q_heads'] // world, max(1, model['kv_heads'] // world)
-    D_, H_, I_l = model['head_dim'], model['hidden'], model['inter'] // world
+    hq_l, hkv_l = model['q_heads'] // tp, max(1, model['kv_heads'] // tp)
+    D_, H_, I_l = model['head_dim'], model['hidden'], model['inter'] // tp
     tilings, prefill_tilings = {}, {}
     pf_rows = min(B * S, args.max_prefill_tokens)     # rows of a prefill forward of this run (max_prefill_token_num chunks)
     if weight_type == 0 and not model.get('moe_experts') and B <= 256:
@@ -576,8 +593,8 @@ def main():
             prefill_tilings[name] = dict(zip(('shape', 'splits'), Engine.pick_tiling(kk, nn, pf_rows, role=role)))
     # the fp16 lm_head runs the general kernel: (tiles per wave, split-K) from the measured table (`G` lines) or the heuristic
     head_tiling = None
-    if B <= 256 and (model['vocab'] // world) % 16 == 0:
-        head_tiling = dict(zip(('nt', 'splits'), Engine.pick_general(1, 5, H_, model['vocab'] // world, B)[:2]))
+    if B <= 256 and (model['vocab'] // tp) % 16 == 0:
+        head_tiling = dict(zip(('nt', 'splits'), Engine.pick_general(1, 5, H_, model['vocab'] // tp, B)[:2]))
     if weight_type != 0 or model.get('moe_experts'):
         # formats other than AWQ u4 / MoE: the weight bytes are what the engine actually streams (packed weights + scales +
         # lm_head); with batch 64 and top-2 of 8 every expert is hit every step
@@ -585,23 +602,25 @@ def main():
 
     if rank == 0:
         ms_step = dt / K * 1e3
-        value = B * K / dt
+        value = B * (world if replicas else 1) * K / dt    # replicas: every GPU ran its own batch of B
         kv_name = {0: 'fp16-KV', 4: 'int4-KV', 8: 'int8-KV'}.get(args.quant_policy, f'quant_policy={args.quant_policy}')
         headline = args.model == 'llama3_8b' and args.quant_policy == 8 and B == 64 and S == 1024 and not args.layers
         out = {
             'metric': f'decode tokens/sec, Llama-3-8B W4A16 {kv_name} batch {B} ({S}-in/1k-out synthetic)'
                       + ('' if headline else ' (NOT the headline config)'),
             'value': round(value, 1), 'unit': 'tokens/s', 'n_gpus': world, 'steps': K, 'warmup': W,
-            'ms_per_step': round(ms_step, 4), 'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None,
+            'ms_per_step': round(ms_step, 4), 'higher_is_better': True, 'scaling': 'weak' if replicas else 'strong', 'vs_baseline': None,
             'dtype': 'f16', 'data': 'synthetic',
             'config': {'workload': f'Llama-3-8B shapes, W4A16 AWQ g128 random weights, quant_policy={args.quant_policy} '
-                                   f'KV, batch {B}, {S}-token random prompts, greedy decode, TP={world}',
+                                   f'KV, batch {B}{" per replica" if replicas else ""}, {S}-token random prompts, greedy decode, '
+                                   + (f'{world} independent TP=1 replicas' if replicas else f'TP={world}'),
                        'batch': B, 'prompt_len': S, 'ctx_first_timed_step': ctx_first, 'ctx_mean': ctx_mean,
-                       'parallelism': f'tp{world}', 'collectives': cinfo['backend'], 'rccl_ranks': cinfo['ranks'] if world > 1 else 0,
+                       'parallelism': f'dp{world} (replicas only)' if replicas else f'tp{world}', 'collectives': cinfo['backend'],
+                       'rccl_ranks': cinfo['ranks'] if tp > 1 else 0,
                        'decode_splits': stats['decode_splits'], 'hipgraph': cinfo['hipgraph'],
                        # RMSNorm folded into the decode GEMMs (tp = 1, dense u4, batch <= 64; TM_FOLD_NORM bit 0: wo -> w1w3, bit 1: w2 ->
                        # w_qkv): 5 launches per layer instead of 7
-                       'rmsnorm_fold': (int(os.environ.get('TM_FOLD_NORM', '0')) & 3) if (world == 1 and emu <= 1 and weight_type == 0
+                       'rmsnorm_fold': (int(os.environ.get('TM_FOLD_NORM', '0')) & 3) if (tp == 1 and emu <= 1 and weight_type == 0
                                                                                          and not model.get('moe_experts') and B <= int(os.environ.get('TM_FOLD_MAX_M', '64'))) else 0,
                        'gemm_dispatch': ('measured at start-up (tm_engine_tune_gemm' + (', rank 0\'s table broadcast' if world > 1 else '') + ')')
                                         if tuned else 'heuristic',
@@ -619,7 +638,7 @@ def main():
             comm_note = (comm_note + '; ' if comm_note else '') + canary_note
         if comm_note:
             out['config']['collectives_note'] = comm_note
-        if world > 1 or emu > 1:
+        if tp > 1 or emu > 1:
             # prefill-sized forwards: all-reduces on the side stream under the other row half's GEMMs (TM_COMM_STREAM, default on)
             out['config']['prefill_allreduce_overlap'] = {
                 'side_stream': cinfo['side_stream'], 'overlapped_forwards': cinfo['overlapped_forwards'],
@@ -634,7 +653,9 @@ def main():
             out['config']['devices_shared'] = True
             out['config']['ranks_per_device'] = ranks_per_device
             out['metric'] += ' -- RANKS SHARE A DEVICE: launcher / bring-up test, not a multi-GPU result'
-        if world > 1 or emu > 1:
+        if replicas:
+            out['metric'] += f' -- TENSOR PARALLELISM COULD NOT RUN ON THIS NODE: {world} independent TP=1 replicas (weak scaling), see config.collectives_note'
+        if tp > 1 or emu > 1:
             out['scaling_note'] = ('no 1 -> 8 GPU scaling curve of this engine has been measured on hardware before this run: the tensor-parallel '
                                    'path was validated on one device only (two processes on one GPU over the native communicator, 1-rank RCCL, '
                                    'gloo world-size-2 CPU tests)')
@@ -677,7 +698,7 @@ def main():
             # the four W4A16 decode GEMMs of a layer; the attention and the whole step follow as named extras
             gemm_roles = ('w_qkv', 'wo', 'w1w3', 'w2')
             if ing and all(r in ing for r in gemm_roles):
-                per_b, _ = gemm_family_bytes(model, max(world, emu, 1))
+                per_b, _ = gemm_family_bytes(model, max(tp, emu, 1))
                 fam = family_roofline(per_b, {r: ing[r] for r in gemm_roles})
                 lin_flop = 2.0 * B * sum(per_b.values()) / (0.5 + 1.0 / 32.0)      # 2 * M * K * N summed over the four linears
                 gemm_obj = {'bound': 'hbm', 'kernel': 'the four W4A16 decode GEMMs of a layer (gemm_dec32_kernel / gemm_dec_lc_kernel: w_qkv, wo, '
@@ -705,7 +726,7 @@ def main():
                 out['roofline'] = attn_obj
                 out['roofline']['in_graph_trace'] = ing_src
             gemm_ms = sum(prof[k][0] for k in ('gemm_qkv', 'gemm_o', 'gemm_gate_up', 'gemm_down'))
-            wbytes = (stats['weight_bytes'] - 2 * model['hidden'] * model['vocab'] / world)
+            wbytes = (stats['weight_bytes'] - 2 * model['hidden'] * model['vocab'] / tp)
             out['gemm_roofline'] = {'bound': 'hbm', 'timing': 'eager HIP events (see roofline / gemm_family_roofline for the in-graph launches)',
                                     'achieved': round(wbytes / (gemm_ms / 1e3) / 1e9, 1),
                                     'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
@@ -733,7 +754,7 @@ def main():
             out['value_1k_out'] = full['value']      # the metric-faithful rate: all 1024 generated tokens of the batch
             out['value_full_run'] = full
             out['value_full_run']['step_roofline_frac'] = round(
-                algorithmic_bytes(model, B, (full['ctx_first'] + full['ctx_last']) / 2.0, kv_bits, world)[0] / (full['ms_per_step'] / 1e3) / 1e9
+                algorithmic_bytes(model, B, (full['ctx_first'] + full['ctx_last']) / 2.0, kv_bits, tp)[0] / (full['ms_per_step'] / 1e3) / 1e9
                 / HBM_PEAK_GBPS, 4) if weight_type == 0 and not model.get('moe_experts') else None
         if not args.no_cpu_baseline and world == 1 and not child:
             from oracle import cpu_baseline

@@ -67,3 +67,33 @@ def test_bench_eight_ranks_on_one_gpu_bring_up(cuda):
     cfg = d['config']
     assert d['n_gpus'] == 8 and d['value'] > 0 and cfg['parallelism'] == 'tp8' and cfg['ranks_per_device'] == 8
     assert cfg['collectives'] == 'native-p2p' and cfg['rccl_ranks'] == 8, cfg
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize('force_replicas', [0, 1])
+def test_bench_canary_fallbacks(cuda, force_replicas):
+    """The driver's scaling run is the first time this engine's collectives cross xGMI.  bench.py sends a canary child through the collective
+    paths first; when it fails (forced here) ALL ranks take the conservative switches after a second canary with those switches passed --
+    and when that fails too (forced) the job still produces a record: N independent TP = 1 replicas, labelled as such (weak scaling, no
+    collective), instead of a hang."""
+    env = dict(os.environ, GPU_MAX_HW_QUEUES='8', HSA_ENABLE_IPC_MODE_LEGACY='0', TM_P2P_2SHOT_GRID='96', TM_BENCH_CANARY_SHARED='1',
+               TM_BENCH_CANARY_FAIL='1', TM_BENCH_FORCE_REPLICAS=str(force_replicas))
+    env.pop('WORLD_SIZE', None)
+    pr = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '6', '--warmup', '3', '--layers', '2',
+                         '--batch', '8', '--prompt-len', '96', '--no-traffic', '--no-cpu-baseline', '--no-full-run', '--profile-steps', '0',
+                         '--allow-shared-devices'],
+                        env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=800)
+    assert pr.returncode == 0, pr.stderr[-3000:]
+    lines = pr.stdout.strip().splitlines()
+    assert len(lines) == 1 and lines[0].startswith('{'), lines[:3]
+    d = json.loads(lines[0])
+    cfg = d['config']
+    assert 'canary run failed or hung on ranks [0, 1]' in cfg['collectives_note']
+    if force_replicas:
+        assert d['scaling'] == 'weak' and cfg['parallelism'] == 'dp2 (replicas only)' and 'TENSOR PARALLELISM COULD NOT RUN' in d['metric']
+        assert cfg['collectives'] == 'none' and cfg['rccl_ranks'] == 0 and 'independent TP = 1 replicas' in cfg['collectives_note']
+        assert d['n_gpus'] == 2 and d['value'] == pytest.approx(2 * 8 * d['steps'] / (d['ms_per_step'] * d['steps'] / 1e3), rel=1e-3)
+    else:
+        # the second canary ran with the conservative switches (two ranks on one GPU: RCCL refuses -> the native communicator, as in the first test)
+        assert d['scaling'] == 'strong' and cfg['parallelism'] == 'tp2' and 'second canary' not in cfg['collectives_note']
+        assert cfg['hipgraph'] is False, 'TM_GRAPH_COMM=0 of the fall-back must reach the run'
