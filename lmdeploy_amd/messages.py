@@ -93,7 +93,7 @@ class GenerationConfig:
         assert 0 <= self.min_p <= 1
         assert self.repetition_penalty > 0, 'repetition_penalty must be > 0'
         unsupported = {'n': 1, 'response_format': None, 'logits_processors': None,
-                       'output_logits': None, 'output_last_hidden_state': None, 'return_ppl': False, 'with_cache': False,
+                       'output_last_hidden_state': None, 'return_ppl': False, 'with_cache': False,
                        'preserve_cache': False, 'migration_request': None, 'return_routed_experts': False,
                        'repetition_ngram_size': 0, 'repetition_ngram_threshold': 0}
         if self.do_sample and self.temperature == 0:
@@ -102,7 +102,10 @@ class GenerationConfig:
             if getattr(self, k) != default:
                 raise NotImplementedError(f'GenerationConfig.{k}={getattr(self, k)!r}: the MI355X hot path implements '
                                           f'greedy decoding, temperature / top-k / top-p / min-p sampling, repetition '
-                                          f'penalty, min_new_tokens, bad_token_ids, stop_token_ids and logprobs only')
+                                          f'penalty, min_new_tokens, bad_token_ids, stop_token_ids, logprobs and output_logits="generation" only')
+        if self.output_logits not in (None, 'generation'):
+            raise NotImplementedError(f'GenerationConfig.output_logits={self.output_logits!r}: only "generation" (the logits every generated token was '
+                                      f'drawn from); the prompt positions\' logits are not computed (the lm_head runs on the last token of a prompt only)')
         if self.logprobs is not None:
             assert isinstance(self.logprobs, int) and self.logprobs >= 0, 'logprobs must be a non-negative integer'
             if self.logprobs > MAX_LOGPROBS:      # the reference clamps with a warning (lmdeploy/turbomind/turbomind.py:840-845)

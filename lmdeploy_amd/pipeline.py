@@ -185,6 +185,9 @@ class Pipeline:
             yield from sorted(self.generate_continuous(prompts, g), key=lambda r: r.index)
             return
         self._resolve_words(g)
+        if g.output_logits:                         # per-step logits are read back from the static batch (Engine.fetch_logits)
+            yield from self._generate_static(prompts, g)
+            return
         if len(prompts) > self.max_batch_size:      # more work than batch slots: let the engine schedule it
             yield from sorted(self.generate_continuous(prompts, g), key=lambda r: r.index)
             return
@@ -201,6 +204,9 @@ class Pipeline:
             gs = [gi or GenerationConfig() for gi in g]
         else:
             gs = [g or GenerationConfig()] * len(ids)
+        if any(gi.output_logits for gi in gs):
+            raise NotImplementedError('GenerationConfig.output_logits with streaming or per-request generation configs: the per-step logits are read '
+                                      'back from the static batch path (one GenerationConfig for all prompts, infer / __call__)')
         stops = []
         pending, out_of_engine, sent = {}, [], {}
         for i, p in enumerate(ids):
@@ -301,12 +307,19 @@ class Pipeline:
                 lp = g.logits_params(sorted(stop)[:_ffi.MAX_STOP_IDS])
                 self.engine.set_logits_params([lp] * len(chunk) if lp else None)
                 self.engine.set_logprobs(g.logprobs or 0)
+                if g.output_logits and (lp or self.backend_config.tp > 1):
+                    # the engine's processors rewrite the logits in place and a tensor-parallel rank holds a vocabulary shard: what could be read
+                    # back would not be the reference's output (the raw lm_head row, src/turbomind/models/language_model.cc OutputLogits)
+                    raise NotImplementedError('output_logits together with repetition_penalty / min_new_tokens / bad_token_ids, or with tp > 1')
                 self.engine.prefill(chunk, max_new_tokens=max_new)
+                step_logits = [self.engine.fetch_logits().copy()] if g.output_logits else None   # [batch, vocab] fp16 behind every step
                 done = 1
                 while done < max_new:
-                    n = min(32, max_new - done)
+                    n = 1 if step_logits is not None else min(32, max_new - done)
                     self.engine.decode(n)
                     done += n
+                    if step_logits is not None:
+                        step_logits.append(self.engine.fetch_logits().copy())
                     if stop:
                         toks = self.engine.fetch()
                         if all(any(int(t) in stop for t in row) for row in toks):
@@ -332,4 +345,7 @@ class Pipeline:
                 if records is not None:
                     lps = [logprobs_of_token(records[0][b, s], records[1][b, s], int(records[2][b, s]), float(records[3][b, s]), tkn,
                                              g.logprobs) for s, tkn in enumerate(out)]
-                yield Response(text, len(out), len(p), reason, out, logprobs=lps, index=i)
+                lg = None
+                if step_logits is not None:     # [generated tokens, vocab]: row s = the logits token s was drawn from (turbomind.py:444-451, 'generation')
+                    lg = np.stack([step_logits[s_][b] for s_ in range(len(out))]).astype(np.float32) if out else np.zeros((0, 0), np.float32)
+                yield Response(text, len(out), len(p), reason, out, logprobs=lps, logits=lg, index=i)

@@ -831,6 +831,13 @@ def test_engine_logprobs_static_batch(cuda, monkeypatch, async_step):
     sched = pipe(ps, g5)
     for i, r in enumerate(sched):
         assert len(acc[i]) == 5 and [sorted(d) for d in acc[i]] == [sorted(d) for d in r.logprobs]
+    # output_logits='generation': row s of Response.logits is the row token s was drawn from -- greedy: its arg-max; and the tokens are those
+    # of the plain run (reading the logits back step by step must not change anything)
+    plain = pipe(ps, lmdeploy_amd.GenerationConfig(max_new_tokens=5, ignore_eos=True))
+    withl = pipe(ps, lmdeploy_amd.GenerationConfig(max_new_tokens=5, ignore_eos=True, output_logits='generation'))
+    for a, b_ in zip(plain, withl):
+        assert a.token_ids == b_.token_ids and b_.logits.shape == (5, 1024) and np.isfinite(b_.logits).all()
+        assert b_.logits.argmax(-1).tolist() == b_.token_ids
     pipe.close()
 
 

@@ -71,6 +71,13 @@ class FakeEngine:
     def fetch(self):
         return np.asarray([[_tok(p, k) for k in range(self.done)] for p in self.static], np.int32)
 
+    def fetch_logits(self):
+        """[batch, VOCAB] fp16 of the last step: one-hot-ish rows whose arg-max is the token that step produced"""
+        out = np.full((len(self.static), VOCAB), -1.0, np.float16)
+        for b, p in enumerate(self.static):
+            out[b, _tok(p, self.done - 1)] = np.float16(self.done)
+        return out
+
     def release(self):
         self.static, self.reqs, self.released = None, {}, self.released + 1
         self.logprobs = 0          # like tm_engine_release
@@ -277,6 +284,23 @@ def test_logprobs_reach_the_responses(pipe):
         assert [d for _, d in got[i]] == [want(t, s_, 2) for s_, (t, _) in enumerate(got[i])] and len(got[i]) == 4
     with pytest.warns(UserWarning):
         assert GenerationConfig(logprobs=5000).logprobs == 1024
+
+
+def test_output_logits_of_the_generated_tokens(pipe):
+    """GenerationConfig.output_logits='generation': Response.logits[s] = the logits token s was drawn from (one decode step per engine call,
+    read back behind every step); more prompts than slots still run as static chunks; streaming / per-request configs / 'all' refuse."""
+    prompts = [[1, 2, 3], [9, 9], [4, 5, 6, 7]]
+    res = pipe(prompts, GenerationConfig(max_new_tokens=5, output_logits='generation', ignore_eos=True))
+    for r in res:
+        assert r.logits.shape == (5, VOCAB) and r.logits.dtype == np.float32
+        assert r.logits.argmax(-1).tolist() == r.token_ids and r.logits.max(-1).tolist() == [1.0, 2.0, 3.0, 4.0, 5.0]
+    assert all(r.logits is None for r in pipe(prompts[:2], GenerationConfig(max_new_tokens=3, ignore_eos=True)))
+    with pytest.raises(NotImplementedError):
+        list(pipe.stream_infer(prompts, GenerationConfig(max_new_tokens=3, output_logits='generation')))
+    with pytest.raises(NotImplementedError):
+        pipe(prompts[:2], GenerationConfig(max_new_tokens=3, output_logits='generation', bad_token_ids=[5]))
+    with pytest.raises(NotImplementedError):
+        GenerationConfig(output_logits='all')
 
 
 def test_one_generation_config_per_prompt(pipe):
